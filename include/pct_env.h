@@ -1,0 +1,183 @@
+/*
+ * pct_env.h -- C ABI of the MI355X-native batched PCT bin-packing environment.
+ *
+ * One handle (`pct_env`) owns N independent packing environments on ONE GPU and
+ * advances all of them with hand-written HIP kernels (gfx950).  The handle replaces,
+ * for the env hot path only, what the reference runs as N forked Python workers:
+ *
+ *   reference interface (file:line under the reference repo)        -> entry point here
+ *   ---------------------------------------------------------------------------------------
+ *   envs.py:75-116 make_vec_envs / envs.py:33-49 gym.make kwargs     -> pct_create(pct_config)
+ *   givenData.py:4-14 item_size_set, binCreator.py:24-39             -> pct_set_item_set
+ *   binCreator.py:41-72 LoadBoxCreator (scripted trajectories)       -> pct_set_item_stream
+ *   binCreator.py:37-39 RandomBoxCreator (on-the-fly sampling)       -> pct_set_sampler
+ *   wrapper/vec_env.py:48-58 VecEnv.reset,
+ *   wrapper/shmem_vec_env.py:61-68,112-117 reset / reset_specific    -> pct_reset
+ *   wrapper/vec_env.py:60-88 step_async/step_wait,
+ *   wrapper/shmem_vec_env.py:70-82,139-143 (auto-reset on done),
+ *   pct_envs/PctDiscrete0/bin3D.py:151-188 PackingDiscrete.step      -> pct_step_rows
+ *   train_tools.py:66-67 leaf_nodes[batchX, idx] gather              -> pct_step_index
+ *   (benchmark-only stand-in policy)                 -> pct_step_hash_policy
+ *   envs.py:178-182 VecPyTorch.step_wait outputs                     -> pct_bind_outputs /
+ *                                                                      pct_obs, pct_reward, ...
+ *   bin3D.py:163-164,186-187 info dict                               -> pct_info_counter/ratio
+ *   wrapper/vec_env.py:90-99 close                                   -> pct_destroy
+ *
+ * Conventions
+ *   - every entry point returns an int status (PCT_OK == 0); pct_last_error() gives text;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); entry points
+ *     only enqueue work, they never synchronise the device;
+ *   - all device pointers returned by getters are owned by the handle (or by the caller
+ *     if bound with pct_bind_outputs) and their contents are valid after the enqueued
+ *     step completes and until the next step/reset on the same handle;
+ *   - a GPU kernel cannot raise: per-env sticky `error_flags` record what the reference
+ *     would have raised as a Python exception (see PCT_ERR_*); an env that hits one is
+ *     force-terminated (done=1) and auto-reset like any finished episode.
+ *
+ * Observation layout (bin3D.py:70-93, tools.py:70-105): per env (I+L+1) rows x 9 float32
+ *   rows 0..I-1    internal nodes [lx,ly,lz,lx+x,ly+y,lz+z,density,0,1]
+ *   rows I..I+L-1  leaf nodes     [xs,ys,zs,xe,ye,H,0,0,1]   (first <=L feasible, list order)
+ *   row  I+L       next item      [density,0,0,s0,s1,s2,0,0,1] (sizes sorted ascending)
+ */
+#ifndef PCT_ENV_H
+#define PCT_ENV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCT_ABI_VERSION 1
+
+/* status codes */
+#define PCT_OK 0
+#define PCT_ERR_INVALID_ARG 1
+#define PCT_ERR_UNSUPPORTED 2
+#define PCT_ERR_HIP 3
+#define PCT_ERR_NO_DEVICE 4
+#define PCT_ERR_STATE 5
+
+/* env_kind */
+#define PCT_ENV_DISCRETE 0   /* pct_envs/PctDiscrete0 */
+#define PCT_ENV_CONTINUOUS 1 /* pct_envs/PctContinuous0 */
+
+/* leaf-node expansion scheme (tools.py:133 --lnes) */
+#define PCT_LNES_EMS 0
+#define PCT_LNES_CP 3
+
+/* item source */
+#define PCT_ITEMS_NONE 0
+#define PCT_ITEMS_STREAM 1  /* scripted per-env trajectories (parity runs) */
+#define PCT_ITEMS_SAMPLER 2 /* counter-based on-device sampler (training / bench) */
+
+/* per-env sticky error flags (bitmask, uint32) */
+#define PCT_FLAG_INTERNAL_OVERFLOW 0x1u  /* packed boxes >= internal_node_holder: reference
+                                            raises IndexError at space.py:385 */
+#define PCT_FLAG_EMS_OVERFLOW 0x2u       /* EMS list exceeded ems_capacity */
+#define PCT_FLAG_CANDIDATE_OVERFLOW 0x4u /* leaf-candidate set exceeded candidate_capacity */
+#define PCT_FLAG_BAD_ACTION 0x8u         /* malformed action: reference raises ValueError at
+                                            bin3D.py:144-145 (list.remove) or in np.max of an
+                                            empty slice (space.py:354-355) */
+
+/* Lattice: all geometry is integral in "lattice units".  Discrete env: 1 unit = 1.
+ * Continuous env: 1 unit = 1e-3 (item sizes are round(U(a,b),3), bin3D.py:106-108). */
+typedef struct pct_config {
+  int32_t struct_size;          /* = sizeof(pct_config), ABI guard */
+  int32_t env_kind;             /* PCT_ENV_* */
+  int32_t setting;              /* 1, 2 or 3 (tools.py:132) */
+  int32_t num_envs;             /* envs owned by this handle (this GPU's shard) */
+  int32_t container[3];         /* W, Ly, H in lattice units (envs.py:35) */
+  int32_t internal_node_holder; /* I (tools.py:173) */
+  int32_t leaf_node_holder;     /* L (tools.py:174) */
+  int32_t lnes;                 /* PCT_LNES_* */
+  int32_t env_id_base;          /* global id of local env 0 (multi-GPU sharding: env e of
+                                   the job lives on rank e / num_envs) */
+  int32_t ems_capacity;         /* 0 = default (256) */
+  int32_t candidate_capacity;   /* hash-table slots for the leaf-candidate set;
+                                   0 = default (2048); power of two */
+  int32_t reserved[4];
+} pct_config;
+
+typedef struct pct_env pct_env;
+
+/* ---- lifetime ---------------------------------------------------------------------- */
+int pct_abi_version(void);
+const char* pct_last_error(void);
+int pct_create(const pct_config* cfg, int device, pct_env** out);
+int pct_destroy(pct_env* env);
+
+/* ---- item sources ------------------------------------------------------------------ */
+/* item_set: host int32 [n,3] in lattice units (givenData.py:10-14).  Also fixes
+ * low_bound = min over all entries (bin3D.py:23). */
+int pct_set_item_set(pct_env* env, const int32_t* item_set, int32_t n);
+/* Continuous sampler bounds in lattice units (tools.py:178-181); low_bound = left. */
+int pct_set_sample_bounds(pct_env* env, int32_t left, int32_t right);
+/* Scripted trajectories: host int32 [num_envs, T, 3]; env e draws items[e][c % T] for its
+ * c-th draw (one draw per reset and one per successful placement,
+ * bin3D.py:61-67,181-182).  Copied to the device. */
+int pct_set_item_stream(pct_env* env, const int32_t* items, int64_t T);
+/* Counter-based sampler: the c-th draw of global env g is
+ * item_set[pct_mix64(seed, g, c) % n] (discrete) -- see pct_mix64 below. */
+int pct_set_sampler(pct_env* env, uint64_t seed);
+
+/* ---- outputs ------------------------------------------------------------------------ */
+/* Bind caller-owned device buffers (e.g. torch tensors).  Any pointer may be NULL to keep
+ * the handle-owned buffer.  obs float32 [N,(I+L+1)*9]; reward float32 [N]; done uint8 [N];
+ * counter int32 [N]; ratio float64 [N]. */
+int pct_bind_outputs(pct_env* env, float* obs, float* reward, uint8_t* done,
+                     int32_t* counter, double* ratio);
+float* pct_obs(pct_env* env);
+float* pct_reward(pct_env* env);
+uint8_t* pct_done(pct_env* env);
+int32_t* pct_info_counter(pct_env* env);
+double* pct_info_ratio(pct_env* env);
+uint32_t* pct_error_flags(pct_env* env);
+int32_t pct_obs_row_len(pct_env* env); /* (I+L+1)*9 */
+
+/* ---- transitions -------------------------------------------------------------------- */
+/* Reset all envs (env_ids == NULL) or the listed local ids (device int32 [n]). */
+int pct_reset(pct_env* env, const int32_t* env_ids, int32_t n, void* stream);
+/* One batched step from leaf rows: device float32 [N,row_len], row_len in {9,6,3}
+ * (bin3D.py:152-153: 3 = (flag,lx,ly) heuristic form). */
+int pct_step_rows(pct_env* env, const float* rows, int32_t row_len, void* stream);
+/* One batched step from leaf indices: device int64 [N], index into the env's current
+ * leaf rows (the gather of train_tools.py:66 fused into the step). */
+int pct_step_index(pct_env* env, const int64_t* leaf_index, void* stream);
+/* n_steps batched steps with the stand-in policy leaf = pct_mix32(g, t) % k over the k
+ * valid leaves (leaf 0 if k == 0), t = the env's lifetime step counter. */
+int pct_step_hash_policy(pct_env* env, int32_t n_steps, void* stream);
+
+/* ---- introspection (tests / debugging) ---------------------------------------------- */
+/* Copies env `local_id`'s geometric state to host: heightmap int32 [A*A] (A = max(W,Ly)),
+ * EMS int32 [*n_ems,6] (<= cap_ems rows written), counters.  Synchronises the device. */
+int pct_debug_state(pct_env* env, int32_t local_id, int32_t* heightmap, int32_t* ems,
+                    int32_t cap_ems, int32_t* n_ems, int32_t* n_boxes, int32_t* next_item,
+                    int64_t* draw_cursor);
+
+/* ---- shared arithmetic: part of the ABI, used identically on host and device -------- */
+#if defined(__HIPCC__)
+#define PCT_INLINE static inline __host__ __device__
+#else
+#define PCT_INLINE static inline
+#endif
+PCT_INLINE uint64_t pct_mix64(uint64_t seed, uint64_t env_global_id, uint64_t counter) {
+  /* splitmix64 finaliser over a 3-word counter; stateless, so any (env, draw) is O(1) */
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (env_global_id + 1) +
+               0xD1B54A32D192ED03ull * (counter + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+PCT_INLINE uint32_t pct_mix32(uint32_t env_global_id, uint32_t t) {
+  uint32_t h = env_global_id * 0x9E3779B1u + t * 0x85EBCA77u + 0xC2B2AE3Du;
+  h ^= h >> 16; h *= 0x7FEB352Du;
+  h ^= h >> 15; h *= 0x846CA68Bu;
+  h ^= h >> 16;
+  return h;
+}
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCT_ENV_H */

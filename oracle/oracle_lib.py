@@ -1,0 +1,172 @@
+"""ctypes binding of the CPU oracle (oracle/libpct_oracle.so).
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package never imports this module.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class PctConfig(ctypes.Structure):
+    """Mirror of `pct_config` in include/pct_env.h."""
+    _fields_ = [
+        ("struct_size", ctypes.c_int32),
+        ("env_kind", ctypes.c_int32),
+        ("setting", ctypes.c_int32),
+        ("num_envs", ctypes.c_int32),
+        ("container", ctypes.c_int32 * 3),
+        ("internal_node_holder", ctypes.c_int32),
+        ("leaf_node_holder", ctypes.c_int32),
+        ("lnes", ctypes.c_int32),
+        ("env_id_base", ctypes.c_int32),
+        ("ems_capacity", ctypes.c_int32),
+        ("candidate_capacity", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 4),
+    ]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libpct_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("pct_oracle.c", "pct_oracle.h")]
+    srcs.append(os.path.join(_HERE, "..", "include", "pct_env.h"))
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libpct_oracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = ctypes.CDLL(build())
+        vp = ctypes.c_void_p
+        L.pcto_create.argtypes = [ctypes.POINTER(PctConfig), ctypes.POINTER(vp)]
+        L.pcto_destroy.argtypes = [vp]
+        L.pcto_last_error.restype = ctypes.c_char_p
+        L.pcto_set_item_set.argtypes = [vp, vp, ctypes.c_int32]
+        L.pcto_set_item_stream.argtypes = [vp, vp, ctypes.c_int64]
+        L.pcto_set_sampler.argtypes = [vp, ctypes.c_uint64]
+        for name in ("pcto_obs", "pcto_reward", "pcto_done", "pcto_info_counter", "pcto_info_ratio",
+                     "pcto_error_flags"):
+            getattr(L, name).argtypes = [vp]
+            getattr(L, name).restype = vp
+        L.pcto_reset.argtypes = [vp, vp, ctypes.c_int32]
+        L.pcto_step_rows.argtypes = [vp, vp, ctypes.c_int32, ctypes.c_int32]
+        L.pcto_step_index.argtypes = [vp, vp, ctypes.c_int32]
+        L.pcto_step_hash_policy.argtypes = [vp, ctypes.c_int32]
+        L.pcto_debug_state.argtypes = [vp, ctypes.c_int32, vp, vp, ctypes.c_int32, vp, vp, vp, vp]
+        L.pcto_pyset_order.argtypes = [vp, ctypes.c_int32, vp]
+        L.pcto_set_num_threads.argtypes = [ctypes.c_int]
+        _LIB = L
+    return _LIB
+
+
+def _np_view(ptr, shape, dtype):
+    n = int(np.prod(shape))
+    buf = (ctypes.c_byte * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+
+class OracleVecEnv(object):
+    """Batched CPU oracle with the same call surface as the HIP handle."""
+
+    def __init__(self, num_envs, setting=2, container_size=(10, 10, 10), item_set=None,
+                 internal_node_holder=80, leaf_node_holder=50, env_kind=0, lnes=0, env_id_base=0,
+                 threads=1):
+        L = lib()
+        cfg = PctConfig()
+        cfg.struct_size = ctypes.sizeof(PctConfig)
+        cfg.env_kind = env_kind
+        cfg.setting = setting
+        cfg.num_envs = num_envs
+        cfg.container[:] = [int(c) for c in container_size]
+        cfg.internal_node_holder = internal_node_holder
+        cfg.leaf_node_holder = leaf_node_holder
+        cfg.lnes = lnes
+        cfg.env_id_base = env_id_base
+        self.cfg = cfg
+        self.N, self.I, self.L = num_envs, internal_node_holder, leaf_node_holder
+        self.row_len = (self.I + self.L + 1) * 9
+        self.A = max(int(container_size[0]), int(container_size[1]))
+        self._h = ctypes.c_void_p()
+        self._check(L.pcto_create(ctypes.byref(cfg), ctypes.byref(self._h)))
+        L.pcto_set_num_threads(threads)
+        items = np.ascontiguousarray(np.asarray(item_set, dtype=np.int32).reshape(-1, 3))
+        self._check(L.pcto_set_item_set(self._h, items.ctypes.data, items.shape[0]))
+        self.obs = _np_view(L.pcto_obs(self._h), (self.N, self.row_len), np.float64)
+        self.reward = _np_view(L.pcto_reward(self._h), (self.N,), np.float64)
+        self.done = _np_view(L.pcto_done(self._h), (self.N,), np.uint8)
+        self.counter = _np_view(L.pcto_info_counter(self._h), (self.N,), np.int32)
+        self.ratio = _np_view(L.pcto_info_ratio(self._h), (self.N,), np.float64)
+        self.flags = _np_view(L.pcto_error_flags(self._h), (self.N,), np.uint32)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError("oracle error %d: %s" % (rc, lib().pcto_last_error().decode()))
+
+    def set_item_stream(self, items):
+        items = np.ascontiguousarray(np.asarray(items, dtype=np.int32))
+        assert items.ndim == 3 and items.shape[0] == self.N and items.shape[2] == 3
+        self._check(lib().pcto_set_item_stream(self._h, items.ctypes.data, items.shape[1]))
+
+    def set_sampler(self, seed):
+        self._check(lib().pcto_set_sampler(self._h, seed))
+
+    def reset(self, env_ids=None):
+        if env_ids is None:
+            self._check(lib().pcto_reset(self._h, None, 0))
+        else:
+            ids = np.ascontiguousarray(np.asarray(env_ids, dtype=np.int32))
+            self._check(lib().pcto_reset(self._h, ids.ctypes.data, ids.size))
+        return self.obs
+
+    def step_rows(self, rows, auto_reset=True):
+        rows = np.ascontiguousarray(np.asarray(rows, dtype=np.float64))
+        assert rows.shape[0] == self.N
+        self._check(lib().pcto_step_rows(self._h, rows.ctypes.data, rows.shape[1], int(auto_reset)))
+        return self.obs, self.reward, self.done
+
+    def step_index(self, idx, auto_reset=True):
+        idx = np.ascontiguousarray(np.asarray(idx, dtype=np.int64))
+        self._check(lib().pcto_step_index(self._h, idx.ctypes.data, int(auto_reset)))
+        return self.obs, self.reward, self.done
+
+    def step_hash_policy(self, n_steps=1):
+        self._check(lib().pcto_step_hash_policy(self._h, n_steps))
+        return self.obs, self.reward, self.done
+
+    def debug_state(self, e, cap_ems=1024):
+        hm = np.zeros(self.A * self.A, np.int32)
+        ems = np.zeros((cap_ems, 6), np.int32)
+        n_ems = ctypes.c_int32()
+        n_boxes = ctypes.c_int32()
+        nxt = np.zeros(3, np.int32)
+        cur = ctypes.c_int64()
+        self._check(lib().pcto_debug_state(self._h, e, hm.ctypes.data, ems.ctypes.data, cap_ems,
+                                           ctypes.byref(n_ems), ctypes.byref(n_boxes), nxt.ctypes.data,
+                                           ctypes.byref(cur)))
+        return dict(heightmap=hm.reshape(self.A, self.A), ems=ems[:n_ems.value].copy(), n_boxes=n_boxes.value,
+                    next_item=nxt, cursor=cur.value)
+
+    def close(self):
+        if self._h:
+            lib().pcto_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def pyset_order(keys):
+    keys = np.ascontiguousarray(np.asarray(keys, dtype=np.int64).reshape(-1, 6))
+    out = np.zeros(keys.shape[0] + 1, np.int32)
+    n = lib().pcto_pyset_order(keys.ctypes.data, keys.shape[0], out.ctypes.data)
+    return out[:n].copy()

@@ -1,0 +1,697 @@
+/*
+ * pct_oracle.c -- CPU restatement of the reference PCT env hot path (TEST INFRASTRUCTURE;
+ * see pct_oracle.h for who may use it and for the parity status).
+ *
+ * Every function cites the reference lines it follows (paths relative to the reference
+ * repo; "D/" = pct_envs/PctDiscrete0/).  The code is written for fidelity, not speed.
+ */
+#include "pct_oracle.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static __thread char g_err[256];
+static int g_threads = 1;
+
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+const char* pcto_last_error(void) { return g_err; }
+int pcto_num_threads(void) { return g_threads; }
+void pcto_set_num_threads(int n) { g_threads = n < 1 ? 1 : n; }
+
+/* ===================================================================================== */
+/* CPython 3.10 set-of-tuples emulation                                                   */
+/* ===================================================================================== */
+/* Objects/tupleobject.c tuplehash (xxHash-derived, CPython >= 3.8); hash(int v) == v for
+ * 0 <= v < 2^61-1 (Objects/longobject.c long_hash). */
+#define XXPRIME_1 11400714785074694791ULL
+#define XXPRIME_2 14029467366897019727ULL
+#define XXPRIME_5 2870177450012600261ULL
+
+static uint64_t py_tuplehash6(const int64_t* v) {
+  uint64_t acc = XXPRIME_5;
+  for (int i = 0; i < 6; i++) {
+    uint64_t lane = (uint64_t)v[i]; /* non-negative small ints hash to themselves */
+    acc += lane * XXPRIME_2;
+    acc = (acc << 31) | (acc >> 33);
+    acc *= XXPRIME_1;
+  }
+  acc += 6ULL ^ (XXPRIME_5 ^ 3527539ULL);
+  if (acc == (uint64_t)-1) return 1546275796ULL;
+  return acc;
+}
+
+/* Objects/setobject.c: set_add_entry (LINEAR_PROBES 9, PERTURB_SHIFT 5, growth when
+ * fill*5 >= mask*3 to the first power of two > used*4), set_table_resize +
+ * set_insert_clean (re-insertion in old-table slot order), iteration = slot order. */
+typedef struct {
+  int32_t* slot;  /* -1 empty, else index into keys */
+  uint64_t* hash; /* per slot */
+  size_t mask;
+  size_t fill;
+} pyset;
+
+static void pyset_init(pyset* s) {
+  s->mask = 7;
+  s->fill = 0;
+  s->slot = (int32_t*)malloc(8 * sizeof(int32_t));
+  s->hash = (uint64_t*)malloc(8 * sizeof(uint64_t));
+  for (int i = 0; i < 8; i++) s->slot[i] = -1;
+}
+static void pyset_free(pyset* s) {
+  free(s->slot);
+  free(s->hash);
+}
+static void pyset_insert_clean(int32_t* slot, uint64_t* hs, size_t mask, int32_t key, uint64_t hash) {
+  size_t perturb = hash;
+  size_t i = (size_t)hash & mask;
+  while (1) {
+    size_t e = i;
+    if (slot[e] < 0) goto found;
+    if (i + 9 <= mask) {
+      for (int j = 0; j < 9; j++) {
+        e++;
+        if (slot[e] < 0) goto found;
+      }
+    }
+    perturb >>= 5;
+    i = (i * 5 + 1 + perturb) & mask;
+    continue;
+  found:
+    slot[e] = key;
+    hs[e] = hash;
+    return;
+  }
+}
+static void pyset_resize(pyset* s, size_t minused) {
+  size_t newsize = 8;
+  while (newsize <= minused) newsize <<= 1;
+  int32_t* ns = (int32_t*)malloc(newsize * sizeof(int32_t));
+  uint64_t* nh = (uint64_t*)malloc(newsize * sizeof(uint64_t));
+  for (size_t i = 0; i < newsize; i++) ns[i] = -1;
+  for (size_t i = 0; i <= s->mask; i++)
+    if (s->slot[i] >= 0) pyset_insert_clean(ns, nh, newsize - 1, s->slot[i], s->hash[i]);
+  free(s->slot);
+  free(s->hash);
+  s->slot = ns;
+  s->hash = nh;
+  s->mask = newsize - 1;
+}
+static void pyset_add(pyset* s, const int64_t* keys, int32_t k) {
+  const int64_t* key = keys + 6 * (size_t)k;
+  uint64_t hash = py_tuplehash6(key);
+  size_t mask = s->mask;
+  size_t i = (size_t)hash & mask;
+  size_t perturb = hash;
+  while (1) {
+    size_t e = i;
+    int probes = (i + 9 <= mask) ? 9 : 0;
+    do {
+      if (s->slot[e] < 0) {
+        s->slot[e] = k;
+        s->hash[e] = hash;
+        s->fill++;
+        if (s->fill * 5 >= mask * 3) pyset_resize(s, s->fill > 50000 ? s->fill * 2 : s->fill * 4);
+        return;
+      }
+      if (s->hash[e] == hash && memcmp(keys + 6 * (size_t)s->slot[e], key, 6 * sizeof(int64_t)) == 0)
+        return;
+      e++;
+    } while (probes--);
+    perturb >>= 5;
+    i = (i * 5 + 1 + perturb) & mask;
+  }
+}
+int pcto_pyset_order(const int64_t* keys, int32_t n, int32_t* order_out) {
+  pyset s;
+  pyset_init(&s);
+  for (int32_t k = 0; k < n; k++) pyset_add(&s, keys, k);
+  int cnt = 0;
+  for (size_t i = 0; i <= s.mask; i++)
+    if (s.slot[i] >= 0) order_out[cnt++] = s.slot[i];
+  pyset_free(&s);
+  return cnt;
+}
+
+/* ===================================================================================== */
+/* per-env state                                                                          */
+/* ===================================================================================== */
+typedef struct {
+  int x, y, z, lx, ly, lz;
+} obox; /* D/space.py:26-33 Box geometry */
+
+typedef struct {
+  /* D/space.py:271-314 Space */
+  int* plain;      /* [A*A] heightmap, plain[x*A+y] */
+  double* box_vec; /* [I*9] */
+  obox* boxes;
+  int n_boxes; /* len(self.boxes) */
+  int box_idx;
+  int64_t* ems; /* [n_ems*6] */
+  int n_ems, cap_ems;
+  /* D/bin3D.py env */
+  int next_box[3];
+  double next_den;
+  int queue_item[3]; /* box_creator.box_list[0] */
+  int queue_len;
+  uint64_t cursor; /* draws taken from the item source */
+  uint32_t t;      /* lifetime step counter (hash policy) */
+} oenv;
+
+struct pcto_env {
+  pct_config cfg;
+  int N, A, I, L, row_len;
+  int low_bound;
+  int32_t* item_set;
+  int n_items;
+  int32_t* stream;
+  int64_t T;
+  uint64_t seed;
+  int source;
+  oenv* envs;
+  double* obs;
+  double* reward;
+  uint8_t* done;
+  int32_t* counter;
+  double* ratio;
+  uint32_t* flags;
+};
+
+/* item source shared with the HIP path (include/pct_env.h pct_set_item_stream /
+ * pct_set_sampler); stands in for binCreator.py:37-39 generate_box_size */
+static void draw_item(const pcto_env* h, int e, oenv* s, int out[3]) {
+  uint64_t c = s->cursor++;
+  if (h->source == PCT_ITEMS_STREAM) {
+    const int32_t* p = h->stream + ((size_t)e * (size_t)h->T + (size_t)(c % (uint64_t)h->T)) * 3;
+    out[0] = p[0]; out[1] = p[1]; out[2] = p[2];
+  } else {
+    uint64_t g = (uint64_t)(h->cfg.env_id_base + e);
+    uint64_t idx = pct_mix64(h->seed, g, c) % (uint64_t)h->n_items;
+    out[0] = h->item_set[idx * 3 + 0];
+    out[1] = h->item_set[idx * 3 + 1];
+    out[2] = h->item_set[idx * 3 + 2];
+  }
+}
+
+/* D/space.py:290-314 Space.reset (ZMAP/EMS3D bookkeeping is unobservable under
+ * LNES='EMS', SURVEY.md a13, and is not restated) */
+static void space_reset(const pcto_env* h, oenv* s) {
+  memset(s->plain, 0, sizeof(int) * h->A * h->A);
+  memset(s->box_vec, 0, sizeof(double) * h->I * 9);
+  s->box_vec[8] = 1.0; /* box_vec[0][-1] = 1 */
+  s->n_ems = 1;
+  s->ems[0] = 0; s->ems[1] = 0; s->ems[2] = 0;
+  s->ems[3] = h->cfg.container[0]; s->ems[4] = h->cfg.container[1]; s->ems[5] = h->cfg.container[2];
+  s->n_boxes = 0;
+  s->box_idx = 0;
+}
+
+/* np.max(self.plain[lx:lx+x, ly:ly+y]) with NumPy slice clipping (D/space.py:354-355,
+ * 400-401).  Returns -1 for an empty slice (NumPy raises ValueError there). */
+static int footprint_max(const pcto_env* h, const oenv* s, int lx, int ly, int x, int y) {
+  int A = h->A;
+  /* Python slice semantics for possibly negative / out-of-range bounds */
+  int x0 = lx, x1 = lx + x, y0 = ly, y1 = ly + y;
+  if (x0 < 0) { x0 += A; if (x0 < 0) x0 = 0; }
+  if (x1 < 0) { x1 += A; if (x1 < 0) x1 = 0; }
+  if (y0 < 0) { y0 += A; if (y0 < 0) y0 = 0; }
+  if (y1 < 0) { y1 += A; if (y1 < 0) y1 = 0; }
+  if (x0 > A) x0 = A;
+  if (x1 > A) x1 = A;
+  if (y0 > A) y0 = A;
+  if (y1 > A) y1 = A;
+  if (x1 <= x0 || y1 <= y0) return -1;
+  int m = 0;
+  for (int i = x0; i < x1; i++)
+    for (int j = y0; j < y1; j++)
+      if (s->plain[i * A + j] > m) m = s->plain[i * A + j];
+  return m;
+}
+
+/* D/space.py:436-454 check_box, setting 2 branch (stability branch: not restated yet) */
+static int check_box(const pcto_env* h, int x, int y, int lx, int ly, int z, int max_h) {
+  if (lx + x > h->cfg.container[0] || ly + y > h->cfg.container[1]) return 0;
+  if (lx < 0 || ly < 0) return 0;
+  if (max_h + z > h->cfg.container[2]) return 0; /* self.height stays == H (space.py:383) */
+  return 1; /* setting == 2 */
+}
+
+/* D/space.py:393-433 drop_box_virtual(box_size, idx, False, den, setting) */
+static int drop_box_virtual(const pcto_env* h, const oenv* s, int x, int y, int z, int lx, int ly) {
+  int max_h = footprint_max(h, s, lx, ly, x, y);
+  if (max_h < 0) return 0; /* unreachable for EMS-generated candidates */
+  return check_box(h, x, y, lx, ly, z, max_h);
+}
+
+/* D/space.py:347-389 drop_box.  Returns 1 ok, 0 infeasible; sets *flags on what the
+ * reference would raise. */
+static int drop_box(const pcto_env* h, oenv* s, const int box[3], int lx, int ly, int flag, double density,
+                    uint32_t* flags) {
+  int x, y, z;
+  if (!flag) { x = box[0]; y = box[1]; z = box[2]; }
+  else       { y = box[0]; x = box[1]; z = box[2]; }
+  int max_h = footprint_max(h, s, lx, ly, x, y);
+  if (max_h < 0) { *flags |= PCT_FLAG_BAD_ACTION; return 0; } /* ValueError in np.max */
+  if (!check_box(h, x, y, lx, ly, z, max_h)) return 0;
+  if (s->box_idx >= h->I) { *flags |= PCT_FLAG_INTERNAL_OVERFLOW; return 0; } /* IndexError :385 */
+  obox b = {x, y, z, lx, ly, max_h};
+  s->boxes[s->n_boxes++] = b;
+  /* update_height_graph :316-326 */
+  int A = h->A, top = max_h + z;
+  for (int i = lx; i < lx + x; i++)
+    for (int j = ly; j < ly + y; j++) s->plain[i * A + j] = top;
+  double* r = s->box_vec + 9 * s->box_idx;
+  r[0] = lx; r[1] = ly; r[2] = max_h; r[3] = lx + x; r[4] = ly + y; r[5] = max_h + z;
+  r[6] = density; r[7] = 0; r[8] = 1;
+  s->box_idx++;
+  return 1;
+}
+
+/* D/space.py:514-515 AddNewEMS */
+static int add_ems(const pcto_env* h, oenv* s, int64_t a, int64_t b, int64_t c, int64_t x, int64_t y, int64_t z) {
+  (void)h;
+  if (s->n_ems >= s->cap_ems) {
+    s->cap_ems *= 2;
+    s->ems = (int64_t*)realloc(s->ems, sizeof(int64_t) * 6 * s->cap_ems);
+  }
+  int64_t* e = s->ems + 6 * s->n_ems++;
+  e[0] = a; e[1] = b; e[2] = c; e[3] = x; e[4] = y; e[5] = z;
+  return 0;
+}
+
+/* D/space.py:18-24 IsUsableEMS + :498-512 Difference (low_bound 0 -> 0.1, :501-502) */
+static void difference(const pcto_env* h, oenv* s, int emsID, const int64_t inter[6]) {
+  int64_t x1 = s->ems[6 * emsID + 0], y1 = s->ems[6 * emsID + 1], z1 = s->ems[6 * emsID + 2];
+  int64_t x2 = s->ems[6 * emsID + 3], y2 = s->ems[6 * emsID + 4], z2 = s->ems[6 * emsID + 5];
+  int64_t x3 = inter[0], y3 = inter[1], z3 = inter[2], x4 = inter[3], y4 = inter[4], z4 = inter[5];
+  (void)z3;
+  int64_t lb = h->low_bound <= 0 ? 1 : h->low_bound; /* ints: >= 0.1  <=>  >= 1 */
+#define USABLE(ax, ay, az, bx, by, bz) (((bx) - (ax) >= lb) && ((by) - (ay) >= lb) && ((bz) - (az) >= lb))
+  if (USABLE(x1, y1, z1, x3, y2, z2)) add_ems(h, s, x1, y1, z1, x3, y2, z2);
+  if (USABLE(x4, y1, z1, x2, y2, z2)) add_ems(h, s, x4, y1, z1, x2, y2, z2);
+  if (USABLE(x1, y1, z1, x2, y3, z2)) add_ems(h, s, x1, y1, z1, x2, y3, z2);
+  if (USABLE(x1, y4, z1, x2, y2, z2)) add_ems(h, s, x1, y4, z1, x2, y2, z2);
+  if (USABLE(x1, y1, z4, x2, y2, z2)) add_ems(h, s, x1, y1, z4, x2, y2, z2);
+#undef USABLE
+}
+
+/* D/space.py:518-531 EliminateInscribedEMS (non-strict containment evaluated on the
+ * pre-deletion list: identical EMS delete each other) */
+static void eliminate_inscribed(oenv* s) {
+  int n = s->n_ems;
+  char* del = (char*)calloc((size_t)n + 1, 1);
+  for (int i = 0; i < n; i++) {
+    const int64_t* a = s->ems + 6 * i;
+    for (int j = 0; j < n; j++) {
+      if (i == j) continue;
+      const int64_t* b = s->ems + 6 * j;
+      if (a[0] >= b[0] && a[1] >= b[1] && a[2] >= b[2] && a[3] <= b[3] && a[4] <= b[4] && a[5] <= b[5]) {
+        del[i] = 1;
+        break;
+      }
+    }
+  }
+  int m = 0;
+  for (int i = 0; i < n; i++)
+    if (!del[i]) {
+      if (m != i) memcpy(s->ems + 6 * m, s->ems + 6 * i, 6 * sizeof(int64_t));
+      m++;
+    }
+  s->n_ems = m;
+  free(del);
+}
+
+/* D/space.py:457-483 GENEMS (event-point upkeep :485-495 omitted, see space_reset) */
+static void genems(const pcto_env* h, oenv* s, const int64_t item[6]) {
+  int numofemss = s->n_ems;
+  char* delflag = (char*)calloc((size_t)numofemss + 1, 1);
+  int ndel = 0;
+  for (int emsIdx = 0; emsIdx < numofemss; emsIdx++) {
+    const int64_t* e = s->ems + 6 * emsIdx;
+    int64_t t1 = item[0], u1 = item[1], v1 = item[2], t2 = item[3], u2 = item[4], v2 = item[5];
+    if (e[0] > t1) t1 = e[0];
+    if (e[1] > u1) u1 = e[1];
+    if (e[2] > v1) v1 = e[2];
+    if (e[3] < t2) t2 = e[3];
+    if (e[4] < u2) u2 = e[4];
+    if (e[5] < v2) v2 = e[5];
+    if (t1 > t2) t1 = t2;
+    if (u1 > u2) u1 = u2;
+    if (v1 > v2) v1 = v2;
+    if (t1 == t2 || u1 == u2 || v1 == v2) continue;
+    int64_t inter[6] = {t1, u1, v1, t2, u2, v2};
+    difference(h, s, emsIdx, inter);
+    delflag[emsIdx] = 1;
+    ndel++;
+  }
+  if (ndel) {
+    int total = s->n_ems, m = 0;
+    for (int i = 0; i < total; i++) {
+      if (i < numofemss && delflag[i]) continue;
+      if (m != i) memcpy(s->ems + 6 * m, s->ems + 6 * i, 6 * sizeof(int64_t));
+      m++;
+    }
+    s->n_ems = m;
+  }
+  free(delflag);
+  eliminate_inscribed(s);
+}
+
+/* D/space.py:534-570 EMSPoint: candidate placements in CPython-set iteration order.
+ * Returns count; *out (malloc'd) holds [count,6]. */
+static int ems_point(const pcto_env* h, const oenv* s, int64_t** out) {
+  int orientation = (h->cfg.setting == 2) ? 6 : 2;
+  const int* nb = s->next_box;
+  int64_t* keys = (int64_t*)malloc(sizeof(int64_t) * 6 * (size_t)(s->n_ems * orientation * 4 + 1));
+  int nk = 0;
+  for (int ei = 0; ei < s->n_ems; ei++) {
+    const int64_t* ems = s->ems + 6 * ei;
+    for (int rot = 0; rot < orientation; rot++) {
+      int64_t sx, sy, sz;
+      switch (rot) {
+        case 0: sx = nb[0]; sy = nb[1]; sz = nb[2]; break;
+        case 1: sx = nb[1]; sy = nb[0]; sz = nb[2]; if (sx == sy) continue; break;
+        case 2: sx = nb[0]; sy = nb[2]; sz = nb[1]; if (sx == sy && sy == sz) continue; break;
+        case 3: sx = nb[1]; sy = nb[2]; sz = nb[0]; if (sx == sy && sy == sz) continue; break;
+        case 4: sx = nb[2]; sy = nb[0]; sz = nb[1]; if (sx == sy) continue; break;
+        default: sx = nb[2]; sy = nb[1]; sz = nb[0]; if (sx == sy) continue; break;
+      }
+      if (ems[3] - ems[0] >= sx && ems[4] - ems[1] >= sy && ems[5] - ems[2] >= sz) {
+        int64_t c[4][6] = {
+            {ems[0], ems[1], ems[2], ems[0] + sx, ems[1] + sy, ems[2] + sz},
+            {ems[3] - sx, ems[1], ems[2], ems[3], ems[1] + sy, ems[2] + sz},
+            {ems[0], ems[4] - sy, ems[2], ems[0] + sx, ems[4], ems[2] + sz},
+            {ems[3] - sx, ems[4] - sy, ems[2], ems[3], ems[4], ems[2] + sz}};
+        memcpy(keys + 6 * (size_t)nk, c, sizeof c);
+        nk += 4;
+      }
+    }
+  }
+  int32_t* order = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nk + 1));
+  int cnt = pcto_pyset_order(keys, nk, order);
+  int64_t* res = (int64_t*)malloc(sizeof(int64_t) * 6 * (size_t)(cnt + 1));
+  for (int i = 0; i < cnt; i++) memcpy(res + 6 * (size_t)i, keys + 6 * (size_t)order[i], 6 * sizeof(int64_t));
+  free(order);
+  free(keys);
+  *out = res;
+  return cnt;
+}
+
+/* D/bin3D.py:100-136 get_possible_position (LNES='EMS', shuffle=False): writes the L
+ * leaf rows into leaf[L*9] */
+static void get_possible_position(const pcto_env* h, const oenv* s, double* leaf) {
+  memset(leaf, 0, sizeof(double) * 9 * h->L);
+  int64_t* pos = NULL;
+  int n = ems_point(h, s, &pos);
+  int idx = 0;
+  for (int i = 0; i < n; i++) {
+    const int64_t* p = pos + 6 * i;
+    int x = (int)(p[3] - p[0]), y = (int)(p[4] - p[1]), z = (int)(p[5] - p[2]);
+    if (drop_box_virtual(h, s, x, y, z, (int)p[0], (int)p[1])) {
+      double* r = leaf + 9 * idx;
+      r[0] = (double)p[0]; r[1] = (double)p[1]; r[2] = (double)p[2];
+      r[3] = (double)p[3]; r[4] = (double)p[4]; r[5] = (double)h->cfg.container[2];
+      r[6] = 0; r[7] = 0; r[8] = 1;
+      idx++;
+    }
+    if (idx >= h->L) break;
+  }
+  free(pos);
+}
+
+/* D/bin3D.py:70-93 cur_observation (setting < 3: next_den = 1) */
+static void cur_observation(const pcto_env* h, int e, oenv* s, double* obs) {
+  /* gen_next_box -> box_creator.preview(1)[0] (binCreator.py:15-18) */
+  if (s->queue_len < 1) {
+    draw_item(h, e, s, s->queue_item);
+    s->queue_len = 1;
+  }
+  s->next_box[0] = s->queue_item[0]; s->next_box[1] = s->queue_item[1]; s->next_box[2] = s->queue_item[2];
+  s->next_den = 1.0;
+  memcpy(obs, s->box_vec, sizeof(double) * 9 * h->I);
+  get_possible_position(h, s, obs + 9 * h->I);
+  int a = s->next_box[0], b = s->next_box[1], c = s->next_box[2], tmp;
+  if (a > b) { tmp = a; a = b; b = tmp; }
+  if (b > c) { tmp = b; b = c; c = tmp; }
+  if (a > b) { tmp = a; a = b; b = tmp; }
+  double* r = obs + 9 * (h->I + h->L);
+  r[0] = s->next_den; r[1] = 0; r[2] = 0; r[3] = a; r[4] = b; r[5] = c; r[6] = 0; r[7] = 0; r[8] = 1;
+}
+
+/* D/bin3D.py:61-67 reset */
+static void env_reset(const pcto_env* h, int e, oenv* s, double* obs) {
+  s->queue_len = 0;            /* box_creator.reset() */
+  space_reset(h, s);           /* space.reset() */
+  draw_item(h, e, s, s->queue_item); /* box_creator.generate_box_size() */
+  s->queue_len = 1;
+  cur_observation(h, e, s, obs);
+}
+
+/* D/space.py:334-339 get_ratio */
+static double get_ratio(const pcto_env* h, const oenv* s) {
+  double vo = 0.0;
+  for (int i = 0; i < s->n_boxes; i++) vo = vo + (double)((int64_t)s->boxes[i].x * s->boxes[i].y * s->boxes[i].z);
+  double mx = (double)((int64_t)h->cfg.container[0] * h->cfg.container[1] * h->cfg.container[2]);
+  return vo / mx;
+}
+
+/* D/bin3D.py:139-149 LeafNode2Action + :151-188 step.  `act` has `len` entries. */
+static void env_step(const pcto_env* h, int e, oenv* s, const double* act, int len, double* obs, double* reward,
+                     uint8_t* done, int32_t* counter, double* ratio, uint32_t* flags) {
+  int flag, lx, ly, nb[3];
+  s->t++;
+  if (len != 3) {
+    double sum = 0;
+    for (int i = 0; i < 6; i++) sum += act[i];
+    if (sum == 0) {
+      flag = 0; lx = 0; ly = 0;
+      nb[0] = s->next_box[0]; nb[1] = s->next_box[1]; nb[2] = s->next_box[2];
+    } else {
+      int x = (int)(act[3] - act[0]);
+      int y = (int)(act[4] - act[1]);
+      int z[3] = {s->next_box[0], s->next_box[1], s->next_box[2]};
+      int nz = 3, found = 0;
+      for (int i = 0; i < nz; i++)
+        if (z[i] == x) { for (int j = i; j < nz - 1; j++) z[j] = z[j + 1]; nz--; found = 1; break; }
+      if (found) {
+        found = 0;
+        for (int i = 0; i < nz; i++)
+          if (z[i] == y) { for (int j = i; j < nz - 1; j++) z[j] = z[j + 1]; nz--; found = 1; break; }
+      }
+      if (!found) { /* ValueError: list.remove(x): x not in list */
+        *flags |= PCT_FLAG_BAD_ACTION;
+        *reward = 0.0; *done = 1; *counter = s->n_boxes; *ratio = get_ratio(h, s);
+        cur_observation(h, e, s, obs);
+        return;
+      }
+      flag = 0; lx = (int)act[0]; ly = (int)act[1];
+      nb[0] = x; nb[1] = y; nb[2] = z[0];
+    }
+  } else {
+    flag = (int)act[0]; lx = (int)act[1]; ly = (int)act[2];
+    nb[0] = s->next_box[0]; nb[1] = s->next_box[1]; nb[2] = s->next_box[2];
+  }
+  int ok = drop_box(h, s, nb, lx, ly, flag, s->next_den, flags);
+  if (!ok) {
+    *reward = 0.0;
+    *done = 1;
+    *counter = s->n_boxes;
+    *ratio = get_ratio(h, s);
+    cur_observation(h, e, s, obs);
+    return;
+  }
+  const obox* pb = &s->boxes[s->n_boxes - 1];
+  int64_t loc[6] = {pb->lx, pb->ly, pb->lz, pb->lx + pb->x, pb->ly + pb->y, pb->lz + pb->z};
+  genems(h, s, loc);
+  /* get_box_ratio :57-59 on self.next_box (the unrotated item) */
+  double box_ratio = (double)((int64_t)s->next_box[0] * s->next_box[1] * s->next_box[2]) /
+                     (double)((int64_t)h->cfg.container[0] * h->cfg.container[1] * h->cfg.container[2]);
+  s->queue_len = 0;                  /* box_creator.drop_box() */
+  draw_item(h, e, s, s->queue_item); /* generate_box_size() */
+  s->queue_len = 1;
+  *reward = box_ratio * 10;
+  *done = 0;
+  *counter = s->n_boxes;
+  *ratio = 0.0; /* not part of a non-terminal info dict (:186-187) */
+  cur_observation(h, e, s, obs);
+}
+
+/* ===================================================================================== */
+/* batched handle                                                                         */
+/* ===================================================================================== */
+int pcto_create(const pct_config* cfg, pcto_env** out) {
+  if (!cfg || !out) return fail(PCT_ERR_INVALID_ARG, "null argument");
+  if (cfg->struct_size != (int32_t)sizeof(pct_config)) return fail(PCT_ERR_INVALID_ARG, "pct_config size mismatch");
+  if (cfg->env_kind != PCT_ENV_DISCRETE) return fail(PCT_ERR_UNSUPPORTED, "oracle: only the discrete env is restated");
+  if (cfg->setting != 2) return fail(PCT_ERR_UNSUPPORTED, "oracle: only setting 2 is restated");
+  if (cfg->lnes != PCT_LNES_EMS) return fail(PCT_ERR_UNSUPPORTED, "oracle: only LNES=EMS is restated");
+  if (cfg->num_envs < 1 || cfg->internal_node_holder < 1 || cfg->leaf_node_holder < 1)
+    return fail(PCT_ERR_INVALID_ARG, "bad sizes");
+  pcto_env* h = (pcto_env*)calloc(1, sizeof *h);
+  h->cfg = *cfg;
+  h->N = cfg->num_envs;
+  h->A = cfg->container[0] > cfg->container[1] ? cfg->container[0] : cfg->container[1];
+  h->I = cfg->internal_node_holder;
+  h->L = cfg->leaf_node_holder;
+  h->row_len = (h->I + h->L + 1) * 9;
+  h->envs = (oenv*)calloc((size_t)h->N, sizeof(oenv));
+  for (int e = 0; e < h->N; e++) {
+    oenv* s = &h->envs[e];
+    s->plain = (int*)calloc((size_t)h->A * h->A, sizeof(int));
+    s->box_vec = (double*)calloc((size_t)h->I * 9, sizeof(double));
+    s->boxes = (obox*)calloc((size_t)h->I + 1, sizeof(obox));
+    s->cap_ems = 64;
+    s->ems = (int64_t*)calloc((size_t)s->cap_ems * 6, sizeof(int64_t));
+  }
+  h->obs = (double*)calloc((size_t)h->N * h->row_len, sizeof(double));
+  h->reward = (double*)calloc((size_t)h->N, sizeof(double));
+  h->done = (uint8_t*)calloc((size_t)h->N, 1);
+  h->counter = (int32_t*)calloc((size_t)h->N, sizeof(int32_t));
+  h->ratio = (double*)calloc((size_t)h->N, sizeof(double));
+  h->flags = (uint32_t*)calloc((size_t)h->N, sizeof(uint32_t));
+  *out = h;
+  return PCT_OK;
+}
+
+int pcto_destroy(pcto_env* h) {
+  if (!h) return PCT_OK;
+  for (int e = 0; e < h->N; e++) {
+    free(h->envs[e].plain); free(h->envs[e].box_vec); free(h->envs[e].boxes); free(h->envs[e].ems);
+  }
+  free(h->envs); free(h->obs); free(h->reward); free(h->done); free(h->counter); free(h->ratio);
+  free(h->flags); free(h->item_set); free(h->stream);
+  free(h);
+  return PCT_OK;
+}
+
+int pcto_set_item_set(pcto_env* h, const int32_t* item_set, int32_t n) {
+  if (!h || !item_set || n < 1) return fail(PCT_ERR_INVALID_ARG, "bad item set");
+  free(h->item_set);
+  h->item_set = (int32_t*)malloc(sizeof(int32_t) * 3 * (size_t)n);
+  memcpy(h->item_set, item_set, sizeof(int32_t) * 3 * (size_t)n);
+  h->n_items = n;
+  int mn = item_set[0];
+  for (int i = 0; i < 3 * n; i++) if (item_set[i] < mn) mn = item_set[i];
+  h->low_bound = mn; /* bin3D.py:23 size_minimum */
+  return PCT_OK;
+}
+int pcto_set_item_stream(pcto_env* h, const int32_t* items, int64_t T) {
+  if (!h || !items || T < 1) return fail(PCT_ERR_INVALID_ARG, "bad stream");
+  free(h->stream);
+  size_t n = (size_t)h->N * (size_t)T * 3;
+  h->stream = (int32_t*)malloc(sizeof(int32_t) * n);
+  memcpy(h->stream, items, sizeof(int32_t) * n);
+  h->T = T;
+  h->source = PCT_ITEMS_STREAM;
+  return PCT_OK;
+}
+int pcto_set_sampler(pcto_env* h, uint64_t seed) {
+  if (!h || !h->item_set) return fail(PCT_ERR_STATE, "set the item set first");
+  h->seed = seed;
+  h->source = PCT_ITEMS_SAMPLER;
+  return PCT_OK;
+}
+
+double* pcto_obs(pcto_env* h) { return h->obs; }
+double* pcto_reward(pcto_env* h) { return h->reward; }
+uint8_t* pcto_done(pcto_env* h) { return h->done; }
+int32_t* pcto_info_counter(pcto_env* h) { return h->counter; }
+double* pcto_info_ratio(pcto_env* h) { return h->ratio; }
+uint32_t* pcto_error_flags(pcto_env* h) { return h->flags; }
+
+static int ready(const pcto_env* h) {
+  if (!h) return fail(PCT_ERR_INVALID_ARG, "null handle");
+  if (!h->item_set) return fail(PCT_ERR_STATE, "item set not configured");
+  if (h->source == PCT_ITEMS_NONE) return fail(PCT_ERR_STATE, "item source not configured");
+  return PCT_OK;
+}
+
+int pcto_reset(pcto_env* h, const int32_t* env_ids, int32_t n) {
+  int rc = ready(h);
+  if (rc) return rc;
+  int cnt = env_ids ? n : h->N;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+  for (int k = 0; k < cnt; k++) {
+    int e = env_ids ? env_ids[k] : k;
+    if (e < 0 || e >= h->N) continue;
+    env_reset(h, e, &h->envs[e], h->obs + (size_t)e * h->row_len);
+  }
+  return PCT_OK;
+}
+
+int pcto_step_rows(pcto_env* h, const double* rows, int32_t row_len, int32_t auto_reset) {
+  int rc = ready(h);
+  if (rc) return rc;
+  if (row_len != 9 && row_len != 6 && row_len != 3) return fail(PCT_ERR_INVALID_ARG, "row_len must be 9, 6 or 3");
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 8)
+  for (int e = 0; e < h->N; e++) {
+    oenv* s = &h->envs[e];
+    double* obs = h->obs + (size_t)e * h->row_len;
+    env_step(h, e, s, rows + (size_t)e * row_len, row_len, obs, &h->reward[e], &h->done[e], &h->counter[e],
+             &h->ratio[e], &h->flags[e]);
+    if (h->done[e] && auto_reset) env_reset(h, e, s, obs);
+  }
+  return PCT_OK;
+}
+
+int pcto_step_index(pcto_env* h, const int64_t* leaf_index, int32_t auto_reset) {
+  int rc = ready(h);
+  if (rc) return rc;
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 8)
+  for (int e = 0; e < h->N; e++) {
+    oenv* s = &h->envs[e];
+    double* obs = h->obs + (size_t)e * h->row_len;
+    double row[9];
+    int64_t li = leaf_index[e];
+    if (li < 0 || li >= h->L) li = 0;
+    memcpy(row, obs + 9 * ((size_t)h->I + (size_t)li), sizeof row);
+    env_step(h, e, s, row, 9, obs, &h->reward[e], &h->done[e], &h->counter[e], &h->ratio[e], &h->flags[e]);
+    if (h->done[e] && auto_reset) env_reset(h, e, s, obs);
+  }
+  return PCT_OK;
+}
+
+int pcto_step_hash_policy(pcto_env* h, int32_t n_steps) {
+  int rc = ready(h);
+  if (rc) return rc;
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 8)
+  for (int e = 0; e < h->N; e++) {
+    oenv* s = &h->envs[e];
+    double* obs = h->obs + (size_t)e * h->row_len;
+    for (int it = 0; it < n_steps; it++) {
+      const double* leaf = obs + 9 * (size_t)h->I;
+      int k = 0;
+      for (int i = 0; i < h->L; i++) k += leaf[9 * i + 8] != 0;
+      int li = k > 0 ? (int)(pct_mix32((uint32_t)(h->cfg.env_id_base + e), s->t) % (uint32_t)k) : 0;
+      double row[9];
+      memcpy(row, leaf + 9 * li, sizeof row);
+      env_step(h, e, s, row, 9, obs, &h->reward[e], &h->done[e], &h->counter[e], &h->ratio[e], &h->flags[e]);
+      if (h->done[e]) env_reset(h, e, s, obs);
+    }
+  }
+  return PCT_OK;
+}
+
+int pcto_debug_state(pcto_env* h, int32_t e, int32_t* heightmap, int32_t* ems, int32_t cap_ems, int32_t* n_ems,
+                     int32_t* n_boxes, int32_t* next_item, int64_t* draw_cursor) {
+  if (!h || e < 0 || e >= h->N) return fail(PCT_ERR_INVALID_ARG, "bad env id");
+  const oenv* s = &h->envs[e];
+  if (heightmap) for (int i = 0; i < h->A * h->A; i++) heightmap[i] = s->plain[i];
+  if (ems) for (int i = 0; i < s->n_ems && i < cap_ems; i++) for (int c = 0; c < 6; c++) ems[6 * i + c] = (int32_t)s->ems[6 * i + c];
+  if (n_ems) *n_ems = s->n_ems;
+  if (n_boxes) *n_boxes = s->n_boxes;
+  if (next_item) { next_item[0] = s->next_box[0]; next_item[1] = s->next_box[1]; next_item[2] = s->next_box[2]; }
+  if (draw_cursor) *draw_cursor = (int64_t)s->cursor;
+  return PCT_OK;
+}

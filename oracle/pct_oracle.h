@@ -1,0 +1,70 @@
+/*
+ * pct_oracle.h -- CPU restatement (plain C) of the reference env hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is the parity oracle for the HIP path: only tests/,
+ * __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may load it.  The product
+ * (online-3d-bpp-pct_amd/) never links, imports or falls back to it.
+ *
+ * Parity status: PINNED for the discrete env, setting 2, LNES='EMS' -- the restatement is
+ * checked bit-for-bit against the unmodified Python reference (imported from
+ * /root/reference under tests/golden/ref_shim.py) by tests/golden/gen_golden.py, which
+ * also writes the committed fixtures the tests/golden/ .npz files, and it reproduces the survey's
+ * known-answer hashes.  Anything else this file grows is marked where it
+ * is defined.
+ *
+ * The batched API mirrors include/pct_env.h one to one (pcto_* instead of pct_*, host
+ * pointers instead of device pointers, float64 observations like the gym env returns
+ * before envs.py:180 casts them).
+ */
+#ifndef PCT_ORACLE_H
+#define PCT_ORACLE_H
+
+#include "../include/pct_env.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pcto_env pcto_env;
+
+int pcto_create(const pct_config* cfg, pcto_env** out);
+int pcto_destroy(pcto_env* env);
+const char* pcto_last_error(void);
+
+int pcto_set_item_set(pcto_env* env, const int32_t* item_set, int32_t n);
+int pcto_set_item_stream(pcto_env* env, const int32_t* items, int64_t T);
+int pcto_set_sampler(pcto_env* env, uint64_t seed);
+
+/* outputs (host, owned by the handle) */
+double* pcto_obs(pcto_env* env);      /* float64 [N,(I+L+1)*9] */
+double* pcto_reward(pcto_env* env);   /* float64 [N] */
+uint8_t* pcto_done(pcto_env* env);    /* [N] */
+int32_t* pcto_info_counter(pcto_env* env);
+double* pcto_info_ratio(pcto_env* env);
+uint32_t* pcto_error_flags(pcto_env* env);
+
+int pcto_reset(pcto_env* env, const int32_t* env_ids, int32_t n);
+/* auto_reset != 0: VecEnv worker semantics (shmem_vec_env.py:139-143) -- a done env is
+ * reset inside the step and its observation is the reset observation.
+ * auto_reset == 0: raw gym env semantics (bin3D.py:160-165). */
+int pcto_step_rows(pcto_env* env, const double* rows, int32_t row_len, int32_t auto_reset);
+int pcto_step_index(pcto_env* env, const int64_t* leaf_index, int32_t auto_reset);
+int pcto_step_hash_policy(pcto_env* env, int32_t n_steps);
+
+int pcto_debug_state(pcto_env* env, int32_t local_id, int32_t* heightmap, int32_t* ems,
+                     int32_t cap_ems, int32_t* n_ems, int32_t* n_boxes, int32_t* next_item,
+                     int64_t* draw_cursor);
+
+/* number of threads used by the batched entry points (OpenMP if built with it, else 1) */
+int pcto_num_threads(void);
+void pcto_set_num_threads(int n);
+
+/* CPython 3.10 `set` of 6-int tuples: insertion -> iteration order (Objects/setobject.c,
+ * Objects/tupleobject.c tuplehash).  keys int64 [n,6]; writes the iteration order as
+ * indices into `keys` (first occurrence of each distinct tuple); returns the count. */
+int pcto_pyset_order(const int64_t* keys, int32_t n, int32_t* order_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,219 @@
+"""Pins the CPU oracle to the UNMODIFIED Python reference and writes the golden fixtures.
+
+Run in the build container (needs /root/reference):
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py
+
+For every case below the reference env classes (pct_envs/PctDiscrete0/bin3D.py
+PackingDiscrete, ...) are driven step by step; the item stream is scripted through the
+reference's own plug-in point (a BoxCreator subclass assigned to env.box_creator,
+binCreator.py:5-22) and the policy is the stand-in hash policy of include/pct_env.h
+(pct_mix32).  Recorded per step: float32 observation (what envs.py:180 hands the trainer),
+float64 reward, done, info counter / ratio.  The oracle is run on the same inputs and must
+agree bit for bit before a fixture is written.
+
+The fixtures travel to the GPU box (the reference does not): tests compare both the oracle
+and the HIP path against them.
+"""
+import hashlib
+import os
+import sys
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+warnings.filterwarnings("ignore")
+
+import ref_shim  # noqa: E402
+
+M32 = 0xFFFFFFFF
+
+
+def mix32(g, t):
+    """include/pct_env.h pct_mix32"""
+    h = (g * 0x9E3779B1 + t * 0x85EBCA77 + 0xC2B2AE3D) & M32
+    h ^= h >> 16
+    h = (h * 0x7FEB352D) & M32
+    h ^= h >> 15
+    h = (h * 0x846CA68B) & M32
+    h ^= h >> 16
+    return h
+
+
+def make_stream(seed, n_envs, T, item_set):
+    rng = np.random.RandomState(seed)
+    items = np.asarray(item_set, dtype=np.int32)
+    idx = rng.randint(0, len(items), size=(n_envs, T))
+    return items[idx]  # [N,T,3]
+
+
+def scripted_creator(stream_row):
+    """A reference BoxCreator whose generate_box_size reads a scripted trajectory."""
+    ref_shim.install()
+    from pct_envs.PctDiscrete0.binCreator import BoxCreator
+
+    class ScriptedBoxCreator(BoxCreator):
+        def __init__(self, row):
+            super().__init__()
+            self.row = row
+            self.cursor = 0
+
+        def generate_box_size(self, **kwargs):
+            it = self.row[self.cursor % len(self.row)]
+            self.cursor += 1
+            self.box_list.append((int(it[0]), int(it[1]), int(it[2])))
+
+    return ScriptedBoxCreator(stream_row)
+
+
+CASES = {
+    # name: dict(setting, container, item range, I, L, N, T_steps, stream_T, seed, base)
+    "discrete_s2_10_80_50": dict(setting=2, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, N=8, steps=300,
+                                 stream_T=512, seed=11, base=0),
+    "discrete_s2_rect_60_30": dict(setting=2, container=(12, 9, 11), lo=1, hi=6, I=60, L=30, N=4, steps=200,
+                                   stream_T=256, seed=12, base=100),
+    "discrete_s2_10_80_5": dict(setting=2, container=(10, 10, 10), lo=1, hi=5, I=80, L=5, N=4, steps=200,
+                                stream_T=256, seed=13, base=7),
+    "discrete_s2_20_120_400": dict(setting=2, container=(20, 20, 20), lo=2, hi=7, I=120, L=400, N=2, steps=200,
+                                   stream_T=256, seed=14, base=3),
+}
+
+
+def item_set_range(lo, hi):
+    return [(i, j, k) for i in range(lo, hi + 1) for j in range(lo, hi + 1) for k in range(lo, hi + 1)]
+
+
+def run_reference(case):
+    PD, PC, _ = ref_shim.load_reference_envs()
+    c = case
+    item_set = item_set_range(c["lo"], c["hi"])
+    stream = make_stream(c["seed"], c["N"], c["stream_T"], item_set)
+    N, I, L = c["N"], c["I"], c["L"]
+    row_len = (I + L + 1) * 9
+    obs_rec = np.zeros((c["steps"] + 1, N, row_len), np.float32)
+    rew = np.zeros((c["steps"], N), np.float64)
+    done = np.zeros((c["steps"], N), np.uint8)
+    counter = np.zeros((c["steps"], N), np.int32)
+    ratio = np.zeros((c["steps"], N), np.float64)
+    for e in range(N):
+        env = PD(setting=c["setting"], container_size=list(c["container"]), item_set=item_set,
+                 internal_node_holder=I, leaf_node_holder=L, shuffle=False, LNES="EMS")
+        env.box_creator = scripted_creator(stream[e])
+        obs = env.reset()
+        g = c["base"] + e
+        for t in range(c["steps"]):
+            obs_rec[t, e] = obs.astype(np.float32)
+            leaf = obs.reshape(-1, 9)[I:I + L]
+            k = int((leaf[:, 8] != 0).sum())
+            li = mix32(g, t) % k if k > 0 else 0
+            # float32 leaf row, exactly what train_tools.py:66-67 sends
+            act = obs_rec[t, e].reshape(-1, 9)[I + li].copy()
+            obs, r, d, info = env.step(act)
+            rew[t, e] = r
+            done[t, e] = d
+            counter[t, e] = info["counter"]
+            ratio[t, e] = info.get("ratio", 0.0)
+            if d:
+                obs = env.reset()  # shmem_vec_env.py:141-143
+        obs_rec[c["steps"], e] = obs.astype(np.float32)
+    return dict(stream=stream, obs=obs_rec, reward=rew, done=done, counter=counter, ratio=ratio)
+
+
+def run_oracle(case, stream):
+    from oracle.oracle_lib import OracleVecEnv
+    c = case
+    env = OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"],
+                       item_set=item_set_range(c["lo"], c["hi"]), internal_node_holder=c["I"],
+                       leaf_node_holder=c["L"], env_id_base=c["base"])
+    env.set_item_stream(stream)
+    N, I, L = c["N"], c["I"], c["L"]
+    row_len = (I + L + 1) * 9
+    obs_rec = np.zeros((c["steps"] + 1, N, row_len), np.float32)
+    rew = np.zeros((c["steps"], N), np.float64)
+    done = np.zeros((c["steps"], N), np.uint8)
+    counter = np.zeros((c["steps"], N), np.int32)
+    ratio = np.zeros((c["steps"], N), np.float64)
+    env.reset()
+    for t in range(c["steps"]):
+        obs_rec[t] = env.obs.astype(np.float32)
+        env.step_hash_policy(1)
+        rew[t], done[t], counter[t], ratio[t] = env.reward, env.done, env.counter, env.ratio
+    obs_rec[c["steps"]] = env.obs.astype(np.float32)
+    assert not env.flags.any()
+    env.close()
+    return dict(obs=obs_rec, reward=rew, done=done, counter=counter, ratio=ratio)
+
+
+def known_answer_discrete_s2():
+    """SURVEY.md 8(c) recipe: reference RandomBoxCreator under env.seed(4), RandomState(0)
+    policy, sha256 over the 500 float32 observations.  The item draws are recorded from the
+    reference and replayed into the oracle together with the same actions."""
+    PD, PC, item_set = ref_shim.load_reference_envs()
+    env = PD(setting=2, container_size=[10, 10, 10], item_set=item_set, internal_node_holder=80,
+             leaf_node_holder=50, shuffle=False, LNES="EMS")
+    drawn = []
+    orig = env.box_creator.generate_box_size
+
+    def rec(**kw):
+        orig(**kw)
+        drawn.append(env.box_creator.box_list[-1])
+    env.box_creator.generate_box_size = rec
+    env.seed(4)
+    rng = np.random.RandomState(0)
+    obs = env.reset()
+    h = hashlib.sha256()
+    acts = []
+    for t in range(500):
+        h.update(obs.astype(np.float32).tobytes())
+        leaf = obs.reshape(-1, 9)[80:130]
+        k = int(leaf[:, 8].sum())
+        a = leaf[rng.randint(k)] if k > 0 else leaf[0]
+        acts.append(np.array(a, dtype=np.float64))
+        obs, r, d, info = env.step(a)
+        if d:
+            obs = env.reset()
+    ref_hash = h.hexdigest()[:16]
+    assert ref_hash == "e882162eebfb9734", ref_hash
+
+    from oracle.oracle_lib import OracleVecEnv
+    o = OracleVecEnv(1, setting=2, container_size=(10, 10, 10), item_set=item_set)
+    o.set_item_stream(np.asarray(drawn, np.int32)[None])
+    o.reset()
+    h2 = hashlib.sha256()
+    for t in range(500):
+        h2.update(o.obs[0].astype(np.float32).tobytes())
+        o.step_rows(acts[t][None], auto_reset=True)
+    assert h2.hexdigest()[:16] == ref_hash, (h2.hexdigest()[:16], ref_hash)
+    np.savez_compressed(os.path.join(HERE, "kat_discrete_s2.npz"), items=np.asarray(drawn, np.int32),
+                        actions=np.asarray(acts, np.float32), sha256_16=np.array(ref_hash))
+    print("known answer discrete s2: oracle == reference ==", ref_hash)
+
+
+def main():
+    known_answer_discrete_s2()
+    for name, case in CASES.items():
+        ref = run_reference(case)
+        ora = run_oracle(case, ref["stream"])
+        for key in ("obs", "reward", "done", "counter", "ratio"):
+            a, b = ref[key], ora[key]
+            if key == "ratio":  # only terminal steps carry a ratio in the reference info
+                a = a * (ref["done"] != 0)
+                b = b * (ora["done"] != 0)
+            if not np.array_equal(a, b):
+                bad = np.argwhere(a != b)
+                raise SystemExit("MISMATCH %s/%s first at %s" % (name, key, bad[0]))
+        eps = int(ref["done"].sum())
+        feas = (ref["obs"][:, :, :].reshape(ref["obs"].shape[0], case["N"], -1, 9)[:, :, case["I"]:case["I"] + case["L"], 8] != 0).sum(-1)
+        print("%-28s steps=%d envs=%d episodes=%d  leaf-cap hit %.2f  oracle == reference" % (
+            name, case["steps"], case["N"], eps, float((feas >= case["L"]).mean())))
+        meta = np.array(repr(case))
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), meta=meta, stream=ref["stream"],
+                            obs=ref["obs"], reward=ref["reward"], done=ref["done"],
+                            counter=ref["counter"], ratio=ref["ratio"] * (ref["done"] != 0))
+
+
+if __name__ == "__main__":
+    main()
