@@ -124,9 +124,9 @@ int pct_set_sampler(pct_env* env, uint64_t seed);
 /* ---- outputs ------------------------------------------------------------------------ */
 /* Bind caller-owned device buffers (e.g. torch tensors).  Any pointer may be NULL to keep
  * the handle-owned buffer.  obs float32 [N,(I+L+1)*9]; reward float32 [N]; done uint8 [N];
- * counter int32 [N]; ratio float64 [N]. */
+ * counter int32 [N]; ratio float64 [N]; error_flags uint32 [N] (must be zero-filled). */
 int pct_bind_outputs(pct_env* env, float* obs, float* reward, uint8_t* done,
-                     int32_t* counter, double* ratio);
+                     int32_t* counter, double* ratio, uint32_t* error_flags);
 float* pct_obs(pct_env* env);
 float* pct_reward(pct_env* env);
 uint8_t* pct_done(pct_env* env);
@@ -147,6 +147,20 @@ int pct_step_index(pct_env* env, const int64_t* leaf_index, void* stream);
 /* n_steps batched steps with the stand-in policy leaf = pct_mix32(g, t) % k over the k
  * valid leaves (leaf 0 if k == 0), t = the env's lifetime step counter. */
 int pct_step_hash_policy(pct_env* env, int32_t n_steps, void* stream);
+
+/* The stand-in policy as its own kernel (what a policy network would do between two
+ * steps): reads each env's leaf-mask column from the observation, picks
+ * leaf = pct_mix32(g, t) % k and writes that leaf row to rows_out (device float32 [N,9]),
+ * ready for pct_step_rows. */
+int pct_policy_hash_rows(pct_env* env, float* rows_out, void* stream);
+
+/* ---- kernel timing ------------------------------------------------------------------- */
+/* When enabled, every transition launch (reset / step_*) is bracketed by a pair of
+ * hipEvents recorded on the launch stream.  pct_profile_read synchronises on the recorded
+ * events, returns the number of launches and their summed duration since the last read,
+ * and clears the accumulator. */
+int pct_profile_enable(pct_env* env, int32_t on);
+int pct_profile_read(pct_env* env, int64_t* n_launches, double* total_ms);
 
 /* ---- introspection (tests / debugging) ---------------------------------------------- */
 /* Copies env `local_id`'s geometric state to host: heightmap int32 [A*A] (A = max(W,Ly)),

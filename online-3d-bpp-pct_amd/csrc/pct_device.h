@@ -1,0 +1,50 @@
+// pct_device.h -- parameter blocks shared by the kernels and the C-ABI host code.
+#ifndef PCT_DEVICE_H
+#define PCT_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#define PCT_SCALARS 16 /* int32 words of per-env scalar state */
+
+namespace pct {
+
+// HBM layout of the discrete env state: struct-of-arrays over envs, every array holds one
+// contiguous slice per env (a wave reads its env's slice with consecutive lanes on
+// consecutive addresses).
+struct DiscreteParams {
+  // geometry / sizes
+  int N, W, Ly, H, A, AA; /* AA = A*A rounded up to a multiple of 8 */
+  int I, L, row_len;
+  int setting, low_bound;
+  int ems_cap, cand_cap;
+  int key_bytes; /* 4: six 5-bit coords (bins <= 31); 8: six 10-bit coords (<= 1023) */
+  // item source
+  int source, n_items, env_id_base;
+  long long T;
+  unsigned long long seed;
+  const int32_t* item_set; /* [n_items,3] */
+  const int32_t* stream;   /* [N,T,3] */
+  // persistent state
+  int16_t* hmap;    /* [N,AA] heightmap */
+  void* ems;        /* [N,ems_cap] packed EMS (key words) */
+  void* boxes;      /* [N,I] packed placed boxes, placement order */
+  void* leaves;     /* [N,L] packed current leaf nodes */
+  int32_t* scalars; /* [N,PCT_SCALARS]: n_ems,n_boxes,n_leaf,item[3],t,-,cursor lo/hi,vol lo/hi */
+  uint32_t* flags;  /* [N] sticky PCT_FLAG_* */
+  // outputs
+  float* obs;       /* [N,row_len] */
+  float* reward;    /* [N] */
+  uint8_t* done;    /* [N] */
+  int32_t* counter; /* [N] */
+  double* ratio;    /* [N] */
+};
+
+size_t discrete_lds_bytes(const DiscreteParams& p);
+hipError_t launch_policy_hash_rows(const DiscreteParams& p, float* rows_out, hipStream_t stream);
+hipError_t launch_discrete(const DiscreteParams& p, int act, const void* actions, int row_len, int n_steps,
+                           const int32_t* env_ids, int n_ids, hipStream_t stream);
+
+}  // namespace pct
+#endif

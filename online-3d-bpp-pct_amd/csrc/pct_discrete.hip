@@ -1,0 +1,742 @@
+// pct_discrete.hip -- gfx950 kernels for the batched PctDiscrete0 environment.
+//
+// One 64-lane wavefront (= one 64-thread workgroup) owns one environment for a whole
+// transition; the env's heightmap, EMS list, candidate hash table, placed boxes and leaf
+// list are staged in LDS, the persistent state lives in HBM as struct-of-arrays over envs
+// (each env's slice contiguous, so the wave's lanes read consecutive addresses).
+// Integer / branchy AABB, scan and compaction work: no MFMA anywhere on this path.
+//
+// Reference semantics restated here (paths under the reference repo,
+// D/ = pct_envs/PctDiscrete0/):
+//   step / auto-reset        D/bin3D.py:151-188, wrapper/shmem_vec_env.py:139-143
+//   LeafNode2Action          D/bin3D.py:139-149
+//   drop_box / check_box     D/space.py:347-389, 436-454
+//   GENEMS / Difference      D/space.py:457-483, 498-512
+//   EliminateInscribedEMS    D/space.py:518-531
+//   EMSPoint                 D/space.py:534-570  (a CPython `set`: its iteration order is
+//                            reproduced exactly -- Objects/setobject.c set_add_entry /
+//                            set_table_resize / set_insert_clean, tupleobject.c tuplehash)
+//   get_possible_position    D/bin3D.py:100-136
+//   cur_observation          D/bin3D.py:70-93
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pct_env.h"
+#include "pct_device.h"
+
+namespace pct {
+
+// ----------------------------------------------------------------------------------------
+// packed boxes: six coordinates, BITS bits each, in one key word.  Key 0 is never a valid
+// candidate (a candidate has positive extents), so 0 marks an empty hash-table slot.
+// ----------------------------------------------------------------------------------------
+template <typename K, int BITS>
+struct Pack {
+  static constexpr uint32_t M = (1u << BITS) - 1u;
+  __device__ static inline K pack(int a, int b, int c, int d, int e, int f) {
+    return (K)a | ((K)b << BITS) | ((K)c << (2 * BITS)) | ((K)d << (3 * BITS)) | ((K)e << (4 * BITS)) |
+           ((K)f << (5 * BITS));
+  }
+  __device__ static inline int get(K k, int i) { return (int)((k >> (i * BITS)) & (K)M); }
+};
+
+__device__ inline int wave_max_i32(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    int o = __shfl_xor(v, off, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+__device__ inline uint64_t lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
+__device__ inline uint64_t bcast_u64(uint64_t v, int src) {
+  uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, src);
+  uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), src);
+  return ((uint64_t)hi << 32) | lo;
+}
+template <typename K>
+__device__ inline K bcast_key(K v, int src);
+template <>
+__device__ inline uint32_t bcast_key<uint32_t>(uint32_t v, int src) {
+  return __builtin_amdgcn_readlane(v, src);
+}
+template <>
+__device__ inline uint64_t bcast_key<uint64_t>(uint64_t v, int src) {
+  return bcast_u64(v, src);
+}
+template <typename K>
+__device__ inline K uniform_key(K v);
+template <>
+__device__ inline uint32_t uniform_key<uint32_t>(uint32_t v) {
+  return __builtin_amdgcn_readfirstlane(v);
+}
+template <>
+__device__ inline uint64_t uniform_key<uint64_t>(uint64_t v) {
+  uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// CPython tuplehash of a 6-tuple of small non-negative ints (hash(int) == int).
+#define PCT_XXPRIME_1 11400714785074694791ULL
+#define PCT_XXPRIME_2 14029467366897019727ULL
+#define PCT_XXPRIME_5 2870177450012600261ULL
+template <typename K, int BITS>
+__device__ inline uint64_t tuplehash6(K key) {
+  uint64_t acc = PCT_XXPRIME_5;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    uint64_t lane = (uint64_t)Pack<K, BITS>::get(key, i);
+    acc += lane * PCT_XXPRIME_2;
+    acc = (acc << 31) | (acc >> 33);
+    acc *= PCT_XXPRIME_1;
+  }
+  acc += 6ULL ^ (PCT_XXPRIME_5 ^ 3527539ULL);
+  if (acc == (uint64_t)-1) return 1546275796ULL;
+  return acc;
+}
+
+// Per-lane read-only probe (set_add_entry's search, without the insertion).
+template <typename K>
+__device__ inline bool pyset_lookup(const K* tab, uint32_t mask, K key, uint64_t hash) {
+  uint64_t perturb = hash;
+  uint32_t i = (uint32_t)hash & mask;
+  while (true) {
+    uint32_t e = i;
+    int probes = (i + 9u <= mask) ? 9 : 0;
+    do {
+      K cur = tab[e];
+      if (cur == 0) return false;
+      if (cur == key) return true;
+      e++;
+    } while (probes--);
+    perturb >>= 5;
+    i = (i * 5u + 1u + (uint32_t)perturb) & mask;
+  }
+}
+// Wave-uniform insertion (every lane runs the same probe sequence on the same key).
+// Returns true if the key was new.
+template <typename K>
+__device__ inline bool pyset_insert_uniform(K* tab, uint32_t mask, K key, uint64_t hash) {
+  uint64_t perturb = hash;
+  uint32_t i = (uint32_t)hash & mask;
+  while (true) {
+    uint32_t e = i;
+    int probes = (i + 9u <= mask) ? 9 : 0;
+    do {
+      K cur = uniform_key<K>(tab[e]);
+      if (cur == 0) {
+        tab[e] = key;
+        return true;
+      }
+      if (cur == key) return false;
+      e++;
+    } while (probes--);
+    perturb >>= 5;
+    i = (i * 5u + 1u + (uint32_t)perturb) & mask;
+  }
+}
+// set_insert_clean: the key is known to be absent, the table has no dummies.
+template <typename K>
+__device__ inline void pyset_insert_clean_uniform(K* tab, uint32_t mask, K key, uint64_t hash) {
+  uint64_t perturb = hash;
+  uint32_t i = (uint32_t)hash & mask;
+  while (true) {
+    uint32_t e = i;
+    if (uniform_key<K>(tab[e]) == 0) {
+      tab[e] = key;
+      return;
+    }
+    if (i + 9u <= mask) {
+      for (int j = 0; j < 9; j++) {
+        e++;
+        if (uniform_key<K>(tab[e]) == 0) {
+          tab[e] = key;
+          return;
+        }
+      }
+    }
+    perturb >>= 5;
+    i = (i * 5u + 1u + (uint32_t)perturb) & mask;
+  }
+}
+
+// Which LDS region holds a table of `size` slots (ping-pong so that a resize can stream
+// old -> new without a temporary): cap in region 0, cap/4 in region 1, cap/16 in 0, ...
+__device__ inline int table_region(uint32_t cap, uint32_t size) {
+  int lv = 0;
+  while (size < cap) {
+    size <<= 2;
+    lv++;
+  }
+  return lv & 1;
+}
+
+struct EnvRegs {  // wave-uniform per-env scalars
+  int n_ems, n_boxes, n_leaf;
+  int item0, item1, item2;
+  uint64_t cursor;
+  uint32_t t;
+  int64_t vol;
+  uint32_t flags;
+};
+
+template <typename K, int BITS>
+struct Lds {
+  K* tab0;
+  K* tab1;
+  K* ems_a;
+  K* ems_b;
+  K* box;
+  K* leaf;
+  int16_t* hmap;
+};
+
+template <typename K, int BITS>
+__device__ inline Lds<K, BITS> carve_lds(const DiscreteParams& p, unsigned char* base) {
+  Lds<K, BITS> l;
+  K* q = reinterpret_cast<K*>(base);
+  l.tab0 = q; q += p.cand_cap;
+  l.tab1 = q; q += p.cand_cap / 4;
+  l.ems_a = q; q += p.ems_cap;
+  l.ems_b = q; q += p.ems_cap;
+  l.box = q; q += p.I;
+  l.leaf = q; q += p.L;
+  l.hmap = reinterpret_cast<int16_t*>(q);
+  return l;
+}
+
+__device__ inline void draw_item(const DiscreteParams& p, int e, EnvRegs& r) {
+  // binCreator.py:37-39 generate_box_size, through the scripted / counter-based sources
+  uint64_t c = r.cursor++;
+  const int32_t* it;
+  if (p.source == PCT_ITEMS_STREAM) {
+    it = p.stream + ((size_t)e * (size_t)p.T + (size_t)(c % (uint64_t)p.T)) * 3;
+  } else {
+    uint64_t g = (uint64_t)(p.env_id_base + e);
+    it = p.item_set + (size_t)(pct_mix64(p.seed, g, c) % (uint64_t)p.n_items) * 3;
+  }
+  r.item0 = it[0];
+  r.item1 = it[1];
+  r.item2 = it[2];
+}
+
+// D/space.py:290-314 Space.reset on the LDS-resident state
+template <typename K, int BITS>
+__device__ inline void space_reset(const DiscreteParams& p, Lds<K, BITS>& l, EnvRegs& r, int lane) {
+  for (int c = lane; c < p.AA; c += 64) l.hmap[c] = 0;
+  if (lane == 0) l.ems_a[0] = Pack<K, BITS>::pack(0, 0, 0, p.W, p.Ly, p.H);
+  r.n_ems = 1;
+  r.n_boxes = 0;
+  r.vol = 0;
+}
+
+// D/space.py:457-483 GENEMS + :518-531 EliminateInscribedEMS.  ems_a -> ems_a.
+template <typename K, int BITS>
+__device__ inline void genems(const DiscreteParams& p, Lds<K, BITS>& l, EnvRegs& r, int lane, int bx0, int by0,
+                              int bz0, int bx1, int by1, int bz1) {
+  typedef Pack<K, BITS> P;
+  const int E = r.n_ems;
+  const int lb = p.low_bound <= 0 ? 1 : p.low_bound;
+  const uint64_t lt = lanemask_lt(lane);
+  // sweep 1: survivors (EMS not intersected by the box) keep their order at the front
+  int S = 0;
+  for (int base = 0; base < E; base += 64) {
+    int i = base + lane;
+    bool live = i < E;
+    K k = live ? l.ems_a[i] : (K)0;
+    int x1 = P::get(k, 0), y1 = P::get(k, 1), z1 = P::get(k, 2), x2 = P::get(k, 3), y2 = P::get(k, 4),
+        z2 = P::get(k, 5);
+    int t1 = max(bx0, x1), u1 = max(by0, y1), v1 = max(bz0, z1);
+    int t2 = min(bx1, x2), u2 = min(by1, y2), v2 = min(bz1, z2);
+    bool inter = live && (t1 < t2) && (u1 < u2) && (v1 < v2);
+    bool surv = live && !inter;
+    uint64_t m = __ballot(surv);
+    if (surv) l.ems_b[S + __popcll(m & lt)] = k;
+    S += __popcll(m);
+  }
+  // sweep 2: children of every intersected EMS, by parent index then branch order
+  int C = 0;
+  bool overflow = false;
+  for (int base = 0; base < E; base += 64) {
+    int i = base + lane;
+    bool live = i < E;
+    K k = live ? l.ems_a[i] : (K)0;
+    int x1 = P::get(k, 0), y1 = P::get(k, 1), z1 = P::get(k, 2), x2 = P::get(k, 3), y2 = P::get(k, 4),
+        z2 = P::get(k, 5);
+    int x3 = max(bx0, x1), y3 = max(by0, y1), z3 = max(bz0, z1);
+    int x4 = min(bx1, x2), y4 = min(by1, y2), z4 = min(bz1, z2);
+    bool inter = live && (x3 < x4) && (y3 < y4) && (z3 < z4);
+    (void)z3;
+    bool ylz = (y2 - y1 >= lb) && (z2 - z1 >= lb);
+    bool xlz = (x2 - x1 >= lb) && (z2 - z1 >= lb);
+    bool c0 = inter && (x3 - x1 >= lb) && ylz;                       // [x1,y1,z1,x3,y2,z2]
+    bool c1 = inter && (x2 - x4 >= lb) && ylz;                       // [x4,y1,z1,x2,y2,z2]
+    bool c2 = inter && (y3 - y1 >= lb) && xlz;                       // [x1,y1,z1,x2,y3,z2]
+    bool c3 = inter && (y2 - y4 >= lb) && xlz;                       // [x1,y4,z1,x2,y2,z2]
+    bool c4 = inter && (z2 - z4 >= lb) && (x2 - x1 >= lb) && (y2 - y1 >= lb);  // [x1,y1,z4,x2,y2,z2]
+    uint64_t m0 = __ballot(c0), m1 = __ballot(c1), m2 = __ballot(c2), m3 = __ballot(c3), m4 = __ballot(c4);
+    int pos = S + C + __popcll(m0 & lt) + __popcll(m1 & lt) + __popcll(m2 & lt) + __popcll(m3 & lt) +
+              __popcll(m4 & lt);
+    if (c0) { if (pos < p.ems_cap) l.ems_b[pos] = P::pack(x1, y1, z1, x3, y2, z2); pos++; }
+    if (c1) { if (pos < p.ems_cap) l.ems_b[pos] = P::pack(x4, y1, z1, x2, y2, z2); pos++; }
+    if (c2) { if (pos < p.ems_cap) l.ems_b[pos] = P::pack(x1, y1, z1, x2, y3, z2); pos++; }
+    if (c3) { if (pos < p.ems_cap) l.ems_b[pos] = P::pack(x1, y4, z1, x2, y2, z2); pos++; }
+    if (c4) { if (pos < p.ems_cap) l.ems_b[pos] = P::pack(x1, y1, z4, x2, y2, z2); pos++; }
+    C += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3) + __popcll(m4);
+  }
+  int n = S + C;
+  if (n > p.ems_cap) {
+    overflow = true;
+    n = p.ems_cap;
+  }
+  if (overflow) r.flags |= PCT_FLAG_EMS_OVERFLOW;
+  __syncthreads();
+  // elimination: i is deleted iff some j != i contains it (non-strict, pre-deletion list)
+  int out = 0;
+  for (int base = 0; base < n; base += 64) {
+    int i = base + lane;
+    bool live = i < n;
+    K k = live ? l.ems_b[i] : (K)0;
+    int a0 = P::get(k, 0), a1 = P::get(k, 1), a2 = P::get(k, 2), a3 = P::get(k, 3), a4 = P::get(k, 4),
+        a5 = P::get(k, 5);
+    bool del = false;
+    for (int j = 0; j < n; j++) {
+      K kj = uniform_key<K>(l.ems_b[j]);
+      int b0 = P::get(kj, 0), b1 = P::get(kj, 1), b2 = P::get(kj, 2), b3 = P::get(kj, 3), b4 = P::get(kj, 4),
+          b5 = P::get(kj, 5);
+      bool inside = (a0 >= b0) & (a1 >= b1) & (a2 >= b2) & (a3 <= b3) & (a4 <= b4) & (a5 <= b5);
+      del |= inside & (j != i);
+    }
+    bool keep = live && !del;
+    uint64_t m = __ballot(keep);
+    if (keep) l.ems_a[out + __popcll(m & lt)] = k;
+    out += __popcll(m);
+  }
+  r.n_ems = out;
+  __syncthreads();
+}
+
+// D/space.py:534-570 EMSPoint (CPython-set order) + D/bin3D.py:100-136
+// get_possible_position: fills l.leaf[0..n_leaf) with the first <= L feasible candidates.
+template <typename K, int BITS>
+__device__ inline void leaf_nodes(const DiscreteParams& p, Lds<K, BITS>& l, EnvRegs& r, int lane) {
+  typedef Pack<K, BITS> P;
+  const uint64_t lt = lanemask_lt(lane);
+  const int E = r.n_ems;
+  const int b0 = r.item0, b1 = r.item1, b2 = r.item2;
+  const int orient = (p.setting == 2) ? 6 : 2;
+  const int per = orient * 4;
+  const int G = E * per;
+
+  // fresh set: PySet_MINSIZE = 8 slots
+  uint32_t size = 8, fill = 0;
+  K* tab = table_region(p.cand_cap, size) ? l.tab1 : l.tab0;
+  if (lane < 8) tab[lane] = 0;
+  __syncthreads();
+  bool cand_overflow = false;
+
+  for (int base = 0; base < G && !cand_overflow; base += 64) {
+    int g = base + lane;
+    int ei = g / per;
+    int rem = g - ei * per;
+    int rot = rem >> 2, corner = rem & 3;
+    bool valid = g < G;
+    int sx, sy, sz;
+    bool skip;
+    switch (rot) {  // D/space.py:540-562
+      case 0: sx = b0; sy = b1; sz = b2; skip = false; break;
+      case 1: sx = b1; sy = b0; sz = b2; skip = (sx == sy); break;
+      case 2: sx = b0; sy = b2; sz = b1; skip = (sx == sy && sy == sz); break;
+      case 3: sx = b1; sy = b2; sz = b0; skip = (sx == sy && sy == sz); break;
+      case 4: sx = b2; sy = b0; sz = b1; skip = (sx == sy); break;
+      default: sx = b2; sy = b1; sz = b0; skip = (sx == sy); break;
+    }
+    K ek = valid ? l.ems_a[ei] : (K)0;
+    int x0 = P::get(ek, 0), y0 = P::get(ek, 1), z0 = P::get(ek, 2), x1 = P::get(ek, 3), y1 = P::get(ek, 4),
+        z1 = P::get(ek, 5);
+    valid = valid && !skip && (x1 - x0 >= sx) && (y1 - y0 >= sy) && (z1 - z0 >= sz);
+    int xs = (corner & 1) ? x1 - sx : x0;
+    int ys = (corner & 2) ? y1 - sy : y0;
+    K key = P::pack(xs, ys, z0, xs + sx, ys + sy, z0 + sz);
+    uint64_t hash = tuplehash6<K, BITS>(key);
+    bool found = valid && pyset_lookup<K>(tab, size - 1, key, hash);
+    uint64_t misses = __ballot(valid && !found);
+    while (misses) {
+      int src = __ffsll((unsigned long long)misses) - 1;
+      misses &= misses - 1;
+      K ukey = bcast_key<K>(key, src);
+      uint64_t uhash = bcast_u64(hash, src);
+      if (pyset_insert_uniform<K>(tab, size - 1, ukey, uhash)) {
+        fill++;
+        if (fill * 5u >= (size - 1) * 3u) {  // set_table_resize(used * 4)
+          uint32_t newsize = 8;
+          while (newsize <= fill * 4u) newsize <<= 1;
+          if (newsize > (uint32_t)p.cand_cap) {
+            cand_overflow = true;
+            break;
+          }
+          K* ntab = table_region(p.cand_cap, newsize) ? l.tab1 : l.tab0;
+          __syncthreads();
+          for (uint32_t s = lane; s < newsize; s += 64) ntab[s] = 0;
+          __syncthreads();
+          for (uint32_t sb = 0; sb < size; sb += 64) {
+            uint32_t s = sb + lane;
+            K ok = (s < size) ? tab[s] : (K)0;
+            uint64_t oh = tuplehash6<K, BITS>(ok);
+            uint64_t occ = __ballot(ok != 0);
+            while (occ) {
+              int q = __ffsll((unsigned long long)occ) - 1;
+              occ &= occ - 1;
+              pyset_insert_clean_uniform<K>(ntab, newsize - 1, bcast_key<K>(ok, q), bcast_u64(oh, q));
+            }
+          }
+          tab = ntab;
+          size = newsize;
+          __syncthreads();
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (cand_overflow) r.flags |= PCT_FLAG_CANDIDATE_OVERFLOW;
+
+  // iterate the table in slot order (= list(set)), test feasibility, keep the first L
+  int nleaf = 0;
+  for (uint32_t sb = 0; sb < size && nleaf < p.L; sb += 64) {
+    uint32_t s = sb + lane;
+    K k = (s < size) ? tab[s] : (K)0;
+    bool feas = false;
+    if (k != 0) {
+      int xs = P::get(k, 0), ys = P::get(k, 1), xe = P::get(k, 3), ye = P::get(k, 4);
+      int z = P::get(k, 5) - P::get(k, 2);
+      int mh = 0;  // D/space.py:400-401 footprint maximum (candidate's own zs is ignored)
+      for (int x = xs; x < xe; x++)
+        for (int y = ys; y < ye; y++) {
+          int h = l.hmap[x * p.A + y];
+          mh = h > mh ? h : mh;
+        }
+      // check_box :436-446: EMS candidates are inside the bin by construction
+      feas = (xe <= p.W) && (ye <= p.Ly) && (mh + z <= p.H);
+    }
+    uint64_t m = __ballot(feas);
+    int idx = nleaf + __popcll(m & lt);
+    if (feas && idx < p.L) l.leaf[idx] = k;
+    nleaf += __popcll(m);
+  }
+  r.n_leaf = nleaf < p.L ? nleaf : p.L;
+  __syncthreads();
+}
+
+// D/bin3D.py:70-93: the [I+L+1, 9] float32 observation, written once, coalesced
+template <typename K, int BITS>
+__device__ inline void write_obs(const DiscreteParams& p, const Lds<K, BITS>& l, const EnvRegs& r, int lane,
+                                 float* __restrict__ obs) {
+  typedef Pack<K, BITS> P;
+  int a = r.item0, b = r.item1, c = r.item2, tmp;
+  if (a > b) { tmp = a; a = b; b = tmp; }
+  if (b > c) { tmp = b; b = c; c = tmp; }
+  if (a > b) { tmp = a; a = b; b = tmp; }
+  for (int f = lane; f < p.row_len; f += 64) {
+    int row = f / 9;
+    int col = f - row * 9;
+    float v = 0.f;
+    if (row < p.I) {
+      if (row < r.n_boxes) {
+        K k = l.box[row];
+        v = col < 6 ? (float)P::get(k, col) : (col == 6 ? 1.0f : (col == 8 ? 1.0f : 0.f));
+      } else if (row == 0 && col == 8) {
+        v = 1.0f;  // D/space.py:294-295 dummy valid node after reset
+      }
+    } else if (row < p.I + p.L) {
+      int j = row - p.I;
+      if (j < r.n_leaf) {
+        K k = l.leaf[j];
+        v = col < 5 ? (float)P::get(k, col) : (col == 5 ? (float)p.H : (col == 8 ? 1.0f : 0.f));
+      }
+    } else {
+      v = col == 0 ? 1.0f : (col == 3 ? (float)a : (col == 4 ? (float)b : (col == 5 ? (float)c : (col == 8 ? 1.0f : 0.f))));
+    }
+    obs[f] = v;
+  }
+}
+
+template <typename K, int BITS>
+__device__ inline void load_state(const DiscreteParams& p, int e, Lds<K, BITS>& l, EnvRegs& r, int lane) {
+  const K* g_ems = reinterpret_cast<const K*>(p.ems) + (size_t)e * p.ems_cap;
+  const K* g_box = reinterpret_cast<const K*>(p.boxes) + (size_t)e * p.I;
+  const K* g_leaf = reinterpret_cast<const K*>(p.leaves) + (size_t)e * p.L;
+  const int16_t* g_h = p.hmap + (size_t)e * p.AA;
+  const int32_t* sc = p.scalars + (size_t)e * PCT_SCALARS;
+  r.n_ems = sc[0]; r.n_boxes = sc[1]; r.n_leaf = sc[2];
+  r.item0 = sc[3]; r.item1 = sc[4]; r.item2 = sc[5];
+  r.t = (uint32_t)sc[6];
+  r.flags = p.flags[e];
+  r.cursor = ((uint64_t)(uint32_t)sc[9] << 32) | (uint32_t)sc[8];
+  r.vol = (int64_t)(((uint64_t)(uint32_t)sc[11] << 32) | (uint32_t)sc[10]);
+  for (int i = lane; i < r.n_ems; i += 64) l.ems_a[i] = g_ems[i];
+  for (int i = lane; i < r.n_boxes; i += 64) l.box[i] = g_box[i];
+  for (int i = lane; i < r.n_leaf; i += 64) l.leaf[i] = g_leaf[i];
+  for (int i = lane; i < p.AA; i += 64) l.hmap[i] = g_h[i];
+  __syncthreads();
+}
+
+template <typename K, int BITS>
+__device__ inline void store_state(const DiscreteParams& p, int e, const Lds<K, BITS>& l, const EnvRegs& r, int lane) {
+  K* g_ems = reinterpret_cast<K*>(p.ems) + (size_t)e * p.ems_cap;
+  K* g_box = reinterpret_cast<K*>(p.boxes) + (size_t)e * p.I;
+  K* g_leaf = reinterpret_cast<K*>(p.leaves) + (size_t)e * p.L;
+  int16_t* g_h = p.hmap + (size_t)e * p.AA;
+  int32_t* sc = p.scalars + (size_t)e * PCT_SCALARS;
+  for (int i = lane; i < r.n_ems; i += 64) g_ems[i] = l.ems_a[i];
+  for (int i = lane; i < r.n_boxes; i += 64) g_box[i] = l.box[i];
+  for (int i = lane; i < r.n_leaf; i += 64) g_leaf[i] = l.leaf[i];
+  for (int i = lane; i < p.AA; i += 64) g_h[i] = l.hmap[i];
+  if (lane == 0) {
+    sc[0] = r.n_ems; sc[1] = r.n_boxes; sc[2] = r.n_leaf;
+    sc[3] = r.item0; sc[4] = r.item1; sc[5] = r.item2;
+    sc[6] = (int32_t)r.t;
+    sc[7] = 0;
+    p.flags[e] = r.flags;
+    sc[8] = (int32_t)(uint32_t)r.cursor; sc[9] = (int32_t)(uint32_t)(r.cursor >> 32);
+    sc[10] = (int32_t)(uint32_t)(uint64_t)r.vol; sc[11] = (int32_t)(uint32_t)((uint64_t)r.vol >> 32);
+  }
+}
+
+// One transition of one env with the state resident in LDS (D/bin3D.py:151-188 plus the
+// VecEnv worker's auto-reset).  (flag, lx, ly) + (bx, by, bz) is the decoded action.
+template <typename K, int BITS>
+__device__ inline void transition(const DiscreteParams& p, int e, Lds<K, BITS>& l, EnvRegs& r, int lane, bool bad,
+                                  int flag, int lx, int ly, int bx, int by, int bz) {
+  typedef Pack<K, BITS> P;
+  r.t++;
+  int x = flag ? by : bx, y = flag ? bx : by, z = bz;  // D/space.py:348-351
+  bool ok = !bad;
+  int max_h = 0;
+  if (ok) {
+    // np.max(plain[lx:lx+x, ly:ly+y]) with Python slice normalisation (D/space.py:354-355)
+    int xa = lx, xb = lx + x, ya = ly, yb = ly + y;
+    if (xa < 0) { xa += p.A; if (xa < 0) xa = 0; }
+    if (xb < 0) { xb += p.A; if (xb < 0) xb = 0; }
+    if (ya < 0) { ya += p.A; if (ya < 0) ya = 0; }
+    if (yb < 0) { yb += p.A; if (yb < 0) yb = 0; }
+    xa = min(xa, p.A); xb = min(xb, p.A); ya = min(ya, p.A); yb = min(yb, p.A);
+    if (xb <= xa || yb <= ya) {
+      ok = false;  // empty slice: np.max raises ValueError
+      r.flags |= PCT_FLAG_BAD_ACTION;
+    } else if (lx < 0 || ly < 0) {
+      ok = false;  // check_box D/space.py:440-441 rejects it whatever max_h is
+    } else {
+      int w = yb - ya, cells = (xb - xa) * w, m = 0;
+      for (int c = lane; c < cells; c += 64) {
+        int cx = xa + c / w, cy = ya + c % w;
+        int h = l.hmap[cx * p.A + cy];
+        m = h > m ? h : m;
+      }
+      max_h = wave_max_i32(m);
+      // check_box D/space.py:436-446 (setting 2)
+      ok = !(lx + x > p.W || ly + y > p.Ly) && !(max_h + z > p.H);
+    }
+  }
+  if (ok && r.n_boxes >= p.I) {  // IndexError at D/space.py:385
+    ok = false;
+    r.flags |= PCT_FLAG_INTERNAL_OVERFLOW;
+  }
+  float reward;
+  uint8_t done;
+  int counter;
+  double ratio = 0.0;
+  const double binvol = (double)((int64_t)p.W * p.Ly * p.H);
+  if (ok) {
+    int top = max_h + z;
+    int cells = x * y;
+    for (int c = lane; c < cells; c += 64) l.hmap[(lx + c / y) * p.A + (ly + c % y)] = (int16_t)top;
+    if (lane == 0) l.box[r.n_boxes] = P::pack(lx, ly, max_h, lx + x, ly + y, top);
+    r.n_boxes++;
+    r.vol += (int64_t)x * y * z;
+    __syncthreads();
+    genems<K, BITS>(p, l, r, lane, lx, ly, max_h, lx + x, ly + y, top);
+    // D/bin3D.py:57-59,183: 10 * vol(item) / vol(bin), float64 then envs.py:181 .float()
+    reward = (float)(((double)((int64_t)r.item0 * r.item1 * r.item2) / binvol) * 10.0);
+    done = 0;
+    counter = r.n_boxes;
+  } else {
+    reward = 0.f;
+    done = 1;
+    counter = r.n_boxes;
+    ratio = (double)r.vol / binvol;  // D/space.py:334-339
+    __syncthreads();
+    space_reset<K, BITS>(p, l, r, lane);  // shmem_vec_env.py:141-143 -> D/bin3D.py:61-67
+    __syncthreads();
+  }
+  draw_item(p, e, r);
+  if (lane == 0) {
+    p.reward[e] = reward;
+    p.done[e] = done;
+    p.counter[e] = counter;
+    p.ratio[e] = ratio;
+  }
+}
+
+// D/bin3D.py:139-149 LeafNode2Action for a leaf given as six integers (zero row -> (0,0,0)
+// with the unrotated item)
+__device__ inline void decode_leaf(const EnvRegs& r, bool zero_row, int xs, int ys, int xe, int ye, bool& bad,
+                                   int& lx, int& ly, int& bx, int& by, int& bz) {
+  bad = false;
+  if (zero_row) {
+    lx = 0; ly = 0; bx = r.item0; by = r.item1; bz = r.item2;
+    return;
+  }
+  int x = xe - xs, y = ye - ys;
+  int z0 = r.item0, z1 = r.item1, z2 = r.item2;
+  // z = list(next_box); z.remove(x); z.remove(y); z = z[0]
+  int a, b;  // the two survivors after removing x
+  if (z0 == x) { a = z1; b = z2; }
+  else if (z1 == x) { a = z0; b = z2; }
+  else if (z2 == x) { a = z0; b = z1; }
+  else { bad = true; a = b = 0; }
+  int zz = 0;
+  if (!bad) {
+    if (a == y) zz = b;
+    else if (b == y) zz = a;
+    else bad = true;
+  }
+  lx = xs; ly = ys; bx = x; by = y; bz = zz;
+}
+
+enum { ACT_ROWS = 0, ACT_INDEX = 1, ACT_HASH = 2, ACT_RESET = 3 };
+
+template <typename K, int BITS, int ACT>
+__global__ void __launch_bounds__(64) pct_discrete_kernel(DiscreteParams p, const void* __restrict__ actions,
+                                                          int row_len, int n_steps,
+                                                          const int32_t* __restrict__ env_ids, int n_ids) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = threadIdx.x;
+  int e = blockIdx.x;
+  if (ACT == ACT_RESET && env_ids) {
+    if (e >= n_ids) return;
+    e = env_ids[e];
+    if (e < 0 || e >= p.N) return;
+  }
+  Lds<K, BITS> l = carve_lds<K, BITS>(p, smem);
+  EnvRegs r;
+  load_state<K, BITS>(p, e, l, r, lane);
+  float* obs = p.obs + (size_t)e * p.row_len;
+
+  if (ACT == ACT_RESET) {
+    space_reset<K, BITS>(p, l, r, lane);
+    __syncthreads();
+    draw_item(p, e, r);
+    leaf_nodes<K, BITS>(p, l, r, lane);
+    write_obs<K, BITS>(p, l, r, lane, obs);
+    store_state<K, BITS>(p, e, l, r, lane);
+    return;
+  }
+
+  for (int it = 0; it < n_steps; it++) {
+    bool bad = false, zero_row = false;
+    int flag = 0, lx = 0, ly = 0, bx = 0, by = 0, bz = 0;
+    if (ACT == ACT_ROWS) {
+      const float* row = reinterpret_cast<const float*>(actions) + (size_t)e * row_len;
+      float v = lane < row_len ? row[lane] : 0.f;
+      float a0 = __shfl(v, 0, 64), a1 = __shfl(v, 1, 64), a2 = __shfl(v, 2, 64), a3 = __shfl(v, 3, 64),
+            a4 = __shfl(v, 4, 64), a5 = __shfl(v, 5, 64);
+      if (row_len == 3) {  // (flag, lx, ly) with the unrotated item, D/bin3D.py:152-153
+        flag = (int)a0; lx = (int)a1; ly = (int)a2;
+        bx = r.item0; by = r.item1; bz = r.item2;
+      } else {
+        float sum = ((((a0 + a1) + a2) + a3) + a4) + a5;  // np.sum(leaf_node[0:6]) == 0
+        zero_row = (sum == 0.f);
+        decode_leaf(r, zero_row, (int)a0, (int)a1, (int)a0 + (int)(a3 - a0), (int)a1 + (int)(a4 - a1), bad, lx, ly,
+                    bx, by, bz);
+      }
+    } else {
+      int64_t li;
+      if (ACT == ACT_INDEX) {
+        li = reinterpret_cast<const int64_t*>(actions)[e];
+      } else {  // stand-in policy: leaf = pct_mix32(g, t) % k over the k valid leaves
+        li = r.n_leaf > 0 ? (int64_t)(pct_mix32((uint32_t)(p.env_id_base + e), r.t) % (uint32_t)r.n_leaf) : 0;
+      }
+      zero_row = !(li >= 0 && li < r.n_leaf);
+      K k = zero_row ? (K)0 : l.leaf[li];
+      typedef Pack<K, BITS> P;
+      decode_leaf(r, zero_row, P::get(k, 0), P::get(k, 1), P::get(k, 3), P::get(k, 4), bad, lx, ly, bx, by, bz);
+    }
+    if (bad) r.flags |= PCT_FLAG_BAD_ACTION;  // ValueError in list.remove, D/bin3D.py:144-145
+    transition<K, BITS>(p, e, l, r, lane, bad, flag, lx, ly, bx, by, bz);
+    leaf_nodes<K, BITS>(p, l, r, lane);
+    write_obs<K, BITS>(p, l, r, lane, obs);
+    __syncthreads();
+  }
+  store_state<K, BITS>(p, e, l, r, lane);
+}
+
+// Stand-in policy kernel: one wave per env reads the leaf-mask column (col 8 of rows
+// I..I+L-1, tools.py:103) of the observation, k = number of valid leaves, picks
+// pct_mix32(g, t) % k and copies that row out (train_tools.py:66 gather).
+__global__ void __launch_bounds__(64) pct_policy_hash_rows_kernel(DiscreteParams p, float* __restrict__ rows_out) {
+  const int lane = threadIdx.x;
+  const int e = blockIdx.x;
+  const float* obs = p.obs + (size_t)e * p.row_len;
+  int k = 0;
+  for (int base = 0; base < p.L; base += 64) {
+    int j = base + lane;
+    bool v = j < p.L && obs[(p.I + j) * 9 + 8] != 0.f;
+    k += __popcll(__ballot(v));
+  }
+  uint32_t t = (uint32_t)p.scalars[(size_t)e * PCT_SCALARS + 6];
+  int li = k > 0 ? (int)(pct_mix32((uint32_t)(p.env_id_base + e), t) % (uint32_t)k) : 0;
+  if (lane < 9) rows_out[(size_t)e * 9 + lane] = obs[(p.I + li) * 9 + lane];
+}
+
+}  // namespace pct
+
+// ----------------------------------------------------------------------------------------
+// launchers (called from pct_env.hip)
+// ----------------------------------------------------------------------------------------
+namespace pct {
+
+size_t discrete_lds_bytes(const DiscreteParams& p) {
+  size_t k = p.key_bytes;
+  size_t n = (size_t)p.cand_cap + p.cand_cap / 4 + 2 * (size_t)p.ems_cap + p.I + p.L;
+  return n * k + (size_t)p.AA * sizeof(int16_t) + 16;
+}
+
+template <typename K, int BITS>
+static hipError_t launch_typed(const DiscreteParams& p, int act, const void* actions, int row_len, int n_steps,
+                               const int32_t* env_ids, int n_ids, hipStream_t stream) {
+  size_t lds = discrete_lds_bytes(p);
+  int grid = (act == ACT_RESET && env_ids) ? n_ids : p.N;
+  if (grid <= 0) return hipSuccess;
+#define PCT_LAUNCH(A)                                                                                        \
+  do {                                                                                                       \
+    auto kern = pct_discrete_kernel<K, BITS, A>;                                                             \
+    if (lds > 48 * 1024) {                                                                                   \
+      hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                               \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
+      if (er != hipSuccess) return er;                                                                       \
+    }                                                                                                        \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, stream, p, actions, row_len, n_steps, env_ids, n_ids); \
+  } while (0)
+  switch (act) {
+    case ACT_ROWS: PCT_LAUNCH(ACT_ROWS); break;
+    case ACT_INDEX: PCT_LAUNCH(ACT_INDEX); break;
+    case ACT_HASH: PCT_LAUNCH(ACT_HASH); break;
+    default: PCT_LAUNCH(ACT_RESET); break;
+  }
+#undef PCT_LAUNCH
+  return hipGetLastError();
+}
+
+hipError_t launch_policy_hash_rows(const DiscreteParams& p, float* rows_out, hipStream_t stream) {
+  hipLaunchKernelGGL(pct_policy_hash_rows_kernel, dim3(p.N), dim3(64), 0, stream, p, rows_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_discrete(const DiscreteParams& p, int act, const void* actions, int row_len, int n_steps,
+                           const int32_t* env_ids, int n_ids, hipStream_t stream) {
+  if (p.key_bytes == 4) return launch_typed<uint32_t, 5>(p, act, actions, row_len, n_steps, env_ids, n_ids, stream);
+  return launch_typed<uint64_t, 10>(p, act, actions, row_len, n_steps, env_ids, n_ids, stream);
+}
+
+}  // namespace pct

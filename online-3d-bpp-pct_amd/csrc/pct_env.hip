@@ -1,0 +1,392 @@
+// pct_env.hip -- the C-ABI of include/pct_env.h: handle lifetime, HBM state, launches.
+// No torch types, no CPU fallback: every transition is a HIP kernel launch; if there is no
+// usable device pct_create fails with PCT_ERR_NO_DEVICE / PCT_ERR_HIP.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <utility>
+#include <vector>
+
+#include "../../include/pct_env.h"
+#include "pct_device.h"
+
+namespace {
+thread_local char g_err[512] = "";
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) return fail(PCT_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e));    \
+  } while (0)
+
+enum { ACT_ROWS = 0, ACT_INDEX = 1, ACT_HASH = 2, ACT_RESET = 3 };
+}  // namespace
+
+struct pct_env {
+  pct_config cfg;
+  int device;
+  pct::DiscreteParams dp;
+  // owned device memory
+  std::vector<void*> owned;
+  float* own_obs;
+  float* own_reward;
+  uint8_t* own_done;
+  int32_t* own_counter;
+  double* own_ratio;
+  uint32_t* own_flags;
+  int32_t* d_item_set;
+  int32_t* d_stream;
+  bool have_items;
+  bool was_reset;
+  // kernel timing (pct_profile_*)
+  bool profiling;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  size_t ev_used;
+  int64_t prof_launches;
+  double prof_ms;
+};
+
+namespace {
+int dev_alloc(pct_env* h, void** p, size_t bytes, bool zero) {
+  HIP_TRY(hipMalloc(p, bytes ? bytes : 16));
+  h->owned.push_back(*p);
+  if (zero) HIP_TRY(hipMemset(*p, 0, bytes ? bytes : 16));
+  return PCT_OK;
+}
+int use_device(const pct_env* h) {
+  HIP_TRY(hipSetDevice(h->device));
+  return PCT_OK;
+}
+// drain the recorded event pairs into the accumulator
+int prof_drain(pct_env* h) {
+  for (size_t i = 0; i < h->ev_used; i++) {
+    HIP_TRY(hipEventSynchronize(h->ev_pool[i].second));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev_pool[i].first, h->ev_pool[i].second));
+    h->prof_ms += ms;
+    h->prof_launches++;
+  }
+  h->ev_used = 0;
+  return PCT_OK;
+}
+int prof_begin(pct_env* h, hipStream_t s, size_t* slot) {
+  if (h->ev_used == h->ev_pool.size()) {
+    if (h->ev_pool.size() >= 8192) {
+      int rc = prof_drain(h);
+      if (rc) return rc;
+    } else {
+      hipEvent_t a, b;
+      HIP_TRY(hipEventCreate(&a));
+      HIP_TRY(hipEventCreate(&b));
+      h->ev_pool.push_back(std::make_pair(a, b));
+    }
+  }
+  *slot = h->ev_used++;
+  HIP_TRY(hipEventRecord(h->ev_pool[*slot].first, s));
+  return PCT_OK;
+}
+int launch(pct_env* h, int act, const void* actions, int row_len, int n_steps, const int32_t* ids, int n_ids,
+           void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  size_t slot = 0;
+  if (h->profiling) {
+    int rc = prof_begin(h, s, &slot);
+    if (rc) return rc;
+  }
+  HIP_TRY(pct::launch_discrete(h->dp, act, actions, row_len, n_steps, ids, n_ids, s));
+  if (h->profiling) HIP_TRY(hipEventRecord(h->ev_pool[slot].second, s));
+  return PCT_OK;
+}
+bool is_cand_cap_ok(int c) {
+  for (int s = 8; s <= (1 << 20); s <<= 2)
+    if (s == c) return true;
+  return false;
+}
+}  // namespace
+
+extern "C" {
+
+int pct_abi_version(void) { return PCT_ABI_VERSION; }
+const char* pct_last_error(void) { return g_err; }
+
+int pct_create(const pct_config* cfg, int device, pct_env** out) {
+  if (!cfg || !out) return fail(PCT_ERR_INVALID_ARG, "null argument");
+  if (cfg->struct_size != (int32_t)sizeof(pct_config))
+    return fail(PCT_ERR_INVALID_ARG, "pct_config size mismatch (%d vs %d)", cfg->struct_size, (int)sizeof(pct_config));
+  if (cfg->env_kind != PCT_ENV_DISCRETE) return fail(PCT_ERR_UNSUPPORTED, "only the discrete env is built so far");
+  if (cfg->setting != 2) return fail(PCT_ERR_UNSUPPORTED, "only setting 2 is built so far");
+  if (cfg->lnes != PCT_LNES_EMS) return fail(PCT_ERR_UNSUPPORTED, "only LNES=EMS is built so far");
+  if (cfg->num_envs < 1 || cfg->internal_node_holder < 1 || cfg->leaf_node_holder < 1)
+    return fail(PCT_ERR_INVALID_ARG, "num_envs / holders must be positive");
+  int W = cfg->container[0], Ly = cfg->container[1], H = cfg->container[2];
+  if (W < 1 || Ly < 1 || H < 1) return fail(PCT_ERR_INVALID_ARG, "bad container");
+  int maxdim = W > Ly ? W : Ly;
+  if (H > maxdim) maxdim = H;
+  if (maxdim > 1023) return fail(PCT_ERR_UNSUPPORTED, "discrete bins are limited to 1023 per axis");
+  int ems_cap = cfg->ems_capacity > 0 ? cfg->ems_capacity : 256;
+  int cand_cap = cfg->candidate_capacity > 0 ? cfg->candidate_capacity : 2048;
+  if (!is_cand_cap_ok(cand_cap)) return fail(PCT_ERR_INVALID_ARG, "candidate_capacity must be 8*4^k (8,32,...,2048,8192)");
+
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev < 1) return fail(PCT_ERR_NO_DEVICE, "no HIP device: %s", hipGetErrorString(e));
+  if (device < 0 || device >= ndev) return fail(PCT_ERR_INVALID_ARG, "device %d out of range (%d devices)", device, ndev);
+
+  pct_env* h = new pct_env();
+  h->cfg = *cfg;
+  h->device = device;
+  h->have_items = false;
+  h->was_reset = false;
+  h->d_item_set = nullptr;
+  h->d_stream = nullptr;
+  h->profiling = false;
+  h->ev_used = 0;
+  h->prof_launches = 0;
+  h->prof_ms = 0.0;
+  int rc = use_device(h);
+  if (rc) { delete h; return rc; }
+
+  pct::DiscreteParams& p = h->dp;
+  memset(&p, 0, sizeof p);
+  p.N = cfg->num_envs;
+  p.W = W; p.Ly = Ly; p.H = H;
+  p.A = W > Ly ? W : Ly;
+  p.AA = (p.A * p.A + 7) & ~7;
+  p.I = cfg->internal_node_holder;
+  p.L = cfg->leaf_node_holder;
+  p.row_len = (p.I + p.L + 1) * 9;
+  p.setting = cfg->setting;
+  p.ems_cap = ems_cap;
+  p.cand_cap = cand_cap;
+  p.key_bytes = maxdim <= 31 ? 4 : 8;
+  p.env_id_base = cfg->env_id_base;
+  p.source = PCT_ITEMS_NONE;
+
+  size_t lds = pct::discrete_lds_bytes(p);
+  if (lds > 160 * 1024) { delete h; return fail(PCT_ERR_INVALID_ARG, "capacities need %zu B of LDS (> 160 KiB)", lds); }
+
+  size_t N = (size_t)p.N;
+#define ALLOC(ptr, bytes)                                   \
+  do {                                                      \
+    rc = dev_alloc(h, (void**)&(ptr), (bytes), true);       \
+    if (rc) { pct_destroy(h); return rc; }                  \
+  } while (0)
+  ALLOC(p.hmap, N * p.AA * sizeof(int16_t));
+  ALLOC(p.ems, N * p.ems_cap * p.key_bytes);
+  ALLOC(p.boxes, N * p.I * p.key_bytes);
+  ALLOC(p.leaves, N * p.L * p.key_bytes);
+  ALLOC(p.scalars, N * PCT_SCALARS * sizeof(int32_t));
+  ALLOC(h->own_flags, N * sizeof(uint32_t));
+  ALLOC(h->own_obs, N * p.row_len * sizeof(float));
+  ALLOC(h->own_reward, N * sizeof(float));
+  ALLOC(h->own_done, N);
+  ALLOC(h->own_counter, N * sizeof(int32_t));
+  ALLOC(h->own_ratio, N * sizeof(double));
+#undef ALLOC
+  p.obs = h->own_obs;
+  p.reward = h->own_reward;
+  p.done = h->own_done;
+  p.counter = h->own_counter;
+  p.ratio = h->own_ratio;
+  p.flags = h->own_flags;
+  *out = h;
+  return PCT_OK;
+}
+
+int pct_destroy(pct_env* h) {
+  if (!h) return PCT_OK;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  for (void* q : h->owned) (void)hipFree(q);
+  for (auto& ev : h->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  delete h;
+  return PCT_OK;
+}
+
+int pct_set_item_set(pct_env* h, const int32_t* item_set, int32_t n) {
+  if (!h || !item_set || n < 1) return fail(PCT_ERR_INVALID_ARG, "bad item set");
+  int rc = use_device(h);
+  if (rc) return rc;
+  int mn = item_set[0], mx = item_set[0];
+  for (int i = 0; i < 3 * n; i++) {
+    if (item_set[i] < mn) mn = item_set[i];
+    if (item_set[i] > mx) mx = item_set[i];
+  }
+  if (mn < 1) return fail(PCT_ERR_INVALID_ARG, "item sizes must be >= 1 lattice unit");
+  (void)mx;
+  void* d = nullptr;
+  rc = dev_alloc(h, &d, sizeof(int32_t) * 3 * (size_t)n, false);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(d, item_set, sizeof(int32_t) * 3 * (size_t)n, hipMemcpyHostToDevice));
+  h->d_item_set = (int32_t*)d;
+  h->dp.item_set = h->d_item_set;
+  h->dp.n_items = n;
+  h->dp.low_bound = mn; /* bin3D.py:23 size_minimum */
+  h->have_items = true;
+  return PCT_OK;
+}
+
+int pct_set_sample_bounds(pct_env* h, int32_t left, int32_t right) {
+  (void)h; (void)left; (void)right;
+  return fail(PCT_ERR_UNSUPPORTED, "continuous env not built yet");
+}
+
+int pct_set_item_stream(pct_env* h, const int32_t* items, int64_t T) {
+  if (!h || !items || T < 1) return fail(PCT_ERR_INVALID_ARG, "bad stream");
+  int rc = use_device(h);
+  if (rc) return rc;
+  size_t n = (size_t)h->dp.N * (size_t)T * 3;
+  void* d = nullptr;
+  rc = dev_alloc(h, &d, sizeof(int32_t) * n, false);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(d, items, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+  h->d_stream = (int32_t*)d;
+  h->dp.stream = h->d_stream;
+  h->dp.T = T;
+  h->dp.source = PCT_ITEMS_STREAM;
+  return PCT_OK;
+}
+
+int pct_set_sampler(pct_env* h, uint64_t seed) {
+  if (!h) return fail(PCT_ERR_INVALID_ARG, "null handle");
+  if (!h->have_items) return fail(PCT_ERR_STATE, "pct_set_item_set must come first");
+  h->dp.seed = seed;
+  h->dp.source = PCT_ITEMS_SAMPLER;
+  return PCT_OK;
+}
+
+int pct_bind_outputs(pct_env* h, float* obs, float* reward, uint8_t* done, int32_t* counter, double* ratio,
+                     uint32_t* error_flags) {
+  if (!h) return fail(PCT_ERR_INVALID_ARG, "null handle");
+  h->dp.obs = obs ? obs : h->own_obs;
+  h->dp.reward = reward ? reward : h->own_reward;
+  h->dp.done = done ? done : h->own_done;
+  h->dp.counter = counter ? counter : h->own_counter;
+  h->dp.ratio = ratio ? ratio : h->own_ratio;
+  h->dp.flags = error_flags ? error_flags : h->own_flags;
+  return PCT_OK;
+}
+
+float* pct_obs(pct_env* h) { return h ? h->dp.obs : nullptr; }
+float* pct_reward(pct_env* h) { return h ? h->dp.reward : nullptr; }
+uint8_t* pct_done(pct_env* h) { return h ? h->dp.done : nullptr; }
+int32_t* pct_info_counter(pct_env* h) { return h ? h->dp.counter : nullptr; }
+double* pct_info_ratio(pct_env* h) { return h ? h->dp.ratio : nullptr; }
+uint32_t* pct_error_flags(pct_env* h) { return h ? h->dp.flags : nullptr; }
+int32_t pct_obs_row_len(pct_env* h) { return h ? h->dp.row_len : 0; }
+
+static int ready(pct_env* h, bool need_reset) {
+  if (!h) return fail(PCT_ERR_INVALID_ARG, "null handle");
+  if (!h->have_items) return fail(PCT_ERR_STATE, "item set not configured");
+  if (h->dp.source == PCT_ITEMS_NONE) return fail(PCT_ERR_STATE, "item source not configured");
+  if (need_reset && !h->was_reset) return fail(PCT_ERR_STATE, "step before the first reset");
+  return use_device(h);
+}
+
+int pct_reset(pct_env* h, const int32_t* env_ids, int32_t n, void* stream) {
+  int rc = ready(h, false);
+  if (rc) return rc;
+  if (env_ids && !h->was_reset) return fail(PCT_ERR_STATE, "first reset must cover all envs");
+  rc = launch(h, ACT_RESET, nullptr, 0, 1, env_ids, n, stream);
+  if (rc) return rc;
+  h->was_reset = true;
+  return PCT_OK;
+}
+
+int pct_step_rows(pct_env* h, const float* rows, int32_t row_len, void* stream) {
+  int rc = ready(h, true);
+  if (rc) return rc;
+  if (!rows) return fail(PCT_ERR_INVALID_ARG, "null actions");
+  if (row_len != 9 && row_len != 6 && row_len != 3) return fail(PCT_ERR_INVALID_ARG, "row_len must be 9, 6 or 3");
+  return launch(h, ACT_ROWS, rows, row_len, 1, nullptr, 0, stream);
+}
+
+int pct_step_index(pct_env* h, const int64_t* leaf_index, void* stream) {
+  int rc = ready(h, true);
+  if (rc) return rc;
+  if (!leaf_index) return fail(PCT_ERR_INVALID_ARG, "null actions");
+  return launch(h, ACT_INDEX, leaf_index, 0, 1, nullptr, 0, stream);
+}
+
+int pct_step_hash_policy(pct_env* h, int32_t n_steps, void* stream) {
+  int rc = ready(h, true);
+  if (rc) return rc;
+  if (n_steps < 1) return fail(PCT_ERR_INVALID_ARG, "n_steps must be >= 1");
+  return launch(h, ACT_HASH, nullptr, 0, n_steps, nullptr, 0, stream);
+}
+
+int pct_policy_hash_rows(pct_env* h, float* rows_out, void* stream) {
+  int rc = ready(h, true);
+  if (rc) return rc;
+  if (!rows_out) return fail(PCT_ERR_INVALID_ARG, "null rows_out");
+  HIP_TRY(pct::launch_policy_hash_rows(h->dp, rows_out, (hipStream_t)stream));
+  return PCT_OK;
+}
+
+int pct_profile_enable(pct_env* h, int32_t on) {
+  if (!h) return fail(PCT_ERR_INVALID_ARG, "null handle");
+  int rc = use_device(h);
+  if (rc) return rc;
+  if (!on && h->profiling) {
+    rc = prof_drain(h);
+    if (rc) return rc;
+  }
+  h->profiling = on != 0;
+  return PCT_OK;
+}
+
+int pct_profile_read(pct_env* h, int64_t* n_launches, double* total_ms) {
+  if (!h) return fail(PCT_ERR_INVALID_ARG, "null handle");
+  int rc = use_device(h);
+  if (rc) return rc;
+  rc = prof_drain(h);
+  if (rc) return rc;
+  if (n_launches) *n_launches = h->prof_launches;
+  if (total_ms) *total_ms = h->prof_ms;
+  h->prof_launches = 0;
+  h->prof_ms = 0.0;
+  return PCT_OK;
+}
+
+int pct_debug_state(pct_env* h, int32_t e, int32_t* heightmap, int32_t* ems, int32_t cap_ems, int32_t* n_ems,
+                    int32_t* n_boxes, int32_t* next_item, int64_t* draw_cursor) {
+  if (!h || e < 0 || e >= h->dp.N) return fail(PCT_ERR_INVALID_ARG, "bad env id");
+  int rc = use_device(h);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  const pct::DiscreteParams& p = h->dp;
+  int32_t sc[PCT_SCALARS];
+  HIP_TRY(hipMemcpy(sc, p.scalars + (size_t)e * PCT_SCALARS, sizeof sc, hipMemcpyDeviceToHost));
+  if (heightmap) {
+    std::vector<int16_t> hm(p.AA);
+    HIP_TRY(hipMemcpy(hm.data(), p.hmap + (size_t)e * p.AA, sizeof(int16_t) * p.AA, hipMemcpyDeviceToHost));
+    for (int i = 0; i < p.A * p.A; i++) heightmap[i] = hm[i];
+  }
+  if (ems) {
+    int n = sc[0];
+    std::vector<unsigned char> raw((size_t)p.ems_cap * p.key_bytes);
+    HIP_TRY(hipMemcpy(raw.data(), (const char*)p.ems + (size_t)e * p.ems_cap * p.key_bytes, raw.size(),
+                      hipMemcpyDeviceToHost));
+    int bits = p.key_bytes == 4 ? 5 : 10;
+    for (int i = 0; i < n && i < cap_ems; i++) {
+      uint64_t k = p.key_bytes == 4 ? (uint64_t)((uint32_t*)raw.data())[i] : ((uint64_t*)raw.data())[i];
+      for (int c = 0; c < 6; c++) ems[6 * i + c] = (int32_t)((k >> (c * bits)) & ((1u << bits) - 1));
+    }
+  }
+  if (n_ems) *n_ems = sc[0];
+  if (n_boxes) *n_boxes = sc[1];
+  if (next_item) { next_item[0] = sc[3]; next_item[1] = sc[4]; next_item[2] = sc[5]; }
+  if (draw_cursor) *draw_cursor = (int64_t)(((uint64_t)(uint32_t)sc[9] << 32) | (uint32_t)sc[8]);
+  return PCT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,397 @@
+"""Host-side mirror of the reference VecEnv surface over the HIP C ABI.
+
+`PctVecEnv` is what `envs.make_vec_envs` returns in the reference -- a `VecPyTorch` around
+`ShmemVecEnv` (envs.py:75-116,159-182; wrapper/shmem_vec_env.py:20-117) -- collapsed into
+one object whose N envs live on one MI355X:
+
+  reset()            -> obs  float32 [N,(I+L+1)*9] on `device`          (envs.py:166-169)
+  step_async(a)      a: float32 [N,9|6|3] leaf rows (numpy / torch, host or device;
+                        train_tools.py:66-67, bin3D.py:152-153) or an int64 [N] / [N,1]
+                        tensor of leaf indices (extension: no D2H of the selected row)
+  step_wait()        -> (obs on device, reward float32 [N,1] on CPU, done numpy bool [N],
+                         infos)                                         (envs.py:178-182)
+  step(a), close(), num_envs, observation_space, action_space, reset_specific(ids)
+
+Auto-reset: a finished env is reset inside the step; its observation is the reset
+observation while reward/done/info are the terminal step's (shmem_vec_env.py:139-143).
+`infos[i]` is `{'counter': n}` or, for a finished env, `{'counter','ratio','reward',
+'episode': {'r','l','t'}}` (bin3D.py:163-164,186-187; wrapper/monitor.py:64-75); the
+dicts are built lazily so that 65k envs do not cost 65k Python dicts per step.
+
+Ownership: the returned `obs` tensor is the handle's output buffer -- valid until the next
+step_wait()/reset(); the reference trainer copies it into its rollout storage right away
+(storage.py:33-38).
+
+Errors: what the reference raises inside a worker process (IndexError on holder overflow,
+ValueError on a malformed action) is recorded per env in sticky device flags; step_wait()
+raises `PctEnvError` when any flag is set (strict=True, default) or exposes them as
+`error_flags`.
+"""
+import ctypes
+import time
+from abc import ABC, abstractmethod
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class PctEnvError(RuntimeError):
+    pass
+
+
+class Box(object):
+    """Minimal stand-in for gym.spaces.Box (bin3D.py:41-42)."""
+
+    def __init__(self, low, high, shape, dtype=np.float32):
+        self.low, self.high, self.shape, self.dtype = low, high, tuple(shape), np.dtype(dtype)
+
+
+class VecEnv(ABC):
+    """Same abstract surface as wrapper/vec_env.py:29-108."""
+    closed = False
+    viewer = None
+    metadata = {"render.modes": ["human", "rgb_array"]}
+
+    def __init__(self, num_envs, observation_space, action_space):
+        self.num_envs = num_envs
+        self.observation_space = observation_space
+        self.action_space = action_space
+
+    @abstractmethod
+    def reset(self):
+        pass
+
+    @abstractmethod
+    def step_async(self, actions):
+        pass
+
+    @abstractmethod
+    def policy_hash_rows(self, out=None):
+        """Stand-in policy as its own kernel: float32 [N,9] leaf rows on the device."""
+        if out is None:
+            out = torch.empty(self.N, 9, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self._dev_index):
+            _lib.check(self._L.pct_policy_hash_rows(self._h, out.data_ptr(), self._stream()))
+        return out
+
+    def step_rows_device(self, rows):
+        """Enqueue one step from device-resident float32 [N,9|6|3] rows; no host work."""
+        with torch.cuda.device(self._dev_index):
+            _lib.check(self._L.pct_step_rows(self._h, rows.data_ptr(), rows.shape[1], self._stream()))
+        self.waiting_step = True
+
+    def profile_enable(self, on=True):
+        _lib.check(self._L.pct_profile_enable(self._h, int(bool(on))))
+
+    def profile_read(self):
+        """(launches, total_ms) of the transition kernels since the last read (HIP events
+        recorded by the library on the launch stream)."""
+        n, ms = ctypes.c_int64(), ctypes.c_double()
+        _lib.check(self._L.pct_profile_read(self._h, ctypes.byref(n), ctypes.byref(ms)))
+        return n.value, ms.value
+
+    def step_wait(self):
+        pass
+
+    def close_extras(self):
+        pass
+
+    def close(self):
+        if self.closed:
+            return
+        self.close_extras()
+        self.closed = True
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    @property
+    def unwrapped(self):
+        return self
+
+
+class LazyInfos(object):
+    """Sequence of per-env info dicts, materialised on access."""
+
+    def __init__(self, counter, ratio, done, ep_r, ep_l, ep_t):
+        self._c, self._ratio, self._d = counter, ratio, done
+        self._r, self._l, self._t = ep_r, ep_l, ep_t
+
+    def __len__(self):
+        return len(self._c)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        if not self._d[i]:
+            return {"counter": int(self._c[i])}
+        ratio = float(self._ratio[i])
+        info = {"counter": int(self._c[i]), "ratio": ratio, "reward": ratio * 10}
+        if self._r is not None:
+            info["episode"] = {"r": round(float(self._r[i]), 6), "l": int(self._l[i]), "t": round(float(self._t), 6)}
+        return info
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+
+_LNES = {"EMS": _lib.LNES_EMS, "CP": _lib.LNES_CP}
+
+
+class PctVecEnv(VecEnv):
+    """N independent PCT packing envs on one GPU behind the reference VecEnv surface."""
+
+    def __init__(self, num_envs, setting=2, container_size=(10, 10, 10), item_set=None, data_name=None,
+                 load_test_data=False, internal_node_holder=80, leaf_node_holder=50, LNES="EMS", shuffle=False,
+                 sample_from_distribution=False, sample_left_bound=None, sample_right_bound=None,
+                 device="cuda:0", seed=0, env_id_base=0, item_stream=None, continuous=False, monitor=True,
+                 strict=True, ems_capacity=0, candidate_capacity=0):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise PctEnvError("PctVecEnv runs on an AMD GPU only (device=%r); there is no CPU path" % (device,))
+        if not torch.cuda.is_available():
+            raise PctEnvError("no GPU visible to PyTorch-ROCm: the env hot path has no CPU fallback")
+        if shuffle:
+            raise NotImplementedError("shuffle=True (np.random.shuffle of the candidates, bin3D.py:114-115) "
+                                      "is not available yet; construct with shuffle=False")
+        if load_test_data or data_name is not None:
+            raise NotImplementedError("dataset trajectories: pass them as item_stream=[N,T,3]")
+        if continuous or sample_from_distribution:
+            raise NotImplementedError("the continuous env is not built yet")
+        if LNES not in _LNES:
+            raise NotImplementedError("LNES=%r" % (LNES,))
+        self._L = _lib.load()
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self._dev_index = dev_index
+        cfg = _lib.PctConfig()
+        cfg.struct_size = ctypes.sizeof(_lib.PctConfig)
+        cfg.env_kind = _lib.ENV_DISCRETE
+        cfg.setting = int(setting)
+        cfg.num_envs = int(num_envs)
+        cfg.container[:] = [int(c) for c in container_size]
+        cfg.internal_node_holder = int(internal_node_holder)
+        cfg.leaf_node_holder = int(leaf_node_holder)
+        cfg.lnes = _LNES[LNES]
+        cfg.env_id_base = int(env_id_base)
+        cfg.ems_capacity = int(ems_capacity)
+        cfg.candidate_capacity = int(candidate_capacity)
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(dev_index):
+            torch.cuda.init()
+            _lib.check(self._L.pct_create(ctypes.byref(cfg), dev_index, ctypes.byref(self._h)))
+        self.cfg = cfg
+        self.N, self.I, self.Lh = int(num_envs), int(internal_node_holder), int(leaf_node_holder)
+        self.row_len = (self.I + self.Lh + 1) * 9
+        self.bin_size = tuple(int(c) for c in container_size)
+        self.setting = int(setting)
+        self.env_id_base = int(env_id_base)
+        self.strict = strict
+
+        if item_set is None:
+            raise ValueError("item_set is required (givenData.py:10-14)")
+        items = np.ascontiguousarray(np.asarray(item_set, dtype=np.int32).reshape(-1, 3))
+        _lib.check(self._L.pct_set_item_set(self._h, items.ctypes.data, items.shape[0]))
+        self.item_set = items
+        if item_stream is not None:
+            self.set_item_stream(item_stream)
+        else:
+            _lib.check(self._L.pct_set_sampler(self._h, int(seed)))
+
+        # outputs live in torch tensors bound into the handle (zero copy)
+        dev = self.device
+        self._obs = torch.zeros(self.N, self.row_len, dtype=torch.float32, device=dev)
+        self._reward = torch.zeros(self.N, dtype=torch.float32, device=dev)
+        self._done = torch.zeros(self.N, dtype=torch.uint8, device=dev)
+        self._counter = torch.zeros(self.N, dtype=torch.int32, device=dev)
+        self._ratio = torch.zeros(self.N, dtype=torch.float64, device=dev)
+        self._flags = torch.zeros(self.N, dtype=torch.int32, device=dev)
+        _lib.check(self._L.pct_bind_outputs(self._h, self._obs.data_ptr(), self._reward.data_ptr(),
+                                            self._done.data_ptr(), self._counter.data_ptr(), self._ratio.data_ptr(),
+                                            self._flags.data_ptr()))
+        # pinned host mirrors for the small per-step outputs
+        self._h_reward = torch.zeros(self.N, dtype=torch.float32).pin_memory()
+        self._h_done = torch.zeros(self.N, dtype=torch.uint8).pin_memory()
+        self._h_counter = torch.zeros(self.N, dtype=torch.int32).pin_memory()
+        self._h_ratio = torch.zeros(self.N, dtype=torch.float64).pin_memory()
+        self._h_flags = torch.zeros(self.N, dtype=torch.int32).pin_memory()
+        self._actions_keepalive = None
+        self.waiting_step = False
+
+        # Monitor emulation (wrapper/monitor.py:51-77)
+        self._monitor = monitor
+        self._ep_r = np.zeros(self.N, np.float64)
+        self._ep_l = np.zeros(self.N, np.int64)
+        self._tstart = time.time()
+
+        obs_space = Box(low=0.0, high=float(self.bin_size[2]), shape=(self.row_len,))
+        VecEnv.__init__(self, self.N, obs_space, None)
+
+    # ------------------------------------------------------------------ item sources
+    def set_item_stream(self, items):
+        items = np.ascontiguousarray(np.asarray(items, dtype=np.int32))
+        if items.ndim != 3 or items.shape[0] != self.N or items.shape[2] != 3:
+            raise ValueError("item_stream must be int [num_envs, T, 3]")
+        _lib.check(self._L.pct_set_item_stream(self._h, items.ctypes.data, items.shape[1]))
+
+    def set_sampler(self, seed):
+        _lib.check(self._L.pct_set_sampler(self._h, int(seed)))
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    @property
+    def error_flags(self):
+        """Sticky per-env PCT_FLAG_* bits (synchronises the stream)."""
+        return self._flags.cpu().numpy().view(np.uint32)
+
+    # ------------------------------------------------------------------ VecEnv surface
+    def reset(self):
+        with torch.cuda.device(self._dev_index):
+            _lib.check(self._L.pct_reset(self._h, None, 0, self._stream()))
+        self.waiting_step = False
+        self._ep_r[:] = 0
+        self._ep_l[:] = 0
+        return self._obs
+
+    def reset_specific(self, indexs):
+        ids = torch.as_tensor(np.asarray(indexs, dtype=np.int32), device=self.device)
+        with torch.cuda.device(self._dev_index):
+            _lib.check(self._L.pct_reset(self._h, ids.data_ptr(), ids.numel(), self._stream()))
+        self._ids_keepalive = ids
+        idx = np.asarray(indexs, dtype=np.int64)
+        self._ep_r[idx] = 0
+        self._ep_l[idx] = 0
+        return self._obs[ids.long()]
+
+    def step_async(self, actions):
+        if isinstance(actions, np.ndarray):
+            actions = torch.from_numpy(actions)
+        if not torch.is_tensor(actions):
+            actions = torch.as_tensor(np.asarray(actions))
+        if actions.shape[0] != self.N:  # shmem_vec_env.py:71
+            raise AssertionError("expected %d actions, got %d" % (self.N, actions.shape[0]))
+        with torch.cuda.device(self._dev_index):
+            if actions.dtype in (torch.int64, torch.int32) and (actions.dim() == 1 or actions.shape[-1] == 1):
+                idx = actions.reshape(self.N).to(device=self.device, dtype=torch.int64).contiguous()
+                self._actions_keepalive = idx
+                _lib.check(self._L.pct_step_index(self._h, idx.data_ptr(), self._stream()))
+            else:
+                rows = actions.to(device=self.device, dtype=torch.float32).contiguous()
+                if rows.dim() != 2 or rows.shape[1] not in (9, 6, 3):
+                    raise ValueError("actions must be [N,9], [N,6] or [N,3] leaf rows, or [N] leaf indices")
+                self._actions_keepalive = rows
+                _lib.check(self._L.pct_step_rows(self._h, rows.data_ptr(), rows.shape[1], self._stream()))
+        self.waiting_step = True
+
+    def step_hash_policy(self, n_steps=1):
+        """n_steps transitions with the on-device stand-in policy (benchmarks / parity)."""
+        with torch.cuda.device(self._dev_index):
+            _lib.check(self._L.pct_step_hash_policy(self._h, int(n_steps), self._stream()))
+        self.waiting_step = True
+
+    def policy_hash_rows(self, out=None):
+        """Stand-in policy as its own kernel: float32 [N,9] leaf rows on the device."""
+        if out is None:
+            out = torch.empty(self.N, 9, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self._dev_index):
+            _lib.check(self._L.pct_policy_hash_rows(self._h, out.data_ptr(), self._stream()))
+        return out
+
+    def step_rows_device(self, rows):
+        """Enqueue one step from device-resident float32 [N,9|6|3] rows; no host work."""
+        with torch.cuda.device(self._dev_index):
+            _lib.check(self._L.pct_step_rows(self._h, rows.data_ptr(), rows.shape[1], self._stream()))
+        self.waiting_step = True
+
+    def profile_enable(self, on=True):
+        _lib.check(self._L.pct_profile_enable(self._h, int(bool(on))))
+
+    def profile_read(self):
+        """(launches, total_ms) of the transition kernels since the last read (HIP events
+        recorded by the library on the launch stream)."""
+        n, ms = ctypes.c_int64(), ctypes.c_double()
+        _lib.check(self._L.pct_profile_read(self._h, ctypes.byref(n), ctypes.byref(ms)))
+        return n.value, ms.value
+
+    def step_wait(self):
+        # one small async D2H per output, then a single stream sync (envs.py:178-182)
+        self._h_reward.copy_(self._reward, non_blocking=True)
+        self._h_done.copy_(self._done, non_blocking=True)
+        self._h_counter.copy_(self._counter, non_blocking=True)
+        self._h_ratio.copy_(self._ratio, non_blocking=True)
+        self._h_flags.copy_(self._flags, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        self.waiting_step = False
+        reward = self._h_reward.clone().unsqueeze(1)
+        done = self._h_done.numpy().astype(bool)
+        counter = self._h_counter.numpy().copy()
+        ratio = self._h_ratio.numpy().copy()
+        if self.strict:
+            f = self._h_flags.numpy().view(np.uint32)
+            if f.any():
+                bad = int(np.nonzero(f)[0][0])
+                raise PctEnvError("env %d raised error flags 0x%x (include/pct_env.h PCT_FLAG_*)" % (bad, int(f[bad])))
+        ep_r = ep_l = None
+        if self._monitor:
+            self._ep_r += reward[:, 0].numpy()
+            self._ep_l += 1
+            ep_r, ep_l = self._ep_r.copy(), self._ep_l.copy()
+            self._ep_r[done] = 0
+            self._ep_l[done] = 0
+        infos = LazyInfos(counter, ratio, done, ep_r, ep_l, time.time() - self._tstart)
+        return self._obs, reward, done, infos
+
+    def debug_state(self, e, cap_ems=1024):
+        A = max(self.bin_size[0], self.bin_size[1])
+        hm = np.zeros(A * A, np.int32)
+        ems = np.zeros((cap_ems, 6), np.int32)
+        n_ems, n_boxes, cur = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64()
+        nxt = np.zeros(3, np.int32)
+        _lib.check(self._L.pct_debug_state(self._h, int(e), hm.ctypes.data, ems.ctypes.data, cap_ems,
+                                           ctypes.byref(n_ems), ctypes.byref(n_boxes), nxt.ctypes.data,
+                                           ctypes.byref(cur)))
+        return dict(heightmap=hm.reshape(A, A), ems=ems[:n_ems.value].copy(), n_boxes=n_boxes.value,
+                    next_item=nxt, cursor=cur.value)
+
+    def close_extras(self):
+        if self._h:
+            torch.cuda.synchronize(self.device)
+            self._L.pct_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def make_vec_envs(args, log_dir=None, allow_early_resets=True):
+    """Drop-in for envs.make_vec_envs (envs.py:75-116): same `args` namespace
+    (tools.py:130-198), returns the object the trainer steps (train_tools.py:39,67)."""
+    kind = str(getattr(args, "id", "PctDiscrete-v0"))
+    return PctVecEnv(
+        num_envs=args.num_processes,
+        setting=args.setting,
+        container_size=args.container_size,
+        item_set=args.item_size_set,
+        data_name=getattr(args, "dataset_path", None) if getattr(args, "load_dataset", False) else None,
+        load_test_data=getattr(args, "load_dataset", False),
+        internal_node_holder=args.internal_node_holder,
+        leaf_node_holder=args.leaf_node_holder,
+        LNES=getattr(args, "lnes", "EMS"),
+        shuffle=getattr(args, "shuffle", False),
+        sample_from_distribution=getattr(args, "sample_from_distribution", False),
+        sample_left_bound=getattr(args, "sample_left_bound", None),
+        sample_right_bound=getattr(args, "sample_right_bound", None),
+        device=getattr(args, "device", "cuda:0"),
+        seed=getattr(args, "seed", 0),
+        continuous=kind.startswith("PctContinuous"),
+    )

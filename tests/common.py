@@ -1,0 +1,57 @@
+"""Shared helpers for the parity tests (host-side stand-in policy, fixtures, item sets)."""
+import ast
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+M32 = 0xFFFFFFFF
+
+
+def mix32(g, t):
+    """include/pct_env.h pct_mix32 (vectorised over numpy uint64 arrays)."""
+    g = np.asarray(g, dtype=np.uint64)
+    t = np.asarray(t, dtype=np.uint64)
+    h = (g * np.uint64(0x9E3779B1) + t * np.uint64(0x85EBCA77) + np.uint64(0xC2B2AE3D)) & np.uint64(M32)
+    h ^= h >> np.uint64(16)
+    h = (h * np.uint64(0x7FEB352D)) & np.uint64(M32)
+    h ^= h >> np.uint64(15)
+    h = (h * np.uint64(0x846CA68B)) & np.uint64(M32)
+    h ^= h >> np.uint64(16)
+    return h
+
+
+def item_set_range(lo, hi):
+    return [(i, j, k) for i in range(lo, hi + 1) for j in range(lo, hi + 1) for k in range(lo, hi + 1)]
+
+
+def make_stream(seed, n_envs, T, item_set):
+    rng = np.random.RandomState(seed)
+    items = np.asarray(item_set, dtype=np.int32)
+    return items[rng.randint(0, len(items), size=(n_envs, T))]
+
+
+def load_case(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    meta = ast.literal_eval(str(z["meta"]))
+    return meta, z
+
+
+def hash_policy_index(obs, I, L, base, t_vec):
+    """leaf index per env from a [N,row_len] observation: mix32(g, t) % k, 0 if k == 0."""
+    obs = np.asarray(obs)
+    N = obs.shape[0]
+    leaf = obs.reshape(N, -1, 9)[:, I:I + L]
+    k = (leaf[:, :, 8] != 0).sum(1).astype(np.uint64)
+    g = np.arange(N, dtype=np.uint64) + np.uint64(base)
+    h = mix32(g, t_vec)
+    return np.where(k > 0, h % np.maximum(k, np.uint64(1)), np.uint64(0)).astype(np.int64)
+
+
+def gather_rows(obs, I, idx):
+    obs = np.asarray(obs)
+    N = obs.shape[0]
+    return obs.reshape(N, -1, 9)[np.arange(N), I + idx].copy()
+
+
+GOLDEN_CASES = ["discrete_s2_10_80_50", "discrete_s2_rect_60_30", "discrete_s2_10_80_5", "discrete_s2_20_120_400"]

@@ -1,0 +1,134 @@
+"""CPU: the oracle (oracle/pct_oracle.c) against the committed reference fixtures.
+
+The fixtures were produced by tests/golden/gen_golden.py from the UNMODIFIED Python
+reference; they are what pins the oracle (and through it the HIP path) to the reference on
+a box where /root/reference does not exist."""
+import hashlib
+import random
+
+import numpy as np
+import pytest
+
+from oracle.oracle_lib import OracleVecEnv, pyset_order
+from tests.common import GOLDEN_CASES, gather_rows, hash_policy_index, item_set_range, load_case, GOLDEN
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_oracle_matches_reference_fixture_fused_policy(name):
+    c, z = load_case(name)
+    env = OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"],
+                       item_set=item_set_range(c["lo"], c["hi"]), internal_node_holder=c["I"],
+                       leaf_node_holder=c["L"], env_id_base=c["base"])
+    env.set_item_stream(z["stream"])
+    env.reset()
+    for t in range(c["steps"]):
+        assert np.array_equal(env.obs.astype(np.float32), z["obs"][t]), (name, t)
+        env.step_hash_policy(1)
+        assert np.array_equal(env.reward, z["reward"][t])
+        assert np.array_equal(env.done, z["done"][t])
+        assert np.array_equal(env.counter, z["counter"][t])
+        assert np.array_equal(env.ratio * (env.done != 0), z["ratio"][t])
+    assert np.array_equal(env.obs.astype(np.float32), z["obs"][c["steps"]])
+    assert not env.flags.any()
+
+
+@pytest.mark.parametrize("mode", ["rows9", "rows6", "index"])
+def test_oracle_action_forms_agree(mode):
+    """9-vector rows (trainer), 6-vector rows (evaluation_tools.py:24) and leaf indices all
+    reproduce the fixture."""
+    name = "discrete_s2_rect_60_30"
+    c, z = load_case(name)
+    env = OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"],
+                       item_set=item_set_range(c["lo"], c["hi"]), internal_node_holder=c["I"],
+                       leaf_node_holder=c["L"], env_id_base=c["base"])
+    env.set_item_stream(z["stream"])
+    env.reset()
+    for t in range(c["steps"]):
+        obs32 = env.obs.astype(np.float32)
+        assert np.array_equal(obs32, z["obs"][t])
+        idx = hash_policy_index(obs32, c["I"], c["L"], c["base"], np.full(c["N"], t, np.uint64))
+        if mode == "index":
+            env.step_index(idx)
+        else:
+            rows = gather_rows(obs32, c["I"], idx)
+            env.step_rows(rows[:, :6] if mode == "rows6" else rows)
+        assert np.array_equal(env.done, z["done"][t])
+        assert np.array_equal(env.reward, z["reward"][t])
+
+
+def test_oracle_three_vector_action_form():
+    """(flag, lx, ly) heuristic form (bin3D.py:152-153): flag swaps x and y of the raw item."""
+    items = np.array([[[2, 3, 4], [5, 1, 2], [1, 1, 1]]], np.int32)
+    env = OracleVecEnv(1, setting=2, container_size=(10, 10, 10), item_set=item_set_range(1, 5))
+    env.set_item_stream(items)
+    env.reset()
+    env.step_rows(np.array([[1.0, 0.0, 0.0]]))  # rotated: x=3, y=2
+    row0 = env.obs[0].reshape(-1, 9)[0]
+    assert list(row0[:6]) == [0, 0, 0, 3, 2, 4] and row0[6] == 1 and row0[8] == 1
+    assert env.reward[0] == pytest.approx(10 * 24 / 1000) and env.done[0] == 0 and env.counter[0] == 1
+    env.step_rows(np.array([[0.0, 8.0, 8.0]]))  # 5 wide at x=8 leaves the bin -> episode ends
+    assert env.done[0] == 1 and env.reward[0] == 0 and env.counter[0] == 1
+    assert env.ratio[0] == pytest.approx(24 / 1000)
+
+
+def test_known_answer_hash_replay():
+    """sha256[:16] of 500 float32 observations of the reference under
+    env.seed(4) / RandomState(0) policy = e882162eebfb9734; the recorded item draws and
+    actions are replayed through the oracle."""
+    z = np.load(GOLDEN + "/kat_discrete_s2.npz")
+    env = OracleVecEnv(1, setting=2, container_size=(10, 10, 10), item_set=item_set_range(1, 5))
+    env.set_item_stream(z["items"][None])
+    env.reset()
+    h = hashlib.sha256()
+    for t in range(500):
+        h.update(env.obs[0].astype(np.float32).tobytes())
+        env.step_rows(z["actions"][t][None].astype(np.float64))
+    assert h.hexdigest()[:16] == str(z["sha256_16"]) == "e882162eebfb9734"
+
+
+def test_pyset_order_matches_this_cpython():
+    """The emulated set iteration order against the interpreter's own `set` (CPython 3.10
+    is what the reference was probed under; the algorithm is unchanged 3.7-3.12)."""
+    rnd = random.Random(5)
+    for trial in range(300):
+        n = rnd.choice([1, 4, 6, 19, 20, 77, 78, 300, 310, 1229, 1500])
+        hi = rnd.randint(2, 12)
+        keys = [tuple(rnd.randint(0, hi) for _ in range(6)) for _ in range(n)]
+        s = set()
+        for k in keys:
+            s.add(k)
+        order = pyset_order(np.array(keys, np.int64))
+        assert [keys[i] for i in order] == list(s)
+
+
+def test_reset_specific_and_sampler_determinism():
+    a = OracleVecEnv(6, item_set=item_set_range(1, 5), env_id_base=10)
+    b = OracleVecEnv(6, item_set=item_set_range(1, 5), env_id_base=10)
+    a.set_sampler(99)
+    b.set_sampler(99)
+    a.reset()
+    b.reset()
+    for _ in range(40):
+        a.step_hash_policy(1)
+        b.step_hash_policy(1)
+    assert np.array_equal(a.obs, b.obs)
+    before = a.obs.copy()
+    a.reset(env_ids=[1, 4])
+    changed = [e for e in range(6) if not np.array_equal(before[e], a.obs[e])]
+    assert set(changed) <= {1, 4}
+    for e in (1, 4):
+        st = a.debug_state(e)
+        assert st["n_boxes"] == 0 and len(st["ems"]) == 1 and st["heightmap"].sum() == 0
+
+
+def test_edge_cases_zero_row_and_bad_action():
+    env = OracleVecEnv(2, item_set=item_set_range(1, 5))
+    env.set_item_stream(np.array([[[5, 5, 5]], [[2, 3, 4]]], np.int32))
+    env.reset()
+    # env 0: all-zero row -> (0,0,0) + unrotated item (bin3D.py:140): succeeds in an empty bin
+    # env 1: extents that are not a permutation of the item -> ValueError in the reference
+    rows = np.zeros((2, 9))
+    rows[1, :6] = [0, 0, 0, 7, 7, 10]
+    env.step_rows(rows)
+    assert env.done[0] == 0 and env.counter[0] == 1
+    assert env.done[1] == 1 and env.flags[1] == 8
