@@ -170,6 +170,12 @@ int pct_debug_state(pct_env* env, int32_t local_id, int32_t* heightmap, int32_t*
                     int64_t* draw_cursor);
 
 /* ---- shared arithmetic: part of the ABI, used identically on host and device -------- */
+/* Per-phase cycle accounting of the transition kernel (profiling aid).  on != 0: (re)start
+ * accumulation; host_out, if non-NULL, first receives the accumulators gathered so far:
+ * uint64 [N,8] = s_memtime cycles in {load, drop_box, GENEMS, candidate set, feasibility,
+ * observation write, state store} and the number of steps.  Synchronises the device. */
+int pct_debug_phase_timing(pct_env* env, int32_t on, uint64_t* host_out);
+
 #if defined(__HIPCC__)
 #define PCT_INLINE static inline __host__ __device__
 #else

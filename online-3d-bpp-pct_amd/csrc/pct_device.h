@@ -33,6 +33,7 @@ struct DiscreteParams {
   void* leaves;     /* [N,L] packed current leaf nodes */
   int32_t* scalars; /* [N,PCT_SCALARS]: n_ems,n_boxes,n_leaf,item[3],t,-,cursor lo/hi,vol lo/hi */
   uint32_t* flags;  /* [N] sticky PCT_FLAG_* */
+  unsigned long long* timing; /* [N,8] per-phase cycle accumulators, or null */
   // outputs
   float* obs;       /* [N,row_len] */
   float* reward;    /* [N] */

@@ -27,8 +27,8 @@
 namespace pct {
 
 // ----------------------------------------------------------------------------------------
-// packed boxes: six coordinates, BITS bits each, in one key word.  Key 0 is never a valid
-// candidate (a candidate has positive extents), so 0 marks an empty hash-table slot.
+// packed boxes: six coordinates, BITS bits each, in one key word; the top bits stay clear
+// (30 of 32 / 60 of 64 bits used), which the hash-table slot encoding relies on.
 // ----------------------------------------------------------------------------------------
 template <typename K, int BITS>
 struct Pack {
@@ -96,81 +96,151 @@ __device__ inline uint64_t tuplehash6(K key) {
   return acc;
 }
 
-// Per-lane read-only probe (set_add_entry's search, without the insertion).
+// ----------------------------------------------------------------------------------------
+// CPython set emulation, wave-parallel and exact.
+//
+// Slot words: EMPTY (all ones) | a key (tag bit clear) | TAG|lane (tentative holder, only
+// while a batch is being matched).  Sequential set.add of keys k0,k1,.. (each takes the first
+// free slot on its own probe path: LINEAR_PROBES 9, PERTURB_SHIFT 5) is a serial
+// dictatorship; because every slot ranks keys by the same priority (insertion order) its
+// outcome is the unique stable matching, which the lanes reach in parallel by proposing
+// along their paths with atomicMin on TAG|lane: a lower lane evicts a higher one, the
+// evicted lane walks on.  A slot a lane has walked past stays held by a higher-priority key
+// for ever, so the fixed point equals the sequential result, slot for slot.
+// ----------------------------------------------------------------------------------------
 template <typename K>
-__device__ inline bool pyset_lookup(const K* tab, uint32_t mask, K key, uint64_t hash) {
-  uint64_t perturb = hash;
-  uint32_t i = (uint32_t)hash & mask;
-  while (true) {
-    uint32_t e = i;
-    int probes = (i + 9u <= mask) ? 9 : 0;
-    do {
-      K cur = tab[e];
-      if (cur == 0) return false;
-      if (cur == key) return true;
-      e++;
-    } while (probes--);
-    perturb >>= 5;
-    i = (i * 5u + 1u + (uint32_t)perturb) & mask;
-  }
+struct SlotWord;
+template <>
+struct SlotWord<uint32_t> {
+  static constexpr uint32_t EMPTY = 0xFFFFFFFFu, TAG = 0x80000000u;
+};
+template <>
+struct SlotWord<uint64_t> {
+  static constexpr uint64_t EMPTY = ~0ull, TAG = 1ull << 63;
+};
+__device__ inline uint32_t lds_atomic_min(uint32_t* p, uint32_t v) { return atomicMin(p, v); }
+__device__ inline uint64_t lds_atomic_min(uint64_t* p, uint64_t v) {
+  return (uint64_t)atomicMin(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v);
 }
-// Wave-uniform insertion (every lane runs the same probe sequence on the same key).
-// Returns true if the key was new.
-template <typename K>
-__device__ inline bool pyset_insert_uniform(K* tab, uint32_t mask, K key, uint64_t hash) {
-  uint64_t perturb = hash;
-  uint32_t i = (uint32_t)hash & mask;
-  while (true) {
-    uint32_t e = i;
-    int probes = (i + 9u <= mask) ? 9 : 0;
-    do {
-      K cur = uniform_key<K>(tab[e]);
-      if (cur == 0) {
-        tab[e] = key;
-        return true;
-      }
-      if (cur == key) return false;
-      e++;
-    } while (probes--);
-    perturb >>= 5;
-    i = (i * 5u + 1u + (uint32_t)perturb) & mask;
+
+#define PCT_PEND_SLOTS 128
+struct Walk {  // position on a key's probe path: slot = i + j
+  uint32_t i;
+  int j;
+  uint64_t perturb;
+  __device__ inline void start(uint64_t hash, uint32_t mask) {
+    perturb = hash;
+    i = (uint32_t)hash & mask;
+    j = 0;
   }
-}
-// set_insert_clean: the key is known to be absent, the table has no dummies.
-template <typename K>
-__device__ inline void pyset_insert_clean_uniform(K* tab, uint32_t mask, K key, uint64_t hash) {
-  uint64_t perturb = hash;
-  uint32_t i = (uint32_t)hash & mask;
-  while (true) {
-    uint32_t e = i;
-    if (uniform_key<K>(tab[e]) == 0) {
-      tab[e] = key;
-      return;
+  __device__ inline void next(uint32_t mask) {
+    int probes = (i + 9u <= mask) ? 9 : 0;
+    if (j < probes) {
+      j++;
+    } else {
+      perturb >>= 5;
+      i = (i * 5u + 1u + (uint32_t)perturb) & mask;
+      j = 0;
     }
-    if (i + 9u <= mask) {
-      for (int j = 0; j < 9; j++) {
-        e++;
-        if (uniform_key<K>(tab[e]) == 0) {
-          tab[e] = key;
-          return;
+  }
+};
+
+// Read-only membership test (no tags may be present).
+template <typename K>
+__device__ inline bool pyset_contains(const K* tab, uint32_t mask, K key, uint64_t hash) {
+  Walk w;
+  w.start(hash, mask);
+  while (true) {
+    K cur = tab[w.i + w.j];
+    if (cur == SlotWord<K>::EMPTY) return false;
+    if (cur == key) return true;
+    w.next(mask);
+  }
+}
+
+// Matches the participating lanes' keys into the table in lane-priority order.  The
+// participating keys must be pairwise distinct (the caller de-duplicates a batch first: two
+// equal keys can overtake one another on their common path, distinct keys cannot matter to
+// each other except through the slots they hold).  On return a lane with `placed` holds
+// TAG|lane in tab[slot]; a participating lane that is not placed found its key already in the
+// table (check_found).  All 64 lanes must call.
+template <typename K>
+__device__ inline void pyset_match(K* tab, uint32_t mask, bool part, K key, uint64_t hash, int lane,
+                                   bool check_found, bool& placed, uint32_t& slot) {
+  const K TAG = SlotWord<K>::TAG;
+  const K mytag = TAG | (K)lane;
+  Walk w;
+  w.start(hash, mask);
+  bool walking = part;
+  placed = false;
+  slot = 0;
+  while (true) {
+    while (walking) {
+      uint32_t cur = w.i + w.j;
+      K v = tab[cur];
+      if ((v & TAG) && v > mytag) {  // empty, or tentatively held by a later lane
+        K old = lds_atomic_min(&tab[cur], mytag);
+        if (old > mytag) {
+          slot = cur;
+          placed = true;
+          walking = false;
         }
+      } else if (check_found && v == key) {
+        walking = false;  // already a member
+      } else {
+        w.next(mask);  // a different key, or an earlier lane's tentative hold
       }
     }
-    perturb >>= 5;
-    i = (i * 5u + 1u + (uint32_t)perturb) & mask;
+    __syncthreads();
+    if (placed && tab[slot] != mytag) {  // evicted by an earlier lane: walk on
+      placed = false;
+      walking = true;
+      w.next(mask);
+    }
+    if (!__ballot(walking)) break;
   }
 }
 
 // Which LDS region holds a table of `size` slots (ping-pong so that a resize can stream
 // old -> new without a temporary): cap in region 0, cap/4 in region 1, cap/16 in 0, ...
-__device__ inline int table_region(uint32_t cap, uint32_t size) {
+// Returned as a slot OFFSET from tab0 (tab1 follows tab0 in LDS) so that every table access
+// stays a plain LDS access off one base pointer.
+__device__ inline uint32_t table_region(uint32_t cap, uint32_t size) {
   int lv = 0;
   while (size < cap) {
     size <<= 2;
     lv++;
   }
-  return lv & 1;
+  return (lv & 1) ? cap : 0u;
 }
+
+// optional per-phase cycle accounting (pct_debug_phase_timing): s_memtime deltas per env.
+// The untimed specialisation is empty, so production kernels carry no extra registers.
+template <bool ON>
+struct PhaseTimer {
+  __device__ inline void start() {}
+  __device__ inline void tick(int) {}
+  __device__ inline void flush(unsigned long long*, int) {}
+};
+template <>
+struct PhaseTimer<true> {
+  uint64_t last;
+  uint64_t acc[8];
+  __device__ inline void start() {
+    for (int i = 0; i < 8; i++) acc[i] = 0;
+    last = __builtin_readcyclecounter();
+  }
+  __device__ inline void tick(int i) {
+    uint64_t now = __builtin_readcyclecounter();
+    acc[i] += now - last;
+    last = now;
+  }
+  __device__ inline void flush(unsigned long long* o, int n_steps) {
+    for (int i = 0; i < 7; i++) o[i] += acc[i];
+    o[7] += (unsigned long long)n_steps;
+  }
+};
+enum { PH_LOAD = 0, PH_DROP = 1, PH_GENEMS = 2, PH_SET = 3, PH_FEAS = 4, PH_OBS = 5, PH_STORE = 6, PH_STEPS = 7 };
 
 struct EnvRegs {  // wave-uniform per-env scalars
   int n_ems, n_boxes, n_leaf;
@@ -190,6 +260,7 @@ struct Lds {
   K* box;
   K* leaf;
   int16_t* hmap;
+  uint16_t* vp; /* [64] valid (ems, rotation) pairs of the current chunk */
 };
 
 template <typename K, int BITS>
@@ -203,6 +274,7 @@ __device__ inline Lds<K, BITS> carve_lds(const DiscreteParams& p, unsigned char*
   l.box = q; q += p.I;
   l.leaf = q; q += p.L;
   l.hmap = reinterpret_cast<int16_t*>(q);
+  l.vp = reinterpret_cast<uint16_t*>(l.hmap + p.AA);
   return l;
 }
 
@@ -292,9 +364,14 @@ __device__ inline void genems(const DiscreteParams& p, Lds<K, BITS>& l, EnvRegs&
   }
   if (overflow) r.flags |= PCT_FLAG_EMS_OVERFLOW;
   __syncthreads();
-  // elimination: i is deleted iff some j != i contains it (non-strict, pre-deletion list)
-  int out = 0;
-  for (int base = 0; base < n; base += 64) {
+  // elimination: i is deleted iff some j != i contains it (non-strict, pre-deletion list).
+  // The list before GENEMS is containment-free (it is the output of the previous
+  // elimination, or the single initial EMS), and a child is a subset of its intersected
+  // parent, so a survivor can neither lie inside a child nor equal one: only children can be
+  // deleted.  Survivors are copied, children are tested against the whole list.
+  for (int i = lane; i < (S < n ? S : n); i += 64) l.ems_a[i] = l.ems_b[i];
+  int out = S < n ? S : n;
+  for (int base = out; base < n; base += 64) {
     int i = base + lane;
     bool live = i < n;
     K k = live ? l.ems_b[i] : (K)0;
@@ -319,95 +396,147 @@ __device__ inline void genems(const DiscreteParams& p, Lds<K, BITS>& l, EnvRegs&
 
 // D/space.py:534-570 EMSPoint (CPython-set order) + D/bin3D.py:100-136
 // get_possible_position: fills l.leaf[0..n_leaf) with the first <= L feasible candidates.
-template <typename K, int BITS>
-__device__ inline void leaf_nodes(const DiscreteParams& p, Lds<K, BITS>& l, EnvRegs& r, int lane) {
+template <typename K, int BITS, typename TM>
+__device__ inline void leaf_nodes(const DiscreteParams& p, Lds<K, BITS>& l, EnvRegs& r, int lane, TM& tm) {
   typedef Pack<K, BITS> P;
   const uint64_t lt = lanemask_lt(lane);
   const int E = r.n_ems;
   const int b0 = r.item0, b1 = r.item1, b2 = r.item2;
   const int orient = (p.setting == 2) ? 6 : 2;
-  const int per = orient * 4;
-  const int G = E * per;
+  const int NP = E * orient;  // (EMS, rotation) pairs in set-insertion order
 
   // fresh set: PySet_MINSIZE = 8 slots
+  const K EMPTY = SlotWord<K>::EMPTY;
   uint32_t size = 8, fill = 0;
-  K* tab = table_region(p.cand_cap, size) ? l.tab1 : l.tab0;
-  if (lane < 8) tab[lane] = 0;
+  K* const tabs = l.tab0;  // both table regions, contiguous
+  uint32_t toff = table_region(p.cand_cap, size);
+  // ems_b is free outside GENEMS: the queue of keys waiting for insertion + the batch keys
+  K* pend = l.ems_b;
+  K* bkeys = l.ems_b + PCT_PEND_SLOTS;
+  if (lane < 8) tabs[toff + lane] = EMPTY;
   __syncthreads();
   bool cand_overflow = false;
+  int npend = 0;
 
-  for (int base = 0; base < G && !cand_overflow; base += 64) {
-    int g = base + lane;
-    int ei = g / per;
-    int rem = g - ei * per;
-    int rot = rem >> 2, corner = rem & 3;
-    bool valid = g < G;
-    int sx, sy, sz;
-    bool skip;
-    switch (rot) {  // D/space.py:540-562
-      case 0: sx = b0; sy = b1; sz = b2; skip = false; break;
-      case 1: sx = b1; sy = b0; sz = b2; skip = (sx == sy); break;
-      case 2: sx = b0; sy = b2; sz = b1; skip = (sx == sy && sy == sz); break;
-      case 3: sx = b1; sy = b2; sz = b0; skip = (sx == sy && sy == sz); break;
-      case 4: sx = b2; sy = b0; sz = b1; skip = (sx == sy); break;
-      default: sx = b2; sy = b1; sz = b0; skip = (sx == sy); break;
+  // rotation r of the item (D/space.py:540-562): extents and the skip rule
+  auto rot_size = [&](int rot, int& sx, int& sy, int& sz) -> bool {
+    switch (rot) {
+      case 0: sx = b0; sy = b1; sz = b2; return false;
+      case 1: sx = b1; sy = b0; sz = b2; return sx == sy;
+      case 2: sx = b0; sy = b2; sz = b1; return sx == sy && sy == sz;
+      case 3: sx = b1; sy = b2; sz = b0; return sx == sy && sy == sz;
+      case 4: sx = b2; sy = b0; sz = b1; return sx == sy;
+      default: sx = b2; sy = b1; sz = b0; return sx == sy;
     }
-    K ek = valid ? l.ems_a[ei] : (K)0;
-    int x0 = P::get(ek, 0), y0 = P::get(ek, 1), z0 = P::get(ek, 2), x1 = P::get(ek, 3), y1 = P::get(ek, 4),
-        z1 = P::get(ek, 5);
-    valid = valid && !skip && (x1 - x0 >= sx) && (y1 - y0 >= sy) && (z1 - z0 >= sz);
-    int xs = (corner & 1) ? x1 - sx : x0;
-    int ys = (corner & 2) ? y1 - sy : y0;
-    K key = P::pack(xs, ys, z0, xs + sx, ys + sy, z0 + sz);
+  };
+
+  // insert the first `cnt` (<= 64) queued keys, in queue order, exactly as set.add would
+  auto flush = [&](int cnt) {
+    bool pending = lane < cnt;
+    K key = pending ? pend[lane] : (K)0;
+    K mv = (lane + 64 < npend) ? pend[lane + 64] : (K)0;
+    __syncthreads();
+    if (lane + 64 < npend) pend[lane] = mv;
+    bkeys[lane] = key;
+    npend -= cnt;
+    __syncthreads();
+    // exact in-batch de-duplication: keep the first occurrence (set.add of a present key is a
+    // no-op, and the first occurrence is inserted before the later ones in any case)
+    {
+      bool dup = false;
+      for (int i = 0; i < cnt; i++) dup |= (bkeys[i] == key) & (i < lane);
+      pending = pending && !dup;
+    }
     uint64_t hash = tuplehash6<K, BITS>(key);
-    bool found = valid && pyset_lookup<K>(tab, size - 1, key, hash);
-    uint64_t misses = __ballot(valid && !found);
-    while (misses) {
-      int src = __ffsll((unsigned long long)misses) - 1;
-      misses &= misses - 1;
-      K ukey = bcast_key<K>(key, src);
-      uint64_t uhash = bcast_u64(hash, src);
-      if (pyset_insert_uniform<K>(tab, size - 1, ukey, uhash)) {
-        fill++;
-        if (fill * 5u >= (size - 1) * 3u) {  // set_table_resize(used * 4)
-          uint32_t newsize = 8;
-          while (newsize <= fill * 4u) newsize <<= 1;
-          if (newsize > (uint32_t)p.cand_cap) {
-            cand_overflow = true;
-            break;
-          }
-          K* ntab = table_region(p.cand_cap, newsize) ? l.tab1 : l.tab0;
-          __syncthreads();
-          for (uint32_t s = lane; s < newsize; s += 64) ntab[s] = 0;
-          __syncthreads();
-          for (uint32_t sb = 0; sb < size; sb += 64) {
-            uint32_t s = sb + lane;
-            K ok = (s < size) ? tab[s] : (K)0;
-            uint64_t oh = tuplehash6<K, BITS>(ok);
-            uint64_t occ = __ballot(ok != 0);
-            while (occ) {
-              int q = __ffsll((unsigned long long)occ) - 1;
-              occ &= occ - 1;
-              pyset_insert_clean_uniform<K>(ntab, newsize - 1, bcast_key<K>(ok, q), bcast_u64(oh, q));
-            }
-          }
-          tab = ntab;
-          size = newsize;
+    while (true) {
+      uint64_t pm = __ballot(pending);
+      if (!pm) break;
+      // set_add_entry grows the table when fill*5 >= mask*3, checked right after each
+      // insertion: at most thr - fill more keys go into this table
+      uint32_t mask = size - 1;
+      uint32_t thr = (mask * 3u + 4u) / 5u;
+      bool part = pending && (uint32_t)__popcll(pm & lt) < thr - fill;
+      bool placed;
+      uint32_t slot;
+      pyset_match<K>(tabs + toff, mask, part, key, hash, lane, true, placed, slot);
+      if (placed) tabs[toff + slot] = key;
+      pending = pending && !part;
+      fill += (uint32_t)__popcll(__ballot(placed));
+      __syncthreads();
+      if (fill >= thr) {  // set_table_resize(used * 4): re-insert in old-slot order
+        uint32_t newsize = 8;
+        while (newsize <= fill * 4u) newsize <<= 1;
+        if (newsize > (uint32_t)p.cand_cap) {
+          cand_overflow = true;
+          break;
+        }
+        const uint32_t noff = table_region(p.cand_cap, newsize);
+        for (uint32_t s2 = lane; s2 < newsize; s2 += 64) tabs[noff + s2] = EMPTY;
+        __syncthreads();
+        for (uint32_t sb = 0; sb < size; sb += 64) {
+          uint32_t s2 = sb + lane;
+          K ok = (s2 < size) ? tabs[toff + s2] : EMPTY;
+          bool opart = ok != EMPTY;
+          bool oplaced;
+          uint32_t oslot;
+          pyset_match<K>(tabs + noff, newsize - 1, opart, ok, tuplehash6<K, BITS>(ok), lane, false, oplaced, oslot);
+          if (oplaced) tabs[noff + oslot] = ok;
           __syncthreads();
         }
+        toff = noff;
+        size = newsize;
       }
+    }
+  };
+
+  for (int pbase = 0; pbase < NP && !cand_overflow; pbase += 64) {
+    // which (EMS, rotation) pairs of this chunk can hold the item at all
+    int q = pbase + lane;
+    bool pv = q < NP;
+    int ei = q / orient, rot = q - ei * orient;
+    int sx, sy, sz;
+    bool skip = rot_size(rot, sx, sy, sz);
+    K ek = pv ? l.ems_a[ei] : (K)0;
+    pv = pv && !skip && (P::get(ek, 3) - P::get(ek, 0) >= sx) && (P::get(ek, 4) - P::get(ek, 1) >= sy) &&
+         (P::get(ek, 5) - P::get(ek, 2) >= sz);
+    uint64_t pm = __ballot(pv);
+    const int nt = 4 * __popcll(pm);  // four bottom-corner placements per pair (:565-568)
+    if (pv) l.vp[__popcll(pm & lt)] = (uint16_t)q;
+    __syncthreads();
+    for (int tb = 0; tb < nt && !cand_overflow; tb += 64) {
+      int tt = tb + lane;
+      bool valid = tt < nt;
+      int qq = valid ? (int)l.vp[tt >> 2] : 0;
+      int corner = tt & 3;
+      int e2 = qq / orient;
+      rot_size(qq - e2 * orient, sx, sy, sz);
+      K k2 = l.ems_a[e2];
+      int x0 = P::get(k2, 0), y0 = P::get(k2, 1), z0 = P::get(k2, 2), x1 = P::get(k2, 3), y1 = P::get(k2, 4);
+      int xs = (corner & 1) ? x1 - sx : x0;
+      int ys = (corner & 2) ? y1 - sy : y0;
+      K key = P::pack(xs, ys, z0, xs + sx, ys + sy, z0 + sz);
+      uint64_t hash = tuplehash6<K, BITS>(key);
+      bool fresh = valid && !pyset_contains<K>(tabs + toff, size - 1, key, hash);
+      uint64_t nm = __ballot(fresh);
+      if (fresh) pend[npend + __popcll(nm & lt)] = key;
+      npend += __popcll(nm);
+      __syncthreads();
+      if (npend >= 64) flush(64);
     }
     __syncthreads();
   }
+  while (npend > 0 && !cand_overflow) flush(npend < 64 ? npend : 64);
   if (cand_overflow) r.flags |= PCT_FLAG_CANDIDATE_OVERFLOW;
+  __syncthreads();
+  tm.tick(PH_SET);
 
   // iterate the table in slot order (= list(set)), test feasibility, keep the first L
   int nleaf = 0;
   for (uint32_t sb = 0; sb < size && nleaf < p.L; sb += 64) {
     uint32_t s = sb + lane;
-    K k = (s < size) ? tab[s] : (K)0;
+    K k = (s < size) ? tabs[toff + s] : SlotWord<K>::EMPTY;
     bool feas = false;
-    if (k != 0) {
+    if (k != SlotWord<K>::EMPTY) {
       int xs = P::get(k, 0), ys = P::get(k, 1), xe = P::get(k, 3), ye = P::get(k, 4);
       int z = P::get(k, 5) - P::get(k, 2);
       int mh = 0;  // D/space.py:400-401 footprint maximum (candidate's own zs is ignored)
@@ -426,6 +555,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, Lds<K, BITS>& l, EnvR
   }
   r.n_leaf = nleaf < p.L ? nleaf : p.L;
   __syncthreads();
+  tm.tick(PH_FEAS);
 }
 
 // D/bin3D.py:70-93: the [I+L+1, 9] float32 observation, written once, coalesced
@@ -505,9 +635,9 @@ __device__ inline void store_state(const DiscreteParams& p, int e, const Lds<K, 
 
 // One transition of one env with the state resident in LDS (D/bin3D.py:151-188 plus the
 // VecEnv worker's auto-reset).  (flag, lx, ly) + (bx, by, bz) is the decoded action.
-template <typename K, int BITS>
+template <typename K, int BITS, typename TM>
 __device__ inline void transition(const DiscreteParams& p, int e, Lds<K, BITS>& l, EnvRegs& r, int lane, bool bad,
-                                  int flag, int lx, int ly, int bx, int by, int bz) {
+                                  int flag, int lx, int ly, int bx, int by, int bz, TM& tm) {
   typedef Pack<K, BITS> P;
   r.t++;
   int x = flag ? by : bx, y = flag ? bx : by, z = bz;  // D/space.py:348-351
@@ -555,7 +685,9 @@ __device__ inline void transition(const DiscreteParams& p, int e, Lds<K, BITS>& 
     r.n_boxes++;
     r.vol += (int64_t)x * y * z;
     __syncthreads();
+    tm.tick(PH_DROP);
     genems<K, BITS>(p, l, r, lane, lx, ly, max_h, lx + x, ly + y, top);
+    tm.tick(PH_GENEMS);
     // D/bin3D.py:57-59,183: 10 * vol(item) / vol(bin), float64 then envs.py:181 .float()
     reward = (float)(((double)((int64_t)r.item0 * r.item1 * r.item2) / binvol) * 10.0);
     done = 0;
@@ -568,6 +700,7 @@ __device__ inline void transition(const DiscreteParams& p, int e, Lds<K, BITS>& 
     __syncthreads();
     space_reset<K, BITS>(p, l, r, lane);  // shmem_vec_env.py:141-143 -> D/bin3D.py:61-67
     __syncthreads();
+    tm.tick(PH_DROP);
   }
   draw_item(p, e, r);
   if (lane == 0) {
@@ -606,7 +739,7 @@ __device__ inline void decode_leaf(const EnvRegs& r, bool zero_row, int xs, int 
 
 enum { ACT_ROWS = 0, ACT_INDEX = 1, ACT_HASH = 2, ACT_RESET = 3 };
 
-template <typename K, int BITS, int ACT>
+template <typename K, int BITS, int ACT, bool TIMED>
 __global__ void __launch_bounds__(64) pct_discrete_kernel(DiscreteParams p, const void* __restrict__ actions,
                                                           int row_len, int n_steps,
                                                           const int32_t* __restrict__ env_ids, int n_ids) {
@@ -620,14 +753,17 @@ __global__ void __launch_bounds__(64) pct_discrete_kernel(DiscreteParams p, cons
   }
   Lds<K, BITS> l = carve_lds<K, BITS>(p, smem);
   EnvRegs r;
+  PhaseTimer<TIMED> tm;
+  tm.start();
   load_state<K, BITS>(p, e, l, r, lane);
+  tm.tick(PH_LOAD);
   float* obs = p.obs + (size_t)e * p.row_len;
 
   if (ACT == ACT_RESET) {
     space_reset<K, BITS>(p, l, r, lane);
     __syncthreads();
     draw_item(p, e, r);
-    leaf_nodes<K, BITS>(p, l, r, lane);
+    leaf_nodes<K, BITS>(p, l, r, lane, tm);
     write_obs<K, BITS>(p, l, r, lane, obs);
     store_state<K, BITS>(p, e, l, r, lane);
     return;
@@ -663,12 +799,15 @@ __global__ void __launch_bounds__(64) pct_discrete_kernel(DiscreteParams p, cons
       decode_leaf(r, zero_row, P::get(k, 0), P::get(k, 1), P::get(k, 3), P::get(k, 4), bad, lx, ly, bx, by, bz);
     }
     if (bad) r.flags |= PCT_FLAG_BAD_ACTION;  // ValueError in list.remove, D/bin3D.py:144-145
-    transition<K, BITS>(p, e, l, r, lane, bad, flag, lx, ly, bx, by, bz);
-    leaf_nodes<K, BITS>(p, l, r, lane);
+    transition<K, BITS>(p, e, l, r, lane, bad, flag, lx, ly, bx, by, bz, tm);
+    leaf_nodes<K, BITS>(p, l, r, lane, tm);
     write_obs<K, BITS>(p, l, r, lane, obs);
     __syncthreads();
+    tm.tick(PH_OBS);
   }
   store_state<K, BITS>(p, e, l, r, lane);
+  tm.tick(PH_STORE);
+  if (TIMED && lane == 0) tm.flush(p.timing + (size_t)e * 8, n_steps);
 }
 
 // Stand-in policy kernel: one wave per env reads the leaf-mask column (col 8 of rows
@@ -699,18 +838,19 @@ namespace pct {
 size_t discrete_lds_bytes(const DiscreteParams& p) {
   size_t k = p.key_bytes;
   size_t n = (size_t)p.cand_cap + p.cand_cap / 4 + 2 * (size_t)p.ems_cap + p.I + p.L;
-  return n * k + (size_t)p.AA * sizeof(int16_t) + 16;
+  return n * k + (size_t)p.AA * sizeof(int16_t) + 64 * sizeof(uint16_t) + 16;
 }
 
 template <typename K, int BITS>
 static hipError_t launch_typed(const DiscreteParams& p, int act, const void* actions, int row_len, int n_steps,
                                const int32_t* env_ids, int n_ids, hipStream_t stream) {
   size_t lds = discrete_lds_bytes(p);
+  const bool timed = p.timing != nullptr && act != ACT_RESET;
   int grid = (act == ACT_RESET && env_ids) ? n_ids : p.N;
   if (grid <= 0) return hipSuccess;
 #define PCT_LAUNCH(A)                                                                                        \
   do {                                                                                                       \
-    auto kern = pct_discrete_kernel<K, BITS, A>;                                                             \
+    auto kern = timed ? pct_discrete_kernel<K, BITS, A, true> : pct_discrete_kernel<K, BITS, A, false>;                                                             \
     if (lds > 48 * 1024) {                                                                                   \
       hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                               \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \

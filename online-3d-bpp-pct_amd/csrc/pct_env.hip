@@ -53,6 +53,7 @@ struct pct_env {
   size_t ev_used;
   int64_t prof_launches;
   double prof_ms;
+  unsigned long long* timing_buf;
 };
 
 namespace {
@@ -133,6 +134,7 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
   if (H > maxdim) maxdim = H;
   if (maxdim > 1023) return fail(PCT_ERR_UNSUPPORTED, "discrete bins are limited to 1023 per axis");
   int ems_cap = cfg->ems_capacity > 0 ? cfg->ems_capacity : 256;
+  if (ems_cap < 256) return fail(PCT_ERR_INVALID_ARG, "ems_capacity must be >= 256");
   int cand_cap = cfg->candidate_capacity > 0 ? cfg->candidate_capacity : 2048;
   if (!is_cand_cap_ok(cand_cap)) return fail(PCT_ERR_INVALID_ARG, "candidate_capacity must be 8*4^k (8,32,...,2048,8192)");
 
@@ -152,6 +154,7 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
   h->ev_used = 0;
   h->prof_launches = 0;
   h->prof_ms = 0.0;
+  h->timing_buf = nullptr;
   int rc = use_device(h);
   if (rc) { delete h; return rc; }
 
@@ -354,6 +357,26 @@ int pct_profile_read(pct_env* h, int64_t* n_launches, double* total_ms) {
   if (total_ms) *total_ms = h->prof_ms;
   h->prof_launches = 0;
   h->prof_ms = 0.0;
+  return PCT_OK;
+}
+
+int pct_debug_phase_timing(pct_env* h, int32_t on, uint64_t* host_out) {
+  if (!h) return fail(PCT_ERR_INVALID_ARG, "null handle");
+  int rc = use_device(h);
+  if (rc) return rc;
+  size_t bytes = (size_t)h->dp.N * 8 * sizeof(unsigned long long);
+  HIP_TRY(hipDeviceSynchronize());
+  if (host_out && h->timing_buf) HIP_TRY(hipMemcpy(host_out, h->timing_buf, bytes, hipMemcpyDeviceToHost));
+  if (on) {
+    if (!h->timing_buf) {
+      rc = dev_alloc(h, (void**)&h->timing_buf, bytes, true);
+      if (rc) return rc;
+    }
+    HIP_TRY(hipMemset(h->timing_buf, 0, bytes));
+    h->dp.timing = h->timing_buf;
+  } else {
+    h->dp.timing = nullptr;
+  }
   return PCT_OK;
 }
 

@@ -92,6 +92,12 @@ class VecEnv(ABC):
         _lib.check(self._L.pct_profile_read(self._h, ctypes.byref(n), ctypes.byref(ms)))
         return n.value, ms.value
 
+    def phase_timing(self, on=True):
+        """Start/stop per-phase cycle accounting; returns the uint64 [N,8] gathered so far."""
+        out = np.zeros((self.N, 8), np.uint64)
+        _lib.check(self._L.pct_debug_phase_timing(self._h, int(bool(on)), out.ctypes.data))
+        return out
+
     def step_wait(self):
         pass
 
