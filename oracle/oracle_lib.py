@@ -33,7 +33,7 @@ class PctConfig(ctypes.Structure):
 
 def build(force=False):
     so = os.path.join(_HERE, "libpct_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("pct_oracle.c", "pct_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("pct_oracle.c", "pct_oracle_cont.c", "pct_oracle.h", "pct_oracle_internal.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "pct_env.h"))
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libpct_oracle.so"])
@@ -50,6 +50,7 @@ def lib():
         L.pcto_last_error.restype = ctypes.c_char_p
         L.pcto_set_item_set.argtypes = [vp, vp, ctypes.c_int32]
         L.pcto_set_item_stream.argtypes = [vp, vp, ctypes.c_int64]
+        L.pcto_set_sample_bounds.argtypes = [vp, ctypes.c_int32, ctypes.c_int32]
         L.pcto_set_sampler.argtypes = [vp, ctypes.c_uint64]
         for name in ("pcto_obs", "pcto_reward", "pcto_done", "pcto_info_counter", "pcto_info_ratio",
                      "pcto_error_flags"):
@@ -77,14 +78,18 @@ class OracleVecEnv(object):
 
     def __init__(self, num_envs, setting=2, container_size=(10, 10, 10), item_set=None,
                  internal_node_holder=80, leaf_node_holder=50, env_kind=0, lnes=0, env_id_base=0,
-                 threads=1):
+                 threads=1, sample_bounds=None):
+        """env_kind 0: discrete (container / item_set in integer units).
+        env_kind 1: continuous -- container in bin units (integers), sample_bounds=(left,right)
+        in bin units (lattice 1e-3); item streams are int lattice units (1e-3)."""
         L = lib()
         cfg = PctConfig()
         cfg.struct_size = ctypes.sizeof(PctConfig)
         cfg.env_kind = env_kind
         cfg.setting = setting
         cfg.num_envs = num_envs
-        cfg.container[:] = [int(c) for c in container_size]
+        scale = 1000 if env_kind == 1 else 1
+        cfg.container[:] = [int(round(c * scale)) for c in container_size]
         cfg.internal_node_holder = internal_node_holder
         cfg.leaf_node_holder = leaf_node_holder
         cfg.lnes = lnes
@@ -96,8 +101,12 @@ class OracleVecEnv(object):
         self._h = ctypes.c_void_p()
         self._check(L.pcto_create(ctypes.byref(cfg), ctypes.byref(self._h)))
         L.pcto_set_num_threads(threads)
-        items = np.ascontiguousarray(np.asarray(item_set, dtype=np.int32).reshape(-1, 3))
-        self._check(L.pcto_set_item_set(self._h, items.ctypes.data, items.shape[0]))
+        if env_kind == 1:
+            lo, hi = sample_bounds
+            self._check(L.pcto_set_sample_bounds(self._h, int(round(lo * 1000)), int(round(hi * 1000))))
+        else:
+            items = np.ascontiguousarray(np.asarray(item_set, dtype=np.int32).reshape(-1, 3))
+            self._check(L.pcto_set_item_set(self._h, items.ctypes.data, items.shape[0]))
         self.obs = _np_view(L.pcto_obs(self._h), (self.N, self.row_len), np.float64)
         self.reward = _np_view(L.pcto_reward(self._h), (self.N,), np.float64)
         self.done = _np_view(L.pcto_done(self._h), (self.N,), np.uint8)

@@ -5,7 +5,7 @@
  * Every function cites the reference lines it follows (paths relative to the reference
  * repo; "D/" = pct_envs/PctDiscrete0/).  The code is written for fidelity, not speed.
  */
-#include "pct_oracle.h"
+#include "pct_oracle_internal.h"
 
 #include <math.h>
 #include <stdarg.h>
@@ -147,47 +147,6 @@ int pcto_pyset_order(const int64_t* keys, int32_t n, int32_t* order_out) {
 /* ===================================================================================== */
 /* per-env state                                                                          */
 /* ===================================================================================== */
-typedef struct {
-  int x, y, z, lx, ly, lz;
-} obox; /* D/space.py:26-33 Box geometry */
-
-typedef struct {
-  /* D/space.py:271-314 Space */
-  int* plain;      /* [A*A] heightmap, plain[x*A+y] */
-  double* box_vec; /* [I*9] */
-  obox* boxes;
-  int n_boxes; /* len(self.boxes) */
-  int box_idx;
-  int64_t* ems; /* [n_ems*6] */
-  int n_ems, cap_ems;
-  /* D/bin3D.py env */
-  int next_box[3];
-  double next_den;
-  int queue_item[3]; /* box_creator.box_list[0] */
-  int queue_len;
-  uint64_t cursor; /* draws taken from the item source */
-  uint32_t t;      /* lifetime step counter (hash policy) */
-} oenv;
-
-struct pcto_env {
-  pct_config cfg;
-  int N, A, I, L, row_len;
-  int low_bound;
-  int32_t* item_set;
-  int n_items;
-  int32_t* stream;
-  int64_t T;
-  uint64_t seed;
-  int source;
-  oenv* envs;
-  double* obs;
-  double* reward;
-  uint8_t* done;
-  int32_t* counter;
-  double* ratio;
-  uint32_t* flags;
-};
-
 /* item source shared with the HIP path (include/pct_env.h pct_set_item_stream /
  * pct_set_sampler); stands in for binCreator.py:37-39 generate_box_size */
 static void draw_item(const pcto_env* h, int e, oenv* s, int out[3]) {
@@ -533,7 +492,8 @@ static void env_step(const pcto_env* h, int e, oenv* s, const double* act, int l
 int pcto_create(const pct_config* cfg, pcto_env** out) {
   if (!cfg || !out) return fail(PCT_ERR_INVALID_ARG, "null argument");
   if (cfg->struct_size != (int32_t)sizeof(pct_config)) return fail(PCT_ERR_INVALID_ARG, "pct_config size mismatch");
-  if (cfg->env_kind != PCT_ENV_DISCRETE) return fail(PCT_ERR_UNSUPPORTED, "oracle: only the discrete env is restated");
+  if (cfg->env_kind != PCT_ENV_DISCRETE && cfg->env_kind != PCT_ENV_CONTINUOUS)
+    return fail(PCT_ERR_UNSUPPORTED, "oracle: unknown env kind");
   if (cfg->setting != 2) return fail(PCT_ERR_UNSUPPORTED, "oracle: only setting 2 is restated");
   if (cfg->lnes != PCT_LNES_EMS) return fail(PCT_ERR_UNSUPPORTED, "oracle: only LNES=EMS is restated");
   if (cfg->num_envs < 1 || cfg->internal_node_holder < 1 || cfg->leaf_node_holder < 1)
@@ -546,7 +506,10 @@ int pcto_create(const pct_config* cfg, pcto_env** out) {
   h->L = cfg->leaf_node_holder;
   h->row_len = (h->I + h->L + 1) * 9;
   h->envs = (oenv*)calloc((size_t)h->N, sizeof(oenv));
-  for (int e = 0; e < h->N; e++) {
+  if (cfg->env_kind == PCT_ENV_CONTINUOUS) {
+    if (pctc_alloc(h)) return fail(PCT_ERR_INVALID_ARG, "continuous alloc failed");
+  }
+  for (int e = 0; e < h->N && cfg->env_kind == PCT_ENV_DISCRETE; e++) {
     oenv* s = &h->envs[e];
     s->plain = (int*)calloc((size_t)h->A * h->A, sizeof(int));
     s->box_vec = (double*)calloc((size_t)h->I * 9, sizeof(double));
@@ -569,6 +532,7 @@ int pcto_destroy(pcto_env* h) {
   for (int e = 0; e < h->N; e++) {
     free(h->envs[e].plain); free(h->envs[e].box_vec); free(h->envs[e].boxes); free(h->envs[e].ems);
   }
+  if (h->cenvs) pctc_free(h);
   free(h->envs); free(h->obs); free(h->reward); free(h->done); free(h->counter); free(h->ratio);
   free(h->flags); free(h->item_set); free(h->stream);
   free(h);
@@ -586,6 +550,17 @@ int pcto_set_item_set(pcto_env* h, const int32_t* item_set, int32_t n) {
   h->low_bound = mn; /* bin3D.py:23 size_minimum */
   return PCT_OK;
 }
+int pcto_set_sample_bounds(pcto_env* h, int32_t left, int32_t right) {
+  if (!h || left < 1 || right < left) return fail(PCT_ERR_INVALID_ARG, "bad bounds");
+  h->low_bound = left; /* C/bin3D.py:25-27 size_minimum = sample_left_bound */
+  h->sample_left = left;
+  h->sample_right = right;
+  if (!h->item_set) { /* placeholder so that ready() passes; the sampler draws from the bounds */
+    h->item_set = (int32_t*)calloc(3, sizeof(int32_t));
+    h->n_items = 1;
+  }
+  return PCT_OK;
+}
 int pcto_set_item_stream(pcto_env* h, const int32_t* items, int64_t T) {
   if (!h || !items || T < 1) return fail(PCT_ERR_INVALID_ARG, "bad stream");
   free(h->stream);
@@ -597,7 +572,7 @@ int pcto_set_item_stream(pcto_env* h, const int32_t* items, int64_t T) {
   return PCT_OK;
 }
 int pcto_set_sampler(pcto_env* h, uint64_t seed) {
-  if (!h || !h->item_set) return fail(PCT_ERR_STATE, "set the item set first");
+  if (!h || !h->item_set) return fail(PCT_ERR_STATE, "set the item set / sample bounds first");
   h->seed = seed;
   h->source = PCT_ITEMS_SAMPLER;
   return PCT_OK;
@@ -617,6 +592,17 @@ static int ready(const pcto_env* h) {
   return PCT_OK;
 }
 
+static void any_reset(pcto_env* h, int e, double* obs) {
+  if (h->cfg.env_kind == PCT_ENV_CONTINUOUS) pctc_reset(h, e, obs);
+  else env_reset(h, e, &h->envs[e], obs);
+}
+static void any_step(pcto_env* h, int e, const double* act, int len, double* obs) {
+  if (h->cfg.env_kind == PCT_ENV_CONTINUOUS)
+    pctc_step(h, e, act, len, obs, &h->reward[e], &h->done[e], &h->counter[e], &h->ratio[e], &h->flags[e]);
+  else
+    env_step(h, e, &h->envs[e], act, len, obs, &h->reward[e], &h->done[e], &h->counter[e], &h->ratio[e], &h->flags[e]);
+}
+
 int pcto_reset(pcto_env* h, const int32_t* env_ids, int32_t n) {
   int rc = ready(h);
   if (rc) return rc;
@@ -625,7 +611,7 @@ int pcto_reset(pcto_env* h, const int32_t* env_ids, int32_t n) {
   for (int k = 0; k < cnt; k++) {
     int e = env_ids ? env_ids[k] : k;
     if (e < 0 || e >= h->N) continue;
-    env_reset(h, e, &h->envs[e], h->obs + (size_t)e * h->row_len);
+    any_reset(h, e, h->obs + (size_t)e * h->row_len);
   }
   return PCT_OK;
 }
@@ -636,11 +622,9 @@ int pcto_step_rows(pcto_env* h, const double* rows, int32_t row_len, int32_t aut
   if (row_len != 9 && row_len != 6 && row_len != 3) return fail(PCT_ERR_INVALID_ARG, "row_len must be 9, 6 or 3");
 #pragma omp parallel for num_threads(g_threads) schedule(dynamic, 8)
   for (int e = 0; e < h->N; e++) {
-    oenv* s = &h->envs[e];
     double* obs = h->obs + (size_t)e * h->row_len;
-    env_step(h, e, s, rows + (size_t)e * row_len, row_len, obs, &h->reward[e], &h->done[e], &h->counter[e],
-             &h->ratio[e], &h->flags[e]);
-    if (h->done[e] && auto_reset) env_reset(h, e, s, obs);
+    any_step(h, e, rows + (size_t)e * row_len, row_len, obs);
+    if (h->done[e] && auto_reset) any_reset(h, e, obs);
   }
   return PCT_OK;
 }
@@ -650,14 +634,13 @@ int pcto_step_index(pcto_env* h, const int64_t* leaf_index, int32_t auto_reset) 
   if (rc) return rc;
 #pragma omp parallel for num_threads(g_threads) schedule(dynamic, 8)
   for (int e = 0; e < h->N; e++) {
-    oenv* s = &h->envs[e];
     double* obs = h->obs + (size_t)e * h->row_len;
     double row[9];
     int64_t li = leaf_index[e];
     if (li < 0 || li >= h->L) li = 0;
     memcpy(row, obs + 9 * ((size_t)h->I + (size_t)li), sizeof row);
-    env_step(h, e, s, row, 9, obs, &h->reward[e], &h->done[e], &h->counter[e], &h->ratio[e], &h->flags[e]);
-    if (h->done[e] && auto_reset) env_reset(h, e, s, obs);
+    any_step(h, e, row, 9, obs);
+    if (h->done[e] && auto_reset) any_reset(h, e, obs);
   }
   return PCT_OK;
 }
@@ -673,11 +656,12 @@ int pcto_step_hash_policy(pcto_env* h, int32_t n_steps) {
       const double* leaf = obs + 9 * (size_t)h->I;
       int k = 0;
       for (int i = 0; i < h->L; i++) k += leaf[9 * i + 8] != 0;
-      int li = k > 0 ? (int)(pct_mix32((uint32_t)(h->cfg.env_id_base + e), s->t) % (uint32_t)k) : 0;
+      uint32_t tt = h->cfg.env_kind == PCT_ENV_CONTINUOUS ? pctc_t(h, e) : s->t;
+      int li = k > 0 ? (int)(pct_mix32((uint32_t)(h->cfg.env_id_base + e), tt) % (uint32_t)k) : 0;
       double row[9];
       memcpy(row, leaf + 9 * li, sizeof row);
-      env_step(h, e, s, row, 9, obs, &h->reward[e], &h->done[e], &h->counter[e], &h->ratio[e], &h->flags[e]);
-      if (h->done[e]) env_reset(h, e, s, obs);
+      any_step(h, e, row, 9, obs);
+      if (h->done[e]) any_reset(h, e, obs);
     }
   }
   return PCT_OK;

@@ -32,6 +32,7 @@ int pcto_destroy(pcto_env* env);
 const char* pcto_last_error(void);
 
 int pcto_set_item_set(pcto_env* env, const int32_t* item_set, int32_t n);
+int pcto_set_sample_bounds(pcto_env* env, int32_t left, int32_t right);
 int pcto_set_item_stream(pcto_env* env, const int32_t* items, int64_t T);
 int pcto_set_sampler(pcto_env* env, uint64_t seed);
 

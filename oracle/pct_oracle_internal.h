@@ -1,0 +1,62 @@
+/* pct_oracle_internal.h -- shared between the discrete and continuous restatements
+ * (TEST INFRASTRUCTURE, see pct_oracle.h). */
+#ifndef PCT_ORACLE_INTERNAL_H
+#define PCT_ORACLE_INTERNAL_H
+#include "pct_oracle.h"
+
+typedef struct {
+  int x, y, z, lx, ly, lz;
+} obox; /* D/space.py:26-33 Box geometry */
+
+typedef struct {
+  /* D/space.py:271-314 Space */
+  int* plain;      /* [A*A] heightmap, plain[x*A+y] */
+  double* box_vec; /* [I*9] */
+  obox* boxes;
+  int n_boxes; /* len(self.boxes) */
+  int box_idx;
+  int64_t* ems; /* [n_ems*6] */
+  int n_ems, cap_ems;
+  /* D/bin3D.py env */
+  int next_box[3];
+  double next_den;
+  int queue_item[3]; /* box_creator.box_list[0] */
+  int queue_len;
+  uint64_t cursor; /* draws taken from the item source */
+  uint32_t t;      /* lifetime step counter (hash policy) */
+} oenv;
+
+struct cenv; /* continuous per-env state, pct_oracle_cont.c */
+
+struct pcto_env {
+  pct_config cfg;
+  struct cenv* cenvs; /* env_kind == PCT_ENV_CONTINUOUS */
+  int N, A, I, L, row_len;
+  int low_bound; /* lattice units */
+  int sample_left, sample_right; /* continuous sampler bounds, lattice units */
+  int32_t* item_set;
+  int n_items;
+  int32_t* stream;
+  int64_t T;
+  uint64_t seed;
+  int source;
+  oenv* envs;
+  double* obs;
+  double* reward;
+  uint8_t* done;
+  int32_t* counter;
+  double* ratio;
+  uint32_t* flags;
+};
+
+
+/* continuous env (pct_oracle_cont.c) */
+int pctc_alloc(struct pcto_env* h);
+void pctc_free(struct pcto_env* h);
+void pctc_reset(struct pcto_env* h, int e, double* obs);
+void pctc_step(struct pcto_env* h, int e, const double* act, int len, double* obs, double* reward, uint8_t* done,
+               int32_t* counter, double* ratio, uint32_t* flags);
+uint32_t pctc_t(const struct pcto_env* h, int e);
+int pctc_debug_state(struct pcto_env* h, int e, double* ems, int cap_ems, int* n_ems, int* n_boxes, double* next_item,
+                     int64_t* cursor);
+#endif

@@ -82,6 +82,144 @@ CASES = {
 }
 
 
+CONT_CASES = {
+    # continuous env, setting 2: container in bin units, items on the 1e-3 lattice in [lo, hi]
+    "continuous_s2_10_80_50": dict(setting=2, container=(10, 10, 10), lo=1.0, hi=5.0, I=80, L=50, N=4, steps=250,
+                                   stream_T=256, seed=21, base=0),
+    "continuous_s2_100_200_200": dict(setting=2, container=(100, 100, 100), lo=5.0, hi=25.0, I=200, L=200, N=1,
+                                      steps=260, stream_T=512, seed=22, base=9),
+    "continuous_s2_rect_60_20": dict(setting=2, container=(8, 12, 9), lo=0.5, hi=4.0, I=60, L=20, N=3, steps=200,
+                                     stream_T=256, seed=23, base=40),
+}
+
+
+def make_cont_stream(seed, n_envs, T, lo, hi):
+    rng = np.random.RandomState(seed)
+    return rng.randint(int(round(lo * 1000)), int(round(hi * 1000)) + 1, size=(n_envs, T, 3)).astype(np.int32)
+
+
+def scripted_cont_creator(stream_row):
+    ref_shim.install()
+    from pct_envs.PctContinuous0.binCreator import BoxCreator
+
+    class ScriptedBoxCreator(BoxCreator):
+        def __init__(self, row):
+            super().__init__()
+            self.row = row
+            self.cursor = 0
+
+        def generate_box_size(self, **kwargs):
+            it = self.row[self.cursor % len(self.row)]
+            self.cursor += 1
+            # the float the reference would hold for a 3-decimal size (round(U(a,b), 3))
+            self.box_list.append((int(it[0]) / 1000.0, int(it[1]) / 1000.0, int(it[2]) / 1000.0))
+
+    return ScriptedBoxCreator(stream_row)
+
+
+def run_reference_cont(case):
+    """Reference PackingContinuous driven with float64 leaf rows (the observation's own rows)."""
+    PD, PC, _ = ref_shim.load_reference_envs()
+    c = case
+    stream = make_cont_stream(c["seed"], c["N"], c["stream_T"], c["lo"], c["hi"])
+    N, I, L = c["N"], c["I"], c["L"]
+    row_len = (I + L + 1) * 9
+    obs_rec = np.zeros((c["steps"] + 1, N, row_len), np.float64)
+    rew = np.zeros((c["steps"], N), np.float64)
+    done = np.zeros((c["steps"], N), np.uint8)
+    counter = np.zeros((c["steps"], N), np.int32)
+    ratio = np.zeros((c["steps"], N), np.float64)
+    for e in range(N):
+        # sample_from_distribution=False + item_set minimum == lo reproduces size_minimum = lo
+        # (C/bin3D.py:25-29) while items come from the scripted creator (C/bin3D.py:116)
+        env = PC(setting=c["setting"], container_size=list(c["container"]), item_set=[(c["lo"], c["lo"], c["lo"])],
+                 internal_node_holder=I, leaf_node_holder=L, shuffle=False, sample_from_distribution=False)
+        env.box_creator = scripted_cont_creator(stream[e])
+        obs = env.reset()
+        g = c["base"] + e
+        for t in range(c["steps"]):
+            obs_rec[t, e] = obs
+            leaf = obs.reshape(-1, 9)[I:I + L]
+            k = int((leaf[:, 8] != 0).sum())
+            li = mix32(g, t) % k if k > 0 else 0
+            obs, r, d, info = env.step(leaf[li].copy())
+            rew[t, e] = r
+            done[t, e] = d
+            counter[t, e] = info["counter"]
+            ratio[t, e] = info.get("ratio", 0.0)
+            if d:
+                obs = env.reset()
+        obs_rec[c["steps"], e] = obs
+    return dict(stream=stream, obs=obs_rec, reward=rew, done=done, counter=counter, ratio=ratio)
+
+
+def run_oracle_cont(case, stream):
+    from oracle.oracle_lib import OracleVecEnv
+    c = case
+    env = OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"], env_kind=1,
+                       sample_bounds=(c["lo"], c["hi"]), internal_node_holder=c["I"], leaf_node_holder=c["L"],
+                       env_id_base=c["base"])
+    env.set_item_stream(stream)
+    N, I, L = c["N"], c["I"], c["L"]
+    obs_rec = np.zeros((c["steps"] + 1, N, (I + L + 1) * 9), np.float64)
+    rew = np.zeros((c["steps"], N), np.float64)
+    done = np.zeros((c["steps"], N), np.uint8)
+    counter = np.zeros((c["steps"], N), np.int32)
+    ratio = np.zeros((c["steps"], N), np.float64)
+    env.reset()
+    for t in range(c["steps"]):
+        obs_rec[t] = env.obs
+        env.step_hash_policy(1)
+        rew[t], done[t], counter[t], ratio[t] = env.reward, env.done, env.counter, env.ratio
+    obs_rec[c["steps"]] = env.obs
+    assert not env.flags.any()
+    env.close()
+    return dict(obs=obs_rec, reward=rew, done=done, counter=counter, ratio=ratio)
+
+
+def known_answer_continuous_s2():
+    """continuous setting 2, env.seed(4), RandomState(0) policy, sampling mode
+    (np.random.uniform inside every cur_observation, C/bin3D.py:103-113), sha256 over the 500
+    observations rounded to 5 decimals and cast to float32 = 506b5c0349c89b9d.  The items that
+    reached a returned observation are recorded and replayed into the oracle."""
+    PD, PC, _ = ref_shim.load_reference_envs()
+    env = PC(setting=2, container_size=[10, 10, 10], item_set=[(1, 1, 1)], internal_node_holder=80,
+             leaf_node_holder=50, shuffle=False, sample_from_distribution=True, sample_left_bound=1.0,
+             sample_right_bound=5.0)
+    env.seed(4)
+    rng = np.random.RandomState(0)
+    obs = env.reset()
+    items = [tuple(env.next_box)]
+    h = hashlib.sha256()
+    acts = []
+    for t in range(500):
+        h.update(np.round(obs, 5).astype(np.float32).tobytes())
+        leaf = obs.reshape(-1, 9)[80:130]
+        k = int(leaf[:, 8].sum())
+        a = leaf[rng.randint(k)] if k > 0 else leaf[0]
+        acts.append(np.array(a, dtype=np.float64))
+        obs, r, d, info = env.step(a)
+        if d:
+            obs = env.reset()
+        items.append(tuple(env.next_box))
+    ref_hash = h.hexdigest()[:16]
+    assert ref_hash == "506b5c0349c89b9d", ref_hash
+    lattice = np.rint(np.asarray(items) * 1000).astype(np.int32)
+    assert np.array_equal(lattice / 1000.0, np.asarray(items))  # items are 3-decimal floats
+    from oracle.oracle_lib import OracleVecEnv
+    o = OracleVecEnv(1, setting=2, container_size=(10, 10, 10), env_kind=1, sample_bounds=(1.0, 5.0))
+    o.set_item_stream(lattice[None])
+    o.reset()
+    h2 = hashlib.sha256()
+    for t in range(500):
+        h2.update(np.round(o.obs[0], 5).astype(np.float32).tobytes())
+        o.step_rows(acts[t][None], auto_reset=True)
+    assert h2.hexdigest()[:16] == ref_hash, (h2.hexdigest()[:16], ref_hash)
+    np.savez_compressed(os.path.join(HERE, "kat_continuous_s2.npz"), items=lattice, actions=np.asarray(acts, np.float64),
+                        sha256_16=np.array(ref_hash))
+    print("known answer continuous s2: oracle == reference ==", ref_hash)
+
+
 def item_set_range(lo, hi):
     return [(i, j, k) for i in range(lo, hi + 1) for j in range(lo, hi + 1) for k in range(lo, hi + 1)]
 
@@ -194,6 +332,22 @@ def known_answer_discrete_s2():
 
 def main():
     known_answer_discrete_s2()
+    known_answer_continuous_s2()
+    for name, case in CONT_CASES.items():
+        ref = run_reference_cont(case)
+        ora = run_oracle_cont(case, ref["stream"])
+        for key in ("obs", "reward", "done", "counter", "ratio"):
+            a, b = ref[key], ora[key]
+            if key == "ratio":
+                a = a * (ref["done"] != 0)
+                b = b * (ora["done"] != 0)
+            if not np.array_equal(a, b):
+                raise SystemExit("MISMATCH %s/%s first at %s" % (name, key, np.argwhere(a != b)[0]))
+        print("%-28s steps=%d envs=%d episodes=%d  oracle == reference (float64, bit-exact)" % (
+            name, case["steps"], case["N"], int(ref["done"].sum())))
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), meta=np.array(repr(case)), stream=ref["stream"],
+                            obs=ref["obs"], reward=ref["reward"], done=ref["done"], counter=ref["counter"],
+                            ratio=ref["ratio"] * (ref["done"] != 0))
     for name, case in CASES.items():
         ref = run_reference(case)
         ora = run_oracle(case, ref["stream"])

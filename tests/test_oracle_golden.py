@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from oracle.oracle_lib import OracleVecEnv, pyset_order
-from tests.common import GOLDEN_CASES, gather_rows, hash_policy_index, item_set_range, load_case, GOLDEN
+from tests.common import CONT_CASES, GOLDEN_CASES, gather_rows, hash_policy_index, item_set_range, load_case, GOLDEN
 
 
 @pytest.mark.parametrize("name", GOLDEN_CASES)
@@ -132,3 +132,37 @@ def test_edge_cases_zero_row_and_bad_action():
     env.step_rows(rows)
     assert env.done[0] == 0 and env.counter[0] == 1
     assert env.done[1] == 1 and env.flags[1] == 8
+
+
+@pytest.mark.parametrize("name", CONT_CASES)
+def test_continuous_oracle_matches_reference_fixture(name):
+    """PctContinuous0, setting 2: float64 observations bit-exact against the reference fixture
+    (same float64 operation order, same CPython set order over float tuples)."""
+    c, z = load_case(name)
+    env = OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"], env_kind=1,
+                       sample_bounds=(c["lo"], c["hi"]), internal_node_holder=c["I"], leaf_node_holder=c["L"],
+                       env_id_base=c["base"])
+    env.set_item_stream(z["stream"])
+    env.reset()
+    for t in range(c["steps"]):
+        assert np.array_equal(env.obs, z["obs"][t]), (name, t)
+        env.step_hash_policy(1)
+        assert np.array_equal(env.reward, z["reward"][t])
+        assert np.array_equal(env.done, z["done"][t])
+        assert np.array_equal(env.counter, z["counter"][t])
+        assert np.array_equal(env.ratio * (env.done != 0), z["ratio"][t])
+    assert np.array_equal(env.obs, z["obs"][c["steps"]])
+    assert not env.flags.any()
+
+
+def test_continuous_known_answer_hash_replay():
+    """506b5c0349c89b9d (observations rounded to 5 decimals, float32)."""
+    z = np.load(GOLDEN + "/kat_continuous_s2.npz")
+    env = OracleVecEnv(1, setting=2, container_size=(10, 10, 10), env_kind=1, sample_bounds=(1.0, 5.0))
+    env.set_item_stream(z["items"][None])
+    env.reset()
+    h = hashlib.sha256()
+    for t in range(500):
+        h.update(np.round(env.obs[0], 5).astype(np.float32).tobytes())
+        env.step_rows(z["actions"][t][None])
+    assert h.hexdigest()[:16] == str(z["sha256_16"]) == "506b5c0349c89b9d"
