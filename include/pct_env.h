@@ -111,7 +111,15 @@ int pct_destroy(pct_env* env);
 /* item_set: host int32 [n,3] in lattice units (givenData.py:10-14).  Also fixes
  * low_bound = min over all entries (bin3D.py:23). */
 int pct_set_item_set(pct_env* env, const int32_t* item_set, int32_t n);
-/* Continuous sampler bounds in lattice units (tools.py:178-181); low_bound = left. */
+/* Continuous env (PCT_ENV_CONTINUOUS): pct_config.container is given in lattice units
+ * (1e-3; the reference's integer bin sizes are multiples of 1000) and items are 3-decimal
+ * sizes (C/bin3D.py:106-108).  Sampler bounds in lattice units (tools.py:178-181);
+ * low_bound = left (C/bin3D.py:25-27).  The c-th draw of global env g is
+ * left + pct_mix64(seed, g, 3c+d) % (right-left+1) for d = 0,1,2.  A float32 action row is
+ * matched back to the env's current leaf whose float32 cast it is and decoded from that
+ * leaf's float64 values, i.e. exactly like the reference decodes the float64 row
+ * (round(.,6), C/bin3D.py:153-173); a row matching no leaf is decoded from the widened
+ * floats.  pct_step_index carries the leaf in full precision by construction. */
 int pct_set_sample_bounds(pct_env* env, int32_t left, int32_t right);
 /* Scripted trajectories: host int32 [num_envs, T, 3]; env e draws items[e][c % T] for its
  * c-th draw (one draw per reset and one per successful placement,
@@ -170,6 +178,10 @@ int pct_debug_state(pct_env* env, int32_t local_id, int32_t* heightmap, int32_t*
                     int64_t* draw_cursor);
 
 /* ---- shared arithmetic: part of the ABI, used identically on host and device -------- */
+/* Continuous env: EMS float64 [*n_ems,6] (row-major copy), next item in bin units. */
+int pct_debug_state_f64(pct_env* env, int32_t local_id, double* ems, int32_t cap_ems, int32_t* n_ems,
+                        int32_t* n_boxes, double* next_item, int64_t* draw_cursor);
+
 /* Per-phase cycle accounting of the transition kernel (profiling aid).  on != 0: (re)start
  * accumulation; host_out, if non-NULL, first receives the accumulators gathered so far:
  * uint64 [N,8] = s_memtime cycles in {load, drop_box, GENEMS, candidate set, feasibility,

@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "pct_set_sample_bounds", "pct_set_item_stream", "pct_set_sampler", "pct_bind_outputs", "pct_obs",
     "pct_reward", "pct_done", "pct_info_counter", "pct_info_ratio", "pct_error_flags", "pct_obs_row_len",
     "pct_reset", "pct_step_rows", "pct_step_index", "pct_step_hash_policy", "pct_debug_state",
-    "pct_policy_hash_rows", "pct_profile_enable", "pct_profile_read", "pct_debug_phase_timing",
+    "pct_policy_hash_rows", "pct_profile_enable", "pct_profile_read", "pct_debug_phase_timing", "pct_debug_state_f64",
 ]
 
 
@@ -83,6 +83,7 @@ def load():
     L.pct_profile_enable.argtypes = [vp, i32]
     L.pct_profile_read.argtypes = [vp, ctypes.POINTER(i64), ctypes.POINTER(ctypes.c_double)]
     L.pct_debug_phase_timing.argtypes = [vp, i32, vp]
+    L.pct_debug_state_f64.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp]
     L.pct_debug_state.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp, vp]
     _LIB = L
     return L

@@ -10,8 +10,9 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpct_hip.so")
-SOURCES = ["pct_env.hip", "pct_discrete.hip"]
-HEADERS = [os.path.join(CSRC, "pct_device.h"), os.path.join(HERE, "..", "include", "pct_env.h")]
+SOURCES = ["pct_env.hip", "pct_discrete.hip", "pct_continuous.hip"]
+HEADERS = [os.path.join(CSRC, "pct_device.h"), os.path.join(CSRC, "pct_set.cuh"),
+           os.path.join(HERE, "..", "include", "pct_env.h")]
 
 
 def _hipcc():
@@ -25,7 +26,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -33,6 +34,8 @@ def build_library(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           # the continuous env mirrors the reference's float64 operation order: no FMA contraction
+           "-ffp-contract=off",
            *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
     if verbose:
         print(" ".join(cmd))

@@ -1,0 +1,766 @@
+// pct_continuous.hip -- gfx950 kernels for the batched PctContinuous0 environment.
+//
+// Same execution shape as pct_discrete.hip (one 64-lane wavefront = one workgroup = one env
+// per transition, state staged in LDS, SoA over envs in HBM).  The reference computes in
+// float64 with 1e-6 epsilons, np.around(.,6) and exact float comparisons, and its candidate
+// order is the iteration order of a CPython set of float 6-tuples; to be identical this
+// kernel performs THE SAME float64 operations in the same order (IEEE add/sub/mul/div/rint
+// are deterministic), hashes doubles exactly like CPython, and emulates the set.  Where the
+// reference rounds with np.around before comparing, the comparison is done on the integer
+// lattice index rint(v*1e6), which is equivalent (v -> rint(v*1e6)/1e6 is strictly monotone
+// in the index and odd) and keeps the per-candidate box scan in int32.
+//
+// Reference lines restated (C/ = pct_envs/PctContinuous0/):
+//   step / LeafNode2Action      C/bin3D.py:151-207, wrapper/shmem_vec_env.py:139-143
+//   drop_box / interSect2D      C/space.py:305-314, 329-376
+//   drop_box_virtual            C/space.py:380-425
+//   GENEMS / interSectEMS3D     C/space.py:441-487, Difference :490-506, IsUsableEMS :17-20
+//   EliminateInscribedEMS       C/space.py:510-528
+//   EMSPoint                    C/space.py:531-568
+//   get_possible_position       C/bin3D.py:118-148, cur_observation :78-100
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pct_env.h"
+#include "pct_device.h"
+#include "pct_set.cuh"
+
+namespace pct {
+
+__device__ inline double around6(double x) { return rint(x * 1e6) / 1e6; }  // np.around(x, 6)
+__device__ inline int klat(double x) { return (int)rint(x * 1e6); }
+__device__ inline double wave_max_f64(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    double o = __shfl_xor(v, off, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+// Python/pyhash.c _Py_HashDouble for finite v: (M * 2^k) mod (2^61 - 1) with v = M * 2^k,
+// i.e. the 53-bit mantissa rotated left by k mod 61 inside 61 bits; sign applied after; -1 -> -2.
+__device__ inline uint64_t py_hash_double(double v) {
+  if (v == 0.0) return 0;
+  uint64_t bits = (uint64_t)__double_as_longlong(v);
+  int ef = (int)((bits >> 52) & 0x7FF);
+  uint64_t M = (bits & 0xFFFFFFFFFFFFFull) | (ef ? 0x10000000000000ull : 0ull);
+  int k = (ef ? ef : 1) - 1075;
+  int r = k % 61;
+  if (r < 0) r += 61;
+  const uint64_t P = (1ull << 61) - 1;
+  uint64_t x = r ? (((M << r) & P) | (M >> (61 - r))) : M;
+  int64_t sx = (bits >> 63) ? -(int64_t)x : (int64_t)x;
+  if (sx == -1) sx = -2;
+  return (uint64_t)sx;
+}
+__device__ inline uint64_t tuplehash6d(const double t[6]) {
+  uint64_t acc = tuplehash_begin();
+#pragma unroll
+  for (int i = 0; i < 6; i++) acc = tuplehash_lane(acc, py_hash_double(t[i]));
+  return tuplehash_end6(acc);
+}
+
+struct CRegs {  // wave-uniform per-env scalars
+  int n_ems, n_boxes, n_leaf;
+  int ik0, ik1, ik2;  // current item, lattice 1e-3
+  double b0, b1, b2;  // the same as the floats the reference holds
+  uint64_t cursor;
+  uint32_t t;
+  double volsum;
+  uint32_t flags;
+};
+
+struct CLds {
+  double* ems;    // [6][ems_cap] SoA current EMS list
+  double* ems_b;  // [6][ems_cap] scratch during GENEMS (aliases the hash table)
+  uint32_t* tab;  // [cand_cap + cand_cap/4] hash table regions (aliases ems_b)
+  double* box;    // [6][I] lx,ly,lz,xe,ye,top
+  double* leaf;   // [6][L]
+  uint64_t* bhash;  // [64]
+  int32_t* bk;      // [4][I] lattice indices of (-lx,-ly,xe,ye)
+  uint32_t* pend;   // [128] generator ids waiting for insertion
+  uint32_t* bg;     // [64]
+  uint16_t* order;  // [order_cap] table iteration order (generator ids)
+  uint16_t* vp;     // [64]
+};
+
+__device__ inline CLds carve(const ContinuousParams& p, unsigned char* base) {
+  CLds l;
+  double* d = reinterpret_cast<double*>(base);
+  l.ems = d; d += 6 * p.ems_cap;
+  l.ems_b = d;
+  l.tab = reinterpret_cast<uint32_t*>(d);
+  d += p.union_doubles;
+  l.box = d; d += 6 * p.I;
+  l.leaf = d; d += 6 * p.L;
+  l.bhash = reinterpret_cast<uint64_t*>(d); d += 64;
+  int32_t* q = reinterpret_cast<int32_t*>(d);
+  l.bk = q; q += 4 * p.I;
+  l.pend = reinterpret_cast<uint32_t*>(q); q += 128;
+  l.bg = reinterpret_cast<uint32_t*>(q); q += 64;
+  uint16_t* h = reinterpret_cast<uint16_t*>(q);
+  l.order = h; h += p.order_cap;
+  l.vp = h;
+  return l;
+}
+
+size_t continuous_lds_bytes(const ContinuousParams& p) {
+  size_t dbl = (size_t)6 * p.ems_cap + p.union_doubles + 6 * (size_t)p.I + 6 * (size_t)p.L + 64;
+  size_t i32 = 4 * (size_t)p.I + 128 + 64;
+  size_t u16 = (size_t)p.order_cap + 64;
+  return dbl * 8 + i32 * 4 + u16 * 2 + 16;
+}
+
+__device__ inline void cdraw_item(const ContinuousParams& p, int e, CRegs& r) {
+  uint64_t c = r.cursor++;
+  if (p.source == PCT_ITEMS_STREAM) {
+    const int32_t* it = p.stream + ((size_t)e * (size_t)p.T + (size_t)(c % (uint64_t)p.T)) * 3;
+    r.ik0 = it[0]; r.ik1 = it[1]; r.ik2 = it[2];
+  } else {
+    uint64_t g = (uint64_t)(p.env_id_base + e);
+    uint64_t span = (uint64_t)(p.sample_right - p.sample_left + 1);
+    r.ik0 = p.sample_left + (int)(pct_mix64(p.seed, g, c * 3 + 0) % span);
+    r.ik1 = p.sample_left + (int)(pct_mix64(p.seed, g, c * 3 + 1) % span);
+    r.ik2 = p.sample_left + (int)(pct_mix64(p.seed, g, c * 3 + 2) % span);
+  }
+  // round(U(a,b), 3) (C/bin3D.py:106-108): the double nearest to k/1000
+  r.b0 = (double)r.ik0 / 1000.0; r.b1 = (double)r.ik1 / 1000.0; r.b2 = (double)r.ik2 / 1000.0;
+}
+
+// C/space.py:281-303 reset
+__device__ inline void cspace_reset(const ContinuousParams& p, CLds& l, CRegs& r, int lane) {
+  if (lane == 0) {
+    l.ems[0 * p.ems_cap] = 0.0; l.ems[1 * p.ems_cap] = 0.0; l.ems[2 * p.ems_cap] = 0.0;
+    l.ems[3 * p.ems_cap] = p.W; l.ems[4 * p.ems_cap] = p.Ly; l.ems[5 * p.ems_cap] = p.H;
+  }
+  r.n_ems = 1;
+  r.n_boxes = 0;
+  r.volsum = 0.0;
+}
+
+// rotation `rot` of the item (C/space.py:537-557): extents and the skip rule (abs < 1e-6)
+__device__ inline bool crot_size(const CRegs& r, int rot, double& sx, double& sy, double& sz) {
+  switch (rot) {
+    case 0: sx = r.b0; sy = r.b1; sz = r.b2; return false;
+    case 1: sx = r.b1; sy = r.b0; sz = r.b2; return fabs(sx - sy) < 1e-6;
+    case 2: sx = r.b0; sy = r.b2; sz = r.b1; return fabs(sx - sy) < 1e-6 && fabs(sy - sz) < 1e-6;
+    case 3: sx = r.b1; sy = r.b2; sz = r.b0; return fabs(sx - sy) < 1e-6 && fabs(sy - sz) < 1e-6;
+    case 4: sx = r.b2; sy = r.b0; sz = r.b1; return fabs(sx - sy) < 1e-6;
+    default: sx = r.b2; sy = r.b1; sz = r.b0; return fabs(sx - sy) < 1e-6;
+  }
+}
+
+// The 6-tuple a generator id stands for: g = (ems * orient + rot) * 4 + corner (:560-563)
+__device__ inline void cand_tuple(const ContinuousParams& p, const CLds& l, const CRegs& r, int orient, uint32_t g,
+                                  double t[6]) {
+  int corner = (int)(g & 3u);
+  int q = (int)(g >> 2);
+  int ei = q / orient, rot = q - ei * orient;
+  double sx, sy, sz;
+  crot_size(r, rot, sx, sy, sz);
+  double x0 = l.ems[0 * p.ems_cap + ei], y0 = l.ems[1 * p.ems_cap + ei], z0 = l.ems[2 * p.ems_cap + ei];
+  double x1 = l.ems[3 * p.ems_cap + ei], y1 = l.ems[4 * p.ems_cap + ei];
+  if (corner & 1) { t[0] = x1 - sx; t[3] = x1; } else { t[0] = x0; t[3] = x0 + sx; }
+  if (corner & 2) { t[1] = y1 - sy; t[4] = y1; } else { t[1] = y0; t[4] = y0 + sy; }
+  t[2] = z0;
+  t[5] = z0 + sz;
+}
+__device__ inline bool tuple_eq(const double a[6], const double b[6]) {
+  return (a[0] == b[0]) & (a[1] == b[1]) & (a[2] == b[2]) & (a[3] == b[3]) & (a[4] == b[4]) & (a[5] == b[5]);
+}
+// table word of a key: 15-bit fingerprint of its hash | 16-bit generator id (tag bit clear)
+__device__ inline uint32_t cword(uint64_t hash, uint32_t g) { return (uint32_t)((hash >> 40) & 0x7FFFu) << 16 | g; }
+
+// C/space.py:441-487 GENEMS + :510-528 EliminateInscribedEMS.  l.ems -> l.ems.
+__device__ inline void cgenems(const ContinuousParams& p, CLds& l, CRegs& r, int lane, const double loc[6]) {
+  const int E = r.n_ems, cap = p.ems_cap;
+  const double lb = p.low_bound;
+  const uint64_t lt = lanemask_lt(lane);
+  const double n0 = -loc[0], n1 = -loc[1], n2 = -loc[2];
+  int S = 0;
+  for (int base = 0; base < E; base += 64) {
+    int i = base + lane;
+    bool live = i < E;
+    double e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0, e5 = 0;
+    if (live) {
+      e0 = l.ems[0 * cap + i]; e1 = l.ems[1 * cap + i]; e2 = l.ems[2 * cap + i];
+      e3 = l.ems[3 * cap + i]; e4 = l.ems[4 * cap + i]; e5 = l.ems[5 * cap + i];
+    }
+    // np.around(np.minimum(item, EMS), 6) decides on the lattice: compare indices
+    int k0 = min(klat(n0), klat(-e0)), k1 = min(klat(n1), klat(-e1)), k2 = min(klat(n2), klat(-e2));
+    int k3 = min(klat(loc[3]), klat(e3)), k4 = min(klat(loc[4]), klat(e4)), k5 = min(klat(loc[5]), klat(e5));
+    bool inter = live && (k0 + k3 > 0) && (k1 + k4 > 0) && (k2 + k5 > 0);
+    bool surv = live && !inter;
+    uint64_t m = __ballot(surv);
+    if (surv) {
+      int o = S + __popcll(m & lt);
+      l.ems_b[0 * cap + o] = e0; l.ems_b[1 * cap + o] = e1; l.ems_b[2 * cap + o] = e2;
+      l.ems_b[3 * cap + o] = e3; l.ems_b[4 * cap + o] = e4; l.ems_b[5 * cap + o] = e5;
+    }
+    S += __popcll(m);
+  }
+  int C = 0;
+  for (int base = 0; base < E; base += 64) {
+    int i = base + lane;
+    bool live = i < E;
+    double x1 = 0, y1 = 0, z1 = 0, x2 = 0, y2 = 0, z2 = 0;
+    if (live) {
+      x1 = l.ems[0 * cap + i]; y1 = l.ems[1 * cap + i]; z1 = l.ems[2 * cap + i];
+      x2 = l.ems[3 * cap + i]; y2 = l.ems[4 * cap + i]; z2 = l.ems[5 * cap + i];
+    }
+    double q0 = around6(fmin(n0, -x1)), q1 = around6(fmin(n1, -y1)), q2 = around6(fmin(n2, -z1));
+    double q3 = around6(fmin(loc[3], x2)), q4 = around6(fmin(loc[4], y2)), q5 = around6(fmin(loc[5], z2));
+    bool inter = live && (q0 + q3 > 0) && (q1 + q4 > 0) && (q2 + q5 > 0);
+    double x3 = -q0, y3 = -q1, x4 = q3, y4 = q4, z4 = q5;  // intersect[:, 0:3] *= -1
+    bool uy = (y2 - y1 + 1e-6 >= lb), uz = (z2 - z1 + 1e-6 >= lb), ux = (x2 - x1 + 1e-6 >= lb);
+    bool c0 = inter && (x3 - x1 + 1e-6 >= lb) && uy && uz;  // [x1,y1,z1,x3,y2,z2]
+    bool c1 = inter && (x2 - x4 + 1e-6 >= lb) && uy && uz;  // [x4,y1,z1,x2,y2,z2]
+    bool c2 = inter && ux && (y3 - y1 + 1e-6 >= lb) && uz;  // [x1,y1,z1,x2,y3,z2]
+    bool c3 = inter && ux && (y2 - y4 + 1e-6 >= lb) && uz;  // [x1,y4,z1,x2,y2,z2]
+    bool c4 = inter && ux && uy && (z2 - z4 + 1e-6 >= lb);  // [x1,y1,z4,x2,y2,z2]
+    uint64_t m0 = __ballot(c0), m1 = __ballot(c1), m2 = __ballot(c2), m3 = __ballot(c3), m4 = __ballot(c4);
+    int pos = S + C + __popcll(m0 & lt) + __popcll(m1 & lt) + __popcll(m2 & lt) + __popcll(m3 & lt) +
+              __popcll(m4 & lt);
+#define PCT_PUT(A, B, Cc, D, Ee, F)                                                                   \
+  do {                                                                                               \
+    if (pos < cap) {                                                                                 \
+      l.ems_b[0 * cap + pos] = (A); l.ems_b[1 * cap + pos] = (B); l.ems_b[2 * cap + pos] = (Cc);     \
+      l.ems_b[3 * cap + pos] = (D); l.ems_b[4 * cap + pos] = (Ee); l.ems_b[5 * cap + pos] = (F);     \
+    }                                                                                                \
+    pos++;                                                                                           \
+  } while (0)
+    if (c0) PCT_PUT(x1, y1, z1, x3, y2, z2);
+    if (c1) PCT_PUT(x4, y1, z1, x2, y2, z2);
+    if (c2) PCT_PUT(x1, y1, z1, x2, y3, z2);
+    if (c3) PCT_PUT(x1, y4, z1, x2, y2, z2);
+    if (c4) PCT_PUT(x1, y1, z4, x2, y2, z2);
+#undef PCT_PUT
+    C += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3) + __popcll(m4);
+  }
+  int n = S + C;
+  if (n > cap) {
+    n = cap;
+    r.flags |= PCT_FLAG_EMS_OVERFLOW;
+  }
+  __syncthreads();
+  // survivors stay (the pre-GENEMS list is containment-free and a child lies inside its
+  // parent), children are tested against the whole list with exact float compares
+  int keepS = S < n ? S : n;
+  for (int i = lane; i < keepS; i += 64)
+    for (int c = 0; c < 6; c++) l.ems[c * cap + i] = l.ems_b[c * cap + i];
+  int out = keepS;
+  for (int base = keepS; base < n; base += 64) {
+    int i = base + lane;
+    bool live = i < n;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
+    if (live) {
+      a0 = l.ems_b[0 * cap + i]; a1 = l.ems_b[1 * cap + i]; a2 = l.ems_b[2 * cap + i];
+      a3 = l.ems_b[3 * cap + i]; a4 = l.ems_b[4 * cap + i]; a5 = l.ems_b[5 * cap + i];
+    }
+    bool del = false;
+    for (int j = 0; j < n; j++) {
+      double b0 = l.ems_b[0 * cap + j], b1 = l.ems_b[1 * cap + j], b2 = l.ems_b[2 * cap + j];
+      double b3 = l.ems_b[3 * cap + j], b4 = l.ems_b[4 * cap + j], b5 = l.ems_b[5 * cap + j];
+      bool inside = (a0 >= b0) & (a1 >= b1) & (a2 >= b2) & (a3 <= b3) & (a4 <= b4) & (a5 <= b5);
+      del |= inside & (j != i);
+    }
+    bool keep = live && !del;
+    uint64_t m = __ballot(keep);
+    if (keep) {
+      int o = out + __popcll(m & lt);
+      l.ems[0 * cap + o] = a0; l.ems[1 * cap + o] = a1; l.ems[2 * cap + o] = a2;
+      l.ems[3 * cap + o] = a3; l.ems[4 * cap + o] = a4; l.ems[5 * cap + o] = a5;
+    }
+    out += __popcll(m);
+  }
+  r.n_ems = out;
+  __syncthreads();
+}
+
+// C/space.py:531-568 EMSPoint (CPython set order over float tuples) + C/bin3D.py:118-148
+template <typename TM>
+__device__ inline void cleaf_nodes(const ContinuousParams& p, CLds& l, CRegs& r, int lane, TM& tm) {
+  const uint64_t lt = lanemask_lt(lane);
+  const int E = r.n_ems, cap = p.ems_cap;
+  const int orient = (p.setting == 2) ? 6 : 2;
+  const int NP = E * orient;
+  const uint32_t EMPTY = SlotWord<uint32_t>::EMPTY;
+  uint32_t size = 8, fill = 0;
+  uint32_t* const tabs = l.tab;
+  uint32_t toff = table_region(p.cand_cap, size);
+  if (lane < 8) tabs[toff + lane] = EMPTY;
+  __syncthreads();
+  bool cand_overflow = false;
+  int npend = 0;
+
+  auto flush = [&](int cnt) {
+    bool pending = lane < cnt;
+    uint32_t g = pending ? l.pend[lane] : 0u;
+    uint32_t mv = (lane + 64 < npend) ? l.pend[lane + 64] : 0u;
+    __syncthreads();
+    if (lane + 64 < npend) l.pend[lane] = mv;
+    npend -= cnt;
+    double t[6];
+    cand_tuple(p, l, r, orient, g, t);
+    uint64_t hash = tuplehash6d(t);
+    l.bhash[lane] = hash;
+    l.bg[lane] = g;
+    __syncthreads();
+    {  // exact in-batch de-duplication (first occurrence stays)
+      bool dup = false;
+      for (int i = 0; i < cnt; i++) {
+        if (l.bhash[i] == hash && i < lane && !dup) {
+          double o[6];
+          cand_tuple(p, l, r, orient, l.bg[i], o);
+          dup = tuple_eq(o, t);
+        }
+      }
+      pending = pending && !dup;
+    }
+    const uint32_t word = cword(hash, g);
+    auto same = [&](uint32_t w) -> bool {
+      if ((w >> 16) != (word >> 16)) return false;  // different hash
+      double o[6];
+      cand_tuple(p, l, r, orient, w & 0xFFFFu, o);
+      return tuple_eq(o, t);
+    };
+    while (true) {
+      uint64_t pm = __ballot(pending);
+      if (!pm) break;
+      uint32_t mask = size - 1;
+      uint32_t thr = (mask * 3u + 4u) / 5u;
+      bool part = pending && (uint32_t)__popcll(pm & lt) < thr - fill;
+      bool placed;
+      uint32_t slot;
+      pyset_match<uint32_t>(tabs + toff, mask, part, hash, lane, true, placed, slot, same);
+      if (placed) tabs[toff + slot] = word;
+      pending = pending && !part;
+      fill += (uint32_t)__popcll(__ballot(placed));
+      __syncthreads();
+      if (fill >= thr) {
+        uint32_t newsize = 8;
+        while (newsize <= fill * 4u) newsize <<= 1;
+        if (newsize > (uint32_t)p.cand_cap) {
+          cand_overflow = true;
+          break;
+        }
+        const uint32_t noff = table_region(p.cand_cap, newsize);
+        for (uint32_t s2 = lane; s2 < newsize; s2 += 64) tabs[noff + s2] = EMPTY;
+        __syncthreads();
+        for (uint32_t sb = 0; sb < size; sb += 64) {
+          uint32_t s2 = sb + lane;
+          uint32_t ow = (s2 < size) ? tabs[toff + s2] : EMPTY;
+          bool opart = ow != EMPTY;
+          double o[6];
+          cand_tuple(p, l, r, orient, opart ? (ow & 0xFFFFu) : 0u, o);
+          bool oplaced;
+          uint32_t oslot;
+          pyset_match<uint32_t>(tabs + noff, newsize - 1, opart, tuplehash6d(o), lane, false, oplaced, oslot,
+                                [&](uint32_t) { return false; });
+          if (oplaced) tabs[noff + oslot] = ow;
+          __syncthreads();
+        }
+        toff = noff;
+        size = newsize;
+      }
+    }
+  };
+
+  for (int pbase = 0; pbase < NP && !cand_overflow; pbase += 64) {
+    int q = pbase + lane;
+    bool pv = q < NP;
+    int ei = q / orient, rot = q - ei * orient;
+    double sx, sy, sz;
+    bool skip = crot_size(r, rot, sx, sy, sz);
+    if (pv) {
+      double x0 = l.ems[0 * cap + ei], y0 = l.ems[1 * cap + ei], z0 = l.ems[2 * cap + ei];
+      double x1 = l.ems[3 * cap + ei], y1 = l.ems[4 * cap + ei], z1 = l.ems[5 * cap + ei];
+      pv = !skip && (x1 - x0 + 1e-6 >= sx) && (y1 - y0 + 1e-6 >= sy) && (z1 - z0 + 1e-6 >= sz);
+    }
+    uint64_t pm = __ballot(pv);
+    const int nt = 4 * __popcll(pm);
+    if (pv) l.vp[__popcll(pm & lt)] = (uint16_t)q;
+    __syncthreads();
+    for (int tb = 0; tb < nt && !cand_overflow; tb += 64) {
+      int tt = tb + lane;
+      bool valid = tt < nt;
+      uint32_t g = valid ? ((uint32_t)l.vp[tt >> 2] << 2 | (uint32_t)(tt & 3)) : 0u;
+      double t[6];
+      cand_tuple(p, l, r, orient, g, t);
+      uint64_t hash = tuplehash6d(t);
+      const uint32_t fp = cword(hash, 0) >> 16;
+      bool fresh = valid && !pyset_contains<uint32_t>(tabs + toff, size - 1, hash, [&](uint32_t w) -> bool {
+        if ((w >> 16) != fp) return false;
+        double o[6];
+        cand_tuple(p, l, r, orient, w & 0xFFFFu, o);
+        return tuple_eq(o, t);
+      });
+      uint64_t nm = __ballot(fresh);
+      if (fresh) l.pend[npend + __popcll(nm & lt)] = g;
+      npend += __popcll(nm);
+      __syncthreads();
+      if (npend >= 64) flush(64);
+    }
+    __syncthreads();
+  }
+  while (npend > 0 && !cand_overflow) flush(npend < 64 ? npend : 64);
+  if (cand_overflow) r.flags |= PCT_FLAG_CANDIDATE_OVERFLOW;
+  __syncthreads();
+
+  // list(set): generator ids in slot order
+  int norder = 0;
+  for (uint32_t sb = 0; sb < size; sb += 64) {
+    uint32_t s = sb + lane;
+    uint32_t w = (s < size) ? tabs[toff + s] : EMPTY;
+    uint64_t m = __ballot(w != EMPTY);
+    if (w != EMPTY) l.order[norder + __popcll(m & lt)] = (uint16_t)(w & 0xFFFFu);
+    norder += __popcll(m);
+  }
+  __syncthreads();
+  tm.tick(PH_SET);
+
+  // feasibility in list order (C/space.py:380-425 drop_box_virtual, setting 2), first L kept
+  int nleaf = 0;
+  const int nb = r.n_boxes;
+  for (int base = 0; base < norder && nleaf < p.L; base += 64) {
+    int i = base + lane;
+    bool live = i < norder;
+    double t[6];
+    cand_tuple(p, l, r, orient, live ? (uint32_t)l.order[i] : 0u, t);
+    double lx = t[0], ly = t[1];
+    double x = t[3] - t[0], y = t[4] - t[1], z = t[5] - t[2];
+    bool ok = live;
+    if (lx + x - 1e-6 > p.W || ly + y - 1e-6 > p.Ly) ok = false;
+    if (lx + 1e-6 < 0 || ly + 1e-6 < 0) ok = false;
+    // interSect2D (:305-314) on lattice indices; tops stay float64
+    int c0 = klat(-lx), c1 = klat(-ly), c2 = klat(lx + x), c3 = klat(ly + y);
+    double max_h = 0.0;
+    for (int b = 0; b < nb; b++) {
+      int u0 = l.bk[0 * p.I + b], u1 = l.bk[1 * p.I + b], u2 = l.bk[2 * p.I + b], u3 = l.bk[3 * p.I + b];
+      bool ov = (min(c0, u0) + min(c2, u2) > 0) && (min(c1, u1) + min(c3, u3) > 0);
+      double top = l.box[5 * p.I + b];
+      max_h = (ov && top > max_h) ? top : max_h;
+    }
+    if (max_h + z - 1e-6 > p.H) ok = false;
+    uint64_t m = __ballot(ok);
+    int idx = nleaf + __popcll(m & lt);
+    if (ok && idx < p.L) {
+#pragma unroll
+      for (int c = 0; c < 6; c++) l.leaf[c * p.L + idx] = t[c];
+    }
+    nleaf += __popcll(m);
+  }
+  r.n_leaf = nleaf < p.L ? nleaf : p.L;
+  __syncthreads();
+  tm.tick(PH_FEAS);
+}
+
+// C/bin3D.py:78-100 observation rows, float32 (envs.py:180)
+__device__ inline void cwrite_obs(const ContinuousParams& p, const CLds& l, const CRegs& r, int lane,
+                                  float* __restrict__ obs) {
+  double a = r.b0, b = r.b1, c = r.b2, tmp;
+  if (a > b) { tmp = a; a = b; b = tmp; }
+  if (b > c) { tmp = b; b = c; c = tmp; }
+  if (a > b) { tmp = a; a = b; b = tmp; }
+  for (int f = lane; f < p.row_len; f += 64) {
+    int row = f / 9;
+    int col = f - row * 9;
+    float v = 0.f;
+    if (row < p.I) {
+      if (row < r.n_boxes) {
+        v = col < 6 ? (float)l.box[col * p.I + row] : (col == 8 ? 1.0f : 0.f);  // density column is 0 (:372-373)
+      } else if (row == 0 && col == 8) {
+        v = 1.0f;
+      }
+    } else if (row < p.I + p.L) {
+      int j = row - p.I;
+      if (j < r.n_leaf) v = col < 5 ? (float)l.leaf[col * p.L + j] : (col == 5 ? (float)p.H : (col == 8 ? 1.0f : 0.f));
+    } else {
+      v = col == 0 ? 1.0f : (col == 3 ? (float)a : (col == 4 ? (float)b : (col == 5 ? (float)c : (col == 8 ? 1.0f : 0.f))));
+    }
+    obs[f] = v;
+  }
+}
+
+__device__ inline void cload(const ContinuousParams& p, int e, CLds& l, CRegs& r, int lane) {
+  const int32_t* sc = p.scalars + (size_t)e * PCT_SCALARS;
+  r.n_ems = sc[0]; r.n_boxes = sc[1]; r.n_leaf = sc[2];
+  r.ik0 = sc[3]; r.ik1 = sc[4]; r.ik2 = sc[5];
+  r.b0 = (double)r.ik0 / 1000.0; r.b1 = (double)r.ik1 / 1000.0; r.b2 = (double)r.ik2 / 1000.0;
+  r.t = (uint32_t)sc[6];
+  r.cursor = ((uint64_t)(uint32_t)sc[9] << 32) | (uint32_t)sc[8];
+  r.flags = p.flags[e];
+  r.volsum = p.volsum[e];
+  const double* ge = p.ems + (size_t)e * 6 * p.ems_cap;
+  const double* gb = p.boxes + (size_t)e * 6 * p.I;
+  const double* gl = p.leaves + (size_t)e * 6 * p.L;
+  for (int c = 0; c < 6; c++) {
+    for (int i = lane; i < r.n_ems; i += 64) l.ems[c * p.ems_cap + i] = ge[c * p.ems_cap + i];
+    for (int i = lane; i < r.n_boxes; i += 64) l.box[c * p.I + i] = gb[c * p.I + i];
+    for (int i = lane; i < r.n_leaf; i += 64) l.leaf[c * p.L + i] = gl[c * p.L + i];
+  }
+  __syncthreads();
+  for (int i = lane; i < r.n_boxes; i += 64) {
+    l.bk[0 * p.I + i] = klat(-l.box[0 * p.I + i]);
+    l.bk[1 * p.I + i] = klat(-l.box[1 * p.I + i]);
+    l.bk[2 * p.I + i] = klat(l.box[3 * p.I + i]);
+    l.bk[3 * p.I + i] = klat(l.box[4 * p.I + i]);
+  }
+  __syncthreads();
+}
+
+__device__ inline void cstore(const ContinuousParams& p, int e, const CLds& l, const CRegs& r, int lane) {
+  int32_t* sc = p.scalars + (size_t)e * PCT_SCALARS;
+  double* ge = p.ems + (size_t)e * 6 * p.ems_cap;
+  double* gb = p.boxes + (size_t)e * 6 * p.I;
+  double* gl = p.leaves + (size_t)e * 6 * p.L;
+  for (int c = 0; c < 6; c++) {
+    for (int i = lane; i < r.n_ems; i += 64) ge[c * p.ems_cap + i] = l.ems[c * p.ems_cap + i];
+    for (int i = lane; i < r.n_boxes; i += 64) gb[c * p.I + i] = l.box[c * p.I + i];
+    for (int i = lane; i < r.n_leaf; i += 64) gl[c * p.L + i] = l.leaf[c * p.L + i];
+  }
+  if (lane == 0) {
+    sc[0] = r.n_ems; sc[1] = r.n_boxes; sc[2] = r.n_leaf;
+    sc[3] = r.ik0; sc[4] = r.ik1; sc[5] = r.ik2;
+    sc[6] = (int32_t)r.t;
+    sc[8] = (int32_t)(uint32_t)r.cursor; sc[9] = (int32_t)(uint32_t)(r.cursor >> 32);
+    p.flags[e] = r.flags;
+    p.volsum[e] = r.volsum;
+  }
+}
+
+// C/bin3D.py:169-207 step (+ the VecEnv worker's auto-reset).  a1/a2: raw position entries of
+// the action, (bx,by,bz): the item as LeafNode2Action returns it.
+template <typename TM>
+__device__ inline void ctransition(const ContinuousParams& p, int e, CLds& l, CRegs& r, int lane, int flag, double a1,
+                                   double a2, double bx, double by, double bz, TM& tm) {
+  r.t++;
+  const double lx = around6(a1), ly = around6(a2);  // idx = [round(action[1], 6), round(action[2], 6)]
+  const double x = flag ? by : bx, y = flag ? bx : by, z = bz;  // C/space.py:330-333
+  bool ok = true;
+  if (lx + x - 1e-6 > p.W || ly + y - 1e-6 > p.Ly) ok = false;
+  if (lx + 1e-6 < 0 || ly + 1e-6 < 0) ok = false;
+  double max_h = 0.0;
+  if (ok) {
+    int c0 = klat(-lx), c1 = klat(-ly), c2 = klat(lx + x), c3 = klat(ly + y);
+    double m = 0.0;
+    for (int b = lane; b < r.n_boxes; b += 64) {
+      int u0 = l.bk[0 * p.I + b], u1 = l.bk[1 * p.I + b], u2 = l.bk[2 * p.I + b], u3 = l.bk[3 * p.I + b];
+      bool ov = (min(c0, u0) + min(c2, u2) > 0) && (min(c1, u1) + min(c3, u3) > 0);
+      double top = l.box[5 * p.I + b];
+      m = (ov && top > m) ? top : m;
+    }
+    max_h = wave_max_f64(m);
+    if (max_h + z - 1e-6 > p.H) ok = false;
+  }
+  if (ok && r.n_boxes >= p.I) {  // IndexError at C/space.py:371
+    ok = false;
+    r.flags |= PCT_FLAG_INTERNAL_OVERFLOW;
+  }
+  const double mx = (double)((long long)p.W * (long long)p.Ly * (long long)p.H);
+  float reward;
+  uint8_t done;
+  int counter;
+  double ratio = 0.0;
+  if (ok) {
+    const double top = max_h + z, xe = lx + x, ye = ly + y;
+    const int bi = r.n_boxes;
+    if (lane == 0) {
+      l.box[0 * p.I + bi] = lx; l.box[1 * p.I + bi] = ly; l.box[2 * p.I + bi] = max_h;
+      l.box[3 * p.I + bi] = xe; l.box[4 * p.I + bi] = ye; l.box[5 * p.I + bi] = top;
+      l.bk[0 * p.I + bi] = klat(-lx); l.bk[1 * p.I + bi] = klat(-ly);
+      l.bk[2 * p.I + bi] = klat(xe); l.bk[3 * p.I + bi] = klat(ye);
+    }
+    r.n_boxes++;
+    r.volsum = r.volsum + x * y * z;  // get_ratio's left fold (:316-321)
+    __syncthreads();
+    tm.tick(PH_DROP);
+    // GENEMS([lx, ly, lz, round(lx+x,6), round(ly+y,6), round(lz+z,6)]) (C/bin3D.py:190-194)
+    const double loc[6] = {lx, ly, max_h, around6(lx + x), around6(ly + y), around6(max_h + z)};
+    cgenems(p, l, r, lane, loc);
+    tm.tick(PH_GENEMS);
+    reward = (float)(((r.b0 * r.b1 * r.b2) / mx) * 10);
+    done = 0;
+    counter = r.n_boxes;
+  } else {
+    reward = 0.f;
+    done = 1;
+    counter = r.n_boxes;
+    ratio = r.volsum / mx;
+    __syncthreads();
+    cspace_reset(p, l, r, lane);
+    __syncthreads();
+    tm.tick(PH_DROP);
+  }
+  cdraw_item(p, e, r);
+  if (lane == 0) {
+    p.reward[e] = reward;
+    p.done[e] = done;
+    p.counter[e] = counter;
+    p.ratio[e] = ratio;
+  }
+}
+
+// C/bin3D.py:151-167 LeafNode2Action on a float64 row (a0,a1,_,a3,a4,_)
+__device__ inline void cdecode_leaf(const CRegs& r, bool zero_row, double a0, double a1, double a3, double a4, double& p1,
+                                    double& p2, double& bx, double& by, double& bz) {
+  if (zero_row) {
+    p1 = 0; p2 = 0; bx = r.b0; by = r.b1; bz = r.b2;
+    return;
+  }
+  double x = around6(a3 - a0), y = around6(a4 - a1);
+  const double nb[3] = {r.b0, r.b1, r.b2};
+  int rec[3] = {0, 1, 2}, nr = 3;
+  for (int i = 0; i < nr; i++)
+    if (fabs(x - nb[rec[i]]) < 1e-6) {
+      for (int j = i; j < nr - 1; j++) rec[j] = rec[j + 1];
+      nr--;
+      break;
+    }
+  for (int i = 0; i < nr; i++)
+    if (fabs(y - nb[rec[i]]) < 1e-6) {
+      for (int j = i; j < nr - 1; j++) rec[j] = rec[j + 1];
+      nr--;
+      break;
+    }
+  p1 = a0; p2 = a1; bx = x; by = y; bz = nb[rec[0]];
+}
+
+enum { CACT_ROWS = 0, CACT_INDEX = 1, CACT_HASH = 2, CACT_RESET = 3 };
+
+template <int ACT, bool TIMED>
+__global__ void __launch_bounds__(64) pct_continuous_kernel(ContinuousParams p, const void* __restrict__ actions,
+                                                            int row_len, int n_steps,
+                                                            const int32_t* __restrict__ env_ids, int n_ids) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = threadIdx.x;
+  int e = blockIdx.x;
+  if (ACT == CACT_RESET && env_ids) {
+    if (e >= n_ids) return;
+    e = env_ids[e];
+    if (e < 0 || e >= p.N) return;
+  }
+  CLds l = carve(p, smem);
+  CRegs r;
+  PhaseTimer<TIMED> tm;
+  tm.start();
+  cload(p, e, l, r, lane);
+  tm.tick(PH_LOAD);
+  float* obs = p.obs + (size_t)e * p.row_len;
+
+  if (ACT == CACT_RESET) {
+    cspace_reset(p, l, r, lane);
+    __syncthreads();
+    cdraw_item(p, e, r);
+    cleaf_nodes(p, l, r, lane, tm);
+    cwrite_obs(p, l, r, lane, obs);
+    cstore(p, e, l, r, lane);
+    return;
+  }
+
+  for (int it = 0; it < n_steps; it++) {
+    int flag = 0;
+    double p1 = 0, p2 = 0, bx = 0, by = 0, bz = 0;
+    if (ACT == CACT_ROWS) {
+      const float* row = reinterpret_cast<const float*>(actions) + (size_t)e * row_len;
+      float v = lane < row_len ? row[lane] : 0.f;
+      double a0 = (double)__shfl(v, 0, 64), a1 = (double)__shfl(v, 1, 64), a2 = (double)__shfl(v, 2, 64),
+             a3 = (double)__shfl(v, 3, 64), a4 = (double)__shfl(v, 4, 64), a5 = (double)__shfl(v, 5, 64);
+      if (row_len == 3) {
+        flag = (int)a0; p1 = a1; p2 = a2;
+        bx = r.b0; by = r.b1; bz = r.b2;
+      } else {
+        double sum = ((((a0 + a1) + a2) + a3) + a4) + a5;  // np.sum(leaf_node[0:6]) == 0
+        // A float32 row cannot carry the 1e-6 resolution the reference's round(.,6) decode
+        // assumes (float32 spacing is 9.5e-7 above 8).  The trainer's row is the float32 cast
+        // of one of this env's current leaf rows (train_tools.py:66), so it is matched back to
+        // that leaf and decoded from the leaf's own float64 values; a row that matches no leaf
+        // is decoded from the widened floats.
+        int match = -1;
+        for (int base = 0; base < r.n_leaf && match < 0; base += 64) {
+          int j = base + lane;
+          bool eq = j < r.n_leaf && (float)l.leaf[0 * p.L + j] == (float)a0 && (float)l.leaf[1 * p.L + j] == (float)a1 &&
+                    (float)l.leaf[2 * p.L + j] == (float)a2 && (float)l.leaf[3 * p.L + j] == (float)a3 &&
+                    (float)l.leaf[4 * p.L + j] == (float)a4;
+          uint64_t m = __ballot(eq);
+          if (m) match = base + __ffsll((unsigned long long)m) - 1;
+        }
+        if (match >= 0 && sum != 0.0) {
+          a0 = l.leaf[0 * p.L + match]; a1 = l.leaf[1 * p.L + match];
+          a3 = l.leaf[3 * p.L + match]; a4 = l.leaf[4 * p.L + match];
+        }
+        cdecode_leaf(r, sum == 0.0, a0, a1, a3, a4, p1, p2, bx, by, bz);
+      }
+    } else {
+      int64_t li;
+      if (ACT == CACT_INDEX) li = reinterpret_cast<const int64_t*>(actions)[e];
+      else li = r.n_leaf > 0 ? (int64_t)(pct_mix32((uint32_t)(p.env_id_base + e), r.t) % (uint32_t)r.n_leaf) : 0;
+      bool zero_row = !(li >= 0 && li < r.n_leaf);
+      int q = zero_row ? 0 : (int)li;
+      double a0 = l.leaf[0 * p.L + q], a1 = l.leaf[1 * p.L + q], a3 = l.leaf[3 * p.L + q], a4 = l.leaf[4 * p.L + q];
+      if (!zero_row) {  // a valid leaf row sums to > 0 unless it is the all-zero row
+        double sum = ((((a0 + a1) + l.leaf[2 * p.L + q]) + a3) + a4) + p.H;
+        zero_row = (sum == 0.0);
+      }
+      cdecode_leaf(r, zero_row, a0, a1, a3, a4, p1, p2, bx, by, bz);
+    }
+    ctransition(p, e, l, r, lane, flag, p1, p2, bx, by, bz, tm);
+    cleaf_nodes(p, l, r, lane, tm);
+    cwrite_obs(p, l, r, lane, obs);
+    __syncthreads();
+    tm.tick(PH_OBS);
+  }
+  cstore(p, e, l, r, lane);
+  tm.tick(PH_STORE);
+  if (TIMED && lane == 0) tm.flush(p.timing + (size_t)e * 8, n_steps);
+}
+
+// stand-in policy kernel on the float32 observation (same as the discrete one)
+__global__ void __launch_bounds__(64) pct_cpolicy_hash_rows_kernel(ContinuousParams p, float* __restrict__ rows_out) {
+  const int lane = threadIdx.x;
+  const int e = blockIdx.x;
+  const float* obs = p.obs + (size_t)e * p.row_len;
+  int k = 0;
+  for (int base = 0; base < p.L; base += 64) {
+    int j = base + lane;
+    bool v = j < p.L && obs[(p.I + j) * 9 + 8] != 0.f;
+    k += __popcll(__ballot(v));
+  }
+  uint32_t t = (uint32_t)p.scalars[(size_t)e * PCT_SCALARS + 6];
+  int li = k > 0 ? (int)(pct_mix32((uint32_t)(p.env_id_base + e), t) % (uint32_t)k) : 0;
+  if (lane < 9) rows_out[(size_t)e * 9 + lane] = obs[(p.I + li) * 9 + lane];
+}
+
+hipError_t launch_cpolicy_hash_rows(const ContinuousParams& p, float* rows_out, hipStream_t stream) {
+  hipLaunchKernelGGL(pct_cpolicy_hash_rows_kernel, dim3(p.N), dim3(64), 0, stream, p, rows_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_continuous(const ContinuousParams& p, int act, const void* actions, int row_len, int n_steps,
+                             const int32_t* env_ids, int n_ids, hipStream_t stream) {
+  size_t lds = continuous_lds_bytes(p);
+  const bool timed = p.timing != nullptr && act != CACT_RESET;
+  int grid = (act == CACT_RESET && env_ids) ? n_ids : p.N;
+  if (grid <= 0) return hipSuccess;
+#define PCT_CLAUNCH(A)                                                                                         \
+  do {                                                                                                         \
+    auto kern = timed ? pct_continuous_kernel<A, true> : pct_continuous_kernel<A, false>;                      \
+    if (lds > 48 * 1024) {                                                                                     \
+      hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                 \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
+      if (er != hipSuccess) return er;                                                                         \
+    }                                                                                                          \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, stream, p, actions, row_len, n_steps, env_ids, n_ids); \
+  } while (0)
+  switch (act) {
+    case CACT_ROWS: PCT_CLAUNCH(CACT_ROWS); break;
+    case CACT_INDEX: PCT_CLAUNCH(CACT_INDEX); break;
+    case CACT_HASH: PCT_CLAUNCH(CACT_HASH); break;
+    default: PCT_CLAUNCH(CACT_RESET); break;
+  }
+#undef PCT_CLAUNCH
+  return hipGetLastError();
+}
+
+}  // namespace pct

@@ -42,6 +42,37 @@ struct DiscreteParams {
   double* ratio;    /* [N] */
 };
 
+// HBM layout of the continuous env state (float64, SoA over envs; within an env every
+// coordinate column is contiguous: ems[c][i], boxes[c][i], leaves[c][i]).
+struct ContinuousParams {
+  int N, I, L, row_len, setting;
+  double W, Ly, H; /* container (integral values, as the reference's int64 plain_size) */
+  double low_bound; /* C/bin3D.py:25-29 size_minimum */
+  int ems_cap, cand_cap, order_cap, union_doubles;
+  int source, env_id_base;
+  int sample_left, sample_right; /* lattice 1e-3 */
+  long long T;
+  unsigned long long seed;
+  const int32_t* stream; /* [N,T,3] lattice 1e-3 */
+  double* ems;      /* [N,6,ems_cap] */
+  double* boxes;    /* [N,6,I] lx,ly,lz,xe,ye,top */
+  double* leaves;   /* [N,6,L] */
+  double* volsum;   /* [N] running sum of placed volumes (get_ratio) */
+  int32_t* scalars; /* [N,PCT_SCALARS] */
+  uint32_t* flags;
+  unsigned long long* timing;
+  float* obs;
+  float* reward;
+  uint8_t* done;
+  int32_t* counter;
+  double* ratio;
+};
+
+size_t continuous_lds_bytes(const ContinuousParams& p);
+hipError_t launch_cpolicy_hash_rows(const ContinuousParams& p, float* rows_out, hipStream_t stream);
+hipError_t launch_continuous(const ContinuousParams& p, int act, const void* actions, int row_len, int n_steps,
+                             const int32_t* env_ids, int n_ids, hipStream_t stream);
+
 size_t discrete_lds_bytes(const DiscreteParams& p);
 hipError_t launch_policy_hash_rows(const DiscreteParams& p, float* rows_out, hipStream_t stream);
 hipError_t launch_discrete(const DiscreteParams& p, int act, const void* actions, int row_len, int n_steps,

@@ -35,6 +35,8 @@ struct pct_env {
   pct_config cfg;
   int device;
   pct::DiscreteParams dp;
+  pct::ContinuousParams cp;
+  bool continuous;
   // owned device memory
   std::vector<void*> owned;
   float* own_obs;
@@ -103,7 +105,8 @@ int launch(pct_env* h, int act, const void* actions, int row_len, int n_steps, c
     int rc = prof_begin(h, s, &slot);
     if (rc) return rc;
   }
-  HIP_TRY(pct::launch_discrete(h->dp, act, actions, row_len, n_steps, ids, n_ids, s));
+  if (h->continuous) HIP_TRY(pct::launch_continuous(h->cp, act, actions, row_len, n_steps, ids, n_ids, s));
+  else HIP_TRY(pct::launch_discrete(h->dp, act, actions, row_len, n_steps, ids, n_ids, s));
   if (h->profiling) HIP_TRY(hipEventRecord(h->ev_pool[slot].second, s));
   return PCT_OK;
 }
@@ -123,7 +126,9 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
   if (!cfg || !out) return fail(PCT_ERR_INVALID_ARG, "null argument");
   if (cfg->struct_size != (int32_t)sizeof(pct_config))
     return fail(PCT_ERR_INVALID_ARG, "pct_config size mismatch (%d vs %d)", cfg->struct_size, (int)sizeof(pct_config));
-  if (cfg->env_kind != PCT_ENV_DISCRETE) return fail(PCT_ERR_UNSUPPORTED, "only the discrete env is built so far");
+  if (cfg->env_kind != PCT_ENV_DISCRETE && cfg->env_kind != PCT_ENV_CONTINUOUS)
+    return fail(PCT_ERR_INVALID_ARG, "unknown env_kind");
+  const bool cont = cfg->env_kind == PCT_ENV_CONTINUOUS;
   if (cfg->setting != 2) return fail(PCT_ERR_UNSUPPORTED, "only setting 2 is built so far");
   if (cfg->lnes != PCT_LNES_EMS) return fail(PCT_ERR_UNSUPPORTED, "only LNES=EMS is built so far");
   if (cfg->num_envs < 1 || cfg->internal_node_holder < 1 || cfg->leaf_node_holder < 1)
@@ -132,9 +137,11 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
   if (W < 1 || Ly < 1 || H < 1) return fail(PCT_ERR_INVALID_ARG, "bad container");
   int maxdim = W > Ly ? W : Ly;
   if (H > maxdim) maxdim = H;
-  if (maxdim > 1023) return fail(PCT_ERR_UNSUPPORTED, "discrete bins are limited to 1023 per axis");
+  if (!cont && maxdim > 1023) return fail(PCT_ERR_UNSUPPORTED, "discrete bins are limited to 1023 per axis");
+  if (cont && (W % 1000 || Ly % 1000 || H % 1000))
+    return fail(PCT_ERR_UNSUPPORTED, "continuous container sizes must be whole bin units (multiples of 1000 lattice units)");
   int ems_cap = cfg->ems_capacity > 0 ? cfg->ems_capacity : 256;
-  if (ems_cap < 256) return fail(PCT_ERR_INVALID_ARG, "ems_capacity must be >= 256");
+  if (!cont && ems_cap < 256) return fail(PCT_ERR_INVALID_ARG, "ems_capacity must be >= 256");
   int cand_cap = cfg->candidate_capacity > 0 ? cfg->candidate_capacity : 2048;
   if (!is_cand_cap_ok(cand_cap)) return fail(PCT_ERR_INVALID_ARG, "candidate_capacity must be 8*4^k (8,32,...,2048,8192)");
 
@@ -155,9 +162,55 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
   h->prof_launches = 0;
   h->prof_ms = 0.0;
   h->timing_buf = nullptr;
+  h->continuous = cont;
+  memset(&h->cp, 0, sizeof h->cp);
   int rc = use_device(h);
   if (rc) { delete h; return rc; }
 
+  if (cont) {
+    pct::ContinuousParams& c = h->cp;
+    c.N = cfg->num_envs;
+    c.I = cfg->internal_node_holder;
+    c.L = cfg->leaf_node_holder;
+    c.row_len = (c.I + c.L + 1) * 9;
+    c.setting = cfg->setting;
+    c.W = W / 1000; c.Ly = Ly / 1000; c.H = H / 1000;
+    c.ems_cap = ems_cap;
+    c.cand_cap = cand_cap;
+    c.order_cap = (cand_cap * 3) / 5 + 8;
+    size_t tab_doubles = ((size_t)(cand_cap + cand_cap / 4) * 4 + 7) / 8;
+    c.union_doubles = (int)(tab_doubles > (size_t)6 * ems_cap ? tab_doubles : (size_t)6 * ems_cap);
+    c.env_id_base = cfg->env_id_base;
+    c.source = PCT_ITEMS_NONE;
+    if ((size_t)ems_cap * 24 + 23 > 65535) { delete h; return fail(PCT_ERR_INVALID_ARG, "ems_capacity too large for 16-bit generator ids"); }
+    size_t clds = pct::continuous_lds_bytes(c);
+    if (clds > 160 * 1024) { delete h; return fail(PCT_ERR_INVALID_ARG, "capacities need %zu B of LDS (> 160 KiB)", clds); }
+    size_t Nn = (size_t)c.N;
+#define CALLOC_(ptr, bytes)                                  \
+  do {                                                       \
+    rc = dev_alloc(h, (void**)&(ptr), (bytes), true);        \
+    if (rc) { pct_destroy(h); return rc; }                   \
+  } while (0)
+    CALLOC_(c.ems, Nn * 6 * c.ems_cap * sizeof(double));
+    CALLOC_(c.boxes, Nn * 6 * c.I * sizeof(double));
+    CALLOC_(c.leaves, Nn * 6 * c.L * sizeof(double));
+    CALLOC_(c.volsum, Nn * sizeof(double));
+    CALLOC_(c.scalars, Nn * PCT_SCALARS * sizeof(int32_t));
+    CALLOC_(h->own_flags, Nn * sizeof(uint32_t));
+    CALLOC_(h->own_obs, Nn * c.row_len * sizeof(float));
+    CALLOC_(h->own_reward, Nn * sizeof(float));
+    CALLOC_(h->own_done, Nn);
+    CALLOC_(h->own_counter, Nn * sizeof(int32_t));
+    CALLOC_(h->own_ratio, Nn * sizeof(double));
+#undef CALLOC_
+    c.obs = h->own_obs; c.reward = h->own_reward; c.done = h->own_done; c.counter = h->own_counter;
+    c.ratio = h->own_ratio; c.flags = h->own_flags;
+    h->dp.N = c.N; h->dp.row_len = c.row_len; h->dp.I = c.I; h->dp.L = c.L;
+    h->dp.obs = c.obs; h->dp.reward = c.reward; h->dp.done = c.done; h->dp.counter = c.counter;
+    h->dp.ratio = c.ratio; h->dp.flags = c.flags;
+    *out = h;
+    return PCT_OK;
+  }
   pct::DiscreteParams& p = h->dp;
   memset(&p, 0, sizeof p);
   p.N = cfg->num_envs;
@@ -217,6 +270,7 @@ int pct_destroy(pct_env* h) {
 
 int pct_set_item_set(pct_env* h, const int32_t* item_set, int32_t n) {
   if (!h || !item_set || n < 1) return fail(PCT_ERR_INVALID_ARG, "bad item set");
+  if (h->continuous) return fail(PCT_ERR_UNSUPPORTED, "the continuous env takes pct_set_sample_bounds");
   int rc = use_device(h);
   if (rc) return rc;
   int mn = item_set[0], mx = item_set[0];
@@ -239,8 +293,13 @@ int pct_set_item_set(pct_env* h, const int32_t* item_set, int32_t n) {
 }
 
 int pct_set_sample_bounds(pct_env* h, int32_t left, int32_t right) {
-  (void)h; (void)left; (void)right;
-  return fail(PCT_ERR_UNSUPPORTED, "continuous env not built yet");
+  if (!h || !h->continuous) return fail(PCT_ERR_INVALID_ARG, "sample bounds apply to the continuous env");
+  if (left < 1 || right < left) return fail(PCT_ERR_INVALID_ARG, "bad bounds");
+  h->cp.sample_left = left;
+  h->cp.sample_right = right;
+  h->cp.low_bound = (double)left / 1000.0; /* C/bin3D.py:25-27 */
+  h->have_items = true;
+  return PCT_OK;
 }
 
 int pct_set_item_stream(pct_env* h, const int32_t* items, int64_t T) {
@@ -256,6 +315,9 @@ int pct_set_item_stream(pct_env* h, const int32_t* items, int64_t T) {
   h->dp.stream = h->d_stream;
   h->dp.T = T;
   h->dp.source = PCT_ITEMS_STREAM;
+  h->cp.stream = h->d_stream;
+  h->cp.T = T;
+  h->cp.source = PCT_ITEMS_STREAM;
   return PCT_OK;
 }
 
@@ -264,6 +326,8 @@ int pct_set_sampler(pct_env* h, uint64_t seed) {
   if (!h->have_items) return fail(PCT_ERR_STATE, "pct_set_item_set must come first");
   h->dp.seed = seed;
   h->dp.source = PCT_ITEMS_SAMPLER;
+  h->cp.seed = seed;
+  h->cp.source = PCT_ITEMS_SAMPLER;
   return PCT_OK;
 }
 
@@ -276,6 +340,8 @@ int pct_bind_outputs(pct_env* h, float* obs, float* reward, uint8_t* done, int32
   h->dp.counter = counter ? counter : h->own_counter;
   h->dp.ratio = ratio ? ratio : h->own_ratio;
   h->dp.flags = error_flags ? error_flags : h->own_flags;
+  h->cp.obs = h->dp.obs; h->cp.reward = h->dp.reward; h->cp.done = h->dp.done; h->cp.counter = h->dp.counter;
+  h->cp.ratio = h->dp.ratio; h->cp.flags = h->dp.flags;
   return PCT_OK;
 }
 
@@ -290,7 +356,8 @@ int32_t pct_obs_row_len(pct_env* h) { return h ? h->dp.row_len : 0; }
 static int ready(pct_env* h, bool need_reset) {
   if (!h) return fail(PCT_ERR_INVALID_ARG, "null handle");
   if (!h->have_items) return fail(PCT_ERR_STATE, "item set not configured");
-  if (h->dp.source == PCT_ITEMS_NONE) return fail(PCT_ERR_STATE, "item source not configured");
+  if ((h->continuous ? h->cp.source : h->dp.source) == PCT_ITEMS_NONE)
+    return fail(PCT_ERR_STATE, "item source not configured");
   if (need_reset && !h->was_reset) return fail(PCT_ERR_STATE, "step before the first reset");
   return use_device(h);
 }
@@ -331,7 +398,8 @@ int pct_policy_hash_rows(pct_env* h, float* rows_out, void* stream) {
   int rc = ready(h, true);
   if (rc) return rc;
   if (!rows_out) return fail(PCT_ERR_INVALID_ARG, "null rows_out");
-  HIP_TRY(pct::launch_policy_hash_rows(h->dp, rows_out, (hipStream_t)stream));
+  if (h->continuous) HIP_TRY(pct::launch_cpolicy_hash_rows(h->cp, rows_out, (hipStream_t)stream));
+  else HIP_TRY(pct::launch_policy_hash_rows(h->dp, rows_out, (hipStream_t)stream));
   return PCT_OK;
 }
 
@@ -374,8 +442,10 @@ int pct_debug_phase_timing(pct_env* h, int32_t on, uint64_t* host_out) {
     }
     HIP_TRY(hipMemset(h->timing_buf, 0, bytes));
     h->dp.timing = h->timing_buf;
+    h->cp.timing = h->timing_buf;
   } else {
     h->dp.timing = nullptr;
+    h->cp.timing = nullptr;
   }
   return PCT_OK;
 }
@@ -383,6 +453,7 @@ int pct_debug_phase_timing(pct_env* h, int32_t on, uint64_t* host_out) {
 int pct_debug_state(pct_env* h, int32_t e, int32_t* heightmap, int32_t* ems, int32_t cap_ems, int32_t* n_ems,
                     int32_t* n_boxes, int32_t* next_item, int64_t* draw_cursor) {
   if (!h || e < 0 || e >= h->dp.N) return fail(PCT_ERR_INVALID_ARG, "bad env id");
+  if (h->continuous) return fail(PCT_ERR_UNSUPPORTED, "use pct_debug_state_f64 for the continuous env");
   int rc = use_device(h);
   if (rc) return rc;
   HIP_TRY(hipDeviceSynchronize());
@@ -408,6 +479,28 @@ int pct_debug_state(pct_env* h, int32_t e, int32_t* heightmap, int32_t* ems, int
   if (n_ems) *n_ems = sc[0];
   if (n_boxes) *n_boxes = sc[1];
   if (next_item) { next_item[0] = sc[3]; next_item[1] = sc[4]; next_item[2] = sc[5]; }
+  if (draw_cursor) *draw_cursor = (int64_t)(((uint64_t)(uint32_t)sc[9] << 32) | (uint32_t)sc[8]);
+  return PCT_OK;
+}
+
+int pct_debug_state_f64(pct_env* h, int32_t e, double* ems, int32_t cap_ems, int32_t* n_ems, int32_t* n_boxes,
+                        double* next_item, int64_t* draw_cursor) {
+  if (!h || !h->continuous || e < 0 || e >= h->cp.N) return fail(PCT_ERR_INVALID_ARG, "bad env id / not continuous");
+  int rc = use_device(h);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  const pct::ContinuousParams& c = h->cp;
+  int32_t sc[PCT_SCALARS];
+  HIP_TRY(hipMemcpy(sc, c.scalars + (size_t)e * PCT_SCALARS, sizeof sc, hipMemcpyDeviceToHost));
+  if (ems) {
+    std::vector<double> raw((size_t)6 * c.ems_cap);
+    HIP_TRY(hipMemcpy(raw.data(), c.ems + (size_t)e * 6 * c.ems_cap, raw.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int i = 0; i < sc[0] && i < cap_ems; i++)
+      for (int k = 0; k < 6; k++) ems[6 * i + k] = raw[(size_t)k * c.ems_cap + i];
+  }
+  if (n_ems) *n_ems = sc[0];
+  if (n_boxes) *n_boxes = sc[1];
+  if (next_item) { next_item[0] = sc[3] / 1000.0; next_item[1] = sc[4] / 1000.0; next_item[2] = sc[5] / 1000.0; }
   if (draw_cursor) *draw_cursor = (int64_t)(((uint64_t)(uint32_t)sc[9] << 32) | (uint32_t)sc[8]);
   return PCT_OK;
 }

@@ -1,0 +1,216 @@
+// pct_set.cuh -- wave-level helpers and the exact, wave-parallel CPython `set` emulation shared
+// by the discrete and continuous transition kernels (gfx950, 64-lane wavefronts).
+#ifndef PCT_SET_CUH
+#define PCT_SET_CUH
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pct {
+
+__device__ inline int wave_max_i32(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    int o = __shfl_xor(v, off, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+__device__ inline uint64_t lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
+__device__ inline uint64_t bcast_u64(uint64_t v, int src) {
+  uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, src);
+  uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), src);
+  return ((uint64_t)hi << 32) | lo;
+}
+template <typename K>
+__device__ inline K bcast_key(K v, int src);
+template <>
+__device__ inline uint32_t bcast_key<uint32_t>(uint32_t v, int src) {
+  return __builtin_amdgcn_readlane(v, src);
+}
+template <>
+__device__ inline uint64_t bcast_key<uint64_t>(uint64_t v, int src) {
+  return bcast_u64(v, src);
+}
+template <typename K>
+__device__ inline K uniform_key(K v);
+template <>
+__device__ inline uint32_t uniform_key<uint32_t>(uint32_t v) {
+  return __builtin_amdgcn_readfirstlane(v);
+}
+template <>
+__device__ inline uint64_t uniform_key<uint64_t>(uint64_t v) {
+  uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+
+
+// CPython tuple hash (Objects/tupleobject.c, xxHash-derived, CPython >= 3.8): acc over the
+// element hashes ("lanes").
+#define PCT_XXPRIME_1 11400714785074694791ULL
+#define PCT_XXPRIME_2 14029467366897019727ULL
+#define PCT_XXPRIME_5 2870177450012600261ULL
+__device__ inline uint64_t tuplehash_begin() { return PCT_XXPRIME_5; }
+__device__ inline uint64_t tuplehash_lane(uint64_t acc, uint64_t lane) {
+  acc += lane * PCT_XXPRIME_2;
+  acc = (acc << 31) | (acc >> 33);
+  acc *= PCT_XXPRIME_1;
+  return acc;
+}
+__device__ inline uint64_t tuplehash_end6(uint64_t acc) {
+  acc += 6ULL ^ (PCT_XXPRIME_5 ^ 3527539ULL);
+  if (acc == (uint64_t)-1) return 1546275796ULL;
+  return acc;
+}
+
+// ----------------------------------------------------------------------------------------
+// CPython set emulation, wave-parallel and exact.
+//
+// Slot words: EMPTY (all ones) | a key (tag bit clear) | TAG|lane (tentative holder, only
+// while a batch is being matched).  Sequential set.add of keys k0,k1,.. (each takes the first
+// free slot on its own probe path: LINEAR_PROBES 9, PERTURB_SHIFT 5) is a serial
+// dictatorship; because every slot ranks keys by the same priority (insertion order) its
+// outcome is the unique stable matching, which the lanes reach in parallel by proposing
+// along their paths with atomicMin on TAG|lane: a lower lane evicts a higher one, the
+// evicted lane walks on.  A slot a lane has walked past stays held by a higher-priority key
+// for ever, so the fixed point equals the sequential result, slot for slot.
+// ----------------------------------------------------------------------------------------
+template <typename K>
+struct SlotWord;
+template <>
+struct SlotWord<uint32_t> {
+  static constexpr uint32_t EMPTY = 0xFFFFFFFFu, TAG = 0x80000000u;
+};
+template <>
+struct SlotWord<uint64_t> {
+  static constexpr uint64_t EMPTY = ~0ull, TAG = 1ull << 63;
+};
+__device__ inline uint32_t lds_atomic_min(uint32_t* p, uint32_t v) { return atomicMin(p, v); }
+__device__ inline uint64_t lds_atomic_min(uint64_t* p, uint64_t v) {
+  return (uint64_t)atomicMin(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v);
+}
+
+#define PCT_PEND_SLOTS 128
+struct Walk {  // position on a key's probe path: slot = i + j
+  uint32_t i;
+  int j;
+  uint64_t perturb;
+  __device__ inline void start(uint64_t hash, uint32_t mask) {
+    perturb = hash;
+    i = (uint32_t)hash & mask;
+    j = 0;
+  }
+  __device__ inline void next(uint32_t mask) {
+    int probes = (i + 9u <= mask) ? 9 : 0;
+    if (j < probes) {
+      j++;
+    } else {
+      perturb >>= 5;
+      i = (i * 5u + 1u + (uint32_t)perturb) & mask;
+      j = 0;
+    }
+  }
+};
+
+// Read-only membership test (no tags may be present).
+// `same(word)` decides whether the table entry `word` holds the caller's key (set_add_entry:
+// entry->hash == hash and the keys compare equal).
+template <typename K, typename Same>
+__device__ inline bool pyset_contains(const K* tab, uint32_t mask, uint64_t hash, Same same) {
+  Walk w;
+  w.start(hash, mask);
+  while (true) {
+    K cur = tab[w.i + w.j];
+    if (cur == SlotWord<K>::EMPTY) return false;
+    if (same(cur)) return true;
+    w.next(mask);
+  }
+}
+
+// Matches the participating lanes' keys into the table in lane-priority order.  The
+// participating keys must be pairwise distinct (the caller de-duplicates a batch first: two
+// equal keys can overtake one another on their common path, distinct keys cannot matter to
+// each other except through the slots they hold).  On return a lane with `placed` holds
+// TAG|lane in tab[slot]; a participating lane that is not placed found its key already in the
+// table (check_found).  All 64 lanes must call.
+template <typename K, typename Same>
+__device__ inline void pyset_match(K* tab, uint32_t mask, bool part, uint64_t hash, int lane, bool check_found,
+                                   bool& placed, uint32_t& slot, Same same) {
+  const K TAG = SlotWord<K>::TAG;
+  const K mytag = TAG | (K)lane;
+  Walk w;
+  w.start(hash, mask);
+  bool walking = part;
+  placed = false;
+  slot = 0;
+  while (true) {
+    while (walking) {
+      uint32_t cur = w.i + w.j;
+      K v = tab[cur];
+      if ((v & TAG) && v > mytag) {  // empty, or tentatively held by a later lane
+        K old = lds_atomic_min(&tab[cur], mytag);
+        if (old > mytag) {
+          slot = cur;
+          placed = true;
+          walking = false;
+        }
+      } else if (check_found && same(v)) {
+        walking = false;  // already a member
+      } else {
+        w.next(mask);  // a different key, or an earlier lane's tentative hold
+      }
+    }
+    __syncthreads();
+    if (placed && tab[slot] != mytag) {  // evicted by an earlier lane: walk on
+      placed = false;
+      walking = true;
+      w.next(mask);
+    }
+    if (!__ballot(walking)) break;
+  }
+}
+
+// Which LDS region holds a table of `size` slots (ping-pong so that a resize can stream
+// old -> new without a temporary): cap in region 0, cap/4 in region 1, cap/16 in 0, ...
+// Returned as a slot OFFSET from tab0 (tab1 follows tab0 in LDS) so that every table access
+// stays a plain LDS access off one base pointer.
+__device__ inline uint32_t table_region(uint32_t cap, uint32_t size) {
+  int lv = 0;
+  while (size < cap) {
+    size <<= 2;
+    lv++;
+  }
+  return (lv & 1) ? cap : 0u;
+}
+
+// optional per-phase cycle accounting (pct_debug_phase_timing): s_memtime deltas per env.
+// The untimed specialisation is empty, so production kernels carry no extra registers.
+template <bool ON>
+struct PhaseTimer {
+  __device__ inline void start() {}
+  __device__ inline void tick(int) {}
+  __device__ inline void flush(unsigned long long*, int) {}
+};
+template <>
+struct PhaseTimer<true> {
+  uint64_t last;
+  uint64_t acc[8];
+  __device__ inline void start() {
+    for (int i = 0; i < 8; i++) acc[i] = 0;
+    last = __builtin_readcyclecounter();
+  }
+  __device__ inline void tick(int i) {
+    uint64_t now = __builtin_readcyclecounter();
+    acc[i] += now - last;
+    last = now;
+  }
+  __device__ inline void flush(unsigned long long* o, int n_steps) {
+    for (int i = 0; i < 7; i++) o[i] += acc[i];
+    o[7] += (unsigned long long)n_steps;
+  }
+};
+enum { PH_LOAD = 0, PH_DROP = 1, PH_GENEMS = 2, PH_SET = 3, PH_FEAS = 4, PH_OBS = 5, PH_STORE = 6, PH_STEPS = 7 };
+
+
+}  // namespace pct
+#endif

@@ -168,8 +168,9 @@ class PctVecEnv(VecEnv):
                                       "is not available yet; construct with shuffle=False")
         if load_test_data or data_name is not None:
             raise NotImplementedError("dataset trajectories: pass them as item_stream=[N,T,3]")
-        if continuous or sample_from_distribution:
-            raise NotImplementedError("the continuous env is not built yet")
+        self.continuous = bool(continuous)
+        if self.continuous and (sample_left_bound is None or sample_right_bound is None):
+            raise ValueError("the continuous env needs sample_left_bound / sample_right_bound (tools.py:178-181)")
         if LNES not in _LNES:
             raise NotImplementedError("LNES=%r" % (LNES,))
         self._L = _lib.load()
@@ -177,10 +178,11 @@ class PctVecEnv(VecEnv):
         self._dev_index = dev_index
         cfg = _lib.PctConfig()
         cfg.struct_size = ctypes.sizeof(_lib.PctConfig)
-        cfg.env_kind = _lib.ENV_DISCRETE
+        cfg.env_kind = _lib.ENV_CONTINUOUS if self.continuous else _lib.ENV_DISCRETE
         cfg.setting = int(setting)
         cfg.num_envs = int(num_envs)
-        cfg.container[:] = [int(c) for c in container_size]
+        scale = 1000 if self.continuous else 1  # continuous geometry is on the 1e-3 lattice
+        cfg.container[:] = [int(round(c * scale)) for c in container_size]
         cfg.internal_node_holder = int(internal_node_holder)
         cfg.leaf_node_holder = int(leaf_node_holder)
         cfg.lnes = _LNES[LNES]
@@ -194,16 +196,21 @@ class PctVecEnv(VecEnv):
         self.cfg = cfg
         self.N, self.I, self.Lh = int(num_envs), int(internal_node_holder), int(leaf_node_holder)
         self.row_len = (self.I + self.Lh + 1) * 9
-        self.bin_size = tuple(int(c) for c in container_size)
+        self.bin_size = tuple(container_size)
         self.setting = int(setting)
         self.env_id_base = int(env_id_base)
         self.strict = strict
 
-        if item_set is None:
-            raise ValueError("item_set is required (givenData.py:10-14)")
-        items = np.ascontiguousarray(np.asarray(item_set, dtype=np.int32).reshape(-1, 3))
-        _lib.check(self._L.pct_set_item_set(self._h, items.ctypes.data, items.shape[0]))
-        self.item_set = items
+        if self.continuous:
+            _lib.check(self._L.pct_set_sample_bounds(self._h, int(round(sample_left_bound * 1000)),
+                                                     int(round(sample_right_bound * 1000))))
+            self.item_set = None
+        else:
+            if item_set is None:
+                raise ValueError("item_set is required (givenData.py:10-14)")
+            items = np.ascontiguousarray(np.asarray(item_set, dtype=np.int32).reshape(-1, 3))
+            _lib.check(self._L.pct_set_item_set(self._h, items.ctypes.data, items.shape[0]))
+            self.item_set = items
         if item_stream is not None:
             self.set_item_stream(item_stream)
         else:
@@ -355,6 +362,13 @@ class PctVecEnv(VecEnv):
         return self._obs, reward, done, infos
 
     def debug_state(self, e, cap_ems=1024):
+        if self.continuous:
+            ems = np.zeros((cap_ems, 6), np.float64)
+            n_ems, n_boxes, cur = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64()
+            nxt = np.zeros(3, np.float64)
+            _lib.check(self._L.pct_debug_state_f64(self._h, int(e), ems.ctypes.data, cap_ems, ctypes.byref(n_ems),
+                                                   ctypes.byref(n_boxes), nxt.ctypes.data, ctypes.byref(cur)))
+            return dict(ems=ems[:n_ems.value].copy(), n_boxes=n_boxes.value, next_item=nxt, cursor=cur.value)
         A = max(self.bin_size[0], self.bin_size[1])
         hm = np.zeros(A * A, np.int32)
         ems = np.zeros((cap_ems, 6), np.int32)
@@ -400,4 +414,5 @@ def make_vec_envs(args, log_dir=None, allow_early_resets=True):
         device=getattr(args, "device", "cuda:0"),
         seed=getattr(args, "seed", 0),
         continuous=kind.startswith("PctContinuous"),
+        item_stream=getattr(args, "item_stream", None),
     )

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.common import (GOLDEN, GOLDEN_CASES, gather_rows, hash_policy_index, item_set_range, load_case,
+from tests.common import (CONT_CASES, GOLDEN, GOLDEN_CASES, gather_rows, hash_policy_index, item_set_range, load_case,
                           make_stream)
 
 pytestmark = pytest.mark.gpu
@@ -220,4 +220,97 @@ def test_hip_edge_cases_match_oracle():
     sub = env.reset_specific([0, 2])
     ora.reset(env_ids=[0, 2])
     assert np.array_equal(sub.cpu().numpy(), ora.obs.astype(np.float32)[[0, 2]])
+    env.close()
+
+
+# ------------------------------------------------------------------------------------------
+# continuous env (PctContinuous0, setting 2).  north_star tolerance: 1e-5 on observations.
+# The kernel mirrors the reference's float64 operations, so the float32 observations are in
+# fact compared EXACTLY (atol 0) with the float32 cast of the reference's float64 rows; the
+# stated tolerance is kept as the assertion's documented bound.
+# ------------------------------------------------------------------------------------------
+CONT_TOL = 1e-5
+
+
+def _make_cont(c, stream, **kw):
+    return _pkg().PctVecEnv(c["N"], setting=c["setting"], container_size=c["container"], continuous=True,
+                            sample_left_bound=c["lo"], sample_right_bound=c["hi"], internal_node_holder=c["I"],
+                            leaf_node_holder=c["L"], env_id_base=c["base"], item_stream=stream, device="cuda:0", **kw)
+
+
+@pytest.mark.parametrize("name", CONT_CASES)
+@pytest.mark.parametrize("mode", ["fused", "index", "rows9"])
+def test_hip_continuous_matches_reference_fixture(name, mode):
+    c, z = load_case(name)
+    big = max(c["container"]) > 16
+    many = big or c["lo"] < 1.0  # small items -> more than 1228 distinct candidates are possible
+    env = _make_cont(c, z["stream"], ems_capacity=640 if many else 0, candidate_capacity=8192 if many else 0)
+    obs = env.reset()
+    for t in range(c["steps"]):
+        o = obs.cpu().numpy()
+        ref = z["obs"][t].astype(np.float32)
+        assert np.allclose(o, ref, rtol=0, atol=CONT_TOL), (name, mode, t)
+        assert np.array_equal(o, ref), (name, mode, t, np.argwhere(o != ref)[:4])
+        if mode == "fused":
+            env.step_hash_policy(1)
+        else:
+            idx = hash_policy_index(o, c["I"], c["L"], c["base"], np.full(c["N"], t, np.uint64))
+            if mode == "index":
+                env.step_async(torch.from_numpy(idx))
+            else:
+                env.step_async(gather_rows(o, c["I"], idx))  # float32 rows
+        obs, reward, done, infos = env.step_wait()
+        assert np.array_equal(reward[:, 0].numpy(), z["reward"][t].astype(np.float32)), (name, t)
+        assert np.array_equal(done.astype(np.uint8), z["done"][t]), (name, t)
+        cnt = np.array([infos[i]["counter"] for i in range(len(infos))])
+        assert np.array_equal(cnt, z["counter"][t])
+        for i in np.nonzero(done)[0]:
+            assert infos[i]["ratio"] == z["ratio"][t][i]
+    assert not env.error_flags.any()
+    env.close()
+
+
+def test_hip_continuous_known_answer_hash():
+    """Reference trajectory under env.seed(4) / RandomState(0) (sampling mode) replayed on the
+    GPU: sha256[:16] of the 500 observations rounded to 5 decimals = 506b5c0349c89b9d."""
+    z = np.load(GOLDEN + "/kat_continuous_s2.npz")
+    env = _pkg().PctVecEnv(1, setting=2, container_size=(10, 10, 10), continuous=True, sample_left_bound=1.0,
+                           sample_right_bound=5.0, item_stream=z["items"][None], device="cuda:0")
+    obs = env.reset()
+    h = hashlib.sha256()
+    for t in range(500):
+        h.update(np.round(obs.cpu().numpy()[0].astype(np.float64), 5).astype(np.float32).tobytes())
+        obs, _, _, _ = env.step(z["actions"][t][None].astype(np.float32))
+    assert h.hexdigest()[:16] == "506b5c0349c89b9d"
+    env.close()
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(N=256, container=(10, 10, 10), lo=1.0, hi=5.0, I=80, L=50, steps=120, base=77),
+    dict(N=48, container=(7, 9, 6), lo=0.4, hi=3.0, I=100, L=40, steps=120, base=3),
+])
+def test_hip_continuous_matches_oracle_sampler(cfg):
+    """Counter-based sampler on both sides, fused stand-in policy, plus the internal EMS list."""
+    from oracle.oracle_lib import OracleVecEnv
+    ora = OracleVecEnv(cfg["N"], setting=2, container_size=cfg["container"], env_kind=1,
+                       sample_bounds=(cfg["lo"], cfg["hi"]), internal_node_holder=cfg["I"],
+                       leaf_node_holder=cfg["L"], env_id_base=cfg["base"])
+    ora.set_sampler(2024)
+    env = _pkg().PctVecEnv(cfg["N"], setting=2, container_size=cfg["container"], continuous=True,
+                           sample_left_bound=cfg["lo"], sample_right_bound=cfg["hi"],
+                           internal_node_holder=cfg["I"], leaf_node_holder=cfg["L"], env_id_base=cfg["base"],
+                           seed=2024, device="cuda:0", candidate_capacity=8192 if cfg["lo"] < 1.0 else 0,
+                           ems_capacity=640 if cfg["lo"] < 1.0 else 0)
+    ora.reset()
+    obs = env.reset()
+    for t in range(cfg["steps"]):
+        o, ref = obs.cpu().numpy(), ora.obs.astype(np.float32)
+        assert np.allclose(o, ref, rtol=0, atol=CONT_TOL), t
+        assert np.array_equal(o, ref), t
+        env.step_hash_policy(1)
+        ora.step_hash_policy(1)
+        obs, reward, done, infos = env.step_wait()
+        assert np.array_equal(done.astype(np.uint8), ora.done)
+        assert np.array_equal(reward[:, 0].numpy(), ora.reward.astype(np.float32))
+    assert not env.error_flags.any()
     env.close()
