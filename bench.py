@@ -42,12 +42,16 @@ def item_set():
     return [(i, j, k) for i in range(1, 6) for j in range(1, 6) for k in range(1, 6)]
 
 
-def cpu_baseline(envs, budget_s):
+def cpu_baseline(envs, budget_s, workload="c2"):
     """The oracle on the host cores: same workload, bounded sample."""
     from oracle.oracle_lib import OracleVecEnv
     threads = max(1, min(os.cpu_count() or 1, 64))
-    env = OracleVecEnv(envs, setting=2, container_size=(10, 10, 10), item_set=item_set(),
-                       internal_node_holder=I_NODES, leaf_node_holder=L_NODES, threads=threads)
+    if workload == "c3":
+        env = OracleVecEnv(envs, setting=2, container_size=(10, 10, 10), env_kind=1, sample_bounds=(1.0, 5.0),
+                           internal_node_holder=I_NODES, leaf_node_holder=L_NODES, threads=threads)
+    else:
+        env = OracleVecEnv(envs, setting=2, container_size=(10, 10, 10), item_set=item_set(),
+                           internal_node_holder=I_NODES, leaf_node_holder=L_NODES, threads=threads)
     env.set_sampler(4)
     env.reset()
     env.step_hash_policy(50)  # de-synchronise the episodes
@@ -72,6 +76,8 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--mode", choices=["rows", "fused"], default="rows",
                     help="rows: policy kernel + pct_step_rows per step (default); fused: pct_step_hash_policy(1)")
+    ap.add_argument("--workload", choices=["c2", "c3"], default="c2",
+                    help="c2: BASELINE configs[1] (discrete, the headline metric); c3: configs[2] (continuous setting 2)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -95,9 +101,14 @@ def main():
 
     pkg = importlib.import_module("online-3d-bpp-pct_amd")
     n_local = args.envs_per_gpu
-    env = pkg.PctVecEnv(n_local, setting=2, container_size=(10, 10, 10), item_set=item_set(),
-                        internal_node_holder=I_NODES, leaf_node_holder=L_NODES, seed=4,
-                        env_id_base=rank * n_local, device=dev, monitor=False)
+    if args.workload == "c3":
+        env = pkg.PctVecEnv(n_local, setting=2, container_size=(10, 10, 10), continuous=True, sample_left_bound=1.0,
+                            sample_right_bound=5.0, internal_node_holder=I_NODES, leaf_node_holder=L_NODES, seed=4,
+                            env_id_base=rank * n_local, device=dev, monitor=False)
+    else:
+        env = pkg.PctVecEnv(n_local, setting=2, container_size=(10, 10, 10), item_set=item_set(),
+                            internal_node_holder=I_NODES, leaf_node_holder=L_NODES, seed=4,
+                            env_id_base=rank * n_local, device=dev, monitor=False)
     env.reset()
     rows = torch.empty(n_local, 9, dtype=torch.float32, device=dev)
 
@@ -146,14 +157,15 @@ def main():
     achieved_gbs = ALG_BYTES_PER_STEP * n_local / (kern_avg_ms * 1e-3) / 1e9
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc):
+    if os.path.exists(pmc) and args.workload == "c2" and n_local == 4096:
         try:
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
 
     out = {
-        "metric": "env-steps/sec (whole node), discrete setting 2, 80 internal/50 leaf",
+        "metric": "env-steps/sec (whole node), discrete setting 2, 80 internal/50 leaf" if args.workload == "c2"
+                  else "env-steps/sec (whole node), continuous setting 2, 80 internal/50 leaf",
         "value": value,
         "unit": "env-steps/s",
         "n_gpus": world,
@@ -163,13 +175,16 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "i32",
+        "dtype": "i32" if args.workload == "c2" else "f64",
         "data": "synthetic",
         "config": {
-            "workload": "PctDiscrete0 setting 2 (EMS leaves), bin 10x10x10, 80 internal / 50 leaf, %d batched envs per "
-                        "MI355X (BASELINE.json configs[1]); items ~ U{(1..5)^3} from the on-device counter sampler; "
-                        "per step: policy kernel -> float32 [N,9] leaf rows -> transition kernel (full obs rewrite, "
-                        "auto-reset)" % n_local,
+            "workload": ("PctDiscrete0 setting 2 (EMS leaves), bin 10x10x10, 80 internal / 50 leaf, %d batched envs per "
+                         "MI355X (BASELINE.json configs[1]); items ~ U{(1..5)^3} from the on-device counter sampler; "
+                         "per step: policy kernel -> float32 [N,9] leaf rows -> transition kernel (full obs rewrite, "
+                         "auto-reset)" % n_local) if args.workload == "c2" else
+                        ("PctContinuous0 setting 2, bin 10x10x10, 80 internal / 50 leaf, %d batched envs per MI355X "
+                         "(BASELINE.json configs[2]); item sizes round(U(1,5),3) from the on-device counter sampler; "
+                         "per step: policy kernel -> float32 [N,9] leaf rows -> float64 transition kernel" % n_local),
             "envs_per_gpu": n_local,
             "global_envs": world * n_local,
             "mode": args.mode,
@@ -182,14 +197,15 @@ def main():
             "unit": "GB/s",
             "frac": achieved_gbs / HBM_PEAK_GBS,
             "traffic": traffic,
-            "kernel": "pct_discrete_kernel<u32,5,ACT_ROWS>" if args.mode == "rows" else "pct_discrete_kernel<u32,5,ACT_HASH>",
+            "kernel": ("pct_discrete_kernel<u32,5," if args.workload == "c2" else "pct_continuous_kernel<") +
+                      ("ACT_ROWS>" if args.mode == "rows" else "ACT_HASH>"),
             "kernel_avg_us": kern_avg_ms * 1e3,
             "launches_timed": n_launch,
             "alg_bytes_per_env_step": ALG_BYTES_PER_STEP,
         },
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(256, args.cpu_seconds)
+        out["cpu_baseline"] = cpu_baseline(256, args.cpu_seconds, args.workload)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -18,6 +18,7 @@ struct DiscreteParams {
   int N, W, Ly, H, A, AA; /* AA = A*A rounded up to a multiple of 8 */
   int I, L, row_len;
   int setting, low_bound;
+  int lnes; /* PCT_LNES_EMS / PCT_LNES_CP */
   int ems_cap, cand_cap;
   int key_bytes; /* 4: six 5-bit coords (bins <= 31); 8: six 10-bit coords (<= 1023) */
   // item source

@@ -69,6 +69,7 @@ struct Lds {
   K* leaf;
   int16_t* hmap;
   uint16_t* vp; /* [64] valid (ems, rotation) pairs of the current chunk */
+  uint32_t* cp; /* corner-point scratch: 4 arrays of I+2 words (only when lnes == CP) */
 };
 
 template <typename K, int BITS>
@@ -83,6 +84,7 @@ __device__ inline Lds<K, BITS> carve_lds(const DiscreteParams& p, unsigned char*
   l.leaf = q; q += p.L;
   l.hmap = reinterpret_cast<int16_t*>(q);
   l.vp = reinterpret_cast<uint16_t*>(l.hmap + p.AA);
+  l.cp = reinterpret_cast<uint32_t*>(l.vp + 64);
   return l;
 }
 
@@ -298,32 +300,137 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, Lds<K, BITS>& l, EnvR
     }
   };
 
-  for (int pbase = 0; pbase < NP && !cand_overflow; pbase += 64) {
-    // which (EMS, rotation) pairs of this chunk can hold the item at all
-    int q = pbase + lane;
-    bool pv = q < NP;
-    int ei = q / orient, rot = q - ei * orient;
-    int sx, sy, sz;
-    bool skip = rot_size(rot, sx, sy, sz);
-    K ek = pv ? l.ems_a[ei] : (K)0;
-    pv = pv && !skip && (P::get(ek, 3) - P::get(ek, 0) >= sx) && (P::get(ek, 4) - P::get(ek, 1) >= sy) &&
-         (P::get(ek, 5) - P::get(ek, 2) >= sz);
-    uint64_t pm = __ballot(pv);
-    const int nt = 4 * __popcll(pm);  // four bottom-corner placements per pair (:565-568)
-    if (pv) l.vp[__popcll(pm & lt)] = (uint16_t)q;
+  if (p.lnes == PCT_LNES_CP && r.n_boxes == 0) {
+    // D/space.py:756-757: an empty bin yields a plain two-element LIST (unrotated, x/y
+    // swapped; no set, no in-bin test): slots 0 and 1 of the fresh 8-slot table hold them in
+    // list order, duplicates included
+    if (lane == 0) {
+      tabs[toff + 0] = P::pack(0, 0, 0, b0, b1, b2);
+      tabs[toff + 1] = P::pack(0, 0, 0, b1, b0, b2);
+    }
     __syncthreads();
-    for (int tb = 0; tb < nt && !cand_overflow; tb += 64) {
-      int tt = tb + lane;
-      bool valid = tt < nt;
-      int qq = valid ? (int)l.vp[tt >> 2] : 0;
-      int corner = tt & 3;
-      int e2 = qq / orient;
-      rot_size(qq - e2 * orient, sx, sy, sz);
-      K k2 = l.ems_a[e2];
-      int x0 = P::get(k2, 0), y0 = P::get(k2, 1), z0 = P::get(k2, 2), x1 = P::get(k2, 3), y1 = P::get(k2, 4);
-      int xs = (corner & 1) ? x1 - sx : x0;
-      int ys = (corner & 2) ? y1 - sy : y0;
-      K key = P::pack(xs, ys, z0, xs + sx, ys + sy, z0 + sz);
+  } else if (p.lnes == PCT_LNES_CP) {
+    // D/space.py:758-774 + D/PctTools.py:137-158: per level k (sorted distinct tops, 0 first)
+    // the corner points of the boxes reaching above k, minus those of the previous level
+    const int n = r.n_boxes;
+    uint32_t* T = l.cp;                  // [I+2] levels
+    uint32_t* srt = l.cp + (p.I + 2);    // [I+2] box ids sorted by (ye, xe) descending, stable
+    uint32_t* cik = l.cp + 2 * (p.I + 2);   // [I+2] corners of this level: x | y << 16
+    uint32_t* last = l.cp + 3 * (p.I + 2);  // [I+2] corners of the previous level
+    uint32_t* CI = reinterpret_cast<uint32_t*>(l.ems_a);  // EMS are not kept under CP: x | y<<10 | k<<20
+    const int ci_cap = (int)(p.ems_cap * sizeof(K) / sizeof(uint32_t));
+    // distinct tops, ascending (Tset, D/space.py:758-761)
+    int nT = 1;
+    if (lane == 0) T[0] = 0;
+    for (int base = 0; base < n; base += 64) {  // cik[i] = 1 iff box i is the first with its top
+      int i = base + lane;
+      int top = i < n ? P::get(l.box[i], 5) : 0;
+      bool first = i < n;
+      for (int j = 0; j < n; j++) first = first && !(j < i && P::get(uniform_key<K>(l.box[j]), 5) == top);
+      if (i < n) cik[i] = first ? 1u : 0u;
+    }
+    __syncthreads();
+    for (int base = 0; base < n; base += 64) {
+      int i = base + lane;
+      int top = i < n ? P::get(l.box[i], 5) : 0;
+      bool first = i < n && cik[i] != 0u;
+      int less = 0;
+      for (int j = 0; j < n; j++)
+        less += (uniform_key<uint32_t>(cik[j]) != 0u && P::get(uniform_key<K>(l.box[j]), 5) < top) ? 1 : 0;
+      if (first) T[1 + less] = (uint32_t)top;
+      nT += __popcll(__ballot(first));
+    }
+    __syncthreads();
+    int nCI = 0, nlast = 0;
+    bool ci_overflow = false;
+    for (int ti = 0; ti < nT; ti++) {
+      const int k = (int)uniform_key<uint32_t>(T[ti]);
+      // stable descending sort of the active rectangles by (ye, xe): rank by counting
+      int nact = 0;
+      for (int base = 0; base < n; base += 64) {
+        int i = base + lane;
+        K bi = i < n ? l.box[i] : (K)0;
+        bool act = i < n && P::get(bi, 5) > k;
+        int xe = P::get(bi, 3), ye = P::get(bi, 4);
+        int rank = 0;
+        for (int j = 0; j < n; j++) {
+          K bj = uniform_key<K>(l.box[j]);
+          bool actj = P::get(bj, 5) > k;
+          int xj = P::get(bj, 3), yj = P::get(bj, 4);
+          bool before = (yj > ye) || (yj == ye && xj > xe) || (yj == ye && xj == xe && j < i);
+          rank += (actj && before) ? 1 : 0;
+        }
+        if (act) srt[rank] = (uint32_t)i;
+        nact += __popcll(__ballot(act));
+      }
+      __syncthreads();
+      int nc = 0;
+      if (nact == 0) {
+        if (lane == 0) cik[0] = 0;  // corners2D([]) == [(0, 0)]
+        nc = 1;
+      } else {
+        // extreme items (PctTools.py:145-151): xe above the running maximum of everything sorted
+        // before; the corner an extreme item contributes is (that running maximum, its ye) --
+        // the running maximum is 0 for the first one and the previous extreme item's xe after
+        int m = 0, xmax = 0;
+        for (int base = 0; base < nact; base += 64) {
+          int pos = base + lane;
+          bool live = pos < nact;
+          K bb = live ? l.box[srt[pos]] : (K)0;
+          int xe = P::get(bb, 3), ye = P::get(bb, 4);
+          int run = 0;
+          for (int q = 0; q < nact; q++) {
+            int xq = P::get(uniform_key<K>(l.box[srt[q]]), 3);
+            run = (q < pos && xq > run) ? xq : run;
+          }
+          bool ext = live && xe > run;
+          uint64_t em_mask = __ballot(ext);
+          if (ext) cik[m + __popcll(em_mask & lt)] = (uint32_t)run | ((uint32_t)ye << 16);
+          m += __popcll(em_mask);
+          int passmax = wave_max_i32(live ? xe : 0);
+          xmax = passmax > xmax ? passmax : xmax;
+        }
+        // closing corner (xe of the last extreme item, 0): the running maximum of all xe
+        if (lane == 0) cik[m] = (uint32_t)xmax;
+        nc = m + 1;
+      }
+      __syncthreads();
+      // CI += corners not present at the previous level (order kept)
+      for (int base = 0; base < nc; base += 64) {
+        int c = base + lane;
+        bool live = c < nc;
+        uint32_t v = live ? cik[c] : 0u;
+        bool seen = false;
+        for (int q = 0; q < nlast; q++) seen = seen || (last[q] == v);
+        bool add = live && !seen;
+        uint64_t m2 = __ballot(add);
+        int o = nCI + __popcll(m2 & lt);
+        if (add) {
+          if (o < ci_cap) CI[o] = (v & 0xFFFFu) | ((v >> 16) << 10) | ((uint32_t)k << 20);
+          else ci_overflow = true;
+        }
+        nCI += __popcll(m2);
+      }
+      ci_overflow = __ballot(ci_overflow) != 0;
+      if (nCI > ci_cap) nCI = ci_cap;
+      __syncthreads();
+      for (int c = lane; c < nc; c += 64) last[c] = cik[c];
+      nlast = nc;
+      __syncthreads();
+    }
+    if (ci_overflow) r.flags |= PCT_FLAG_EMS_OVERFLOW;
+    // candidates: corner x rotation, in-bin test (D/space.py:776-803), into the set
+    const int NQ = nCI * orient;
+    for (int base = 0; base < NQ && !cand_overflow; base += 64) {
+      int q = base + lane;
+      bool valid = q < NQ;
+      int ci = q / orient, rot = q - ci * orient;
+      int sx, sy, sz;
+      bool skip = rot_size(rot, sx, sy, sz);
+      uint32_t cv = valid ? CI[ci] : 0u;
+      int px = (int)(cv & 0x3FFu), py = (int)((cv >> 10) & 0x3FFu), pz = (int)(cv >> 20);
+      valid = valid && !skip && (px + sx <= p.W) && (py + sy <= p.Ly) && (pz + sz <= p.H);
+      K key = P::pack(px, py, pz, px + sx, py + sy, pz + sz);
       uint64_t hash = tuplehash6<K, BITS>(key);
       bool fresh = valid && !pyset_contains<K>(tabs + toff, size - 1, hash, [&](K w) { return w == key; });
       uint64_t nm = __ballot(fresh);
@@ -332,7 +439,43 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, Lds<K, BITS>& l, EnvR
       __syncthreads();
       if (npend >= 64) flush(64);
     }
-    __syncthreads();
+  } else {
+    for (int pbase = 0; pbase < NP && !cand_overflow; pbase += 64) {
+      // which (EMS, rotation) pairs of this chunk can hold the item at all
+      int q = pbase + lane;
+      bool pv = q < NP;
+      int ei = q / orient, rot = q - ei * orient;
+      int sx, sy, sz;
+      bool skip = rot_size(rot, sx, sy, sz);
+      K ek = pv ? l.ems_a[ei] : (K)0;
+      pv = pv && !skip && (P::get(ek, 3) - P::get(ek, 0) >= sx) && (P::get(ek, 4) - P::get(ek, 1) >= sy) &&
+           (P::get(ek, 5) - P::get(ek, 2) >= sz);
+      uint64_t pm = __ballot(pv);
+      const int nt = 4 * __popcll(pm);  // four bottom-corner placements per pair (:565-568)
+      if (pv) l.vp[__popcll(pm & lt)] = (uint16_t)q;
+      __syncthreads();
+      for (int tb = 0; tb < nt && !cand_overflow; tb += 64) {
+        int tt = tb + lane;
+        bool valid = tt < nt;
+        int qq = valid ? (int)l.vp[tt >> 2] : 0;
+        int corner = tt & 3;
+        int e2 = qq / orient;
+        rot_size(qq - e2 * orient, sx, sy, sz);
+        K k2 = l.ems_a[e2];
+        int x0 = P::get(k2, 0), y0 = P::get(k2, 1), z0 = P::get(k2, 2), x1 = P::get(k2, 3), y1 = P::get(k2, 4);
+        int xs = (corner & 1) ? x1 - sx : x0;
+        int ys = (corner & 2) ? y1 - sy : y0;
+        K key = P::pack(xs, ys, z0, xs + sx, ys + sy, z0 + sz);
+        uint64_t hash = tuplehash6<K, BITS>(key);
+        bool fresh = valid && !pyset_contains<K>(tabs + toff, size - 1, hash, [&](K w) { return w == key; });
+        uint64_t nm = __ballot(fresh);
+        if (fresh) pend[npend + __popcll(nm & lt)] = key;
+        npend += __popcll(nm);
+        __syncthreads();
+        if (npend >= 64) flush(64);
+      }
+      __syncthreads();
+    }
   }
   while (npend > 0 && !cand_overflow) flush(npend < 64 ? npend : 64);
   if (cand_overflow) r.flags |= PCT_FLAG_CANDIDATE_OVERFLOW;
@@ -495,7 +638,7 @@ __device__ inline void transition(const DiscreteParams& p, int e, Lds<K, BITS>& 
     r.vol += (int64_t)x * y * z;
     __syncthreads();
     tm.tick(PH_DROP);
-    genems<K, BITS>(p, l, r, lane, lx, ly, max_h, lx + x, ly + y, top);
+    if (p.lnes == PCT_LNES_EMS) genems<K, BITS>(p, l, r, lane, lx, ly, max_h, lx + x, ly + y, top);  // D/bin3D.py:172-175
     tm.tick(PH_GENEMS);
     // D/bin3D.py:57-59,183: 10 * vol(item) / vol(bin), float64 then envs.py:181 .float()
     reward = (float)(((double)((int64_t)r.item0 * r.item1 * r.item2) / binvol) * 10.0);
@@ -647,7 +790,8 @@ namespace pct {
 size_t discrete_lds_bytes(const DiscreteParams& p) {
   size_t k = p.key_bytes;
   size_t n = (size_t)p.cand_cap + p.cand_cap / 4 + 2 * (size_t)p.ems_cap + p.I + p.L;
-  return n * k + (size_t)p.AA * sizeof(int16_t) + 64 * sizeof(uint16_t) + 16;
+  size_t cp = p.lnes == PCT_LNES_CP ? 4 * (size_t)(p.I + 2) * sizeof(uint32_t) : 0;
+  return n * k + (size_t)p.AA * sizeof(int16_t) + 64 * sizeof(uint16_t) + cp + 16;
 }
 
 template <typename K, int BITS>

@@ -130,7 +130,10 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
     return fail(PCT_ERR_INVALID_ARG, "unknown env_kind");
   const bool cont = cfg->env_kind == PCT_ENV_CONTINUOUS;
   if (cfg->setting != 2) return fail(PCT_ERR_UNSUPPORTED, "only setting 2 is built so far");
-  if (cfg->lnes != PCT_LNES_EMS) return fail(PCT_ERR_UNSUPPORTED, "only LNES=EMS is built so far");
+  if (cfg->lnes != PCT_LNES_EMS && cfg->lnes != PCT_LNES_CP)
+    return fail(PCT_ERR_UNSUPPORTED, "LNES must be EMS or CP");
+  if (cfg->lnes == PCT_LNES_CP && cfg->env_kind != PCT_ENV_DISCRETE)
+    return fail(PCT_ERR_UNSUPPORTED, "the corner-point scheme exists only in the discrete env");
   if (cfg->num_envs < 1 || cfg->internal_node_holder < 1 || cfg->leaf_node_holder < 1)
     return fail(PCT_ERR_INVALID_ARG, "num_envs / holders must be positive");
   int W = cfg->container[0], Ly = cfg->container[1], H = cfg->container[2];
@@ -221,6 +224,7 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
   p.L = cfg->leaf_node_holder;
   p.row_len = (p.I + p.L + 1) * 9;
   p.setting = cfg->setting;
+  p.lnes = cfg->lnes;
   p.ems_cap = ems_cap;
   p.cand_cap = cand_cap;
   p.key_bytes = maxdim <= 31 ? 4 : 8;

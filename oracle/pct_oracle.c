@@ -367,12 +367,115 @@ static int ems_point(const pcto_env* h, const oenv* s, int64_t** out) {
   return cnt;
 }
 
-/* D/bin3D.py:100-136 get_possible_position (LNES='EMS', shuffle=False): writes the L
+/* D/PctTools.py:137-158 corners2D on rects (lx,ly,xe,ye); writes (x,y) pairs, returns count */
+static int corners2d(const int (*rects)[4], int n, int (*out)[2]) {
+  if (n == 0) { out[0][0] = 0; out[0][1] = 0; return 1; }
+  /* sorted(..., key=(ye, xe), reverse=True): stable, equal keys keep their original order */
+  int* idx = (int*)malloc(sizeof(int) * (size_t)n);
+  for (int i = 0; i < n; i++) {
+    int j = i;
+    while (j > 0) {
+      const int* a = rects[idx[j - 1]];
+      const int* b = rects[i];
+      int less = (a[3] < b[3]) || (a[3] == b[3] && a[2] < b[2]); /* a's key strictly smaller */
+      if (!less) break;
+      idx[j] = idx[j - 1];
+      j--;
+    }
+    idx[j] = i;
+  }
+  int* em = (int*)malloc(sizeof(int) * (size_t)n);
+  int m = 0, xRecord = 0;
+  for (int i = 0; i < n; i++)
+    if (rects[idx[i]][2] > xRecord) { em[m++] = idx[i]; xRecord = rects[idx[i]][2]; }
+  int c = 0;
+  out[c][0] = 0; out[c][1] = rects[idx[0]][3]; c++;
+  for (int q = 1; q < m; q++) { out[c][0] = rects[em[q - 1]][2]; out[c][1] = rects[em[q]][3]; c++; }
+  out[c][0] = rects[em[m - 1]][2]; out[c][1] = 0; c++;
+  free(idx); free(em);
+  return c;
+}
+
+/* D/space.py:752-805 CornerPoint.  Returns count; *out holds [count,6] in list order (the
+ * empty-bin case returns a plain 2-element list, duplicates and all; otherwise a set). */
+static int corner_point(const pcto_env* h, const oenv* s, int64_t** out) {
+  int orientation = (h->cfg.setting == 2) ? 6 : 2;
+  const int* nb = s->next_box;
+  if (s->n_boxes == 0) {
+    int64_t* res = (int64_t*)malloc(sizeof(int64_t) * 12);
+    int64_t a[12] = {0, 0, 0, nb[0], nb[1], nb[2], 0, 0, 0, nb[1], nb[0], nb[2]};
+    memcpy(res, a, sizeof a);
+    *out = res;
+    return 2;
+  }
+  int n = s->n_boxes;
+  int* T = (int*)malloc(sizeof(int) * (size_t)(n + 1));
+  int nT = 0;
+  T[nT++] = 0;
+  for (int i = 0; i < n; i++) {
+    int top = s->boxes[i].z + s->boxes[i].lz, dup = 0;
+    for (int j = 0; j < nT; j++) if (T[j] == top) dup = 1;
+    if (!dup) T[nT++] = top;
+  }
+  for (int i = 1; i < nT; i++) { int v = T[i], j = i; while (j > 0 && T[j - 1] > v) { T[j] = T[j - 1]; j--; } T[j] = v; }
+  int (*rects)[4] = malloc(sizeof(int[4]) * (size_t)n);
+  int (*cik)[2] = malloc(sizeof(int[2]) * (size_t)(n + 2));
+  int (*last)[2] = malloc(sizeof(int[2]) * (size_t)(n + 2));
+  int nlast = 0;
+  int (*CI)[3] = malloc(sizeof(int[3]) * (size_t)(nT * (n + 2)));
+  int nCI = 0;
+  for (int ti = 0; ti < nT; ti++) {
+    int k = T[ti], nr = 0;
+    for (int i = 0; i < n; i++)
+      if (s->boxes[i].lz + s->boxes[i].z > k) {
+        rects[nr][0] = s->boxes[i].lx; rects[nr][1] = s->boxes[i].ly;
+        rects[nr][2] = s->boxes[i].lx + s->boxes[i].x; rects[nr][3] = s->boxes[i].ly + s->boxes[i].y;
+        nr++;
+      }
+    int nc = corners2d(rects, nr, cik);
+    for (int c = 0; c < nc; c++) {
+      int seen = 0;
+      for (int q = 0; q < nlast; q++) if (last[q][0] == cik[c][0] && last[q][1] == cik[c][1]) seen = 1;
+      if (!seen) { CI[nCI][0] = cik[c][0]; CI[nCI][1] = cik[c][1]; CI[nCI][2] = k; nCI++; }
+    }
+    memcpy(last, cik, sizeof(int[2]) * (size_t)nc);
+    nlast = nc;
+  }
+  int64_t* keys = (int64_t*)malloc(sizeof(int64_t) * 6 * (size_t)(nCI * orientation + 1));
+  int nk = 0;
+  for (int c = 0; c < nCI; c++)
+    for (int rot = 0; rot < orientation; rot++) {
+      int64_t sx, sy, sz;
+      switch (rot) {
+        case 0: sx = nb[0]; sy = nb[1]; sz = nb[2]; break;
+        case 1: sx = nb[1]; sy = nb[0]; sz = nb[2]; if (sx == sy) continue; break;
+        case 2: sx = nb[0]; sy = nb[2]; sz = nb[1]; if (sx == sy && sy == sz) continue; break;
+        case 3: sx = nb[1]; sy = nb[2]; sz = nb[0]; if (sx == sy && sy == sz) continue; break;
+        case 4: sx = nb[2]; sy = nb[0]; sz = nb[1]; if (sx == sy) continue; break;
+        default: sx = nb[2]; sy = nb[1]; sz = nb[0]; if (sx == sy) continue; break;
+      }
+      if (CI[c][0] + sx <= h->cfg.container[0] && CI[c][1] + sy <= h->cfg.container[1] &&
+          CI[c][2] + sz <= h->cfg.container[2]) {
+        int64_t* kk = keys + 6 * (size_t)nk++;
+        kk[0] = CI[c][0]; kk[1] = CI[c][1]; kk[2] = CI[c][2];
+        kk[3] = CI[c][0] + sx; kk[4] = CI[c][1] + sy; kk[5] = CI[c][2] + sz;
+      }
+    }
+  int32_t* order = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nk + 1));
+  int cnt = pcto_pyset_order(keys, nk, order);
+  int64_t* res = (int64_t*)malloc(sizeof(int64_t) * 6 * (size_t)(cnt + 1));
+  for (int i = 0; i < cnt; i++) memcpy(res + 6 * (size_t)i, keys + 6 * (size_t)order[i], 6 * sizeof(int64_t));
+  free(order); free(keys); free(T); free(rects); free(cik); free(last); free(CI);
+  *out = res;
+  return cnt;
+}
+
+/* D/bin3D.py:100-136 get_possible_position (LNES='EMS' / 'CP', shuffle=False): writes the L
  * leaf rows into leaf[L*9] */
 static void get_possible_position(const pcto_env* h, const oenv* s, double* leaf) {
   memset(leaf, 0, sizeof(double) * 9 * h->L);
   int64_t* pos = NULL;
-  int n = ems_point(h, s, &pos);
+  int n = h->cfg.lnes == PCT_LNES_CP ? corner_point(h, s, &pos) : ems_point(h, s, &pos);
   int idx = 0;
   for (int i = 0; i < n; i++) {
     const int64_t* p = pos + 6 * i;
@@ -472,7 +575,7 @@ static void env_step(const pcto_env* h, int e, oenv* s, const double* act, int l
   }
   const obox* pb = &s->boxes[s->n_boxes - 1];
   int64_t loc[6] = {pb->lx, pb->ly, pb->lz, pb->lx + pb->x, pb->ly + pb->y, pb->lz + pb->z};
-  genems(h, s, loc);
+  if (h->cfg.lnes == PCT_LNES_EMS) genems(h, s, loc); /* D/bin3D.py:172-175 */
   /* get_box_ratio :57-59 on self.next_box (the unrotated item) */
   double box_ratio = (double)((int64_t)s->next_box[0] * s->next_box[1] * s->next_box[2]) /
                      (double)((int64_t)h->cfg.container[0] * h->cfg.container[1] * h->cfg.container[2]);
@@ -495,7 +598,10 @@ int pcto_create(const pct_config* cfg, pcto_env** out) {
   if (cfg->env_kind != PCT_ENV_DISCRETE && cfg->env_kind != PCT_ENV_CONTINUOUS)
     return fail(PCT_ERR_UNSUPPORTED, "oracle: unknown env kind");
   if (cfg->setting != 2) return fail(PCT_ERR_UNSUPPORTED, "oracle: only setting 2 is restated");
-  if (cfg->lnes != PCT_LNES_EMS) return fail(PCT_ERR_UNSUPPORTED, "oracle: only LNES=EMS is restated");
+  if (cfg->lnes != PCT_LNES_EMS && cfg->lnes != PCT_LNES_CP)
+    return fail(PCT_ERR_UNSUPPORTED, "oracle: only LNES=EMS and LNES=CP are restated");
+  if (cfg->lnes == PCT_LNES_CP && cfg->env_kind != PCT_ENV_DISCRETE)
+    return fail(PCT_ERR_UNSUPPORTED, "the corner-point scheme exists only in the discrete env");
   if (cfg->num_envs < 1 || cfg->internal_node_holder < 1 || cfg->leaf_node_holder < 1)
     return fail(PCT_ERR_INVALID_ARG, "bad sizes");
   pcto_env* h = (pcto_env*)calloc(1, sizeof *h);

@@ -54,6 +54,7 @@ def gather_rows(obs, I, idx):
     return obs.reshape(N, -1, 9)[np.arange(N), I + idx].copy()
 
 
-GOLDEN_CASES = ["discrete_s2_10_80_50", "discrete_s2_rect_60_30", "discrete_s2_10_80_5", "discrete_s2_20_120_400"]
+GOLDEN_CASES = ["discrete_s2_10_80_50", "discrete_s2_rect_60_30", "discrete_s2_10_80_5", "discrete_s2_20_120_400",
+                "discrete_s2_cp_10_80_50", "discrete_s2_cp_rect_60_16"]
 
 CONT_CASES = ["continuous_s2_10_80_50", "continuous_s2_100_200_200", "continuous_s2_rect_60_20"]

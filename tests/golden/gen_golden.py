@@ -79,6 +79,11 @@ CASES = {
                                 stream_T=256, seed=13, base=7),
     "discrete_s2_20_120_400": dict(setting=2, container=(20, 20, 20), lo=2, hi=7, I=120, L=400, N=2, steps=200,
                                    stream_T=256, seed=14, base=3),
+    # corner-point leaf expansion (--lnes CP, D/space.py:752-805)
+    "discrete_s2_cp_10_80_50": dict(setting=2, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, N=6, steps=250,
+                                    stream_T=256, seed=15, base=11, lnes="CP"),
+    "discrete_s2_cp_rect_60_16": dict(setting=2, container=(9, 13, 10), lo=1, hi=6, I=60, L=16, N=3, steps=200,
+                                      stream_T=256, seed=16, base=0, lnes="CP"),
 }
 
 
@@ -238,7 +243,7 @@ def run_reference(case):
     ratio = np.zeros((c["steps"], N), np.float64)
     for e in range(N):
         env = PD(setting=c["setting"], container_size=list(c["container"]), item_set=item_set,
-                 internal_node_holder=I, leaf_node_holder=L, shuffle=False, LNES="EMS")
+                 internal_node_holder=I, leaf_node_holder=L, shuffle=False, LNES=c.get("lnes", "EMS"))
         env.box_creator = scripted_creator(stream[e])
         obs = env.reset()
         g = c["base"] + e
@@ -265,7 +270,7 @@ def run_oracle(case, stream):
     c = case
     env = OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"],
                        item_set=item_set_range(c["lo"], c["hi"]), internal_node_holder=c["I"],
-                       leaf_node_holder=c["L"], env_id_base=c["base"])
+                       leaf_node_holder=c["L"], env_id_base=c["base"], lnes=3 if c.get("lnes") == "CP" else 0)
     env.set_item_stream(stream)
     N, I, L = c["N"], c["I"], c["L"]
     row_len = (I + L + 1) * 9

@@ -22,7 +22,8 @@ def _pkg():
 def _make(c, stream, **kw):
     return _pkg().PctVecEnv(c["N"], setting=c["setting"], container_size=c["container"],
                             item_set=item_set_range(c["lo"], c["hi"]), internal_node_holder=c["I"],
-                            leaf_node_holder=c["L"], env_id_base=c["base"], item_stream=stream, device="cuda:0", **kw)
+                            leaf_node_holder=c["L"], env_id_base=c["base"], item_stream=stream, device="cuda:0",
+                            LNES=c.get("lnes", "EMS"), **kw)
 
 
 def _check_step(name, t, z, obs, reward, done, infos):
