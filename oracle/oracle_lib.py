@@ -33,7 +33,7 @@ class PctConfig(ctypes.Structure):
 
 def build(force=False):
     so = os.path.join(_HERE, "libpct_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("pct_oracle.c", "pct_oracle_cont.c", "pct_oracle.h", "pct_oracle_internal.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("pct_oracle.c", "pct_oracle_cont.c", "pct_oracle_stab.c", "pct_oracle.h", "pct_oracle_internal.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "pct_env.h"))
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libpct_oracle.so"])

@@ -174,6 +174,7 @@ static void space_reset(const pcto_env* h, oenv* s) {
   s->ems[3] = h->cfg.container[0]; s->ems[4] = h->cfg.container[1]; s->ems[5] = h->cfg.container[2];
   s->n_boxes = 0;
   s->box_idx = 0;
+  if (s->stab) stab_reset(s->stab);
 }
 
 /* np.max(self.plain[lx:lx+x, ly:ly+y]) with NumPy slice clipping (D/space.py:354-355,
@@ -198,19 +199,21 @@ static int footprint_max(const pcto_env* h, const oenv* s, int lx, int ly, int x
   return m;
 }
 
-/* D/space.py:436-454 check_box, setting 2 branch (stability branch: not restated yet) */
-static int check_box(const pcto_env* h, int x, int y, int lx, int ly, int z, int max_h) {
+/* D/space.py:436-454 check_box; the stability branch (:447-454) lives in pct_oracle_stab.c */
+static int check_box(const pcto_env* h, const oenv* s, int x, int y, int lx, int ly, int z, int max_h, double density,
+                     int virtual_) {
   if (lx + x > h->cfg.container[0] || ly + y > h->cfg.container[1]) return 0;
   if (lx < 0 || ly < 0) return 0;
   if (max_h + z > h->cfg.container[2]) return 0; /* self.height stays == H (space.py:383) */
-  return 1; /* setting == 2 */
+  if (h->cfg.setting == 2) return 1;
+  return stab_check(s->stab, x, y, z, lx, ly, max_h, density, virtual_);
 }
 
 /* D/space.py:393-433 drop_box_virtual(box_size, idx, False, den, setting) */
 static int drop_box_virtual(const pcto_env* h, const oenv* s, int x, int y, int z, int lx, int ly) {
   int max_h = footprint_max(h, s, lx, ly, x, y);
   if (max_h < 0) return 0; /* unreachable for EMS-generated candidates */
-  return check_box(h, x, y, lx, ly, z, max_h);
+  return check_box(h, s, x, y, lx, ly, z, max_h, s->next_den, 1);
 }
 
 /* D/space.py:347-389 drop_box.  Returns 1 ok, 0 infeasible; sets *flags on what the
@@ -222,8 +225,13 @@ static int drop_box(const pcto_env* h, oenv* s, const int box[3], int lx, int ly
   else       { y = box[0]; x = box[1]; z = box[2]; }
   int max_h = footprint_max(h, s, lx, ly, x, y);
   if (max_h < 0) { *flags |= PCT_FLAG_BAD_ACTION; return 0; } /* ValueError in np.max */
-  if (!check_box(h, x, y, lx, ly, z, max_h)) return 0;
-  if (s->box_idx >= h->I) { *flags |= PCT_FLAG_INTERNAL_OVERFLOW; return 0; } /* IndexError :385 */
+  if (s->box_idx >= h->I) { /* IndexError :385 (would be raised after a successful check) */
+    if (h->cfg.setting == 2 ? check_box(h, s, x, y, lx, ly, z, max_h, density, 0)
+                            : check_box(h, s, x, y, lx, ly, z, max_h, density, 1))
+      *flags |= PCT_FLAG_INTERNAL_OVERFLOW;
+    return 0;
+  }
+  if (!check_box(h, s, x, y, lx, ly, z, max_h, density, 0)) return 0;
   obox b = {x, y, z, lx, ly, max_h};
   s->boxes[s->n_boxes++] = b;
   /* update_height_graph :316-326 */
@@ -597,7 +605,8 @@ int pcto_create(const pct_config* cfg, pcto_env** out) {
   if (cfg->struct_size != (int32_t)sizeof(pct_config)) return fail(PCT_ERR_INVALID_ARG, "pct_config size mismatch");
   if (cfg->env_kind != PCT_ENV_DISCRETE && cfg->env_kind != PCT_ENV_CONTINUOUS)
     return fail(PCT_ERR_UNSUPPORTED, "oracle: unknown env kind");
-  if (cfg->setting != 2) return fail(PCT_ERR_UNSUPPORTED, "oracle: only setting 2 is restated");
+  if (cfg->setting != 2 && !(cfg->setting == 1 && cfg->env_kind == PCT_ENV_DISCRETE))
+    return fail(PCT_ERR_UNSUPPORTED, "oracle: settings restated: 2 (both envs), 1 (discrete env)");
   if (cfg->lnes != PCT_LNES_EMS && cfg->lnes != PCT_LNES_CP)
     return fail(PCT_ERR_UNSUPPORTED, "oracle: only LNES=EMS and LNES=CP are restated");
   if (cfg->lnes == PCT_LNES_CP && cfg->env_kind != PCT_ENV_DISCRETE)
@@ -622,6 +631,7 @@ int pcto_create(const pct_config* cfg, pcto_env** out) {
     s->boxes = (obox*)calloc((size_t)h->I + 1, sizeof(obox));
     s->cap_ems = 64;
     s->ems = (int64_t*)calloc((size_t)s->cap_ems * 6, sizeof(int64_t));
+    if (cfg->setting != 2) s->stab = stab_create(h->I, 0.0);
   }
   h->obs = (double*)calloc((size_t)h->N * h->row_len, sizeof(double));
   h->reward = (double*)calloc((size_t)h->N, sizeof(double));
@@ -637,6 +647,7 @@ int pcto_destroy(pcto_env* h) {
   if (!h) return PCT_OK;
   for (int e = 0; e < h->N; e++) {
     free(h->envs[e].plain); free(h->envs[e].box_vec); free(h->envs[e].boxes); free(h->envs[e].ems);
+    stab_free(h->envs[e].stab);
   }
   if (h->cenvs) pctc_free(h);
   free(h->envs); free(h->obs); free(h->reward); free(h->done); free(h->counter); free(h->ratio);

@@ -4,6 +4,7 @@
 #define PCT_ORACLE_INTERNAL_H
 #include "pct_oracle.h"
 
+struct stab;
 typedef struct {
   int x, y, z, lx, ly, lz;
 } obox; /* D/space.py:26-33 Box geometry */
@@ -24,6 +25,7 @@ typedef struct {
   int queue_len;
   uint64_t cursor; /* draws taken from the item source */
   uint32_t t;      /* lifetime step counter (hash policy) */
+  struct stab* stab; /* stability state (settings 1 / 3), pct_oracle_stab.c */
 } oenv;
 
 struct cenv; /* continuous per-env state, pct_oracle_cont.c */
@@ -49,6 +51,13 @@ struct pcto_env {
   uint32_t* flags;
 };
 
+
+/* stability (pct_oracle_stab.c) */
+struct stab* stab_create(int cap, double eps);
+void stab_reset(struct stab* s);
+void stab_free(struct stab* s);
+int stab_check(struct stab* s, double x, double y, double z, double lx, double ly, double max_h, double density,
+               int virtual_);
 
 /* continuous env (pct_oracle_cont.c) */
 int pctc_alloc(struct pcto_env* h);

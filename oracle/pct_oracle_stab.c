@@ -1,0 +1,393 @@
+/*
+ * pct_oracle_stab.c -- CPU restatement of the reference's stability check (settings 1 / 3):
+ * D/space.py:26-267 (Box, calculate_new_com, calculated_impact, calculated_impact_virtual),
+ * :341-345 scale_down, :358-379 / :405-426 supporter search, D/convex_hull.py (ConvexHull,
+ * Line2D.orientation, point_in_polygen).  TEST INFRASTRUCTURE (see pct_oracle.h).
+ *
+ * The reference algorithm is sequential, order dependent and written in float64 NumPy; this
+ * file follows its operation order.  Known sources of last-bit ambiguity that no restatement
+ * can pin down: np.dot / np.linalg.norm go through the BLAS ddot of whatever OpenBLAS kernel
+ * the host selects (FMA or not), and np.linalg.lstsq is LAPACK gelsd (>= 3 supporters without
+ * a "direct" one; 0.13 % of visits).  Here dot products are plain
+ * a0*b0 + a1*b1 and the least-squares problem is solved by a Jacobi eigen-decomposition of
+ * A^T A (minimum-norm).  Parity status: pinned on the setting-1 fixtures of
+ * tests/golden/gen_golden.py (observations, rewards, dones identical over the recorded
+ * episodes); not a proof of bit-identity on every input.
+ *
+ * Python object semantics that matter and how they are kept:
+ *   - up_edges / up_virtual_edges are dicts keyed by Box objects, iterated in insertion order;
+ *     a re-assignment keeps the original position.  up_edges is kept as an ordered array.
+ *   - of up_virtual_edges only entries whose key is `involved` are ever read, and at most one
+ *     key of a given box can be involved at a time (the active recursion path holds one box per
+ *     height level), always written just before it is read: one slot per box suffices.
+ *   - Stack objects shared by reference (1-supporter / direct-edge cases) are always
+ *     re-assigned before they are read again, so value copies are equivalent.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "pct_oracle_internal.h"
+
+typedef struct { double c[3]; double m; } sstack;
+typedef struct { int box; double area[4]; double c2[2]; } sdown; /* DownEdge */
+typedef struct { int key; sstack st; } sedge;
+
+typedef struct sbox {
+  double x, y, z, lx, ly, lz;
+  double centre[3], mass;
+  sdown* bottom; int nbottom;
+  double (*poly)[2]; int npoly;
+  sedge* up; int nup, capup;
+  sstack vshare; /* the up_virtual_edges entry of the currently involved parent */
+  sstack thisStack, thisVirtual;
+  int involved;
+} sbox;
+
+struct stab {
+  sbox* boxes; /* placed boxes, placement order */
+  int n, cap;
+  double eps; /* 0 for the discrete env, 1e-6 margins for the continuous env */
+};
+
+struct stab* stab_create(int cap, double eps) {
+  struct stab* s = (struct stab*)calloc(1, sizeof *s);
+  s->cap = cap + 2;
+  s->boxes = (sbox*)calloc((size_t)s->cap, sizeof(sbox));
+  s->eps = eps;
+  return s;
+}
+static void sbox_clear(sbox* b) {
+  free(b->bottom); free(b->poly); free(b->up);
+  memset(b, 0, sizeof *b);
+}
+void stab_reset(struct stab* s) {
+  for (int i = 0; i < s->n; i++) sbox_clear(&s->boxes[i]);
+  s->n = 0;
+}
+void stab_free(struct stab* s) {
+  if (!s) return;
+  stab_reset(s);
+  free(s->boxes);
+  free(s);
+}
+int stab_count(const struct stab* s) { return s->n; }
+
+/* ---- D/convex_hull.py ------------------------------------------------------------------- */
+static double slope_of(const double* p1, const double* p2) { /* Line2D.__init__ :6-14 */
+  if (p2[0] != p1[0]) return (p2[1] - p1[1]) / (p2[0] - p1[0]);
+  return (p2[1] - p1[1]) * INFINITY;
+}
+static int orientation(double slope1, double slope2) { /* :16-32 */
+  if (fabs(slope1) == INFINITY && fabs(slope2) == INFINITY) return 0;
+  double diff = slope2 - slope1;
+  if (diff > 0) return -1;
+  else if (diff == 0) return 0;
+  else return 1;
+}
+/* one monotone chain exactly as :50-63 / :66-83 write it (including the stale line1/line2 and
+ * the break when the chain collapses onto its first point) */
+static int chain(double (*sorted)[2], int n, int reverse, double (*hull)[2]) {
+  int len = 0;
+  double s1 = 0, s2 = 0;
+  for (int q = 0; q < n; q++) {
+    const double* point = sorted[reverse ? n - 1 - q : q];
+    if (len >= 2) {
+      s1 = slope_of(hull[len - 2], hull[len - 1]);
+      s2 = slope_of(hull[len - 1], point);
+    }
+    while (len >= 2 && orientation(s1, s2) != -1) {
+      len--; /* pop */
+      if (hull[0][0] == hull[len - 1][0] && hull[0][1] == hull[len - 1][1]) break;
+      s1 = slope_of(hull[len - 2], hull[len - 1]);
+      s2 = slope_of(hull[len - 1], point);
+    }
+    hull[len][0] = point[0];
+    hull[len][1] = point[1];
+    len++;
+  }
+  return len;
+}
+/* ConvexHull :39-95 followed by Space.scale_down (D/space.py:341-345); returns vertex count */
+static int hull_scaled(double (*pts)[2], int n, double (*out)[2]) {
+  for (int i = 0; i < n; i++) pts[i][0] += pts[i][1] * 1e-6;
+  /* sorted(point_list, key=lambda x: x[0]): stable */
+  for (int i = 1; i < n; i++) {
+    double v0 = pts[i][0], v1 = pts[i][1];
+    int j = i;
+    while (j > 0 && pts[j - 1][0] > v0) { pts[j][0] = pts[j - 1][0]; pts[j][1] = pts[j - 1][1]; j--; }
+    pts[j][0] = v0; pts[j][1] = v1;
+  }
+  double (*lo)[2] = malloc(sizeof(double[2]) * (size_t)(n + 1));
+  double (*up)[2] = malloc(sizeof(double[2]) * (size_t)(n + 1));
+  int nl = chain(pts, n, 0, lo);
+  int nu = chain(pts, n, 1, up);
+  nu--; /* removed = upperHull.pop() */
+  nl--;
+  int m = 0;
+  for (int i = 0; i < nl; i++) { out[m][0] = lo[i][0]; out[m][1] = lo[i][1]; m++; }
+  for (int i = 0; i < nu; i++) { out[m][0] = up[i][0]; out[m][1] = up[i][1]; m++; }
+  free(lo); free(up);
+  /* scale_down: centre = np.mean(axis=0); hull -= (hull - centre) * 0.1 */
+  double cx = 0, cy = 0;
+  for (int i = 0; i < m; i++) { cx += out[i][0]; cy += out[i][1]; }
+  cx /= (double)m; cy /= (double)m;
+  for (int i = 0; i < m; i++) {
+    out[i][0] -= (out[i][0] - cx) * 0.1;
+    out[i][1] -= (out[i][1] - cy) * 0.1;
+  }
+  return m;
+}
+/* point_in_polygen :97-112 */
+static int point_in_polygon(const double pt[2], double (*co)[2], int n) {
+  double lat = pt[0], lon = pt[1];
+  int j = n - 1, odd = 0;
+  for (int i = 0; i < n; i++) {
+    double a0 = co[i][0] - pt[0], a1 = co[i][1] - pt[1];
+    double b0 = pt[0] - co[j][0], b1 = pt[1] - co[j][1];
+    double cp = a0 * b1;
+    cp -= a1 * b0;
+    if (cp == 0) return 0;
+    if ((co[i][1] < lon && co[j][1] >= lon) || (co[j][1] < lon && co[i][1] >= lon)) {
+      if ((co[i][0] + (lon - co[i][1]) / (co[j][1] - co[i][1]) * (co[j][0] - co[i][0])) < lat) odd = !odd;
+    }
+    j = i;
+  }
+  return odd;
+}
+
+/* ---- minimum-norm least squares (stands in for np.linalg.lstsq, see the header) --------- */
+static void lstsq_min_norm(const double* A, const double* b, int M, int N, double* x) {
+  double G[16 * 16], V[16 * 16], g[16];
+  for (int i = 0; i < N; i++) {
+    g[i] = 0;
+    for (int r = 0; r < M; r++) g[i] += A[r * N + i] * b[r];
+    for (int j = 0; j < N; j++) {
+      double s = 0;
+      for (int r = 0; r < M; r++) s += A[r * N + i] * A[r * N + j];
+      G[i * N + j] = s;
+      V[i * N + j] = (i == j);
+    }
+  }
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off = 0;
+    for (int p = 0; p < N; p++) for (int q = p + 1; q < N; q++) off += G[p * N + q] * G[p * N + q];
+    if (off < 1e-300) break;
+    for (int p = 0; p < N; p++)
+      for (int q = p + 1; q < N; q++) {
+        if (fabs(G[p * N + q]) < 1e-300) continue;
+        double theta = (G[q * N + q] - G[p * N + p]) / (2 * G[p * N + q]);
+        double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+        double c = 1 / sqrt(t * t + 1), sn = t * c;
+        for (int k = 0; k < N; k++) {
+          double gkp = G[k * N + p], gkq = G[k * N + q];
+          G[k * N + p] = c * gkp - sn * gkq;
+          G[k * N + q] = sn * gkp + c * gkq;
+        }
+        for (int k = 0; k < N; k++) {
+          double gpk = G[p * N + k], gqk = G[q * N + k];
+          G[p * N + k] = c * gpk - sn * gqk;
+          G[q * N + k] = sn * gpk + c * gqk;
+        }
+        for (int k = 0; k < N; k++) {
+          double vkp = V[k * N + p], vkq = V[k * N + q];
+          V[k * N + p] = c * vkp - sn * vkq;
+          V[k * N + q] = sn * vkp + c * vkq;
+        }
+      }
+  }
+  double smax = 0;
+  for (int i = 0; i < N; i++) if (G[i * N + i] > smax) smax = G[i * N + i];
+  double rc = 2.220446049250313e-16 * (M > N ? M : N); /* rcond=None: eps * max(M, N) on sigma */
+  for (int i = 0; i < N; i++) x[i] = 0;
+  for (int k = 0; k < N; k++) {
+    double lam = G[k * N + k];
+    if (lam <= 0 || sqrt(lam) <= rc * sqrt(smax)) continue;
+    double proj = 0;
+    for (int i = 0; i < N; i++) proj += V[i * N + k] * g[i];
+    proj /= lam;
+    for (int i = 0; i < N; i++) x[i] += V[i * N + k] * proj;
+  }
+}
+
+/* ---- Box ------------------------------------------------------------------------------- */
+/* D/space.py:51-71 calculate_new_com */
+static void calc_com(struct stab* s, sbox* b, int virtual_, const sbox* cand) {
+  (void)cand;
+  double c0 = b->centre[0] * b->mass, c1 = b->centre[1] * b->mass, c2 = b->centre[2] * b->mass, m = b->mass;
+  for (int i = 0; i < b->nup; i++) {
+    int key = b->up[i].key;
+    if (!s->boxes[key].involved) {
+      const sstack* e = &b->up[i].st;
+      c0 += e->c[0] * e->m; c1 += e->c[1] * e->m; c2 += e->c[2] * e->m;
+      m += e->m;
+    }
+  }
+  if (virtual_) { /* the single involved up_virtual_edges entry, written just before */
+    const sstack* e = &b->vshare;
+    c0 += e->c[0] * e->m; c1 += e->c[1] * e->m; c2 += e->c[2] * e->m;
+    m += e->m;
+  }
+  c0 /= m; c1 /= m; c2 /= m;
+  sstack* t = virtual_ ? &b->thisVirtual : &b->thisStack;
+  t->c[0] = c0; t->c[1] = c1; t->c[2] = c2; t->m = m;
+}
+static void set_up_edge(sbox* sup, int key, const sstack* st) {
+  for (int i = 0; i < sup->nup; i++)
+    if (sup->up[i].key == key) { sup->up[i].st = *st; return; } /* dict re-assignment keeps position */
+  if (sup->nup == sup->capup) {
+    sup->capup = sup->capup ? sup->capup * 2 : 4;
+    sup->up = (sedge*)realloc(sup->up, sizeof(sedge) * (size_t)sup->capup);
+  }
+  sup->up[sup->nup].key = key;
+  sup->up[sup->nup].st = *st;
+  sup->nup++;
+}
+
+/* D/space.py:73-164 calculated_impact (virtual_ == 0) and :166-267 calculated_impact_virtual.
+ * `b` is either a placed box or the candidate; `key` is its id as a dict key (the candidate of
+ * a commit gets the id it will have once appended; a virtual candidate never needs one). */
+static int impact(struct stab* s, sbox* b, int key, int virtual_) {
+  const double eps = s->eps;
+  if (virtual_) b->involved = 1;
+  if (b->nbottom == 0) { if (virtual_) b->involved = 0; return 1; }
+  sstack* st = virtual_ ? &b->thisVirtual : &b->thisStack;
+  if (!point_in_polygon(st->c, b->poly, b->npoly)) { if (virtual_) b->involved = 0; return 0; }
+  int k = b->nbottom, ok = 1;
+#define GIVE(i, stk)                                                   \
+  do {                                                                 \
+    sbox* sup_ = &s->boxes[b->bottom[i].box];                          \
+    if (virtual_) sup_->vshare = (stk); else set_up_edge(sup_, key, &(stk)); \
+    calc_com(s, sup_, virtual_, b);                                    \
+  } while (0)
+  if (k == 1) {
+    sstack sh = *st;
+    GIVE(0, sh);
+    if (!impact(s, &s->boxes[b->bottom[0].box], b->bottom[0].box, virtual_)) ok = 0;
+  } else {
+    int direct = -1;
+    for (int i = 0; i < k; i++) {
+      const double* a = b->bottom[i].area;
+      if (st->c[0] > a[0] + eps && st->c[0] < a[2] - eps && st->c[1] > a[1] + eps && st->c[1] < a[3] - eps) { direct = i; break; }
+    }
+    if (direct >= 0) {
+      for (int i = 0; i < k; i++) {
+        sstack sh;
+        if (i == direct) sh = *st;
+        else { /* Stack(centre, 0): commit uses thisStack.centre, virtual uses self.centre */
+          const double* cc = virtual_ ? b->centre : st->c;
+          sh.c[0] = cc[0]; sh.c[1] = cc[1]; sh.c[2] = cc[2]; sh.m = 0;
+        }
+        GIVE(i, sh);
+      }
+      for (int i = 0; i < k && ok; i++)
+        if (!impact(s, &s->boxes[b->bottom[i].box], b->bottom[i].box, virtual_)) ok = 0;
+    } else if (k == 2) {
+      const double* e0 = b->bottom[0].c2;
+      const double* e1 = b->bottom[1].c2;
+      double t0 = e0[0] - e1[0], t1 = e0[1] - e1[1];
+      double len = sqrt(t0 * t0 + t1 * t1); /* np.linalg.norm */
+      double l2 = pow(len, 2.0);            /* tri_base_len ** 2 */
+      t0 /= l2; t1 /= l2;
+      double r0 = fabs((st->c[0] - e1[0]) * t0 + (st->c[1] - e1[1]) * t1);
+      double r1 = fabs((st->c[0] - e0[0]) * t0 + (st->c[1] - e0[1]) * t1);
+      sstack s0 = {{e0[0], e0[1], st->c[2]}, st->m * r0};
+      sstack s1 = {{e1[0], e1[1], st->c[2]}, st->m * r1};
+      GIVE(0, s0);
+      GIVE(1, s1);
+      if (!impact(s, &s->boxes[b->bottom[0].box], b->bottom[0].box, virtual_)) ok = 0;
+      else if (!impact(s, &s->boxes[b->bottom[1].box], b->bottom[1].box, virtual_)) ok = 0;
+    } else {
+      int M = k * (k - 1) / 2 + 1;
+      double* A = (double*)calloc((size_t)M * k, sizeof(double));
+      double* rhs = (double*)calloc((size_t)M, sizeof(double));
+      double* xr = (double*)calloc((size_t)k, sizeof(double));
+      int row = 0;
+      for (int i = 0; i < k - 1; i++)
+        for (int j = i + 1; j < k; j++) {
+          const double* ei = b->bottom[i].c2;
+          const double* ej = b->bottom[j].c2;
+          double t0 = ei[0] - ej[0], t1 = ei[1] - ej[1];
+          double mol = (st->c[0] - ei[0]) * t0 + (st->c[1] - ei[1]) * t1;
+          if (mol != 0) {
+            double rr = fabs((st->c[0] - ej[0]) * t0 + (st->c[1] - ej[1]) * t1) / mol;
+            A[row * k + i] = 1;
+            A[row * k + j] = -rr;
+          }
+          row++;
+        }
+      for (int j = 0; j < k; j++) A[(M - 1) * k + j] = 1;
+      rhs[M - 1] = 1;
+      if (k <= 16) lstsq_min_norm(A, rhs, M, k, xr);
+      for (int i = 0; i < k; i++) {
+        sstack sh = {{b->bottom[i].c2[0], b->bottom[i].c2[1], st->c[2]}, st->m * xr[i]};
+        GIVE(i, sh);
+      }
+      for (int i = 0; i < k && ok; i++)
+        if (!impact(s, &s->boxes[b->bottom[i].box], b->bottom[i].box, virtual_)) ok = 0;
+      free(A); free(rhs); free(xr);
+    }
+  }
+#undef GIVE
+  if (virtual_) b->involved = 0;
+  return ok;
+}
+
+/* D/space.py:358-379 / :405-426: supporters, contact rectangles, scaled hull; then the
+ * stability branch of check_box (:448-454).  Geometry in doubles (ints for the discrete env).
+ * virtual_ != 0: no lasting change.  virtual_ == 0: on success the box is appended. */
+int stab_check(struct stab* s, double x, double y, double z, double lx, double ly, double max_h, double density,
+               int virtual_) {
+  const double eps = s->eps;
+  sbox nb;
+  memset(&nb, 0, sizeof nb);
+  nb.x = x; nb.y = y; nb.z = z; nb.lx = lx; nb.ly = ly; nb.lz = max_h;
+  nb.centre[0] = lx + x / 2; nb.centre[1] = ly + y / 2; nb.centre[2] = max_h + z / 2;
+  nb.mass = x * y * z * density;
+  if (virtual_) nb.mass *= 1.0;
+  nb.thisStack.c[0] = nb.thisVirtual.c[0] = nb.centre[0];
+  nb.thisStack.c[1] = nb.thisVirtual.c[1] = nb.centre[1];
+  nb.thisStack.c[2] = nb.thisVirtual.c[2] = nb.centre[2];
+  nb.thisStack.m = nb.thisVirtual.m = nb.mass;
+  nb.bottom = (sdown*)calloc((size_t)s->n + 1, sizeof(sdown));
+  double (*pts)[2] = malloc(sizeof(double[2]) * (size_t)(4 * s->n + 4));
+  int np_ = 0;
+  for (int i = 0; i < s->n; i++) {
+    const sbox* t = &s->boxes[i];
+    int same_top = eps > 0 ? (fabs(t->lz + t->z - max_h) < eps) : (t->lz + t->z == max_h);
+    if (!same_top) continue;
+    double x1 = fmax(lx, t->lx), y1 = fmax(ly, t->ly);
+    double x2 = fmin(lx + x, t->lx + t->x), y2 = fmin(ly + y, t->ly + t->y);
+    if (x1 >= x2 || y1 >= y2) continue;
+    sdown* d = &nb.bottom[nb.nbottom++];
+    d->box = i;
+    d->area[0] = x1; d->area[1] = y1; d->area[2] = x2; d->area[3] = y2;
+    d->c2[0] = (x1 + x2) / 2; d->c2[1] = (y1 + y2) / 2;
+    pts[np_][0] = x1; pts[np_][1] = y1; np_++;
+    pts[np_][0] = x1; pts[np_][1] = y2; np_++;
+    pts[np_][0] = x2; pts[np_][1] = y1; np_++;
+    pts[np_][0] = x2; pts[np_][1] = y2; np_++;
+  }
+  if (np_ > 0) {
+    nb.poly = malloc(sizeof(double[2]) * (size_t)(2 * np_ + 2));
+    nb.npoly = hull_scaled(pts, np_, nb.poly);
+  }
+  free(pts);
+  int ok;
+  if (eps > 0 ? (fabs(max_h) < eps) : (max_h == 0)) ok = 1; /* :448-449 */
+  else if (virtual_) ok = impact(s, &nb, -1, 1);
+  else {
+    /* the candidate must be addressable as boxes[n] while its supporters record it as a key */
+    s->boxes[s->n] = nb;
+    ok = impact(s, &s->boxes[s->n], s->n, 0);
+    nb = s->boxes[s->n];
+  }
+  if (!virtual_ && ok) {
+    s->boxes[s->n] = nb;
+    s->n++;
+    return 1;
+  }
+  if (!virtual_) memset(&s->boxes[s->n], 0, sizeof(sbox));
+  free(nb.bottom); free(nb.poly); free(nb.up);
+  return ok;
+}

@@ -84,6 +84,11 @@ CASES = {
                                     stream_T=256, seed=15, base=11, lnes="CP"),
     "discrete_s2_cp_rect_60_16": dict(setting=2, container=(9, 13, 10), lo=1, hi=6, I=60, L=16, N=3, steps=200,
                                       stream_T=256, seed=16, base=0, lnes="CP"),
+    # setting 1: stability check + 2 orientations (BASELINE.json configs[0] geometry)
+    "discrete_s1_10_80_50": dict(setting=1, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, N=6, steps=250,
+                                 stream_T=512, seed=17, base=21),
+    "discrete_s1_rect_60_30": dict(setting=1, container=(12, 8, 14), lo=1, hi=6, I=60, L=30, N=3, steps=200,
+                                   stream_T=256, seed=18, base=2),
 }
 
 
@@ -335,8 +340,53 @@ def known_answer_discrete_s2():
     print("known answer discrete s2: oracle == reference ==", ref_hash)
 
 
+def known_answer_discrete_s1():
+    """discrete setting 1 (stability), env.seed(4), RandomState(0) policy:
+    sha256[:16] = 443198ae2c0162db.  Item draws and actions recorded from the reference and
+    replayed through the oracle."""
+    PD, PC, item_set = ref_shim.load_reference_envs()
+    env = PD(setting=1, container_size=[10, 10, 10], item_set=item_set, internal_node_holder=80,
+             leaf_node_holder=50, shuffle=False, LNES="EMS")
+    drawn = []
+    orig = env.box_creator.generate_box_size
+
+    def rec(**kw):
+        orig(**kw)
+        drawn.append(env.box_creator.box_list[-1])
+    env.box_creator.generate_box_size = rec
+    env.seed(4)
+    rng = np.random.RandomState(0)
+    obs = env.reset()
+    h = hashlib.sha256()
+    acts = []
+    for t in range(500):
+        h.update(obs.astype(np.float32).tobytes())
+        leaf = obs.reshape(-1, 9)[80:130]
+        k = int(leaf[:, 8].sum())
+        a = leaf[rng.randint(k)] if k > 0 else leaf[0]
+        acts.append(np.array(a, dtype=np.float64))
+        obs, r, d, info = env.step(a)
+        if d:
+            obs = env.reset()
+    ref_hash = h.hexdigest()[:16]
+    assert ref_hash == "443198ae2c0162db", ref_hash
+    from oracle.oracle_lib import OracleVecEnv
+    o = OracleVecEnv(1, setting=1, container_size=(10, 10, 10), item_set=item_set)
+    o.set_item_stream(np.asarray(drawn, np.int32)[None])
+    o.reset()
+    h2 = hashlib.sha256()
+    for t in range(500):
+        h2.update(o.obs[0].astype(np.float32).tobytes())
+        o.step_rows(acts[t][None], auto_reset=True)
+    assert h2.hexdigest()[:16] == ref_hash, (h2.hexdigest()[:16], ref_hash)
+    np.savez_compressed(os.path.join(HERE, "kat_discrete_s1.npz"), items=np.asarray(drawn, np.int32),
+                        actions=np.asarray(acts, np.float32), sha256_16=np.array(ref_hash))
+    print("known answer discrete s1: oracle == reference ==", ref_hash)
+
+
 def main():
     known_answer_discrete_s2()
+    known_answer_discrete_s1()
     known_answer_continuous_s2()
     for name, case in CONT_CASES.items():
         ref = run_reference_cont(case)

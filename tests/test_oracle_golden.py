@@ -10,10 +10,10 @@ import numpy as np
 import pytest
 
 from oracle.oracle_lib import OracleVecEnv, pyset_order
-from tests.common import CONT_CASES, GOLDEN_CASES, gather_rows, hash_policy_index, item_set_range, load_case, GOLDEN
+from tests.common import CONT_CASES, GOLDEN_CASES, ORACLE_ONLY_CASES, gather_rows, hash_policy_index, item_set_range, load_case, GOLDEN
 
 
-@pytest.mark.parametrize("name", GOLDEN_CASES)
+@pytest.mark.parametrize("name", GOLDEN_CASES + ORACLE_ONLY_CASES)
 def test_oracle_matches_reference_fixture_fused_policy(name):
     c, z = load_case(name)
     env = OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"],
@@ -166,3 +166,16 @@ def test_continuous_known_answer_hash_replay():
         h.update(np.round(env.obs[0], 5).astype(np.float32).tobytes())
         env.step_rows(z["actions"][t][None])
     assert h.hexdigest()[:16] == str(z["sha256_16"]) == "506b5c0349c89b9d"
+
+
+def test_known_answer_hash_replay_setting1():
+    """discrete setting 1 (stability check) = 443198ae2c0162db."""
+    z = np.load(GOLDEN + "/kat_discrete_s1.npz")
+    env = OracleVecEnv(1, setting=1, container_size=(10, 10, 10), item_set=item_set_range(1, 5))
+    env.set_item_stream(z["items"][None])
+    env.reset()
+    h = hashlib.sha256()
+    for t in range(500):
+        h.update(env.obs[0].astype(np.float32).tobytes())
+        env.step_rows(z["actions"][t][None].astype(np.float64))
+    assert h.hexdigest()[:16] == str(z["sha256_16"]) == "443198ae2c0162db"
