@@ -76,6 +76,8 @@ extern "C" {
                                             raises IndexError at space.py:385 */
 #define PCT_FLAG_EMS_OVERFLOW 0x2u       /* EMS list exceeded ems_capacity */
 #define PCT_FLAG_CANDIDATE_OVERFLOW 0x4u /* leaf-candidate set exceeded candidate_capacity */
+#define PCT_FLAG_STABILITY_OVERFLOW 0x10u /* stability check: more supporters / hull vertices /
+                                             support-graph depth than the kernel keeps */
 #define PCT_FLAG_BAD_ACTION 0x8u         /* malformed action: reference raises ValueError at
                                             bin3D.py:144-145 (list.remove) or in np.max of an
                                             empty slice (space.py:354-355) */

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpct_hip.so")
 SOURCES = ["pct_env.hip", "pct_discrete.hip", "pct_continuous.hip"]
-HEADERS = [os.path.join(CSRC, "pct_device.h"), os.path.join(CSRC, "pct_set.cuh"),
+HEADERS = [os.path.join(CSRC, "pct_device.h"), os.path.join(CSRC, "pct_set.cuh"), os.path.join(CSRC, "pct_stab.cuh"),
            os.path.join(HERE, "..", "include", "pct_env.h")]
 
 

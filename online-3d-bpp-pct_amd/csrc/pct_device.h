@@ -35,6 +35,13 @@ struct DiscreteParams {
   int32_t* scalars; /* [N,PCT_SCALARS]: n_ems,n_boxes,n_leaf,item[3],t,-,cursor lo/hi,vol lo/hi */
   uint32_t* flags;  /* [N] sticky PCT_FLAG_* */
   unsigned long long* timing; /* [N,8] per-phase cycle accumulators, or null */
+  // stability state (settings 1/3 only; csrc/pct_stab.cuh): per env and placed box
+  double* st_stack; /* [N,I,4] committed stack: centre xyz, mass */
+  int* st_nsup;     /* [N,I] */
+  int* st_sup;      /* [N,I,STAB_SMAX] supporters in bottom_edges order */
+  double* st_share; /* [N,I,STAB_SMAX,4] share handed to each supporter */
+  int* st_npoly;    /* [N,I] */
+  double* st_poly;  /* [N,I,STAB_PMAX,2] scaled support polygon */
   // outputs
   float* obs;       /* [N,row_len] */
   float* reward;    /* [N] */

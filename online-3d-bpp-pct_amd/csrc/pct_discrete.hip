@@ -25,6 +25,7 @@
 #include "pct_device.h"
 
 #include "pct_set.cuh"
+#include "pct_stab.cuh"
 
 namespace pct {
 
@@ -86,6 +87,28 @@ __device__ inline Lds<K, BITS> carve_lds(const DiscreteParams& p, unsigned char*
   l.vp = reinterpret_cast<uint16_t*>(l.hmap + p.AA);
   l.cp = reinterpret_cast<uint32_t*>(l.vp + 64);
   return l;
+}
+
+// placed-box geometry for the stability code: lx,ly,lz,xe,ye,ze from the packed LDS boxes
+template <typename K, int BITS>
+struct BoxGeo {
+  const K* box;
+  __device__ inline void operator()(int i, double g[6]) const {
+    K k = box[i];
+#pragma unroll
+    for (int c = 0; c < 6; c++) g[c] = (double)Pack<K, BITS>::get(k, c);
+  }
+};
+__device__ inline StabState stab_view(const DiscreteParams& p, int e) {
+  StabState st;
+  st.I = p.I;
+  st.stack = p.st_stack + (size_t)e * p.I * 4;
+  st.nsup = p.st_nsup + (size_t)e * p.I;
+  st.sup = p.st_sup + (size_t)e * p.I * STAB_SMAX;
+  st.share = p.st_share + (size_t)e * p.I * STAB_SMAX * 4;
+  st.npoly = p.st_npoly + (size_t)e * p.I;
+  st.poly = p.st_poly + (size_t)e * p.I * STAB_PMAX * 2;
+  return st;
 }
 
 __device__ inline void draw_item(const DiscreteParams& p, int e, EnvRegs& r) {
@@ -206,8 +229,8 @@ __device__ inline void genems(const DiscreteParams& p, Lds<K, BITS>& l, EnvRegs&
 
 // D/space.py:534-570 EMSPoint (CPython-set order) + D/bin3D.py:100-136
 // get_possible_position: fills l.leaf[0..n_leaf) with the first <= L feasible candidates.
-template <typename K, int BITS, typename TM>
-__device__ inline void leaf_nodes(const DiscreteParams& p, Lds<K, BITS>& l, EnvRegs& r, int lane, TM& tm) {
+template <typename K, int BITS, bool STAB, bool CP, typename TM>
+__device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& l, EnvRegs& r, int lane, TM& tm) {
   typedef Pack<K, BITS> P;
   const uint64_t lt = lanemask_lt(lane);
   const int E = r.n_ems;
@@ -300,7 +323,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, Lds<K, BITS>& l, EnvR
     }
   };
 
-  if (p.lnes == PCT_LNES_CP && r.n_boxes == 0) {
+  if (CP && r.n_boxes == 0) {
     // D/space.py:756-757: an empty bin yields a plain two-element LIST (unrotated, x/y
     // swapped; no set, no in-bin test): slots 0 and 1 of the fresh 8-slot table hold them in
     // list order, duplicates included
@@ -309,7 +332,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, Lds<K, BITS>& l, EnvR
       tabs[toff + 1] = P::pack(0, 0, 0, b1, b0, b2);
     }
     __syncthreads();
-  } else if (p.lnes == PCT_LNES_CP) {
+  } else if (CP) {
     // D/space.py:758-774 + D/PctTools.py:137-158: per level k (sorted distinct tops, 0 first)
     // the corner points of the boxes reaching above k, minus those of the previous level
     const int n = r.n_boxes;
@@ -484,6 +507,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, Lds<K, BITS>& l, EnvR
 
   // iterate the table in slot order (= list(set)), test feasibility, keep the first L
   int nleaf = 0;
+  bool stab_err = false;
   for (uint32_t sb = 0; sb < size && nleaf < p.L; sb += 64) {
     uint32_t s = sb + lane;
     K k = (s < size) ? tabs[toff + s] : SlotWord<K>::EMPTY;
@@ -499,12 +523,20 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, Lds<K, BITS>& l, EnvR
         }
       // check_box :436-446: EMS candidates are inside the bin by construction
       feas = (xe <= p.W) && (ye <= p.Ly) && (mh + z <= p.H);
+      if (STAB && feas && mh != 0) {  // :447-454 calculated_impact_virtual(first=True)
+        const double cand[6] = {(double)xs, (double)ys, (double)mh, (double)xe, (double)ye, (double)(mh + z)};
+        BoxGeo<K, BITS> geo{l.box};
+        bool err;
+        feas = stab_virtual(geo, stab_view(p, e), r.n_boxes, cand, 1.0, err);
+        if (err) stab_err = true;
+      }
     }
     uint64_t m = __ballot(feas);
     int idx = nleaf + __popcll(m & lt);
     if (feas && idx < p.L) l.leaf[idx] = k;
     nleaf += __popcll(m);
   }
+  if (STAB && __ballot(stab_err)) r.flags |= PCT_FLAG_STABILITY_OVERFLOW;
   r.n_leaf = nleaf < p.L ? nleaf : p.L;
   __syncthreads();
   tm.tick(PH_FEAS);
@@ -587,7 +619,7 @@ __device__ inline void store_state(const DiscreteParams& p, int e, const Lds<K, 
 
 // One transition of one env with the state resident in LDS (D/bin3D.py:151-188 plus the
 // VecEnv worker's auto-reset).  (flag, lx, ly) + (bx, by, bz) is the decoded action.
-template <typename K, int BITS, typename TM>
+template <typename K, int BITS, bool STAB, bool CP, typename TM>
 __device__ inline void transition(const DiscreteParams& p, int e, Lds<K, BITS>& l, EnvRegs& r, int lane, bool bad,
                                   int flag, int lx, int ly, int bx, int by, int bz, TM& tm) {
   typedef Pack<K, BITS> P;
@@ -620,6 +652,33 @@ __device__ inline void transition(const DiscreteParams& p, int e, Lds<K, BITS>& 
       ok = !(lx + x > p.W || ly + y > p.Ly) && !(max_h + z > p.H);
     }
   }
+  if (STAB && ok && r.n_boxes < p.I && max_h != 0) {
+    // check_box :450-451: box_now.calculated_impact() -- one lane walks the support graph and
+    // commits the new shares / stacks (the box is only kept if the verdict is True)
+    if (lane == 0) l.box[r.n_boxes] = P::pack(lx, ly, max_h, lx + x, ly + y, max_h + z);
+    __syncthreads();
+    int verdict = 1, serr = 0;
+    if (lane == 0) {
+      BoxGeo<K, BITS> geo{l.box};
+      StabState st = stab_view(p, e);
+      bool err;
+      verdict = stab_commit(geo, st, r.n_boxes, 1.0, err) ? 1 : 0;
+      serr = err ? 1 : 0;
+    }
+    verdict = __shfl(verdict, 0, 64);
+    if (__shfl(serr, 0, 64)) r.flags |= PCT_FLAG_STABILITY_OVERFLOW;
+    ok = verdict != 0;
+  } else if (STAB && ok && r.n_boxes < p.I) {
+    // resting on the floor: no supporters, stack = own (still recorded for later checks)
+    if (lane == 0) l.box[r.n_boxes] = P::pack(lx, ly, max_h, lx + x, ly + y, max_h + z);
+    __syncthreads();
+    if (lane == 0) {
+      BoxGeo<K, BITS> geo{l.box};
+      StabState st = stab_view(p, e);
+      bool err;
+      stab_commit(geo, st, r.n_boxes, 1.0, err);
+    }
+  }
   if (ok && r.n_boxes >= p.I) {  // IndexError at D/space.py:385
     ok = false;
     r.flags |= PCT_FLAG_INTERNAL_OVERFLOW;
@@ -638,7 +697,7 @@ __device__ inline void transition(const DiscreteParams& p, int e, Lds<K, BITS>& 
     r.vol += (int64_t)x * y * z;
     __syncthreads();
     tm.tick(PH_DROP);
-    if (p.lnes == PCT_LNES_EMS) genems<K, BITS>(p, l, r, lane, lx, ly, max_h, lx + x, ly + y, top);  // D/bin3D.py:172-175
+    if (!CP) genems<K, BITS>(p, l, r, lane, lx, ly, max_h, lx + x, ly + y, top);  // D/bin3D.py:172-175
     tm.tick(PH_GENEMS);
     // D/bin3D.py:57-59,183: 10 * vol(item) / vol(bin), float64 then envs.py:181 .float()
     reward = (float)(((double)((int64_t)r.item0 * r.item1 * r.item2) / binvol) * 10.0);
@@ -691,7 +750,7 @@ __device__ inline void decode_leaf(const EnvRegs& r, bool zero_row, int xs, int 
 
 enum { ACT_ROWS = 0, ACT_INDEX = 1, ACT_HASH = 2, ACT_RESET = 3 };
 
-template <typename K, int BITS, int ACT, bool TIMED>
+template <typename K, int BITS, int ACT, bool TIMED, bool STAB, bool CP>
 __global__ void __launch_bounds__(64) pct_discrete_kernel(DiscreteParams p, const void* __restrict__ actions,
                                                           int row_len, int n_steps,
                                                           const int32_t* __restrict__ env_ids, int n_ids) {
@@ -715,7 +774,7 @@ __global__ void __launch_bounds__(64) pct_discrete_kernel(DiscreteParams p, cons
     space_reset<K, BITS>(p, l, r, lane);
     __syncthreads();
     draw_item(p, e, r);
-    leaf_nodes<K, BITS>(p, l, r, lane, tm);
+    leaf_nodes<K, BITS, STAB, CP>(p, e, l, r, lane, tm);
     write_obs<K, BITS>(p, l, r, lane, obs);
     store_state<K, BITS>(p, e, l, r, lane);
     return;
@@ -751,8 +810,8 @@ __global__ void __launch_bounds__(64) pct_discrete_kernel(DiscreteParams p, cons
       decode_leaf(r, zero_row, P::get(k, 0), P::get(k, 1), P::get(k, 3), P::get(k, 4), bad, lx, ly, bx, by, bz);
     }
     if (bad) r.flags |= PCT_FLAG_BAD_ACTION;  // ValueError in list.remove, D/bin3D.py:144-145
-    transition<K, BITS>(p, e, l, r, lane, bad, flag, lx, ly, bx, by, bz, tm);
-    leaf_nodes<K, BITS>(p, l, r, lane, tm);
+    transition<K, BITS, STAB, CP>(p, e, l, r, lane, bad, flag, lx, ly, bx, by, bz, tm);
+    leaf_nodes<K, BITS, STAB, CP>(p, e, l, r, lane, tm);
     write_obs<K, BITS>(p, l, r, lane, obs);
     __syncthreads();
     tm.tick(PH_OBS);
@@ -799,11 +858,17 @@ static hipError_t launch_typed(const DiscreteParams& p, int act, const void* act
                                const int32_t* env_ids, int n_ids, hipStream_t stream) {
   size_t lds = discrete_lds_bytes(p);
   const bool timed = p.timing != nullptr && act != ACT_RESET;
+  const bool stab = p.setting != 2;
+  const bool cp = p.lnes == PCT_LNES_CP;
   int grid = (act == ACT_RESET && env_ids) ? n_ids : p.N;
   if (grid <= 0) return hipSuccess;
 #define PCT_LAUNCH(A)                                                                                        \
   do {                                                                                                       \
-    auto kern = timed ? pct_discrete_kernel<K, BITS, A, true> : pct_discrete_kernel<K, BITS, A, false>;                                                             \
+    auto kern = stab ? (cp ? pct_discrete_kernel<K, BITS, A, false, true, true>                              \
+                           : pct_discrete_kernel<K, BITS, A, false, true, false>)                            \
+                     : (cp ? pct_discrete_kernel<K, BITS, A, false, false, true>                             \
+                           : (timed ? pct_discrete_kernel<K, BITS, A, true, false, false>                    \
+                                    : pct_discrete_kernel<K, BITS, A, false, false, false>));                \
     if (lds > 48 * 1024) {                                                                                   \
       hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                               \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \

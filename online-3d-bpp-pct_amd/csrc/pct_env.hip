@@ -12,6 +12,7 @@
 
 #include "../../include/pct_env.h"
 #include "pct_device.h"
+#include "pct_stab.cuh"
 
 namespace {
 thread_local char g_err[512] = "";
@@ -129,7 +130,8 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
   if (cfg->env_kind != PCT_ENV_DISCRETE && cfg->env_kind != PCT_ENV_CONTINUOUS)
     return fail(PCT_ERR_INVALID_ARG, "unknown env_kind");
   const bool cont = cfg->env_kind == PCT_ENV_CONTINUOUS;
-  if (cfg->setting != 2) return fail(PCT_ERR_UNSUPPORTED, "only setting 2 is built so far");
+  if (cfg->setting != 2 && !(cfg->setting == 1 && cfg->env_kind == PCT_ENV_DISCRETE))
+    return fail(PCT_ERR_UNSUPPORTED, "settings built: 2 (both envs) and 1 (discrete env)");
   if (cfg->lnes != PCT_LNES_EMS && cfg->lnes != PCT_LNES_CP)
     return fail(PCT_ERR_UNSUPPORTED, "LNES must be EMS or CP");
   if (cfg->lnes == PCT_LNES_CP && cfg->env_kind != PCT_ENV_DISCRETE)
@@ -245,6 +247,14 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
   ALLOC(p.boxes, N * p.I * p.key_bytes);
   ALLOC(p.leaves, N * p.L * p.key_bytes);
   ALLOC(p.scalars, N * PCT_SCALARS * sizeof(int32_t));
+  if (cfg->setting != 2) {
+    ALLOC(p.st_stack, N * p.I * 4 * sizeof(double));
+    ALLOC(p.st_nsup, N * p.I * sizeof(int));
+    ALLOC(p.st_sup, N * p.I * pct::STAB_SMAX * sizeof(int));
+    ALLOC(p.st_share, N * p.I * pct::STAB_SMAX * 4 * sizeof(double));
+    ALLOC(p.st_npoly, N * p.I * sizeof(int));
+    ALLOC(p.st_poly, N * p.I * pct::STAB_PMAX * 2 * sizeof(double));
+  }
   ALLOC(h->own_flags, N * sizeof(uint32_t));
   ALLOC(h->own_obs, N * p.row_len * sizeof(float));
   ALLOC(h->own_reward, N * sizeof(float));

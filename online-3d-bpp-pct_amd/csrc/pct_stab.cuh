@@ -1,0 +1,466 @@
+// pct_stab.cuh -- the reference's stability check (settings 1 / 3) restructured for one GPU
+// lane per candidate: no recursion, no per-box dictionaries, no hidden state.
+//
+// Reference (D/ = pct_envs/PctDiscrete0/): Box.calculate_new_com D/space.py:51-71,
+// calculated_impact :73-164, calculated_impact_virtual :166-267, scale_down :341-345, supporter
+// search :358-379 / :405-426, check_box :447-454; ConvexHull / Line2D.orientation /
+// point_in_polygen D/convex_hull.py:4-112.
+//
+// What is stored per placed box b (HBM, per env): its committed stack `stack[b]` (centre xyz,
+// mass), its supporters `sup[b][i]` in bottom_edges order, the share it hands each of them
+// `share[b][i]` and its scaled support polygon.  Everything else is recomputed:
+//   * S.up_edges (a dict keyed by boxes, iterated in insertion order) == the boxes that list S
+//     as a supporter, in ascending id (a key is first inserted when that box is committed), so
+//     calculate_new_com(S) is a scan over the boxes above S reading share[B][idx(S)];
+//   * of S.up_virtual_edges only the entry of the currently `involved` parent is ever read and
+//     it is written just before; `involved` == "on the active path";
+//   * a supporter's virtual stack is recomputed when it is visited instead of when its parent
+//     distributes: nothing it depends on can change in between (siblings' subtrees lie strictly
+//     below the parent and never contain a sibling).
+// The control flow (first False anywhere aborts everything) makes the recursion an iterative
+// depth-first walk with a small explicit stack.
+//
+// The same source compiles for the host (tests/host/stab_host.cpp) so that the restructured
+// algorithm is checked against the oracle and the reference fixtures on the CPU as well.
+#ifndef PCT_STAB_CUH
+#define PCT_STAB_CUH
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define PCT_SD __device__ inline
+#else
+#define PCT_SD static inline
+#endif
+
+namespace pct {
+
+constexpr int STAB_SMAX = 8;    // supporters per box kept (more -> PCT_FLAG_STABILITY_OVERFLOW)
+constexpr int STAB_PMAX = 24;   // hull vertices kept
+constexpr int STAB_DEPTH = 24;  // explicit stack depth
+
+// per-env view of the stability state; geometry via `geo(i, g)` -> lx,ly,lz,xe,ye,ze (doubles)
+struct StabState {
+  int I;           // internal_node_holder (row stride)
+  double* stack;   // [I][4]
+  int* nsup;       // [I]
+  int* sup;        // [I][STAB_SMAX]
+  double* share;   // [I][STAB_SMAX][4]
+  int* npoly;      // [I]
+  double* poly;    // [I][STAB_PMAX][2]
+};
+
+struct StabBox {  // a box being examined (candidate or placed), with its supporters
+  double g[6];    // lx,ly,lz,xe,ye,ze
+  int nsup;
+  int sup[STAB_SMAX];
+  double area[STAB_SMAX][4];
+  double c2[STAB_SMAX][2];
+};
+
+// ---- D/convex_hull.py ---------------------------------------------------------------------
+PCT_SD double stab_slope(const double* p1, const double* p2) {
+  if (p2[0] != p1[0]) return (p2[1] - p1[1]) / (p2[0] - p1[0]);
+  return (p2[1] - p1[1]) * INFINITY;
+}
+PCT_SD int stab_orientation(double s1, double s2) {
+  if (fabs(s1) == INFINITY && fabs(s2) == INFINITY) return 0;
+  double diff = s2 - s1;
+  if (diff > 0) return -1;
+  else if (diff == 0) return 0;
+  return 1;
+}
+// one chain of ConvexHull (:50-63 / :66-83), stale line slopes and collapse-break included
+PCT_SD int stab_chain(const double (*sorted)[2], int n, bool reverse, double (*hull)[2]) {
+  int len = 0;
+  double s1 = 0, s2 = 0;
+  for (int q = 0; q < n; q++) {
+    const double* point = sorted[reverse ? n - 1 - q : q];
+    if (len >= 2) {
+      s1 = stab_slope(hull[len - 2], hull[len - 1]);
+      s2 = stab_slope(hull[len - 1], point);
+    }
+    while (len >= 2 && stab_orientation(s1, s2) != -1) {
+      len--;
+      if (hull[0][0] == hull[len - 1][0] && hull[0][1] == hull[len - 1][1]) break;
+      s1 = stab_slope(hull[len - 2], hull[len - 1]);
+      s2 = stab_slope(hull[len - 1], point);
+    }
+    hull[len][0] = point[0];
+    hull[len][1] = point[1];
+    len++;
+  }
+  return len;
+}
+// ConvexHull + scale_down of the 4*nsup contact corners of `b`; returns the vertex count
+// (<= STAB_PMAX, else -1)
+PCT_SD int stab_polygon(const StabBox& b, double (*out)[2]) {
+  double pts[4 * STAB_SMAX][2];
+  int n = 0;
+  for (int i = 0; i < b.nsup; i++) {
+    const double* a = b.area[i];
+    pts[n][0] = a[0]; pts[n][1] = a[1]; n++;
+    pts[n][0] = a[0]; pts[n][1] = a[3]; n++;
+    pts[n][0] = a[2]; pts[n][1] = a[1]; n++;
+    pts[n][0] = a[2]; pts[n][1] = a[3]; n++;
+  }
+  for (int i = 0; i < n; i++) pts[i][0] += pts[i][1] * 1e-6;
+  for (int i = 1; i < n; i++) {  // stable sort by x
+    double v0 = pts[i][0], v1 = pts[i][1];
+    int j = i;
+    while (j > 0 && pts[j - 1][0] > v0) { pts[j][0] = pts[j - 1][0]; pts[j][1] = pts[j - 1][1]; j--; }
+    pts[j][0] = v0; pts[j][1] = v1;
+  }
+  double lo[4 * STAB_SMAX + 1][2], up[4 * STAB_SMAX + 1][2];
+  int nl = stab_chain(pts, n, false, lo) - 1;
+  int nu = stab_chain(pts, n, true, up) - 1;
+  if (nl + nu > STAB_PMAX) return -1;
+  int m = 0;
+  for (int i = 0; i < nl; i++) { out[m][0] = lo[i][0]; out[m][1] = lo[i][1]; m++; }
+  for (int i = 0; i < nu; i++) { out[m][0] = up[i][0]; out[m][1] = up[i][1]; m++; }
+  double cx = 0, cy = 0;
+  for (int i = 0; i < m; i++) { cx += out[i][0]; cy += out[i][1]; }
+  cx /= (double)m; cy /= (double)m;
+  for (int i = 0; i < m; i++) {
+    out[i][0] -= (out[i][0] - cx) * 0.1;
+    out[i][1] -= (out[i][1] - cy) * 0.1;
+  }
+  return m;
+}
+// point_in_polygen :97-112
+PCT_SD bool stab_pip(const double* pt, const double (*co)[2], int n) {
+  double lat = pt[0], lon = pt[1];
+  int j = n - 1;
+  bool odd = false;
+  for (int i = 0; i < n; i++) {
+    double a0 = co[i][0] - pt[0], a1 = co[i][1] - pt[1];
+    double b0 = pt[0] - co[j][0], b1 = pt[1] - co[j][1];
+    double cp = a0 * b1;
+    cp -= a1 * b0;
+    if (cp == 0) return false;
+    if ((co[i][1] < lon && co[j][1] >= lon) || (co[j][1] < lon && co[i][1] >= lon)) {
+      if ((co[i][0] + (lon - co[i][1]) / (co[j][1] - co[i][1]) * (co[j][0] - co[i][0])) < lat) odd = !odd;
+    }
+    j = i;
+  }
+  return odd;
+}
+
+// minimum-norm least squares for the >= 3 supporter case (stands in for np.linalg.lstsq /
+// LAPACK gelsd: Jacobi eigen-decomposition of A^T A; same method as the oracle)
+PCT_SD void stab_lstsq(const double* A, const double* b, int M, int N, double* x) {
+  double G[STAB_SMAX * STAB_SMAX], V[STAB_SMAX * STAB_SMAX], g[STAB_SMAX];
+  for (int i = 0; i < N; i++) {
+    g[i] = 0;
+    for (int r = 0; r < M; r++) g[i] += A[r * N + i] * b[r];
+    for (int j = 0; j < N; j++) {
+      double s = 0;
+      for (int r = 0; r < M; r++) s += A[r * N + i] * A[r * N + j];
+      G[i * N + j] = s;
+      V[i * N + j] = (i == j) ? 1.0 : 0.0;
+    }
+  }
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off = 0;
+    for (int p = 0; p < N; p++)
+      for (int q = p + 1; q < N; q++) off += G[p * N + q] * G[p * N + q];
+    if (off < 1e-300) break;
+    for (int p = 0; p < N; p++)
+      for (int q = p + 1; q < N; q++) {
+        if (fabs(G[p * N + q]) < 1e-300) continue;
+        double theta = (G[q * N + q] - G[p * N + p]) / (2 * G[p * N + q]);
+        double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+        double c = 1 / sqrt(t * t + 1), sn = t * c;
+        for (int k = 0; k < N; k++) {
+          double gkp = G[k * N + p], gkq = G[k * N + q];
+          G[k * N + p] = c * gkp - sn * gkq;
+          G[k * N + q] = sn * gkp + c * gkq;
+        }
+        for (int k = 0; k < N; k++) {
+          double gpk = G[p * N + k], gqk = G[q * N + k];
+          G[p * N + k] = c * gpk - sn * gqk;
+          G[q * N + k] = sn * gpk + c * gqk;
+        }
+        for (int k = 0; k < N; k++) {
+          double vkp = V[k * N + p], vkq = V[k * N + q];
+          V[k * N + p] = c * vkp - sn * vkq;
+          V[k * N + q] = sn * vkp + c * vkq;
+        }
+      }
+  }
+  double smax = 0;
+  for (int i = 0; i < N; i++)
+    if (G[i * N + i] > smax) smax = G[i * N + i];
+  double rc = 2.220446049250313e-16 * (M > N ? M : N);
+  for (int i = 0; i < N; i++) x[i] = 0;
+  for (int k = 0; k < N; k++) {
+    double lam = G[k * N + k];
+    if (lam <= 0 || sqrt(lam) <= rc * sqrt(smax)) continue;
+    double proj = 0;
+    for (int i = 0; i < N; i++) proj += V[i * N + k] * g[i];
+    proj /= lam;
+    for (int i = 0; i < N; i++) x[i] += V[i * N + k] * proj;
+  }
+}
+
+// supporters of a box with footprint [lx,xe) x [ly,ye) resting at height lz among the first n
+// placed boxes (D/space.py:358-376): same top, non-degenerate overlap, box order.
+// Returns false if there are more than STAB_SMAX.
+template <typename Geo>
+PCT_SD bool stab_find_supporters(const Geo& geo, int n, StabBox& b) {
+  b.nsup = 0;
+  for (int i = 0; i < n; i++) {
+    double t[6];
+    geo(i, t);
+    if (t[5] != b.g[2]) continue;
+    double x1 = fmax(b.g[0], t[0]), y1 = fmax(b.g[1], t[1]);
+    double x2 = fmin(b.g[3], t[3]), y2 = fmin(b.g[4], t[4]);
+    if (x1 >= x2 || y1 >= y2) continue;
+    if (b.nsup == STAB_SMAX) return false;
+    int k = b.nsup++;
+    b.sup[k] = i;
+    b.area[k][0] = x1; b.area[k][1] = y1; b.area[k][2] = x2; b.area[k][3] = y2;
+    b.c2[k][0] = (x1 + x2) / 2;
+    b.c2[k][1] = (y1 + y2) / 2;
+  }
+  return true;
+}
+// a placed box again as a StabBox, from its stored supporter ids
+template <typename Geo>
+PCT_SD void stab_load_box(const Geo& geo, const StabState& st, int id, StabBox& b) {
+  geo(id, b.g);
+  b.nsup = st.nsup[id];
+  for (int k = 0; k < b.nsup; k++) {
+    int s = st.sup[id * STAB_SMAX + k];
+    double t[6];
+    geo(s, t);
+    b.sup[k] = s;
+    double x1 = fmax(b.g[0], t[0]), y1 = fmax(b.g[1], t[1]);
+    double x2 = fmin(b.g[3], t[3]), y2 = fmin(b.g[4], t[4]);
+    b.area[k][0] = x1; b.area[k][1] = y1; b.area[k][2] = x2; b.area[k][3] = y2;
+    b.c2[k][0] = (x1 + x2) / 2;
+    b.c2[k][1] = (y1 + y2) / 2;
+  }
+}
+
+// how `b` with stack (c, m) splits over its supporters (D/space.py:88-160 / :182-256).
+// `own_centre` is the box's own centre (the virtual flavour's zero-mass shares use it).
+PCT_SD void stab_shares(const StabBox& b, const double stk[4], const double own_centre[3], bool virtual_,
+                        double out[STAB_SMAX][4]) {
+  const int k = b.nsup;
+  if (k == 1) {
+    out[0][0] = stk[0]; out[0][1] = stk[1]; out[0][2] = stk[2]; out[0][3] = stk[3];
+    return;
+  }
+  int direct = -1;
+  for (int i = 0; i < k; i++) {
+    const double* a = b.area[i];
+    if (stk[0] > a[0] && stk[0] < a[2] && stk[1] > a[1] && stk[1] < a[3]) { direct = i; break; }
+  }
+  if (direct >= 0) {
+    for (int i = 0; i < k; i++) {
+      if (i == direct) { out[i][0] = stk[0]; out[i][1] = stk[1]; out[i][2] = stk[2]; out[i][3] = stk[3]; }
+      else {
+        const double* cc = virtual_ ? own_centre : stk;
+        out[i][0] = cc[0]; out[i][1] = cc[1]; out[i][2] = cc[2]; out[i][3] = 0;
+      }
+    }
+    return;
+  }
+  if (k == 2) {
+    const double* e0 = b.c2[0];
+    const double* e1 = b.c2[1];
+    double t0 = e0[0] - e1[0], t1 = e0[1] - e1[1];
+    double len = sqrt(t0 * t0 + t1 * t1);
+    // tri_base_len ** 2: NumPy calls libm pow(len, 2.0); a correctly rounded square is len*len
+    // (glibc's pow agrees except for rare near-midpoint roundings; the device pow does not)
+    double l2 = len * len;
+    t0 /= l2; t1 /= l2;
+    double r0 = fabs((stk[0] - e1[0]) * t0 + (stk[1] - e1[1]) * t1);
+    double r1 = fabs((stk[0] - e0[0]) * t0 + (stk[1] - e0[1]) * t1);
+    out[0][0] = e0[0]; out[0][1] = e0[1]; out[0][2] = stk[2]; out[0][3] = stk[3] * r0;
+    out[1][0] = e1[0]; out[1][1] = e1[1]; out[1][2] = stk[2]; out[1][3] = stk[3] * r1;
+    return;
+  }
+  const int M = k * (k - 1) / 2 + 1;
+  double A[(STAB_SMAX * (STAB_SMAX - 1) / 2 + 1) * STAB_SMAX], rhs[STAB_SMAX * (STAB_SMAX - 1) / 2 + 1], xr[STAB_SMAX];
+  for (int i = 0; i < M * k; i++) A[i] = 0;
+  for (int i = 0; i < M; i++) rhs[i] = 0;
+  int row = 0;
+  for (int i = 0; i < k - 1; i++)
+    for (int j = i + 1; j < k; j++) {
+      const double* ei = b.c2[i];
+      const double* ej = b.c2[j];
+      double t0 = ei[0] - ej[0], t1 = ei[1] - ej[1];
+      double mol = (stk[0] - ei[0]) * t0 + (stk[1] - ei[1]) * t1;
+      if (mol != 0) {
+        double rr = fabs((stk[0] - ej[0]) * t0 + (stk[1] - ej[1]) * t1) / mol;
+        A[row * k + i] = 1;
+        A[row * k + j] = -rr;
+      }
+      row++;
+    }
+  for (int j = 0; j < k; j++) A[(M - 1) * k + j] = 1;
+  rhs[M - 1] = 1;
+  stab_lstsq(A, rhs, M, k, xr);
+  for (int i = 0; i < k; i++) {
+    out[i][0] = b.c2[i][0]; out[i][1] = b.c2[i][1]; out[i][2] = stk[2]; out[i][3] = stk[3] * xr[i];
+  }
+}
+
+// calculate_new_com (D/space.py:51-71) of placed box S: own + the committed shares of the
+// boxes resting on it that are not on the active path (ascending id) + `extra` (the involved
+// parent's virtual share, or null).  n = number of placed boxes to consider.
+template <typename Geo>
+PCT_SD void stab_com(const Geo& geo, const StabState& st, int n, int S, const int* path, int npath,
+                     const double* extra, double density, double out[4]) {
+  double g[6];
+  geo(S, g);
+  double sx = g[3] - g[0], sy = g[4] - g[1], sz = g[5] - g[2];
+  double mass = sx * sy * sz * density;
+  double c0 = (g[0] + sx / 2) * mass, c1 = (g[1] + sy / 2) * mass, c2 = (g[2] + sz / 2) * mass, m = mass;
+  for (int B = S + 1; B < n; B++) {
+    bool inv = false;
+    for (int q = 0; q < npath; q++) inv = inv || (path[q] == B);
+    if (inv) continue;
+    const int ns = st.nsup[B];
+    for (int k = 0; k < ns; k++)
+      if (st.sup[B * STAB_SMAX + k] == S) {
+        const double* e = st.share + ((size_t)B * STAB_SMAX + k) * 4;
+        c0 += e[0] * e[3]; c1 += e[1] * e[3]; c2 += e[2] * e[3];
+        m += e[3];
+      }
+  }
+  if (extra) {
+    c0 += extra[0] * extra[3]; c1 += extra[1] * extra[3]; c2 += extra[2] * extra[3];
+    m += extra[3];
+  }
+  out[0] = c0 / m; out[1] = c1 / m; out[2] = c2 / m; out[3] = m;
+}
+
+// calculated_impact_virtual(first=True) for a candidate (D/space.py:166-267): is it stable?
+// err is set if a capacity (supporters, hull vertices, depth) was exceeded.
+template <typename Geo>
+PCT_SD bool stab_virtual(const Geo& geo, const StabState& st, int n, const double cand[6], double density, bool& err) {
+  err = false;
+  StabBox b;
+  for (int i = 0; i < 6; i++) b.g[i] = cand[i];
+  if (!stab_find_supporters(geo, n, b)) { err = true; return false; }
+  if (b.nsup == 0) return true;
+  // explicit depth-first walk: frame = (box id or -1, its virtual stack, next supporter)
+  int fid[STAB_DEPTH], fnext[STAB_DEPTH];
+  double fstk[STAB_DEPTH][4];
+  int path[STAB_DEPTH];  // ids of the placed boxes on the active path (frames 1..depth-1)
+  int depth = 0;
+  {
+    double sx = cand[3] - cand[0], sy = cand[4] - cand[1], sz = cand[5] - cand[2];
+    fid[0] = -1; fnext[0] = 0;
+    fstk[0][0] = cand[0] + sx / 2; fstk[0][1] = cand[1] + sy / 2; fstk[0][2] = cand[2] + sz / 2;
+    fstk[0][3] = sx * sy * sz * density * 1.0;
+    depth = 1;
+  }
+  double poly[STAB_PMAX][2];
+  double shares[STAB_SMAX][4];
+  while (depth > 0) {
+    const int d = depth - 1;
+    if (fid[d] >= 0) stab_load_box(geo, st, fid[d], b);
+    else { for (int i = 0; i < 6; i++) b.g[i] = cand[i]; stab_find_supporters(geo, n, b); }
+    if (fnext[d] == 0) {
+      if (b.nsup == 0) { depth--; continue; }
+      int np;
+      if (fid[d] >= 0) {
+        np = st.npoly[fid[d]];
+        for (int i = 0; i < np; i++) {
+          poly[i][0] = st.poly[((size_t)fid[d] * STAB_PMAX + i) * 2 + 0];
+          poly[i][1] = st.poly[((size_t)fid[d] * STAB_PMAX + i) * 2 + 1];
+        }
+      } else {
+        np = stab_polygon(b, poly);
+        if (np < 0) { err = true; return false; }
+      }
+      if (!stab_pip(fstk[d], poly, np)) return false;
+    }
+    if (fnext[d] >= b.nsup) { depth--; continue; }
+    const int i = fnext[d]++;
+    double own[3] = {b.g[0] + (b.g[3] - b.g[0]) / 2, b.g[1] + (b.g[4] - b.g[1]) / 2, b.g[2] + (b.g[5] - b.g[2]) / 2};
+    stab_shares(b, fstk[d], own, true, shares);
+    if (depth >= STAB_DEPTH) { err = true; return false; }
+    const int S = b.sup[i];
+    // path = placed boxes currently involved: frames 1..d (the candidate has no id)
+    int np2 = 0;
+    for (int q = 1; q <= d; q++) path[np2++] = fid[q];
+    stab_com(geo, st, n, S, path, np2, shares[i], density, fstk[depth]);
+    fid[depth] = S;
+    fnext[depth] = 0;
+    depth++;
+  }
+  return true;
+}
+
+// calculated_impact() of the box just placed as id `n` (geometry already visible through
+// geo(n, .)): records its supporters / polygon / stack, propagates the shares downward and
+// re-checks every box on the way (D/space.py:73-164).  Returns the stability verdict.
+template <typename Geo>
+PCT_SD bool stab_commit(const Geo& geo, StabState& st, int n, double density, bool& err) {
+  err = false;
+  StabBox b;
+  geo(n, b.g);
+  if (!stab_find_supporters(geo, n, b)) { err = true; return false; }
+  {
+    double sx = b.g[3] - b.g[0], sy = b.g[4] - b.g[1], sz = b.g[5] - b.g[2];
+    double* s = st.stack + (size_t)n * 4;
+    s[0] = b.g[0] + sx / 2; s[1] = b.g[1] + sy / 2; s[2] = b.g[2] + sz / 2; s[3] = sx * sy * sz * density;
+  }
+  st.nsup[n] = b.nsup;
+  for (int k = 0; k < b.nsup; k++) st.sup[n * STAB_SMAX + k] = b.sup[k];
+  st.npoly[n] = 0;
+  if (b.nsup > 0) {
+    double poly[STAB_PMAX][2];
+    int np = stab_polygon(b, poly);
+    if (np < 0) { err = true; return false; }
+    st.npoly[n] = np;
+    for (int i = 0; i < np; i++) {
+      st.poly[((size_t)n * STAB_PMAX + i) * 2 + 0] = poly[i][0];
+      st.poly[((size_t)n * STAB_PMAX + i) * 2 + 1] = poly[i][1];
+    }
+  }
+  if (b.g[2] == 0) return true;  // max_h == 0: check_box returns before calculated_impact (:448-449)
+  int fid[STAB_DEPTH], fnext[STAB_DEPTH];
+  int depth = 1;
+  fid[0] = n; fnext[0] = 0;
+  double poly[STAB_PMAX][2];
+  double shares[STAB_SMAX][4];
+  while (depth > 0) {
+    const int d = depth - 1;
+    const int id = fid[d];
+    stab_load_box(geo, st, id, b);
+    if (fnext[d] == 0) {
+      if (b.nsup == 0) { depth--; continue; }
+      const int np = st.npoly[id];
+      for (int i = 0; i < np; i++) {
+        poly[i][0] = st.poly[((size_t)id * STAB_PMAX + i) * 2 + 0];
+        poly[i][1] = st.poly[((size_t)id * STAB_PMAX + i) * 2 + 1];
+      }
+      const double* stk = st.stack + (size_t)id * 4;
+      if (!stab_pip(stk, poly, np)) return false;
+      // distribute to every supporter first (up_edges[self] = share; calculate_new_com())
+      double own[3] = {stk[0], stk[1], stk[2]};
+      stab_shares(b, stk, own, false, shares);
+      for (int k = 0; k < b.nsup; k++) {
+        double* e = st.share + ((size_t)id * STAB_SMAX + k) * 4;
+        e[0] = shares[k][0]; e[1] = shares[k][1]; e[2] = shares[k][2]; e[3] = shares[k][3];
+        stab_com(geo, st, n + 1, b.sup[k], (const int*)0, 0, (const double*)0, density, st.stack + (size_t)b.sup[k] * 4);
+      }
+    }
+    if (fnext[d] >= b.nsup) { depth--; continue; }
+    const int i = fnext[d]++;
+    if (depth >= STAB_DEPTH) { err = true; return false; }
+    fid[depth] = b.sup[i];
+    fnext[depth] = 0;
+    depth++;
+  }
+  return true;
+}
+
+}  // namespace pct
+#endif

@@ -55,9 +55,10 @@ def gather_rows(obs, I, idx):
 
 
 GOLDEN_CASES = ["discrete_s2_10_80_50", "discrete_s2_rect_60_30", "discrete_s2_10_80_5", "discrete_s2_20_120_400",
-                "discrete_s2_cp_10_80_50", "discrete_s2_cp_rect_60_16"]
+                "discrete_s2_cp_10_80_50", "discrete_s2_cp_rect_60_16", "discrete_s1_10_80_50", "discrete_s1_rect_60_30"]
 
 CONT_CASES = ["continuous_s2_10_80_50", "continuous_s2_100_200_200", "continuous_s2_rect_60_20"]
 
 # CPU-only fixtures (stability, settings 1/3: restated in the oracle, not yet on the GPU)
-ORACLE_ONLY_CASES = ["discrete_s1_10_80_50", "discrete_s1_rect_60_30"]
+ORACLE_ONLY_CASES = []
+STAB_CASES = ["discrete_s1_10_80_50", "discrete_s1_rect_60_30"]

@@ -1,0 +1,79 @@
+// stab_host.cpp -- TEST HARNESS: compiles the product's restructured stability check
+// (online-3d-bpp-pct_amd/csrc/pct_stab.cuh, the code the GPU lanes run) for the host and
+// exposes it under the oracle's stab_* interface, so that `make -C tests/host` yields an
+// oracle variant (libpct_oracle_prodstab.so) whose stability decisions come from the product
+// source.  tests/test_stab_host.py runs the setting-1 reference fixtures through it: the
+// restructuring (no recursion, no dictionaries, lazy virtual stacks) is thereby checked on the
+// CPU against the reference before it is trusted on the GPU.  Nothing in the product uses this.
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../online-3d-bpp-pct_amd/csrc/pct_stab.cuh"
+
+struct stab {
+  int cap;
+  int n;
+  std::vector<double> geo;  // [cap][6] lx,ly,lz,xe,ye,ze
+  std::vector<double> stack, share, poly;
+  std::vector<int> nsup, sup, npoly;
+  int overflow;
+};
+
+struct GeoFn {
+  const double* g;
+  void operator()(int i, double out[6]) const { memcpy(out, g + 6 * (size_t)i, 6 * sizeof(double)); }
+};
+
+static pct::StabState view(stab* s) {
+  pct::StabState st;
+  st.I = s->cap;
+  st.stack = s->stack.data();
+  st.nsup = s->nsup.data();
+  st.sup = s->sup.data();
+  st.share = s->share.data();
+  st.npoly = s->npoly.data();
+  st.poly = s->poly.data();
+  return st;
+}
+
+extern "C" {
+struct stab* stab_create(int cap, double eps) {
+  (void)eps;
+  stab* s = new stab();
+  s->cap = cap + 2;
+  s->n = 0;
+  s->overflow = 0;
+  s->geo.assign((size_t)s->cap * 6, 0.0);
+  s->stack.assign((size_t)s->cap * 4, 0.0);
+  s->share.assign((size_t)s->cap * pct::STAB_SMAX * 4, 0.0);
+  s->poly.assign((size_t)s->cap * pct::STAB_PMAX * 2, 0.0);
+  s->nsup.assign((size_t)s->cap, 0);
+  s->sup.assign((size_t)s->cap * pct::STAB_SMAX, 0);
+  s->npoly.assign((size_t)s->cap, 0);
+  return s;
+}
+void stab_reset(struct stab* s) { s->n = 0; }
+void stab_free(struct stab* s) { delete s; }
+int stab_overflowed(struct stab* s) { return s->overflow; }
+
+int stab_check(struct stab* s, double x, double y, double z, double lx, double ly, double max_h, double density,
+               int virtual_) {
+  GeoFn geo{s->geo.data()};
+  pct::StabState st = view(s);
+  bool err = false;
+  double cand[6] = {lx, ly, max_h, lx + x, ly + y, max_h + z};
+  if (virtual_) {
+    if (max_h == 0) return 1;  // D/space.py:448-449
+    bool ok = pct::stab_virtual(geo, st, s->n, cand, density, err);
+    if (err) s->overflow = 1;
+    return ok ? 1 : 0;
+  }
+  memcpy(s->geo.data() + 6 * (size_t)s->n, cand, sizeof cand);
+  bool ok = pct::stab_commit(geo, st, s->n, density, err);
+  if (err) s->overflow = 1;
+  if (ok) s->n++;
+  return ok ? 1 : 0;
+}
+}

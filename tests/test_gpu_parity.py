@@ -75,6 +75,43 @@ def test_hip_known_answer_hash():
     env.close()
 
 
+def test_hip_known_answer_hash_setting1():
+    """Setting 1 (stability check on the GPU): 443198ae2c0162db."""
+    z = np.load(GOLDEN + "/kat_discrete_s1.npz")
+    env = _pkg().PctVecEnv(1, setting=1, container_size=(10, 10, 10), item_set=item_set_range(1, 5),
+                           item_stream=z["items"][None], device="cuda:0")
+    obs = env.reset()
+    h = hashlib.sha256()
+    for t in range(500):
+        h.update(obs.cpu().numpy()[0].tobytes())
+        obs, _, _, _ = env.step(z["actions"][t][None])
+    assert h.hexdigest()[:16] == "443198ae2c0162db"
+    env.close()
+
+
+def test_hip_setting1_matches_oracle_random_streams():
+    from oracle.oracle_lib import OracleVecEnv
+    items = item_set_range(1, 5)
+    N = 192
+    stream = make_stream(41, N, 256, items)
+    kw = dict(setting=1, container_size=(10, 10, 10), item_set=items, internal_node_holder=80, leaf_node_holder=50,
+              env_id_base=500)
+    ora = OracleVecEnv(N, **kw)
+    ora.set_item_stream(stream)
+    env = _pkg().PctVecEnv(N, item_stream=stream, device="cuda:0", **kw)
+    ora.reset()
+    obs = env.reset()
+    for t in range(200):
+        assert np.array_equal(obs.cpu().numpy(), ora.obs.astype(np.float32)), t
+        env.step_hash_policy(1)
+        ora.step_hash_policy(1)
+        obs, reward, done, infos = env.step_wait()
+        assert np.array_equal(done.astype(np.uint8), ora.done)
+        assert np.array_equal(reward[:, 0].numpy(), ora.reward.astype(np.float32))
+    assert not env.error_flags.any()
+    env.close()
+
+
 @pytest.mark.parametrize("cfg", [
     dict(N=256, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, steps=150, seed=3, base=1000),
     dict(N=64, container=(31, 17, 23), lo=2, hi=9, I=100, L=64, steps=120, seed=4, base=5),
