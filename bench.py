@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--mode", choices=["rows", "fused"], default="rows",
                     help="rows: policy kernel + pct_step_rows per step (default); fused: pct_step_hash_policy(1)")
-    ap.add_argument("--workload", choices=["c2", "c3"], default="c2",
+    ap.add_argument("--workload", choices=["c2", "c3", "c5"], default="c2",
                     help="c2: BASELINE configs[1] (discrete, the headline metric); c3: configs[2] (continuous setting 2)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -101,7 +101,15 @@ def main():
 
     pkg = importlib.import_module("online-3d-bpp-pct_amd")
     n_local = args.envs_per_gpu
-    if args.workload == "c3":
+    if args.workload == "c5":  # BASELINE.json configs[4]: 100^3, 200/200, items U(5,25)
+        global I_NODES, L_NODES, ALG_BYTES_PER_STEP
+        I_NODES, L_NODES = 200, 200
+        ALG_BYTES_PER_STEP = 4 * 9 * (I_NODES + L_NODES + 1) + 36 + 4 + 1
+        env = pkg.PctVecEnv(n_local, setting=2, container_size=(100, 100, 100), continuous=True, sample_left_bound=5.0,
+                            sample_right_bound=25.0, internal_node_holder=I_NODES, leaf_node_holder=L_NODES, seed=4,
+                            env_id_base=rank * n_local, device=dev, monitor=False, ems_capacity=768,
+                            candidate_capacity=32768)
+    elif args.workload == "c3":
         env = pkg.PctVecEnv(n_local, setting=2, container_size=(10, 10, 10), continuous=True, sample_left_bound=1.0,
                             sample_right_bound=5.0, internal_node_holder=I_NODES, leaf_node_holder=L_NODES, seed=4,
                             env_id_base=rank * n_local, device=dev, monitor=False)
@@ -204,6 +212,11 @@ def main():
             "alg_bytes_per_env_step": ALG_BYTES_PER_STEP,
         },
     }
+    if args.workload == "c5":
+        out["metric"] = "env-steps/sec (whole node), continuous setting 2, 100^3 bin, 200 internal/200 leaf"
+        out["config"]["workload"] = ("PctContinuous0 setting 2, bin 100^3, 200 internal / 200 leaf, %d batched envs per MI355X "
+                                     "(BASELINE.json configs[4]); item sizes round(U(5,25),3)" % n_local)
+        args.no_cpu_baseline = True
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(256, args.cpu_seconds, args.workload)
     elif rank == 0:

@@ -100,7 +100,7 @@ __device__ inline CLds carve(const ContinuousParams& p, unsigned char* base) {
   l.pend = reinterpret_cast<uint32_t*>(q); q += 128;
   l.bg = reinterpret_cast<uint32_t*>(q); q += 64;
   uint16_t* h = reinterpret_cast<uint16_t*>(q);
-  l.order = h; h += p.order_cap;
+  l.order = h; h += p.table_global ? 0 : p.order_cap;
   l.vp = h;
   return l;
 }
@@ -108,7 +108,7 @@ __device__ inline CLds carve(const ContinuousParams& p, unsigned char* base) {
 size_t continuous_lds_bytes(const ContinuousParams& p) {
   size_t dbl = (size_t)6 * p.ems_cap + p.union_doubles + 6 * (size_t)p.I + 6 * (size_t)p.L + 64;
   size_t i32 = 4 * (size_t)p.I + 128 + 64;
-  size_t u16 = (size_t)p.order_cap + 64;
+  size_t u16 = (size_t)(p.table_global ? 0 : p.order_cap) + 64;
   return dbl * 8 + i32 * 4 + u16 * 2 + 16;
 }
 
@@ -279,17 +279,19 @@ __device__ inline void cgenems(const ContinuousParams& p, CLds& l, CRegs& r, int
 }
 
 // C/space.py:531-568 EMSPoint (CPython set order over float tuples) + C/bin3D.py:118-148
-template <typename TM>
-__device__ inline void cleaf_nodes(const ContinuousParams& p, CLds& l, CRegs& r, int lane, TM& tm) {
+template <bool GT, typename TM>
+__device__ inline void cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CRegs& r, int lane, TM& tm) {
   const uint64_t lt = lanemask_lt(lane);
   const int E = r.n_ems, cap = p.ems_cap;
   const int orient = (p.setting == 2) ? 6 : 2;
   const int NP = E * orient;
   const uint32_t EMPTY = SlotWord<uint32_t>::EMPTY;
   uint32_t size = 8, fill = 0;
-  uint32_t* const tabs = l.tab;
+  // table and list(set) order: LDS, or this env's HBM slice when the capacity does not fit
+  uint32_t* const tabs = GT ? p.gtab + (size_t)e * (size_t)(p.cand_cap + p.cand_cap / 4) : l.tab;
+  uint16_t* const order = GT ? p.gorder + (size_t)e * (size_t)p.order_cap : l.order;
   uint32_t toff = table_region(p.cand_cap, size);
-  if (lane < 8) tabs[toff + lane] = EMPTY;
+  if (lane < 8) tab_st<GT, uint32_t>(&tabs[toff + lane], EMPTY);
   __syncthreads();
   bool cand_overflow = false;
   int npend = 0;
@@ -333,8 +335,8 @@ __device__ inline void cleaf_nodes(const ContinuousParams& p, CLds& l, CRegs& r,
       bool part = pending && (uint32_t)__popcll(pm & lt) < thr - fill;
       bool placed;
       uint32_t slot;
-      pyset_match<uint32_t>(tabs + toff, mask, part, hash, lane, true, placed, slot, same);
-      if (placed) tabs[toff + slot] = word;
+      pyset_match<uint32_t, GT>(tabs + toff, mask, part, hash, lane, true, placed, slot, same);
+      if (placed) tab_st<GT, uint32_t>(&tabs[toff + slot], word);
       pending = pending && !part;
       fill += (uint32_t)__popcll(__ballot(placed));
       __syncthreads();
@@ -346,19 +348,19 @@ __device__ inline void cleaf_nodes(const ContinuousParams& p, CLds& l, CRegs& r,
           break;
         }
         const uint32_t noff = table_region(p.cand_cap, newsize);
-        for (uint32_t s2 = lane; s2 < newsize; s2 += 64) tabs[noff + s2] = EMPTY;
+        for (uint32_t s2 = lane; s2 < newsize; s2 += 64) tab_st<GT, uint32_t>(&tabs[noff + s2], EMPTY);
         __syncthreads();
         for (uint32_t sb = 0; sb < size; sb += 64) {
           uint32_t s2 = sb + lane;
-          uint32_t ow = (s2 < size) ? tabs[toff + s2] : EMPTY;
+          uint32_t ow = (s2 < size) ? tab_ld<GT, uint32_t>(&tabs[toff + s2]) : EMPTY;
           bool opart = ow != EMPTY;
           double o[6];
           cand_tuple(p, l, r, orient, opart ? (ow & 0xFFFFu) : 0u, o);
           bool oplaced;
           uint32_t oslot;
-          pyset_match<uint32_t>(tabs + noff, newsize - 1, opart, tuplehash6d(o), lane, false, oplaced, oslot,
-                                [&](uint32_t) { return false; });
-          if (oplaced) tabs[noff + oslot] = ow;
+          pyset_match<uint32_t, GT>(tabs + noff, newsize - 1, opart, tuplehash6d(o), lane, false, oplaced, oslot,
+                                    [&](uint32_t) { return false; });
+          if (oplaced) tab_st<GT, uint32_t>(&tabs[noff + oslot], ow);
           __syncthreads();
         }
         toff = noff;
@@ -390,7 +392,7 @@ __device__ inline void cleaf_nodes(const ContinuousParams& p, CLds& l, CRegs& r,
       cand_tuple(p, l, r, orient, g, t);
       uint64_t hash = tuplehash6d(t);
       const uint32_t fp = cword(hash, 0) >> 16;
-      bool fresh = valid && !pyset_contains<uint32_t>(tabs + toff, size - 1, hash, [&](uint32_t w) -> bool {
+      bool fresh = valid && !pyset_contains<uint32_t, GT>(tabs + toff, size - 1, hash, [&](uint32_t w) -> bool {
         if ((w >> 16) != fp) return false;
         double o[6];
         cand_tuple(p, l, r, orient, w & 0xFFFFu, o);
@@ -412,9 +414,9 @@ __device__ inline void cleaf_nodes(const ContinuousParams& p, CLds& l, CRegs& r,
   int norder = 0;
   for (uint32_t sb = 0; sb < size; sb += 64) {
     uint32_t s = sb + lane;
-    uint32_t w = (s < size) ? tabs[toff + s] : EMPTY;
+    uint32_t w = (s < size) ? tab_ld<GT, uint32_t>(&tabs[toff + s]) : EMPTY;
     uint64_t m = __ballot(w != EMPTY);
-    if (w != EMPTY) l.order[norder + __popcll(m & lt)] = (uint16_t)(w & 0xFFFFu);
+    if (w != EMPTY) tab_st<GT, uint16_t>(&order[norder + __popcll(m & lt)], (uint16_t)(w & 0xFFFFu));
     norder += __popcll(m);
   }
   __syncthreads();
@@ -427,7 +429,7 @@ __device__ inline void cleaf_nodes(const ContinuousParams& p, CLds& l, CRegs& r,
     int i = base + lane;
     bool live = i < norder;
     double t[6];
-    cand_tuple(p, l, r, orient, live ? (uint32_t)l.order[i] : 0u, t);
+    cand_tuple(p, l, r, orient, live ? (uint32_t)tab_ld<GT, uint16_t>(&order[i]) : 0u, t);
     double lx = t[0], ly = t[1];
     double x = t[3] - t[0], y = t[4] - t[1], z = t[5] - t[2];
     bool ok = live;
@@ -629,7 +631,7 @@ __device__ inline void cdecode_leaf(const CRegs& r, bool zero_row, double a0, do
 
 enum { CACT_ROWS = 0, CACT_INDEX = 1, CACT_HASH = 2, CACT_RESET = 3 };
 
-template <int ACT, bool TIMED>
+template <int ACT, bool TIMED, bool GT>
 __global__ void __launch_bounds__(64) pct_continuous_kernel(ContinuousParams p, const void* __restrict__ actions,
                                                             int row_len, int n_steps,
                                                             const int32_t* __restrict__ env_ids, int n_ids) {
@@ -653,7 +655,7 @@ __global__ void __launch_bounds__(64) pct_continuous_kernel(ContinuousParams p, 
     cspace_reset(p, l, r, lane);
     __syncthreads();
     cdraw_item(p, e, r);
-    cleaf_nodes(p, l, r, lane, tm);
+    cleaf_nodes<GT>(p, e, l, r, lane, tm);
     cwrite_obs(p, l, r, lane, obs);
     cstore(p, e, l, r, lane);
     return;
@@ -706,7 +708,7 @@ __global__ void __launch_bounds__(64) pct_continuous_kernel(ContinuousParams p, 
       cdecode_leaf(r, zero_row, a0, a1, a3, a4, p1, p2, bx, by, bz);
     }
     ctransition(p, e, l, r, lane, flag, p1, p2, bx, by, bz, tm);
-    cleaf_nodes(p, l, r, lane, tm);
+    cleaf_nodes<GT>(p, e, l, r, lane, tm);
     cwrite_obs(p, l, r, lane, obs);
     __syncthreads();
     tm.tick(PH_OBS);
@@ -745,7 +747,8 @@ hipError_t launch_continuous(const ContinuousParams& p, int act, const void* act
   if (grid <= 0) return hipSuccess;
 #define PCT_CLAUNCH(A)                                                                                         \
   do {                                                                                                         \
-    auto kern = timed ? pct_continuous_kernel<A, true> : pct_continuous_kernel<A, false>;                      \
+    auto kern = p.table_global ? pct_continuous_kernel<A, false, true>                                         \
+                               : (timed ? pct_continuous_kernel<A, true, false> : pct_continuous_kernel<A, false, false>); \
     if (lds > 48 * 1024) {                                                                                     \
       hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                 \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \

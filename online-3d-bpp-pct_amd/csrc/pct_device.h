@@ -66,6 +66,9 @@ struct ContinuousParams {
   double* boxes;    /* [N,6,I] lx,ly,lz,xe,ye,top */
   double* leaves;   /* [N,6,L] */
   double* volsum;   /* [N] running sum of placed volumes (get_ratio) */
+  int table_global; /* 1: hash table + order list live in HBM (capacity beyond LDS) */
+  uint32_t* gtab;   /* [N, cand_cap*5/4] */
+  uint16_t* gorder; /* [N, order_cap] */
   int32_t* scalars; /* [N,PCT_SCALARS] */
   uint32_t* flags;
   unsigned long long* timing;

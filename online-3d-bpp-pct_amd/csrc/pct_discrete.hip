@@ -235,7 +235,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
   const uint64_t lt = lanemask_lt(lane);
   const int E = r.n_ems;
   const int b0 = r.item0, b1 = r.item1, b2 = r.item2;
-  const int orient = (p.setting == 2) ? 6 : 2;
+  constexpr int orient = STAB ? 2 : 6;  // setting 2 <=> no stability check <=> 6 orientations (D/space.py:536-537)
   const int NP = E * orient;  // (EMS, rotation) pairs in set-insertion order
 
   // fresh set: PySet_MINSIZE = 8 slots
@@ -551,14 +551,18 @@ __device__ inline void write_obs(const DiscreteParams& p, const Lds<K, BITS>& l,
   if (a > b) { tmp = a; a = b; b = tmp; }
   if (b > c) { tmp = b; b = c; c = tmp; }
   if (a > b) { tmp = a; a = b; b = tmp; }
-  for (int f = lane; f < p.row_len; f += 64) {
-    int row = f / 9;
-    int col = f - row * 9;
+  // 7 rows (63 consecutive floats) per pass: a lane keeps its column, only the row advances
+  const int col = lane % 9, rsub = lane / 9;
+  const bool lane_on = lane < 63;
+  const int rows = p.I + p.L + 1;
+  for (int rbase = 0; rbase < rows; rbase += 7) {
+    const int row = rbase + rsub;
+    if (!lane_on || row >= rows) continue;
     float v = 0.f;
     if (row < p.I) {
       if (row < r.n_boxes) {
         K k = l.box[row];
-        v = col < 6 ? (float)P::get(k, col) : (col == 6 ? 1.0f : (col == 8 ? 1.0f : 0.f));
+        v = col < 6 ? (float)P::get(k, col) : (col == 7 ? 0.f : 1.0f);  // density 1, pad 0, mask 1
       } else if (row == 0 && col == 8) {
         v = 1.0f;  // D/space.py:294-295 dummy valid node after reset
       }
@@ -571,7 +575,7 @@ __device__ inline void write_obs(const DiscreteParams& p, const Lds<K, BITS>& l,
     } else {
       v = col == 0 ? 1.0f : (col == 3 ? (float)a : (col == 4 ? (float)b : (col == 5 ? (float)c : (col == 8 ? 1.0f : 0.f))));
     }
-    obs[f] = v;
+    obs[row * 9 + col] = v;
   }
 }
 
@@ -641,12 +645,15 @@ __device__ inline void transition(const DiscreteParams& p, int e, Lds<K, BITS>& 
     } else if (lx < 0 || ly < 0) {
       ok = false;  // check_box D/space.py:440-441 rejects it whatever max_h is
     } else {
-      int w = yb - ya, cells = (xb - xa) * w, m = 0;
-      for (int c = lane; c < cells; c += 64) {
-        int cx = xa + c / w, cy = ya + c % w;
-        int h = l.hmap[cx * p.A + cy];
-        m = h > m ? h : m;
-      }
+      int m = 0;  // 8x8 tiles of the footprint, one cell per lane
+      for (int tx = xa; tx < xb; tx += 8)
+        for (int ty = ya; ty < yb; ty += 8) {
+          int cx = tx + (lane >> 3), cy = ty + (lane & 7);
+          if (cx < xb && cy < yb) {
+            int h = l.hmap[cx * p.A + cy];
+            m = h > m ? h : m;
+          }
+        }
       max_h = wave_max_i32(m);
       // check_box D/space.py:436-446 (setting 2)
       ok = !(lx + x > p.W || ly + y > p.Ly) && !(max_h + z > p.H);
@@ -690,8 +697,11 @@ __device__ inline void transition(const DiscreteParams& p, int e, Lds<K, BITS>& 
   const double binvol = (double)((int64_t)p.W * p.Ly * p.H);
   if (ok) {
     int top = max_h + z;
-    int cells = x * y;
-    for (int c = lane; c < cells; c += 64) l.hmap[(lx + c / y) * p.A + (ly + c % y)] = (int16_t)top;
+    for (int tx = lx; tx < lx + x; tx += 8)
+      for (int ty = ly; ty < ly + y; ty += 8) {
+        int cx = tx + (lane >> 3), cy = ty + (lane & 7);
+        if (cx < lx + x && cy < ly + y) l.hmap[cx * p.A + cy] = (int16_t)top;
+      }
     if (lane == 0) l.box[r.n_boxes] = P::pack(lx, ly, max_h, lx + x, ly + y, top);
     r.n_boxes++;
     r.vol += (int64_t)x * y * z;

@@ -183,7 +183,8 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
     c.ems_cap = ems_cap;
     c.cand_cap = cand_cap;
     c.order_cap = (cand_cap * 3) / 5 + 8;
-    size_t tab_doubles = ((size_t)(cand_cap + cand_cap / 4) * 4 + 7) / 8;
+    c.table_global = cand_cap > 8192 ? 1 : 0; /* beyond 8192 slots the table cannot share LDS with the EMS */
+    size_t tab_doubles = c.table_global ? 0 : ((size_t)(cand_cap + cand_cap / 4) * 4 + 7) / 8;
     c.union_doubles = (int)(tab_doubles > (size_t)6 * ems_cap ? tab_doubles : (size_t)6 * ems_cap);
     c.env_id_base = cfg->env_id_base;
     c.source = PCT_ITEMS_NONE;
@@ -200,6 +201,10 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
     CALLOC_(c.boxes, Nn * 6 * c.I * sizeof(double));
     CALLOC_(c.leaves, Nn * 6 * c.L * sizeof(double));
     CALLOC_(c.volsum, Nn * sizeof(double));
+    if (c.table_global) {
+      CALLOC_(c.gtab, Nn * (size_t)(cand_cap + cand_cap / 4) * sizeof(uint32_t));
+      CALLOC_(c.gorder, Nn * (size_t)c.order_cap * sizeof(uint16_t));
+    }
     CALLOC_(c.scalars, Nn * PCT_SCALARS * sizeof(int32_t));
     CALLOC_(h->own_flags, Nn * sizeof(uint32_t));
     CALLOC_(h->own_obs, Nn * c.row_len * sizeof(float));

@@ -91,6 +91,21 @@ __device__ inline uint64_t lds_atomic_min(uint64_t* p, uint64_t v) {
 }
 
 #define PCT_PEND_SLOTS 128
+// Table accessors.  GT == false: the table is in LDS (plain accesses).  GT == true: the table
+// is a per-env slice of HBM (capacities that do not fit in LDS): every access goes to L2
+// (agent-scope relaxed atomics) because a vector L1 line is not refreshed by this wave's own
+// atomics.
+template <bool GT, typename K>
+__device__ inline K tab_ld(const K* p) {
+  if (GT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
+}
+template <bool GT, typename K>
+__device__ inline void tab_st(K* p, K v) {
+  if (GT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+
 struct Walk {  // position on a key's probe path: slot = i + j
   uint32_t i;
   int j;
@@ -115,12 +130,12 @@ struct Walk {  // position on a key's probe path: slot = i + j
 // Read-only membership test (no tags may be present).
 // `same(word)` decides whether the table entry `word` holds the caller's key (set_add_entry:
 // entry->hash == hash and the keys compare equal).
-template <typename K, typename Same>
+template <typename K, bool GT = false, typename Same>
 __device__ inline bool pyset_contains(const K* tab, uint32_t mask, uint64_t hash, Same same) {
   Walk w;
   w.start(hash, mask);
   while (true) {
-    K cur = tab[w.i + w.j];
+    K cur = tab_ld<GT, K>(&tab[w.i + w.j]);
     if (cur == SlotWord<K>::EMPTY) return false;
     if (same(cur)) return true;
     w.next(mask);
@@ -133,7 +148,7 @@ __device__ inline bool pyset_contains(const K* tab, uint32_t mask, uint64_t hash
 // each other except through the slots they hold).  On return a lane with `placed` holds
 // TAG|lane in tab[slot]; a participating lane that is not placed found its key already in the
 // table (check_found).  All 64 lanes must call.
-template <typename K, typename Same>
+template <typename K, bool GT = false, typename Same>
 __device__ inline void pyset_match(K* tab, uint32_t mask, bool part, uint64_t hash, int lane, bool check_found,
                                    bool& placed, uint32_t& slot, Same same) {
   const K TAG = SlotWord<K>::TAG;
@@ -146,7 +161,7 @@ __device__ inline void pyset_match(K* tab, uint32_t mask, bool part, uint64_t ha
   while (true) {
     while (walking) {
       uint32_t cur = w.i + w.j;
-      K v = tab[cur];
+      K v = tab_ld<GT, K>(&tab[cur]);
       if ((v & TAG) && v > mytag) {  // empty, or tentatively held by a later lane
         K old = lds_atomic_min(&tab[cur], mytag);
         if (old > mytag) {
@@ -161,7 +176,7 @@ __device__ inline void pyset_match(K* tab, uint32_t mask, bool part, uint64_t ha
       }
     }
     __syncthreads();
-    if (placed && tab[slot] != mytag) {  // evicted by an earlier lane: walk on
+    if (placed && tab_ld<GT, K>(&tab[slot]) != mytag) {  // evicted by an earlier lane: walk on
       placed = false;
       walking = true;
       w.next(mask);

@@ -308,6 +308,22 @@ def test_hip_continuous_matches_reference_fixture(name, mode):
     env.close()
 
 
+def test_hip_continuous_hbm_table_variant_matches_fixture():
+    """candidate_capacity > 8192 moves the hash table and the list(set) order to HBM (the
+    C5-scale path): same results as the LDS-resident table."""
+    c, z = load_case("continuous_s2_100_200_200")
+    env = _make_cont(c, z["stream"], ems_capacity=448, candidate_capacity=32768)
+    obs = env.reset()
+    for t in range(c["steps"]):
+        o = obs.cpu().numpy()
+        assert np.array_equal(o, z["obs"][t].astype(np.float32)), t
+        env.step_hash_policy(1)
+        obs, reward, done, infos = env.step_wait()
+        assert np.array_equal(done.astype(np.uint8), z["done"][t])
+    assert not env.error_flags.any()
+    env.close()
+
+
 def test_hip_continuous_known_answer_hash():
     """Reference trajectory under env.seed(4) / RandomState(0) (sampling mode) replayed on the
     GPU: sha256[:16] of the 500 observations rounded to 5 decimals = 506b5c0349c89b9d."""
