@@ -70,6 +70,7 @@ extern "C" {
 #define PCT_ITEMS_NONE 0
 #define PCT_ITEMS_STREAM 1  /* scripted per-env trajectories (parity runs) */
 #define PCT_ITEMS_SAMPLER 2 /* counter-based on-device sampler (training / bench) */
+#define PCT_ITEMS_DATASET 3 /* the reference's dataset trajectories (binCreator.py:41-72) */
 
 /* per-env sticky error flags (bitmask, uint32) */
 #define PCT_FLAG_INTERNAL_OVERFLOW 0x1u  /* packed boxes >= internal_node_holder: reference
@@ -78,6 +79,8 @@ extern "C" {
 #define PCT_FLAG_CANDIDATE_OVERFLOW 0x4u /* leaf-candidate set exceeded candidate_capacity */
 #define PCT_FLAG_STABILITY_OVERFLOW 0x10u /* stability check: more supporters / hull vertices /
                                              support-graph depth than the kernel keeps */
+#define PCT_FLAG_DATASET_EXHAUSTED 0x20u /* LoadBoxCreator ran past its last trajectory: the
+                                            reference raises IndexError at binCreator.py:58 */
 #define PCT_FLAG_BAD_ACTION 0x8u         /* malformed action: reference raises ValueError at
                                             bin3D.py:144-145 (list.remove) or in np.max of an
                                             empty slice (space.py:354-355) */
@@ -127,6 +130,13 @@ int pct_set_sample_bounds(pct_env* env, int32_t left, int32_t right);
  * c-th draw (one draw per reset and one per successful placement,
  * bin3D.py:61-67,181-182).  Copied to the device. */
 int pct_set_item_stream(pct_env* env, const int32_t* items, int64_t T);
+/* Dataset trajectories with LoadBoxCreator semantics (binCreator.py:41-72): host int32
+ * [n_traj, max_len, 3] + lengths [n_traj].  Every reset moves the env to the NEXT trajectory --
+ * the first episode plays trajectory 1, not 0 (:54-55) -- an exhausted trajectory is followed
+ * by the sentinel (100,100,100) (:62, in the units of `items`) and then (10,10,10) for ever
+ * (:69-72).  All envs walk the same trajectory sequence, like the reference's workers. */
+int pct_set_item_dataset(pct_env* env, const int32_t* items, const int32_t* lengths, int32_t n_traj,
+                         int32_t max_len);
 /* Counter-based sampler: the c-th draw of global env g is
  * item_set[pct_mix64(seed, g, c) % n] (discrete) -- see pct_mix64 below. */
 int pct_set_sampler(pct_env* env, uint64_t seed);

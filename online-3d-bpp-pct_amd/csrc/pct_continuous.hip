@@ -69,6 +69,7 @@ struct CRegs {  // wave-uniform per-env scalars
   uint32_t t;
   double volsum;
   uint32_t flags;
+  int traj;
 };
 
 struct CLds {
@@ -114,7 +115,17 @@ size_t continuous_lds_bytes(const ContinuousParams& p) {
 
 __device__ inline void cdraw_item(const ContinuousParams& p, int e, CRegs& r) {
   uint64_t c = r.cursor++;
-  if (p.source == PCT_ITEMS_STREAM) {
+  if (p.source == PCT_ITEMS_DATASET) {  // binCreator.py:64-72; sizes round(.,3) (C/bin3D.py:85)
+    int t = r.traj < p.ds_ntraj ? r.traj : p.ds_ntraj - 1;
+    int len = p.ds_len[t];
+    if (c < (uint64_t)len) {
+      const int32_t* it = p.stream + ((size_t)t * p.ds_maxlen + (size_t)c) * 3;
+      r.ik0 = it[0]; r.ik1 = it[1]; r.ik2 = it[2];
+    } else {
+      int v = (c == (uint64_t)len) ? 100000 : 10000;
+      r.ik0 = v; r.ik1 = v; r.ik2 = v;
+    }
+  } else if (p.source == PCT_ITEMS_STREAM) {
     const int32_t* it = p.stream + ((size_t)e * (size_t)p.T + (size_t)(c % (uint64_t)p.T)) * 3;
     r.ik0 = it[0]; r.ik1 = it[1]; r.ik2 = it[2];
   } else {
@@ -137,6 +148,11 @@ __device__ inline void cspace_reset(const ContinuousParams& p, CLds& l, CRegs& r
   r.n_ems = 1;
   r.n_boxes = 0;
   r.volsum = 0.0;
+  if (p.source == PCT_ITEMS_DATASET) {
+    r.traj++;
+    r.cursor = 0;
+    if (r.traj >= p.ds_ntraj) r.flags |= PCT_FLAG_DATASET_EXHAUSTED;
+  }
 }
 
 // rotation `rot` of the item (C/space.py:537-557): extents and the skip rule (abs < 1e-6)
@@ -494,6 +510,7 @@ __device__ inline void cload(const ContinuousParams& p, int e, CLds& l, CRegs& r
   r.cursor = ((uint64_t)(uint32_t)sc[9] << 32) | (uint32_t)sc[8];
   r.flags = p.flags[e];
   r.volsum = p.volsum[e];
+  r.traj = sc[12];
   const double* ge = p.ems + (size_t)e * 6 * p.ems_cap;
   const double* gb = p.boxes + (size_t)e * 6 * p.I;
   const double* gl = p.leaves + (size_t)e * 6 * p.L;
@@ -527,6 +544,7 @@ __device__ inline void cstore(const ContinuousParams& p, int e, const CLds& l, c
     sc[3] = r.ik0; sc[4] = r.ik1; sc[5] = r.ik2;
     sc[6] = (int32_t)r.t;
     sc[8] = (int32_t)(uint32_t)r.cursor; sc[9] = (int32_t)(uint32_t)(r.cursor >> 32);
+    sc[12] = r.traj;
     p.flags[e] = r.flags;
     p.volsum[e] = r.volsum;
   }

@@ -26,7 +26,9 @@ struct DiscreteParams {
   long long T;
   unsigned long long seed;
   const int32_t* item_set; /* [n_items,3] */
-  const int32_t* stream;   /* [N,T,3] */
+  const int32_t* stream;   /* [N,T,3]; dataset mode: [n_traj,max_len,3] */
+  const int32_t* ds_len;   /* dataset mode: [n_traj] */
+  int ds_ntraj, ds_maxlen;
   // persistent state
   int16_t* hmap;    /* [N,AA] heightmap */
   void* ems;        /* [N,ems_cap] packed EMS (key words) */
@@ -61,7 +63,9 @@ struct ContinuousParams {
   int sample_left, sample_right; /* lattice 1e-3 */
   long long T;
   unsigned long long seed;
-  const int32_t* stream; /* [N,T,3] lattice 1e-3 */
+  const int32_t* stream; /* [N,T,3] lattice 1e-3; dataset mode: [n_traj,max_len,3] */
+  const int32_t* ds_len;
+  int ds_ntraj, ds_maxlen;
   double* ems;      /* [N,6,ems_cap] */
   double* boxes;    /* [N,6,I] lx,ly,lz,xe,ye,top */
   double* leaves;   /* [N,6,L] */

@@ -58,6 +58,7 @@ struct EnvRegs {  // wave-uniform per-env scalars
   uint32_t t;
   int64_t vol;
   uint32_t flags;
+  int traj;  // dataset mode: current trajectory (LoadBoxCreator.index)
 };
 
 template <typename K, int BITS>
@@ -115,7 +116,17 @@ __device__ inline void draw_item(const DiscreteParams& p, int e, EnvRegs& r) {
   // binCreator.py:37-39 generate_box_size, through the scripted / counter-based sources
   uint64_t c = r.cursor++;
   const int32_t* it;
-  if (p.source == PCT_ITEMS_STREAM) {
+  if (p.source == PCT_ITEMS_DATASET) {  // binCreator.py:64-72 generate_box_size
+    int t = r.traj < p.ds_ntraj ? r.traj : p.ds_ntraj - 1;
+    int len = p.ds_len[t];
+    if (c < (uint64_t)len) {
+      it = p.stream + ((size_t)t * p.ds_maxlen + (size_t)c) * 3;
+    } else {
+      int v = (c == (uint64_t)len) ? 100 : 10;
+      r.item0 = v; r.item1 = v; r.item2 = v;
+      return;
+    }
+  } else if (p.source == PCT_ITEMS_STREAM) {
     it = p.stream + ((size_t)e * (size_t)p.T + (size_t)(c % (uint64_t)p.T)) * 3;
   } else {
     uint64_t g = (uint64_t)(p.env_id_base + e);
@@ -134,6 +145,11 @@ __device__ inline void space_reset(const DiscreteParams& p, Lds<K, BITS>& l, Env
   r.n_ems = 1;
   r.n_boxes = 0;
   r.vol = 0;
+  if (p.source == PCT_ITEMS_DATASET) {  // LoadBoxCreator.reset (binCreator.py:51-62)
+    r.traj++;
+    r.cursor = 0;
+    if (r.traj >= p.ds_ntraj) r.flags |= PCT_FLAG_DATASET_EXHAUSTED;
+  }
 }
 
 // D/space.py:457-483 GENEMS + :518-531 EliminateInscribedEMS.  ems_a -> ems_a.
@@ -592,6 +608,7 @@ __device__ inline void load_state(const DiscreteParams& p, int e, Lds<K, BITS>& 
   r.flags = p.flags[e];
   r.cursor = ((uint64_t)(uint32_t)sc[9] << 32) | (uint32_t)sc[8];
   r.vol = (int64_t)(((uint64_t)(uint32_t)sc[11] << 32) | (uint32_t)sc[10]);
+  r.traj = sc[12];
   for (int i = lane; i < r.n_ems; i += 64) l.ems_a[i] = g_ems[i];
   for (int i = lane; i < r.n_boxes; i += 64) l.box[i] = g_box[i];
   for (int i = lane; i < r.n_leaf; i += 64) l.leaf[i] = g_leaf[i];
@@ -618,6 +635,7 @@ __device__ inline void store_state(const DiscreteParams& p, int e, const Lds<K, 
     p.flags[e] = r.flags;
     sc[8] = (int32_t)(uint32_t)r.cursor; sc[9] = (int32_t)(uint32_t)(r.cursor >> 32);
     sc[10] = (int32_t)(uint32_t)(uint64_t)r.vol; sc[11] = (int32_t)(uint32_t)((uint64_t)r.vol >> 32);
+    sc[12] = r.traj;
   }
 }
 

@@ -340,6 +340,27 @@ int pct_set_item_stream(pct_env* h, const int32_t* items, int64_t T) {
   return PCT_OK;
 }
 
+int pct_set_item_dataset(pct_env* h, const int32_t* items, const int32_t* lengths, int32_t n_traj, int32_t max_len) {
+  if (!h || !items || !lengths || n_traj < 2 || max_len < 1)
+    return fail(PCT_ERR_INVALID_ARG, "bad dataset (at least 2 trajectories: the first episode plays trajectory 1)");
+  int rc = use_device(h);
+  if (rc) return rc;
+  void* d = nullptr;
+  void* dl = nullptr;
+  size_t n = (size_t)n_traj * (size_t)max_len * 3;
+  rc = dev_alloc(h, &d, sizeof(int32_t) * n, false);
+  if (rc) return rc;
+  rc = dev_alloc(h, &dl, sizeof(int32_t) * (size_t)n_traj, false);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(d, items, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dl, lengths, sizeof(int32_t) * (size_t)n_traj, hipMemcpyHostToDevice));
+  h->dp.stream = (int32_t*)d; h->dp.ds_len = (int32_t*)dl; h->dp.ds_ntraj = n_traj; h->dp.ds_maxlen = max_len;
+  h->dp.source = PCT_ITEMS_DATASET;
+  h->cp.stream = (int32_t*)d; h->cp.ds_len = (int32_t*)dl; h->cp.ds_ntraj = n_traj; h->cp.ds_maxlen = max_len;
+  h->cp.source = PCT_ITEMS_DATASET;
+  return PCT_OK;
+}
+
 int pct_set_sampler(pct_env* h, uint64_t seed) {
   if (!h) return fail(PCT_ERR_INVALID_ARG, "null handle");
   if (!h->have_items) return fail(PCT_ERR_STATE, "pct_set_item_set must come first");

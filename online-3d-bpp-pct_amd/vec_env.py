@@ -68,6 +68,26 @@ class VecEnv(ABC):
         pass
 
     @abstractmethod
+    def current_obs(self):
+        """The handle's observation buffer (valid until the next transition)."""
+        return self._obs
+
+    def step_device(self, leaf_index):
+        """Device-resident step: `leaf_index` int64 [N] / [N,1] on the
+        device; returns (obs, reward float32 [N,1], mask = 1 - done float32 [N,1]) as DEVICE
+        tensors with no host synchronisation and no info dicts (terminal statistics stay
+        readable through `terminal_stats()`).  Replaces the D2H of the selected row, the host
+        `done` round trip and the CPU reward tensor of train_tools.py:66-70 / envs.py:181."""
+        idx = leaf_index.reshape(self.N).to(device=self.device, dtype=torch.int64).contiguous()
+        self._actions_keepalive = idx
+        with torch.cuda.device(self._dev_index):
+            _lib.check(self._L.pct_step_index(self._h, idx.data_ptr(), self._stream()))
+        return self._obs, self._reward.unsqueeze(1), (1 - self._done.to(torch.float32)).unsqueeze(1)
+
+    def terminal_stats(self):
+        """(done bool [N], counter int32 [N], ratio float64 [N]) of the last step (one sync)."""
+        return self._done.bool().cpu().numpy(), self._counter.cpu().numpy(), self._ratio.cpu().numpy()
+
     def policy_hash_rows(self, out=None):
         """Stand-in policy as its own kernel: float32 [N,9] leaf rows on the device."""
         if out is None:
@@ -166,8 +186,11 @@ class PctVecEnv(VecEnv):
         if shuffle:
             raise NotImplementedError("shuffle=True (np.random.shuffle of the candidates, bin3D.py:114-115) "
                                       "is not available yet; construct with shuffle=False")
-        if load_test_data or data_name is not None:
-            raise NotImplementedError("dataset trajectories: pass them as item_stream=[N,T,3]")
+        self._dataset = None
+        if load_test_data:
+            if data_name is None:
+                raise ValueError("load_test_data=True needs data_name (a torch.save'd list of trajectories)")
+            self._dataset = [np.asarray(t, dtype=np.float64)[:, :3] for t in torch.load(data_name)]  # binCreator.py:48-49
         self.continuous = bool(continuous)
         if self.continuous and (sample_left_bound is None or sample_right_bound is None):
             raise ValueError("the continuous env needs sample_left_bound / sample_right_bound (tools.py:178-181)")
@@ -211,7 +234,9 @@ class PctVecEnv(VecEnv):
             items = np.ascontiguousarray(np.asarray(item_set, dtype=np.int32).reshape(-1, 3))
             _lib.check(self._L.pct_set_item_set(self._h, items.ctypes.data, items.shape[0]))
             self.item_set = items
-        if item_stream is not None:
+        if self._dataset is not None:
+            self.set_item_dataset(self._dataset)
+        elif item_stream is not None:
             self.set_item_stream(item_stream)
         else:
             _lib.check(self._L.pct_set_sampler(self._h, int(seed)))
@@ -251,6 +276,21 @@ class PctVecEnv(VecEnv):
         if items.ndim != 3 or items.shape[0] != self.N or items.shape[2] != 3:
             raise ValueError("item_stream must be int [num_envs, T, 3]")
         _lib.check(self._L.pct_set_item_stream(self._h, items.ctypes.data, items.shape[1]))
+
+    def set_item_dataset(self, trajectories):
+        """The reference's dataset format (README.md:75-77, binCreator.py:41-72): a list of
+        trajectories, each [len,3] item sizes (the continuous env takes bin units and stores them
+        on its 1e-3 lattice).  Episode k (1-based) plays trajectory k."""
+        scale = 1000 if self.continuous else 1
+        n = len(trajectories)
+        max_len = max(len(t) for t in trajectories)
+        items = np.zeros((n, max_len, 3), np.int32)
+        lengths = np.zeros(n, np.int32)
+        for i, t in enumerate(trajectories):
+            a = np.rint(np.asarray(t, dtype=np.float64).reshape(-1, 3) * scale).astype(np.int32)
+            items[i, :len(a)] = a
+            lengths[i] = len(a)
+        _lib.check(self._L.pct_set_item_dataset(self._h, items.ctypes.data, lengths.ctypes.data, n, max_len))
 
     def set_sampler(self, seed):
         _lib.check(self._L.pct_set_sampler(self._h, int(seed)))
@@ -308,6 +348,26 @@ class PctVecEnv(VecEnv):
         with torch.cuda.device(self._dev_index):
             _lib.check(self._L.pct_step_hash_policy(self._h, int(n_steps), self._stream()))
         self.waiting_step = True
+
+    def current_obs(self):
+        """The handle's observation buffer (valid until the next transition)."""
+        return self._obs
+
+    def step_device(self, leaf_index):
+        """Device-resident step: `leaf_index` int64 [N] / [N,1] on the
+        device; returns (obs, reward float32 [N,1], mask = 1 - done float32 [N,1]) as DEVICE
+        tensors with no host synchronisation and no info dicts (terminal statistics stay
+        readable through `terminal_stats()`).  Replaces the D2H of the selected row, the host
+        `done` round trip and the CPU reward tensor of train_tools.py:66-70 / envs.py:181."""
+        idx = leaf_index.reshape(self.N).to(device=self.device, dtype=torch.int64).contiguous()
+        self._actions_keepalive = idx
+        with torch.cuda.device(self._dev_index):
+            _lib.check(self._L.pct_step_index(self._h, idx.data_ptr(), self._stream()))
+        return self._obs, self._reward.unsqueeze(1), (1 - self._done.to(torch.float32)).unsqueeze(1)
+
+    def terminal_stats(self):
+        """(done bool [N], counter int32 [N], ratio float64 [N]) of the last step (one sync)."""
+        return self._done.bool().cpu().numpy(), self._counter.cpu().numpy(), self._ratio.cpu().numpy()
 
     def policy_hash_rows(self, out=None):
         """Stand-in policy as its own kernel: float32 [N,9] leaf rows on the device."""

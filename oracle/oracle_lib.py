@@ -51,6 +51,7 @@ def lib():
         L.pcto_set_item_set.argtypes = [vp, vp, ctypes.c_int32]
         L.pcto_set_item_stream.argtypes = [vp, vp, ctypes.c_int64]
         L.pcto_set_sample_bounds.argtypes = [vp, ctypes.c_int32, ctypes.c_int32]
+        L.pcto_set_item_dataset.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int32]
         L.pcto_set_sampler.argtypes = [vp, ctypes.c_uint64]
         for name in ("pcto_obs", "pcto_reward", "pcto_done", "pcto_info_counter", "pcto_info_ratio",
                      "pcto_error_flags"):
@@ -123,6 +124,12 @@ class OracleVecEnv(object):
         assert items.ndim == 3 and items.shape[0] == self.N and items.shape[2] == 3
         self._check(lib().pcto_set_item_stream(self._h, items.ctypes.data, items.shape[1]))
 
+    def set_item_dataset(self, trajectories):
+        """trajectories: list of [len_i,3] int arrays (lattice units), LoadBoxCreator semantics."""
+        items, lengths = pack_dataset(trajectories)
+        self._check(lib().pcto_set_item_dataset(self._h, items.ctypes.data, lengths.ctypes.data, items.shape[0],
+                                                items.shape[1]))
+
     def set_sampler(self, seed):
         self._check(lib().pcto_set_sampler(self._h, seed))
 
@@ -172,6 +179,18 @@ class OracleVecEnv(object):
             self.close()
         except Exception:
             pass
+
+
+def pack_dataset(trajectories):
+    n = len(trajectories)
+    max_len = max(len(t) for t in trajectories)
+    items = np.zeros((n, max_len, 3), np.int32)
+    lengths = np.zeros(n, np.int32)
+    for i, t in enumerate(trajectories):
+        a = np.asarray(t, dtype=np.int32).reshape(-1, 3)
+        items[i, :len(a)] = a
+        lengths[i] = len(a)
+    return np.ascontiguousarray(items), np.ascontiguousarray(lengths)
 
 
 def pyset_order(keys):

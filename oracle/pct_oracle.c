@@ -151,7 +151,16 @@ int pcto_pyset_order(const int64_t* keys, int32_t n, int32_t* order_out) {
  * pct_set_sampler); stands in for binCreator.py:37-39 generate_box_size */
 static void draw_item(const pcto_env* h, int e, oenv* s, int out[3]) {
   uint64_t c = s->cursor++;
-  if (h->source == PCT_ITEMS_STREAM) {
+  if (h->source == PCT_ITEMS_DATASET) { /* binCreator.py:64-72 LoadBoxCreator.generate_box_size */
+    int t = s->traj < h->ds_ntraj ? s->traj : h->ds_ntraj - 1;
+    int len = h->ds_len[t];
+    if (c < (uint64_t)len) {
+      const int32_t* p = h->stream + ((size_t)t * h->ds_maxlen + (size_t)c) * 3;
+      out[0] = p[0]; out[1] = p[1]; out[2] = p[2];
+    } else {
+      out[0] = out[1] = out[2] = (c == (uint64_t)len) ? 100 : 10; /* sentinel :62, then (10,10,10) :69-72 */
+    }
+  } else if (h->source == PCT_ITEMS_STREAM) {
     const int32_t* p = h->stream + ((size_t)e * (size_t)h->T + (size_t)(c % (uint64_t)h->T)) * 3;
     out[0] = p[0]; out[1] = p[1]; out[2] = p[2];
   } else {
@@ -522,6 +531,11 @@ static void cur_observation(const pcto_env* h, int e, oenv* s, double* obs) {
 /* D/bin3D.py:61-67 reset */
 static void env_reset(const pcto_env* h, int e, oenv* s, double* obs) {
   s->queue_len = 0;            /* box_creator.reset() */
+  if (h->source == PCT_ITEMS_DATASET) { /* LoadBoxCreator.reset: index += 1 (:51-62) */
+    s->traj++;
+    s->cursor = 0;
+    if (s->traj >= h->ds_ntraj) h->flags[e] |= PCT_FLAG_DATASET_EXHAUSTED; /* IndexError :58 */
+  }
   space_reset(h, s);           /* space.reset() */
   draw_item(h, e, s, s->queue_item); /* box_creator.generate_box_size() */
   s->queue_len = 1;
@@ -651,7 +665,7 @@ int pcto_destroy(pcto_env* h) {
   }
   if (h->cenvs) pctc_free(h);
   free(h->envs); free(h->obs); free(h->reward); free(h->done); free(h->counter); free(h->ratio);
-  free(h->flags); free(h->item_set); free(h->stream);
+  free(h->flags); free(h->item_set); free(h->stream); free(h->ds_len);
   free(h);
   return PCT_OK;
 }
@@ -686,6 +700,20 @@ int pcto_set_item_stream(pcto_env* h, const int32_t* items, int64_t T) {
   memcpy(h->stream, items, sizeof(int32_t) * n);
   h->T = T;
   h->source = PCT_ITEMS_STREAM;
+  return PCT_OK;
+}
+int pcto_set_item_dataset(pcto_env* h, const int32_t* items, const int32_t* lengths, int32_t n_traj, int32_t max_len) {
+  if (!h || !items || !lengths || n_traj < 2 || max_len < 1) return fail(PCT_ERR_INVALID_ARG, "bad dataset");
+  free(h->stream);
+  free(h->ds_len);
+  size_t n = (size_t)n_traj * (size_t)max_len * 3;
+  h->stream = (int32_t*)malloc(sizeof(int32_t) * n);
+  memcpy(h->stream, items, sizeof(int32_t) * n);
+  h->ds_len = (int32_t*)malloc(sizeof(int32_t) * (size_t)n_traj);
+  memcpy(h->ds_len, lengths, sizeof(int32_t) * (size_t)n_traj);
+  h->ds_ntraj = n_traj;
+  h->ds_maxlen = max_len;
+  h->source = PCT_ITEMS_DATASET;
   return PCT_OK;
 }
 int pcto_set_sampler(pcto_env* h, uint64_t seed) {

@@ -34,6 +34,7 @@ const char* pcto_last_error(void);
 int pcto_set_item_set(pcto_env* env, const int32_t* item_set, int32_t n);
 int pcto_set_sample_bounds(pcto_env* env, int32_t left, int32_t right);
 int pcto_set_item_stream(pcto_env* env, const int32_t* items, int64_t T);
+int pcto_set_item_dataset(pcto_env* env, const int32_t* items, const int32_t* lengths, int32_t n_traj, int32_t max_len);
 int pcto_set_sampler(pcto_env* env, uint64_t seed);
 
 /* outputs (host, owned by the handle) */

@@ -37,6 +37,7 @@ struct cenv {
   int queue_len;
   uint64_t cursor;
   uint32_t t;
+  int traj;
 };
 
 static double around6(double x) { return rint(x * 1e6) / 1e6; }
@@ -146,7 +147,16 @@ static void dset_add(dset* s, const double* keys, int32_t k) {
 static void draw_item(const struct pcto_env* h, int e, struct cenv* s, double out[3]) {
   uint64_t c = s->cursor++;
   int32_t k[3];
-  if (h->source == PCT_ITEMS_STREAM) {
+  if (h->source == PCT_ITEMS_DATASET) { /* binCreator.py:64-72; sizes are round(.,3) (C/bin3D.py:85) */
+    int t = s->traj < h->ds_ntraj ? s->traj : h->ds_ntraj - 1;
+    int len = h->ds_len[t];
+    if (c < (uint64_t)len) {
+      const int32_t* p = h->stream + ((size_t)t * h->ds_maxlen + (size_t)c) * 3;
+      k[0] = p[0]; k[1] = p[1]; k[2] = p[2];
+    } else {
+      k[0] = k[1] = k[2] = (c == (uint64_t)len) ? 100000 : 10000;
+    }
+  } else if (h->source == PCT_ITEMS_STREAM) {
     const int32_t* p = h->stream + ((size_t)e * (size_t)h->T + (size_t)(c % (uint64_t)h->T)) * 3;
     k[0] = p[0]; k[1] = p[1]; k[2] = p[2];
   } else {
@@ -382,6 +392,11 @@ static double get_ratio(const struct pcto_env* h, const struct cenv* s) {
 void pctc_reset(struct pcto_env* h, int e, double* obs) {
   struct cenv* s = &h->cenvs[e];
   s->queue_len = 0;
+  if (h->source == PCT_ITEMS_DATASET) {
+    s->traj++;
+    s->cursor = 0;
+    if (s->traj >= h->ds_ntraj) h->flags[e] |= PCT_FLAG_DATASET_EXHAUSTED;
+  }
   space_reset(h, s);
   draw_item(h, e, s, s->queue_item);
   s->queue_len = 1;

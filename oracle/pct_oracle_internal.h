@@ -26,6 +26,7 @@ typedef struct {
   uint64_t cursor; /* draws taken from the item source */
   uint32_t t;      /* lifetime step counter (hash policy) */
   struct stab* stab; /* stability state (settings 1 / 3), pct_oracle_stab.c */
+  int traj;          /* dataset mode: LoadBoxCreator.index (binCreator.py:46,54-55) */
 } oenv;
 
 struct cenv; /* continuous per-env state, pct_oracle_cont.c */
@@ -40,6 +41,8 @@ struct pcto_env {
   int n_items;
   int32_t* stream;
   int64_t T;
+  int32_t* ds_len; /* dataset mode: stream is [n_traj,max_len,3] */
+  int ds_ntraj, ds_maxlen;
   uint64_t seed;
   int source;
   oenv* envs;

@@ -62,3 +62,14 @@ CONT_CASES = ["continuous_s2_10_80_50", "continuous_s2_100_200_200", "continuous
 # CPU-only fixtures (stability, settings 1/3: restated in the oracle, not yet on the GPU)
 ORACLE_ONLY_CASES = []
 STAB_CASES = ["discrete_s1_10_80_50", "discrete_s1_rect_60_30"]
+
+DATASET_CASES = ["discrete_s2_dataset", "continuous_s2_dataset"]
+
+
+def dataset_trajectories(z):
+    """list of [len,3] float arrays from a dataset fixture"""
+    out, o = [], 0
+    for n in z["traj_len"]:
+        out.append(np.asarray(z["traj_items"][o:o + int(n)], np.float64))
+        o += int(n)
+    return out

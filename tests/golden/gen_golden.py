@@ -340,6 +340,91 @@ def known_answer_discrete_s2():
     print("known answer discrete s2: oracle == reference ==", ref_hash)
 
 
+DATASET_CASES = {
+    # the reference's LoadBoxCreator path (load_test_data=True; binCreator.py:41-72)
+    "discrete_s2_dataset": dict(kind="discrete", setting=2, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, N=2, steps=200,
+                                n_traj=40, traj_len=60, seed=31, base=0),
+    "continuous_s2_dataset": dict(kind="continuous", setting=2, container=(10, 10, 10), lo=1.0, hi=5.0, I=80, L=50, N=2,
+                                  steps=150, n_traj=30, traj_len=40, seed=32, base=5),
+}
+
+
+def make_dataset(case):
+    rng = np.random.RandomState(case["seed"])
+    trajs = []
+    for _ in range(case["n_traj"]):
+        n = int(rng.randint(case["traj_len"] // 2, case["traj_len"] + 1))
+        if case["kind"] == "discrete":
+            trajs.append(rng.randint(case["lo"], case["hi"] + 1, size=(n, 3)).astype(np.int64).tolist())
+        else:
+            k = rng.randint(int(case["lo"] * 1000), int(case["hi"] * 1000) + 1, size=(n, 3))
+            trajs.append((k / 1000.0).tolist())
+    return trajs
+
+
+def run_reference_dataset(case, trajs, path):
+    import torch
+    torch.save(trajs, path)
+    PD, PC, _ = ref_shim.load_reference_envs()
+    c = case
+    N, I, L = c["N"], c["I"], c["L"]
+    row_len = (I + L + 1) * 9
+    obs_rec = np.zeros((c["steps"] + 1, N, row_len), np.float64)
+    rew = np.zeros((c["steps"], N), np.float64)
+    done = np.zeros((c["steps"], N), np.uint8)
+    counter = np.zeros((c["steps"], N), np.int32)
+    for e in range(N):
+        if c["kind"] == "discrete":
+            env = PD(setting=c["setting"], container_size=list(c["container"]), item_set=item_set_range(c["lo"], c["hi"]),
+                     data_name=path, load_test_data=True, internal_node_holder=I, leaf_node_holder=L, shuffle=False,
+                     LNES="EMS")
+        else:
+            env = PC(setting=c["setting"], container_size=list(c["container"]), item_set=[(1, 1, 1)], data_name=path,
+                     load_test_data=True, internal_node_holder=I, leaf_node_holder=L, shuffle=False,
+                     sample_from_distribution=True, sample_left_bound=c["lo"], sample_right_bound=c["hi"])
+        obs = env.reset()
+        g = c["base"] + e
+        for t in range(c["steps"]):
+            obs_rec[t, e] = obs
+            leaf = obs.reshape(-1, 9)[I:I + L]
+            k = int((leaf[:, 8] != 0).sum())
+            li = mix32(g, t) % k if k > 0 else 0
+            obs, r, d, info = env.step(leaf[li].copy())
+            rew[t, e], done[t, e], counter[t, e] = r, d, info["counter"]
+            if d:
+                obs = env.reset()
+        obs_rec[c["steps"], e] = obs
+    return dict(obs=obs_rec, reward=rew, done=done, counter=counter)
+
+
+def run_oracle_dataset(case, trajs):
+    from oracle.oracle_lib import OracleVecEnv
+    c = case
+    if c["kind"] == "discrete":
+        env = OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"],
+                           item_set=item_set_range(c["lo"], c["hi"]), internal_node_holder=c["I"],
+                           leaf_node_holder=c["L"], env_id_base=c["base"])
+        env.set_item_dataset([np.asarray(t, np.int32) for t in trajs])
+    else:
+        env = OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"], env_kind=1,
+                           sample_bounds=(c["lo"], c["hi"]), internal_node_holder=c["I"], leaf_node_holder=c["L"],
+                           env_id_base=c["base"])
+        env.set_item_dataset([np.rint(np.asarray(t) * 1000).astype(np.int32) for t in trajs])
+    obs_rec = np.zeros((c["steps"] + 1, c["N"], (c["I"] + c["L"] + 1) * 9), np.float64)
+    rew = np.zeros((c["steps"], c["N"]), np.float64)
+    done = np.zeros((c["steps"], c["N"]), np.uint8)
+    counter = np.zeros((c["steps"], c["N"]), np.int32)
+    env.reset()
+    for t in range(c["steps"]):
+        obs_rec[t] = env.obs
+        env.step_hash_policy(1)
+        rew[t], done[t], counter[t] = env.reward, env.done, env.counter
+    obs_rec[c["steps"]] = env.obs
+    assert not env.flags.any()
+    env.close()
+    return dict(obs=obs_rec, reward=rew, done=done, counter=counter)
+
+
 def known_answer_discrete_s1():
     """discrete setting 1 (stability), env.seed(4), RandomState(0) policy:
     sha256[:16] = 443198ae2c0162db.  Item draws and actions recorded from the reference and
@@ -384,7 +469,27 @@ def known_answer_discrete_s1():
     print("known answer discrete s1: oracle == reference ==", ref_hash)
 
 
+def dataset_cases():
+    import tempfile
+    for name, case in DATASET_CASES.items():
+        trajs = make_dataset(case)
+        with tempfile.TemporaryDirectory() as td:
+            ref = run_reference_dataset(case, trajs, os.path.join(td, "data.pt"))
+        ora = run_oracle_dataset(case, trajs)
+        for key in ("obs", "reward", "done", "counter"):
+            if not np.array_equal(ref[key], ora[key]):
+                raise SystemExit("MISMATCH %s/%s first at %s" % (name, key, np.argwhere(ref[key] != ora[key])[0]))
+        print("%-28s steps=%d envs=%d episodes=%d  oracle == reference (LoadBoxCreator semantics)" % (
+            name, case["steps"], case["N"], int(ref["done"].sum())))
+        flat = np.concatenate([np.asarray(t, np.float64).reshape(-1, 3) for t in trajs])
+        lens = np.array([len(t) for t in trajs], np.int32)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), meta=np.array(repr(case)), traj_items=flat, traj_len=lens,
+                            obs=ref["obs"] if case["kind"] == "continuous" else ref["obs"].astype(np.float32),
+                            reward=ref["reward"], done=ref["done"], counter=ref["counter"])
+
+
 def main():
+    dataset_cases()
     known_answer_discrete_s2()
     known_answer_discrete_s1()
     known_answer_continuous_s2()

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.common import (CONT_CASES, GOLDEN, GOLDEN_CASES, gather_rows, hash_policy_index, item_set_range, load_case,
+from tests.common import (CONT_CASES, DATASET_CASES, GOLDEN, GOLDEN_CASES, dataset_trajectories, gather_rows, hash_policy_index, item_set_range, load_case,
                           make_stream)
 
 pytestmark = pytest.mark.gpu
@@ -366,5 +366,30 @@ def test_hip_continuous_matches_oracle_sampler(cfg):
         obs, reward, done, infos = env.step_wait()
         assert np.array_equal(done.astype(np.uint8), ora.done)
         assert np.array_equal(reward[:, 0].numpy(), ora.reward.astype(np.float32))
+    assert not env.error_flags.any()
+    env.close()
+
+
+@pytest.mark.parametrize("name", DATASET_CASES)
+def test_hip_dataset_semantics_match_reference(name, tmp_path):
+    """The reference's dataset path end to end: a torch.save'd list of trajectories loaded with
+    load_test_data=True / data_name=... (envs.py:37-38, binCreator.py:41-72)."""
+    c, z = load_case(name)
+    trajs = dataset_trajectories(z)
+    path = str(tmp_path / "data.pt")
+    torch.save([t.tolist() for t in trajs], path)
+    kw = dict(setting=2, container_size=c["container"], internal_node_holder=c["I"], leaf_node_holder=c["L"],
+              env_id_base=c["base"], data_name=path, load_test_data=True, device="cuda:0")
+    if c["kind"] == "discrete":
+        env = _pkg().PctVecEnv(c["N"], item_set=item_set_range(c["lo"], c["hi"]), **kw)
+    else:
+        env = _pkg().PctVecEnv(c["N"], continuous=True, sample_left_bound=c["lo"], sample_right_bound=c["hi"], **kw)
+    obs = env.reset()
+    for t in range(c["steps"]):
+        assert np.array_equal(obs.cpu().numpy(), z["obs"][t].astype(np.float32)), (name, t)
+        env.step_hash_policy(1)
+        obs, reward, done, infos = env.step_wait()
+        assert np.array_equal(done.astype(np.uint8), z["done"][t])
+        assert np.array_equal(reward[:, 0].numpy(), z["reward"][t].astype(np.float32))
     assert not env.error_flags.any()
     env.close()

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from oracle.oracle_lib import OracleVecEnv, pyset_order
-from tests.common import CONT_CASES, GOLDEN_CASES, ORACLE_ONLY_CASES, gather_rows, hash_policy_index, item_set_range, load_case, GOLDEN
+from tests.common import CONT_CASES, DATASET_CASES, GOLDEN_CASES, ORACLE_ONLY_CASES, dataset_trajectories, gather_rows, hash_policy_index, item_set_range, load_case, GOLDEN
 
 
 @pytest.mark.parametrize("name", GOLDEN_CASES + ORACLE_ONLY_CASES)
@@ -179,3 +179,24 @@ def test_known_answer_hash_replay_setting1():
         h.update(env.obs[0].astype(np.float32).tobytes())
         env.step_rows(z["actions"][t][None].astype(np.float64))
     assert h.hexdigest()[:16] == str(z["sha256_16"]) == "443198ae2c0162db"
+
+
+@pytest.mark.parametrize("name", DATASET_CASES)
+def test_oracle_dataset_semantics_match_reference(name):
+    """LoadBoxCreator (binCreator.py:41-72): episode k plays trajectory k (1-based), sentinel
+    (100,100,100) after the last item, then (10,10,10)."""
+    c, z = load_case(name)
+    trajs = dataset_trajectories(z)
+    if c["kind"] == "discrete":
+        env = OracleVecEnv(c["N"], setting=2, container_size=c["container"], item_set=item_set_range(c["lo"], c["hi"]),
+                           internal_node_holder=c["I"], leaf_node_holder=c["L"], env_id_base=c["base"])
+        env.set_item_dataset([t.astype(np.int32) for t in trajs])
+    else:
+        env = OracleVecEnv(c["N"], setting=2, container_size=c["container"], env_kind=1, sample_bounds=(c["lo"], c["hi"]),
+                           internal_node_holder=c["I"], leaf_node_holder=c["L"], env_id_base=c["base"])
+        env.set_item_dataset([np.rint(t * 1000).astype(np.int32) for t in trajs])
+    env.reset()
+    for t in range(c["steps"]):
+        assert np.array_equal(env.obs.astype(z["obs"].dtype), z["obs"][t]), (name, t)
+        env.step_hash_policy(1)
+        assert np.array_equal(env.done, z["done"][t]) and np.array_equal(env.reward, z["reward"][t])
