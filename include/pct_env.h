@@ -65,6 +65,7 @@ extern "C" {
 /* leaf-node expansion scheme (tools.py:133 --lnes) */
 #define PCT_LNES_EMS 0
 #define PCT_LNES_CP 3
+#define PCT_LNES_FC 4 /* full coordinate space (D/space.py:573-610) */
 
 /* item source */
 #define PCT_ITEMS_NONE 0

@@ -245,7 +245,7 @@ __device__ inline void genems(const DiscreteParams& p, Lds<K, BITS>& l, EnvRegs&
 
 // D/space.py:534-570 EMSPoint (CPython-set order) + D/bin3D.py:100-136
 // get_possible_position: fills l.leaf[0..n_leaf) with the first <= L feasible candidates.
-template <typename K, int BITS, bool STAB, bool CP, typename TM>
+template <typename K, int BITS, bool STAB, int SCHEME, typename TM>
 __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& l, EnvRegs& r, int lane, TM& tm) {
   typedef Pack<K, BITS> P;
   const uint64_t lt = lanemask_lt(lane);
@@ -339,7 +339,30 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
     }
   };
 
-  if (CP && r.n_boxes == 0) {
+  constexpr bool CP = SCHEME == 1;
+  if (SCHEME == 2) {
+    // D/space.py:573-610 FullCoord: rotation-major, then lx, then ly; lz = the cell's own height
+    const int NQ = orient * p.W * p.Ly;
+    for (int base = 0; base < NQ && !cand_overflow; base += 64) {
+      int q = base + lane;
+      bool valid = q < NQ;
+      int rot = q / (p.W * p.Ly);
+      int rem = q - rot * (p.W * p.Ly);
+      int px = rem / p.Ly, py = rem - px * p.Ly;
+      int sx, sy, sz;
+      bool skip = rot_size(rot, sx, sy, sz);
+      int pz = valid ? (int)l.hmap[px * p.A + py] : 0;
+      valid = valid && !skip && (px + sx <= p.W) && (py + sy <= p.Ly) && (pz + sz <= p.H);
+      K key = P::pack(px, py, pz, px + sx, py + sy, pz + sz);
+      uint64_t hash = tuplehash6<K, BITS>(key);
+      bool fresh = valid && !pyset_contains<K>(tabs + toff, size - 1, hash, [&](K w) { return w == key; });
+      uint64_t nm = __ballot(fresh);
+      if (fresh) pend[npend + __popcll(nm & lt)] = key;
+      npend += __popcll(nm);
+      __syncthreads();
+      if (npend >= 64) flush(64);
+    }
+  } else if (CP && r.n_boxes == 0) {
     // D/space.py:756-757: an empty bin yields a plain two-element LIST (unrotated, x/y
     // swapped; no set, no in-bin test): slots 0 and 1 of the fresh 8-slot table hold them in
     // list order, duplicates included
@@ -641,7 +664,7 @@ __device__ inline void store_state(const DiscreteParams& p, int e, const Lds<K, 
 
 // One transition of one env with the state resident in LDS (D/bin3D.py:151-188 plus the
 // VecEnv worker's auto-reset).  (flag, lx, ly) + (bx, by, bz) is the decoded action.
-template <typename K, int BITS, bool STAB, bool CP, typename TM>
+template <typename K, int BITS, bool STAB, int SCHEME, typename TM>
 __device__ inline void transition(const DiscreteParams& p, int e, Lds<K, BITS>& l, EnvRegs& r, int lane, bool bad,
                                   int flag, int lx, int ly, int bx, int by, int bz, TM& tm) {
   typedef Pack<K, BITS> P;
@@ -725,7 +748,7 @@ __device__ inline void transition(const DiscreteParams& p, int e, Lds<K, BITS>& 
     r.vol += (int64_t)x * y * z;
     __syncthreads();
     tm.tick(PH_DROP);
-    if (!CP) genems<K, BITS>(p, l, r, lane, lx, ly, max_h, lx + x, ly + y, top);  // D/bin3D.py:172-175
+    if (SCHEME == 0) genems<K, BITS>(p, l, r, lane, lx, ly, max_h, lx + x, ly + y, top);  // D/bin3D.py:172-175
     tm.tick(PH_GENEMS);
     // D/bin3D.py:57-59,183: 10 * vol(item) / vol(bin), float64 then envs.py:181 .float()
     reward = (float)(((double)((int64_t)r.item0 * r.item1 * r.item2) / binvol) * 10.0);
@@ -778,7 +801,7 @@ __device__ inline void decode_leaf(const EnvRegs& r, bool zero_row, int xs, int 
 
 enum { ACT_ROWS = 0, ACT_INDEX = 1, ACT_HASH = 2, ACT_RESET = 3 };
 
-template <typename K, int BITS, int ACT, bool TIMED, bool STAB, bool CP>
+template <typename K, int BITS, int ACT, bool TIMED, bool STAB, int SCHEME>
 __global__ void __launch_bounds__(64) pct_discrete_kernel(DiscreteParams p, const void* __restrict__ actions,
                                                           int row_len, int n_steps,
                                                           const int32_t* __restrict__ env_ids, int n_ids) {
@@ -802,7 +825,7 @@ __global__ void __launch_bounds__(64) pct_discrete_kernel(DiscreteParams p, cons
     space_reset<K, BITS>(p, l, r, lane);
     __syncthreads();
     draw_item(p, e, r);
-    leaf_nodes<K, BITS, STAB, CP>(p, e, l, r, lane, tm);
+    leaf_nodes<K, BITS, STAB, SCHEME>(p, e, l, r, lane, tm);
     write_obs<K, BITS>(p, l, r, lane, obs);
     store_state<K, BITS>(p, e, l, r, lane);
     return;
@@ -838,8 +861,8 @@ __global__ void __launch_bounds__(64) pct_discrete_kernel(DiscreteParams p, cons
       decode_leaf(r, zero_row, P::get(k, 0), P::get(k, 1), P::get(k, 3), P::get(k, 4), bad, lx, ly, bx, by, bz);
     }
     if (bad) r.flags |= PCT_FLAG_BAD_ACTION;  // ValueError in list.remove, D/bin3D.py:144-145
-    transition<K, BITS, STAB, CP>(p, e, l, r, lane, bad, flag, lx, ly, bx, by, bz, tm);
-    leaf_nodes<K, BITS, STAB, CP>(p, e, l, r, lane, tm);
+    transition<K, BITS, STAB, SCHEME>(p, e, l, r, lane, bad, flag, lx, ly, bx, by, bz, tm);
+    leaf_nodes<K, BITS, STAB, SCHEME>(p, e, l, r, lane, tm);
     write_obs<K, BITS>(p, l, r, lane, obs);
     __syncthreads();
     tm.tick(PH_OBS);
@@ -887,16 +910,18 @@ static hipError_t launch_typed(const DiscreteParams& p, int act, const void* act
   size_t lds = discrete_lds_bytes(p);
   const bool timed = p.timing != nullptr && act != ACT_RESET;
   const bool stab = p.setting != 2;
-  const bool cp = p.lnes == PCT_LNES_CP;
+  const int scheme = p.lnes == PCT_LNES_CP ? 1 : (p.lnes == PCT_LNES_FC ? 2 : 0);
   int grid = (act == ACT_RESET && env_ids) ? n_ids : p.N;
   if (grid <= 0) return hipSuccess;
+#define PCT_KERN(A, T, S, C) pct_discrete_kernel<K, BITS, A, T, S, C>
 #define PCT_LAUNCH(A)                                                                                        \
   do {                                                                                                       \
-    auto kern = stab ? (cp ? pct_discrete_kernel<K, BITS, A, false, true, true>                              \
-                           : pct_discrete_kernel<K, BITS, A, false, true, false>)                            \
-                     : (cp ? pct_discrete_kernel<K, BITS, A, false, false, true>                             \
-                           : (timed ? pct_discrete_kernel<K, BITS, A, true, false, false>                    \
-                                    : pct_discrete_kernel<K, BITS, A, false, false, false>));                \
+    void (*kern)(DiscreteParams, const void*, int, int, const int32_t*, int);                                \
+    if (stab) kern = scheme == 1 ? PCT_KERN(A, false, true, 1) : scheme == 2 ? PCT_KERN(A, false, true, 2)   \
+                                                                              : PCT_KERN(A, false, true, 0); \
+    else if (scheme == 1) kern = PCT_KERN(A, false, false, 1);                                               \
+    else if (scheme == 2) kern = PCT_KERN(A, false, false, 2);                                               \
+    else kern = timed ? PCT_KERN(A, true, false, 0) : PCT_KERN(A, false, false, 0);                          \
     if (lds > 48 * 1024) {                                                                                   \
       hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                               \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \

@@ -132,10 +132,10 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
   const bool cont = cfg->env_kind == PCT_ENV_CONTINUOUS;
   if (cfg->setting != 2 && !(cfg->setting == 1 && cfg->env_kind == PCT_ENV_DISCRETE))
     return fail(PCT_ERR_UNSUPPORTED, "settings built: 2 (both envs) and 1 (discrete env)");
-  if (cfg->lnes != PCT_LNES_EMS && cfg->lnes != PCT_LNES_CP)
-    return fail(PCT_ERR_UNSUPPORTED, "LNES must be EMS or CP");
-  if (cfg->lnes == PCT_LNES_CP && cfg->env_kind != PCT_ENV_DISCRETE)
-    return fail(PCT_ERR_UNSUPPORTED, "the corner-point scheme exists only in the discrete env");
+  if (cfg->lnes != PCT_LNES_EMS && cfg->lnes != PCT_LNES_CP && cfg->lnes != PCT_LNES_FC)
+    return fail(PCT_ERR_UNSUPPORTED, "LNES built: EMS, CP, FC (EV / EP are not)");
+  if (cfg->lnes != PCT_LNES_EMS && cfg->env_kind != PCT_ENV_DISCRETE)
+    return fail(PCT_ERR_UNSUPPORTED, "CP / FC exist only in the discrete env (C/bin3D.py:53)");
   if (cfg->num_envs < 1 || cfg->internal_node_holder < 1 || cfg->leaf_node_holder < 1)
     return fail(PCT_ERR_INVALID_ARG, "num_envs / holders must be positive");
   int W = cfg->container[0], Ly = cfg->container[1], H = cfg->container[2];

@@ -167,7 +167,7 @@ class LazyInfos(object):
             yield self[i]
 
 
-_LNES = {"EMS": _lib.LNES_EMS, "CP": _lib.LNES_CP}
+_LNES = {"EMS": _lib.LNES_EMS, "CP": _lib.LNES_CP, "FC": _lib.LNES_FC}
 
 
 class PctVecEnv(VecEnv):

@@ -487,12 +487,48 @@ static int corner_point(const pcto_env* h, const oenv* s, int64_t** out) {
   return cnt;
 }
 
-/* D/bin3D.py:100-136 get_possible_position (LNES='EMS' / 'CP', shuffle=False): writes the L
+/* D/space.py:573-610 FullCoord: every (lx, ly) at its own cell height, every rotation */
+static int full_coord(const pcto_env* h, const oenv* s, int64_t** out) {
+  int orientation = (h->cfg.setting == 2) ? 6 : 2;
+  const int* nb = s->next_box;
+  int W = h->cfg.container[0], L = h->cfg.container[1], H = h->cfg.container[2], A = h->A;
+  int64_t* keys = (int64_t*)malloc(sizeof(int64_t) * 6 * (size_t)(orientation * W * L + 1));
+  int nk = 0;
+  for (int rot = 0; rot < orientation; rot++) {
+    int64_t sx, sy, sz;
+    switch (rot) {
+      case 0: sx = nb[0]; sy = nb[1]; sz = nb[2]; break;
+      case 1: sx = nb[1]; sy = nb[0]; sz = nb[2]; if (sx == sy) continue; break;
+      case 2: sx = nb[0]; sy = nb[2]; sz = nb[1]; if (sx == sy && sy == sz) continue; break;
+      case 3: sx = nb[1]; sy = nb[2]; sz = nb[0]; if (sx == sy && sy == sz) continue; break;
+      case 4: sx = nb[2]; sy = nb[0]; sz = nb[1]; if (sx == sy) continue; break;
+      default: sx = nb[2]; sy = nb[1]; sz = nb[0]; if (sx == sy) continue; break;
+    }
+    for (int lx = 0; lx < W; lx++)
+      for (int ly = 0; ly < L; ly++) {
+        int lz = s->plain[lx * A + ly];
+        if (lx + sx <= W && ly + sy <= L && lz + sz <= H) {
+          int64_t* kk = keys + 6 * (size_t)nk++;
+          kk[0] = lx; kk[1] = ly; kk[2] = lz; kk[3] = lx + sx; kk[4] = ly + sy; kk[5] = lz + sz;
+        }
+      }
+  }
+  int32_t* order = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nk + 1));
+  int cnt = pcto_pyset_order(keys, nk, order);
+  int64_t* res = (int64_t*)malloc(sizeof(int64_t) * 6 * (size_t)(cnt + 1));
+  for (int i = 0; i < cnt; i++) memcpy(res + 6 * (size_t)i, keys + 6 * (size_t)order[i], 6 * sizeof(int64_t));
+  free(order); free(keys);
+  *out = res;
+  return cnt;
+}
+
+/* D/bin3D.py:100-136 get_possible_position (LNES='EMS' / 'CP' / 'FC', shuffle=False): writes the L
  * leaf rows into leaf[L*9] */
 static void get_possible_position(const pcto_env* h, const oenv* s, double* leaf) {
   memset(leaf, 0, sizeof(double) * 9 * h->L);
   int64_t* pos = NULL;
-  int n = h->cfg.lnes == PCT_LNES_CP ? corner_point(h, s, &pos) : ems_point(h, s, &pos);
+  int n = h->cfg.lnes == PCT_LNES_CP ? corner_point(h, s, &pos)
+          : h->cfg.lnes == PCT_LNES_FC ? full_coord(h, s, &pos) : ems_point(h, s, &pos);
   int idx = 0;
   for (int i = 0; i < n; i++) {
     const int64_t* p = pos + 6 * i;
@@ -621,9 +657,9 @@ int pcto_create(const pct_config* cfg, pcto_env** out) {
     return fail(PCT_ERR_UNSUPPORTED, "oracle: unknown env kind");
   if (cfg->setting != 2 && !(cfg->setting == 1 && cfg->env_kind == PCT_ENV_DISCRETE))
     return fail(PCT_ERR_UNSUPPORTED, "oracle: settings restated: 2 (both envs), 1 (discrete env)");
-  if (cfg->lnes != PCT_LNES_EMS && cfg->lnes != PCT_LNES_CP)
-    return fail(PCT_ERR_UNSUPPORTED, "oracle: only LNES=EMS and LNES=CP are restated");
-  if (cfg->lnes == PCT_LNES_CP && cfg->env_kind != PCT_ENV_DISCRETE)
+  if (cfg->lnes != PCT_LNES_EMS && cfg->lnes != PCT_LNES_CP && cfg->lnes != PCT_LNES_FC)
+    return fail(PCT_ERR_UNSUPPORTED, "oracle: LNES restated: EMS, CP, FC");
+  if (cfg->lnes != PCT_LNES_EMS && cfg->env_kind != PCT_ENV_DISCRETE)
     return fail(PCT_ERR_UNSUPPORTED, "the corner-point scheme exists only in the discrete env");
   if (cfg->num_envs < 1 || cfg->internal_node_holder < 1 || cfg->leaf_node_holder < 1)
     return fail(PCT_ERR_INVALID_ARG, "bad sizes");

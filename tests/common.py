@@ -55,7 +55,8 @@ def gather_rows(obs, I, idx):
 
 
 GOLDEN_CASES = ["discrete_s2_10_80_50", "discrete_s2_rect_60_30", "discrete_s2_10_80_5", "discrete_s2_20_120_400",
-                "discrete_s2_cp_10_80_50", "discrete_s2_cp_rect_60_16", "discrete_s1_10_80_50", "discrete_s1_rect_60_30"]
+                "discrete_s2_cp_10_80_50", "discrete_s2_cp_rect_60_16", "discrete_s1_10_80_50", "discrete_s1_rect_60_30",
+                "discrete_s2_fc_10_80_50", "discrete_s1_fc_rect_60_24"]
 
 CONT_CASES = ["continuous_s2_10_80_50", "continuous_s2_100_200_200", "continuous_s2_rect_60_20"]
 

@@ -84,6 +84,11 @@ CASES = {
                                     stream_T=256, seed=15, base=11, lnes="CP"),
     "discrete_s2_cp_rect_60_16": dict(setting=2, container=(9, 13, 10), lo=1, hi=6, I=60, L=16, N=3, steps=200,
                                       stream_T=256, seed=16, base=0, lnes="CP"),
+    # full-coordinate leaf expansion (--lnes FC, D/space.py:573-610)
+    "discrete_s2_fc_10_80_50": dict(setting=2, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, N=4, steps=200,
+                                    stream_T=256, seed=19, base=4, lnes="FC"),
+    "discrete_s1_fc_rect_60_24": dict(setting=1, container=(8, 11, 9), lo=1, hi=5, I=60, L=24, N=3, steps=150,
+                                      stream_T=256, seed=20, base=1, lnes="FC"),
     # setting 1: stability check + 2 orientations (BASELINE.json configs[0] geometry)
     "discrete_s1_10_80_50": dict(setting=1, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, N=6, steps=250,
                                  stream_T=512, seed=17, base=21),
@@ -275,7 +280,7 @@ def run_oracle(case, stream):
     c = case
     env = OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"],
                        item_set=item_set_range(c["lo"], c["hi"]), internal_node_holder=c["I"],
-                       leaf_node_holder=c["L"], env_id_base=c["base"], lnes=3 if c.get("lnes") == "CP" else 0)
+                       leaf_node_holder=c["L"], env_id_base=c["base"], lnes={"CP": 3, "FC": 4}.get(c.get("lnes"), 0))
     env.set_item_stream(stream)
     N, I, L = c["N"], c["I"], c["L"]
     row_len = (I + L + 1) * 9

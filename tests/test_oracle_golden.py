@@ -18,7 +18,7 @@ def test_oracle_matches_reference_fixture_fused_policy(name):
     c, z = load_case(name)
     env = OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"],
                        item_set=item_set_range(c["lo"], c["hi"]), internal_node_holder=c["I"],
-                       leaf_node_holder=c["L"], env_id_base=c["base"], lnes=3 if c.get("lnes") == "CP" else 0)
+                       leaf_node_holder=c["L"], env_id_base=c["base"], lnes={"CP": 3, "FC": 4}.get(c.get("lnes"), 0))
     env.set_item_stream(z["stream"])
     env.reset()
     for t in range(c["steps"]):
