@@ -12,7 +12,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
-KERNEL = "pct_discrete_kernel<unsigned int, 5, 0"
+KERNEL = "pct_discrete_kernel<unsigned int, 5, 0, false, false, 0"
 
 out = {"tag": tag, "command": "python bench.py --no-cpu-baseline --steps 2000 --warmup 200 (kernel trace); "
                               "--steps 200 --warmup 50 for each --pmc pass"}
