@@ -24,6 +24,7 @@
 #include "../../include/pct_env.h"
 #include "pct_device.h"
 #include "pct_set.cuh"
+#include "pct_stab.cuh"
 
 namespace pct {
 
@@ -78,6 +79,7 @@ struct CLds {
   uint32_t* tab;  // [cand_cap + cand_cap/4] hash table regions (aliases ems_b)
   double* box;    // [6][I] lx,ly,lz,xe,ye,top
   double* leaf;   // [6][L]
+  double* bsz;    // [3][I] item sizes as placed (x,y,z): (lx + x) - lx need not equal x
   uint64_t* bhash;  // [64]
   int32_t* bk;      // [4][I] lattice indices of (-lx,-ly,xe,ye)
   uint32_t* pend;   // [128] generator ids waiting for insertion
@@ -95,6 +97,7 @@ __device__ inline CLds carve(const ContinuousParams& p, unsigned char* base) {
   d += p.union_doubles;
   l.box = d; d += 6 * p.I;
   l.leaf = d; d += 6 * p.L;
+  l.bsz = d; d += 3 * p.I;
   l.bhash = reinterpret_cast<uint64_t*>(d); d += 64;
   int32_t* q = reinterpret_cast<int32_t*>(d);
   l.bk = q; q += 4 * p.I;
@@ -107,7 +110,7 @@ __device__ inline CLds carve(const ContinuousParams& p, unsigned char* base) {
 }
 
 size_t continuous_lds_bytes(const ContinuousParams& p) {
-  size_t dbl = (size_t)6 * p.ems_cap + p.union_doubles + 6 * (size_t)p.I + 6 * (size_t)p.L + 64;
+  size_t dbl = (size_t)6 * p.ems_cap + p.union_doubles + 9 * (size_t)p.I + 6 * (size_t)p.L + 64;
   size_t i32 = 4 * (size_t)p.I + 128 + 64;
   size_t u16 = (size_t)(p.table_global ? 0 : p.order_cap) + 64;
   return dbl * 8 + i32 * 4 + u16 * 2 + 16;
@@ -187,6 +190,28 @@ __device__ inline bool tuple_eq(const double a[6], const double b[6]) {
 }
 // table word of a key: 15-bit fingerprint of its hash | 16-bit generator id (tag bit clear)
 __device__ inline uint32_t cword(uint64_t hash, uint32_t g) { return (uint32_t)((hash >> 40) & 0x7FFFu) << 16 | g; }
+
+struct CGeo {  // placed-box geometry for the stability code
+  const double* box;
+  const double* bsz;
+  int I;
+  __device__ inline void operator()(int i, double g[9]) const {
+#pragma unroll
+    for (int c = 0; c < 6; c++) g[c] = box[c * I + i];
+    g[6] = bsz[0 * I + i]; g[7] = bsz[1 * I + i]; g[8] = bsz[2 * I + i];
+  }
+};
+__device__ inline StabState cstab_view(const ContinuousParams& p, int e) {
+  StabState st;
+  st.I = p.I;
+  st.stack = p.st_stack + (size_t)e * p.I * 4;
+  st.nsup = p.st_nsup + (size_t)e * p.I;
+  st.sup = p.st_sup + (size_t)e * p.I * STAB_SMAX;
+  st.share = p.st_share + (size_t)e * p.I * STAB_SMAX * 4;
+  st.npoly = p.st_npoly + (size_t)e * p.I;
+  st.poly = p.st_poly + (size_t)e * p.I * STAB_PMAX * 2;
+  return st;
+}
 
 // C/space.py:441-487 GENEMS + :510-528 EliminateInscribedEMS.  l.ems -> l.ems.
 __device__ inline void cgenems(const ContinuousParams& p, CLds& l, CRegs& r, int lane, const double loc[6]) {
@@ -295,7 +320,7 @@ __device__ inline void cgenems(const ContinuousParams& p, CLds& l, CRegs& r, int
 }
 
 // C/space.py:531-568 EMSPoint (CPython set order over float tuples) + C/bin3D.py:118-148
-template <bool GT, typename TM>
+template <bool GT, bool STAB, typename TM>
 __device__ inline void cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CRegs& r, int lane, TM& tm) {
   const uint64_t lt = lanemask_lt(lane);
   const int E = r.n_ems, cap = p.ems_cap;
@@ -440,6 +465,7 @@ __device__ inline void cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
 
   // feasibility in list order (C/space.py:380-425 drop_box_virtual, setting 2), first L kept
   int nleaf = 0;
+  bool stab_err = false;
   const int nb = r.n_boxes;
   for (int base = 0; base < norder && nleaf < p.L; base += 64) {
     int i = base + lane;
@@ -461,6 +487,13 @@ __device__ inline void cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
       max_h = (ov && top > max_h) ? top : max_h;
     }
     if (max_h + z - 1e-6 > p.H) ok = false;
+    if (STAB && ok && !(fabs(max_h) < 1e-6)) {  // C/space.py:432-439 calculated_impact_virtual(True)
+      const double cand[9] = {lx, ly, max_h, lx + x, ly + y, max_h + z, x, y, z};
+      CGeo geo{l.box, l.bsz, p.I};
+      bool err;
+      ok = stab_virtual<true>(geo, cstab_view(p, e), nb, cand, 1.0, err);
+      if (err) stab_err = true;
+    }
     uint64_t m = __ballot(ok);
     int idx = nleaf + __popcll(m & lt);
     if (ok && idx < p.L) {
@@ -469,6 +502,7 @@ __device__ inline void cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
     }
     nleaf += __popcll(m);
   }
+  if (STAB && __ballot(stab_err)) r.flags |= PCT_FLAG_STABILITY_OVERFLOW;
   r.n_leaf = nleaf < p.L ? nleaf : p.L;
   __syncthreads();
   tm.tick(PH_FEAS);
@@ -514,6 +548,9 @@ __device__ inline void cload(const ContinuousParams& p, int e, CLds& l, CRegs& r
   const double* ge = p.ems + (size_t)e * 6 * p.ems_cap;
   const double* gb = p.boxes + (size_t)e * 6 * p.I;
   const double* gl = p.leaves + (size_t)e * 6 * p.L;
+  const double* gs = p.bsz + (size_t)e * 3 * p.I;
+  for (int c = 0; c < 3; c++)
+    for (int i = lane; i < r.n_boxes; i += 64) l.bsz[c * p.I + i] = gs[c * p.I + i];
   for (int c = 0; c < 6; c++) {
     for (int i = lane; i < r.n_ems; i += 64) l.ems[c * p.ems_cap + i] = ge[c * p.ems_cap + i];
     for (int i = lane; i < r.n_boxes; i += 64) l.box[c * p.I + i] = gb[c * p.I + i];
@@ -534,6 +571,9 @@ __device__ inline void cstore(const ContinuousParams& p, int e, const CLds& l, c
   double* ge = p.ems + (size_t)e * 6 * p.ems_cap;
   double* gb = p.boxes + (size_t)e * 6 * p.I;
   double* gl = p.leaves + (size_t)e * 6 * p.L;
+  double* gs = p.bsz + (size_t)e * 3 * p.I;
+  for (int c = 0; c < 3; c++)
+    for (int i = lane; i < r.n_boxes; i += 64) gs[c * p.I + i] = l.bsz[c * p.I + i];
   for (int c = 0; c < 6; c++) {
     for (int i = lane; i < r.n_ems; i += 64) ge[c * p.ems_cap + i] = l.ems[c * p.ems_cap + i];
     for (int i = lane; i < r.n_boxes; i += 64) gb[c * p.I + i] = l.box[c * p.I + i];
@@ -552,7 +592,7 @@ __device__ inline void cstore(const ContinuousParams& p, int e, const CLds& l, c
 
 // C/bin3D.py:169-207 step (+ the VecEnv worker's auto-reset).  a1/a2: raw position entries of
 // the action, (bx,by,bz): the item as LeafNode2Action returns it.
-template <typename TM>
+template <bool STAB, typename TM>
 __device__ inline void ctransition(const ContinuousParams& p, int e, CLds& l, CRegs& r, int lane, int flag, double a1,
                                    double a2, double bx, double by, double bz, TM& tm) {
   r.t++;
@@ -574,6 +614,28 @@ __device__ inline void ctransition(const ContinuousParams& p, int e, CLds& l, CR
     max_h = wave_max_f64(m);
     if (max_h + z - 1e-6 > p.H) ok = false;
   }
+  if (STAB && ok && r.n_boxes < p.I) {
+    // check_box :432-437: box_now.calculated_impact() (or True on the floor); the box is kept
+    // only if the verdict is True, so it is written beyond n_boxes first
+    const int bi = r.n_boxes;
+    if (lane == 0) {
+      l.box[0 * p.I + bi] = lx; l.box[1 * p.I + bi] = ly; l.box[2 * p.I + bi] = max_h;
+      l.box[3 * p.I + bi] = lx + x; l.box[4 * p.I + bi] = ly + y; l.box[5 * p.I + bi] = max_h + z;
+      l.bsz[0 * p.I + bi] = x; l.bsz[1 * p.I + bi] = y; l.bsz[2 * p.I + bi] = z;
+    }
+    __syncthreads();
+    int verdict = 1, serr = 0;
+    if (lane == 0) {
+      CGeo geo{l.box, l.bsz, p.I};
+      StabState st = cstab_view(p, e);
+      bool err;
+      verdict = stab_commit<true>(geo, st, bi, 1.0, err) ? 1 : 0;
+      serr = err ? 1 : 0;
+    }
+    verdict = __shfl(verdict, 0, 64);
+    if (__shfl(serr, 0, 64)) r.flags |= PCT_FLAG_STABILITY_OVERFLOW;
+    ok = verdict != 0;
+  }
   if (ok && r.n_boxes >= p.I) {  // IndexError at C/space.py:371
     ok = false;
     r.flags |= PCT_FLAG_INTERNAL_OVERFLOW;
@@ -591,6 +653,7 @@ __device__ inline void ctransition(const ContinuousParams& p, int e, CLds& l, CR
       l.box[3 * p.I + bi] = xe; l.box[4 * p.I + bi] = ye; l.box[5 * p.I + bi] = top;
       l.bk[0 * p.I + bi] = klat(-lx); l.bk[1 * p.I + bi] = klat(-ly);
       l.bk[2 * p.I + bi] = klat(xe); l.bk[3 * p.I + bi] = klat(ye);
+      l.bsz[0 * p.I + bi] = x; l.bsz[1 * p.I + bi] = y; l.bsz[2 * p.I + bi] = z;
     }
     r.n_boxes++;
     r.volsum = r.volsum + x * y * z;  // get_ratio's left fold (:316-321)
@@ -649,7 +712,7 @@ __device__ inline void cdecode_leaf(const CRegs& r, bool zero_row, double a0, do
 
 enum { CACT_ROWS = 0, CACT_INDEX = 1, CACT_HASH = 2, CACT_RESET = 3 };
 
-template <int ACT, bool TIMED, bool GT>
+template <int ACT, bool TIMED, bool GT, bool STAB>
 __global__ void __launch_bounds__(64) pct_continuous_kernel(ContinuousParams p, const void* __restrict__ actions,
                                                             int row_len, int n_steps,
                                                             const int32_t* __restrict__ env_ids, int n_ids) {
@@ -673,7 +736,7 @@ __global__ void __launch_bounds__(64) pct_continuous_kernel(ContinuousParams p, 
     cspace_reset(p, l, r, lane);
     __syncthreads();
     cdraw_item(p, e, r);
-    cleaf_nodes<GT>(p, e, l, r, lane, tm);
+    cleaf_nodes<GT, STAB>(p, e, l, r, lane, tm);
     cwrite_obs(p, l, r, lane, obs);
     cstore(p, e, l, r, lane);
     return;
@@ -725,8 +788,8 @@ __global__ void __launch_bounds__(64) pct_continuous_kernel(ContinuousParams p, 
       }
       cdecode_leaf(r, zero_row, a0, a1, a3, a4, p1, p2, bx, by, bz);
     }
-    ctransition(p, e, l, r, lane, flag, p1, p2, bx, by, bz, tm);
-    cleaf_nodes<GT>(p, e, l, r, lane, tm);
+    ctransition<STAB>(p, e, l, r, lane, flag, p1, p2, bx, by, bz, tm);
+    cleaf_nodes<GT, STAB>(p, e, l, r, lane, tm);
     cwrite_obs(p, l, r, lane, obs);
     __syncthreads();
     tm.tick(PH_OBS);
@@ -761,12 +824,16 @@ hipError_t launch_continuous(const ContinuousParams& p, int act, const void* act
                              const int32_t* env_ids, int n_ids, hipStream_t stream) {
   size_t lds = continuous_lds_bytes(p);
   const bool timed = p.timing != nullptr && act != CACT_RESET;
+  const bool stab = p.setting != 2;
   int grid = (act == CACT_RESET && env_ids) ? n_ids : p.N;
   if (grid <= 0) return hipSuccess;
 #define PCT_CLAUNCH(A)                                                                                         \
   do {                                                                                                         \
-    auto kern = p.table_global ? pct_continuous_kernel<A, false, true>                                         \
-                               : (timed ? pct_continuous_kernel<A, true, false> : pct_continuous_kernel<A, false, false>); \
+    void (*kern)(ContinuousParams, const void*, int, int, const int32_t*, int);                                \
+    if (stab) kern = p.table_global ? pct_continuous_kernel<A, false, true, true>                              \
+                                    : pct_continuous_kernel<A, false, false, true>;                            \
+    else if (p.table_global) kern = pct_continuous_kernel<A, false, true, false>;                              \
+    else kern = timed ? pct_continuous_kernel<A, true, false, false> : pct_continuous_kernel<A, false, false, false>; \
     if (lds > 48 * 1024) {                                                                                     \
       hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                 \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \

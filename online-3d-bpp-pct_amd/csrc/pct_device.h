@@ -70,6 +70,13 @@ struct ContinuousParams {
   double* boxes;    /* [N,6,I] lx,ly,lz,xe,ye,top */
   double* leaves;   /* [N,6,L] */
   double* volsum;   /* [N] running sum of placed volumes (get_ratio) */
+  double* bsz;      /* [N,3,I] placed sizes x,y,z */
+  double* st_stack; /* stability state, as in DiscreteParams (settings 1/3 only) */
+  int* st_nsup;
+  int* st_sup;
+  double* st_share;
+  int* st_npoly;
+  double* st_poly;
   int table_global; /* 1: hash table + order list live in HBM (capacity beyond LDS) */
   uint32_t* gtab;   /* [N, cand_cap*5/4] */
   uint16_t* gorder; /* [N, order_cap] */

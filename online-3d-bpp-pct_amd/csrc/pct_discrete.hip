@@ -94,10 +94,11 @@ __device__ inline Lds<K, BITS> carve_lds(const DiscreteParams& p, unsigned char*
 template <typename K, int BITS>
 struct BoxGeo {
   const K* box;
-  __device__ inline void operator()(int i, double g[6]) const {
+  __device__ inline void operator()(int i, double g[9]) const {
     K k = box[i];
 #pragma unroll
     for (int c = 0; c < 6; c++) g[c] = (double)Pack<K, BITS>::get(k, c);
+    g[6] = g[3] - g[0]; g[7] = g[4] - g[1]; g[8] = g[5] - g[2];  // exact for integers
   }
 };
 __device__ inline StabState stab_view(const DiscreteParams& p, int e) {
@@ -563,10 +564,11 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
       // check_box :436-446: EMS candidates are inside the bin by construction
       feas = (xe <= p.W) && (ye <= p.Ly) && (mh + z <= p.H);
       if (STAB && feas && mh != 0) {  // :447-454 calculated_impact_virtual(first=True)
-        const double cand[6] = {(double)xs, (double)ys, (double)mh, (double)xe, (double)ye, (double)(mh + z)};
+        const double cand[9] = {(double)xs, (double)ys, (double)mh, (double)xe, (double)ye, (double)(mh + z),
+                                (double)(xe - xs), (double)(ye - ys), (double)z};
         BoxGeo<K, BITS> geo{l.box};
         bool err;
-        feas = stab_virtual(geo, stab_view(p, e), r.n_boxes, cand, 1.0, err);
+        feas = stab_virtual<false>(geo, stab_view(p, e), r.n_boxes, cand, 1.0, err);
         if (err) stab_err = true;
       }
     }
@@ -710,7 +712,7 @@ __device__ inline void transition(const DiscreteParams& p, int e, Lds<K, BITS>& 
       BoxGeo<K, BITS> geo{l.box};
       StabState st = stab_view(p, e);
       bool err;
-      verdict = stab_commit(geo, st, r.n_boxes, 1.0, err) ? 1 : 0;
+      verdict = stab_commit<false>(geo, st, r.n_boxes, 1.0, err) ? 1 : 0;
       serr = err ? 1 : 0;
     }
     verdict = __shfl(verdict, 0, 64);
@@ -724,7 +726,7 @@ __device__ inline void transition(const DiscreteParams& p, int e, Lds<K, BITS>& 
       BoxGeo<K, BITS> geo{l.box};
       StabState st = stab_view(p, e);
       bool err;
-      stab_commit(geo, st, r.n_boxes, 1.0, err);
+      stab_commit<false>(geo, st, r.n_boxes, 1.0, err);
     }
   }
   if (ok && r.n_boxes >= p.I) {  // IndexError at D/space.py:385

@@ -130,8 +130,8 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
   if (cfg->env_kind != PCT_ENV_DISCRETE && cfg->env_kind != PCT_ENV_CONTINUOUS)
     return fail(PCT_ERR_INVALID_ARG, "unknown env_kind");
   const bool cont = cfg->env_kind == PCT_ENV_CONTINUOUS;
-  if (cfg->setting != 2 && !(cfg->setting == 1 && cfg->env_kind == PCT_ENV_DISCRETE))
-    return fail(PCT_ERR_UNSUPPORTED, "settings built: 2 (both envs) and 1 (discrete env)");
+  if (cfg->setting != 2 && cfg->setting != 1)
+    return fail(PCT_ERR_UNSUPPORTED, "settings built: 1 and 2 (setting 3 = random item densities is not)");
   if (cfg->lnes != PCT_LNES_EMS && cfg->lnes != PCT_LNES_CP && cfg->lnes != PCT_LNES_FC)
     return fail(PCT_ERR_UNSUPPORTED, "LNES built: EMS, CP, FC (EV / EP are not)");
   if (cfg->lnes != PCT_LNES_EMS && cfg->env_kind != PCT_ENV_DISCRETE)
@@ -201,6 +201,15 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
     CALLOC_(c.boxes, Nn * 6 * c.I * sizeof(double));
     CALLOC_(c.leaves, Nn * 6 * c.L * sizeof(double));
     CALLOC_(c.volsum, Nn * sizeof(double));
+    CALLOC_(c.bsz, Nn * 3 * c.I * sizeof(double));
+    if (cfg->setting != 2) {
+      CALLOC_(c.st_stack, Nn * c.I * 4 * sizeof(double));
+      CALLOC_(c.st_nsup, Nn * c.I * sizeof(int));
+      CALLOC_(c.st_sup, Nn * c.I * pct::STAB_SMAX * sizeof(int));
+      CALLOC_(c.st_share, Nn * c.I * pct::STAB_SMAX * 4 * sizeof(double));
+      CALLOC_(c.st_npoly, Nn * c.I * sizeof(int));
+      CALLOC_(c.st_poly, Nn * c.I * pct::STAB_PMAX * 2 * sizeof(double));
+    }
     if (c.table_global) {
       CALLOC_(c.gtab, Nn * (size_t)(cand_cap + cand_cap / 4) * sizeof(uint32_t));
       CALLOC_(c.gorder, Nn * (size_t)c.order_cap * sizeof(uint16_t));
@@ -431,6 +440,15 @@ int pct_step_hash_policy(pct_env* h, int32_t n_steps, void* stream) {
   int rc = ready(h, true);
   if (rc) return rc;
   if (n_steps < 1) return fail(PCT_ERR_INVALID_ARG, "n_steps must be >= 1");
+  if (h->cfg.setting != 2) {
+    /* the stability state is written by one lane and read by the others through HBM: one
+     * launch per step keeps those reads behind a kernel boundary */
+    for (int i = 0; i < n_steps; i++) {
+      rc = launch(h, ACT_HASH, nullptr, 0, 1, nullptr, 0, stream);
+      if (rc) return rc;
+    }
+    return PCT_OK;
+  }
   return launch(h, ACT_HASH, nullptr, 0, n_steps, nullptr, 0, stream);
 }
 

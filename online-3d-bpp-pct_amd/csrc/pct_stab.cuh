@@ -35,11 +35,13 @@
 
 namespace pct {
 
-constexpr int STAB_SMAX = 8;    // supporters per box kept (more -> PCT_FLAG_STABILITY_OVERFLOW)
+constexpr int STAB_SMAX = 16;   // supporters per box kept (more -> PCT_FLAG_STABILITY_OVERFLOW)
+constexpr int STAB_LSQ = 8;     // supporters the least-squares split handles
 constexpr int STAB_PMAX = 24;   // hull vertices kept
 constexpr int STAB_DEPTH = 24;  // explicit stack depth
 
-// per-env view of the stability state; geometry via `geo(i, g)` -> lx,ly,lz,xe,ye,ze (doubles)
+// per-env view of the stability state; geometry via `geo(i, g)` -> lx,ly,lz,xe,ye,ze,sx,sy,sz
+// (the sizes are carried explicitly: in float64 (lx + x) - lx need not equal x)
 struct StabState {
   int I;           // internal_node_holder (row stride)
   double* stack;   // [I][4]
@@ -51,7 +53,7 @@ struct StabState {
 };
 
 struct StabBox {  // a box being examined (candidate or placed), with its supporters
-  double g[6];    // lx,ly,lz,xe,ye,ze
+  double g[9];    // lx,ly,lz,xe,ye,ze,sx,sy,sz
   int nsup;
   int sup[STAB_SMAX];
   double area[STAB_SMAX][4];
@@ -149,7 +151,7 @@ PCT_SD bool stab_pip(const double* pt, const double (*co)[2], int n) {
 // minimum-norm least squares for the >= 3 supporter case (stands in for np.linalg.lstsq /
 // LAPACK gelsd: Jacobi eigen-decomposition of A^T A; same method as the oracle)
 PCT_SD void stab_lstsq(const double* A, const double* b, int M, int N, double* x) {
-  double G[STAB_SMAX * STAB_SMAX], V[STAB_SMAX * STAB_SMAX], g[STAB_SMAX];
+  double G[STAB_LSQ * STAB_LSQ], V[STAB_LSQ * STAB_LSQ], g[STAB_LSQ];
   for (int i = 0; i < N; i++) {
     g[i] = 0;
     for (int r = 0; r < M; r++) g[i] += A[r * N + i] * b[r];
@@ -203,59 +205,80 @@ PCT_SD void stab_lstsq(const double* A, const double* b, int M, int N, double* x
   }
 }
 
-// supporters of a box with footprint [lx,xe) x [ly,ye) resting at height lz among the first n
-// placed boxes (D/space.py:358-376): same top, non-degenerate overlap, box order.
-// Returns false if there are more than STAB_SMAX.
-template <typename Geo>
+PCT_SD double stab_around6(double x) { return rint(x * 1e6) / 1e6; }
+
+// contact rectangle of box `b` with placed box geometry `t`, or false if `t` does not support it.
+// Discrete (D/space.py:358-376): same top, non-degenerate overlap.  Continuous
+// (C/space.py:305-314,351-357): overlap decided on the np.around(.,6) of the negated-min
+// intersection, top within 1e-6, rectangle = the rounded intersection.
+template <bool CONT>
+PCT_SD bool stab_contact(const double* bg, const double* t, double area[4]) {
+  if (CONT) {
+    double i0 = stab_around6(fmin(-bg[0], -t[0])), i1 = stab_around6(fmin(-bg[1], -t[1]));
+    double i2 = stab_around6(fmin(bg[3], t[3])), i3 = stab_around6(fmin(bg[4], t[4]));
+    if (!((i0 + i2 > 0) && (i1 + i3 > 0))) return false;
+    if (!(fabs(t[5] - bg[2]) < 1e-6)) return false;
+    area[0] = -i0; area[1] = -i1; area[2] = i2; area[3] = i3;
+    return true;
+  }
+  if (t[5] != bg[2]) return false;
+  double x1 = fmax(bg[0], t[0]), y1 = fmax(bg[1], t[1]);
+  double x2 = fmin(bg[3], t[3]), y2 = fmin(bg[4], t[4]);
+  if (x1 >= x2 || y1 >= y2) return false;
+  area[0] = x1; area[1] = y1; area[2] = x2; area[3] = y2;
+  return true;
+}
+
+// supporters of `b` among the first n placed boxes, in box order.  False if > STAB_SMAX.
+template <bool CONT, typename Geo>
 PCT_SD bool stab_find_supporters(const Geo& geo, int n, StabBox& b) {
   b.nsup = 0;
   for (int i = 0; i < n; i++) {
-    double t[6];
+    double t[9], area[4];
     geo(i, t);
-    if (t[5] != b.g[2]) continue;
-    double x1 = fmax(b.g[0], t[0]), y1 = fmax(b.g[1], t[1]);
-    double x2 = fmin(b.g[3], t[3]), y2 = fmin(b.g[4], t[4]);
-    if (x1 >= x2 || y1 >= y2) continue;
+    if (!stab_contact<CONT>(b.g, t, area)) continue;
     if (b.nsup == STAB_SMAX) return false;
     int k = b.nsup++;
     b.sup[k] = i;
-    b.area[k][0] = x1; b.area[k][1] = y1; b.area[k][2] = x2; b.area[k][3] = y2;
-    b.c2[k][0] = (x1 + x2) / 2;
-    b.c2[k][1] = (y1 + y2) / 2;
+    b.area[k][0] = area[0]; b.area[k][1] = area[1]; b.area[k][2] = area[2]; b.area[k][3] = area[3];
+    b.c2[k][0] = (area[0] + area[2]) / 2;
+    b.c2[k][1] = (area[1] + area[3]) / 2;
   }
   return true;
 }
 // a placed box again as a StabBox, from its stored supporter ids
-template <typename Geo>
+template <bool CONT, typename Geo>
 PCT_SD void stab_load_box(const Geo& geo, const StabState& st, int id, StabBox& b) {
   geo(id, b.g);
   b.nsup = st.nsup[id];
   for (int k = 0; k < b.nsup; k++) {
     int s = st.sup[id * STAB_SMAX + k];
-    double t[6];
+    double t[9], area[4];
     geo(s, t);
+    stab_contact<CONT>(b.g, t, area);
     b.sup[k] = s;
-    double x1 = fmax(b.g[0], t[0]), y1 = fmax(b.g[1], t[1]);
-    double x2 = fmin(b.g[3], t[3]), y2 = fmin(b.g[4], t[4]);
-    b.area[k][0] = x1; b.area[k][1] = y1; b.area[k][2] = x2; b.area[k][3] = y2;
-    b.c2[k][0] = (x1 + x2) / 2;
-    b.c2[k][1] = (y1 + y2) / 2;
+    b.area[k][0] = area[0]; b.area[k][1] = area[1]; b.area[k][2] = area[2]; b.area[k][3] = area[3];
+    b.c2[k][0] = (area[0] + area[2]) / 2;
+    b.c2[k][1] = (area[1] + area[3]) / 2;
   }
 }
 
 // how `b` with stack (c, m) splits over its supporters (D/space.py:88-160 / :182-256).
 // `own_centre` is the box's own centre (the virtual flavour's zero-mass shares use it).
-PCT_SD void stab_shares(const StabBox& b, const double stk[4], const double own_centre[3], bool virtual_,
+template <bool CONT>
+PCT_SD bool stab_shares(const StabBox& b, const double stk[4], const double own_centre[3], bool virtual_,
                         double out[STAB_SMAX][4]) {
   const int k = b.nsup;
   if (k == 1) {
     out[0][0] = stk[0]; out[0][1] = stk[1]; out[0][2] = stk[2]; out[0][3] = stk[3];
-    return;
+    return true;
   }
   int direct = -1;
   for (int i = 0; i < k; i++) {
     const double* a = b.area[i];
-    if (stk[0] > a[0] && stk[0] < a[2] && stk[1] > a[1] && stk[1] < a[3]) { direct = i; break; }
+    bool inside = CONT ? (stk[0] - a[0] > 1e-6 && a[2] - stk[0] > 1e-6 && stk[1] - a[1] > 1e-6 && a[3] - stk[1] > 1e-6)
+                       : (stk[0] > a[0] && stk[0] < a[2] && stk[1] > a[1] && stk[1] < a[3]);
+    if (inside) { direct = i; break; }
   }
   if (direct >= 0) {
     for (int i = 0; i < k; i++) {
@@ -265,7 +288,7 @@ PCT_SD void stab_shares(const StabBox& b, const double stk[4], const double own_
         out[i][0] = cc[0]; out[i][1] = cc[1]; out[i][2] = cc[2]; out[i][3] = 0;
       }
     }
-    return;
+    return true;
   }
   if (k == 2) {
     const double* e0 = b.c2[0];
@@ -280,10 +303,11 @@ PCT_SD void stab_shares(const StabBox& b, const double stk[4], const double own_
     double r1 = fabs((stk[0] - e0[0]) * t0 + (stk[1] - e0[1]) * t1);
     out[0][0] = e0[0]; out[0][1] = e0[1]; out[0][2] = stk[2]; out[0][3] = stk[3] * r0;
     out[1][0] = e1[0]; out[1][1] = e1[1]; out[1][2] = stk[2]; out[1][3] = stk[3] * r1;
-    return;
+    return true;
   }
+  if (k > STAB_LSQ) return false;
   const int M = k * (k - 1) / 2 + 1;
-  double A[(STAB_SMAX * (STAB_SMAX - 1) / 2 + 1) * STAB_SMAX], rhs[STAB_SMAX * (STAB_SMAX - 1) / 2 + 1], xr[STAB_SMAX];
+  double A[(STAB_LSQ * (STAB_LSQ - 1) / 2 + 1) * STAB_LSQ], rhs[STAB_LSQ * (STAB_LSQ - 1) / 2 + 1], xr[STAB_LSQ];
   for (int i = 0; i < M * k; i++) A[i] = 0;
   for (int i = 0; i < M; i++) rhs[i] = 0;
   int row = 0;
@@ -306,6 +330,7 @@ PCT_SD void stab_shares(const StabBox& b, const double stk[4], const double own_
   for (int i = 0; i < k; i++) {
     out[i][0] = b.c2[i][0]; out[i][1] = b.c2[i][1]; out[i][2] = stk[2]; out[i][3] = stk[3] * xr[i];
   }
+  return true;
 }
 
 // calculate_new_com (D/space.py:51-71) of placed box S: own + the committed shares of the
@@ -314,9 +339,9 @@ PCT_SD void stab_shares(const StabBox& b, const double stk[4], const double own_
 template <typename Geo>
 PCT_SD void stab_com(const Geo& geo, const StabState& st, int n, int S, const int* path, int npath,
                      const double* extra, double density, double out[4]) {
-  double g[6];
+  double g[9];
   geo(S, g);
-  double sx = g[3] - g[0], sy = g[4] - g[1], sz = g[5] - g[2];
+  double sx = g[6], sy = g[7], sz = g[8];
   double mass = sx * sy * sz * density;
   double c0 = (g[0] + sx / 2) * mass, c1 = (g[1] + sy / 2) * mass, c2 = (g[2] + sz / 2) * mass, m = mass;
   for (int B = S + 1; B < n; B++) {
@@ -340,12 +365,12 @@ PCT_SD void stab_com(const Geo& geo, const StabState& st, int n, int S, const in
 
 // calculated_impact_virtual(first=True) for a candidate (D/space.py:166-267): is it stable?
 // err is set if a capacity (supporters, hull vertices, depth) was exceeded.
-template <typename Geo>
-PCT_SD bool stab_virtual(const Geo& geo, const StabState& st, int n, const double cand[6], double density, bool& err) {
+template <bool CONT, typename Geo>
+PCT_SD bool stab_virtual(const Geo& geo, const StabState& st, int n, const double cand[9], double density, bool& err) {
   err = false;
   StabBox b;
-  for (int i = 0; i < 6; i++) b.g[i] = cand[i];
-  if (!stab_find_supporters(geo, n, b)) { err = true; return false; }
+  for (int i = 0; i < 9; i++) b.g[i] = cand[i];
+  if (!stab_find_supporters<CONT>(geo, n, b)) { err = true; return false; }
   if (b.nsup == 0) return true;
   // explicit depth-first walk: frame = (box id or -1, its virtual stack, next supporter)
   int fid[STAB_DEPTH], fnext[STAB_DEPTH];
@@ -353,7 +378,7 @@ PCT_SD bool stab_virtual(const Geo& geo, const StabState& st, int n, const doubl
   int path[STAB_DEPTH];  // ids of the placed boxes on the active path (frames 1..depth-1)
   int depth = 0;
   {
-    double sx = cand[3] - cand[0], sy = cand[4] - cand[1], sz = cand[5] - cand[2];
+    double sx = cand[6], sy = cand[7], sz = cand[8];
     fid[0] = -1; fnext[0] = 0;
     fstk[0][0] = cand[0] + sx / 2; fstk[0][1] = cand[1] + sy / 2; fstk[0][2] = cand[2] + sz / 2;
     fstk[0][3] = sx * sy * sz * density * 1.0;
@@ -363,8 +388,8 @@ PCT_SD bool stab_virtual(const Geo& geo, const StabState& st, int n, const doubl
   double shares[STAB_SMAX][4];
   while (depth > 0) {
     const int d = depth - 1;
-    if (fid[d] >= 0) stab_load_box(geo, st, fid[d], b);
-    else { for (int i = 0; i < 6; i++) b.g[i] = cand[i]; stab_find_supporters(geo, n, b); }
+    if (fid[d] >= 0) stab_load_box<CONT>(geo, st, fid[d], b);
+    else { for (int i = 0; i < 9; i++) b.g[i] = cand[i]; stab_find_supporters<CONT>(geo, n, b); }
     if (fnext[d] == 0) {
       if (b.nsup == 0) { depth--; continue; }
       int np;
@@ -382,8 +407,8 @@ PCT_SD bool stab_virtual(const Geo& geo, const StabState& st, int n, const doubl
     }
     if (fnext[d] >= b.nsup) { depth--; continue; }
     const int i = fnext[d]++;
-    double own[3] = {b.g[0] + (b.g[3] - b.g[0]) / 2, b.g[1] + (b.g[4] - b.g[1]) / 2, b.g[2] + (b.g[5] - b.g[2]) / 2};
-    stab_shares(b, fstk[d], own, true, shares);
+    double own[3] = {b.g[0] + b.g[6] / 2, b.g[1] + b.g[7] / 2, b.g[2] + b.g[8] / 2};
+    if (!stab_shares<CONT>(b, fstk[d], own, true, shares)) { err = true; return false; }
     if (depth >= STAB_DEPTH) { err = true; return false; }
     const int S = b.sup[i];
     // path = placed boxes currently involved: frames 1..d (the candidate has no id)
@@ -400,14 +425,14 @@ PCT_SD bool stab_virtual(const Geo& geo, const StabState& st, int n, const doubl
 // calculated_impact() of the box just placed as id `n` (geometry already visible through
 // geo(n, .)): records its supporters / polygon / stack, propagates the shares downward and
 // re-checks every box on the way (D/space.py:73-164).  Returns the stability verdict.
-template <typename Geo>
+template <bool CONT, typename Geo>
 PCT_SD bool stab_commit(const Geo& geo, StabState& st, int n, double density, bool& err) {
   err = false;
   StabBox b;
   geo(n, b.g);
-  if (!stab_find_supporters(geo, n, b)) { err = true; return false; }
+  if (!stab_find_supporters<CONT>(geo, n, b)) { err = true; return false; }
   {
-    double sx = b.g[3] - b.g[0], sy = b.g[4] - b.g[1], sz = b.g[5] - b.g[2];
+    double sx = b.g[6], sy = b.g[7], sz = b.g[8];
     double* s = st.stack + (size_t)n * 4;
     s[0] = b.g[0] + sx / 2; s[1] = b.g[1] + sy / 2; s[2] = b.g[2] + sz / 2; s[3] = sx * sy * sz * density;
   }
@@ -424,7 +449,7 @@ PCT_SD bool stab_commit(const Geo& geo, StabState& st, int n, double density, bo
       st.poly[((size_t)n * STAB_PMAX + i) * 2 + 1] = poly[i][1];
     }
   }
-  if (b.g[2] == 0) return true;  // max_h == 0: check_box returns before calculated_impact (:448-449)
+  if (CONT ? (fabs(b.g[2]) < 1e-6) : (b.g[2] == 0)) return true;  // max_h == 0: check_box returns first (:448-449)
   int fid[STAB_DEPTH], fnext[STAB_DEPTH];
   int depth = 1;
   fid[0] = n; fnext[0] = 0;
@@ -433,7 +458,7 @@ PCT_SD bool stab_commit(const Geo& geo, StabState& st, int n, double density, bo
   while (depth > 0) {
     const int d = depth - 1;
     const int id = fid[d];
-    stab_load_box(geo, st, id, b);
+    stab_load_box<CONT>(geo, st, id, b);
     if (fnext[d] == 0) {
       if (b.nsup == 0) { depth--; continue; }
       const int np = st.npoly[id];
@@ -445,7 +470,7 @@ PCT_SD bool stab_commit(const Geo& geo, StabState& st, int n, double density, bo
       if (!stab_pip(stk, poly, np)) return false;
       // distribute to every supporter first (up_edges[self] = share; calculate_new_com())
       double own[3] = {stk[0], stk[1], stk[2]};
-      stab_shares(b, stk, own, false, shares);
+      if (!stab_shares<CONT>(b, stk, own, false, shares)) { err = true; return false; }
       for (int k = 0; k < b.nsup; k++) {
         double* e = st.share + ((size_t)id * STAB_SMAX + k) * 4;
         e[0] = shares[k][0]; e[1] = shares[k][1]; e[2] = shares[k][2]; e[3] = shares[k][3];

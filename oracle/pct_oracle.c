@@ -655,8 +655,7 @@ int pcto_create(const pct_config* cfg, pcto_env** out) {
   if (cfg->struct_size != (int32_t)sizeof(pct_config)) return fail(PCT_ERR_INVALID_ARG, "pct_config size mismatch");
   if (cfg->env_kind != PCT_ENV_DISCRETE && cfg->env_kind != PCT_ENV_CONTINUOUS)
     return fail(PCT_ERR_UNSUPPORTED, "oracle: unknown env kind");
-  if (cfg->setting != 2 && !(cfg->setting == 1 && cfg->env_kind == PCT_ENV_DISCRETE))
-    return fail(PCT_ERR_UNSUPPORTED, "oracle: settings restated: 2 (both envs), 1 (discrete env)");
+  if (cfg->setting != 2 && cfg->setting != 1) return fail(PCT_ERR_UNSUPPORTED, "oracle: settings restated: 1 and 2");
   if (cfg->lnes != PCT_LNES_EMS && cfg->lnes != PCT_LNES_CP && cfg->lnes != PCT_LNES_FC)
     return fail(PCT_ERR_UNSUPPORTED, "oracle: LNES restated: EMS, CP, FC");
   if (cfg->lnes != PCT_LNES_EMS && cfg->env_kind != PCT_ENV_DISCRETE)

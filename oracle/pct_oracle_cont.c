@@ -38,6 +38,7 @@ struct cenv {
   uint64_t cursor;
   uint32_t t;
   int traj;
+  struct stab* stab; /* settings 1 / 3 */
 };
 
 static double around6(double x) { return rint(x * 1e6) / 1e6; }
@@ -179,6 +180,7 @@ static void space_reset(const struct pcto_env* h, struct cenv* s) {
   s->noems = 1;
   s->n_boxes = 0;
   s->box_idx = 0;
+  if (s->stab) stab_reset(s->stab);
 }
 
 /* :305-314 interSect2D: max top of the placed boxes whose footprint overlaps `box`
@@ -210,6 +212,8 @@ static int drop_box_virtual(const struct pcto_env* h, const struct cenv* s, doub
   double box[5] = {-lx, -ly, lx + x, ly + y, 0};
   double max_h = intersect2d(h, s, box);
   if (max_h + z - 1e-6 > H) ok = 0;
+  /* :399-425: supporters / hull only if checkResult; check_box :428-439 */
+  if (ok && h->cfg.setting != 2) ok = stab_check(s->stab, x, y, z, lx, ly, max_h, s->next_den, 1);
   return ok;
 }
 
@@ -226,7 +230,11 @@ static int drop_box(const struct pcto_env* h, struct cenv* s, const double bs[3]
   double max_h = intersect2d(h, s, box);
   if (max_h + z - 1e-6 > H) return 0;
   box[4] = max_h + z;
-  if (s->box_idx >= h->I) { *flags |= PCT_FLAG_INTERNAL_OVERFLOW; return 0; } /* IndexError :371 */
+  if (s->box_idx >= h->I) { /* IndexError :371 (raised after a successful check_box) */
+    if (h->cfg.setting == 2 || stab_check(s->stab, x, y, z, lx, ly, max_h, s->next_den, 1)) *flags |= PCT_FLAG_INTERNAL_OVERFLOW;
+    return 0;
+  }
+  if (h->cfg.setting != 2 && !stab_check(s->stab, x, y, z, lx, ly, max_h, s->next_den, 0)) return 0; /* :366 check_box */
   s->vol[s->n_boxes++] = x * y * z;
   memcpy(s->upLetter + 5 * s->box_idx, box, sizeof box);
   double* r = s->box_vec + 9 * s->box_idx;
@@ -465,12 +473,14 @@ int pctc_alloc(struct pcto_env* h) {
     s->box_vec = (double*)calloc((size_t)h->I * 9, sizeof(double));
     s->vol = (double*)calloc((size_t)h->I + 1, sizeof(double));
     s->ems = (double*)calloc((size_t)EMS_ROWS * 6, sizeof(double));
+    if (h->cfg.setting != 2) s->stab = stab_create(h->I, 1e-6);
   }
   return 0;
 }
 void pctc_free(struct pcto_env* h) {
   for (int e = 0; e < h->N; e++) {
     free(h->cenvs[e].upLetter); free(h->cenvs[e].box_vec); free(h->cenvs[e].vol); free(h->cenvs[e].ems);
+    stab_free(h->cenvs[e].stab);
   }
   free(h->cenvs);
   h->cenvs = NULL;

@@ -268,7 +268,10 @@ static int impact(struct stab* s, sbox* b, int key, int virtual_) {
     int direct = -1;
     for (int i = 0; i < k; i++) {
       const double* a = b->bottom[i].area;
-      if (st->c[0] > a[0] + eps && st->c[0] < a[2] - eps && st->c[1] > a[1] + eps && st->c[1] < a[3] - eps) { direct = i; break; }
+      int inside = eps > 0 /* C/space.py:85-86,182-183 vs D/space.py:89-90,186-187 */
+                       ? (st->c[0] - a[0] > 1e-6 && a[2] - st->c[0] > 1e-6 && st->c[1] - a[1] > 1e-6 && a[3] - st->c[1] > 1e-6)
+                       : (st->c[0] > a[0] && st->c[0] < a[2] && st->c[1] > a[1] && st->c[1] < a[3]);
+      if (inside) { direct = i; break; }
     }
     if (direct >= 0) {
       for (int i = 0; i < k; i++) {
@@ -354,11 +357,22 @@ int stab_check(struct stab* s, double x, double y, double z, double lx, double l
   int np_ = 0;
   for (int i = 0; i < s->n; i++) {
     const sbox* t = &s->boxes[i];
-    int same_top = eps > 0 ? (fabs(t->lz + t->z - max_h) < eps) : (t->lz + t->z == max_h);
-    if (!same_top) continue;
-    double x1 = fmax(lx, t->lx), y1 = fmax(ly, t->ly);
-    double x2 = fmin(lx + x, t->lx + t->x), y2 = fmin(ly + y, t->ly + t->y);
-    if (x1 >= x2 || y1 >= y2) continue;
+    double x1, y1, x2, y2;
+    if (eps > 0) {
+      /* C/space.py:305-314 interSect2D picks the overlapping boxes on rounded values, then
+       * :353 keeps those whose top is max_h within 1e-6; the contact rectangle is the rounded
+       * intersection (:355-357) */
+      double i0 = rint(fmin(-lx, -t->lx) * 1e6) / 1e6, i1 = rint(fmin(-ly, -t->ly) * 1e6) / 1e6;
+      double i2 = rint(fmin(lx + x, t->lx + t->x) * 1e6) / 1e6, i3 = rint(fmin(ly + y, t->ly + t->y) * 1e6) / 1e6;
+      if (!((i0 + i2 > 0) && (i1 + i3 > 0))) continue;
+      if (!(fabs(t->lz + t->z - max_h) < 1e-6)) continue;
+      x1 = -i0; y1 = -i1; x2 = i2; y2 = i3;
+    } else {
+      if (!(t->lz + t->z == max_h)) continue;
+      x1 = fmax(lx, t->lx); y1 = fmax(ly, t->ly);
+      x2 = fmin(lx + x, t->lx + t->x); y2 = fmin(ly + y, t->ly + t->y);
+      if (x1 >= x2 || y1 >= y2) continue;
+    }
     sdown* d = &nb.bottom[nb.nbottom++];
     d->box = i;
     d->area[0] = x1; d->area[1] = y1; d->area[2] = x2; d->area[3] = y2;

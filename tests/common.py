@@ -58,7 +58,9 @@ GOLDEN_CASES = ["discrete_s2_10_80_50", "discrete_s2_rect_60_30", "discrete_s2_1
                 "discrete_s2_cp_10_80_50", "discrete_s2_cp_rect_60_16", "discrete_s1_10_80_50", "discrete_s1_rect_60_30",
                 "discrete_s2_fc_10_80_50", "discrete_s1_fc_rect_60_24"]
 
-CONT_CASES = ["continuous_s2_10_80_50", "continuous_s2_100_200_200", "continuous_s2_rect_60_20"]
+CONT_CASES = ["continuous_s2_10_80_50", "continuous_s2_100_200_200", "continuous_s2_rect_60_20",
+              "continuous_s1_10_80_50", "continuous_s1_unit_80_50"]
+CONT_STAB_CASES = ["continuous_s1_10_80_50", "continuous_s1_unit_80_50"]
 
 # CPU-only fixtures (stability, settings 1/3: restated in the oracle, not yet on the GPU)
 ORACLE_ONLY_CASES = []

@@ -105,12 +105,22 @@ CONT_CASES = {
                                       steps=260, stream_T=512, seed=22, base=9),
     "continuous_s2_rect_60_20": dict(setting=2, container=(8, 12, 9), lo=0.5, hi=4.0, I=60, L=20, N=3, steps=200,
                                      stream_T=256, seed=23, base=40),
+    # setting 1 in the continuous env: stability check with the 1e-6 margins (C/space.py)
+    "continuous_s1_10_80_50": dict(setting=1, container=(10, 10, 10), lo=1.0, hi=5.0, I=80, L=50, N=4, steps=250,
+                                   stream_T=256, seed=24, base=60),
+    # the reference's own sampling domain for settings != 2: unit bin, x,y ~ U(0.1,0.5) rounded to
+    # 3 decimals, z from {0.1,...,0.5} (C/bin3D.py:110-112, givenData.py:5)
+    "continuous_s1_unit_80_50": dict(setting=1, container=(1, 1, 1), lo=0.1, hi=0.5, I=80, L=50, N=3, steps=250,
+                                     stream_T=256, seed=25, base=70, z_choice=True),
 }
 
 
-def make_cont_stream(seed, n_envs, T, lo, hi):
+def make_cont_stream(seed, n_envs, T, lo, hi, z_choice=False):
     rng = np.random.RandomState(seed)
-    return rng.randint(int(round(lo * 1000)), int(round(hi * 1000)) + 1, size=(n_envs, T, 3)).astype(np.int32)
+    st = rng.randint(int(round(lo * 1000)), int(round(hi * 1000)) + 1, size=(n_envs, T, 3)).astype(np.int32)
+    if z_choice:
+        st[:, :, 2] = rng.choice([100, 200, 300, 400, 500], size=(n_envs, T))
+    return st
 
 
 def scripted_cont_creator(stream_row):
@@ -136,7 +146,7 @@ def run_reference_cont(case):
     """Reference PackingContinuous driven with float64 leaf rows (the observation's own rows)."""
     PD, PC, _ = ref_shim.load_reference_envs()
     c = case
-    stream = make_cont_stream(c["seed"], c["N"], c["stream_T"], c["lo"], c["hi"])
+    stream = make_cont_stream(c["seed"], c["N"], c["stream_T"], c["lo"], c["hi"], c.get("z_choice", False))
     N, I, L = c["N"], c["I"], c["L"]
     row_len = (I + L + 1) * 9
     obs_rec = np.zeros((c["steps"] + 1, N, row_len), np.float64)

@@ -5,6 +5,7 @@
 // source.  tests/test_stab_host.py runs the setting-1 reference fixtures through it: the
 // restructuring (no recursion, no dictionaries, lazy virtual stacks) is thereby checked on the
 // CPU against the reference before it is trusted on the GPU.  Nothing in the product uses this.
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -15,7 +16,8 @@
 struct stab {
   int cap;
   int n;
-  std::vector<double> geo;  // [cap][6] lx,ly,lz,xe,ye,ze
+  std::vector<double> geo;  // [cap][9] lx,ly,lz,xe,ye,ze,sx,sy,sz
+  bool cont;
   std::vector<double> stack, share, poly;
   std::vector<int> nsup, sup, npoly;
   int overflow;
@@ -23,7 +25,7 @@ struct stab {
 
 struct GeoFn {
   const double* g;
-  void operator()(int i, double out[6]) const { memcpy(out, g + 6 * (size_t)i, 6 * sizeof(double)); }
+  void operator()(int i, double out[9]) const { memcpy(out, g + 9 * (size_t)i, 9 * sizeof(double)); }
 };
 
 static pct::StabState view(stab* s) {
@@ -40,12 +42,12 @@ static pct::StabState view(stab* s) {
 
 extern "C" {
 struct stab* stab_create(int cap, double eps) {
-  (void)eps;
   stab* s = new stab();
+  s->cont = eps > 0;
   s->cap = cap + 2;
   s->n = 0;
   s->overflow = 0;
-  s->geo.assign((size_t)s->cap * 6, 0.0);
+  s->geo.assign((size_t)s->cap * 9, 0.0);
   s->stack.assign((size_t)s->cap * 4, 0.0);
   s->share.assign((size_t)s->cap * pct::STAB_SMAX * 4, 0.0);
   s->poly.assign((size_t)s->cap * pct::STAB_PMAX * 2, 0.0);
@@ -63,15 +65,16 @@ int stab_check(struct stab* s, double x, double y, double z, double lx, double l
   GeoFn geo{s->geo.data()};
   pct::StabState st = view(s);
   bool err = false;
-  double cand[6] = {lx, ly, max_h, lx + x, ly + y, max_h + z};
+  double cand[9] = {lx, ly, max_h, lx + x, ly + y, max_h + z, x, y, z};
   if (virtual_) {
-    if (max_h == 0) return 1;  // D/space.py:448-449
-    bool ok = pct::stab_virtual(geo, st, s->n, cand, density, err);
+    if (s->cont ? (fabs(max_h) < 1e-6) : (max_h == 0)) return 1;  // space.py:448-449
+    bool ok = s->cont ? pct::stab_virtual<true>(geo, st, s->n, cand, density, err)
+                      : pct::stab_virtual<false>(geo, st, s->n, cand, density, err);
     if (err) s->overflow = 1;
     return ok ? 1 : 0;
   }
-  memcpy(s->geo.data() + 6 * (size_t)s->n, cand, sizeof cand);
-  bool ok = pct::stab_commit(geo, st, s->n, density, err);
+  memcpy(s->geo.data() + 9 * (size_t)s->n, cand, sizeof cand);
+  bool ok = s->cont ? pct::stab_commit<true>(geo, st, s->n, density, err) : pct::stab_commit<false>(geo, st, s->n, density, err);
   if (err) s->overflow = 1;
   if (ok) s->n++;
   return ok ? 1 : 0;

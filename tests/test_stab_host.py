@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import oracle.oracle_lib as ol
-from tests.common import GOLDEN, STAB_CASES, item_set_range, load_case, make_stream
+from tests.common import CONT_STAB_CASES, GOLDEN, STAB_CASES, item_set_range, load_case, make_stream
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 VARIANT = os.path.join(HERE, "host", "libpct_oracle_prodstab.so")
@@ -80,3 +80,21 @@ def test_product_stability_equals_oracle_on_random_streams():
             b.step_hash_policy(1)
             assert np.array_equal(b.done, ref_done[t]), t
         b.close()
+
+
+@pytest.mark.parametrize("name", CONT_STAB_CASES)
+def test_product_stability_continuous_matches_reference_fixture(name):
+    """Continuous env, setting 1: the product's stability code (1e-6 margins, rounded contact
+    rectangles) inside the continuous oracle, against the float64 reference fixture."""
+    c, z = load_case(name)
+    with _Variant():
+        env = ol.OracleVecEnv(c["N"], setting=1, container_size=c["container"], env_kind=1,
+                              sample_bounds=(c["lo"], c["hi"]), internal_node_holder=c["I"], leaf_node_holder=c["L"],
+                              env_id_base=c["base"])
+        env.set_item_stream(z["stream"])
+        env.reset()
+        for t in range(c["steps"]):
+            assert np.array_equal(env.obs, z["obs"][t]), (name, t)
+            env.step_hash_policy(1)
+            assert np.array_equal(env.done, z["done"][t]) and np.array_equal(env.reward, z["reward"][t])
+        env.close()
