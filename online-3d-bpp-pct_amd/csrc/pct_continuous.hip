@@ -321,7 +321,7 @@ __device__ inline void cgenems(const ContinuousParams& p, CLds& l, CRegs& r, int
 
 // C/space.py:531-568 EMSPoint (CPython set order over float tuples) + C/bin3D.py:118-148
 template <bool GT, bool STAB, typename TM>
-__device__ inline void cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CRegs& r, int lane, TM& tm) {
+__device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CRegs& r, int lane, TM& tm) {
   const uint64_t lt = lanemask_lt(lane);
   const int E = r.n_ems, cap = p.ems_cap;
   const int orient = (p.setting == 2) ? 6 : 2;
@@ -329,8 +329,9 @@ __device__ inline void cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
   const uint32_t EMPTY = SlotWord<uint32_t>::EMPTY;
   uint32_t size = 8, fill = 0;
   // table and list(set) order: LDS, or this env's HBM slice when the capacity does not fit
-  uint32_t* const tabs = GT ? p.gtab + (size_t)e * (size_t)(p.cand_cap + p.cand_cap / 4) : l.tab;
-  uint16_t* const order = GT ? p.gorder + (size_t)e * (size_t)p.order_cap : l.order;
+  const size_t gslot = p.gt_by_block ? (size_t)blockIdx.x : (size_t)e;
+  uint32_t* const tabs = GT ? p.gtab + gslot * (size_t)(p.cand_cap + p.cand_cap / 4) : l.tab;
+  uint16_t* const order = GT ? p.gorder + gslot * (size_t)p.order_cap : l.order;
   uint32_t toff = table_region(p.cand_cap, size);
   if (lane < 8) tab_st<GT, uint32_t>(&tabs[toff + lane], EMPTY);
   __syncthreads();
@@ -448,7 +449,12 @@ __device__ inline void cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
     __syncthreads();
   }
   while (npend > 0 && !cand_overflow) flush(npend < 64 ? npend : 64);
-  if (cand_overflow) r.flags |= PCT_FLAG_CANDIDATE_OVERFLOW;
+  if (cand_overflow) {
+    // the table outgrew this launch's capacity: hand the env to the large-capacity pass
+    // (state untouched) if there is one, else record the overflow
+    if (p.retry_ids != nullptr && !p.retry_mode) return true;
+    r.flags |= PCT_FLAG_CANDIDATE_OVERFLOW;
+  }
   __syncthreads();
 
   // list(set): generator ids in slot order
@@ -506,6 +512,7 @@ __device__ inline void cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
   r.n_leaf = nleaf < p.L ? nleaf : p.L;
   __syncthreads();
   tm.tick(PH_FEAS);
+  return false;
 }
 
 // C/bin3D.py:78-100 observation rows, float32 (envs.py:180)
@@ -718,12 +725,13 @@ __global__ void __launch_bounds__(64) pct_continuous_kernel(ContinuousParams p, 
                                                             const int32_t* __restrict__ env_ids, int n_ids) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x;
-  int e = blockIdx.x;
-  if (ACT == CACT_RESET && env_ids) {
-    if (e >= n_ids) return;
-    e = env_ids[e];
-    if (e < 0 || e >= p.N) return;
-  }
+  // work items: every env (normal pass), the listed envs (reset_specific), or -- in the
+  // large-capacity retry pass -- the envs the normal pass queued, grid-strided
+  const bool listed = (ACT == CACT_RESET && env_ids != nullptr);
+  const int limit = p.retry_mode ? *p.retry_count : (listed ? n_ids : p.N);
+  for (int work = blockIdx.x; work < limit; work += gridDim.x) {
+  const int e = p.retry_mode ? p.retry_ids[work] : (listed ? env_ids[work] : work);
+  if (e < 0 || e >= p.N) continue;
   CLds l = carve(p, smem);
   CRegs r;
   PhaseTimer<TIMED> tm;
@@ -731,17 +739,18 @@ __global__ void __launch_bounds__(64) pct_continuous_kernel(ContinuousParams p, 
   cload(p, e, l, r, lane);
   tm.tick(PH_LOAD);
   float* obs = p.obs + (size_t)e * p.row_len;
+  bool requeue = false;
 
   if (ACT == CACT_RESET) {
     cspace_reset(p, l, r, lane);
     __syncthreads();
     cdraw_item(p, e, r);
-    cleaf_nodes<GT, STAB>(p, e, l, r, lane, tm);
-    cwrite_obs(p, l, r, lane, obs);
-    cstore(p, e, l, r, lane);
-    return;
-  }
-
+    requeue = cleaf_nodes<GT, STAB>(p, e, l, r, lane, tm);
+    if (!requeue) {
+      cwrite_obs(p, l, r, lane, obs);
+      cstore(p, e, l, r, lane);
+    }
+  } else {
   for (int it = 0; it < n_steps; it++) {
     int flag = 0;
     double p1 = 0, p2 = 0, bx = 0, by = 0, bz = 0;
@@ -789,14 +798,21 @@ __global__ void __launch_bounds__(64) pct_continuous_kernel(ContinuousParams p, 
       cdecode_leaf(r, zero_row, a0, a1, a3, a4, p1, p2, bx, by, bz);
     }
     ctransition<STAB>(p, e, l, r, lane, flag, p1, p2, bx, by, bz, tm);
-    cleaf_nodes<GT, STAB>(p, e, l, r, lane, tm);
+    requeue = cleaf_nodes<GT, STAB>(p, e, l, r, lane, tm);
+    if (requeue) break;
     cwrite_obs(p, l, r, lane, obs);
     __syncthreads();
     tm.tick(PH_OBS);
   }
-  cstore(p, e, l, r, lane);
-  tm.tick(PH_STORE);
-  if (TIMED && lane == 0) tm.flush(p.timing + (size_t)e * 8, n_steps);
+  if (!requeue) {
+    cstore(p, e, l, r, lane);
+    tm.tick(PH_STORE);
+    if (TIMED && lane == 0) tm.flush(p.timing + (size_t)e * 8, n_steps);
+  }
+  }  // step / reset
+  if (requeue && lane == 0) p.retry_ids[atomicAdd(p.retry_count, 1)] = e;
+  __syncthreads();
+  }  // work items
 }
 
 // stand-in policy kernel on the float32 observation (same as the discrete one)
@@ -825,7 +841,7 @@ hipError_t launch_continuous(const ContinuousParams& p, int act, const void* act
   size_t lds = continuous_lds_bytes(p);
   const bool timed = p.timing != nullptr && act != CACT_RESET;
   const bool stab = p.setting != 2;
-  int grid = (act == CACT_RESET && env_ids) ? n_ids : p.N;
+  int grid = p.retry_mode ? n_ids : ((act == CACT_RESET && env_ids) ? n_ids : p.N);
   if (grid <= 0) return hipSuccess;
 #define PCT_CLAUNCH(A)                                                                                         \
   do {                                                                                                         \

@@ -80,6 +80,10 @@ struct ContinuousParams {
   int table_global; /* 1: hash table + order list live in HBM (capacity beyond LDS) */
   uint32_t* gtab;   /* [N, cand_cap*5/4] */
   uint16_t* gorder; /* [N, order_cap] */
+  int gt_by_block;  /* HBM table slices indexed by blockIdx (retry pass) instead of env */
+  int retry_mode;   /* this launch is the large-capacity retry pass */
+  int* retry_count; /* [1] envs queued by the normal pass (zeroed before it) */
+  int* retry_ids;   /* [N] */
   int32_t* scalars; /* [N,PCT_SCALARS] */
   uint32_t* flags;
   unsigned long long* timing;

@@ -37,6 +37,9 @@ struct pct_env {
   int device;
   pct::DiscreteParams dp;
   pct::ContinuousParams cp;
+  pct::ContinuousParams cp_retry; /* large-capacity HBM-table pass for envs whose candidate set outgrew LDS */
+  bool has_retry;
+  int cp_retry_blocks;
   bool continuous;
   // owned device memory
   std::vector<void*> owned;
@@ -106,8 +109,22 @@ int launch(pct_env* h, int act, const void* actions, int row_len, int n_steps, c
     int rc = prof_begin(h, s, &slot);
     if (rc) return rc;
   }
-  if (h->continuous) HIP_TRY(pct::launch_continuous(h->cp, act, actions, row_len, n_steps, ids, n_ids, s));
-  else HIP_TRY(pct::launch_discrete(h->dp, act, actions, row_len, n_steps, ids, n_ids, s));
+  if (h->continuous) {
+    if (h->has_retry) HIP_TRY(hipMemsetAsync(h->cp.retry_count, 0, sizeof(int), s));
+    HIP_TRY(pct::launch_continuous(h->cp, act, actions, row_len, n_steps, ids, n_ids, s));
+    if (h->has_retry) {
+      /* keep the retry pass in step with everything that may have changed on the handle */
+      pct::ContinuousParams& q = h->cp_retry;
+      const pct::ContinuousParams& c = h->cp;
+      q.source = c.source; q.stream = c.stream; q.T = c.T; q.seed = c.seed; q.ds_len = c.ds_len;
+      q.ds_ntraj = c.ds_ntraj; q.ds_maxlen = c.ds_maxlen; q.sample_left = c.sample_left; q.sample_right = c.sample_right;
+      q.low_bound = c.low_bound; q.obs = c.obs; q.reward = c.reward; q.done = c.done; q.counter = c.counter;
+      q.ratio = c.ratio; q.flags = c.flags; q.timing = nullptr;
+      HIP_TRY(pct::launch_continuous(q, act, actions, row_len, n_steps, ids, h->cp_retry_blocks, s));
+    }
+  } else {
+    HIP_TRY(pct::launch_discrete(h->dp, act, actions, row_len, n_steps, ids, n_ids, s));
+  }
   if (h->profiling) HIP_TRY(hipEventRecord(h->ev_pool[slot].second, s));
   return PCT_OK;
 }
@@ -221,6 +238,26 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
     CALLOC_(h->own_done, Nn);
     CALLOC_(h->own_counter, Nn * sizeof(int32_t));
     CALLOC_(h->own_ratio, Nn * sizeof(double));
+    h->has_retry = false;
+    if (!c.table_global) {
+      /* normal pass: table in LDS; envs that need more are re-run by a small grid-strided pass
+       * with 32768-slot tables in HBM (covers ems_capacity * 24 candidates up to 19660) */
+      const int RB = 128, big = 32768;
+      CALLOC_(c.retry_count, sizeof(int));
+      CALLOC_(c.retry_ids, Nn * sizeof(int));
+      h->has_retry = true;
+      h->cp_retry_blocks = RB;
+      h->cp_retry = c;
+      pct::ContinuousParams& q = h->cp_retry;
+      q.retry_mode = 1;
+      q.table_global = 1;
+      q.gt_by_block = 1;
+      q.cand_cap = big;
+      q.order_cap = (big * 3) / 5 + 8;
+      q.union_doubles = 6 * ems_cap;
+      CALLOC_(q.gtab, (size_t)RB * (size_t)(big + big / 4) * sizeof(uint32_t));
+      CALLOC_(q.gorder, (size_t)RB * (size_t)q.order_cap * sizeof(uint16_t));
+    }
 #undef CALLOC_
     c.obs = h->own_obs; c.reward = h->own_reward; c.done = h->own_done; c.counter = h->own_counter;
     c.ratio = h->own_ratio; c.flags = h->own_flags;

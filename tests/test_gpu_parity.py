@@ -393,3 +393,19 @@ def test_hip_dataset_semantics_match_reference(name, tmp_path):
         assert np.array_equal(reward[:, 0].numpy(), z["reward"][t].astype(np.float32))
     assert not env.error_flags.any()
     env.close()
+
+
+def test_hip_continuous_candidate_overflow_is_rerun_with_hbm_tables():
+    """A 512-slot LDS table is far too small for the 10^3 continuous env: every env that
+    outgrows it is transparently re-run by the large-capacity pass (32768-slot tables in HBM),
+    so the results still equal the reference fixture and no overflow flag is raised."""
+    c, z = load_case("continuous_s2_10_80_50")
+    env = _make_cont(c, z["stream"], candidate_capacity=512)
+    obs = env.reset()
+    for t in range(120):
+        assert np.array_equal(obs.cpu().numpy(), z["obs"][t].astype(np.float32)), t
+        env.step_hash_policy(1)
+        obs, reward, done, infos = env.step_wait()
+        assert np.array_equal(done.astype(np.uint8), z["done"][t])
+    assert not env.error_flags.any()
+    env.close()
