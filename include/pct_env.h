@@ -102,7 +102,9 @@ typedef struct pct_config {
   int32_t ems_capacity;         /* 0 = default (256) */
   int32_t candidate_capacity;   /* hash-table slots for the leaf-candidate set;
                                    0 = default (2048); power of two */
-  int32_t reserved[4];
+  int32_t shuffle;              /* 1: permute the candidate list before the first-L cut
+                                   (bin3D.py:114-115 `--shuffle`); see pct_shuffle_priority */
+  int32_t reserved[3];
 } pct_config;
 
 typedef struct pct_env pct_env;
@@ -141,6 +143,9 @@ int pct_set_item_dataset(pct_env* env, const int32_t* items, const int32_t* leng
 /* Counter-based sampler: the c-th draw of global env g is
  * item_set[pct_mix64(seed, g, c) % n] (discrete) -- see pct_mix64 below. */
 int pct_set_sampler(pct_env* env, uint64_t seed);
+
+/* Seed of the shuffle permutation (default 0). */
+int pct_set_shuffle_seed(pct_env* env, uint64_t seed);
 
 /* ---- outputs ------------------------------------------------------------------------ */
 /* Bind caller-owned device buffers (e.g. torch tensors).  Any pointer may be NULL to keep
@@ -213,6 +218,15 @@ PCT_INLINE uint64_t pct_mix64(uint64_t seed, uint64_t env_global_id, uint64_t co
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
+}
+/* shuffle=True.  The reference permutes the candidate list with the process-global NumPy
+ * MT19937 (np.random.shuffle), which is shared with item sampling and cannot be reproduced
+ * per env.  Here candidate i of the list (set iteration order) gets this priority and the list
+ * is visited in ascending (priority, i) order: a uniform random permutation keyed by (seed,
+ * global env id, observation counter).  The oracle implements the same rule, so the HIP path is
+ * still checked bit for bit; against the reference the comparison is distributional. */
+PCT_INLINE uint32_t pct_shuffle_priority(uint64_t seed, uint64_t env_global_id, uint64_t obs_counter, uint32_t i) {
+  return (uint32_t)(pct_mix64(seed ^ 0x5BD1E9955BD1E995ull, env_global_id, (obs_counter << 20) | (uint64_t)i) >> 32);
 }
 PCT_INLINE uint32_t pct_mix32(uint32_t env_global_id, uint32_t t) {
   uint32_t h = env_global_id * 0x9E3779B1u + t * 0x85EBCA77u + 0xC2B2AE3Du;

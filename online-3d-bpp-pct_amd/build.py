@@ -10,8 +10,9 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpct_hip.so")
-SOURCES = ["pct_env.hip", "pct_discrete.hip", "pct_continuous.hip"]
+SOURCES = ["pct_env.hip", "pct_discrete.hip", "pct_discrete_u64.hip", "pct_continuous.hip"]
 HEADERS = [os.path.join(CSRC, "pct_device.h"), os.path.join(CSRC, "pct_set.cuh"), os.path.join(CSRC, "pct_stab.cuh"),
+           os.path.join(CSRC, "pct_discrete_impl.cuh"),
            os.path.join(HERE, "..", "include", "pct_env.h")]
 
 
@@ -33,13 +34,28 @@ def needs_build():
 def build_library(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           # the continuous env mirrors the reference's float64 operation order: no FMA contraction
-           "-ffp-contract=off",
-           *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
+    # one hipcc per translation unit, in parallel, then a link step
+    from concurrent.futures import ThreadPoolExecutor
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+             # the continuous env mirrors the reference's float64 operation order: no FMA contraction
+             "-ffp-contract=off"]
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        cmd = [_hipcc(), *flags, "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        print(" ".join(link))
+    subprocess.check_call(link)
     return LIB
 
 

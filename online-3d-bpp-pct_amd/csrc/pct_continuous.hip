@@ -71,6 +71,7 @@ struct CRegs {  // wave-uniform per-env scalars
   double volsum;
   uint32_t flags;
   int traj;
+  uint32_t oc;  // observations produced so far (shuffle key)
 };
 
 struct CLds {
@@ -86,6 +87,7 @@ struct CLds {
   uint32_t* bg;     // [64]
   uint16_t* order;  // [order_cap] table iteration order (generator ids)
   uint16_t* vp;     // [64]
+  uint32_t* fpri;   // [order_cap] shuffle priorities of the feasible candidates (shuffle only)
 };
 
 __device__ inline CLds carve(const ContinuousParams& p, unsigned char* base) {
@@ -105,14 +107,16 @@ __device__ inline CLds carve(const ContinuousParams& p, unsigned char* base) {
   l.bg = reinterpret_cast<uint32_t*>(q); q += 64;
   uint16_t* h = reinterpret_cast<uint16_t*>(q);
   l.order = h; h += p.table_global ? 0 : p.order_cap;
-  l.vp = h;
+  l.vp = h; h += 64;
+  l.fpri = reinterpret_cast<uint32_t*>(h + ((p.table_global ? 0 : p.order_cap) & 1));
   return l;
 }
 
 size_t continuous_lds_bytes(const ContinuousParams& p) {
   size_t dbl = (size_t)6 * p.ems_cap + p.union_doubles + 9 * (size_t)p.I + 6 * (size_t)p.L + 64;
   size_t i32 = 4 * (size_t)p.I + 128 + 64;
-  size_t u16 = (size_t)(p.table_global ? 0 : p.order_cap) + 64;
+  size_t u16 = (size_t)(p.table_global ? 0 : p.order_cap) + 64 + 2;
+  if (p.shuffle && !p.table_global) u16 += 2 * (size_t)p.order_cap;
   return dbl * 8 + i32 * 4 + u16 * 2 + 16;
 }
 
@@ -469,27 +473,23 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
   __syncthreads();
   tm.tick(PH_SET);
 
-  // feasibility in list order (C/space.py:380-425 drop_box_virtual, setting 2), first L kept
+  // feasibility in list order (C/space.py:380-425 drop_box_virtual), first L kept
   int nleaf = 0;
   bool stab_err = false;
   const int nb = r.n_boxes;
-  for (int base = 0; base < norder && nleaf < p.L; base += 64) {
-    int i = base + lane;
-    bool live = i < norder;
-    double t[6];
-    cand_tuple(p, l, r, orient, live ? (uint32_t)tab_ld<GT, uint16_t>(&order[i]) : 0u, t);
+  auto feasible = [&](const double t[6]) -> bool {
     double lx = t[0], ly = t[1];
     double x = t[3] - t[0], y = t[4] - t[1], z = t[5] - t[2];
-    bool ok = live;
+    bool ok = true;
     if (lx + x - 1e-6 > p.W || ly + y - 1e-6 > p.Ly) ok = false;
     if (lx + 1e-6 < 0 || ly + 1e-6 < 0) ok = false;
     // interSect2D (:305-314) on lattice indices; tops stay float64
     int c0 = klat(-lx), c1 = klat(-ly), c2 = klat(lx + x), c3 = klat(ly + y);
     double max_h = 0.0;
-    for (int b = 0; b < nb; b++) {
-      int u0 = l.bk[0 * p.I + b], u1 = l.bk[1 * p.I + b], u2 = l.bk[2 * p.I + b], u3 = l.bk[3 * p.I + b];
+    for (int b2 = 0; b2 < nb; b2++) {
+      int u0 = l.bk[0 * p.I + b2], u1 = l.bk[1 * p.I + b2], u2 = l.bk[2 * p.I + b2], u3 = l.bk[3 * p.I + b2];
       bool ov = (min(c0, u0) + min(c2, u2) > 0) && (min(c1, u1) + min(c3, u3) > 0);
-      double top = l.box[5 * p.I + b];
+      double top = l.box[5 * p.I + b2];
       max_h = (ov && top > max_h) ? top : max_h;
     }
     if (max_h + z - 1e-6 > p.H) ok = false;
@@ -500,14 +500,64 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
       ok = stab_virtual<true>(geo, cstab_view(p, e), nb, cand, 1.0, err);
       if (err) stab_err = true;
     }
-    uint64_t m = __ballot(ok);
-    int idx = nleaf + __popcll(m & lt);
-    if (ok && idx < p.L) {
-#pragma unroll
-      for (int c = 0; c < 6; c++) l.leaf[c * p.L + idx] = t[c];
+    return ok;
+  };
+  if (p.shuffle) {
+    // C/bin3D.py:126-127 np.random.shuffle -> pct_shuffle_priority: every candidate is tested,
+    // the feasible ones are ranked by (priority, list index), the first L ranks are kept
+    uint32_t* const fpri = GT ? p.gfpri + gslot * (size_t)p.order_cap : l.fpri;
+    int nf = 0;
+    for (int base = 0; base < norder; base += 64) {
+      int i = base + lane;
+      bool live = i < norder;
+      uint32_t g = live ? (uint32_t)tab_ld<GT, uint16_t>(&order[i]) : 0u;
+      double t[6];
+      cand_tuple(p, l, r, orient, g, t);
+      bool ok = live && feasible(t);
+      uint64_t m = __ballot(ok);
+      int o = nf + __popcll(m & lt);
+      __syncthreads();
+      if (ok) {
+        tab_st<GT, uint16_t>(&order[o], (uint16_t)g);  // in-place compaction (o <= i)
+        tab_st<GT, uint32_t>(&fpri[o], pct_shuffle_priority(p.shuffle_seed, (uint64_t)(p.env_id_base + e), (uint64_t)r.oc, (uint32_t)i));
+      }
+      nf += __popcll(m);
+      __syncthreads();
     }
-    nleaf += __popcll(m);
+    for (int base = 0; base < nf; base += 64) {
+      int a2 = base + lane;
+      bool live = a2 < nf;
+      uint32_t pa = live ? tab_ld<GT, uint32_t>(&fpri[a2]) : 0u;
+      int rank = 0;
+      for (int j = 0; j < nf; j++) {
+        uint32_t pj = tab_ld<GT, uint32_t>(&fpri[j]);
+        rank += (pj < pa || (pj == pa && j < a2)) ? 1 : 0;
+      }
+      if (live && rank < p.L) {
+        double t[6];
+        cand_tuple(p, l, r, orient, (uint32_t)tab_ld<GT, uint16_t>(&order[a2]), t);
+#pragma unroll
+        for (int c2 = 0; c2 < 6; c2++) l.leaf[c2 * p.L + rank] = t[c2];
+      }
+    }
+    nleaf = nf;
+  } else {
+    for (int base = 0; base < norder && nleaf < p.L; base += 64) {
+      int i = base + lane;
+      bool live = i < norder;
+      double t[6];
+      cand_tuple(p, l, r, orient, live ? (uint32_t)tab_ld<GT, uint16_t>(&order[i]) : 0u, t);
+      bool ok = live && feasible(t);
+      uint64_t m = __ballot(ok);
+      int idx = nleaf + __popcll(m & lt);
+      if (ok && idx < p.L) {
+#pragma unroll
+        for (int c2 = 0; c2 < 6; c2++) l.leaf[c2 * p.L + idx] = t[c2];
+      }
+      nleaf += __popcll(m);
+    }
   }
+  r.oc++;
   if (STAB && __ballot(stab_err)) r.flags |= PCT_FLAG_STABILITY_OVERFLOW;
   r.n_leaf = nleaf < p.L ? nleaf : p.L;
   __syncthreads();
@@ -552,6 +602,7 @@ __device__ inline void cload(const ContinuousParams& p, int e, CLds& l, CRegs& r
   r.flags = p.flags[e];
   r.volsum = p.volsum[e];
   r.traj = sc[12];
+  r.oc = (uint32_t)sc[13];
   const double* ge = p.ems + (size_t)e * 6 * p.ems_cap;
   const double* gb = p.boxes + (size_t)e * 6 * p.I;
   const double* gl = p.leaves + (size_t)e * 6 * p.L;
@@ -592,6 +643,7 @@ __device__ inline void cstore(const ContinuousParams& p, int e, const CLds& l, c
     sc[6] = (int32_t)r.t;
     sc[8] = (int32_t)(uint32_t)r.cursor; sc[9] = (int32_t)(uint32_t)(r.cursor >> 32);
     sc[12] = r.traj;
+    sc[13] = (int32_t)r.oc;
     p.flags[e] = r.flags;
     p.volsum[e] = r.volsum;
   }
@@ -678,6 +730,7 @@ __device__ inline void ctransition(const ContinuousParams& p, int e, CLds& l, CR
     done = 1;
     counter = r.n_boxes;
     ratio = r.volsum / mx;
+    r.oc++;  // the terminal step's own (discarded) observation (C/bin3D.py:183)
     __syncthreads();
     cspace_reset(p, l, r, lane);
     __syncthreads();

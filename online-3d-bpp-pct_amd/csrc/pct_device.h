@@ -18,7 +18,9 @@ struct DiscreteParams {
   int N, W, Ly, H, A, AA; /* AA = A*A rounded up to a multiple of 8 */
   int I, L, row_len;
   int setting, low_bound;
-  int lnes; /* PCT_LNES_EMS / PCT_LNES_CP */
+  int lnes; /* PCT_LNES_EMS / PCT_LNES_CP / PCT_LNES_FC */
+  int shuffle;
+  unsigned long long shuffle_seed;
   int ems_cap, cand_cap;
   int key_bytes; /* 4: six 5-bit coords (bins <= 31); 8: six 10-bit coords (<= 1023) */
   // item source
@@ -58,6 +60,8 @@ struct ContinuousParams {
   int N, I, L, row_len, setting;
   double W, Ly, H; /* container (integral values, as the reference's int64 plain_size) */
   double low_bound; /* C/bin3D.py:25-29 size_minimum */
+  int shuffle;
+  unsigned long long shuffle_seed;
   int ems_cap, cand_cap, order_cap, union_doubles;
   int source, env_id_base;
   int sample_left, sample_right; /* lattice 1e-3 */
@@ -80,6 +84,7 @@ struct ContinuousParams {
   int table_global; /* 1: hash table + order list live in HBM (capacity beyond LDS) */
   uint32_t* gtab;   /* [N, cand_cap*5/4] */
   uint16_t* gorder; /* [N, order_cap] */
+  uint32_t* gfpri;  /* [N, order_cap] shuffle priorities (HBM-table variant + shuffle) */
   int gt_by_block;  /* HBM table slices indexed by blockIdx (retry pass) instead of env */
   int retry_mode;   /* this launch is the large-capacity retry pass */
   int* retry_count; /* [1] envs queued by the normal pass (zeroed before it) */

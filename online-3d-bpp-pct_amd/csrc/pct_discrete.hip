@@ -1,878 +1,14 @@
-// pct_discrete.hip -- gfx950 kernels for the batched PctDiscrete0 environment.
-//
-// One 64-lane wavefront (= one 64-thread workgroup) owns one environment for a whole
-// transition; the env's heightmap, EMS list, candidate hash table, placed boxes and leaf
-// list are staged in LDS, the persistent state lives in HBM as struct-of-arrays over envs
-// (each env's slice contiguous, so the wave's lanes read consecutive addresses).
-// Integer / branchy AABB, scan and compaction work: no MFMA anywhere on this path.
-//
-// Reference semantics restated here (paths under the reference repo,
-// D/ = pct_envs/PctDiscrete0/):
-//   step / auto-reset        D/bin3D.py:151-188, wrapper/shmem_vec_env.py:139-143
-//   LeafNode2Action          D/bin3D.py:139-149
-//   drop_box / check_box     D/space.py:347-389, 436-454
-//   GENEMS / Difference      D/space.py:457-483, 498-512
-//   EliminateInscribedEMS    D/space.py:518-531
-//   EMSPoint                 D/space.py:534-570  (a CPython `set`: its iteration order is
-//                            reproduced exactly -- Objects/setobject.c set_add_entry /
-//                            set_table_resize / set_insert_clean, tupleobject.c tuplehash)
-//   get_possible_position    D/bin3D.py:100-136
-//   cur_observation          D/bin3D.py:70-93
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-
-#include "../../include/pct_env.h"
-#include "pct_device.h"
-
-#include "pct_set.cuh"
-#include "pct_stab.cuh"
+// pct_discrete.hip -- instantiates the discrete-env kernels for 32-bit keys (bins <= 31 per
+// axis: six 5-bit coordinates) and hosts the launch dispatcher; the kernels themselves are in
+// pct_discrete_impl.cuh, the 64-bit-key instantiation in pct_discrete_u64.hip.
+#include "pct_discrete_impl.cuh"
 
 namespace pct {
 
-// ----------------------------------------------------------------------------------------
-// packed boxes: six coordinates, BITS bits each, in one key word; the top bits stay clear
-// (30 of 32 / 60 of 64 bits used), which the hash-table slot encoding relies on.
-// ----------------------------------------------------------------------------------------
-template <typename K, int BITS>
-struct Pack {
-  static constexpr uint32_t M = (1u << BITS) - 1u;
-  __device__ static inline K pack(int a, int b, int c, int d, int e, int f) {
-    return (K)a | ((K)b << BITS) | ((K)c << (2 * BITS)) | ((K)d << (3 * BITS)) | ((K)e << (4 * BITS)) |
-           ((K)f << (5 * BITS));
-  }
-  __device__ static inline int get(K k, int i) { return (int)((k >> (i * BITS)) & (K)M); }
-};
+size_t discrete_lds_bytes(const DiscreteParams& p) { return discrete_lds_bytes_impl(p); }
 
-template <typename K, int BITS>
-__device__ inline uint64_t tuplehash6(K key) {
-  uint64_t acc = tuplehash_begin();
-#pragma unroll
-  for (int i = 0; i < 6; i++) acc = tuplehash_lane(acc, (uint64_t)Pack<K, BITS>::get(key, i));  // hash(int) == int
-  return tuplehash_end6(acc);
-}
-
-struct EnvRegs {  // wave-uniform per-env scalars
-  int n_ems, n_boxes, n_leaf;
-  int item0, item1, item2;
-  uint64_t cursor;
-  uint32_t t;
-  int64_t vol;
-  uint32_t flags;
-  int traj;  // dataset mode: current trajectory (LoadBoxCreator.index)
-};
-
-template <typename K, int BITS>
-struct Lds {
-  K* tab0;
-  K* tab1;
-  K* ems_a;
-  K* ems_b;
-  K* box;
-  K* leaf;
-  int16_t* hmap;
-  uint16_t* vp; /* [64] valid (ems, rotation) pairs of the current chunk */
-  uint32_t* cp; /* corner-point scratch: 4 arrays of I+2 words (only when lnes == CP) */
-};
-
-template <typename K, int BITS>
-__device__ inline Lds<K, BITS> carve_lds(const DiscreteParams& p, unsigned char* base) {
-  Lds<K, BITS> l;
-  K* q = reinterpret_cast<K*>(base);
-  l.tab0 = q; q += p.cand_cap;
-  l.tab1 = q; q += p.cand_cap / 4;
-  l.ems_a = q; q += p.ems_cap;
-  l.ems_b = q; q += p.ems_cap;
-  l.box = q; q += p.I;
-  l.leaf = q; q += p.L;
-  l.hmap = reinterpret_cast<int16_t*>(q);
-  l.vp = reinterpret_cast<uint16_t*>(l.hmap + p.AA);
-  l.cp = reinterpret_cast<uint32_t*>(l.vp + 64);
-  return l;
-}
-
-// placed-box geometry for the stability code: lx,ly,lz,xe,ye,ze from the packed LDS boxes
-template <typename K, int BITS>
-struct BoxGeo {
-  const K* box;
-  __device__ inline void operator()(int i, double g[9]) const {
-    K k = box[i];
-#pragma unroll
-    for (int c = 0; c < 6; c++) g[c] = (double)Pack<K, BITS>::get(k, c);
-    g[6] = g[3] - g[0]; g[7] = g[4] - g[1]; g[8] = g[5] - g[2];  // exact for integers
-  }
-};
-__device__ inline StabState stab_view(const DiscreteParams& p, int e) {
-  StabState st;
-  st.I = p.I;
-  st.stack = p.st_stack + (size_t)e * p.I * 4;
-  st.nsup = p.st_nsup + (size_t)e * p.I;
-  st.sup = p.st_sup + (size_t)e * p.I * STAB_SMAX;
-  st.share = p.st_share + (size_t)e * p.I * STAB_SMAX * 4;
-  st.npoly = p.st_npoly + (size_t)e * p.I;
-  st.poly = p.st_poly + (size_t)e * p.I * STAB_PMAX * 2;
-  return st;
-}
-
-__device__ inline void draw_item(const DiscreteParams& p, int e, EnvRegs& r) {
-  // binCreator.py:37-39 generate_box_size, through the scripted / counter-based sources
-  uint64_t c = r.cursor++;
-  const int32_t* it;
-  if (p.source == PCT_ITEMS_DATASET) {  // binCreator.py:64-72 generate_box_size
-    int t = r.traj < p.ds_ntraj ? r.traj : p.ds_ntraj - 1;
-    int len = p.ds_len[t];
-    if (c < (uint64_t)len) {
-      it = p.stream + ((size_t)t * p.ds_maxlen + (size_t)c) * 3;
-    } else {
-      int v = (c == (uint64_t)len) ? 100 : 10;
-      r.item0 = v; r.item1 = v; r.item2 = v;
-      return;
-    }
-  } else if (p.source == PCT_ITEMS_STREAM) {
-    it = p.stream + ((size_t)e * (size_t)p.T + (size_t)(c % (uint64_t)p.T)) * 3;
-  } else {
-    uint64_t g = (uint64_t)(p.env_id_base + e);
-    it = p.item_set + (size_t)(pct_mix64(p.seed, g, c) % (uint64_t)p.n_items) * 3;
-  }
-  r.item0 = it[0];
-  r.item1 = it[1];
-  r.item2 = it[2];
-}
-
-// D/space.py:290-314 Space.reset on the LDS-resident state
-template <typename K, int BITS>
-__device__ inline void space_reset(const DiscreteParams& p, Lds<K, BITS>& l, EnvRegs& r, int lane) {
-  for (int c = lane; c < p.AA; c += 64) l.hmap[c] = 0;
-  if (lane == 0) l.ems_a[0] = Pack<K, BITS>::pack(0, 0, 0, p.W, p.Ly, p.H);
-  r.n_ems = 1;
-  r.n_boxes = 0;
-  r.vol = 0;
-  if (p.source == PCT_ITEMS_DATASET) {  // LoadBoxCreator.reset (binCreator.py:51-62)
-    r.traj++;
-    r.cursor = 0;
-    if (r.traj >= p.ds_ntraj) r.flags |= PCT_FLAG_DATASET_EXHAUSTED;
-  }
-}
-
-// D/space.py:457-483 GENEMS + :518-531 EliminateInscribedEMS.  ems_a -> ems_a.
-template <typename K, int BITS>
-__device__ inline void genems(const DiscreteParams& p, Lds<K, BITS>& l, EnvRegs& r, int lane, int bx0, int by0,
-                              int bz0, int bx1, int by1, int bz1) {
-  typedef Pack<K, BITS> P;
-  const int E = r.n_ems;
-  const int lb = p.low_bound <= 0 ? 1 : p.low_bound;
-  const uint64_t lt = lanemask_lt(lane);
-  // sweep 1: survivors (EMS not intersected by the box) keep their order at the front
-  int S = 0;
-  for (int base = 0; base < E; base += 64) {
-    int i = base + lane;
-    bool live = i < E;
-    K k = live ? l.ems_a[i] : (K)0;
-    int x1 = P::get(k, 0), y1 = P::get(k, 1), z1 = P::get(k, 2), x2 = P::get(k, 3), y2 = P::get(k, 4),
-        z2 = P::get(k, 5);
-    int t1 = max(bx0, x1), u1 = max(by0, y1), v1 = max(bz0, z1);
-    int t2 = min(bx1, x2), u2 = min(by1, y2), v2 = min(bz1, z2);
-    bool inter = live && (t1 < t2) && (u1 < u2) && (v1 < v2);
-    bool surv = live && !inter;
-    uint64_t m = __ballot(surv);
-    if (surv) l.ems_b[S + __popcll(m & lt)] = k;
-    S += __popcll(m);
-  }
-  // sweep 2: children of every intersected EMS, by parent index then branch order
-  int C = 0;
-  bool overflow = false;
-  for (int base = 0; base < E; base += 64) {
-    int i = base + lane;
-    bool live = i < E;
-    K k = live ? l.ems_a[i] : (K)0;
-    int x1 = P::get(k, 0), y1 = P::get(k, 1), z1 = P::get(k, 2), x2 = P::get(k, 3), y2 = P::get(k, 4),
-        z2 = P::get(k, 5);
-    int x3 = max(bx0, x1), y3 = max(by0, y1), z3 = max(bz0, z1);
-    int x4 = min(bx1, x2), y4 = min(by1, y2), z4 = min(bz1, z2);
-    bool inter = live && (x3 < x4) && (y3 < y4) && (z3 < z4);
-    (void)z3;
-    bool ylz = (y2 - y1 >= lb) && (z2 - z1 >= lb);
-    bool xlz = (x2 - x1 >= lb) && (z2 - z1 >= lb);
-    bool c0 = inter && (x3 - x1 >= lb) && ylz;                       // [x1,y1,z1,x3,y2,z2]
-    bool c1 = inter && (x2 - x4 >= lb) && ylz;                       // [x4,y1,z1,x2,y2,z2]
-    bool c2 = inter && (y3 - y1 >= lb) && xlz;                       // [x1,y1,z1,x2,y3,z2]
-    bool c3 = inter && (y2 - y4 >= lb) && xlz;                       // [x1,y4,z1,x2,y2,z2]
-    bool c4 = inter && (z2 - z4 >= lb) && (x2 - x1 >= lb) && (y2 - y1 >= lb);  // [x1,y1,z4,x2,y2,z2]
-    uint64_t m0 = __ballot(c0), m1 = __ballot(c1), m2 = __ballot(c2), m3 = __ballot(c3), m4 = __ballot(c4);
-    int pos = S + C + __popcll(m0 & lt) + __popcll(m1 & lt) + __popcll(m2 & lt) + __popcll(m3 & lt) +
-              __popcll(m4 & lt);
-    if (c0) { if (pos < p.ems_cap) l.ems_b[pos] = P::pack(x1, y1, z1, x3, y2, z2); pos++; }
-    if (c1) { if (pos < p.ems_cap) l.ems_b[pos] = P::pack(x4, y1, z1, x2, y2, z2); pos++; }
-    if (c2) { if (pos < p.ems_cap) l.ems_b[pos] = P::pack(x1, y1, z1, x2, y3, z2); pos++; }
-    if (c3) { if (pos < p.ems_cap) l.ems_b[pos] = P::pack(x1, y4, z1, x2, y2, z2); pos++; }
-    if (c4) { if (pos < p.ems_cap) l.ems_b[pos] = P::pack(x1, y1, z4, x2, y2, z2); pos++; }
-    C += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3) + __popcll(m4);
-  }
-  int n = S + C;
-  if (n > p.ems_cap) {
-    overflow = true;
-    n = p.ems_cap;
-  }
-  if (overflow) r.flags |= PCT_FLAG_EMS_OVERFLOW;
-  __syncthreads();
-  // elimination: i is deleted iff some j != i contains it (non-strict, pre-deletion list).
-  // The list before GENEMS is containment-free (it is the output of the previous
-  // elimination, or the single initial EMS), and a child is a subset of its intersected
-  // parent, so a survivor can neither lie inside a child nor equal one: only children can be
-  // deleted.  Survivors are copied, children are tested against the whole list.
-  for (int i = lane; i < (S < n ? S : n); i += 64) l.ems_a[i] = l.ems_b[i];
-  int out = S < n ? S : n;
-  for (int base = out; base < n; base += 64) {
-    int i = base + lane;
-    bool live = i < n;
-    K k = live ? l.ems_b[i] : (K)0;
-    int a0 = P::get(k, 0), a1 = P::get(k, 1), a2 = P::get(k, 2), a3 = P::get(k, 3), a4 = P::get(k, 4),
-        a5 = P::get(k, 5);
-    bool del = false;
-    for (int j = 0; j < n; j++) {
-      K kj = uniform_key<K>(l.ems_b[j]);
-      int b0 = P::get(kj, 0), b1 = P::get(kj, 1), b2 = P::get(kj, 2), b3 = P::get(kj, 3), b4 = P::get(kj, 4),
-          b5 = P::get(kj, 5);
-      bool inside = (a0 >= b0) & (a1 >= b1) & (a2 >= b2) & (a3 <= b3) & (a4 <= b4) & (a5 <= b5);
-      del |= inside & (j != i);
-    }
-    bool keep = live && !del;
-    uint64_t m = __ballot(keep);
-    if (keep) l.ems_a[out + __popcll(m & lt)] = k;
-    out += __popcll(m);
-  }
-  r.n_ems = out;
-  __syncthreads();
-}
-
-// D/space.py:534-570 EMSPoint (CPython-set order) + D/bin3D.py:100-136
-// get_possible_position: fills l.leaf[0..n_leaf) with the first <= L feasible candidates.
-template <typename K, int BITS, bool STAB, int SCHEME, typename TM>
-__device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& l, EnvRegs& r, int lane, TM& tm) {
-  typedef Pack<K, BITS> P;
-  const uint64_t lt = lanemask_lt(lane);
-  const int E = r.n_ems;
-  const int b0 = r.item0, b1 = r.item1, b2 = r.item2;
-  constexpr int orient = STAB ? 2 : 6;  // setting 2 <=> no stability check <=> 6 orientations (D/space.py:536-537)
-  const int NP = E * orient;  // (EMS, rotation) pairs in set-insertion order
-
-  // fresh set: PySet_MINSIZE = 8 slots
-  const K EMPTY = SlotWord<K>::EMPTY;
-  uint32_t size = 8, fill = 0;
-  K* const tabs = l.tab0;  // both table regions, contiguous
-  uint32_t toff = table_region(p.cand_cap, size);
-  // ems_b is free outside GENEMS: the queue of keys waiting for insertion + the batch keys
-  K* pend = l.ems_b;
-  K* bkeys = l.ems_b + PCT_PEND_SLOTS;
-  if (lane < 8) tabs[toff + lane] = EMPTY;
-  __syncthreads();
-  bool cand_overflow = false;
-  int npend = 0;
-
-  // rotation r of the item (D/space.py:540-562): extents and the skip rule
-  auto rot_size = [&](int rot, int& sx, int& sy, int& sz) -> bool {
-    switch (rot) {
-      case 0: sx = b0; sy = b1; sz = b2; return false;
-      case 1: sx = b1; sy = b0; sz = b2; return sx == sy;
-      case 2: sx = b0; sy = b2; sz = b1; return sx == sy && sy == sz;
-      case 3: sx = b1; sy = b2; sz = b0; return sx == sy && sy == sz;
-      case 4: sx = b2; sy = b0; sz = b1; return sx == sy;
-      default: sx = b2; sy = b1; sz = b0; return sx == sy;
-    }
-  };
-
-  // insert the first `cnt` (<= 64) queued keys, in queue order, exactly as set.add would
-  auto flush = [&](int cnt) {
-    bool pending = lane < cnt;
-    K key = pending ? pend[lane] : (K)0;
-    K mv = (lane + 64 < npend) ? pend[lane + 64] : (K)0;
-    __syncthreads();
-    if (lane + 64 < npend) pend[lane] = mv;
-    bkeys[lane] = key;
-    npend -= cnt;
-    __syncthreads();
-    // exact in-batch de-duplication: keep the first occurrence (set.add of a present key is a
-    // no-op, and the first occurrence is inserted before the later ones in any case)
-    {
-      bool dup = false;
-      for (int i = 0; i < cnt; i++) dup |= (bkeys[i] == key) & (i < lane);
-      pending = pending && !dup;
-    }
-    uint64_t hash = tuplehash6<K, BITS>(key);
-    while (true) {
-      uint64_t pm = __ballot(pending);
-      if (!pm) break;
-      // set_add_entry grows the table when fill*5 >= mask*3, checked right after each
-      // insertion: at most thr - fill more keys go into this table
-      uint32_t mask = size - 1;
-      uint32_t thr = (mask * 3u + 4u) / 5u;
-      bool part = pending && (uint32_t)__popcll(pm & lt) < thr - fill;
-      bool placed;
-      uint32_t slot;
-      pyset_match<K>(tabs + toff, mask, part, hash, lane, true, placed, slot, [&](K w) { return w == key; });
-      if (placed) tabs[toff + slot] = key;
-      pending = pending && !part;
-      fill += (uint32_t)__popcll(__ballot(placed));
-      __syncthreads();
-      if (fill >= thr) {  // set_table_resize(used * 4): re-insert in old-slot order
-        uint32_t newsize = 8;
-        while (newsize <= fill * 4u) newsize <<= 1;
-        if (newsize > (uint32_t)p.cand_cap) {
-          cand_overflow = true;
-          break;
-        }
-        const uint32_t noff = table_region(p.cand_cap, newsize);
-        for (uint32_t s2 = lane; s2 < newsize; s2 += 64) tabs[noff + s2] = EMPTY;
-        __syncthreads();
-        for (uint32_t sb = 0; sb < size; sb += 64) {
-          uint32_t s2 = sb + lane;
-          K ok = (s2 < size) ? tabs[toff + s2] : EMPTY;
-          bool opart = ok != EMPTY;
-          bool oplaced;
-          uint32_t oslot;
-          pyset_match<K>(tabs + noff, newsize - 1, opart, tuplehash6<K, BITS>(ok), lane, false, oplaced, oslot,
-                         [&](K) { return false; });
-          if (oplaced) tabs[noff + oslot] = ok;
-          __syncthreads();
-        }
-        toff = noff;
-        size = newsize;
-      }
-    }
-  };
-
-  constexpr bool CP = SCHEME == 1;
-  if (SCHEME == 2) {
-    // D/space.py:573-610 FullCoord: rotation-major, then lx, then ly; lz = the cell's own height
-    const int NQ = orient * p.W * p.Ly;
-    for (int base = 0; base < NQ && !cand_overflow; base += 64) {
-      int q = base + lane;
-      bool valid = q < NQ;
-      int rot = q / (p.W * p.Ly);
-      int rem = q - rot * (p.W * p.Ly);
-      int px = rem / p.Ly, py = rem - px * p.Ly;
-      int sx, sy, sz;
-      bool skip = rot_size(rot, sx, sy, sz);
-      int pz = valid ? (int)l.hmap[px * p.A + py] : 0;
-      valid = valid && !skip && (px + sx <= p.W) && (py + sy <= p.Ly) && (pz + sz <= p.H);
-      K key = P::pack(px, py, pz, px + sx, py + sy, pz + sz);
-      uint64_t hash = tuplehash6<K, BITS>(key);
-      bool fresh = valid && !pyset_contains<K>(tabs + toff, size - 1, hash, [&](K w) { return w == key; });
-      uint64_t nm = __ballot(fresh);
-      if (fresh) pend[npend + __popcll(nm & lt)] = key;
-      npend += __popcll(nm);
-      __syncthreads();
-      if (npend >= 64) flush(64);
-    }
-  } else if (CP && r.n_boxes == 0) {
-    // D/space.py:756-757: an empty bin yields a plain two-element LIST (unrotated, x/y
-    // swapped; no set, no in-bin test): slots 0 and 1 of the fresh 8-slot table hold them in
-    // list order, duplicates included
-    if (lane == 0) {
-      tabs[toff + 0] = P::pack(0, 0, 0, b0, b1, b2);
-      tabs[toff + 1] = P::pack(0, 0, 0, b1, b0, b2);
-    }
-    __syncthreads();
-  } else if (CP) {
-    // D/space.py:758-774 + D/PctTools.py:137-158: per level k (sorted distinct tops, 0 first)
-    // the corner points of the boxes reaching above k, minus those of the previous level
-    const int n = r.n_boxes;
-    uint32_t* T = l.cp;                  // [I+2] levels
-    uint32_t* srt = l.cp + (p.I + 2);    // [I+2] box ids sorted by (ye, xe) descending, stable
-    uint32_t* cik = l.cp + 2 * (p.I + 2);   // [I+2] corners of this level: x | y << 16
-    uint32_t* last = l.cp + 3 * (p.I + 2);  // [I+2] corners of the previous level
-    uint32_t* CI = reinterpret_cast<uint32_t*>(l.ems_a);  // EMS are not kept under CP: x | y<<10 | k<<20
-    const int ci_cap = (int)(p.ems_cap * sizeof(K) / sizeof(uint32_t));
-    // distinct tops, ascending (Tset, D/space.py:758-761)
-    int nT = 1;
-    if (lane == 0) T[0] = 0;
-    for (int base = 0; base < n; base += 64) {  // cik[i] = 1 iff box i is the first with its top
-      int i = base + lane;
-      int top = i < n ? P::get(l.box[i], 5) : 0;
-      bool first = i < n;
-      for (int j = 0; j < n; j++) first = first && !(j < i && P::get(uniform_key<K>(l.box[j]), 5) == top);
-      if (i < n) cik[i] = first ? 1u : 0u;
-    }
-    __syncthreads();
-    for (int base = 0; base < n; base += 64) {
-      int i = base + lane;
-      int top = i < n ? P::get(l.box[i], 5) : 0;
-      bool first = i < n && cik[i] != 0u;
-      int less = 0;
-      for (int j = 0; j < n; j++)
-        less += (uniform_key<uint32_t>(cik[j]) != 0u && P::get(uniform_key<K>(l.box[j]), 5) < top) ? 1 : 0;
-      if (first) T[1 + less] = (uint32_t)top;
-      nT += __popcll(__ballot(first));
-    }
-    __syncthreads();
-    int nCI = 0, nlast = 0;
-    bool ci_overflow = false;
-    for (int ti = 0; ti < nT; ti++) {
-      const int k = (int)uniform_key<uint32_t>(T[ti]);
-      // stable descending sort of the active rectangles by (ye, xe): rank by counting
-      int nact = 0;
-      for (int base = 0; base < n; base += 64) {
-        int i = base + lane;
-        K bi = i < n ? l.box[i] : (K)0;
-        bool act = i < n && P::get(bi, 5) > k;
-        int xe = P::get(bi, 3), ye = P::get(bi, 4);
-        int rank = 0;
-        for (int j = 0; j < n; j++) {
-          K bj = uniform_key<K>(l.box[j]);
-          bool actj = P::get(bj, 5) > k;
-          int xj = P::get(bj, 3), yj = P::get(bj, 4);
-          bool before = (yj > ye) || (yj == ye && xj > xe) || (yj == ye && xj == xe && j < i);
-          rank += (actj && before) ? 1 : 0;
-        }
-        if (act) srt[rank] = (uint32_t)i;
-        nact += __popcll(__ballot(act));
-      }
-      __syncthreads();
-      int nc = 0;
-      if (nact == 0) {
-        if (lane == 0) cik[0] = 0;  // corners2D([]) == [(0, 0)]
-        nc = 1;
-      } else {
-        // extreme items (PctTools.py:145-151): xe above the running maximum of everything sorted
-        // before; the corner an extreme item contributes is (that running maximum, its ye) --
-        // the running maximum is 0 for the first one and the previous extreme item's xe after
-        int m = 0, xmax = 0;
-        for (int base = 0; base < nact; base += 64) {
-          int pos = base + lane;
-          bool live = pos < nact;
-          K bb = live ? l.box[srt[pos]] : (K)0;
-          int xe = P::get(bb, 3), ye = P::get(bb, 4);
-          int run = 0;
-          for (int q = 0; q < nact; q++) {
-            int xq = P::get(uniform_key<K>(l.box[srt[q]]), 3);
-            run = (q < pos && xq > run) ? xq : run;
-          }
-          bool ext = live && xe > run;
-          uint64_t em_mask = __ballot(ext);
-          if (ext) cik[m + __popcll(em_mask & lt)] = (uint32_t)run | ((uint32_t)ye << 16);
-          m += __popcll(em_mask);
-          int passmax = wave_max_i32(live ? xe : 0);
-          xmax = passmax > xmax ? passmax : xmax;
-        }
-        // closing corner (xe of the last extreme item, 0): the running maximum of all xe
-        if (lane == 0) cik[m] = (uint32_t)xmax;
-        nc = m + 1;
-      }
-      __syncthreads();
-      // CI += corners not present at the previous level (order kept)
-      for (int base = 0; base < nc; base += 64) {
-        int c = base + lane;
-        bool live = c < nc;
-        uint32_t v = live ? cik[c] : 0u;
-        bool seen = false;
-        for (int q = 0; q < nlast; q++) seen = seen || (last[q] == v);
-        bool add = live && !seen;
-        uint64_t m2 = __ballot(add);
-        int o = nCI + __popcll(m2 & lt);
-        if (add) {
-          if (o < ci_cap) CI[o] = (v & 0xFFFFu) | ((v >> 16) << 10) | ((uint32_t)k << 20);
-          else ci_overflow = true;
-        }
-        nCI += __popcll(m2);
-      }
-      ci_overflow = __ballot(ci_overflow) != 0;
-      if (nCI > ci_cap) nCI = ci_cap;
-      __syncthreads();
-      for (int c = lane; c < nc; c += 64) last[c] = cik[c];
-      nlast = nc;
-      __syncthreads();
-    }
-    if (ci_overflow) r.flags |= PCT_FLAG_EMS_OVERFLOW;
-    // candidates: corner x rotation, in-bin test (D/space.py:776-803), into the set
-    const int NQ = nCI * orient;
-    for (int base = 0; base < NQ && !cand_overflow; base += 64) {
-      int q = base + lane;
-      bool valid = q < NQ;
-      int ci = q / orient, rot = q - ci * orient;
-      int sx, sy, sz;
-      bool skip = rot_size(rot, sx, sy, sz);
-      uint32_t cv = valid ? CI[ci] : 0u;
-      int px = (int)(cv & 0x3FFu), py = (int)((cv >> 10) & 0x3FFu), pz = (int)(cv >> 20);
-      valid = valid && !skip && (px + sx <= p.W) && (py + sy <= p.Ly) && (pz + sz <= p.H);
-      K key = P::pack(px, py, pz, px + sx, py + sy, pz + sz);
-      uint64_t hash = tuplehash6<K, BITS>(key);
-      bool fresh = valid && !pyset_contains<K>(tabs + toff, size - 1, hash, [&](K w) { return w == key; });
-      uint64_t nm = __ballot(fresh);
-      if (fresh) pend[npend + __popcll(nm & lt)] = key;
-      npend += __popcll(nm);
-      __syncthreads();
-      if (npend >= 64) flush(64);
-    }
-  } else {
-    for (int pbase = 0; pbase < NP && !cand_overflow; pbase += 64) {
-      // which (EMS, rotation) pairs of this chunk can hold the item at all
-      int q = pbase + lane;
-      bool pv = q < NP;
-      int ei = q / orient, rot = q - ei * orient;
-      int sx, sy, sz;
-      bool skip = rot_size(rot, sx, sy, sz);
-      K ek = pv ? l.ems_a[ei] : (K)0;
-      pv = pv && !skip && (P::get(ek, 3) - P::get(ek, 0) >= sx) && (P::get(ek, 4) - P::get(ek, 1) >= sy) &&
-           (P::get(ek, 5) - P::get(ek, 2) >= sz);
-      uint64_t pm = __ballot(pv);
-      const int nt = 4 * __popcll(pm);  // four bottom-corner placements per pair (:565-568)
-      if (pv) l.vp[__popcll(pm & lt)] = (uint16_t)q;
-      __syncthreads();
-      for (int tb = 0; tb < nt && !cand_overflow; tb += 64) {
-        int tt = tb + lane;
-        bool valid = tt < nt;
-        int qq = valid ? (int)l.vp[tt >> 2] : 0;
-        int corner = tt & 3;
-        int e2 = qq / orient;
-        rot_size(qq - e2 * orient, sx, sy, sz);
-        K k2 = l.ems_a[e2];
-        int x0 = P::get(k2, 0), y0 = P::get(k2, 1), z0 = P::get(k2, 2), x1 = P::get(k2, 3), y1 = P::get(k2, 4);
-        int xs = (corner & 1) ? x1 - sx : x0;
-        int ys = (corner & 2) ? y1 - sy : y0;
-        K key = P::pack(xs, ys, z0, xs + sx, ys + sy, z0 + sz);
-        uint64_t hash = tuplehash6<K, BITS>(key);
-        bool fresh = valid && !pyset_contains<K>(tabs + toff, size - 1, hash, [&](K w) { return w == key; });
-        uint64_t nm = __ballot(fresh);
-        if (fresh) pend[npend + __popcll(nm & lt)] = key;
-        npend += __popcll(nm);
-        __syncthreads();
-        if (npend >= 64) flush(64);
-      }
-      __syncthreads();
-    }
-  }
-  while (npend > 0 && !cand_overflow) flush(npend < 64 ? npend : 64);
-  if (cand_overflow) r.flags |= PCT_FLAG_CANDIDATE_OVERFLOW;
-  __syncthreads();
-  tm.tick(PH_SET);
-
-  // iterate the table in slot order (= list(set)), test feasibility, keep the first L
-  int nleaf = 0;
-  bool stab_err = false;
-  for (uint32_t sb = 0; sb < size && nleaf < p.L; sb += 64) {
-    uint32_t s = sb + lane;
-    K k = (s < size) ? tabs[toff + s] : SlotWord<K>::EMPTY;
-    bool feas = false;
-    if (k != SlotWord<K>::EMPTY) {
-      int xs = P::get(k, 0), ys = P::get(k, 1), xe = P::get(k, 3), ye = P::get(k, 4);
-      int z = P::get(k, 5) - P::get(k, 2);
-      int mh = 0;  // D/space.py:400-401 footprint maximum (candidate's own zs is ignored)
-      for (int x = xs; x < xe; x++)
-        for (int y = ys; y < ye; y++) {
-          int h = l.hmap[x * p.A + y];
-          mh = h > mh ? h : mh;
-        }
-      // check_box :436-446: EMS candidates are inside the bin by construction
-      feas = (xe <= p.W) && (ye <= p.Ly) && (mh + z <= p.H);
-      if (STAB && feas && mh != 0) {  // :447-454 calculated_impact_virtual(first=True)
-        const double cand[9] = {(double)xs, (double)ys, (double)mh, (double)xe, (double)ye, (double)(mh + z),
-                                (double)(xe - xs), (double)(ye - ys), (double)z};
-        BoxGeo<K, BITS> geo{l.box};
-        bool err;
-        feas = stab_virtual<false>(geo, stab_view(p, e), r.n_boxes, cand, 1.0, err);
-        if (err) stab_err = true;
-      }
-    }
-    uint64_t m = __ballot(feas);
-    int idx = nleaf + __popcll(m & lt);
-    if (feas && idx < p.L) l.leaf[idx] = k;
-    nleaf += __popcll(m);
-  }
-  if (STAB && __ballot(stab_err)) r.flags |= PCT_FLAG_STABILITY_OVERFLOW;
-  r.n_leaf = nleaf < p.L ? nleaf : p.L;
-  __syncthreads();
-  tm.tick(PH_FEAS);
-}
-
-// D/bin3D.py:70-93: the [I+L+1, 9] float32 observation, written once, coalesced
-template <typename K, int BITS>
-__device__ inline void write_obs(const DiscreteParams& p, const Lds<K, BITS>& l, const EnvRegs& r, int lane,
-                                 float* __restrict__ obs) {
-  typedef Pack<K, BITS> P;
-  int a = r.item0, b = r.item1, c = r.item2, tmp;
-  if (a > b) { tmp = a; a = b; b = tmp; }
-  if (b > c) { tmp = b; b = c; c = tmp; }
-  if (a > b) { tmp = a; a = b; b = tmp; }
-  // 7 rows (63 consecutive floats) per pass: a lane keeps its column, only the row advances
-  const int col = lane % 9, rsub = lane / 9;
-  const bool lane_on = lane < 63;
-  const int rows = p.I + p.L + 1;
-  for (int rbase = 0; rbase < rows; rbase += 7) {
-    const int row = rbase + rsub;
-    if (!lane_on || row >= rows) continue;
-    float v = 0.f;
-    if (row < p.I) {
-      if (row < r.n_boxes) {
-        K k = l.box[row];
-        v = col < 6 ? (float)P::get(k, col) : (col == 7 ? 0.f : 1.0f);  // density 1, pad 0, mask 1
-      } else if (row == 0 && col == 8) {
-        v = 1.0f;  // D/space.py:294-295 dummy valid node after reset
-      }
-    } else if (row < p.I + p.L) {
-      int j = row - p.I;
-      if (j < r.n_leaf) {
-        K k = l.leaf[j];
-        v = col < 5 ? (float)P::get(k, col) : (col == 5 ? (float)p.H : (col == 8 ? 1.0f : 0.f));
-      }
-    } else {
-      v = col == 0 ? 1.0f : (col == 3 ? (float)a : (col == 4 ? (float)b : (col == 5 ? (float)c : (col == 8 ? 1.0f : 0.f))));
-    }
-    obs[row * 9 + col] = v;
-  }
-}
-
-template <typename K, int BITS>
-__device__ inline void load_state(const DiscreteParams& p, int e, Lds<K, BITS>& l, EnvRegs& r, int lane) {
-  const K* g_ems = reinterpret_cast<const K*>(p.ems) + (size_t)e * p.ems_cap;
-  const K* g_box = reinterpret_cast<const K*>(p.boxes) + (size_t)e * p.I;
-  const K* g_leaf = reinterpret_cast<const K*>(p.leaves) + (size_t)e * p.L;
-  const int16_t* g_h = p.hmap + (size_t)e * p.AA;
-  const int32_t* sc = p.scalars + (size_t)e * PCT_SCALARS;
-  r.n_ems = sc[0]; r.n_boxes = sc[1]; r.n_leaf = sc[2];
-  r.item0 = sc[3]; r.item1 = sc[4]; r.item2 = sc[5];
-  r.t = (uint32_t)sc[6];
-  r.flags = p.flags[e];
-  r.cursor = ((uint64_t)(uint32_t)sc[9] << 32) | (uint32_t)sc[8];
-  r.vol = (int64_t)(((uint64_t)(uint32_t)sc[11] << 32) | (uint32_t)sc[10]);
-  r.traj = sc[12];
-  for (int i = lane; i < r.n_ems; i += 64) l.ems_a[i] = g_ems[i];
-  for (int i = lane; i < r.n_boxes; i += 64) l.box[i] = g_box[i];
-  for (int i = lane; i < r.n_leaf; i += 64) l.leaf[i] = g_leaf[i];
-  for (int i = lane; i < p.AA; i += 64) l.hmap[i] = g_h[i];
-  __syncthreads();
-}
-
-template <typename K, int BITS>
-__device__ inline void store_state(const DiscreteParams& p, int e, const Lds<K, BITS>& l, const EnvRegs& r, int lane) {
-  K* g_ems = reinterpret_cast<K*>(p.ems) + (size_t)e * p.ems_cap;
-  K* g_box = reinterpret_cast<K*>(p.boxes) + (size_t)e * p.I;
-  K* g_leaf = reinterpret_cast<K*>(p.leaves) + (size_t)e * p.L;
-  int16_t* g_h = p.hmap + (size_t)e * p.AA;
-  int32_t* sc = p.scalars + (size_t)e * PCT_SCALARS;
-  for (int i = lane; i < r.n_ems; i += 64) g_ems[i] = l.ems_a[i];
-  for (int i = lane; i < r.n_boxes; i += 64) g_box[i] = l.box[i];
-  for (int i = lane; i < r.n_leaf; i += 64) g_leaf[i] = l.leaf[i];
-  for (int i = lane; i < p.AA; i += 64) g_h[i] = l.hmap[i];
-  if (lane == 0) {
-    sc[0] = r.n_ems; sc[1] = r.n_boxes; sc[2] = r.n_leaf;
-    sc[3] = r.item0; sc[4] = r.item1; sc[5] = r.item2;
-    sc[6] = (int32_t)r.t;
-    sc[7] = 0;
-    p.flags[e] = r.flags;
-    sc[8] = (int32_t)(uint32_t)r.cursor; sc[9] = (int32_t)(uint32_t)(r.cursor >> 32);
-    sc[10] = (int32_t)(uint32_t)(uint64_t)r.vol; sc[11] = (int32_t)(uint32_t)((uint64_t)r.vol >> 32);
-    sc[12] = r.traj;
-  }
-}
-
-// One transition of one env with the state resident in LDS (D/bin3D.py:151-188 plus the
-// VecEnv worker's auto-reset).  (flag, lx, ly) + (bx, by, bz) is the decoded action.
-template <typename K, int BITS, bool STAB, int SCHEME, typename TM>
-__device__ inline void transition(const DiscreteParams& p, int e, Lds<K, BITS>& l, EnvRegs& r, int lane, bool bad,
-                                  int flag, int lx, int ly, int bx, int by, int bz, TM& tm) {
-  typedef Pack<K, BITS> P;
-  r.t++;
-  int x = flag ? by : bx, y = flag ? bx : by, z = bz;  // D/space.py:348-351
-  bool ok = !bad;
-  int max_h = 0;
-  if (ok) {
-    // np.max(plain[lx:lx+x, ly:ly+y]) with Python slice normalisation (D/space.py:354-355)
-    int xa = lx, xb = lx + x, ya = ly, yb = ly + y;
-    if (xa < 0) { xa += p.A; if (xa < 0) xa = 0; }
-    if (xb < 0) { xb += p.A; if (xb < 0) xb = 0; }
-    if (ya < 0) { ya += p.A; if (ya < 0) ya = 0; }
-    if (yb < 0) { yb += p.A; if (yb < 0) yb = 0; }
-    xa = min(xa, p.A); xb = min(xb, p.A); ya = min(ya, p.A); yb = min(yb, p.A);
-    if (xb <= xa || yb <= ya) {
-      ok = false;  // empty slice: np.max raises ValueError
-      r.flags |= PCT_FLAG_BAD_ACTION;
-    } else if (lx < 0 || ly < 0) {
-      ok = false;  // check_box D/space.py:440-441 rejects it whatever max_h is
-    } else {
-      int m = 0;  // 8x8 tiles of the footprint, one cell per lane
-      for (int tx = xa; tx < xb; tx += 8)
-        for (int ty = ya; ty < yb; ty += 8) {
-          int cx = tx + (lane >> 3), cy = ty + (lane & 7);
-          if (cx < xb && cy < yb) {
-            int h = l.hmap[cx * p.A + cy];
-            m = h > m ? h : m;
-          }
-        }
-      max_h = wave_max_i32(m);
-      // check_box D/space.py:436-446 (setting 2)
-      ok = !(lx + x > p.W || ly + y > p.Ly) && !(max_h + z > p.H);
-    }
-  }
-  if (STAB && ok && r.n_boxes < p.I && max_h != 0) {
-    // check_box :450-451: box_now.calculated_impact() -- one lane walks the support graph and
-    // commits the new shares / stacks (the box is only kept if the verdict is True)
-    if (lane == 0) l.box[r.n_boxes] = P::pack(lx, ly, max_h, lx + x, ly + y, max_h + z);
-    __syncthreads();
-    int verdict = 1, serr = 0;
-    if (lane == 0) {
-      BoxGeo<K, BITS> geo{l.box};
-      StabState st = stab_view(p, e);
-      bool err;
-      verdict = stab_commit<false>(geo, st, r.n_boxes, 1.0, err) ? 1 : 0;
-      serr = err ? 1 : 0;
-    }
-    verdict = __shfl(verdict, 0, 64);
-    if (__shfl(serr, 0, 64)) r.flags |= PCT_FLAG_STABILITY_OVERFLOW;
-    ok = verdict != 0;
-  } else if (STAB && ok && r.n_boxes < p.I) {
-    // resting on the floor: no supporters, stack = own (still recorded for later checks)
-    if (lane == 0) l.box[r.n_boxes] = P::pack(lx, ly, max_h, lx + x, ly + y, max_h + z);
-    __syncthreads();
-    if (lane == 0) {
-      BoxGeo<K, BITS> geo{l.box};
-      StabState st = stab_view(p, e);
-      bool err;
-      stab_commit<false>(geo, st, r.n_boxes, 1.0, err);
-    }
-  }
-  if (ok && r.n_boxes >= p.I) {  // IndexError at D/space.py:385
-    ok = false;
-    r.flags |= PCT_FLAG_INTERNAL_OVERFLOW;
-  }
-  float reward;
-  uint8_t done;
-  int counter;
-  double ratio = 0.0;
-  const double binvol = (double)((int64_t)p.W * p.Ly * p.H);
-  if (ok) {
-    int top = max_h + z;
-    for (int tx = lx; tx < lx + x; tx += 8)
-      for (int ty = ly; ty < ly + y; ty += 8) {
-        int cx = tx + (lane >> 3), cy = ty + (lane & 7);
-        if (cx < lx + x && cy < ly + y) l.hmap[cx * p.A + cy] = (int16_t)top;
-      }
-    if (lane == 0) l.box[r.n_boxes] = P::pack(lx, ly, max_h, lx + x, ly + y, top);
-    r.n_boxes++;
-    r.vol += (int64_t)x * y * z;
-    __syncthreads();
-    tm.tick(PH_DROP);
-    if (SCHEME == 0) genems<K, BITS>(p, l, r, lane, lx, ly, max_h, lx + x, ly + y, top);  // D/bin3D.py:172-175
-    tm.tick(PH_GENEMS);
-    // D/bin3D.py:57-59,183: 10 * vol(item) / vol(bin), float64 then envs.py:181 .float()
-    reward = (float)(((double)((int64_t)r.item0 * r.item1 * r.item2) / binvol) * 10.0);
-    done = 0;
-    counter = r.n_boxes;
-  } else {
-    reward = 0.f;
-    done = 1;
-    counter = r.n_boxes;
-    ratio = (double)r.vol / binvol;  // D/space.py:334-339
-    __syncthreads();
-    space_reset<K, BITS>(p, l, r, lane);  // shmem_vec_env.py:141-143 -> D/bin3D.py:61-67
-    __syncthreads();
-    tm.tick(PH_DROP);
-  }
-  draw_item(p, e, r);
-  if (lane == 0) {
-    p.reward[e] = reward;
-    p.done[e] = done;
-    p.counter[e] = counter;
-    p.ratio[e] = ratio;
-  }
-}
-
-// D/bin3D.py:139-149 LeafNode2Action for a leaf given as six integers (zero row -> (0,0,0)
-// with the unrotated item)
-__device__ inline void decode_leaf(const EnvRegs& r, bool zero_row, int xs, int ys, int xe, int ye, bool& bad,
-                                   int& lx, int& ly, int& bx, int& by, int& bz) {
-  bad = false;
-  if (zero_row) {
-    lx = 0; ly = 0; bx = r.item0; by = r.item1; bz = r.item2;
-    return;
-  }
-  int x = xe - xs, y = ye - ys;
-  int z0 = r.item0, z1 = r.item1, z2 = r.item2;
-  // z = list(next_box); z.remove(x); z.remove(y); z = z[0]
-  int a, b;  // the two survivors after removing x
-  if (z0 == x) { a = z1; b = z2; }
-  else if (z1 == x) { a = z0; b = z2; }
-  else if (z2 == x) { a = z0; b = z1; }
-  else { bad = true; a = b = 0; }
-  int zz = 0;
-  if (!bad) {
-    if (a == y) zz = b;
-    else if (b == y) zz = a;
-    else bad = true;
-  }
-  lx = xs; ly = ys; bx = x; by = y; bz = zz;
-}
-
-enum { ACT_ROWS = 0, ACT_INDEX = 1, ACT_HASH = 2, ACT_RESET = 3 };
-
-template <typename K, int BITS, int ACT, bool TIMED, bool STAB, int SCHEME>
-__global__ void __launch_bounds__(64) pct_discrete_kernel(DiscreteParams p, const void* __restrict__ actions,
-                                                          int row_len, int n_steps,
-                                                          const int32_t* __restrict__ env_ids, int n_ids) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int lane = threadIdx.x;
-  int e = blockIdx.x;
-  if (ACT == ACT_RESET && env_ids) {
-    if (e >= n_ids) return;
-    e = env_ids[e];
-    if (e < 0 || e >= p.N) return;
-  }
-  Lds<K, BITS> l = carve_lds<K, BITS>(p, smem);
-  EnvRegs r;
-  PhaseTimer<TIMED> tm;
-  tm.start();
-  load_state<K, BITS>(p, e, l, r, lane);
-  tm.tick(PH_LOAD);
-  float* obs = p.obs + (size_t)e * p.row_len;
-
-  if (ACT == ACT_RESET) {
-    space_reset<K, BITS>(p, l, r, lane);
-    __syncthreads();
-    draw_item(p, e, r);
-    leaf_nodes<K, BITS, STAB, SCHEME>(p, e, l, r, lane, tm);
-    write_obs<K, BITS>(p, l, r, lane, obs);
-    store_state<K, BITS>(p, e, l, r, lane);
-    return;
-  }
-
-  for (int it = 0; it < n_steps; it++) {
-    bool bad = false, zero_row = false;
-    int flag = 0, lx = 0, ly = 0, bx = 0, by = 0, bz = 0;
-    if (ACT == ACT_ROWS) {
-      const float* row = reinterpret_cast<const float*>(actions) + (size_t)e * row_len;
-      float v = lane < row_len ? row[lane] : 0.f;
-      float a0 = __shfl(v, 0, 64), a1 = __shfl(v, 1, 64), a2 = __shfl(v, 2, 64), a3 = __shfl(v, 3, 64),
-            a4 = __shfl(v, 4, 64), a5 = __shfl(v, 5, 64);
-      if (row_len == 3) {  // (flag, lx, ly) with the unrotated item, D/bin3D.py:152-153
-        flag = (int)a0; lx = (int)a1; ly = (int)a2;
-        bx = r.item0; by = r.item1; bz = r.item2;
-      } else {
-        float sum = ((((a0 + a1) + a2) + a3) + a4) + a5;  // np.sum(leaf_node[0:6]) == 0
-        zero_row = (sum == 0.f);
-        decode_leaf(r, zero_row, (int)a0, (int)a1, (int)a0 + (int)(a3 - a0), (int)a1 + (int)(a4 - a1), bad, lx, ly,
-                    bx, by, bz);
-      }
-    } else {
-      int64_t li;
-      if (ACT == ACT_INDEX) {
-        li = reinterpret_cast<const int64_t*>(actions)[e];
-      } else {  // stand-in policy: leaf = pct_mix32(g, t) % k over the k valid leaves
-        li = r.n_leaf > 0 ? (int64_t)(pct_mix32((uint32_t)(p.env_id_base + e), r.t) % (uint32_t)r.n_leaf) : 0;
-      }
-      zero_row = !(li >= 0 && li < r.n_leaf);
-      K k = zero_row ? (K)0 : l.leaf[li];
-      typedef Pack<K, BITS> P;
-      decode_leaf(r, zero_row, P::get(k, 0), P::get(k, 1), P::get(k, 3), P::get(k, 4), bad, lx, ly, bx, by, bz);
-    }
-    if (bad) r.flags |= PCT_FLAG_BAD_ACTION;  // ValueError in list.remove, D/bin3D.py:144-145
-    transition<K, BITS, STAB, SCHEME>(p, e, l, r, lane, bad, flag, lx, ly, bx, by, bz, tm);
-    leaf_nodes<K, BITS, STAB, SCHEME>(p, e, l, r, lane, tm);
-    write_obs<K, BITS>(p, l, r, lane, obs);
-    __syncthreads();
-    tm.tick(PH_OBS);
-  }
-  store_state<K, BITS>(p, e, l, r, lane);
-  tm.tick(PH_STORE);
-  if (TIMED && lane == 0) tm.flush(p.timing + (size_t)e * 8, n_steps);
-}
+hipError_t launch_discrete_u64(const DiscreteParams& p, int act, const void* actions, int row_len, int n_steps,
+                               const int32_t* env_ids, int n_ids, hipStream_t stream);
 
 // Stand-in policy kernel: one wave per env reads the leaf-mask column (col 8 of rows
 // I..I+L-1, tools.py:103) of the observation, k = number of valid leaves, picks
@@ -892,54 +28,6 @@ __global__ void __launch_bounds__(64) pct_policy_hash_rows_kernel(DiscreteParams
   if (lane < 9) rows_out[(size_t)e * 9 + lane] = obs[(p.I + li) * 9 + lane];
 }
 
-}  // namespace pct
-
-// ----------------------------------------------------------------------------------------
-// launchers (called from pct_env.hip)
-// ----------------------------------------------------------------------------------------
-namespace pct {
-
-size_t discrete_lds_bytes(const DiscreteParams& p) {
-  size_t k = p.key_bytes;
-  size_t n = (size_t)p.cand_cap + p.cand_cap / 4 + 2 * (size_t)p.ems_cap + p.I + p.L;
-  size_t cp = p.lnes == PCT_LNES_CP ? 4 * (size_t)(p.I + 2) * sizeof(uint32_t) : 0;
-  return n * k + (size_t)p.AA * sizeof(int16_t) + 64 * sizeof(uint16_t) + cp + 16;
-}
-
-template <typename K, int BITS>
-static hipError_t launch_typed(const DiscreteParams& p, int act, const void* actions, int row_len, int n_steps,
-                               const int32_t* env_ids, int n_ids, hipStream_t stream) {
-  size_t lds = discrete_lds_bytes(p);
-  const bool timed = p.timing != nullptr && act != ACT_RESET;
-  const bool stab = p.setting != 2;
-  const int scheme = p.lnes == PCT_LNES_CP ? 1 : (p.lnes == PCT_LNES_FC ? 2 : 0);
-  int grid = (act == ACT_RESET && env_ids) ? n_ids : p.N;
-  if (grid <= 0) return hipSuccess;
-#define PCT_KERN(A, T, S, C) pct_discrete_kernel<K, BITS, A, T, S, C>
-#define PCT_LAUNCH(A)                                                                                        \
-  do {                                                                                                       \
-    void (*kern)(DiscreteParams, const void*, int, int, const int32_t*, int);                                \
-    if (stab) kern = scheme == 1 ? PCT_KERN(A, false, true, 1) : scheme == 2 ? PCT_KERN(A, false, true, 2)   \
-                                                                              : PCT_KERN(A, false, true, 0); \
-    else if (scheme == 1) kern = PCT_KERN(A, false, false, 1);                                               \
-    else if (scheme == 2) kern = PCT_KERN(A, false, false, 2);                                               \
-    else kern = timed ? PCT_KERN(A, true, false, 0) : PCT_KERN(A, false, false, 0);                          \
-    if (lds > 48 * 1024) {                                                                                   \
-      hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                               \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
-      if (er != hipSuccess) return er;                                                                       \
-    }                                                                                                        \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, stream, p, actions, row_len, n_steps, env_ids, n_ids); \
-  } while (0)
-  switch (act) {
-    case ACT_ROWS: PCT_LAUNCH(ACT_ROWS); break;
-    case ACT_INDEX: PCT_LAUNCH(ACT_INDEX); break;
-    case ACT_HASH: PCT_LAUNCH(ACT_HASH); break;
-    default: PCT_LAUNCH(ACT_RESET); break;
-  }
-#undef PCT_LAUNCH
-  return hipGetLastError();
-}
 
 hipError_t launch_policy_hash_rows(const DiscreteParams& p, float* rows_out, hipStream_t stream) {
   hipLaunchKernelGGL(pct_policy_hash_rows_kernel, dim3(p.N), dim3(64), 0, stream, p, rows_out);
@@ -949,7 +37,7 @@ hipError_t launch_policy_hash_rows(const DiscreteParams& p, float* rows_out, hip
 hipError_t launch_discrete(const DiscreteParams& p, int act, const void* actions, int row_len, int n_steps,
                            const int32_t* env_ids, int n_ids, hipStream_t stream) {
   if (p.key_bytes == 4) return launch_typed<uint32_t, 5>(p, act, actions, row_len, n_steps, env_ids, n_ids, stream);
-  return launch_typed<uint64_t, 10>(p, act, actions, row_len, n_steps, env_ids, n_ids, stream);
+  return launch_discrete_u64(p, act, actions, row_len, n_steps, env_ids, n_ids, stream);
 }
 
 }  // namespace pct

@@ -196,6 +196,7 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
     c.L = cfg->leaf_node_holder;
     c.row_len = (c.I + c.L + 1) * 9;
     c.setting = cfg->setting;
+    c.shuffle = cfg->shuffle ? 1 : 0;
     c.W = W / 1000; c.Ly = Ly / 1000; c.H = H / 1000;
     c.ems_cap = ems_cap;
     c.cand_cap = cand_cap;
@@ -230,6 +231,7 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
     if (c.table_global) {
       CALLOC_(c.gtab, Nn * (size_t)(cand_cap + cand_cap / 4) * sizeof(uint32_t));
       CALLOC_(c.gorder, Nn * (size_t)c.order_cap * sizeof(uint16_t));
+      if (c.shuffle) CALLOC_(c.gfpri, Nn * (size_t)c.order_cap * sizeof(uint32_t));
     }
     CALLOC_(c.scalars, Nn * PCT_SCALARS * sizeof(int32_t));
     CALLOC_(h->own_flags, Nn * sizeof(uint32_t));
@@ -257,6 +259,7 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
       q.union_doubles = 6 * ems_cap;
       CALLOC_(q.gtab, (size_t)RB * (size_t)(big + big / 4) * sizeof(uint32_t));
       CALLOC_(q.gorder, (size_t)RB * (size_t)q.order_cap * sizeof(uint16_t));
+      if (c.shuffle) CALLOC_(q.gfpri, (size_t)RB * (size_t)q.order_cap * sizeof(uint32_t));
     }
 #undef CALLOC_
     c.obs = h->own_obs; c.reward = h->own_reward; c.done = h->own_done; c.counter = h->own_counter;
@@ -278,6 +281,7 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
   p.row_len = (p.I + p.L + 1) * 9;
   p.setting = cfg->setting;
   p.lnes = cfg->lnes;
+  p.shuffle = cfg->shuffle ? 1 : 0;
   p.ems_cap = ems_cap;
   p.cand_cap = cand_cap;
   p.key_bytes = maxdim <= 31 ? 4 : 8;
@@ -404,6 +408,14 @@ int pct_set_item_dataset(pct_env* h, const int32_t* items, const int32_t* length
   h->dp.source = PCT_ITEMS_DATASET;
   h->cp.stream = (int32_t*)d; h->cp.ds_len = (int32_t*)dl; h->cp.ds_ntraj = n_traj; h->cp.ds_maxlen = max_len;
   h->cp.source = PCT_ITEMS_DATASET;
+  return PCT_OK;
+}
+
+int pct_set_shuffle_seed(pct_env* h, uint64_t seed) {
+  if (!h) return fail(PCT_ERR_INVALID_ARG, "null handle");
+  h->dp.shuffle_seed = seed;
+  h->cp.shuffle_seed = seed;
+  h->cp_retry.shuffle_seed = seed;
   return PCT_OK;
 }
 

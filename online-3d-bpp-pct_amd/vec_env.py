@@ -183,9 +183,6 @@ class PctVecEnv(VecEnv):
             raise PctEnvError("PctVecEnv runs on an AMD GPU only (device=%r); there is no CPU path" % (device,))
         if not torch.cuda.is_available():
             raise PctEnvError("no GPU visible to PyTorch-ROCm: the env hot path has no CPU fallback")
-        if shuffle:
-            raise NotImplementedError("shuffle=True (np.random.shuffle of the candidates, bin3D.py:114-115) "
-                                      "is not available yet; construct with shuffle=False")
         self._dataset = None
         if load_test_data:
             if data_name is None:
@@ -210,6 +207,7 @@ class PctVecEnv(VecEnv):
         cfg.leaf_node_holder = int(leaf_node_holder)
         cfg.lnes = _LNES[LNES]
         cfg.env_id_base = int(env_id_base)
+        cfg.shuffle = 1 if shuffle else 0  # bin3D.py:114-115; see include/pct_env.h pct_shuffle_priority
         cfg.ems_capacity = int(ems_capacity)
         cfg.candidate_capacity = int(candidate_capacity)
         self._h = ctypes.c_void_p()
@@ -241,6 +239,8 @@ class PctVecEnv(VecEnv):
         else:
             _lib.check(self._L.pct_set_sampler(self._h, int(seed)))
 
+        if shuffle:
+            _lib.check(self._L.pct_set_shuffle_seed(self._h, int(seed)))
         # outputs live in torch tensors bound into the handle (zero copy)
         dev = self.device
         self._obs = torch.zeros(self.N, self.row_len, dtype=torch.float32, device=dev)

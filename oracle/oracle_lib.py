@@ -27,7 +27,8 @@ class PctConfig(ctypes.Structure):
         ("env_id_base", ctypes.c_int32),
         ("ems_capacity", ctypes.c_int32),
         ("candidate_capacity", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 4),
+        ("shuffle", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 3),
     ]
 
 
@@ -53,6 +54,7 @@ def lib():
         L.pcto_set_sample_bounds.argtypes = [vp, ctypes.c_int32, ctypes.c_int32]
         L.pcto_set_item_dataset.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int32]
         L.pcto_set_sampler.argtypes = [vp, ctypes.c_uint64]
+        L.pcto_set_shuffle_seed.argtypes = [vp, ctypes.c_uint64]
         for name in ("pcto_obs", "pcto_reward", "pcto_done", "pcto_info_counter", "pcto_info_ratio",
                      "pcto_error_flags"):
             getattr(L, name).argtypes = [vp]
@@ -79,7 +81,7 @@ class OracleVecEnv(object):
 
     def __init__(self, num_envs, setting=2, container_size=(10, 10, 10), item_set=None,
                  internal_node_holder=80, leaf_node_holder=50, env_kind=0, lnes=0, env_id_base=0,
-                 threads=1, sample_bounds=None):
+                 threads=1, sample_bounds=None, shuffle=False, shuffle_seed=0):
         """env_kind 0: discrete (container / item_set in integer units).
         env_kind 1: continuous -- container in bin units (integers), sample_bounds=(left,right)
         in bin units (lattice 1e-3); item streams are int lattice units (1e-3)."""
@@ -95,6 +97,7 @@ class OracleVecEnv(object):
         cfg.leaf_node_holder = leaf_node_holder
         cfg.lnes = lnes
         cfg.env_id_base = env_id_base
+        cfg.shuffle = 1 if shuffle else 0
         self.cfg = cfg
         self.N, self.I, self.L = num_envs, internal_node_holder, leaf_node_holder
         self.row_len = (self.I + self.L + 1) * 9
@@ -102,6 +105,7 @@ class OracleVecEnv(object):
         self._h = ctypes.c_void_p()
         self._check(L.pcto_create(ctypes.byref(cfg), ctypes.byref(self._h)))
         L.pcto_set_num_threads(threads)
+        L.pcto_set_shuffle_seed(self._h, ctypes.c_uint64(shuffle_seed))
         if env_kind == 1:
             lo, hi = sample_bounds
             self._check(L.pcto_set_sample_bounds(self._h, int(round(lo * 1000)), int(round(hi * 1000))))

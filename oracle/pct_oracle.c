@@ -524,11 +524,30 @@ static int full_coord(const pcto_env* h, const oenv* s, int64_t** out) {
 
 /* D/bin3D.py:100-136 get_possible_position (LNES='EMS' / 'CP' / 'FC', shuffle=False): writes the L
  * leaf rows into leaf[L*9] */
-static void get_possible_position(const pcto_env* h, const oenv* s, double* leaf) {
+static void shuffle_rows_i64(const pcto_env* h, int e, uint64_t oc, int64_t* pos, int n) {
+  /* include/pct_env.h pct_shuffle_priority: ascending (priority, index) */
+  if (n < 2) return;
+  uint32_t* pr = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)n);
+  int* idx = (int*)malloc(sizeof(int) * (size_t)n);
+  for (int i = 0; i < n; i++) { pr[i] = pct_shuffle_priority(h->shuffle_seed, (uint64_t)(h->cfg.env_id_base + e), oc, (uint32_t)i); idx[i] = i; }
+  for (int i = 1; i < n; i++) { /* stable insertion sort by priority */
+    int v = idx[i], j = i;
+    while (j > 0 && pr[idx[j - 1]] > pr[v]) { idx[j] = idx[j - 1]; j--; }
+    idx[j] = v;
+  }
+  int64_t* tmp = (int64_t*)malloc(sizeof(int64_t) * 6 * (size_t)n);
+  for (int i = 0; i < n; i++) memcpy(tmp + 6 * (size_t)i, pos + 6 * (size_t)idx[i], 6 * sizeof(int64_t));
+  memcpy(pos, tmp, sizeof(int64_t) * 6 * (size_t)n);
+  free(tmp); free(idx); free(pr);
+}
+
+static void get_possible_position(const pcto_env* h, int e, oenv* s, double* leaf) {
   memset(leaf, 0, sizeof(double) * 9 * h->L);
   int64_t* pos = NULL;
   int n = h->cfg.lnes == PCT_LNES_CP ? corner_point(h, s, &pos)
           : h->cfg.lnes == PCT_LNES_FC ? full_coord(h, s, &pos) : ems_point(h, s, &pos);
+  if (h->cfg.shuffle) shuffle_rows_i64(h, e, s->oc, pos, n); /* D/bin3D.py:114-115 */
+  s->oc++;
   int idx = 0;
   for (int i = 0; i < n; i++) {
     const int64_t* p = pos + 6 * i;
@@ -555,7 +574,7 @@ static void cur_observation(const pcto_env* h, int e, oenv* s, double* obs) {
   s->next_box[0] = s->queue_item[0]; s->next_box[1] = s->queue_item[1]; s->next_box[2] = s->queue_item[2];
   s->next_den = 1.0;
   memcpy(obs, s->box_vec, sizeof(double) * 9 * h->I);
-  get_possible_position(h, s, obs + 9 * h->I);
+  get_possible_position(h, e, s, obs + 9 * h->I);
   int a = s->next_box[0], b = s->next_box[1], c = s->next_box[2], tmp;
   if (a > b) { tmp = a; a = b; b = tmp; }
   if (b > c) { tmp = b; b = c; c = tmp; }
@@ -749,6 +768,11 @@ int pcto_set_item_dataset(pcto_env* h, const int32_t* items, const int32_t* leng
   h->ds_ntraj = n_traj;
   h->ds_maxlen = max_len;
   h->source = PCT_ITEMS_DATASET;
+  return PCT_OK;
+}
+int pcto_set_shuffle_seed(pcto_env* h, uint64_t seed) {
+  if (!h) return fail(PCT_ERR_INVALID_ARG, "null handle");
+  h->shuffle_seed = seed;
   return PCT_OK;
 }
 int pcto_set_sampler(pcto_env* h, uint64_t seed) {

@@ -36,6 +36,7 @@ int pcto_set_sample_bounds(pcto_env* env, int32_t left, int32_t right);
 int pcto_set_item_stream(pcto_env* env, const int32_t* items, int64_t T);
 int pcto_set_item_dataset(pcto_env* env, const int32_t* items, const int32_t* lengths, int32_t n_traj, int32_t max_len);
 int pcto_set_sampler(pcto_env* env, uint64_t seed);
+int pcto_set_shuffle_seed(pcto_env* env, uint64_t seed);
 
 /* outputs (host, owned by the handle) */
 double* pcto_obs(pcto_env* env);      /* float64 [N,(I+L+1)*9] */

@@ -39,6 +39,7 @@ struct cenv {
   uint32_t t;
   int traj;
   struct stab* stab; /* settings 1 / 3 */
+  uint64_t oc;       /* observations produced so far (shuffle key) */
 };
 
 static double around6(double x) { return rint(x * 1e6) / 1e6; }
@@ -357,10 +358,21 @@ static int ems_point(const struct pcto_env* h, const struct cenv* s, double** ou
 }
 
 /* C/bin3D.py:118-148 get_possible_position */
-static void get_possible_position(const struct pcto_env* h, const struct cenv* s, double* leaf) {
+static void get_possible_position(const struct pcto_env* h, int e, struct cenv* s, double* leaf) {
   memset(leaf, 0, sizeof(double) * 9 * h->L);
   double* pos = NULL;
   int n = ems_point(h, s, &pos), idx = 0;
+  if (h->cfg.shuffle && n > 1) { /* C/bin3D.py:126-127 -> include/pct_env.h pct_shuffle_priority */
+    uint32_t* pr = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)n);
+    int* ord = (int*)malloc(sizeof(int) * (size_t)n);
+    for (int i = 0; i < n; i++) { pr[i] = pct_shuffle_priority(h->shuffle_seed, (uint64_t)(h->cfg.env_id_base + e), s->oc, (uint32_t)i); ord[i] = i; }
+    for (int i = 1; i < n; i++) { int v = ord[i], j = i; while (j > 0 && pr[ord[j - 1]] > pr[v]) { ord[j] = ord[j - 1]; j--; } ord[j] = v; }
+    double* tmp = (double*)malloc(sizeof(double) * 6 * (size_t)n);
+    for (int i = 0; i < n; i++) memcpy(tmp + 6 * (size_t)i, pos + 6 * (size_t)ord[i], 6 * sizeof(double));
+    memcpy(pos, tmp, sizeof(double) * 6 * (size_t)n);
+    free(tmp); free(ord); free(pr);
+  }
+  s->oc++;
   double H = h->cfg.container[2] / 1000;
   for (int i = 0; i < n; i++) {
     const double* p = pos + 6 * i;
@@ -381,7 +393,7 @@ static void cur_observation(const struct pcto_env* h, int e, struct cenv* s, dou
   memcpy(s->next_box, s->queue_item, sizeof s->next_box);
   s->next_den = 1.0;
   memcpy(obs, s->box_vec, sizeof(double) * 9 * h->I);
-  get_possible_position(h, s, obs + 9 * h->I);
+  get_possible_position(h, e, s, obs + 9 * h->I);
   double a = s->next_box[0], b = s->next_box[1], c = s->next_box[2], t;
   if (a > b) { t = a; a = b; b = t; }
   if (b > c) { t = b; b = c; c = t; }

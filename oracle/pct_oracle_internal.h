@@ -27,6 +27,7 @@ typedef struct {
   uint32_t t;      /* lifetime step counter (hash policy) */
   struct stab* stab; /* stability state (settings 1 / 3), pct_oracle_stab.c */
   int traj;          /* dataset mode: LoadBoxCreator.index (binCreator.py:46,54-55) */
+  uint64_t oc;       /* observations produced so far (shuffle key) */
 } oenv;
 
 struct cenv; /* continuous per-env state, pct_oracle_cont.c */
@@ -44,6 +45,7 @@ struct pcto_env {
   int32_t* ds_len; /* dataset mode: stream is [n_traj,max_len,3] */
   int ds_ntraj, ds_maxlen;
   uint64_t seed;
+  uint64_t shuffle_seed;
   int source;
   oenv* envs;
   double* obs;

@@ -409,3 +409,31 @@ def test_hip_continuous_candidate_overflow_is_rerun_with_hbm_tables():
         assert np.array_equal(done.astype(np.uint8), z["done"][t])
     assert not env.error_flags.any()
     env.close()
+
+
+@pytest.mark.parametrize("kind", ["discrete", "continuous"])
+def test_hip_shuffle_matches_oracle(kind):
+    """shuffle=True: the counter-keyed permutation of include/pct_env.h (pct_shuffle_priority)
+    is the same rule in the kernel and in the oracle."""
+    from oracle.oracle_lib import OracleVecEnv
+    N = 128
+    if kind == "discrete":
+        items = item_set_range(1, 5)
+        ora = OracleVecEnv(N, item_set=items, env_id_base=40, shuffle=True, shuffle_seed=9)
+        env = _pkg().PctVecEnv(N, item_set=items, env_id_base=40, shuffle=True, seed=9, device="cuda:0")
+    else:
+        ora = OracleVecEnv(N, container_size=(10, 10, 10), env_kind=1, sample_bounds=(1.0, 5.0), env_id_base=40,
+                           shuffle=True, shuffle_seed=9)
+        env = _pkg().PctVecEnv(N, container_size=(10, 10, 10), continuous=True, sample_left_bound=1.0,
+                               sample_right_bound=5.0, env_id_base=40, shuffle=True, seed=9, device="cuda:0")
+    ora.set_sampler(9)
+    ora.reset()
+    obs = env.reset()
+    for t in range(150):
+        assert np.array_equal(obs.cpu().numpy(), ora.obs.astype(np.float32)), (kind, t)
+        env.step_hash_policy(1)
+        ora.step_hash_policy(1)
+        obs, reward, done, infos = env.step_wait()
+        assert np.array_equal(done.astype(np.uint8), ora.done)
+    assert not env.error_flags.any()
+    env.close()

@@ -200,3 +200,26 @@ def test_oracle_dataset_semantics_match_reference(name):
         assert np.array_equal(env.obs.astype(z["obs"].dtype), z["obs"][t]), (name, t)
         env.step_hash_policy(1)
         assert np.array_equal(env.done, z["done"][t]) and np.array_equal(env.reward, z["reward"][t])
+
+
+def test_shuffle_is_a_permutation_of_the_unshuffled_candidates():
+    """shuffle=True (bin3D.py:114-115): with L large enough to hold every feasible candidate the
+    shuffled leaf rows are a permutation of the unshuffled ones; with the default L the first-L
+    cut differs, and the permutation depends on the seed."""
+    items = item_set_range(1, 5)
+    stream = np.array([[[3, 4, 2], [2, 2, 5], [4, 1, 3], [5, 5, 1], [2, 3, 3], [1, 4, 4]]], np.int32)
+    envs = []
+    for sh, seed in ((False, 0), (True, 1), (True, 2)):
+        e = OracleVecEnv(1, item_set=items, leaf_node_holder=600, shuffle=sh, shuffle_seed=seed)
+        e.set_item_stream(stream)
+        e.reset()
+        envs.append(e)
+    for t in range(5):
+        rows = [sorted(map(tuple, e.obs[0].reshape(-1, 9)[80:680][e.obs[0].reshape(-1, 9)[80:680, 8] != 0])) for e in envs]
+        assert rows[0] == rows[1] == rows[2]
+        seqs = [e.obs[0].reshape(-1, 9)[80:680].copy() for e in envs]
+        if len(rows[0]) > 3:
+            assert not np.array_equal(seqs[0], seqs[1]) and not np.array_equal(seqs[1], seqs[2])
+        first = seqs[0][0].copy()  # same placement everywhere keeps the states identical
+        for e in envs:
+            e.step_rows(first[None])
