@@ -202,8 +202,10 @@ int pct_debug_state_f64(pct_env* env, int32_t local_id, double* ems, int32_t cap
 
 /* Per-phase cycle accounting of the transition kernel (profiling aid).  on != 0: (re)start
  * accumulation; host_out, if non-NULL, first receives the accumulators gathered so far:
- * uint64 [N,8] = s_memtime cycles in {load, drop_box, GENEMS, candidate set, feasibility,
- * observation write, state store} and the number of steps.  Synchronises the device. */
+ * uint64 [N,16] = s_memtime cycles in {load, drop_box, GENEMS, candidate set, feasibility,
+ * observation write, state store}, the number of steps, then the candidate-set detail
+ * {generation + membership probes, batch de-duplication, matching, rebuilds}.  Synchronises
+ * the device. */
 int pct_debug_phase_timing(pct_env* env, int32_t on, uint64_t* host_out);
 
 #if defined(__HIPCC__)

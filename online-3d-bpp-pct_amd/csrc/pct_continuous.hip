@@ -88,6 +88,7 @@ struct CLds {
   uint16_t* order;  // [order_cap] table iteration order (generator ids)
   uint16_t* vp;     // [64]
   uint32_t* fpri;   // [order_cap] shuffle priorities of the feasible candidates (shuffle only)
+  uint32_t* dd;     // [128] bucket words of the batch de-duplication
 };
 
 __device__ inline CLds carve(const ContinuousParams& p, unsigned char* base) {
@@ -105,6 +106,7 @@ __device__ inline CLds carve(const ContinuousParams& p, unsigned char* base) {
   l.bk = q; q += 4 * p.I;
   l.pend = reinterpret_cast<uint32_t*>(q); q += 128;
   l.bg = reinterpret_cast<uint32_t*>(q); q += 64;
+  l.dd = reinterpret_cast<uint32_t*>(q); q += 128;
   uint16_t* h = reinterpret_cast<uint16_t*>(q);
   l.order = h; h += p.table_global ? 0 : p.order_cap;
   l.vp = h; h += 64;
@@ -114,7 +116,7 @@ __device__ inline CLds carve(const ContinuousParams& p, unsigned char* base) {
 
 size_t continuous_lds_bytes(const ContinuousParams& p) {
   size_t dbl = (size_t)6 * p.ems_cap + p.union_doubles + 9 * (size_t)p.I + 6 * (size_t)p.L + 64;
-  size_t i32 = 4 * (size_t)p.I + 128 + 64;
+  size_t i32 = 4 * (size_t)p.I + 128 + 64 + 128;
   size_t u16 = (size_t)(p.table_global ? 0 : p.order_cap) + 64 + 2;
   if (p.shuffle && !p.table_global) u16 += 2 * (size_t)p.order_cap;
   return dbl * 8 + i32 * 4 + u16 * 2 + 16;
@@ -338,9 +340,12 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
   uint16_t* const order = GT ? p.gorder + gslot * (size_t)p.order_cap : l.order;
   uint32_t toff = table_region(p.cand_cap, size);
   if (lane < 8) tab_st<GT, uint32_t>(&tabs[toff + lane], EMPTY);
+  l.dd[lane] = 0xFFFFFFFFu;
+  l.dd[lane + 64] = 0xFFFFFFFFu;
   __syncthreads();
   bool cand_overflow = false;
   int npend = 0;
+  tm.sub_start();
 
   auto flush = [&](int cnt) {
     bool pending = lane < cnt;
@@ -349,23 +354,21 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
     __syncthreads();
     if (lane + 64 < npend) l.pend[lane] = mv;
     npend -= cnt;
+    tm.sub_tick(PH_SET_GEN);
     double t[6];
     cand_tuple(p, l, r, orient, g, t);
     uint64_t hash = tuplehash6d(t);
     l.bhash[lane] = hash;
     l.bg[lane] = g;
     __syncthreads();
-    {  // exact in-batch de-duplication (first occurrence stays)
-      bool dup = false;
-      for (int i = 0; i < cnt; i++) {
-        if (l.bhash[i] == hash && i < lane && !dup) {
-          double o[6];
-          cand_tuple(p, l, r, orient, l.bg[i], o);
-          dup = tuple_eq(o, t);
-        }
-      }
-      pending = pending && !dup;
-    }
+    // exact in-batch de-duplication (first occurrence stays): equal hashes first, then the tuples
+    pending = pending && !batch_find_duplicates<128>(l.dd, pending, hash, lane, cnt, [&](int w) -> bool {
+      if (l.bhash[w] != hash) return false;
+      double o[6];
+      cand_tuple(p, l, r, orient, l.bg[w], o);
+      return tuple_eq(o, t);
+    });
+    tm.sub_tick(PH_SET_DEDUP);
     const uint32_t word = cword(hash, g);
     auto same = [&](uint32_t w) -> bool {
       if ((w >> 16) != (word >> 16)) return false;  // different hash
@@ -386,6 +389,7 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
       pending = pending && !part;
       fill += (uint32_t)__popcll(__ballot(placed));
       __syncthreads();
+      tm.sub_tick(PH_SET_MATCH);
       if (fill >= thr) {
         uint32_t newsize = 8;
         while (newsize <= fill * 4u) newsize <<= 1;
@@ -411,6 +415,7 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
         }
         toff = noff;
         size = newsize;
+        tm.sub_tick(PH_SET_REBUILD);
       }
     }
   };
@@ -471,6 +476,7 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
     norder += __popcll(m);
   }
   __syncthreads();
+  tm.sub_tick(PH_SET_GEN);
   tm.tick(PH_SET);
 
   // feasibility in list order (C/space.py:380-425 drop_box_virtual), first L kept
@@ -860,7 +866,7 @@ __global__ void __launch_bounds__(64) pct_continuous_kernel(ContinuousParams p, 
   if (!requeue) {
     cstore(p, e, l, r, lane);
     tm.tick(PH_STORE);
-    if (TIMED && lane == 0) tm.flush(p.timing + (size_t)e * 8, n_steps);
+    if (TIMED && lane == 0) tm.flush(p.timing + (size_t)e * 16, n_steps);
   }
   }  // step / reset
   if (requeue && lane == 0) p.retry_ids[atomicAdd(p.retry_count, 1)] = e;

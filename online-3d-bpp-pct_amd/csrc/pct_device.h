@@ -38,7 +38,7 @@ struct DiscreteParams {
   void* leaves;     /* [N,L] packed current leaf nodes */
   int32_t* scalars; /* [N,PCT_SCALARS]: n_ems,n_boxes,n_leaf,item[3],t,-,cursor lo/hi,vol lo/hi */
   uint32_t* flags;  /* [N] sticky PCT_FLAG_* */
-  unsigned long long* timing; /* [N,8] per-phase cycle accumulators, or null */
+  unsigned long long* timing; /* [N,16] per-phase cycle accumulators, or null */
   // stability state (settings 1/3 only; csrc/pct_stab.cuh): per env and placed box
   double* st_stack; /* [N,I,4] committed stack: centre xyz, mass */
   int* st_nsup;     /* [N,I] */

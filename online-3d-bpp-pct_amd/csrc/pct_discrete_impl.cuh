@@ -273,10 +273,14 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
   // ems_b is free outside GENEMS: the queue of keys waiting for insertion + the batch keys
   K* pend = l.ems_b;
   K* bkeys = l.ems_b + PCT_PEND_SLOTS;
+  // 64 bucket words for the batch de-duplication (ems_capacity >= 256 key words is enforced)
+  uint32_t* dd = reinterpret_cast<uint32_t*>(l.ems_b + PCT_PEND_SLOTS + 64);
   if (lane < 8) tabs[toff + lane] = EMPTY;
+  dd[lane] = 0xFFFFFFFFu;
   __syncthreads();
   bool cand_overflow = false;
   int npend = 0;
+  tm.sub_start();
 
   // rotation r of the item (D/space.py:540-562): extents and the skip rule
   auto rot_size = [&](int rot, int& sx, int& sy, int& sz) -> bool {
@@ -300,14 +304,12 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
     bkeys[lane] = key;
     npend -= cnt;
     __syncthreads();
+    tm.sub_tick(PH_SET_GEN);
     // exact in-batch de-duplication: keep the first occurrence (set.add of a present key is a
     // no-op, and the first occurrence is inserted before the later ones in any case)
-    {
-      bool dup = false;
-      for (int i = 0; i < cnt; i++) dup |= (bkeys[i] == key) & (i < lane);
-      pending = pending && !dup;
-    }
     uint64_t hash = tuplehash6<K, BITS>(key);
+    pending = pending && !batch_find_duplicates<64>(dd, pending, hash, lane, cnt, [&](int w) { return bkeys[w] == key; });
+    tm.sub_tick(PH_SET_DEDUP);
     while (true) {
       uint64_t pm = __ballot(pending);
       if (!pm) break;
@@ -323,6 +325,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
       pending = pending && !part;
       fill += (uint32_t)__popcll(__ballot(placed));
       __syncthreads();
+      tm.sub_tick(PH_SET_MATCH);
       if (fill >= thr) {  // set_table_resize(used * 4): re-insert in old-slot order
         uint32_t newsize = 8;
         while (newsize <= fill * 4u) newsize <<= 1;
@@ -346,6 +349,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
         }
         toff = noff;
         size = newsize;
+        tm.sub_tick(PH_SET_REBUILD);
       }
     }
   };
@@ -553,6 +557,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
   while (npend > 0 && !cand_overflow) flush(npend < 64 ? npend : 64);
   if (cand_overflow) r.flags |= PCT_FLAG_CANDIDATE_OVERFLOW;
   __syncthreads();
+  tm.sub_tick(PH_SET_GEN);
   tm.tick(PH_SET);
 
   // iterate the table in slot order (= list(set)), test feasibility, keep the first L
@@ -921,7 +926,7 @@ __global__ void __launch_bounds__(64) pct_discrete_kernel(DiscreteParams p, cons
   }
   store_state<K, BITS>(p, e, l, r, lane);
   tm.tick(PH_STORE);
-  if (TIMED && lane == 0) tm.flush(p.timing + (size_t)e * 8, n_steps);
+  if (TIMED && lane == 0) tm.flush(p.timing + (size_t)e * 16, n_steps);
 }
 
 }  // namespace pct

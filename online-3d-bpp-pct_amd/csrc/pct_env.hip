@@ -539,7 +539,7 @@ int pct_debug_phase_timing(pct_env* h, int32_t on, uint64_t* host_out) {
   if (!h) return fail(PCT_ERR_INVALID_ARG, "null handle");
   int rc = use_device(h);
   if (rc) return rc;
-  size_t bytes = (size_t)h->dp.N * 8 * sizeof(unsigned long long);
+  size_t bytes = (size_t)h->dp.N * 16 * sizeof(unsigned long long);
   HIP_TRY(hipDeviceSynchronize());
   if (host_out && h->timing_buf) HIP_TRY(hipMemcpy(host_out, h->timing_buf, bytes, hipMemcpyDeviceToHost));
   if (on) {

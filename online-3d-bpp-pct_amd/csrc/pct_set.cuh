@@ -185,6 +185,41 @@ __device__ inline void pyset_match(K* tab, uint32_t mask, bool part, uint64_t ha
   }
 }
 
+// Exact removal of duplicates inside a batch of <= 64 keys (lane = position in insertion order):
+// returns true for a lane whose key also sits in an EARLIER active lane.  Lanes scatter their
+// lane id into a bucket chosen by hash bits (LDS atomicMin); the minimum lane of a bucket is the
+// first holder of every key hashing there, so it is unique; any other lane compares with that
+// minimum lane (`same_as(w)`): equal -> duplicate, different -> the two merely collided and both
+// the later lane and all its potential duplicates (same hash, hence same bucket in every round)
+// stay for the next round, which uses other hash bits.  `dd` = NB words of LDS, all ones.
+template <int NB, typename SameAs>
+__device__ inline bool batch_find_duplicates(uint32_t* dd, bool active, uint64_t hash, int lane, int cnt,
+                                             SameAs same_as) {
+  bool unresolved = active, dup = false;
+  for (int round = 0; round < 8; round++) {
+    if (!__ballot(unresolved)) return dup;
+    const uint32_t b = (uint32_t)(hash >> (3 + 7 * round)) & (uint32_t)(NB - 1);
+    if (unresolved) atomicMin(&dd[b], (uint32_t)lane);
+    __syncthreads();
+    const uint32_t w = unresolved ? dd[b] : (uint32_t)lane;
+    __syncthreads();
+    if (unresolved) {
+      dd[b] = 0xFFFFFFFFu;
+      if (w == (uint32_t)lane) {
+        unresolved = false;
+      } else if (same_as((int)w)) {
+        dup = true;
+        unresolved = false;
+      }
+    }
+    __syncthreads();
+  }
+  // eight rounds of pure collisions between distinct keys: fall back to the exhaustive scan
+  for (int i = 0; i < cnt; i++)
+    if (unresolved && i < lane && same_as(i)) dup = true;
+  return dup;
+}
+
 // Which LDS region holds a table of `size` slots (ping-pong so that a resize can stream
 // old -> new without a temporary): cap in region 0, cap/4 in region 1, cap/16 in 0, ...
 // Returned as a slot OFFSET from tab0 (tab1 follows tab0 in LDS) so that every table access
@@ -205,13 +240,15 @@ struct PhaseTimer {
   __device__ inline void start() {}
   __device__ inline void tick(int) {}
   __device__ inline void flush(unsigned long long*, int) {}
+  __device__ inline void sub_start() {}
+  __device__ inline void sub_tick(int) {}
 };
 template <>
 struct PhaseTimer<true> {
   uint64_t last;
-  uint64_t acc[8];
+  uint64_t acc[16];
   __device__ inline void start() {
-    for (int i = 0; i < 8; i++) acc[i] = 0;
+    for (int i = 0; i < 16; i++) acc[i] = 0;
     last = __builtin_readcyclecounter();
   }
   __device__ inline void tick(int i) {
@@ -219,12 +256,23 @@ struct PhaseTimer<true> {
     acc[i] += now - last;
     last = now;
   }
+  uint64_t sub_last;
+  __device__ inline void sub_start() { sub_last = __builtin_readcyclecounter(); }
+  __device__ inline void sub_tick(int i) {
+    uint64_t now = __builtin_readcyclecounter();
+    acc[i] += now - sub_last;
+    sub_last = now;
+  }
   __device__ inline void flush(unsigned long long* o, int n_steps) {
-    for (int i = 0; i < 7; i++) o[i] += acc[i];
+    for (int i = 0; i < 16; i++)
+      if (i != 7) o[i] += acc[i];
     o[7] += (unsigned long long)n_steps;
   }
 };
-enum { PH_LOAD = 0, PH_DROP = 1, PH_GENEMS = 2, PH_SET = 3, PH_FEAS = 4, PH_OBS = 5, PH_STORE = 6, PH_STEPS = 7 };
+enum { PH_LOAD = 0, PH_DROP = 1, PH_GENEMS = 2, PH_SET = 3, PH_FEAS = 4, PH_OBS = 5, PH_STORE = 6, PH_STEPS = 7,
+       // detail of PH_SET (they sum to it): tuple generation + membership probes, batch de-duplication,
+       // matching passes, table rebuilds
+       PH_SET_GEN = 8, PH_SET_DEDUP = 9, PH_SET_MATCH = 10, PH_SET_REBUILD = 11 };
 
 
 }  // namespace pct

@@ -113,8 +113,9 @@ class VecEnv(ABC):
         return n.value, ms.value
 
     def phase_timing(self, on=True):
-        """Start/stop per-phase cycle accounting; returns the uint64 [N,8] gathered so far."""
-        out = np.zeros((self.N, 8), np.uint64)
+        """Start/stop per-phase cycle accounting; returns the uint64 [N,16] gathered so far
+        (columns: load, drop, genems, set, feas, obs, store, steps, set-gen, set-dedup, set-match, set-rebuild)."""
+        out = np.zeros((self.N, 16), np.uint64)
         _lib.check(self._L.pct_debug_phase_timing(self._h, int(bool(on)), out.ctypes.data))
         return out
 

@@ -27,7 +27,8 @@ torch.cuda.synchronize()
 env.phase_timing(True)
 per_step_max = []
 names = ["load", "drop", "genems", "set", "feas", "obs", "store"]
-prev = np.zeros((N, 8), np.uint64)
+sub = {8: "set.gen", 9: "set.dedup", 10: "set.match", 11: "set.rebuild"}
+prev = np.zeros((N, 16), np.uint64)
 for s in range(K):
     env.policy_hash_rows(rows)
     env.step_rows_device(rows)
@@ -48,6 +49,9 @@ tot = acc[:, :7].sum(1) / steps
 for i, n in enumerate(names):
     v = acc[:, i] / steps
     print("  %-7s mean %9.0f cyc  p99 %9.0f  max %9.0f   (%.1f%%)" % (n, v.mean(), np.percentile(v, 99), v.max(), 100 * v.mean() / tot.mean()))
+for i, n in sub.items():
+    v = acc[:, i] / steps
+    print("    %-11s mean %9.0f cyc  p99 %9.0f  max %9.0f" % (n, v.mean(), np.percentile(v, 99), v.max()))
 print("  total   mean %9.0f cyc  p99 %9.0f  max %9.0f" % (tot.mean(), np.percentile(tot, 99), tot.max()))
 pm = np.array(per_step_max)
 print("per-10-step windows: mean of env-mean %.0f, mean of env-p99 %.0f, mean of env-max %.0f cycles/step" % tuple(pm.mean(0)))
