@@ -27,6 +27,8 @@
 #include "../../include/pct_env.h"
 #include "pct_device.h"
 
+#include <type_traits>
+
 #include "pct_set.cuh"
 #include "pct_stab.cuh"
 
@@ -67,31 +69,40 @@ struct EnvRegs {  // wave-uniform per-env scalars
 
 template <typename K, int BITS>
 struct Lds {
-  K* tab0;
-  K* tab1;
-  K* ems_a;
-  K* ems_b;
+  typedef typename std::conditional<sizeof(K) == 4, uint8_t, int16_t>::type HT;  // heights <= 31 fit a byte
+  K* tab0;     // candidate hash table(s): table_words_compact(cand_cap) key words
+  K* ems_a;    // [ems_cap] current EMS list
+  K* ems_b;    // GENEMS scratch list: aliases the table region (idle during GENEMS)
+  K* pend;     // [128] keys waiting for insertion
+  uint32_t* dd;  // [64] bucket words of the batch de-duplication
   K* box;
   K* leaf;
-  int16_t* hmap;
+  HT* hmap;
   uint16_t* vp; /* [64] valid (ems, rotation) pairs of the current chunk */
   uint32_t* cp; /* corner-point scratch: 4 arrays of I+2 words (only when lnes == CP) */
   K* fkey;       /* shuffle: feasible candidates in list order ... */
   uint32_t* fpri; /* ... and their priorities (only when shuffle) */
 };
 
+__host__ __device__ inline int discrete_scratch_words(const DiscreteParams& p) {
+  return 128 + (int)(64 * sizeof(uint32_t) / p.key_bytes);  // pend[128] + dd[64 x u32]
+}
+
 template <typename K, int BITS>
 __device__ inline Lds<K, BITS> carve_lds(const DiscreteParams& p, unsigned char* base) {
   Lds<K, BITS> l;
   K* q = reinterpret_cast<K*>(base);
-  l.tab0 = q; q += p.cand_cap;
-  l.tab1 = q; q += p.cand_cap / 4;
+  l.tab0 = q; q += table_words_compact((uint32_t)p.cand_cap);
   l.ems_a = q; q += p.ems_cap;
-  l.ems_b = q; q += p.ems_cap;
+  l.ems_b = l.tab0;
+  l.pend = q;
+  l.dd = reinterpret_cast<uint32_t*>(q + 128);
+  q += discrete_scratch_words(p);
   l.box = q; q += p.I;
   l.leaf = q; q += p.L;
-  l.hmap = reinterpret_cast<int16_t*>(q);
-  l.vp = reinterpret_cast<uint16_t*>(l.hmap + p.AA);
+  l.hmap = reinterpret_cast<typename Lds<K, BITS>::HT*>(q);
+  size_t hb = ((size_t)p.AA * sizeof(typename Lds<K, BITS>::HT) + 3) & ~(size_t)3;
+  l.vp = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(q) + hb);
   l.cp = reinterpret_cast<uint32_t*>(l.vp + 64);
   uint32_t* after_cp = l.cp + (p.lnes == PCT_LNES_CP ? 4 * (p.I + 2) : 0);
   const int fcap = (p.cand_cap * 3) / 5 + 2;
@@ -169,6 +180,7 @@ __device__ inline void genems(const DiscreteParams& p, Lds<K, BITS>& l, EnvRegs&
                               int bz0, int bx1, int by1, int bz1) {
   typedef Pack<K, BITS> P;
   const int E = r.n_ems;
+  const int scap = (int)table_words_compact((uint32_t)p.cand_cap);  // pre-elimination list capacity
   const int lb = p.low_bound <= 0 ? 1 : p.low_bound;
   const uint64_t lt = lanemask_lt(lane);
   // sweep 1: survivors (EMS not intersected by the box) keep their order at the front
@@ -210,17 +222,17 @@ __device__ inline void genems(const DiscreteParams& p, Lds<K, BITS>& l, EnvRegs&
     uint64_t m0 = __ballot(c0), m1 = __ballot(c1), m2 = __ballot(c2), m3 = __ballot(c3), m4 = __ballot(c4);
     int pos = S + C + __popcll(m0 & lt) + __popcll(m1 & lt) + __popcll(m2 & lt) + __popcll(m3 & lt) +
               __popcll(m4 & lt);
-    if (c0) { if (pos < p.ems_cap) l.ems_b[pos] = P::pack(x1, y1, z1, x3, y2, z2); pos++; }
-    if (c1) { if (pos < p.ems_cap) l.ems_b[pos] = P::pack(x4, y1, z1, x2, y2, z2); pos++; }
-    if (c2) { if (pos < p.ems_cap) l.ems_b[pos] = P::pack(x1, y1, z1, x2, y3, z2); pos++; }
-    if (c3) { if (pos < p.ems_cap) l.ems_b[pos] = P::pack(x1, y4, z1, x2, y2, z2); pos++; }
-    if (c4) { if (pos < p.ems_cap) l.ems_b[pos] = P::pack(x1, y1, z4, x2, y2, z2); pos++; }
+    if (c0) { if (pos < scap) l.ems_b[pos] = P::pack(x1, y1, z1, x3, y2, z2); pos++; }
+    if (c1) { if (pos < scap) l.ems_b[pos] = P::pack(x4, y1, z1, x2, y2, z2); pos++; }
+    if (c2) { if (pos < scap) l.ems_b[pos] = P::pack(x1, y1, z1, x2, y3, z2); pos++; }
+    if (c3) { if (pos < scap) l.ems_b[pos] = P::pack(x1, y4, z1, x2, y2, z2); pos++; }
+    if (c4) { if (pos < scap) l.ems_b[pos] = P::pack(x1, y1, z4, x2, y2, z2); pos++; }
     C += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3) + __popcll(m4);
   }
   int n = S + C;
-  if (n > p.ems_cap) {
+  if (n > scap) {
     overflow = true;
-    n = p.ems_cap;
+    n = scap;
   }
   if (overflow) r.flags |= PCT_FLAG_EMS_OVERFLOW;
   __syncthreads();
@@ -247,8 +259,13 @@ __device__ inline void genems(const DiscreteParams& p, Lds<K, BITS>& l, EnvRegs&
     }
     bool keep = live && !del;
     uint64_t m = __ballot(keep);
-    if (keep) l.ems_a[out + __popcll(m & lt)] = k;
+    int o = out + __popcll(m & lt);
+    if (keep && o < p.ems_cap) l.ems_a[o] = k;
     out += __popcll(m);
+  }
+  if (out > p.ems_cap) {  // the list that survives elimination must fit the state array
+    out = p.ems_cap;
+    r.flags |= PCT_FLAG_EMS_OVERFLOW;
   }
   r.n_ems = out;
   __syncthreads();
@@ -269,12 +286,10 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
   const K EMPTY = SlotWord<K>::EMPTY;
   uint32_t size = 8, fill = 0;
   K* const tabs = l.tab0;  // both table regions, contiguous
-  uint32_t toff = table_region(p.cand_cap, size);
+  uint32_t toff = table_offset_compact((uint32_t)p.cand_cap, size);
   // ems_b is free outside GENEMS: the queue of keys waiting for insertion + the batch keys
-  K* pend = l.ems_b;
-  K* bkeys = l.ems_b + PCT_PEND_SLOTS;
-  // 64 bucket words for the batch de-duplication (ems_capacity >= 256 key words is enforced)
-  uint32_t* dd = reinterpret_cast<uint32_t*>(l.ems_b + PCT_PEND_SLOTS + 64);
+  K* const pend = l.pend;
+  uint32_t* const dd = l.dd;
   if (lane < 8) tabs[toff + lane] = EMPTY;
   dd[lane] = 0xFFFFFFFFu;
   __syncthreads();
@@ -301,14 +316,13 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
     K mv = (lane + 64 < npend) ? pend[lane + 64] : (K)0;
     __syncthreads();
     if (lane + 64 < npend) pend[lane] = mv;
-    bkeys[lane] = key;
     npend -= cnt;
     __syncthreads();
     tm.sub_tick(PH_SET_GEN);
     // exact in-batch de-duplication: keep the first occurrence (set.add of a present key is a
     // no-op, and the first occurrence is inserted before the later ones in any case)
     uint64_t hash = tuplehash6<K, BITS>(key);
-    pending = pending && !batch_find_duplicates<64>(dd, pending, hash, lane, cnt, [&](int w) { return bkeys[w] == key; });
+    pending = pending && !batch_find_duplicates_reg<64, K>(dd, pending, key, hash, lane);
     tm.sub_tick(PH_SET_DEDUP);
     while (true) {
       uint64_t pm = __ballot(pending);
@@ -333,19 +347,46 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
           cand_overflow = true;
           break;
         }
-        const uint32_t noff = table_region(p.cand_cap, newsize);
-        for (uint32_t s2 = lane; s2 < newsize; s2 += 64) tabs[noff + s2] = EMPTY;
-        __syncthreads();
-        for (uint32_t sb = 0; sb < size; sb += 64) {
-          uint32_t s2 = sb + lane;
-          K ok = (s2 < size) ? tabs[toff + s2] : EMPTY;
-          bool opart = ok != EMPTY;
-          bool oplaced;
-          uint32_t oslot;
-          pyset_match<K>(tabs + noff, newsize - 1, opart, tuplehash6<K, BITS>(ok), lane, false, oplaced, oslot,
-                         [&](K) { return false; });
-          if (oplaced) tabs[noff + oslot] = ok;
+        const uint32_t noff = table_offset_compact((uint32_t)p.cand_cap, newsize);
+        if (noff == toff) {
+          // same region: lift the old table (<= 512 slots = 8 per lane) into registers, wipe, and
+          // re-insert chunk by chunk in old-slot order
+          K oldk[8];
+#pragma unroll
+          for (int c = 0; c < 8; c++) {
+            uint32_t s2 = (uint32_t)c * 64u + lane;
+            oldk[c] = (s2 < size) ? tabs[toff + s2] : EMPTY;
+          }
           __syncthreads();
+          for (uint32_t s2 = lane; s2 < newsize; s2 += 64) tabs[noff + s2] = EMPTY;
+          __syncthreads();
+#pragma unroll
+          for (int c = 0; c < 8; c++) {
+            if ((uint32_t)c * 64u < size) {
+              K ok = oldk[c];
+              bool opart = ok != EMPTY;
+              bool oplaced;
+              uint32_t oslot;
+              pyset_match<K>(tabs + noff, newsize - 1, opart, tuplehash6<K, BITS>(ok), lane, false, oplaced, oslot,
+                             [&](K) { return false; });
+              if (oplaced) tabs[noff + oslot] = ok;
+              __syncthreads();
+            }
+          }
+        } else {
+          for (uint32_t s2 = lane; s2 < newsize; s2 += 64) tabs[noff + s2] = EMPTY;
+          __syncthreads();
+          for (uint32_t sb = 0; sb < size; sb += 64) {
+            uint32_t s2 = sb + lane;
+            K ok = (s2 < size) ? tabs[toff + s2] : EMPTY;
+            bool opart = ok != EMPTY;
+            bool oplaced;
+            uint32_t oslot;
+            pyset_match<K>(tabs + noff, newsize - 1, opart, tuplehash6<K, BITS>(ok), lane, false, oplaced, oslot,
+                           [&](K) { return false; });
+            if (oplaced) tabs[noff + oslot] = ok;
+            __syncthreads();
+          }
         }
         toff = noff;
         size = newsize;
@@ -690,7 +731,7 @@ __device__ inline void load_state(const DiscreteParams& p, int e, Lds<K, BITS>& 
   for (int i = lane; i < r.n_ems; i += 64) l.ems_a[i] = g_ems[i];
   for (int i = lane; i < r.n_boxes; i += 64) l.box[i] = g_box[i];
   for (int i = lane; i < r.n_leaf; i += 64) l.leaf[i] = g_leaf[i];
-  for (int i = lane; i < p.AA; i += 64) l.hmap[i] = g_h[i];
+  for (int i = lane; i < p.AA; i += 64) l.hmap[i] = (typename Lds<K, BITS>::HT)g_h[i];
   __syncthreads();
 }
 
@@ -704,7 +745,7 @@ __device__ inline void store_state(const DiscreteParams& p, int e, const Lds<K, 
   for (int i = lane; i < r.n_ems; i += 64) g_ems[i] = l.ems_a[i];
   for (int i = lane; i < r.n_boxes; i += 64) g_box[i] = l.box[i];
   for (int i = lane; i < r.n_leaf; i += 64) g_leaf[i] = l.leaf[i];
-  for (int i = lane; i < p.AA; i += 64) g_h[i] = l.hmap[i];
+  for (int i = lane; i < p.AA; i += 64) g_h[i] = (int16_t)l.hmap[i];
   if (lane == 0) {
     sc[0] = r.n_ems; sc[1] = r.n_boxes; sc[2] = r.n_leaf;
     sc[3] = r.item0; sc[4] = r.item1; sc[5] = r.item2;
@@ -797,7 +838,7 @@ __device__ inline void transition(const DiscreteParams& p, int e, Lds<K, BITS>& 
     for (int tx = lx; tx < lx + x; tx += 8)
       for (int ty = ly; ty < ly + y; ty += 8) {
         int cx = tx + (lane >> 3), cy = ty + (lane & 7);
-        if (cx < lx + x && cy < ly + y) l.hmap[cx * p.A + cy] = (int16_t)top;
+        if (cx < lx + x && cy < ly + y) l.hmap[cx * p.A + cy] = (typename Lds<K, BITS>::HT)top;
       }
     if (lane == 0) l.box[r.n_boxes] = P::pack(lx, ly, max_h, lx + x, ly + y, top);
     r.n_boxes++;
@@ -938,10 +979,11 @@ namespace pct {
 
 inline size_t discrete_lds_bytes_impl(const DiscreteParams& p) {
   size_t k = p.key_bytes;
-  size_t n = (size_t)p.cand_cap + p.cand_cap / 4 + 2 * (size_t)p.ems_cap + p.I + p.L;
+  size_t n = (size_t)table_words_compact((uint32_t)p.cand_cap) + p.ems_cap + discrete_scratch_words(p) + p.I + p.L;
+  size_t hb = ((size_t)p.AA * (k == 4 ? 1 : 2) + 3) & ~(size_t)3;
   size_t cp = p.lnes == PCT_LNES_CP ? 4 * (size_t)(p.I + 2) * sizeof(uint32_t) : 0;
   if (p.shuffle) cp += ((size_t)(p.cand_cap * 3) / 5 + 4) * (sizeof(uint32_t) + k);
-  return n * k + (size_t)p.AA * sizeof(int16_t) + 64 * sizeof(uint16_t) + cp + 16;
+  return n * k + hb + 64 * sizeof(uint16_t) + cp;
 }
 
 template <typename K, int BITS>

@@ -162,8 +162,10 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
   if (!cont && maxdim > 1023) return fail(PCT_ERR_UNSUPPORTED, "discrete bins are limited to 1023 per axis");
   if (cont && (W % 1000 || Ly % 1000 || H % 1000))
     return fail(PCT_ERR_UNSUPPORTED, "continuous container sizes must be whole bin units (multiples of 1000 lattice units)");
-  int ems_cap = cfg->ems_capacity > 0 ? cfg->ems_capacity : 256;
-  if (!cont && ems_cap < 256) return fail(PCT_ERR_INVALID_ARG, "ems_capacity must be >= 256");
+  /* discrete bins <= 31 per axis (32-bit keys): 128 EMS (82 is the most the 10^3 probes ever
+   * held before elimination) keeps the env at 10 KB of LDS = 16 resident envs per CU */
+  int ems_cap = cfg->ems_capacity > 0 ? cfg->ems_capacity : ((!cont && maxdim <= 31) ? 128 : 256);
+  if (!cont && ems_cap < 64) return fail(PCT_ERR_INVALID_ARG, "ems_capacity must be >= 64");
   int cand_cap = cfg->candidate_capacity > 0 ? cfg->candidate_capacity : 2048;
   if (!is_cand_cap_ok(cand_cap)) return fail(PCT_ERR_INVALID_ARG, "candidate_capacity must be 8*4^k (8,32,...,2048,8192)");
 

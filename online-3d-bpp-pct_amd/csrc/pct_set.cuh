@@ -220,6 +220,56 @@ __device__ inline bool batch_find_duplicates(uint32_t* dd, bool active, uint64_t
   return dup;
 }
 
+template <typename K>
+__device__ inline K shfl_key(K v, int src);
+template <>
+__device__ inline uint32_t shfl_key<uint32_t>(uint32_t v, int src) {
+  return (uint32_t)__shfl((int)v, src, 64);
+}
+template <>
+__device__ inline uint64_t shfl_key<uint64_t>(uint64_t v, int src) {
+  uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, 64);
+  uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// Same, for keys that fit a register: the minimum lane's key is fetched with a cross-lane
+// shuffle instead of an LDS copy of the batch.
+template <int NB, typename K>
+__device__ inline bool batch_find_duplicates_reg(uint32_t* dd, bool active, K key, uint64_t hash, int lane) {
+  bool unresolved = active, dup = false;
+  for (int round = 0; round < 9; round++) {
+    if (!__ballot(unresolved)) return dup;
+    const uint32_t b = (uint32_t)(hash >> (3 + 6 * round)) & (uint32_t)(NB - 1);
+    if (unresolved) atomicMin(&dd[b], (uint32_t)lane);
+    __syncthreads();
+    const uint32_t w = unresolved ? dd[b] : (uint32_t)lane;
+    __syncthreads();
+    const K kw = shfl_key<K>(key, (int)(w & 63u));
+    if (unresolved) {
+      dd[b] = 0xFFFFFFFFu;
+      if (w == (uint32_t)lane) unresolved = false;
+      else if (kw == key) { dup = true; unresolved = false; }
+    }
+    __syncthreads();
+  }
+  // nine rounds of pure collisions between distinct keys: exhaustive scan
+  for (int i = 0; i < 64; i++) {
+    const K ki = shfl_key<K>(key, i);
+    const bool ai = (__ballot(active) >> i) & 1ull;
+    if (unresolved && ai && i < lane && ki == key) dup = true;
+  }
+  return dup;
+}
+
+// Tables of a set with capacity `cap` in ONE LDS region: every size up to 2048 slots starts at
+// offset 0 (a rebuild first lifts the <= 512 old slots into registers, then reuses the space);
+// only a final table larger than 2048 slots lives behind the quarter-size region it grows from.
+__device__ inline uint32_t table_offset_compact(uint32_t cap, uint32_t size) {
+  return (cap > 2048u && size == cap) ? cap / 4u : 0u;
+}
+__device__ __host__ inline uint32_t table_words_compact(uint32_t cap) { return cap > 2048u ? cap + cap / 4u : cap; }
+
 // Which LDS region holds a table of `size` slots (ping-pong so that a resize can stream
 // old -> new without a temporary): cap in region 0, cap/4 in region 1, cap/16 in 0, ...
 // Returned as a slot OFFSET from tab0 (tab1 follows tab0 in LDS) so that every table access

@@ -128,7 +128,8 @@ def test_hip_matches_oracle_random_streams(cfg):
     ora = OracleVecEnv(cfg["N"], **kw)
     ora.set_item_stream(stream)
     env = _pkg().PctVecEnv(cfg["N"], item_stream=stream, device="cuda:0",
-                           candidate_capacity=8192 if max(cfg["container"]) > 31 else 0, **kw)
+                           candidate_capacity=8192 if max(cfg["container"]) > 31 else 0,
+                           ems_capacity=256 if max(cfg["container"]) > 10 else 0, **kw)
     ora.reset()
     obs = env.reset()
     for t in range(cfg["steps"]):
