@@ -140,6 +140,18 @@ int pct_set_item_stream(pct_env* env, const int32_t* items, int64_t T);
  * (:69-72).  All envs walk the same trajectory sequence, like the reference's workers. */
 int pct_set_item_dataset(pct_env* env, const int32_t* items, const int32_t* lengths, int32_t n_traj,
                          int32_t max_len);
+/* Setting 3 (random item densities, D/bin3D.py:76,80-84; box mass = volume x density in the
+ * stability check, space.py:38).  The reference draws np.random.random() at every
+ * cur_observation(); here the density of an env's c-th observation (c counts every observation
+ * the env has produced, including the one of a terminal step that the VecEnv worker discards) is
+ *   - den[e, c % T] after pct_set_density_stream (host float64 [N,T], scripted), else
+ *   - pct_density(seed, global env id, c), the counter-based uniform (0,1) draw below;
+ * under pct_set_item_dataset it is the fourth column of the previewed dataset item
+ * (bin3D.py:76 `next_box[3]`): pct_set_dataset_density takes it as host float64
+ * [n_traj, max_len], same indexing as `items`; the sentinel items carry density 1 (the
+ * reference raises IndexError on them).  Ignored unless pct_config.setting == 3. */
+int pct_set_density_stream(pct_env* env, const double* den, int64_t T);
+int pct_set_dataset_density(pct_env* env, const double* den);
 /* Counter-based sampler: the c-th draw of global env g is
  * item_set[pct_mix64(seed, g, c) % n] (discrete) -- see pct_mix64 below. */
 int pct_set_sampler(pct_env* env, uint64_t seed);
@@ -229,6 +241,13 @@ PCT_INLINE uint64_t pct_mix64(uint64_t seed, uint64_t env_global_id, uint64_t co
  * still checked bit for bit; against the reference the comparison is distributional. */
 PCT_INLINE uint32_t pct_shuffle_priority(uint64_t seed, uint64_t env_global_id, uint64_t obs_counter, uint32_t i) {
   return (uint32_t)(pct_mix64(seed ^ 0x5BD1E9955BD1E995ull, env_global_id, (obs_counter << 20) | (uint64_t)i) >> 32);
+}
+/* setting 3: density of observation `obs_counter` -- uniform on (0,1), k * 2^-53 with k >= 1
+ * (np.random.random() redrawn while it is 0, bin3D.py:82-84) */
+PCT_INLINE double pct_density(uint64_t seed, uint64_t env_global_id, uint64_t obs_counter) {
+  uint64_t k = pct_mix64(seed ^ 0xD6E8FEB86659FD93ull, env_global_id, obs_counter) >> 11;
+  if (k == 0) k = 1;
+  return (double)k * (1.0 / 9007199254740992.0);
 }
 PCT_INLINE uint32_t pct_mix32(uint32_t env_global_id, uint32_t t) {
   uint32_t h = env_global_id * 0x9E3779B1u + t * 0x85EBCA77u + 0xC2B2AE3Du;

@@ -216,6 +216,7 @@ __device__ inline StabState cstab_view(const ContinuousParams& p, int e) {
   st.share = p.st_share + (size_t)e * p.I * STAB_SMAX * 4;
   st.npoly = p.st_npoly + (size_t)e * p.I;
   st.poly = p.st_poly + (size_t)e * p.I * STAB_PMAX * 2;
+  st.den = p.st_den + (size_t)e * p.I;
   return st;
 }
 
@@ -483,6 +484,7 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
   int nleaf = 0;
   bool stab_err = false;
   const int nb = r.n_boxes;
+  const double next_den = STAB ? next_density(p, e, r.oc, r.traj, r.cursor - 1) : 1.0;  // C/bin3D.py:81-90
   auto feasible = [&](const double t[6]) -> bool {
     double lx = t[0], ly = t[1];
     double x = t[3] - t[0], y = t[4] - t[1], z = t[5] - t[2];
@@ -503,7 +505,7 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
       const double cand[9] = {lx, ly, max_h, lx + x, ly + y, max_h + z, x, y, z};
       CGeo geo{l.box, l.bsz, p.I};
       bool err;
-      ok = stab_virtual<true>(geo, cstab_view(p, e), nb, cand, 1.0, err);
+      ok = stab_virtual<true>(geo, cstab_view(p, e), nb, cand, next_den, err);
       if (err) stab_err = true;
     }
     return ok;
@@ -572,8 +574,9 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
 }
 
 // C/bin3D.py:78-100 observation rows, float32 (envs.py:180)
-__device__ inline void cwrite_obs(const ContinuousParams& p, const CLds& l, const CRegs& r, int lane,
+__device__ inline void cwrite_obs(const ContinuousParams& p, int e, const CLds& l, const CRegs& r, int lane,
                                   float* __restrict__ obs) {
+  const float nden = (float)next_density(p, e, r.oc - 1, r.traj, r.cursor - 1);  // C/bin3D.py:81-90,98
   double a = r.b0, b = r.b1, c = r.b2, tmp;
   if (a > b) { tmp = a; a = b; b = tmp; }
   if (b > c) { tmp = b; b = c; c = tmp; }
@@ -592,7 +595,7 @@ __device__ inline void cwrite_obs(const ContinuousParams& p, const CLds& l, cons
       int j = row - p.I;
       if (j < r.n_leaf) v = col < 5 ? (float)l.leaf[col * p.L + j] : (col == 5 ? (float)p.H : (col == 8 ? 1.0f : 0.f));
     } else {
-      v = col == 0 ? 1.0f : (col == 3 ? (float)a : (col == 4 ? (float)b : (col == 5 ? (float)c : (col == 8 ? 1.0f : 0.f))));
+      v = col == 0 ? nden : (col == 3 ? (float)a : (col == 4 ? (float)b : (col == 5 ? (float)c : (col == 8 ? 1.0f : 0.f))));
     }
     obs[f] = v;
   }
@@ -694,7 +697,7 @@ __device__ inline void ctransition(const ContinuousParams& p, int e, CLds& l, CR
       CGeo geo{l.box, l.bsz, p.I};
       StabState st = cstab_view(p, e);
       bool err;
-      verdict = stab_commit<true>(geo, st, bi, 1.0, err) ? 1 : 0;
+      verdict = stab_commit<true>(geo, st, bi, next_density(p, e, r.oc - 1, r.traj, r.cursor - 1), err) ? 1 : 0;
       serr = err ? 1 : 0;
     }
     verdict = __shfl(verdict, 0, 64);
@@ -806,7 +809,7 @@ __global__ void __launch_bounds__(64) pct_continuous_kernel(ContinuousParams p, 
     cdraw_item(p, e, r);
     requeue = cleaf_nodes<GT, STAB>(p, e, l, r, lane, tm);
     if (!requeue) {
-      cwrite_obs(p, l, r, lane, obs);
+      cwrite_obs(p, e, l, r, lane, obs);
       cstore(p, e, l, r, lane);
     }
   } else {
@@ -859,7 +862,7 @@ __global__ void __launch_bounds__(64) pct_continuous_kernel(ContinuousParams p, 
     ctransition<STAB>(p, e, l, r, lane, flag, p1, p2, bx, by, bz, tm);
     requeue = cleaf_nodes<GT, STAB>(p, e, l, r, lane, tm);
     if (requeue) break;
-    cwrite_obs(p, l, r, lane, obs);
+    cwrite_obs(p, e, l, r, lane, obs);
     __syncthreads();
     tm.tick(PH_OBS);
   }

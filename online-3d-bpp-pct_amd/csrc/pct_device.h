@@ -46,6 +46,11 @@ struct DiscreteParams {
   double* st_share; /* [N,I,STAB_SMAX,4] share handed to each supporter */
   int* st_npoly;    /* [N,I] */
   double* st_poly;  /* [N,I,STAB_PMAX,2] scaled support polygon */
+  double* st_den;   /* [N,I] density of each placed box (1.0 unless setting 3) */
+  // setting 3 density source (include/pct_env.h pct_set_density_stream / pct_set_dataset_density)
+  const double* den_stream; /* [N,den_T] or null */
+  long long den_T;
+  const double* ds_den;     /* dataset mode: [n_traj,max_len] or null */
   // outputs
   float* obs;       /* [N,row_len] */
   float* reward;    /* [N] */
@@ -81,6 +86,10 @@ struct ContinuousParams {
   double* st_share;
   int* st_npoly;
   double* st_poly;
+  double* st_den;
+  const double* den_stream; /* setting 3 density source, as in DiscreteParams */
+  long long den_T;
+  const double* ds_den;
   int table_global; /* 1: hash table + order list live in HBM (capacity beyond LDS) */
   uint32_t* gtab;   /* [N, cand_cap*5/4] */
   uint16_t* gorder; /* [N, order_cap] */
@@ -98,6 +107,20 @@ struct ContinuousParams {
   int32_t* counter;
   double* ratio;
 };
+
+// D/bin3D.py:75-84 next_den of the observation number `oc` (the env's life-long observation
+// counter); traj / item_index locate the previewed item in dataset mode.
+template <typename Params>
+__device__ inline double next_density(const Params& p, int e, uint32_t oc, int traj, unsigned long long item_index) {
+  if (p.setting != 3) return 1.0;
+  if (p.source == PCT_ITEMS_DATASET) {  // self.next_box[3]
+    int t = traj < p.ds_ntraj ? traj : p.ds_ntraj - 1;
+    if (!p.ds_den || t < 0 || item_index >= (unsigned long long)p.ds_len[t]) return 1.0;
+    return p.ds_den[(size_t)t * p.ds_maxlen + (size_t)item_index];
+  }
+  if (p.den_stream) return p.den_stream[(size_t)e * (size_t)p.den_T + (size_t)((unsigned long long)oc % (unsigned long long)p.den_T)];
+  return pct_density(p.seed, (uint64_t)(p.env_id_base + e), (uint64_t)oc);
+}
 
 size_t continuous_lds_bytes(const ContinuousParams& p);
 hipError_t launch_cpolicy_hash_rows(const ContinuousParams& p, float* rows_out, hipStream_t stream);

@@ -131,6 +131,7 @@ __device__ inline StabState stab_view(const DiscreteParams& p, int e) {
   st.share = p.st_share + (size_t)e * p.I * STAB_SMAX * 4;
   st.npoly = p.st_npoly + (size_t)e * p.I;
   st.poly = p.st_poly + (size_t)e * p.I * STAB_PMAX * 2;
+  st.den = p.st_den + (size_t)e * p.I;
   return st;
 }
 
@@ -604,6 +605,8 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
   // iterate the table in slot order (= list(set)), test feasibility, keep the first L
   int nleaf = 0;
   bool stab_err = false;
+  // D/bin3D.py:75-84: the density drawn for this observation (setting 3), else 1
+  const double next_den = STAB ? next_density(p, e, r.oc, r.traj, r.cursor - 1) : 1.0;
   auto feasible = [&](K k) -> bool {
     int xs = P::get(k, 0), ys = P::get(k, 1), xe = P::get(k, 3), ye = P::get(k, 4);
     int z = P::get(k, 5) - P::get(k, 2);
@@ -620,7 +623,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
                               (double)(xe - xs), (double)(ye - ys), (double)z};
       BoxGeo<K, BITS> geo{l.box};
       bool err;
-      feas = stab_virtual<false>(geo, stab_view(p, e), r.n_boxes, cand, 1.0, err);
+      feas = stab_virtual<false>(geo, stab_view(p, e), r.n_boxes, cand, next_den, err);
       if (err) stab_err = true;
     }
     return feas;
@@ -678,7 +681,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
 
 // D/bin3D.py:70-93: the [I+L+1, 9] float32 observation, written once, coalesced
 template <typename K, int BITS>
-__device__ inline void write_obs(const DiscreteParams& p, const Lds<K, BITS>& l, const EnvRegs& r, int lane,
+__device__ inline void write_obs(const DiscreteParams& p, int e, const Lds<K, BITS>& l, const EnvRegs& r, int lane,
                                  float* __restrict__ obs) {
   typedef Pack<K, BITS> P;
   int a = r.item0, b = r.item1, c = r.item2, tmp;
@@ -689,6 +692,9 @@ __device__ inline void write_obs(const DiscreteParams& p, const Lds<K, BITS>& l,
   const int col = lane % 9, rsub = lane / 9;
   const bool lane_on = lane < 63;
   const int rows = p.I + p.L + 1;
+  const bool dens = p.setting == 3;  // densities other than 1 (D/space.py:386, D/bin3D.py:91)
+  const double* bden = p.st_den + (size_t)e * p.I;
+  const float nden = dens ? (float)next_density(p, e, r.oc - 1, r.traj, r.cursor - 1) : 1.0f;
   for (int rbase = 0; rbase < rows; rbase += 7) {
     const int row = rbase + rsub;
     if (!lane_on || row >= rows) continue;
@@ -697,6 +703,7 @@ __device__ inline void write_obs(const DiscreteParams& p, const Lds<K, BITS>& l,
       if (row < r.n_boxes) {
         K k = l.box[row];
         v = col < 6 ? (float)P::get(k, col) : (col == 7 ? 0.f : 1.0f);  // density 1, pad 0, mask 1
+        if (dens && col == 6) v = (float)bden[row];
       } else if (row == 0 && col == 8) {
         v = 1.0f;  // D/space.py:294-295 dummy valid node after reset
       }
@@ -707,7 +714,7 @@ __device__ inline void write_obs(const DiscreteParams& p, const Lds<K, BITS>& l,
         v = col < 5 ? (float)P::get(k, col) : (col == 5 ? (float)p.H : (col == 8 ? 1.0f : 0.f));
       }
     } else {
-      v = col == 0 ? 1.0f : (col == 3 ? (float)a : (col == 4 ? (float)b : (col == 5 ? (float)c : (col == 8 ? 1.0f : 0.f))));
+      v = col == 0 ? nden : (col == 3 ? (float)a : (col == 4 ? (float)b : (col == 5 ? (float)c : (col == 8 ? 1.0f : 0.f))));
     }
     obs[row * 9 + col] = v;
   }
@@ -769,6 +776,8 @@ __device__ inline void transition(const DiscreteParams& p, int e, Lds<K, BITS>& 
   int x = flag ? by : bx, y = flag ? bx : by, z = bz;  // D/space.py:348-351
   bool ok = !bad;
   int max_h = 0;
+  // the density shown with the observation this action answers (D/bin3D.py:158 self.next_den)
+  const double item_den = STAB ? next_density(p, e, r.oc - 1, r.traj, r.cursor - 1) : 1.0;
   if (ok) {
     // np.max(plain[lx:lx+x, ly:ly+y]) with Python slice normalisation (D/space.py:354-355)
     int xa = lx, xb = lx + x, ya = ly, yb = ly + y;
@@ -807,7 +816,7 @@ __device__ inline void transition(const DiscreteParams& p, int e, Lds<K, BITS>& 
       BoxGeo<K, BITS> geo{l.box};
       StabState st = stab_view(p, e);
       bool err;
-      verdict = stab_commit<false>(geo, st, r.n_boxes, 1.0, err) ? 1 : 0;
+      verdict = stab_commit<false>(geo, st, r.n_boxes, item_den, err) ? 1 : 0;
       serr = err ? 1 : 0;
     }
     verdict = __shfl(verdict, 0, 64);
@@ -821,7 +830,7 @@ __device__ inline void transition(const DiscreteParams& p, int e, Lds<K, BITS>& 
       BoxGeo<K, BITS> geo{l.box};
       StabState st = stab_view(p, e);
       bool err;
-      stab_commit<false>(geo, st, r.n_boxes, 1.0, err);
+      stab_commit<false>(geo, st, r.n_boxes, item_den, err);
     }
   }
   if (ok && r.n_boxes >= p.I) {  // IndexError at D/space.py:385
@@ -924,7 +933,7 @@ __global__ void __launch_bounds__(64) pct_discrete_kernel(DiscreteParams p, cons
     __syncthreads();
     draw_item(p, e, r);
     leaf_nodes<K, BITS, STAB, SCHEME, SHUFFLE>(p, e, l, r, lane, tm);
-    write_obs<K, BITS>(p, l, r, lane, obs);
+    write_obs<K, BITS>(p, e, l, r, lane, obs);
     store_state<K, BITS>(p, e, l, r, lane);
     return;
   }
@@ -961,7 +970,7 @@ __global__ void __launch_bounds__(64) pct_discrete_kernel(DiscreteParams p, cons
     if (bad) r.flags |= PCT_FLAG_BAD_ACTION;  // ValueError in list.remove, D/bin3D.py:144-145
     transition<K, BITS, STAB, SCHEME>(p, e, l, r, lane, bad, flag, lx, ly, bx, by, bz, tm);
     leaf_nodes<K, BITS, STAB, SCHEME, SHUFFLE>(p, e, l, r, lane, tm);
-    write_obs<K, BITS>(p, l, r, lane, obs);
+    write_obs<K, BITS>(p, e, l, r, lane, obs);
     __syncthreads();
     tm.tick(PH_OBS);
   }

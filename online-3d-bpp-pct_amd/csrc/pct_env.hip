@@ -117,6 +117,7 @@ int launch(pct_env* h, int act, const void* actions, int row_len, int n_steps, c
       pct::ContinuousParams& q = h->cp_retry;
       const pct::ContinuousParams& c = h->cp;
       q.source = c.source; q.stream = c.stream; q.T = c.T; q.seed = c.seed; q.ds_len = c.ds_len;
+      q.den_stream = c.den_stream; q.den_T = c.den_T; q.ds_den = c.ds_den;
       q.ds_ntraj = c.ds_ntraj; q.ds_maxlen = c.ds_maxlen; q.sample_left = c.sample_left; q.sample_right = c.sample_right;
       q.low_bound = c.low_bound; q.obs = c.obs; q.reward = c.reward; q.done = c.done; q.counter = c.counter;
       q.ratio = c.ratio; q.flags = c.flags; q.timing = nullptr;
@@ -147,8 +148,7 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
   if (cfg->env_kind != PCT_ENV_DISCRETE && cfg->env_kind != PCT_ENV_CONTINUOUS)
     return fail(PCT_ERR_INVALID_ARG, "unknown env_kind");
   const bool cont = cfg->env_kind == PCT_ENV_CONTINUOUS;
-  if (cfg->setting != 2 && cfg->setting != 1)
-    return fail(PCT_ERR_UNSUPPORTED, "settings built: 1 and 2 (setting 3 = random item densities is not)");
+  if (cfg->setting < 1 || cfg->setting > 3) return fail(PCT_ERR_INVALID_ARG, "setting must be 1, 2 or 3 (tools.py:132)");
   if (cfg->lnes != PCT_LNES_EMS && cfg->lnes != PCT_LNES_CP && cfg->lnes != PCT_LNES_FC)
     return fail(PCT_ERR_UNSUPPORTED, "LNES built: EMS, CP, FC (EV / EP are not)");
   if (cfg->lnes != PCT_LNES_EMS && cfg->env_kind != PCT_ENV_DISCRETE)
@@ -229,6 +229,7 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
       CALLOC_(c.st_share, Nn * c.I * pct::STAB_SMAX * 4 * sizeof(double));
       CALLOC_(c.st_npoly, Nn * c.I * sizeof(int));
       CALLOC_(c.st_poly, Nn * c.I * pct::STAB_PMAX * 2 * sizeof(double));
+      CALLOC_(c.st_den, Nn * c.I * sizeof(double));
     }
     if (c.table_global) {
       CALLOC_(c.gtab, Nn * (size_t)(cand_cap + cand_cap / 4) * sizeof(uint32_t));
@@ -311,6 +312,7 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
     ALLOC(p.st_share, N * p.I * pct::STAB_SMAX * 4 * sizeof(double));
     ALLOC(p.st_npoly, N * p.I * sizeof(int));
     ALLOC(p.st_poly, N * p.I * pct::STAB_PMAX * 2 * sizeof(double));
+    ALLOC(p.st_den, N * p.I * sizeof(double));
   }
   ALLOC(h->own_flags, N * sizeof(uint32_t));
   ALLOC(h->own_obs, N * p.row_len * sizeof(float));
@@ -410,6 +412,35 @@ int pct_set_item_dataset(pct_env* h, const int32_t* items, const int32_t* length
   h->dp.source = PCT_ITEMS_DATASET;
   h->cp.stream = (int32_t*)d; h->cp.ds_len = (int32_t*)dl; h->cp.ds_ntraj = n_traj; h->cp.ds_maxlen = max_len;
   h->cp.source = PCT_ITEMS_DATASET;
+  return PCT_OK;
+}
+
+int pct_set_density_stream(pct_env* h, const double* den, int64_t T) {
+  if (!h || !den || T < 1) return fail(PCT_ERR_INVALID_ARG, "bad density stream");
+  int rc = use_device(h);
+  if (rc) return rc;
+  void* d = nullptr;
+  size_t n = (size_t)h->cfg.num_envs * (size_t)T;
+  rc = dev_alloc(h, &d, sizeof(double) * n, false);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(d, den, sizeof(double) * n, hipMemcpyHostToDevice));
+  h->dp.den_stream = (const double*)d; h->dp.den_T = T;
+  h->cp.den_stream = (const double*)d; h->cp.den_T = T;
+  return PCT_OK;
+}
+
+int pct_set_dataset_density(pct_env* h, const double* den) {
+  if (!h || !den) return fail(PCT_ERR_INVALID_ARG, "null argument");
+  if (h->dp.source != PCT_ITEMS_DATASET) return fail(PCT_ERR_STATE, "pct_set_item_dataset must come first");
+  int rc = use_device(h);
+  if (rc) return rc;
+  void* d = nullptr;
+  size_t n = (size_t)h->dp.ds_ntraj * (size_t)h->dp.ds_maxlen;
+  rc = dev_alloc(h, &d, sizeof(double) * n, false);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(d, den, sizeof(double) * n, hipMemcpyHostToDevice));
+  h->dp.ds_den = (const double*)d;
+  h->cp.ds_den = (const double*)d;
   return PCT_OK;
 }
 

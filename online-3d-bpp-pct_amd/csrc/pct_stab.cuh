@@ -50,6 +50,7 @@ struct StabState {
   double* share;   // [I][STAB_SMAX][4]
   int* npoly;      // [I]
   double* poly;    // [I][STAB_PMAX][2]
+  double* den;     // [I] density of each placed box (setting 3; 1.0 otherwise), D/space.py:38
 };
 
 struct StabBox {  // a box being examined (candidate or placed), with its supporters
@@ -338,11 +339,11 @@ PCT_SD bool stab_shares(const StabBox& b, const double stk[4], const double own_
 // parent's virtual share, or null).  n = number of placed boxes to consider.
 template <typename Geo>
 PCT_SD void stab_com(const Geo& geo, const StabState& st, int n, int S, const int* path, int npath,
-                     const double* extra, double density, double out[4]) {
+                     const double* extra, double out[4]) {
   double g[9];
   geo(S, g);
   double sx = g[6], sy = g[7], sz = g[8];
-  double mass = sx * sy * sz * density;
+  double mass = sx * sy * sz * st.den[S];
   double c0 = (g[0] + sx / 2) * mass, c1 = (g[1] + sy / 2) * mass, c2 = (g[2] + sz / 2) * mass, m = mass;
   for (int B = S + 1; B < n; B++) {
     bool inv = false;
@@ -414,7 +415,7 @@ PCT_SD bool stab_virtual(const Geo& geo, const StabState& st, int n, const doubl
     // path = placed boxes currently involved: frames 1..d (the candidate has no id)
     int np2 = 0;
     for (int q = 1; q <= d; q++) path[np2++] = fid[q];
-    stab_com(geo, st, n, S, path, np2, shares[i], density, fstk[depth]);
+    stab_com(geo, st, n, S, path, np2, shares[i], fstk[depth]);
     fid[depth] = S;
     fnext[depth] = 0;
     depth++;
@@ -431,6 +432,7 @@ PCT_SD bool stab_commit(const Geo& geo, StabState& st, int n, double density, bo
   StabBox b;
   geo(n, b.g);
   if (!stab_find_supporters<CONT>(geo, n, b)) { err = true; return false; }
+  st.den[n] = density;
   {
     double sx = b.g[6], sy = b.g[7], sz = b.g[8];
     double* s = st.stack + (size_t)n * 4;
@@ -474,7 +476,7 @@ PCT_SD bool stab_commit(const Geo& geo, StabState& st, int n, double density, bo
       for (int k = 0; k < b.nsup; k++) {
         double* e = st.share + ((size_t)id * STAB_SMAX + k) * 4;
         e[0] = shares[k][0]; e[1] = shares[k][1]; e[2] = shares[k][2]; e[3] = shares[k][3];
-        stab_com(geo, st, n + 1, b.sup[k], (const int*)0, 0, (const double*)0, density, st.stack + (size_t)b.sup[k] * 4);
+        stab_com(geo, st, n + 1, b.sup[k], (const int*)0, 0, (const double*)0, st.stack + (size_t)b.sup[k] * 4);
       }
     }
     if (fnext[d] >= b.nsup) { depth--; continue; }

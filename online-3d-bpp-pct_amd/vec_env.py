@@ -188,7 +188,7 @@ class PctVecEnv(VecEnv):
         if load_test_data:
             if data_name is None:
                 raise ValueError("load_test_data=True needs data_name (a torch.save'd list of trajectories)")
-            self._dataset = [np.asarray(t, dtype=np.float64)[:, :3] for t in torch.load(data_name)]  # binCreator.py:48-49
+            self._dataset = [np.asarray(t, dtype=np.float64) for t in torch.load(data_name)]  # binCreator.py:48-49; [len, 3 or 4]
         self.continuous = bool(continuous)
         if self.continuous and (sample_left_bound is None or sample_right_bound is None):
             raise ValueError("the continuous env needs sample_left_bound / sample_right_bound (tools.py:178-181)")
@@ -281,17 +281,36 @@ class PctVecEnv(VecEnv):
     def set_item_dataset(self, trajectories):
         """The reference's dataset format (README.md:75-77, binCreator.py:41-72): a list of
         trajectories, each [len,3] item sizes (the continuous env takes bin units and stores them
-        on its 1e-3 lattice).  Episode k (1-based) plays trajectory k."""
+        on its 1e-3 lattice) or, for setting 3, [len,4] = size + density (bin3D.py:76).  Episode k
+        (1-based) plays trajectory k."""
         scale = 1000 if self.continuous else 1
         n = len(trajectories)
         max_len = max(len(t) for t in trajectories)
         items = np.zeros((n, max_len, 3), np.int32)
+        dens = np.ones((n, max_len), np.float64)
         lengths = np.zeros(n, np.int32)
+        have_density = False
         for i, t in enumerate(trajectories):
-            a = np.rint(np.asarray(t, dtype=np.float64).reshape(-1, 3) * scale).astype(np.int32)
-            items[i, :len(a)] = a
+            a = np.asarray(t, dtype=np.float64).reshape(len(t), -1)
+            items[i, :len(a)] = np.rint(a[:, :3] * scale).astype(np.int32)
+            if a.shape[1] > 3:
+                dens[i, :len(a)] = a[:, 3]
+                have_density = True
             lengths[i] = len(a)
         _lib.check(self._L.pct_set_item_dataset(self._h, items.ctypes.data, lengths.ctypes.data, n, max_len))
+        if self.setting == 3:
+            if not have_density:
+                raise ValueError("setting 3 reads the density from the dataset items' fourth column (bin3D.py:76)")
+            _lib.check(self._L.pct_set_dataset_density(self._h, dens.ctypes.data))
+
+    def set_density_stream(self, den):
+        """setting 3 with scripted densities: den float64 [N,T]; the env's c-th observation (counting
+        every observation it ever produced) shows den[e, c % T].  Without it the densities come from
+        the counter-based pct_density(seed, env, c)."""
+        den = np.ascontiguousarray(np.asarray(den, dtype=np.float64))
+        if den.ndim != 2 or den.shape[0] != self.num_envs:
+            raise ValueError("density stream must be [num_envs, T]")
+        _lib.check(self._L.pct_set_density_stream(self._h, den.ctypes.data, den.shape[1]))
 
     def set_sampler(self, seed):
         _lib.check(self._L.pct_set_sampler(self._h, int(seed)))

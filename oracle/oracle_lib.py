@@ -55,6 +55,8 @@ def lib():
         L.pcto_set_item_dataset.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int32]
         L.pcto_set_sampler.argtypes = [vp, ctypes.c_uint64]
         L.pcto_set_shuffle_seed.argtypes = [vp, ctypes.c_uint64]
+        L.pcto_set_density_stream.argtypes = [vp, vp, ctypes.c_int64]
+        L.pcto_set_dataset_density.argtypes = [vp, vp]
         for name in ("pcto_obs", "pcto_reward", "pcto_done", "pcto_info_counter", "pcto_info_ratio",
                      "pcto_error_flags"):
             getattr(L, name).argtypes = [vp]
@@ -128,11 +130,21 @@ class OracleVecEnv(object):
         assert items.ndim == 3 and items.shape[0] == self.N and items.shape[2] == 3
         self._check(lib().pcto_set_item_stream(self._h, items.ctypes.data, items.shape[1]))
 
-    def set_item_dataset(self, trajectories):
-        """trajectories: list of [len_i,3] int arrays (lattice units), LoadBoxCreator semantics."""
+    def set_item_dataset(self, trajectories, densities=None):
+        """trajectories: list of [len_i,3] int arrays (lattice units), LoadBoxCreator semantics;
+        densities (setting 3): list of [len_i] float arrays, the dataset's fourth column."""
         items, lengths = pack_dataset(trajectories)
         self._check(lib().pcto_set_item_dataset(self._h, items.ctypes.data, lengths.ctypes.data, items.shape[0],
                                                 items.shape[1]))
+        if densities is not None:
+            den = pack_densities(densities, items.shape[1])
+            self._check(lib().pcto_set_dataset_density(self._h, den.ctypes.data))
+
+    def set_density_stream(self, den):
+        """setting 3: den [N,T] float64, density of each env's c-th observation (c % T)."""
+        den = np.ascontiguousarray(np.asarray(den, dtype=np.float64))
+        assert den.ndim == 2 and den.shape[0] == self.N
+        self._check(lib().pcto_set_density_stream(self._h, den.ctypes.data, den.shape[1]))
 
     def set_sampler(self, seed):
         self._check(lib().pcto_set_sampler(self._h, seed))
@@ -195,6 +207,14 @@ def pack_dataset(trajectories):
         items[i, :len(a)] = a
         lengths[i] = len(a)
     return np.ascontiguousarray(items), np.ascontiguousarray(lengths)
+
+
+def pack_densities(densities, max_len):
+    den = np.ones((len(densities), max_len), np.float64)
+    for i, d in enumerate(densities):
+        d = np.asarray(d, dtype=np.float64).reshape(-1)
+        den[i, :len(d)] = d
+    return np.ascontiguousarray(den)
 
 
 def pyset_order(keys):

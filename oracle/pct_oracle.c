@@ -564,7 +564,7 @@ static void get_possible_position(const pcto_env* h, int e, oenv* s, double* lea
   free(pos);
 }
 
-/* D/bin3D.py:70-93 cur_observation (setting < 3: next_den = 1) */
+/* D/bin3D.py:70-93 cur_observation */
 static void cur_observation(const pcto_env* h, int e, oenv* s, double* obs) {
   /* gen_next_box -> box_creator.preview(1)[0] (binCreator.py:15-18) */
   if (s->queue_len < 1) {
@@ -572,7 +572,7 @@ static void cur_observation(const pcto_env* h, int e, oenv* s, double* obs) {
     s->queue_len = 1;
   }
   s->next_box[0] = s->queue_item[0]; s->next_box[1] = s->queue_item[1]; s->next_box[2] = s->queue_item[2];
-  s->next_den = 1.0;
+  s->next_den = pcto_next_density(h, e, s->oc, s->traj, s->cursor - 1); /* :75-84 */
   memcpy(obs, s->box_vec, sizeof(double) * 9 * h->I);
   get_possible_position(h, e, s, obs + 9 * h->I);
   int a = s->next_box[0], b = s->next_box[1], c = s->next_box[2], tmp;
@@ -674,7 +674,7 @@ int pcto_create(const pct_config* cfg, pcto_env** out) {
   if (cfg->struct_size != (int32_t)sizeof(pct_config)) return fail(PCT_ERR_INVALID_ARG, "pct_config size mismatch");
   if (cfg->env_kind != PCT_ENV_DISCRETE && cfg->env_kind != PCT_ENV_CONTINUOUS)
     return fail(PCT_ERR_UNSUPPORTED, "oracle: unknown env kind");
-  if (cfg->setting != 2 && cfg->setting != 1) return fail(PCT_ERR_UNSUPPORTED, "oracle: settings restated: 1 and 2");
+  if (cfg->setting < 1 || cfg->setting > 3) return fail(PCT_ERR_UNSUPPORTED, "oracle: setting must be 1, 2 or 3");
   if (cfg->lnes != PCT_LNES_EMS && cfg->lnes != PCT_LNES_CP && cfg->lnes != PCT_LNES_FC)
     return fail(PCT_ERR_UNSUPPORTED, "oracle: LNES restated: EMS, CP, FC");
   if (cfg->lnes != PCT_LNES_EMS && cfg->env_kind != PCT_ENV_DISCRETE)
@@ -719,7 +719,7 @@ int pcto_destroy(pcto_env* h) {
   }
   if (h->cenvs) pctc_free(h);
   free(h->envs); free(h->obs); free(h->reward); free(h->done); free(h->counter); free(h->ratio);
-  free(h->flags); free(h->item_set); free(h->stream); free(h->ds_len);
+  free(h->flags); free(h->item_set); free(h->stream); free(h->ds_len); free(h->den_stream); free(h->ds_den);
   free(h);
   return PCT_OK;
 }
@@ -768,6 +768,23 @@ int pcto_set_item_dataset(pcto_env* h, const int32_t* items, const int32_t* leng
   h->ds_ntraj = n_traj;
   h->ds_maxlen = max_len;
   h->source = PCT_ITEMS_DATASET;
+  return PCT_OK;
+}
+int pcto_set_density_stream(pcto_env* h, const double* den, int64_t T) {
+  if (!h || !den || T < 1) return fail(PCT_ERR_INVALID_ARG, "bad density stream");
+  free(h->den_stream);
+  size_t n = (size_t)h->N * (size_t)T;
+  h->den_stream = (double*)malloc(sizeof(double) * n);
+  memcpy(h->den_stream, den, sizeof(double) * n);
+  h->den_T = T;
+  return PCT_OK;
+}
+int pcto_set_dataset_density(pcto_env* h, const double* den) {
+  if (!h || !den || h->source != PCT_ITEMS_DATASET) return fail(PCT_ERR_STATE, "set the dataset items first");
+  free(h->ds_den);
+  size_t n = (size_t)h->ds_ntraj * (size_t)h->ds_maxlen;
+  h->ds_den = (double*)malloc(sizeof(double) * n);
+  memcpy(h->ds_den, den, sizeof(double) * n);
   return PCT_OK;
 }
 int pcto_set_shuffle_seed(pcto_env* h, uint64_t seed) {

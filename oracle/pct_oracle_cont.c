@@ -391,7 +391,7 @@ static void get_possible_position(const struct pcto_env* h, int e, struct cenv* 
 static void cur_observation(const struct pcto_env* h, int e, struct cenv* s, double* obs) {
   if (s->queue_len < 1) { draw_item(h, e, s, s->queue_item); s->queue_len = 1; }
   memcpy(s->next_box, s->queue_item, sizeof s->next_box);
-  s->next_den = 1.0;
+  s->next_den = pcto_next_density(h, e, s->oc, s->traj, s->cursor - 1); /* C/bin3D.py:81-90 */
   memcpy(obs, s->box_vec, sizeof(double) * 9 * h->I);
   get_possible_position(h, e, s, obs + 9 * h->I);
   double a = s->next_box[0], b = s->next_box[1], c = s->next_box[2], t;

@@ -2,6 +2,7 @@
  * (TEST INFRASTRUCTURE, see pct_oracle.h). */
 #ifndef PCT_ORACLE_INTERNAL_H
 #define PCT_ORACLE_INTERNAL_H
+#include <stddef.h>
 #include "pct_oracle.h"
 
 struct stab;
@@ -44,6 +45,9 @@ struct pcto_env {
   int64_t T;
   int32_t* ds_len; /* dataset mode: stream is [n_traj,max_len,3] */
   int ds_ntraj, ds_maxlen;
+  double* den_stream; /* setting 3: scripted densities [N,den_T], or NULL */
+  int64_t den_T;
+  double* ds_den;     /* setting 3, dataset mode: [n_traj,max_len] fourth column, or NULL */
   uint64_t seed;
   uint64_t shuffle_seed;
   int source;
@@ -56,6 +60,19 @@ struct pcto_env {
   uint32_t* flags;
 };
 
+
+/* D/bin3D.py:75-84 next_den of observation number `oc`; `traj`/`item_index` locate the previewed
+ * item in dataset mode */
+static inline double pcto_next_density(const struct pcto_env* h, int e, uint64_t oc, int traj, uint64_t item_index) {
+  if (h->cfg.setting != 3) return 1.0;
+  if (h->source == PCT_ITEMS_DATASET) { /* self.next_box[3] */
+    int t = traj < h->ds_ntraj ? traj : h->ds_ntraj - 1;
+    if (!h->ds_den || t < 0 || item_index >= (uint64_t)h->ds_len[t]) return 1.0;
+    return h->ds_den[(size_t)t * h->ds_maxlen + (size_t)item_index];
+  }
+  if (h->den_stream) return h->den_stream[(size_t)e * (size_t)h->den_T + (size_t)(oc % (uint64_t)h->den_T)];
+  return pct_density(h->seed, (uint64_t)(h->cfg.env_id_base + e), oc);
+}
 
 /* stability (pct_oracle_stab.c) */
 struct stab* stab_create(int cap, double eps);

@@ -56,21 +56,28 @@ def gather_rows(obs, I, idx):
 
 GOLDEN_CASES = ["discrete_s2_10_80_50", "discrete_s2_rect_60_30", "discrete_s2_10_80_5", "discrete_s2_20_120_400",
                 "discrete_s2_cp_10_80_50", "discrete_s2_cp_rect_60_16", "discrete_s1_10_80_50", "discrete_s1_rect_60_30",
-                "discrete_s2_fc_10_80_50", "discrete_s1_fc_rect_60_24"]
+                "discrete_s2_fc_10_80_50", "discrete_s1_fc_rect_60_24",
+                "discrete_s3_10_80_50", "discrete_s3_rect_60_30"]
 
 CONT_CASES = ["continuous_s2_10_80_50", "continuous_s2_100_200_200", "continuous_s2_rect_60_20",
-              "continuous_s1_10_80_50", "continuous_s1_unit_80_50"]
-CONT_STAB_CASES = ["continuous_s1_10_80_50", "continuous_s1_unit_80_50"]
+              "continuous_s1_10_80_50", "continuous_s1_unit_80_50",
+              "continuous_s3_unit_80_50", "continuous_s3_10_80_50"]
+CONT_STAB_CASES = ["continuous_s1_10_80_50", "continuous_s1_unit_80_50", "continuous_s3_unit_80_50", "continuous_s3_10_80_50"]
 
 # CPU-only fixtures (stability, settings 1/3: restated in the oracle, not yet on the GPU)
 ORACLE_ONLY_CASES = []
-STAB_CASES = ["discrete_s1_10_80_50", "discrete_s1_rect_60_30"]
+STAB_CASES = ["discrete_s1_10_80_50", "discrete_s1_rect_60_30", "discrete_s3_10_80_50", "discrete_s3_rect_60_30"]
 
-DATASET_CASES = ["discrete_s2_dataset", "continuous_s2_dataset"]
+DATASET_CASES = ["discrete_s2_dataset", "continuous_s2_dataset", "discrete_s3_dataset", "continuous_s3_dataset"]
+
+
+def case_density(z):
+    """scripted densities [N,T] of a setting-3 fixture, else None"""
+    return z["density"] if "density" in z.files else None
 
 
 def dataset_trajectories(z):
-    """list of [len,3] float arrays from a dataset fixture"""
+    """list of [len,3] (or [len,4] = size + density, setting 3) float arrays from a dataset fixture"""
     out, o = [], 0
     for n in z["traj_len"]:
         out.append(np.asarray(z["traj_items"][o:o + int(n)], np.float64))

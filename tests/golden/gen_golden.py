@@ -94,7 +94,39 @@ CASES = {
                                  stream_T=512, seed=17, base=21),
     "discrete_s1_rect_60_30": dict(setting=1, container=(12, 8, 14), lo=1, hi=6, I=60, L=30, N=3, steps=200,
                                    stream_T=256, seed=18, base=2),
+    # setting 3: setting 1 + a random density per observation (D/bin3D.py:80-84); np.random.random is
+    # scripted in the reference run (make_density) so that the draw sequence is known
+    "discrete_s3_10_80_50": dict(setting=3, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, N=5, steps=250,
+                                 stream_T=512, seed=41, base=33),
+    "discrete_s3_rect_60_30": dict(setting=3, container=(9, 12, 13), lo=1, hi=6, I=60, L=30, N=3, steps=200,
+                                   stream_T=256, seed=42, base=5),
 }
+
+
+def make_density(seed, n_envs, T):
+    """Scripted stand-in for the reference's np.random.random() draws: [N,T] in (0,1)."""
+    rng = np.random.RandomState(seed + 1000)
+    return rng.random_sample((n_envs, T))
+
+
+class scripted_density(object):
+    """Context manager: np.random.random() returns row[c % T] for the c-th call."""
+
+    def __init__(self, row):
+        self.row, self.c = row, 0
+
+    def __enter__(self):
+        self.saved = np.random.random
+        if self.row is not None:
+            def draw():
+                v = float(self.row[self.c % len(self.row)])
+                self.c += 1
+                return v
+            np.random.random = draw
+        return self
+
+    def __exit__(self, *a):
+        np.random.random = self.saved
 
 
 CONT_CASES = {
@@ -112,6 +144,11 @@ CONT_CASES = {
     # 3 decimals, z from {0.1,...,0.5} (C/bin3D.py:110-112, givenData.py:5)
     "continuous_s1_unit_80_50": dict(setting=1, container=(1, 1, 1), lo=0.1, hi=0.5, I=80, L=50, N=3, steps=250,
                                      stream_T=256, seed=25, base=70, z_choice=True),
+    # setting 3 in the continuous env (C/bin3D.py:86-90): scripted densities as above
+    "continuous_s3_unit_80_50": dict(setting=3, container=(1, 1, 1), lo=0.1, hi=0.5, I=80, L=50, N=3, steps=250,
+                                     stream_T=256, seed=43, base=80, z_choice=True),
+    "continuous_s3_10_80_50": dict(setting=3, container=(10, 10, 10), lo=1.0, hi=5.0, I=80, L=50, N=3, steps=200,
+                                   stream_T=256, seed=44, base=90),
 }
 
 
@@ -154,7 +191,9 @@ def run_reference_cont(case):
     done = np.zeros((c["steps"], N), np.uint8)
     counter = np.zeros((c["steps"], N), np.int32)
     ratio = np.zeros((c["steps"], N), np.float64)
+    den = make_density(c["seed"], N, c["stream_T"]) if c["setting"] == 3 else None
     for e in range(N):
+      with scripted_density(None if den is None else den[e]):
         # sample_from_distribution=False + item_set minimum == lo reproduces size_minimum = lo
         # (C/bin3D.py:25-29) while items come from the scripted creator (C/bin3D.py:116)
         env = PC(setting=c["setting"], container_size=list(c["container"]), item_set=[(c["lo"], c["lo"], c["lo"])],
@@ -175,16 +214,18 @@ def run_reference_cont(case):
             if d:
                 obs = env.reset()
         obs_rec[c["steps"], e] = obs
-    return dict(stream=stream, obs=obs_rec, reward=rew, done=done, counter=counter, ratio=ratio)
+    return dict(stream=stream, obs=obs_rec, reward=rew, done=done, counter=counter, ratio=ratio, density=den)
 
 
-def run_oracle_cont(case, stream):
+def run_oracle_cont(case, stream, density=None):
     from oracle.oracle_lib import OracleVecEnv
     c = case
     env = OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"], env_kind=1,
                        sample_bounds=(c["lo"], c["hi"]), internal_node_holder=c["I"], leaf_node_holder=c["L"],
                        env_id_base=c["base"])
     env.set_item_stream(stream)
+    if density is not None:
+        env.set_density_stream(density)
     N, I, L = c["N"], c["I"], c["L"]
     obs_rec = np.zeros((c["steps"] + 1, N, (I + L + 1) * 9), np.float64)
     rew = np.zeros((c["steps"], N), np.float64)
@@ -261,7 +302,9 @@ def run_reference(case):
     done = np.zeros((c["steps"], N), np.uint8)
     counter = np.zeros((c["steps"], N), np.int32)
     ratio = np.zeros((c["steps"], N), np.float64)
+    den = make_density(c["seed"], N, c["stream_T"]) if c["setting"] == 3 else None
     for e in range(N):
+      with scripted_density(None if den is None else den[e]):
         env = PD(setting=c["setting"], container_size=list(c["container"]), item_set=item_set,
                  internal_node_holder=I, leaf_node_holder=L, shuffle=False, LNES=c.get("lnes", "EMS"))
         env.box_creator = scripted_creator(stream[e])
@@ -282,16 +325,18 @@ def run_reference(case):
             if d:
                 obs = env.reset()  # shmem_vec_env.py:141-143
         obs_rec[c["steps"], e] = obs.astype(np.float32)
-    return dict(stream=stream, obs=obs_rec, reward=rew, done=done, counter=counter, ratio=ratio)
+    return dict(stream=stream, obs=obs_rec, reward=rew, done=done, counter=counter, ratio=ratio, density=den)
 
 
-def run_oracle(case, stream):
+def run_oracle(case, stream, density=None):
     from oracle.oracle_lib import OracleVecEnv
     c = case
     env = OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"],
                        item_set=item_set_range(c["lo"], c["hi"]), internal_node_holder=c["I"],
                        leaf_node_holder=c["L"], env_id_base=c["base"], lnes={"CP": 3, "FC": 4}.get(c.get("lnes"), 0))
     env.set_item_stream(stream)
+    if density is not None:
+        env.set_density_stream(density)
     N, I, L = c["N"], c["I"], c["L"]
     row_len = (I + L + 1) * 9
     obs_rec = np.zeros((c["steps"] + 1, N, row_len), np.float32)
@@ -361,6 +406,12 @@ DATASET_CASES = {
                                 n_traj=40, traj_len=60, seed=31, base=0),
     "continuous_s2_dataset": dict(kind="continuous", setting=2, container=(10, 10, 10), lo=1.0, hi=5.0, I=80, L=50, N=2,
                                   steps=150, n_traj=30, traj_len=40, seed=32, base=5),
+    # setting 3 on a dataset: items carry a fourth column, the density (bin3D.py:76); trajectories are long
+    # enough that no episode reaches the 3-element sentinel (the reference raises IndexError there)
+    "discrete_s3_dataset": dict(kind="discrete", setting=3, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, N=2, steps=200,
+                                n_traj=40, traj_len=120, seed=33, base=3),
+    "continuous_s3_dataset": dict(kind="continuous", setting=3, container=(10, 10, 10), lo=1.0, hi=5.0, I=80, L=50, N=2,
+                                  steps=150, n_traj=30, traj_len=120, seed=34, base=8),
 }
 
 
@@ -370,10 +421,13 @@ def make_dataset(case):
     for _ in range(case["n_traj"]):
         n = int(rng.randint(case["traj_len"] // 2, case["traj_len"] + 1))
         if case["kind"] == "discrete":
-            trajs.append(rng.randint(case["lo"], case["hi"] + 1, size=(n, 3)).astype(np.int64).tolist())
+            t = rng.randint(case["lo"], case["hi"] + 1, size=(n, 3)).astype(np.int64).tolist()
         else:
             k = rng.randint(int(case["lo"] * 1000), int(case["hi"] * 1000) + 1, size=(n, 3))
-            trajs.append((k / 1000.0).tolist())
+            t = (k / 1000.0).tolist()
+        if case["setting"] == 3:  # [x, y, z, density]
+            t = [list(it) + [float(d)] for it, d in zip(t, rng.random_sample(n))]
+        trajs.append(t)
     return trajs
 
 
@@ -419,12 +473,14 @@ def run_oracle_dataset(case, trajs):
         env = OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"],
                            item_set=item_set_range(c["lo"], c["hi"]), internal_node_holder=c["I"],
                            leaf_node_holder=c["L"], env_id_base=c["base"])
-        env.set_item_dataset([np.asarray(t, np.int32) for t in trajs])
+        env.set_item_dataset([np.asarray([it[:3] for it in t], np.int32) for t in trajs],
+                             [[it[3] for it in t] for t in trajs] if c["setting"] == 3 else None)
     else:
         env = OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"], env_kind=1,
                            sample_bounds=(c["lo"], c["hi"]), internal_node_holder=c["I"], leaf_node_holder=c["L"],
                            env_id_base=c["base"])
-        env.set_item_dataset([np.rint(np.asarray(t) * 1000).astype(np.int32) for t in trajs])
+        env.set_item_dataset([np.rint(np.asarray([it[:3] for it in t]) * 1000).astype(np.int32) for t in trajs],
+                             [[it[3] for it in t] for t in trajs] if c["setting"] == 3 else None)
     obs_rec = np.zeros((c["steps"] + 1, c["N"], (c["I"] + c["L"] + 1) * 9), np.float64)
     rew = np.zeros((c["steps"], c["N"]), np.float64)
     done = np.zeros((c["steps"], c["N"]), np.uint8)
@@ -484,9 +540,11 @@ def known_answer_discrete_s1():
     print("known answer discrete s1: oracle == reference ==", ref_hash)
 
 
-def dataset_cases():
+def dataset_cases(want=lambda name: True):
     import tempfile
     for name, case in DATASET_CASES.items():
+        if not want(name):
+            continue
         trajs = make_dataset(case)
         with tempfile.TemporaryDirectory() as td:
             ref = run_reference_dataset(case, trajs, os.path.join(td, "data.pt"))
@@ -496,7 +554,7 @@ def dataset_cases():
                 raise SystemExit("MISMATCH %s/%s first at %s" % (name, key, np.argwhere(ref[key] != ora[key])[0]))
         print("%-28s steps=%d envs=%d episodes=%d  oracle == reference (LoadBoxCreator semantics)" % (
             name, case["steps"], case["N"], int(ref["done"].sum())))
-        flat = np.concatenate([np.asarray(t, np.float64).reshape(-1, 3) for t in trajs])
+        flat = np.concatenate([np.asarray(t, np.float64).reshape(len(t), -1) for t in trajs])  # [*, 3 or 4]
         lens = np.array([len(t) for t in trajs], np.int32)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), meta=np.array(repr(case)), traj_items=flat, traj_len=lens,
                             obs=ref["obs"] if case["kind"] == "continuous" else ref["obs"].astype(np.float32),
@@ -504,13 +562,21 @@ def dataset_cases():
 
 
 def main():
-    dataset_cases()
-    known_answer_discrete_s2()
-    known_answer_discrete_s1()
-    known_answer_continuous_s2()
+    only = sys.argv[1:]  # optional name filters: regenerate only the matching cases
+
+    def want(name):
+        return not only or any(o in name for o in only)
+
+    dataset_cases(want)
+    if not only:
+        known_answer_discrete_s2()
+        known_answer_discrete_s1()
+        known_answer_continuous_s2()
     for name, case in CONT_CASES.items():
+        if not want(name):
+            continue
         ref = run_reference_cont(case)
-        ora = run_oracle_cont(case, ref["stream"])
+        ora = run_oracle_cont(case, ref["stream"], ref["density"])
         for key in ("obs", "reward", "done", "counter", "ratio"):
             a, b = ref[key], ora[key]
             if key == "ratio":
@@ -520,12 +586,15 @@ def main():
                 raise SystemExit("MISMATCH %s/%s first at %s" % (name, key, np.argwhere(a != b)[0]))
         print("%-28s steps=%d envs=%d episodes=%d  oracle == reference (float64, bit-exact)" % (
             name, case["steps"], case["N"], int(ref["done"].sum())))
+        extra = {} if ref["density"] is None else {"density": ref["density"]}
         np.savez_compressed(os.path.join(HERE, name + ".npz"), meta=np.array(repr(case)), stream=ref["stream"],
                             obs=ref["obs"], reward=ref["reward"], done=ref["done"], counter=ref["counter"],
-                            ratio=ref["ratio"] * (ref["done"] != 0))
+                            ratio=ref["ratio"] * (ref["done"] != 0), **extra)
     for name, case in CASES.items():
+        if not want(name):
+            continue
         ref = run_reference(case)
-        ora = run_oracle(case, ref["stream"])
+        ora = run_oracle(case, ref["stream"], ref["density"])
         for key in ("obs", "reward", "done", "counter", "ratio"):
             a, b = ref[key], ora[key]
             if key == "ratio":  # only terminal steps carry a ratio in the reference info
@@ -539,9 +608,10 @@ def main():
         print("%-28s steps=%d envs=%d episodes=%d  leaf-cap hit %.2f  oracle == reference" % (
             name, case["steps"], case["N"], eps, float((feas >= case["L"]).mean())))
         meta = np.array(repr(case))
+        extra = {} if ref["density"] is None else {"density": ref["density"]}
         np.savez_compressed(os.path.join(HERE, name + ".npz"), meta=meta, stream=ref["stream"],
                             obs=ref["obs"], reward=ref["reward"], done=ref["done"],
-                            counter=ref["counter"], ratio=ref["ratio"] * (ref["done"] != 0))
+                            counter=ref["counter"], ratio=ref["ratio"] * (ref["done"] != 0), **extra)
 
 
 if __name__ == "__main__":

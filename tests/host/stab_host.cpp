@@ -18,7 +18,7 @@ struct stab {
   int n;
   std::vector<double> geo;  // [cap][9] lx,ly,lz,xe,ye,ze,sx,sy,sz
   bool cont;
-  std::vector<double> stack, share, poly;
+  std::vector<double> stack, share, poly, den;
   std::vector<int> nsup, sup, npoly;
   int overflow;
 };
@@ -37,6 +37,7 @@ static pct::StabState view(stab* s) {
   st.share = s->share.data();
   st.npoly = s->npoly.data();
   st.poly = s->poly.data();
+  st.den = s->den.data();
   return st;
 }
 
@@ -54,6 +55,7 @@ struct stab* stab_create(int cap, double eps) {
   s->nsup.assign((size_t)s->cap, 0);
   s->sup.assign((size_t)s->cap * pct::STAB_SMAX, 0);
   s->npoly.assign((size_t)s->cap, 0);
+  s->den.assign((size_t)s->cap, 1.0);
   return s;
 }
 void stab_reset(struct stab* s) { s->n = 0; }

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.common import (CONT_CASES, DATASET_CASES, GOLDEN, GOLDEN_CASES, dataset_trajectories, gather_rows, hash_policy_index, item_set_range, load_case,
+from tests.common import (case_density, CONT_CASES, DATASET_CASES, GOLDEN, GOLDEN_CASES, dataset_trajectories, gather_rows, hash_policy_index, item_set_range, load_case,
                           make_stream)
 
 pytestmark = pytest.mark.gpu
@@ -41,6 +41,8 @@ def _check_step(name, t, z, obs, reward, done, infos):
 def test_hip_matches_reference_fixture(name, mode):
     c, z = load_case(name)
     env = _make(c, z["stream"])
+    if case_density(z) is not None:
+        env.set_density_stream(case_density(z))
     obs = env.reset()
     for t in range(c["steps"]):
         o = obs.cpu().numpy()
@@ -89,12 +91,14 @@ def test_hip_known_answer_hash_setting1():
     env.close()
 
 
-def test_hip_setting1_matches_oracle_random_streams():
+@pytest.mark.parametrize("setting", [1, 3])
+def test_hip_setting1_matches_oracle_random_streams(setting):
+    """settings 1 and 3 (stability check; setting 3 with the counter-based pct_density draws)"""
     from oracle.oracle_lib import OracleVecEnv
     items = item_set_range(1, 5)
     N = 192
     stream = make_stream(41, N, 256, items)
-    kw = dict(setting=1, container_size=(10, 10, 10), item_set=items, internal_node_holder=80, leaf_node_holder=50,
+    kw = dict(setting=setting, container_size=(10, 10, 10), item_set=items, internal_node_holder=80, leaf_node_holder=50,
               env_id_base=500)
     ora = OracleVecEnv(N, **kw)
     ora.set_item_stream(stream)
@@ -284,6 +288,8 @@ def test_hip_continuous_matches_reference_fixture(name, mode):
     big = max(c["container"]) > 16
     many = big or c["lo"] < 1.0  # small items -> more than 1228 distinct candidates are possible
     env = _make_cont(c, z["stream"], ems_capacity=640 if many else 0, candidate_capacity=8192 if many else 0)
+    if case_density(z) is not None:
+        env.set_density_stream(case_density(z))
     obs = env.reset()
     for t in range(c["steps"]):
         o = obs.cpu().numpy()
@@ -379,7 +385,7 @@ def test_hip_dataset_semantics_match_reference(name, tmp_path):
     trajs = dataset_trajectories(z)
     path = str(tmp_path / "data.pt")
     torch.save([t.tolist() for t in trajs], path)
-    kw = dict(setting=2, container_size=c["container"], internal_node_holder=c["I"], leaf_node_holder=c["L"],
+    kw = dict(setting=c["setting"], container_size=c["container"], internal_node_holder=c["I"], leaf_node_holder=c["L"],
               env_id_base=c["base"], data_name=path, load_test_data=True, device="cuda:0")
     if c["kind"] == "discrete":
         env = _pkg().PctVecEnv(c["N"], item_set=item_set_range(c["lo"], c["hi"]), **kw)

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from oracle.oracle_lib import OracleVecEnv, pyset_order
-from tests.common import CONT_CASES, DATASET_CASES, GOLDEN_CASES, ORACLE_ONLY_CASES, dataset_trajectories, gather_rows, hash_policy_index, item_set_range, load_case, GOLDEN
+from tests.common import case_density, CONT_CASES, DATASET_CASES, GOLDEN_CASES, ORACLE_ONLY_CASES, dataset_trajectories, gather_rows, hash_policy_index, item_set_range, load_case, GOLDEN
 
 
 @pytest.mark.parametrize("name", GOLDEN_CASES + ORACLE_ONLY_CASES)
@@ -20,6 +20,8 @@ def test_oracle_matches_reference_fixture_fused_policy(name):
                        item_set=item_set_range(c["lo"], c["hi"]), internal_node_holder=c["I"],
                        leaf_node_holder=c["L"], env_id_base=c["base"], lnes={"CP": 3, "FC": 4}.get(c.get("lnes"), 0))
     env.set_item_stream(z["stream"])
+    if case_density(z) is not None:
+        env.set_density_stream(case_density(z))
     env.reset()
     for t in range(c["steps"]):
         assert np.array_equal(env.obs.astype(np.float32), z["obs"][t]), (name, t)
@@ -143,6 +145,8 @@ def test_continuous_oracle_matches_reference_fixture(name):
                        sample_bounds=(c["lo"], c["hi"]), internal_node_holder=c["I"], leaf_node_holder=c["L"],
                        env_id_base=c["base"])
     env.set_item_stream(z["stream"])
+    if case_density(z) is not None:
+        env.set_density_stream(case_density(z))
     env.reset()
     for t in range(c["steps"]):
         assert np.array_equal(env.obs, z["obs"][t]), (name, t)
@@ -187,14 +191,15 @@ def test_oracle_dataset_semantics_match_reference(name):
     (100,100,100) after the last item, then (10,10,10)."""
     c, z = load_case(name)
     trajs = dataset_trajectories(z)
+    dens = [t[:, 3] for t in trajs] if c["setting"] == 3 else None
     if c["kind"] == "discrete":
-        env = OracleVecEnv(c["N"], setting=2, container_size=c["container"], item_set=item_set_range(c["lo"], c["hi"]),
+        env = OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"], item_set=item_set_range(c["lo"], c["hi"]),
                            internal_node_holder=c["I"], leaf_node_holder=c["L"], env_id_base=c["base"])
-        env.set_item_dataset([t.astype(np.int32) for t in trajs])
+        env.set_item_dataset([t[:, :3].astype(np.int32) for t in trajs], dens)
     else:
-        env = OracleVecEnv(c["N"], setting=2, container_size=c["container"], env_kind=1, sample_bounds=(c["lo"], c["hi"]),
+        env = OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"], env_kind=1, sample_bounds=(c["lo"], c["hi"]),
                            internal_node_holder=c["I"], leaf_node_holder=c["L"], env_id_base=c["base"])
-        env.set_item_dataset([np.rint(t * 1000).astype(np.int32) for t in trajs])
+        env.set_item_dataset([np.rint(t[:, :3] * 1000).astype(np.int32) for t in trajs], dens)
     env.reset()
     for t in range(c["steps"]):
         assert np.array_equal(env.obs.astype(z["obs"].dtype), z["obs"][t]), (name, t)

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import oracle.oracle_lib as ol
-from tests.common import CONT_STAB_CASES, GOLDEN, STAB_CASES, item_set_range, load_case, make_stream
+from tests.common import case_density, CONT_STAB_CASES, GOLDEN, STAB_CASES, item_set_range, load_case, make_stream
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 VARIANT = os.path.join(HERE, "host", "libpct_oracle_prodstab.so")
@@ -34,9 +34,11 @@ class _Variant(object):
 def test_product_stability_matches_reference_fixture(name):
     c, z = load_case(name)
     with _Variant():
-        env = ol.OracleVecEnv(c["N"], setting=1, container_size=c["container"], item_set=item_set_range(c["lo"], c["hi"]),
+        env = ol.OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"], item_set=item_set_range(c["lo"], c["hi"]),
                               internal_node_holder=c["I"], leaf_node_holder=c["L"], env_id_base=c["base"])
         env.set_item_stream(z["stream"])
+        if case_density(z) is not None:
+            env.set_density_stream(case_density(z))
         env.reset()
         for t in range(c["steps"]):
             assert np.array_equal(env.obs.astype(np.float32), z["obs"][t]), (name, t)
@@ -88,10 +90,12 @@ def test_product_stability_continuous_matches_reference_fixture(name):
     rectangles) inside the continuous oracle, against the float64 reference fixture."""
     c, z = load_case(name)
     with _Variant():
-        env = ol.OracleVecEnv(c["N"], setting=1, container_size=c["container"], env_kind=1,
+        env = ol.OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"], env_kind=1,
                               sample_bounds=(c["lo"], c["hi"]), internal_node_holder=c["I"], leaf_node_holder=c["L"],
                               env_id_base=c["base"])
         env.set_item_stream(z["stream"])
+        if case_density(z) is not None:
+            env.set_density_stream(case_density(z))
         env.reset()
         for t in range(c["steps"]):
             assert np.array_equal(env.obs, z["obs"][t]), (name, t)
