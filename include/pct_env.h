@@ -64,6 +64,8 @@ extern "C" {
 
 /* leaf-node expansion scheme (tools.py:133 --lnes) */
 #define PCT_LNES_EMS 0
+#define PCT_LNES_EV 1 /* event points (D/space.py:613-693; static under the reference's step) */
+#define PCT_LNES_EP 2 /* extreme points (D/space.py:696-750, PctTools.py:114-136) */
 #define PCT_LNES_CP 3
 #define PCT_LNES_FC 4 /* full coordinate space (D/space.py:573-610) */
 

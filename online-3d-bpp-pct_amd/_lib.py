@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(HERE, "libpct_hip.so")
 
 PCT_OK = 0
 ENV_DISCRETE, ENV_CONTINUOUS = 0, 1
-LNES_EMS, LNES_CP, LNES_FC = 0, 3, 4
+LNES_EMS, LNES_EV, LNES_EP, LNES_CP, LNES_FC = 0, 1, 2, 3, 4
 FLAG_INTERNAL_OVERFLOW, FLAG_EMS_OVERFLOW, FLAG_CANDIDATE_OVERFLOW, FLAG_BAD_ACTION = 1, 2, 4, 8
 FLAG_STABILITY_OVERFLOW, FLAG_DATASET_EXHAUSTED = 16, 32
 

@@ -79,11 +79,16 @@ struct Lds {
   K* leaf;
   HT* hmap;
   uint16_t* vp; /* [64] valid (ems, rotation) pairs of the current chunk */
-  uint32_t* cp; /* corner-point scratch: 4 arrays of I+2 words (only when lnes == CP) */
+  uint32_t* cp; /* scheme scratch: CP / EP levels (6 arrays of I+2 words), EV tables (288 words) */
   K* fkey;       /* shuffle: feasible candidates in list order ... */
   uint32_t* fpri; /* ... and their priorities (only when shuffle) */
 };
 
+__host__ __device__ inline int discrete_scheme_words(const DiscreteParams& p) {
+  if (p.lnes == PCT_LNES_CP || p.lnes == PCT_LNES_EP) return 6 * (p.I + 2);
+  if (p.lnes == PCT_LNES_EV) return 288;
+  return 0;
+}
 __host__ __device__ inline int discrete_scratch_words(const DiscreteParams& p) {
   return 128 + (int)(64 * sizeof(uint32_t) / p.key_bytes);  // pend[128] + dd[64 x u32]
 }
@@ -104,7 +109,7 @@ __device__ inline Lds<K, BITS> carve_lds(const DiscreteParams& p, unsigned char*
   size_t hb = ((size_t)p.AA * sizeof(typename Lds<K, BITS>::HT) + 3) & ~(size_t)3;
   l.vp = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(q) + hb);
   l.cp = reinterpret_cast<uint32_t*>(l.vp + 64);
-  uint32_t* after_cp = l.cp + (p.lnes == PCT_LNES_CP ? 4 * (p.I + 2) : 0);
+  uint32_t* after_cp = l.cp + discrete_scheme_words(p);
   const int fcap = (p.cand_cap * 3) / 5 + 2;
   l.fpri = after_cp;
   l.fkey = reinterpret_cast<K*>(after_cp + fcap + (fcap & 1));
@@ -396,8 +401,13 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
     }
   };
 
-  constexpr bool CP = SCHEME == 1;
-  if (SCHEME == 2) {
+  // SCHEME 1 = every expansion other than EMS, selected at run time (coverage paths)
+  const bool FC = SCHEME == 1 && p.lnes == PCT_LNES_FC;
+  const bool EV = SCHEME == 1 && p.lnes == PCT_LNES_EV;
+  const bool EP = SCHEME == 1 && p.lnes == PCT_LNES_EP;
+  const bool CP = SCHEME == 1 && (p.lnes == PCT_LNES_CP || EP);  // CP and EP share the level skeleton
+  int n_ev = 0;  // EV: number of ordered candidates left in l.cp
+  if (FC) {
     // D/space.py:573-610 FullCoord: rotation-major, then lx, then ly; lz = the cell's own height
     const int NQ = orient * p.W * p.Ly;
     for (int base = 0; base < NQ && !cand_overflow; base += 64) {
@@ -419,24 +429,108 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
       __syncthreads();
       if (npend >= 64) flush(64);
     }
+  } else if (EV) {
+    // D/space.py:613-693 EventPoint.  bin3D.py:171 runs GENEMS only under LNES == 'EMS', so under
+    // 'EV' ZMAP and the EMS list stay as Space.reset left them: level 0 with x_up=[0], y_left=[0],
+    // x_bottom=[W], y_right=[Ly] and the whole-bin EMS.  posVec = the four bin corners of every
+    // rotation (<= 24 tuples, possibly with negative coordinates, which is why they do not go
+    // through the packed-key table); one lane replays set.add on a 128-slot table of candidate ids.
+    uint32_t* tb = l.cp;  // [128] ids (rot * 4 + corner), 0xFF = empty
+    auto ev_tuple = [&](int id, int t[6]) {
+      int sx, sy, sz;
+      rot_size(id >> 2, sx, sy, sz);
+      int xs = (id & 2) ? p.W - sx : 0, ys = (id & 1) ? p.Ly - sy : 0;  // add order :654-674
+      t[0] = xs; t[1] = ys; t[2] = 0; t[3] = xs + sx; t[4] = ys + sy; t[5] = sz;
+    };
+    auto ev_hash = [&](const int t[6]) {
+      uint64_t acc = tuplehash_begin();
+      for (int c = 0; c < 6; c++) acc = tuplehash_lane(acc, pyhash_int(t[c]));
+      return tuplehash_end6(acc);
+    };
+    if (lane == 0) {
+      uint32_t sz_t = 8, fill = 0;
+      for (int i = 0; i < 8; i++) tb[i] = 0xFFu;
+      // set_insert_clean / set_add_entry probe sequence (LINEAR_PROBES 9, PERTURB_SHIFT 5)
+      auto probe_insert = [&](uint32_t* tab, uint32_t mask, int id, bool check) -> bool {
+        int t[6];
+        ev_tuple(id, t);
+        Walk w;
+        w.start(ev_hash(t), mask);
+        while (true) {
+          uint32_t cur = tab[w.i + w.j];
+          if (cur == 0xFFu) { tab[w.i + w.j] = (uint32_t)id; return true; }
+          if (check) {
+            int u[6];
+            ev_tuple((int)cur, u);
+            bool eq = true;
+            for (int c = 0; c < 6; c++) eq = eq && (u[c] == t[c]);
+            if (eq) return false;
+          }
+          w.next(mask);
+        }
+      };
+      for (int id = 0; id < orient * 4; id++) {
+        int sx, sy, sz;
+        if (rot_size(id >> 2, sx, sy, sz)) continue;
+        if (probe_insert(tb, sz_t - 1, id, true)) {
+          fill++;
+          uint32_t mask = sz_t - 1;
+          if (fill * 5u >= mask * 3u) {  // set_table_resize(used * 4) into the other half of the scratch
+            uint32_t ns = 8;
+            while (ns <= fill * 4u) ns <<= 1;
+            uint32_t* nt = (tb == l.cp) ? l.cp + 128 : l.cp;
+            for (uint32_t i = 0; i < ns; i++) nt[i] = 0xFFu;
+            for (uint32_t i = 0; i < sz_t; i++)
+              if (tb[i] != 0xFFu) probe_insert(nt, ns - 1, (int)tb[i], false);
+            tb = nt;
+            sz_t = ns;
+          }
+        }
+      }
+      // list(posVec) in slot order, kept if the footprint lies inside the EMS (:677-688)
+      uint32_t* ord = l.cp + 256;
+      int m = 0;
+      for (uint32_t i = 0; i < sz_t; i++) {
+        if (tb[i] == 0xFFu) continue;
+        int t[6];
+        ev_tuple((int)tb[i], t);
+        if (t[0] >= 0 && t[1] >= 0 && t[3] <= p.W && t[4] <= p.Ly) ord[m++] = tb[i];
+      }
+      ord[31] = (uint32_t)m;
+    }
+    __syncthreads();
+    n_ev = (int)l.cp[256 + 31];
+    // the ordered survivors become the "table": slot i of a fresh region holds candidate i
+    {
+      uint32_t id = lane < n_ev ? l.cp[256 + lane] : 0u;
+      int t[6];
+      ev_tuple((int)id, t);
+      __syncthreads();
+      size = 64;
+      toff = 0;
+      tabs[lane] = lane < n_ev ? P::pack(t[0], t[1], t[2], t[3], t[4], t[5]) : EMPTY;
+      __syncthreads();
+    }
   } else if (CP && r.n_boxes == 0) {
-    // D/space.py:756-757: an empty bin yields a plain two-element LIST (unrotated, x/y
-    // swapped; no set, no in-bin test): slots 0 and 1 of the fresh 8-slot table hold them in
-    // list order, duplicates included
+    // D/space.py:756-757 (and :700-701 for EP): an empty bin yields a plain two-element LIST
+    // (unrotated, x/y swapped; no set, no in-bin test): slots 0 and 1 of the fresh 8-slot table hold
+    // them in list order, duplicates included
     if (lane == 0) {
       tabs[toff + 0] = P::pack(0, 0, 0, b0, b1, b2);
       tabs[toff + 1] = P::pack(0, 0, 0, b1, b0, b2);
     }
     __syncthreads();
   } else if (CP) {
-    // D/space.py:758-774 + D/PctTools.py:137-158: per level k (sorted distinct tops, 0 first)
-    // the corner points of the boxes reaching above k, minus those of the previous level
+    // D/space.py:758-774 + D/PctTools.py:137-158 (CP) / :696-716 + PctTools.py:114-136 (EP): per level
+    // k (sorted distinct tops, 0 first) the corner / extreme points of the boxes reaching above k,
+    // minus those of the previous level
     const int n = r.n_boxes;
-    uint32_t* T = l.cp;                  // [I+2] levels
-    uint32_t* srt = l.cp + (p.I + 2);    // [I+2] box ids sorted by (ye, xe) descending, stable
-    uint32_t* cik = l.cp + 2 * (p.I + 2);   // [I+2] corners of this level: x | y << 16
-    uint32_t* last = l.cp + 3 * (p.I + 2);  // [I+2] corners of the previous level
-    uint32_t* CI = reinterpret_cast<uint32_t*>(l.ems_a);  // EMS are not kept under CP: x | y<<10 | k<<20
+    const int cw = p.I + 2;
+    uint32_t* T = l.cp;              // [I+2] levels
+    uint32_t* srt = l.cp + cw;       // [I+2] box ids in the level's sort order
+    uint32_t* cik = l.cp + 2 * cw;   // [2(I+2)] points of this level: x | y << 16
+    uint32_t* last = l.cp + 4 * cw;  // [2(I+2)] points of the previous level
+    uint32_t* CI = reinterpret_cast<uint32_t*>(l.ems_a);  // EMS are not kept under CP/EP: x | y<<10 | k<<20
     const int ci_cap = (int)(p.ems_cap * sizeof(K) / sizeof(uint32_t));
     // distinct tops, ascending (Tset, D/space.py:758-761)
     int nT = 1;
@@ -464,19 +558,21 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
     bool ci_overflow = false;
     for (int ti = 0; ti < nT; ti++) {
       const int k = (int)uniform_key<uint32_t>(T[ti]);
-      // stable descending sort of the active rectangles by (ye, xe): rank by counting
+      // stable sort of the active rectangles, rank by counting: CP descending by (ye, xe)
+      // (PctTools.py:143), EP ascending by (ly, lxe) (PctTools.py:117)
       int nact = 0;
       for (int base = 0; base < n; base += 64) {
         int i = base + lane;
         K bi = i < n ? l.box[i] : (K)0;
         bool act = i < n && P::get(bi, 5) > k;
-        int xe = P::get(bi, 3), ye = P::get(bi, 4);
+        int k1 = EP ? P::get(bi, 1) : P::get(bi, 4), k2 = P::get(bi, 3);
         int rank = 0;
         for (int j = 0; j < n; j++) {
           K bj = uniform_key<K>(l.box[j]);
           bool actj = P::get(bj, 5) > k;
-          int xj = P::get(bj, 3), yj = P::get(bj, 4);
-          bool before = (yj > ye) || (yj == ye && xj > xe) || (yj == ye && xj == xe && j < i);
+          int j1 = EP ? P::get(bj, 1) : P::get(bj, 4), j2 = P::get(bj, 3);
+          bool before = EP ? ((j1 < k1) || (j1 == k1 && j2 < k2) || (j1 == k1 && j2 == k2 && j < i))
+                           : ((j1 > k1) || (j1 == k1 && j2 > k2) || (j1 == k1 && j2 == k2 && j < i));
           rank += (actj && before) ? 1 : 0;
         }
         if (act) srt[rank] = (uint32_t)i;
@@ -485,8 +581,74 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
       __syncthreads();
       int nc = 0;
       if (nact == 0) {
-        if (lane == 0) cik[0] = 0;  // corners2D([]) == [(0, 0)]
+        if (lane == 0) cik[0] = 0;  // corners2D([]) == [(0, 0)]; extreme2D([]) == [(0, 0, 0)]
         nc = 1;
+      } else if (EP) {
+        // extreme2D (PctTools.py:114-136): item i of the sorted list projects onto the walls / the
+        // items before it -> up to two points, in the order of a 2-element set; a point is dropped
+        // if a LATER item's footprint covers it (deleteEps2D runs before the item adds its own)
+        for (int base = 0; base < nact; base += 64) {
+          int pos = base + lane;
+          bool live = pos < nact;
+          K bb = live ? l.box[srt[pos]] : (K)0;
+          const int lx = P::get(bb, 0), ly = P::get(bb, 1), lxe = P::get(bb, 3), lye = P::get(bb, 4);
+          // demo walls smallBox(-1,0,0,10) and smallBox(0,-1,10,0): the literal 10 of PctTools.py:118
+          bool have0 = lx >= 0 && lye < 10, have2 = ly >= 0 && lxe < 10;
+          int max0 = 0, max2 = 0;             // projectedX / projectedY maxima (both walls project 0)
+          int idx0 = have0 ? -2 : 0x7fffffff;  // position (in demo + earlier items) of the first valid box
+          int idx2 = have2 ? -1 : 0x7fffffff;
+          for (int q = 0; q < nact; q++) {
+            K bq = uniform_key<K>(l.box[uniform_key<uint32_t>(srt[q])]);
+            int qxe = P::get(bq, 3), qye = P::get(bq, 4);
+            bool before = q < pos;
+            if (before && lx >= qxe && lye < qye) {  // IsProjectionValid2D(newItem, box, 0)
+              if (!have0 || qxe > max0) max0 = qxe;
+              if (!have0) { have0 = true; idx0 = q; }
+            }
+            if (before && ly >= qye && lxe < qxe) {  // direction 2
+              if (!have2 || qye > max2) max2 = qye;
+              if (!have2) { have2 = true; idx2 = q; }
+            }
+          }
+          // maxBound starts at -10 and every projection is >= 0, so the first valid box always sets it
+          uint32_t e0 = (uint32_t)max0 | ((uint32_t)lye << 16);  // (projectedX, newItem.ly + newItem.y)
+          uint32_t e2 = (uint32_t)lxe | ((uint32_t)max2 << 16);  // (newItem.lx + newItem.x, projectedY)
+          uint32_t ea = 0, eb = 0;
+          int ne = 0;
+          if (live) {
+            if (have0 && have2 && e0 != e2) {
+              uint32_t fa = idx0 < idx2 ? e0 : e2, fb = idx0 < idx2 ? e2 : e0;  // dict insertion order
+              uint64_t ha = tuplehash_end(tuplehash_lane(tuplehash_lane(tuplehash_begin(), fa & 0xFFFFu), fa >> 16), 2ULL);
+              uint64_t hb = tuplehash_end(tuplehash_lane(tuplehash_lane(tuplehash_begin(), fb & 0xFFFFu), fb >> 16), 2ULL);
+              uint32_t ia = (uint32_t)ha & 7u, ib = (uint32_t)hb & 7u;
+              uint64_t perturb = hb;
+              while (ib == ia) {  // 8-slot table: no linear probes
+                perturb >>= 5;
+                ib = (ib * 5u + 1u + (uint32_t)perturb) & 7u;
+              }
+              ea = ia < ib ? fa : fb;
+              eb = ia < ib ? fb : fa;
+              ne = 2;
+            } else if (have0 || have2) {
+              ea = have0 ? e0 : e2;
+              ne = 1;
+            }
+          }
+          bool keep_a = ne >= 1, keep_b = ne >= 2;
+          for (int q = 0; q < nact; q++) {
+            K bq = uniform_key<K>(l.box[uniform_key<uint32_t>(srt[q])]);
+            int qx = P::get(bq, 0), qy = P::get(bq, 1), qxe = P::get(bq, 3), qye = P::get(bq, 4);
+            bool later = q > pos;
+            int ax = (int)(ea & 0xFFFFu), ay = (int)(ea >> 16), bx = (int)(eb & 0xFFFFu), by = (int)(eb >> 16);
+            if (later && ax >= qx && ax < qxe && ay >= qy && ay < qye) keep_a = false;
+            if (later && bx >= qx && bx < qxe && by >= qy && by < qye) keep_b = false;
+          }
+          uint64_t ma = __ballot(keep_a), mb = __ballot(keep_b);
+          int o = nc + __popcll(ma & lt) + __popcll(mb & lt);
+          if (keep_a) cik[o] = ea;
+          if (keep_b) cik[o + (keep_a ? 1 : 0)] = eb;
+          nc += __popcll(ma) + __popcll(mb);
+        }
       } else {
         // extreme items (PctTools.py:145-151): xe above the running maximum of everything sorted
         // before; the corner an extreme item contributes is (that running maximum, its ye) --
@@ -514,14 +676,16 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
         nc = m + 1;
       }
       __syncthreads();
-      // CI += corners not present at the previous level (order kept)
+      // CI += points not present at the previous level (order kept).  EP: the empty level's point is
+      // the 3-tuple (0,0,0), which no 2-tuple of the previous level equals (and vice versa)
+      const bool ep_empty = EP && nact == 0;
       for (int base = 0; base < nc; base += 64) {
         int c = base + lane;
         bool live = c < nc;
         uint32_t v = live ? cik[c] : 0u;
         bool seen = false;
         for (int q = 0; q < nlast; q++) seen = seen || (last[q] == v);
-        bool add = live && !seen;
+        bool add = live && (!seen || ep_empty);
         uint64_t m2 = __ballot(add);
         int o = nCI + __popcll(m2 & lt);
         if (add) {
@@ -534,7 +698,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
       if (nCI > ci_cap) nCI = ci_cap;
       __syncthreads();
       for (int c = lane; c < nc; c += 64) last[c] = cik[c];
-      nlast = nc;
+      nlast = ep_empty ? 0 : nc;
       __syncthreads();
     }
     if (ci_overflow) r.flags |= PCT_FLAG_EMS_OVERFLOW;
@@ -990,7 +1154,7 @@ inline size_t discrete_lds_bytes_impl(const DiscreteParams& p) {
   size_t k = p.key_bytes;
   size_t n = (size_t)table_words_compact((uint32_t)p.cand_cap) + p.ems_cap + discrete_scratch_words(p) + p.I + p.L;
   size_t hb = ((size_t)p.AA * (k == 4 ? 1 : 2) + 3) & ~(size_t)3;
-  size_t cp = p.lnes == PCT_LNES_CP ? 4 * (size_t)(p.I + 2) * sizeof(uint32_t) : 0;
+  size_t cp = (size_t)discrete_scheme_words(p) * sizeof(uint32_t);
   if (p.shuffle) cp += ((size_t)(p.cand_cap * 3) / 5 + 4) * (sizeof(uint32_t) + k);
   return n * k + hb + 64 * sizeof(uint16_t) + cp;
 }
@@ -1001,17 +1165,15 @@ inline hipError_t launch_typed(const DiscreteParams& p, int act, const void* act
   size_t lds = discrete_lds_bytes_impl(p);
   const bool timed = p.timing != nullptr && act != ACT_RESET;
   const bool stab = p.setting != 2;
-  const int scheme = p.lnes == PCT_LNES_CP ? 1 : (p.lnes == PCT_LNES_FC ? 2 : 0);
+  const int scheme = p.lnes == PCT_LNES_EMS ? 0 : 1;  // 1: every other expansion, dispatched inside the kernel
   int grid = (act == ACT_RESET && env_ids) ? n_ids : p.N;
   if (grid <= 0) return hipSuccess;
 #define PCT_KERN(A, T, S, C) (p.shuffle ? pct_discrete_kernel<K, BITS, A, false, S, C, true> : pct_discrete_kernel<K, BITS, A, T, S, C, false>)
 #define PCT_LAUNCH(A)                                                                                        \
   do {                                                                                                       \
     void (*kern)(DiscreteParams, const void*, int, int, const int32_t*, int);                                \
-    if (stab) kern = scheme == 1 ? PCT_KERN(A, false, true, 1) : scheme == 2 ? PCT_KERN(A, false, true, 2)   \
-                                                                              : PCT_KERN(A, false, true, 0); \
+    if (stab) kern = scheme == 1 ? PCT_KERN(A, false, true, 1) : PCT_KERN(A, false, true, 0);                \
     else if (scheme == 1) kern = PCT_KERN(A, false, false, 1);                                               \
-    else if (scheme == 2) kern = PCT_KERN(A, false, false, 2);                                               \
     else kern = timed ? PCT_KERN(A, true, false, 0) : PCT_KERN(A, false, false, 0);                          \
     if (lds > 48 * 1024) {                                                                                   \
       hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                               \

@@ -149,10 +149,9 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
     return fail(PCT_ERR_INVALID_ARG, "unknown env_kind");
   const bool cont = cfg->env_kind == PCT_ENV_CONTINUOUS;
   if (cfg->setting < 1 || cfg->setting > 3) return fail(PCT_ERR_INVALID_ARG, "setting must be 1, 2 or 3 (tools.py:132)");
-  if (cfg->lnes != PCT_LNES_EMS && cfg->lnes != PCT_LNES_CP && cfg->lnes != PCT_LNES_FC)
-    return fail(PCT_ERR_UNSUPPORTED, "LNES built: EMS, CP, FC (EV / EP are not)");
+  if (cfg->lnes < PCT_LNES_EMS || cfg->lnes > PCT_LNES_FC) return fail(PCT_ERR_INVALID_ARG, "unknown LNES (tools.py:133)");
   if (cfg->lnes != PCT_LNES_EMS && cfg->env_kind != PCT_ENV_DISCRETE)
-    return fail(PCT_ERR_UNSUPPORTED, "CP / FC exist only in the discrete env (C/bin3D.py:53)");
+    return fail(PCT_ERR_UNSUPPORTED, "EV / EP / CP / FC are reachable only in the discrete env (C/bin3D.py:53)");
   if (cfg->num_envs < 1 || cfg->internal_node_holder < 1 || cfg->leaf_node_holder < 1)
     return fail(PCT_ERR_INVALID_ARG, "num_envs / holders must be positive");
   int W = cfg->container[0], Ly = cfg->container[1], H = cfg->container[2];

@@ -57,11 +57,14 @@ __device__ inline uint64_t tuplehash_lane(uint64_t acc, uint64_t lane) {
   acc *= PCT_XXPRIME_1;
   return acc;
 }
-__device__ inline uint64_t tuplehash_end6(uint64_t acc) {
-  acc += 6ULL ^ (PCT_XXPRIME_5 ^ 3527539ULL);
+__device__ inline uint64_t tuplehash_end(uint64_t acc, uint64_t len) {
+  acc += len ^ (PCT_XXPRIME_5 ^ 3527539ULL);
   if (acc == (uint64_t)-1) return 1546275796ULL;
   return acc;
 }
+__device__ inline uint64_t tuplehash_end6(uint64_t acc) { return tuplehash_end(acc, 6ULL); }
+// hash(int) as the tuple hash sees it: the value itself (two's complement), except hash(-1) == -2
+__device__ inline uint64_t pyhash_int(int v) { return v == -1 ? (uint64_t)(int64_t)-2 : (uint64_t)(int64_t)v; }
 
 // ----------------------------------------------------------------------------------------
 // CPython set emulation, wave-parallel and exact.

@@ -168,7 +168,7 @@ class LazyInfos(object):
             yield self[i]
 
 
-_LNES = {"EMS": _lib.LNES_EMS, "CP": _lib.LNES_CP, "FC": _lib.LNES_FC}
+_LNES = {"EMS": _lib.LNES_EMS, "EV": _lib.LNES_EV, "EP": _lib.LNES_EP, "CP": _lib.LNES_CP, "FC": _lib.LNES_FC}
 
 
 class PctVecEnv(VecEnv):

@@ -39,18 +39,20 @@ void pcto_set_num_threads(int n) { g_threads = n < 1 ? 1 : n; }
 #define XXPRIME_2 14029467366897019727ULL
 #define XXPRIME_5 2870177450012600261ULL
 
-static uint64_t py_tuplehash6(const int64_t* v) {
+static uint64_t py_tuplehash(const int64_t* v, int len) {
   uint64_t acc = XXPRIME_5;
-  for (int i = 0; i < 6; i++) {
-    uint64_t lane = (uint64_t)v[i]; /* non-negative small ints hash to themselves */
+  for (int i = 0; i < len; i++) {
+    /* small ints hash to themselves, except hash(-1) == -2 (long_hash) */
+    uint64_t lane = v[i] == -1 ? (uint64_t)(int64_t)-2 : (uint64_t)v[i];
     acc += lane * XXPRIME_2;
     acc = (acc << 31) | (acc >> 33);
     acc *= XXPRIME_1;
   }
-  acc += 6ULL ^ (XXPRIME_5 ^ 3527539ULL);
+  acc += (uint64_t)len ^ (XXPRIME_5 ^ 3527539ULL);
   if (acc == (uint64_t)-1) return 1546275796ULL;
   return acc;
 }
+static uint64_t py_tuplehash6(const int64_t* v) { return py_tuplehash(v, 6); }
 
 /* Objects/setobject.c: set_add_entry (LINEAR_PROBES 9, PERTURB_SHIFT 5, growth when
  * fill*5 >= mask*3 to the first power of two > used*4), set_table_resize +
@@ -487,6 +489,196 @@ static int corner_point(const pcto_env* h, const oenv* s, int64_t** out) {
   return cnt;
 }
 
+/* D/PctTools.py:114-136 extreme2D on the rectangles above one level.  in[i] = {lx, ly, lxe, lye};
+ * out gets the extreme points in list order, returns their number (<= 2n).  n == 0 is handled
+ * by the caller (the reference returns the 3-tuple (0,0,0) there). */
+static int extreme2d(int (*in)[4], int n, int (*out)[2]) {
+  int* idx = (int*)malloc(sizeof(int) * (size_t)(n + 1));
+  for (int i = 0; i < n; i++) { /* sorted(key=(ly, lxe)): stable insertion sort, ascending */
+    int j = i;
+    while (j > 0) {
+      const int* a = in[idx[j - 1]];
+      const int* b = in[i];
+      int greater = (a[1] > b[1]) || (a[1] == b[1] && a[2] > b[2]);
+      if (!greater) break;
+      idx[j] = idx[j - 1];
+      j--;
+    }
+    idx[j] = i;
+  }
+  static const int demo[2][4] = {{-1, 0, 0, 10}, {0, -1, 10, 0}}; /* PctTools.py:118, the literal 10 included */
+  int cnt = 0;
+  for (int i = 0; i < n; i++) {
+    const int* nw = in[idx[i]];
+    int max0 = -10, max2 = -10, have0 = 0, have2 = 0, first = -1;
+    int e0[2] = {0, 0}, e2[2] = {0, 0};
+    for (int q = -2; q < i; q++) {
+      const int* bx = q < 0 ? demo[q + 2] : in[idx[q]];
+      int px = bx[2], py = bx[3]; /* projectedX / projectedY */
+      if (nw[0] >= bx[2] && nw[3] < bx[3] && px > max0) { /* IsProjectionValid2D(newItem, box, 0) */
+        e0[0] = px; e0[1] = nw[3]; max0 = px;
+        if (!have0) { have0 = 1; if (first < 0) first = 0; }
+      }
+      if (nw[1] >= bx[3] && nw[2] < bx[2] && py > max2) { /* direction 2 */
+        e2[0] = nw[2]; e2[1] = py; max2 = py;
+        if (!have2) { have2 = 1; if (first < 0) first = 2; }
+      }
+    }
+    /* deleteEps2D(newItem, alleps) */
+    int w = 0;
+    for (int c = 0; c < cnt; c++) {
+      int inside = out[c][0] >= nw[0] && out[c][0] < nw[2] && out[c][1] >= nw[1] && out[c][1] < nw[3];
+      if (!inside) { out[w][0] = out[c][0]; out[w][1] = out[c][1]; w++; }
+    }
+    cnt = w;
+    /* alleps.extend(list(set(newEps.values()))): dict order = first-insertion order of the keys,
+     * then the iteration order of a fresh 8-slot set holding one or two 2-tuples */
+    int nv = have0 + have2;
+    if (nv == 1) {
+      const int* v = have0 ? e0 : e2;
+      out[cnt][0] = v[0]; out[cnt][1] = v[1]; cnt++;
+    } else if (nv == 2) {
+      const int* a = first == 0 ? e0 : e2;
+      const int* b = first == 0 ? e2 : e0;
+      if (a[0] == b[0] && a[1] == b[1]) {
+        out[cnt][0] = a[0]; out[cnt][1] = a[1]; cnt++;
+      } else {
+        int64_t ta[2] = {a[0], a[1]}, tb[2] = {b[0], b[1]};
+        uint64_t ha = py_tuplehash(ta, 2), hb = py_tuplehash(tb, 2);
+        size_t ia = (size_t)ha & 7, ib = (size_t)hb & 7;
+        uint64_t perturb = hb;
+        while (ib == ia) { /* mask 7: no linear probes (i + 9 > mask) */
+          perturb >>= 5;
+          ib = (ib * 5 + 1 + (size_t)perturb) & 7;
+        }
+        const int* f = ia < ib ? a : b;
+        const int* g = ia < ib ? b : a;
+        out[cnt][0] = f[0]; out[cnt][1] = f[1]; cnt++;
+        out[cnt][0] = g[0]; out[cnt][1] = g[1]; cnt++;
+      }
+    }
+  }
+  free(idx);
+  return cnt;
+}
+
+/* rotation `rot` of the item (D/space.py:626-649 and the same block in every scheme); returns 0
+ * for a skipped rotation */
+static int rot_size(const int* nb, int rot, int64_t* sx, int64_t* sy, int64_t* sz) {
+  switch (rot) {
+    case 0: *sx = nb[0]; *sy = nb[1]; *sz = nb[2]; return 1;
+    case 1: *sx = nb[1]; *sy = nb[0]; *sz = nb[2]; return *sx != *sy;
+    case 2: *sx = nb[0]; *sy = nb[2]; *sz = nb[1]; return !(*sx == *sy && *sy == *sz);
+    case 3: *sx = nb[1]; *sy = nb[2]; *sz = nb[0]; return !(*sx == *sy && *sy == *sz);
+    case 4: *sx = nb[2]; *sy = nb[0]; *sz = nb[1]; return *sx != *sy;
+    default: *sx = nb[2]; *sy = nb[1]; *sz = nb[0]; return *sx != *sy;
+  }
+}
+
+/* D/space.py:696-750 ExtremePoint2D */
+static int extreme_point(const pcto_env* h, const oenv* s, int64_t** out) {
+  int orientation = (h->cfg.setting == 2) ? 6 : 2;
+  const int* nb = s->next_box;
+  if (s->n_boxes == 0) { /* :700-701 a plain two-element list */
+    int64_t* res = (int64_t*)malloc(sizeof(int64_t) * 12);
+    int64_t a[12] = {0, 0, 0, nb[0], nb[1], nb[2], 0, 0, 0, nb[1], nb[0], nb[2]};
+    memcpy(res, a, sizeof a);
+    *out = res;
+    return 2;
+  }
+  int n = s->n_boxes;
+  int* T = (int*)malloc(sizeof(int) * (size_t)(n + 1));
+  int nT = 0;
+  T[nT++] = 0;
+  for (int i = 0; i < n; i++) {
+    int top = s->boxes[i].z + s->boxes[i].lz, dup = 0;
+    for (int j = 0; j < nT; j++) if (T[j] == top) dup = 1;
+    if (!dup) T[nT++] = top;
+  }
+  for (int i = 1; i < nT; i++) { int v = T[i], j = i; while (j > 0 && T[j - 1] > v) { T[j] = T[j - 1]; j--; } T[j] = v; }
+  int (*rects)[4] = malloc(sizeof(int[4]) * (size_t)n);
+  int (*cik)[2] = malloc(sizeof(int[2]) * (size_t)(2 * n + 2));
+  int (*last)[2] = malloc(sizeof(int[2]) * (size_t)(2 * n + 2));
+  int nlast = 0;
+  int (*CI)[3] = malloc(sizeof(int[3]) * (size_t)(nT * (2 * n + 2)));
+  int nCI = 0;
+  for (int ti = 0; ti < nT; ti++) {
+    int k = T[ti], nr = 0;
+    for (int i = 0; i < n; i++)
+      if (s->boxes[i].lz + s->boxes[i].z > k) {
+        rects[nr][0] = s->boxes[i].lx; rects[nr][1] = s->boxes[i].ly;
+        rects[nr][2] = s->boxes[i].lx + s->boxes[i].x; rects[nr][3] = s->boxes[i].ly + s->boxes[i].y;
+        nr++;
+      }
+    if (nr == 0) { /* extreme2D([]) == [(0,0,0)]: a 3-tuple, never equal to a 2-tuple of lastCik */
+      CI[nCI][0] = 0; CI[nCI][1] = 0; CI[nCI][2] = k; nCI++;
+      nlast = 0;
+      continue;
+    }
+    int nc = extreme2d(rects, nr, cik);
+    for (int c = 0; c < nc; c++) {
+      int seen = 0;
+      for (int q = 0; q < nlast; q++) if (last[q][0] == cik[c][0] && last[q][1] == cik[c][1]) seen = 1;
+      if (!seen) { CI[nCI][0] = cik[c][0]; CI[nCI][1] = cik[c][1]; CI[nCI][2] = k; nCI++; }
+    }
+    memcpy(last, cik, sizeof(int[2]) * (size_t)nc);
+    nlast = nc;
+  }
+  int64_t* keys = (int64_t*)malloc(sizeof(int64_t) * 6 * (size_t)(nCI * orientation + 1));
+  int nk = 0;
+  for (int c = 0; c < nCI; c++)
+    for (int rot = 0; rot < orientation; rot++) {
+      int64_t sx, sy, sz;
+      if (!rot_size(nb, rot, &sx, &sy, &sz)) continue;
+      if (CI[c][0] + sx <= h->cfg.container[0] && CI[c][1] + sy <= h->cfg.container[1] &&
+          CI[c][2] + sz <= h->cfg.container[2]) {
+        int64_t* kk = keys + 6 * (size_t)nk++;
+        kk[0] = CI[c][0]; kk[1] = CI[c][1]; kk[2] = CI[c][2];
+        kk[3] = CI[c][0] + sx; kk[4] = CI[c][1] + sy; kk[5] = CI[c][2] + sz;
+      }
+    }
+  int32_t* order = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nk + 1));
+  int cnt = pcto_pyset_order(keys, nk, order);
+  int64_t* res = (int64_t*)malloc(sizeof(int64_t) * 6 * (size_t)(cnt + 1));
+  for (int i = 0; i < cnt; i++) memcpy(res + 6 * (size_t)i, keys + 6 * (size_t)order[i], 6 * sizeof(int64_t));
+  free(order); free(keys); free(T); free(rects); free(cik); free(last); free(CI);
+  *out = res;
+  return cnt;
+}
+
+/* D/space.py:613-693 EventPoint.  bin3D.py:171 runs GENEMS only under LNES == 'EMS', so under
+ * 'EV' neither the EMS list nor ZMAP ever changes after Space.reset (space.py:290-314): one
+ * level k = 0 with x_up = [0], y_left = [0], x_bottom = [W], y_right = [Ly] and the single EMS
+ * [0,0,0,W,Ly,H].  posVec = the four bin corners per rotation (a set: may hold negative
+ * coordinates), kept if the footprint lies inside the EMS (:677-688). */
+static int event_point(const pcto_env* h, const oenv* s, int64_t** out) {
+  int orientation = (h->cfg.setting == 2) ? 6 : 2;
+  const int* nb = s->next_box;
+  int64_t W = h->cfg.container[0], L = h->cfg.container[1];
+  int64_t keys[24 * 6];
+  int nk = 0;
+  for (int rot = 0; rot < orientation; rot++) {
+    int64_t sx, sy, sz;
+    if (!rot_size(nb, rot, &sx, &sy, &sz)) continue;
+    int64_t cand[4][2] = {{0, 0}, {0, L - sy}, {W - sx, 0}, {W - sx, L - sy}}; /* :654-674 add order */
+    for (int c = 0; c < 4; c++) {
+      int64_t* kk = keys + 6 * nk++;
+      kk[0] = cand[c][0]; kk[1] = cand[c][1]; kk[2] = 0;
+      kk[3] = cand[c][0] + sx; kk[4] = cand[c][1] + sy; kk[5] = sz;
+    }
+  }
+  int32_t order[25];
+  int cnt = pcto_pyset_order(keys, nk, order);
+  int64_t* res = (int64_t*)malloc(sizeof(int64_t) * 6 * (size_t)(cnt + 1));
+  int m = 0;
+  for (int i = 0; i < cnt; i++) {
+    const int64_t* kk = keys + 6 * (size_t)order[i];
+    if (kk[0] >= 0 && kk[1] >= 0 && kk[3] <= W && kk[4] <= L) memcpy(res + 6 * (size_t)m++, kk, 6 * sizeof(int64_t));
+  }
+  *out = res;
+  return m;
+}
+
 /* D/space.py:573-610 FullCoord: every (lx, ly) at its own cell height, every rotation */
 static int full_coord(const pcto_env* h, const oenv* s, int64_t** out) {
   int orientation = (h->cfg.setting == 2) ? 6 : 2;
@@ -545,7 +737,9 @@ static void get_possible_position(const pcto_env* h, int e, oenv* s, double* lea
   memset(leaf, 0, sizeof(double) * 9 * h->L);
   int64_t* pos = NULL;
   int n = h->cfg.lnes == PCT_LNES_CP ? corner_point(h, s, &pos)
-          : h->cfg.lnes == PCT_LNES_FC ? full_coord(h, s, &pos) : ems_point(h, s, &pos);
+          : h->cfg.lnes == PCT_LNES_FC ? full_coord(h, s, &pos)
+          : h->cfg.lnes == PCT_LNES_EP ? extreme_point(h, s, &pos)
+          : h->cfg.lnes == PCT_LNES_EV ? event_point(h, s, &pos) : ems_point(h, s, &pos);
   if (h->cfg.shuffle) shuffle_rows_i64(h, e, s->oc, pos, n); /* D/bin3D.py:114-115 */
   s->oc++;
   int idx = 0;
@@ -675,10 +869,9 @@ int pcto_create(const pct_config* cfg, pcto_env** out) {
   if (cfg->env_kind != PCT_ENV_DISCRETE && cfg->env_kind != PCT_ENV_CONTINUOUS)
     return fail(PCT_ERR_UNSUPPORTED, "oracle: unknown env kind");
   if (cfg->setting < 1 || cfg->setting > 3) return fail(PCT_ERR_UNSUPPORTED, "oracle: setting must be 1, 2 or 3");
-  if (cfg->lnes != PCT_LNES_EMS && cfg->lnes != PCT_LNES_CP && cfg->lnes != PCT_LNES_FC)
-    return fail(PCT_ERR_UNSUPPORTED, "oracle: LNES restated: EMS, CP, FC");
+  if (cfg->lnes < PCT_LNES_EMS || cfg->lnes > PCT_LNES_FC) return fail(PCT_ERR_INVALID_ARG, "oracle: unknown LNES");
   if (cfg->lnes != PCT_LNES_EMS && cfg->env_kind != PCT_ENV_DISCRETE)
-    return fail(PCT_ERR_UNSUPPORTED, "the corner-point scheme exists only in the discrete env");
+    return fail(PCT_ERR_UNSUPPORTED, "EV / EP / CP / FC are reachable only in the discrete env (C/bin3D.py:53)");
   if (cfg->num_envs < 1 || cfg->internal_node_holder < 1 || cfg->leaf_node_holder < 1)
     return fail(PCT_ERR_INVALID_ARG, "bad sizes");
   pcto_env* h = (pcto_env*)calloc(1, sizeof *h);

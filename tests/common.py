@@ -57,7 +57,10 @@ def gather_rows(obs, I, idx):
 GOLDEN_CASES = ["discrete_s2_10_80_50", "discrete_s2_rect_60_30", "discrete_s2_10_80_5", "discrete_s2_20_120_400",
                 "discrete_s2_cp_10_80_50", "discrete_s2_cp_rect_60_16", "discrete_s1_10_80_50", "discrete_s1_rect_60_30",
                 "discrete_s2_fc_10_80_50", "discrete_s1_fc_rect_60_24",
-                "discrete_s3_10_80_50", "discrete_s3_rect_60_30"]
+                "discrete_s3_10_80_50", "discrete_s3_rect_60_30",
+                "discrete_s2_ep_10_80_50", "discrete_s2_ep_rect_60_16", "discrete_s1_ep_10_80_50",
+                "discrete_s2_ev_10_80_50", "discrete_s1_ev_rect_60_24", "discrete_s2_ev_small_bin"]
+LNES_CODE = {"EMS": 0, "EV": 1, "EP": 2, "CP": 3, "FC": 4}
 
 CONT_CASES = ["continuous_s2_10_80_50", "continuous_s2_100_200_200", "continuous_s2_rect_60_20",
               "continuous_s1_10_80_50", "continuous_s1_unit_80_50",

@@ -89,6 +89,20 @@ CASES = {
                                     stream_T=256, seed=19, base=4, lnes="FC"),
     "discrete_s1_fc_rect_60_24": dict(setting=1, container=(8, 11, 9), lo=1, hi=5, I=60, L=24, N=3, steps=150,
                                       stream_T=256, seed=20, base=1, lnes="FC"),
+    # extreme-point (--lnes EP, D/space.py:696-750) and event-point (--lnes EV, :613-693) expansion
+    "discrete_s2_ep_10_80_50": dict(setting=2, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, N=6, steps=250,
+                                    stream_T=256, seed=51, base=13, lnes="EP"),
+    "discrete_s2_ep_rect_60_16": dict(setting=2, container=(9, 13, 10), lo=1, hi=6, I=60, L=16, N=3, steps=200,
+                                      stream_T=256, seed=52, base=0, lnes="EP"),
+    "discrete_s1_ep_10_80_50": dict(setting=1, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, N=3, steps=200,
+                                    stream_T=256, seed=53, base=2, lnes="EP"),
+    "discrete_s2_ev_10_80_50": dict(setting=2, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, N=4, steps=200,
+                                    stream_T=256, seed=54, base=6, lnes="EV"),
+    "discrete_s1_ev_rect_60_24": dict(setting=1, container=(8, 11, 9), lo=1, hi=5, I=60, L=24, N=3, steps=150,
+                                      stream_T=256, seed=55, base=1, lnes="EV"),
+    # items larger than the bin in x: the event-point set then holds negative coordinates
+    "discrete_s2_ev_small_bin": dict(setting=2, container=(4, 7, 9), lo=1, hi=6, I=40, L=24, N=3, steps=150,
+                                     stream_T=256, seed=56, base=9, lnes="EV"),
     # setting 1: stability check + 2 orientations (BASELINE.json configs[0] geometry)
     "discrete_s1_10_80_50": dict(setting=1, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, N=6, steps=250,
                                  stream_T=512, seed=17, base=21),
@@ -333,7 +347,7 @@ def run_oracle(case, stream, density=None):
     c = case
     env = OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"],
                        item_set=item_set_range(c["lo"], c["hi"]), internal_node_holder=c["I"],
-                       leaf_node_holder=c["L"], env_id_base=c["base"], lnes={"CP": 3, "FC": 4}.get(c.get("lnes"), 0))
+                       leaf_node_holder=c["L"], env_id_base=c["base"], lnes={"EV": 1, "EP": 2, "CP": 3, "FC": 4}.get(c.get("lnes"), 0))
     env.set_item_stream(stream)
     if density is not None:
         env.set_density_stream(density)

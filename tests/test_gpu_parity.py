@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.common import (case_density, CONT_CASES, DATASET_CASES, GOLDEN, GOLDEN_CASES, dataset_trajectories, gather_rows, hash_policy_index, item_set_range, load_case,
+from tests.common import (case_density, LNES_CODE, CONT_CASES, DATASET_CASES, GOLDEN, GOLDEN_CASES, dataset_trajectories, gather_rows, hash_policy_index, item_set_range, load_case,
                           make_stream)
 
 pytestmark = pytest.mark.gpu
@@ -443,4 +443,35 @@ def test_hip_shuffle_matches_oracle(kind):
         obs, reward, done, infos = env.step_wait()
         assert np.array_equal(done.astype(np.uint8), ora.done)
     assert not env.error_flags.any()
+    env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lnes", ["EP", "EV", "CP", "FC"])
+@pytest.mark.parametrize("setting", [2, 1])
+def test_hip_expansion_schemes_match_oracle_many_small_items(lnes, setting):
+    """Small items in a small bin: > 64 placed boxes per episode (several 64-lane chunks per level in
+    the CP / EP level loops), many levels, frequent duplicates among the corner / extreme points."""
+    from oracle.oracle_lib import OracleVecEnv
+    items = [(1, 1, 1), (1, 1, 1), (1, 1, 1), (1, 2, 1), (2, 1, 1), (1, 1, 2)]
+    N = 96
+    stream = make_stream(77, N, 512, items)
+    kw = dict(setting=setting, container_size=(5, 6, 5), item_set=items, internal_node_holder=160, leaf_node_holder=40,
+              env_id_base=31)
+    ora = OracleVecEnv(N, lnes=LNES_CODE[lnes], **kw)
+    ora.set_item_stream(stream)
+    env = _pkg().PctVecEnv(N, item_stream=stream, device="cuda:0", LNES=lnes, **kw)
+    ora.reset()
+    obs = env.reset()
+    most = 0
+    for t in range(260):
+        assert np.array_equal(obs.cpu().numpy(), ora.obs.astype(np.float32)), (lnes, t)
+        env.step_hash_policy(1)
+        ora.step_hash_policy(1)
+        obs, reward, done, infos = env.step_wait()
+        assert np.array_equal(done.astype(np.uint8), ora.done), (lnes, t)
+        most = max(most, int(ora.counter.max()))
+    assert not env.error_flags.any() and not ora.flags.any()
+    if lnes != "EV":
+        assert most > 64, most
     env.close()

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from oracle.oracle_lib import OracleVecEnv, pyset_order
-from tests.common import case_density, CONT_CASES, DATASET_CASES, GOLDEN_CASES, ORACLE_ONLY_CASES, dataset_trajectories, gather_rows, hash_policy_index, item_set_range, load_case, GOLDEN
+from tests.common import case_density, LNES_CODE, CONT_CASES, DATASET_CASES, GOLDEN_CASES, ORACLE_ONLY_CASES, dataset_trajectories, gather_rows, hash_policy_index, item_set_range, load_case, GOLDEN
 
 
 @pytest.mark.parametrize("name", GOLDEN_CASES + ORACLE_ONLY_CASES)
@@ -18,7 +18,7 @@ def test_oracle_matches_reference_fixture_fused_policy(name):
     c, z = load_case(name)
     env = OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"],
                        item_set=item_set_range(c["lo"], c["hi"]), internal_node_holder=c["I"],
-                       leaf_node_holder=c["L"], env_id_base=c["base"], lnes={"CP": 3, "FC": 4}.get(c.get("lnes"), 0))
+                       leaf_node_holder=c["L"], env_id_base=c["base"], lnes=LNES_CODE[c.get("lnes", "EMS")])
     env.set_item_stream(z["stream"])
     if case_density(z) is not None:
         env.set_density_stream(case_density(z))
