@@ -69,6 +69,13 @@ extern "C" {
 #define PCT_LNES_CP 3
 #define PCT_LNES_FC 4 /* full coordinate space (D/space.py:573-610) */
 
+/* heuristic baselines (heuristic.py) usable as in-env policies: pct_step_heuristic */
+#define PCT_HEUR_LSAH 0 /* heuristic.py:138-226 LASH */
+#define PCT_HEUR_HM 1   /* :232-298 heightmap_min */
+#define PCT_HEUR_OBPH 2 /* :364-425 OnlineBPH */
+#define PCT_HEUR_DBL 3  /* :431-498 DBL */
+#define PCT_HEUR_BR 4   /* :500-569 BR */
+
 /* item source */
 #define PCT_ITEMS_NONE 0
 #define PCT_ITEMS_STREAM 1  /* scripted per-env trajectories (parity runs) */
@@ -187,6 +194,13 @@ int pct_step_index(pct_env* env, const int64_t* leaf_index, void* stream);
 /* n_steps batched steps with the stand-in policy leaf = pct_mix32(g, t) % k over the k
  * valid leaves (leaf 0 if k == 0), t = the env's lifetime step counter. */
 int pct_step_hash_policy(pct_env* env, int32_t n_steps, void* stream);
+/* n_steps batched steps with a heuristic baseline of heuristic.py as the in-env policy (kind =
+ * PCT_HEUR_*; discrete env, LNES = EMS): the placement rule reads the env's heightmap / EMS list /
+ * stability state, the chosen placement is stepped exactly as `env.next_box = [x,y,z];
+ * env.step([0,lx,ly])`; an env whose heuristic finds no placement ends its episode WITHOUT a
+ * step (done = 1, reward = 0, counter / ratio as at a failed step) and is reset, as the reference
+ * loops do (e.g. heuristic.py:241-249,291-296).  MACS and RANDOM are not built. */
+int pct_step_heuristic(pct_env* env, int32_t kind, int32_t n_steps, void* stream);
 
 /* The stand-in policy as its own kernel (what a policy network would do between two
  * steps): reads each env's leaf-mask column from the observation, picks

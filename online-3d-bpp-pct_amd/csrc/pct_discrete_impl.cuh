@@ -930,15 +930,228 @@ __device__ inline void store_state(const DiscreteParams& p, int e, const Lds<K, 
   }
 }
 
+// ---- heuristic.py: the placement rules of the heuristic baselines as in-env policies ----------
+// rotation convention of heuristic.py:260-271 (shared by all of them; not EMSPoint's)
+__device__ inline void heur_rot(int b0, int b1, int b2, int rot, int& x, int& y, int& z) {
+  switch (rot) {
+    case 0: x = b0; y = b1; z = b2; break;
+    case 1: y = b0; x = b1; z = b2; break;
+    case 2: z = b0; x = b1; y = b2; break;
+    case 3: z = b0; y = b1; x = b2; break;
+    case 4: x = b0; z = b1; y = b2; break;
+    default: y = b0; z = b1; x = b2; break;
+  }
+}
+
+// Picks the placement heuristic `kind` would step with (heuristic.py; see oracle/pct_oracle.c
+// heur_choose for the sequential statement).  Every lane evaluates its own candidates; the winner
+// is the lexicographic minimum of (score, position in the reference's loop order), which is what
+// "replace on strictly better" leaves.  Returns false if there is no feasible placement.
+template <typename K, int BITS, bool STAB>
+__device__ inline bool heur_choose(const DiscreteParams& p, int e, Lds<K, BITS>& l, const EnvRegs& r, int lane, int kind,
+                                   int& olx, int& oly, int& ox, int& oy, int& oz, bool& stab_err) {
+  typedef Pack<K, BITS> P;
+  const int orient = STAB ? 2 : 6;
+  const int b0 = r.item0, b1 = r.item1, b2 = r.item2;
+  const double den = STAB ? next_density(p, e, r.oc - 1, r.traj, r.cursor - 1) : 1.0;
+  uint32_t* scratch = reinterpret_cast<uint32_t*>(l.tab0);  // the table region is idle between observations
+  // drop_box_virtual (D/space.py:393-433) of size (x,y,z) at (lx,ly): feasibility, height, and the sum of
+  // the heightmap under the footprint (NumPy clips the slice to the array)
+  auto probe = [&](int x, int y, int z, int lx, int ly, int& mh, long long& under) -> bool {
+    mh = 0;
+    under = 0;
+    const int xe = min(lx + x, p.A), ye = min(ly + y, p.A);
+    for (int cx = lx; cx < xe; cx++)
+      for (int cy = ly; cy < ye; cy++) {
+        int hh = l.hmap[cx * p.A + cy];
+        mh = hh > mh ? hh : mh;
+        under += hh;
+      }
+    bool feas = (lx + x <= p.W) && (ly + y <= p.Ly) && (mh + z <= p.H);
+    if (STAB && feas && mh != 0) {
+      const double cand[9] = {(double)lx, (double)ly, (double)mh, (double)(lx + x), (double)(ly + y), (double)(mh + z),
+                              (double)x, (double)y, (double)z};
+      BoxGeo<K, BITS> geo{l.box};
+      bool err;
+      feas = stab_virtual<false>(geo, stab_view(p, e), r.n_boxes, cand, den, err);
+      if (err) stab_err = true;
+    }
+    return feas;
+  };
+  const uint64_t NONE = ~0ull;
+  uint64_t best = NONE;
+  if (kind == PCT_HEUR_DBL || kind == PCT_HEUR_HM) {
+    // :431-498 / :232-298: every (lx, ly) the UNROTATED item fits at, every rotation
+    long long total = 0;
+    if (kind == PCT_HEUR_HM) {
+      long long part = 0;
+      for (int c = lane; c < p.W * p.Ly; c += 64) part += l.hmap[(c / p.Ly) * p.A + (c % p.Ly)];
+      total = wave_sum_i64(part);
+    }
+    const int nx = p.W - b0 + 1, ny = p.Ly - b1 + 1;
+    const int NQ = (nx > 0 && ny > 0) ? nx * ny * orient : 0;
+    for (int base = 0; base < NQ; base += 64) {
+      int q = base + lane;
+      if (q < NQ) {
+        int rot = q % orient, cell = q / orient;
+        int lx = cell / ny, ly = cell - lx * ny;
+        int x, y, z, mh;
+        long long under;
+        heur_rot(b0, b1, b2, rot, x, y, z);
+        if (probe(x, y, z, lx, ly, mh, under)) {
+          long long score = kind == PCT_HEUR_DBL ? (long long)(lx + ly) + 100ll * mh
+                                                 : (long long)(lx + ly) + 100ll * (total - under + (long long)(mh + z) * x * y);
+          uint64_t key = ((uint64_t)score << 24) | (uint64_t)q;
+          best = key < best ? key : best;
+        }
+      }
+    }
+    best = wave_min_u64(best);
+    if (best == NONE) return false;
+    int q = (int)(best & 0xFFFFFFull);
+    int rot = q % orient, cell = q / orient;
+    olx = cell / ny;
+    oly = cell - olx * ny;
+    heur_rot(b0, b1, b2, rot, ox, oy, oz);
+    return true;
+  }
+  const int E = r.n_ems;
+  const int NQ = E * orient;
+  if (kind == PCT_HEUR_OBPH) {
+    // :364-425: EMS in (z, y, x) order (stable), first feasible (corner, rotation); no fit-in-EMS test
+    for (int base = 0; base < NQ; base += 64) {
+      int q = base + lane;
+      if (q < NQ) {
+        int ei = q / orient, rot = q - ei * orient;
+        K ek = l.ems_a[ei];
+        int x, y, z, mh;
+        long long under;
+        heur_rot(b0, b1, b2, rot, x, y, z);
+        if (probe(x, y, z, P::get(ek, 0), P::get(ek, 1), mh, under)) {
+          uint64_t key = ((uint64_t)P::get(ek, 2) << 50) | ((uint64_t)P::get(ek, 1) << 40) | ((uint64_t)P::get(ek, 0) << 30) |
+                         (uint64_t)q;
+          best = key < best ? key : best;
+        }
+      }
+    }
+    best = wave_min_u64(best);
+    if (best == NONE) return false;
+    int q = (int)(best & 0x3FFFFFFFull);
+    int ei = q / orient, rot = q - ei * orient;
+    K ek = l.ems_a[ei];
+    olx = P::get(ek, 0);
+    oly = P::get(ek, 1);
+    heur_rot(b0, b1, b2, rot, ox, oy, oz);
+    return true;
+  }
+  if (kind == PCT_HEUR_BR) {
+    // :500-569: best eval_ems (volume + item types that fit unrotated + 10 if all do), first in order
+    for (int base = 0; base < E; base += 64) {
+      int ei = base + lane;
+      if (ei < E) {
+        K ek = l.ems_a[ei];
+        int dx = P::get(ek, 3) - P::get(ek, 0), dy = P::get(ek, 4) - P::get(ek, 1), dz = P::get(ek, 5) - P::get(ek, 2);
+        int fits = 0;
+        for (int i = 0; i < p.n_items; i++)
+          fits += (dx >= p.item_set[3 * i] && dy >= p.item_set[3 * i + 1] && dz >= p.item_set[3 * i + 2]) ? 1 : 0;
+        scratch[ei] = (uint32_t)(dx * dy * dz + fits + (fits == p.n_items ? 10 : 0));
+      }
+    }
+    __syncthreads();
+    for (int base = 0; base < NQ; base += 64) {
+      int q = base + lane;
+      if (q < NQ) {
+        int ei = q / orient, rot = q - ei * orient;
+        K ek = l.ems_a[ei];
+        int dx = P::get(ek, 3) - P::get(ek, 0), dy = P::get(ek, 4) - P::get(ek, 1), dz = P::get(ek, 5) - P::get(ek, 2);
+        int x, y, z, mh;
+        long long under;
+        heur_rot(b0, b1, b2, rot, x, y, z);
+        if (dx >= x && dy >= y && dz >= z && probe(x, y, z, P::get(ek, 0), P::get(ek, 1), mh, under)) {
+          uint64_t key = ((uint64_t)(0xFFFFFFFFu - scratch[ei]) << 24) | (uint64_t)q;
+          best = key < best ? key : best;
+        }
+      }
+    }
+    best = wave_min_u64(best);
+    __syncthreads();
+    if (best == NONE) return false;
+    int q = (int)(best & 0xFFFFFFull);
+    int ei = q / orient, rot = q - ei * orient;
+    K ek = l.ems_a[ei];
+    olx = P::get(ek, 0);
+    oly = P::get(ek, 1);
+    heur_rot(b0, b1, b2, rot, ox, oy, oz);
+    return true;
+  }
+  // :138-226 LASH: least surface area of the bounding box of everything packed so far
+  int maxX = 0, maxY = 0, minX = p.W, minY = p.Ly;
+  for (int i = 0; i < r.n_boxes; i++) {  // wave-uniform scan of the placed boxes
+    K bk = uniform_key<K>(l.box[i]);
+    maxX = max(maxX, P::get(bk, 3)); maxY = max(maxY, P::get(bk, 4));
+    minX = min(minX, P::get(bk, 0)); minY = min(minY, P::get(bk, 1));
+  }
+  const uint32_t init = (uint32_t)(p.W * p.Ly + p.Ly * p.H + p.H * p.W);
+  uint32_t smin = 0xFFFFFFFFu;
+  for (int base = 0; base < NQ; base += 64) {
+    int q = base + lane;
+    uint32_t sc = 0xFFFFFFFFu;
+    if (q < NQ) {
+      int ei = q / orient, rot = q - ei * orient;
+      K ek = l.ems_a[ei];
+      int dx = P::get(ek, 3) - P::get(ek, 0), dy = P::get(ek, 4) - P::get(ek, 1), dz = P::get(ek, 5) - P::get(ek, 2);
+      int x, y, z, mh;
+      long long under;
+      heur_rot(b0, b1, b2, rot, x, y, z);
+      int lx = P::get(ek, 0), ly = P::get(ek, 1);
+      if (dx >= x && dy >= y && dz >= z && probe(x, y, z, lx, ly, mh, under)) {
+        int ex = max(lx + x, maxX) - min(lx, minX), ey = max(ly + y, maxY) - min(ly, minY);
+        sc = (uint32_t)(ex * ey + (mh + z) * ey + (mh + z) * ex);
+      }
+      scratch[q] = sc;
+    }
+    smin = sc < smin ? sc : smin;
+  }
+  smin = (uint32_t)(wave_min_u64((uint64_t)smin));
+  __syncthreads();
+  bool found = false;
+  if (smin < init) {  // a score equal to the initial bound is never taken (:195-199 needs a best already)
+    int bd0 = 0, bd1 = 0, bd2 = 0;
+    for (int base = 0; base < NQ; base += 64) {
+      int q = base + lane;
+      uint64_t m = __ballot(q < NQ && scratch[q] == smin);
+      while (m) {  // the candidates that tie on the best score, in loop order (:195-199)
+        int bit = __ffsll((unsigned long long)m) - 1;
+        m &= m - 1;
+        int qq = base + bit;
+        int ei = qq / orient, rot = qq - ei * orient;
+        K ek = uniform_key<K>(l.ems_a[ei]);
+        int dx = P::get(ek, 3) - P::get(ek, 0), dy = P::get(ek, 4) - P::get(ek, 1), dz = P::get(ek, 5) - P::get(ek, 2);
+        int x, y, z;
+        heur_rot(b0, b1, b2, rot, x, y, z);
+        bool take = !found;
+        if (found) take = min(min(dx - x, dy - y), dz - z) < min(min(bd0 - x, bd1 - y), bd2 - z);
+        if (take) {
+          found = true;
+          olx = P::get(ek, 0); oly = P::get(ek, 1); ox = x; oy = y; oz = z;
+          bd0 = dx; bd1 = dy; bd2 = dz;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  return found;
+}
+
 // One transition of one env with the state resident in LDS (D/bin3D.py:151-188 plus the
 // VecEnv worker's auto-reset).  (flag, lx, ly) + (bx, by, bz) is the decoded action.
 template <typename K, int BITS, bool STAB, int SCHEME, typename TM>
 __device__ inline void transition(const DiscreteParams& p, int e, Lds<K, BITS>& l, EnvRegs& r, int lane, bool bad,
-                                  int flag, int lx, int ly, int bx, int by, int bz, TM& tm) {
+                                  int flag, int lx, int ly, int bx, int by, int bz, TM& tm, bool giveup = false) {
   typedef Pack<K, BITS> P;
   r.t++;
   int x = flag ? by : bx, y = flag ? bx : by, z = bz;  // D/space.py:348-351
-  bool ok = !bad;
+  bool ok = !bad && !giveup;  // giveup: a heuristic found no placement -- the episode ends without a step()
   int max_h = 0;
   // the density shown with the observation this action answers (D/bin3D.py:158 self.next_den)
   const double item_den = STAB ? next_density(p, e, r.oc - 1, r.traj, r.cursor - 1) : 1.0;
@@ -1029,7 +1242,7 @@ __device__ inline void transition(const DiscreteParams& p, int e, Lds<K, BITS>& 
     done = 1;
     counter = r.n_boxes;
     ratio = (double)r.vol / binvol;  // D/space.py:334-339
-    r.oc++;  // the terminal step's own (discarded) observation consumed a shuffle too (D/bin3D.py:165)
+    if (!giveup) r.oc++;  // the terminal step's own (discarded) observation consumed a shuffle too (D/bin3D.py:165)
     __syncthreads();
     space_reset<K, BITS>(p, l, r, lane);  // shmem_vec_env.py:141-143 -> D/bin3D.py:61-67
     __syncthreads();
@@ -1070,7 +1283,7 @@ __device__ inline void decode_leaf(const EnvRegs& r, bool zero_row, int xs, int 
   lx = xs; ly = ys; bx = x; by = y; bz = zz;
 }
 
-enum { ACT_ROWS = 0, ACT_INDEX = 1, ACT_HASH = 2, ACT_RESET = 3 };
+enum { ACT_ROWS = 0, ACT_INDEX = 1, ACT_HASH = 2, ACT_RESET = 3, ACT_HEUR = 4 /* row_len = PCT_HEUR_* */ };
 
 template <typename K, int BITS, int ACT, bool TIMED, bool STAB, int SCHEME, bool SHUFFLE>
 __global__ void __launch_bounds__(64) pct_discrete_kernel(DiscreteParams p, const void* __restrict__ actions,
@@ -1103,9 +1316,13 @@ __global__ void __launch_bounds__(64) pct_discrete_kernel(DiscreteParams p, cons
   }
 
   for (int it = 0; it < n_steps; it++) {
-    bool bad = false, zero_row = false;
+    bool bad = false, zero_row = false, giveup = false;
     int flag = 0, lx = 0, ly = 0, bx = 0, by = 0, bz = 0;
-    if (ACT == ACT_ROWS) {
+    if (ACT == ACT_HEUR) {
+      bool serr = false;
+      giveup = !heur_choose<K, BITS, STAB>(p, e, l, r, lane, row_len, lx, ly, bx, by, bz, serr);
+      if (STAB && __ballot(serr)) r.flags |= PCT_FLAG_STABILITY_OVERFLOW;
+    } else if (ACT == ACT_ROWS) {
       const float* row = reinterpret_cast<const float*>(actions) + (size_t)e * row_len;
       float v = lane < row_len ? row[lane] : 0.f;
       float a0 = __shfl(v, 0, 64), a1 = __shfl(v, 1, 64), a2 = __shfl(v, 2, 64), a3 = __shfl(v, 3, 64),
@@ -1132,7 +1349,7 @@ __global__ void __launch_bounds__(64) pct_discrete_kernel(DiscreteParams p, cons
       decode_leaf(r, zero_row, P::get(k, 0), P::get(k, 1), P::get(k, 3), P::get(k, 4), bad, lx, ly, bx, by, bz);
     }
     if (bad) r.flags |= PCT_FLAG_BAD_ACTION;  // ValueError in list.remove, D/bin3D.py:144-145
-    transition<K, BITS, STAB, SCHEME>(p, e, l, r, lane, bad, flag, lx, ly, bx, by, bz, tm);
+    transition<K, BITS, STAB, SCHEME>(p, e, l, r, lane, bad, flag, lx, ly, bx, by, bz, tm, giveup);
     leaf_nodes<K, BITS, STAB, SCHEME, SHUFFLE>(p, e, l, r, lane, tm);
     write_obs<K, BITS>(p, e, l, r, lane, obs);
     __syncthreads();
@@ -1182,6 +1399,19 @@ inline hipError_t launch_typed(const DiscreteParams& p, int act, const void* act
     }                                                                                                        \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, stream, p, actions, row_len, n_steps, env_ids, n_ids); \
   } while (0)
+  if (act == ACT_HEUR) {  // heuristic policies read the EMS list: LNES == EMS only (checked by the caller)
+    void (*kern)(DiscreteParams, const void*, int, int, const int32_t*, int);
+    if (stab) kern = p.shuffle ? pct_discrete_kernel<K, BITS, ACT_HEUR, false, true, 0, true>
+                               : pct_discrete_kernel<K, BITS, ACT_HEUR, false, true, 0, false>;
+    else kern = p.shuffle ? pct_discrete_kernel<K, BITS, ACT_HEUR, false, false, 0, true>
+                          : pct_discrete_kernel<K, BITS, ACT_HEUR, false, false, 0, false>;
+    if (lds > 48 * 1024) {
+      hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (er != hipSuccess) return er;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, stream, p, actions, row_len, n_steps, env_ids, n_ids);
+    return hipGetLastError();
+  }
   switch (act) {
     case ACT_ROWS: PCT_LAUNCH(ACT_ROWS); break;
     case ACT_INDEX: PCT_LAUNCH(ACT_INDEX); break;

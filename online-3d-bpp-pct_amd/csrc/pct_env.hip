@@ -29,7 +29,7 @@ int fail(int code, const char* fmt, ...) {
     if (_e != hipSuccess) return fail(PCT_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e));    \
   } while (0)
 
-enum { ACT_ROWS = 0, ACT_INDEX = 1, ACT_HASH = 2, ACT_RESET = 3 };
+enum { ACT_ROWS = 0, ACT_INDEX = 1, ACT_HASH = 2, ACT_RESET = 3, ACT_HEUR = 4 };
 }  // namespace
 
 struct pct_env {
@@ -531,6 +531,22 @@ int pct_step_hash_policy(pct_env* h, int32_t n_steps, void* stream) {
     return PCT_OK;
   }
   return launch(h, ACT_HASH, nullptr, 0, n_steps, nullptr, 0, stream);
+}
+
+int pct_step_heuristic(pct_env* h, int32_t kind, int32_t n_steps, void* stream) {
+  int rc = ready(h, true);
+  if (rc) return rc;
+  if (n_steps < 1) return fail(PCT_ERR_INVALID_ARG, "n_steps must be >= 1");
+  if (kind < PCT_HEUR_LSAH || kind > PCT_HEUR_BR) return fail(PCT_ERR_INVALID_ARG, "unknown heuristic");
+  if (h->continuous || h->cfg.lnes != PCT_LNES_EMS)
+    return fail(PCT_ERR_UNSUPPORTED, "the heuristics read the discrete env's heightmap and EMS list (LNES = EMS)");
+  /* one launch per step when the stability state is live (see pct_step_hash_policy) */
+  const int per = h->cfg.setting != 2 ? 1 : n_steps;
+  for (int done = 0; done < n_steps; done += per) {
+    rc = launch(h, ACT_HEUR, nullptr, kind, per, nullptr, 0, stream);
+    if (rc) return rc;
+  }
+  return PCT_OK;
 }
 
 int pct_policy_hash_rows(pct_env* h, float* rows_out, void* stream) {

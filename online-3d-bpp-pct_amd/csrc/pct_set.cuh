@@ -15,6 +15,23 @@ __device__ inline int wave_max_i32(int v) {
   }
   return v;
 }
+__device__ inline uint64_t wave_min_u64(uint64_t v) {
+  for (int off = 32; off > 0; off >>= 1) {
+    uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, off, 64);
+    uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), off, 64);
+    uint64_t o = ((uint64_t)hi << 32) | lo;
+    v = o < v ? o : v;
+  }
+  return v;
+}
+__device__ inline long long wave_sum_i64(long long v) {
+  for (int off = 32; off > 0; off >>= 1) {
+    uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)(uint64_t)v, off, 64);
+    uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)((uint64_t)v >> 32), off, 64);
+    v += (long long)(((uint64_t)hi << 32) | lo);
+  }
+  return v;
+}
 __device__ inline uint64_t lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
 __device__ inline uint64_t bcast_u64(uint64_t v, int src) {
   uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, src);

@@ -68,6 +68,13 @@ class VecEnv(ABC):
         pass
 
     @abstractmethod
+    def step_heuristic(self, name, n_steps=1):
+        """n_steps transitions with a heuristic baseline of heuristic.py as the in-env policy
+        (`name` in HEURISTICS: LSAH, HM, OnlineBPH, DBL, BR); follow with step_wait()."""
+        with torch.cuda.device(self._dev_index):
+            _lib.check(self._L.pct_step_heuristic(self._h, HEURISTICS[name], int(n_steps), self._stream()))
+        self.waiting_step = True
+
     def current_obs(self):
         """The handle's observation buffer (valid until the next transition)."""
         return self._obs
@@ -169,6 +176,9 @@ class LazyInfos(object):
 
 
 _LNES = {"EMS": _lib.LNES_EMS, "EV": _lib.LNES_EV, "EP": _lib.LNES_EP, "CP": _lib.LNES_CP, "FC": _lib.LNES_FC}
+
+
+HEURISTICS = {"LSAH": 0, "HM": 1, "OnlineBPH": 2, "DBL": 3, "BR": 4}  # include/pct_env.h PCT_HEUR_*
 
 
 class PctVecEnv(VecEnv):
@@ -369,6 +379,13 @@ class PctVecEnv(VecEnv):
             _lib.check(self._L.pct_step_hash_policy(self._h, int(n_steps), self._stream()))
         self.waiting_step = True
 
+    def step_heuristic(self, name, n_steps=1):
+        """n_steps transitions with a heuristic baseline of heuristic.py as the in-env policy
+        (`name` in HEURISTICS: LSAH, HM, OnlineBPH, DBL, BR); follow with step_wait()."""
+        with torch.cuda.device(self._dev_index):
+            _lib.check(self._L.pct_step_heuristic(self._h, HEURISTICS[name], int(n_steps), self._stream()))
+        self.waiting_step = True
+
     def current_obs(self):
         """The handle's observation buffer (valid until the next transition)."""
         return self._obs
@@ -496,3 +513,20 @@ def make_vec_envs(args, log_dir=None, allow_early_resets=True):
         continuous=kind.startswith("PctContinuous"),
         item_stream=getattr(args, "item_stream", None),
     )
+
+
+def evaluate_heuristic(env, name, episodes):
+    """heuristic.py's evaluation loop on the batched env: runs heuristic `name` on every env of `env`
+    until `episodes` episodes have finished in total (counted in completion order) and returns
+    (mean utilisation, variance of the utilisation, mean number of packed items) -- what
+    heuristic.py:226,298,425,498,569 return for one env.  Observations are not read."""
+    util, length = [], []
+    env.reset()
+    while len(util) < episodes:
+        env.step_heuristic(name, 1)
+        _, _, done, infos = env.step_wait()
+        for i in np.nonzero(done)[0]:
+            util.append(infos[i]["ratio"])
+            length.append(infos[i]["counter"])
+    util, length = np.asarray(util[:episodes]), np.asarray(length[:episodes])
+    return float(util.mean()), float(util.var()), float(length.mean())

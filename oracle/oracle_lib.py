@@ -55,6 +55,7 @@ def lib():
         L.pcto_set_item_dataset.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int32]
         L.pcto_set_sampler.argtypes = [vp, ctypes.c_uint64]
         L.pcto_set_shuffle_seed.argtypes = [vp, ctypes.c_uint64]
+        L.pcto_step_heuristic.argtypes = [vp, ctypes.c_int32, ctypes.c_int32]
         L.pcto_set_density_stream.argtypes = [vp, vp, ctypes.c_int64]
         L.pcto_set_dataset_density.argtypes = [vp, vp]
         for name in ("pcto_obs", "pcto_reward", "pcto_done", "pcto_info_counter", "pcto_info_ratio",
@@ -145,6 +146,9 @@ class OracleVecEnv(object):
         den = np.ascontiguousarray(np.asarray(den, dtype=np.float64))
         assert den.ndim == 2 and den.shape[0] == self.N
         self._check(lib().pcto_set_density_stream(self._h, den.ctypes.data, den.shape[1]))
+
+    def step_heuristic(self, kind, n_steps=1):
+        self._check(lib().pcto_step_heuristic(self._h, int(kind), int(n_steps)))
 
     def set_sampler(self, seed):
         self._check(lib().pcto_set_sampler(self._h, seed))

@@ -1081,6 +1081,178 @@ int pcto_step_hash_policy(pcto_env* h, int32_t n_steps) {
   return PCT_OK;
 }
 
+/* ---- heuristic.py: the placement rules of the heuristic baselines, as in-env policies ---------
+ * rotation convention of heuristic.py:260-271 (and every heuristic there): not the one of EMSPoint */
+static void heur_rot(const int nb[3], int rot, int* x, int* y, int* z) {
+  switch (rot) {
+    case 0: *x = nb[0]; *y = nb[1]; *z = nb[2]; break;
+    case 1: *y = nb[0]; *x = nb[1]; *z = nb[2]; break;
+    case 2: *z = nb[0]; *x = nb[1]; *y = nb[2]; break;
+    case 3: *z = nb[0]; *y = nb[1]; *x = nb[2]; break;
+    case 4: *x = nb[0]; *z = nb[1]; *y = nb[2]; break;
+    default: *y = nb[0]; *z = nb[1]; *x = nb[2]; break;
+  }
+}
+
+/* Picks the placement heuristic `kind` would step with.  Returns 0 if it finds none (the
+ * reference loop then records the episode and resets the env WITHOUT stepping). */
+static int heur_choose(const pcto_env* h, const oenv* s, int kind, int* olx, int* oly, int* ox, int* oy, int* oz) {
+  const int W = h->cfg.container[0], L = h->cfg.container[1], H = h->cfg.container[2], A = h->A;
+  const int orientation = h->cfg.setting == 2 ? 6 : 2;
+  const int* nb = s->next_box;
+  int found = 0;
+  if (kind == PCT_HEUR_DBL || kind == PCT_HEUR_HM) {
+    /* heuristic.py:431-498 DBL / :232-298 heightmap_min: every (lx, ly) the UNROTATED item fits at,
+     * every rotation; score lx + ly + 100*height resp. lx + ly + 100*sum(new heightmap); first best */
+    int64_t best = 0, total = 0;
+    if (kind == PCT_HEUR_HM)
+      for (int i = 0; i < W; i++) for (int j = 0; j < L; j++) total += s->plain[i * A + j];
+    for (int lx = 0; lx < W - nb[0] + 1; lx++)
+      for (int ly = 0; ly < L - nb[1] + 1; ly++)
+        for (int rot = 0; rot < orientation; rot++) {
+          int x, y, z;
+          heur_rot(nb, rot, &x, &y, &z);
+          int max_h = footprint_max(h, s, lx, ly, x, y);
+          if (max_h < 0 || !check_box(h, s, x, y, lx, ly, z, max_h, s->next_den, 1)) continue;
+          int64_t score;
+          if (kind == PCT_HEUR_DBL) score = lx + ly + 100 * (int64_t)max_h;
+          else { /* update_height_graph :316-326: the footprint becomes max_h + z */
+            int64_t under = 0;
+            for (int i = lx; i < lx + x; i++) for (int j = ly; j < ly + y; j++) under += s->plain[i * A + j];
+            score = lx + ly + 100 * (total - under + (int64_t)(max_h + z) * x * y);
+          }
+          if (!found || score < best) { best = score; found = 1; *olx = lx; *oly = ly; *ox = x; *oy = y; *oz = z; }
+        }
+    return found;
+  }
+  if (kind == PCT_HEUR_OBPH) {
+    /* :364-425 OnlineBPH: EMS sorted by (z, y, x), stable; first feasible (EMS corner, rotation) */
+    int n = s->n_ems;
+    int* idx = (int*)malloc(sizeof(int) * (size_t)(n + 1));
+    for (int i = 0; i < n; i++) {
+      int j = i;
+      while (j > 0) {
+        const int64_t* a = s->ems + 6 * idx[j - 1];
+        const int64_t* b = s->ems + 6 * i;
+        int greater = a[2] > b[2] || (a[2] == b[2] && (a[1] > b[1] || (a[1] == b[1] && a[0] > b[0])));
+        if (!greater) break;
+        idx[j] = idx[j - 1];
+        j--;
+      }
+      idx[j] = i;
+    }
+    for (int q = 0; q < n && !found; q++) {
+      const int64_t* e = s->ems + 6 * idx[q];
+      for (int rot = 0; rot < orientation; rot++) {
+        int x, y, z;
+        heur_rot(nb, rot, &x, &y, &z);
+        if (drop_box_virtual(h, s, x, y, z, (int)e[0], (int)e[1])) {
+          found = 1; *olx = (int)e[0]; *oly = (int)e[1]; *ox = x; *oy = y; *oz = z;
+          break;
+        }
+      }
+    }
+    free(idx);
+    return found;
+  }
+  if (kind == PCT_HEUR_LSAH) {
+    /* :138-226 LASH: least surface area of the bounding box of everything packed; maxXY / minXY are
+     * the running extents of the placements of this episode (:204-207) */
+    int maxX = 0, maxY = 0, minX = W, minY = L;
+    for (int i = 0; i < s->n_boxes; i++) {
+      const obox* b = &s->boxes[i];
+      if (b->lx + b->x > maxX) maxX = b->lx + b->x;
+      if (b->ly + b->y > maxY) maxY = b->ly + b->y;
+      if (b->lx < minX) minX = b->lx;
+      if (b->ly < minY) minY = b->ly;
+    }
+    int64_t best = (int64_t)W * L + (int64_t)L * H + (int64_t)H * W;
+    int bd[3] = {0, 0, 0};
+    for (int q = 0; q < s->n_ems; q++) {
+      const int64_t* e = s->ems + 6 * q;
+      int dx = (int)(e[3] - e[0]), dy = (int)(e[4] - e[1]), dz = (int)(e[5] - e[2]);
+      for (int rot = 0; rot < orientation; rot++) {
+        int x, y, z;
+        heur_rot(nb, rot, &x, &y, &z);
+        if (!(dx >= x && dy >= y && dz >= z)) continue;
+        int lx = (int)e[0], ly = (int)e[1];
+        int height = footprint_max(h, s, lx, ly, x, y);
+        if (height < 0 || !check_box(h, s, x, y, lx, ly, z, height, s->next_den, 1)) continue;
+        int ex = (lx + x > maxX ? lx + x : maxX) - (lx < minX ? lx : minX);
+        int ey = (ly + y > maxY ? ly + y : maxY) - (ly < minY ? ly : minY);
+        int64_t score = (int64_t)ex * ey + (int64_t)(height + z) * ey + (int64_t)(height + z) * ex;
+        int take = 0;
+        if (score < best) take = 1;
+        else if (score == best && found) {
+          int m1 = dx - x < dy - y ? dx - x : dy - y; if (dz - z < m1) m1 = dz - z;
+          int m2 = bd[0] - x < bd[1] - y ? bd[0] - x : bd[1] - y; if (bd[2] - z < m2) m2 = bd[2] - z;
+          if (m1 < m2) take = 1;
+        }
+        if (take) {
+          best = score; found = 1; *olx = lx; *oly = ly; *ox = x; *oy = y; *oz = z;
+          bd[0] = dx; bd[1] = dy; bd[2] = dz;
+        }
+      }
+    }
+    return found;
+  }
+  if (kind == PCT_HEUR_BR) {
+    /* :500-569 BR: the EMS with the best eval_ems (volume + number of item types that fit unrotated,
+     * + 10 if all do); first best in (EMS, rotation) order */
+    int64_t best = 0;
+    for (int q = 0; q < s->n_ems; q++) {
+      const int64_t* e = s->ems + 6 * q;
+      int dx = (int)(e[3] - e[0]), dy = (int)(e[4] - e[1]), dz = (int)(e[5] - e[2]);
+      int64_t sc = -1;
+      for (int rot = 0; rot < orientation; rot++) {
+        int x, y, z;
+        heur_rot(nb, rot, &x, &y, &z);
+        if (!(dx >= x && dy >= y && dz >= z)) continue;
+        int lx = (int)e[0], ly = (int)e[1];
+        if (!drop_box_virtual(h, s, x, y, z, lx, ly)) continue;
+        if (sc < 0) {
+          int fits = 0;
+          for (int i = 0; i < h->n_items; i++)
+            fits += dx >= h->item_set[3 * i] && dy >= h->item_set[3 * i + 1] && dz >= h->item_set[3 * i + 2];
+          sc = (int64_t)dx * dy * dz + fits + (fits == h->n_items ? 10 : 0);
+        }
+        if (!found || sc > best) { best = sc; found = 1; *olx = lx; *oly = ly; *ox = x; *oy = y; *oz = z; }
+      }
+    }
+    return found;
+  }
+  return 0;
+}
+
+int pcto_step_heuristic(pcto_env* h, int32_t kind, int32_t n_steps) {
+  int rc = ready(h);
+  if (rc) return rc;
+  if (h->cfg.env_kind != PCT_ENV_DISCRETE || h->cfg.lnes != PCT_LNES_EMS)
+    return fail(PCT_ERR_UNSUPPORTED, "the heuristics read the discrete env's heightmap and EMS list");
+  if (kind < PCT_HEUR_LSAH || kind > PCT_HEUR_BR) return fail(PCT_ERR_INVALID_ARG, "unknown heuristic");
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 8)
+  for (int e = 0; e < h->N; e++) {
+    oenv* s = &h->envs[e];
+    double* obs = h->obs + (size_t)e * h->row_len;
+    for (int it = 0; it < n_steps; it++) {
+      int lx = 0, ly = 0, x = 0, y = 0, z = 0;
+      if (heur_choose(h, s, kind, &lx, &ly, &x, &y, &z)) {
+        /* env.next_box = [x, y, z]; env.step([0, lx, ly]) == the 6-vector leaf form of the same placement */
+        double row[6] = {(double)lx, (double)ly, 0.0, (double)(lx + x), (double)(ly + y), (double)z};
+        any_step(h, e, row, 6, obs);
+      } else { /* no feasible placement: the episode is recorded and the env reset, no step() */
+        s->t++;
+        h->reward[e] = 0.0;
+        h->done[e] = 1;
+        h->counter[e] = s->n_boxes;
+        h->ratio[e] = get_ratio(h, s);
+      }
+      if (h->done[e]) any_reset(h, e, obs);
+    }
+  }
+  return PCT_OK;
+}
+
 int pcto_debug_state(pcto_env* h, int32_t e, int32_t* heightmap, int32_t* ems, int32_t cap_ems, int32_t* n_ems,
                      int32_t* n_boxes, int32_t* next_item, int64_t* draw_cursor) {
   if (!h || e < 0 || e >= h->N) return fail(PCT_ERR_INVALID_ARG, "bad env id");

@@ -86,3 +86,7 @@ def dataset_trajectories(z):
         out.append(np.asarray(z["traj_items"][o:o + int(n)], np.float64))
         o += int(n)
     return out
+
+
+HEURISTIC_CASES = ["heur_s2_10", "heur_s1_10", "heur_s2_rect"]
+HEUR_CODE = {"LSAH": 0, "HM": 1, "OnlineBPH": 2, "DBL": 3, "BR": 4}

@@ -575,6 +575,80 @@ def dataset_cases(want=lambda name: True):
                             reward=ref["reward"], done=ref["done"], counter=ref["counter"])
 
 
+HEUR_CODE = {"LSAH": 0, "HM": 1, "OnlineBPH": 2, "DBL": 3, "BR": 4}
+HEURISTIC_CASES = {
+    # heuristic.py baselines as in-env policies: per-episode utilisation and length of the reference loop
+    "heur_s2_10": dict(setting=2, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, episodes=12, stream_T=4096, seed=61),
+    "heur_s1_10": dict(setting=1, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, episodes=8, stream_T=4096, seed=62),
+    "heur_s2_rect": dict(setting=2, container=(9, 12, 8), lo=1, hi=4, I=120, L=30, episodes=8, stream_T=4096, seed=63),
+}
+
+
+def run_reference_heuristic(case, name):
+    """The reference's own loop (heuristic.py) on a scripted env; its per-episode print is captured."""
+    import builtins
+    ref_shim.install()
+    import heuristic as H
+    PD, PC, _ = ref_shim.load_reference_envs()
+    c = case
+    item_set = item_set_range(c["lo"], c["hi"])
+    stream = make_stream(c["seed"], 1, c["stream_T"], item_set)
+    env = PD(setting=c["setting"], container_size=list(c["container"]), item_set=item_set,
+             internal_node_holder=c["I"], leaf_node_holder=c["L"], shuffle=False, LNES="EMS")
+    env.box_creator = scripted_creator(stream[0])
+    fn = {"LSAH": H.LASH, "HM": H.heightmap_min, "OnlineBPH": H.OnlineBPH, "DBL": H.DBL, "BR": H.BR}[name]
+    rec = []
+    saved = builtins.print
+
+    def capture(*a, **k):
+        if a and isinstance(a[0], str) and a[0].startswith("Result of episode"):
+            # 'Result of episode {}, utilization: {}, length: {}'
+            parts = a[0].replace(",", "").split()
+            rec.append((float(parts[5]), int(parts[7])))
+
+    builtins.print = capture
+    try:
+        fn(env, c["episodes"])
+    finally:
+        builtins.print = saved
+    return stream, np.array([r[0] for r in rec], np.float64), np.array([r[1] for r in rec], np.int32)
+
+
+def run_oracle_heuristic(case, name, stream):
+    from oracle.oracle_lib import OracleVecEnv
+    c = case
+    env = OracleVecEnv(1, setting=c["setting"], container_size=c["container"], item_set=item_set_range(c["lo"], c["hi"]),
+                       internal_node_holder=c["I"], leaf_node_holder=c["L"])
+    env.set_item_stream(stream)
+    env.reset()
+    util, length = [], []
+    while len(util) < c["episodes"]:
+        env.step_heuristic(HEUR_CODE[name], 1)
+        if env.done[0]:
+            util.append(float(env.ratio[0]))
+            length.append(int(env.counter[0]))
+    assert not env.flags.any()
+    env.close()
+    return np.array(util, np.float64), np.array(length, np.int32)
+
+
+def heuristic_cases(want=lambda name: True):
+    for cname, case in HEURISTIC_CASES.items():
+        if not want(cname):
+            continue
+        out = {}
+        for name in HEUR_CODE:
+            stream, util, length = run_reference_heuristic(case, name)
+            o_util, o_len = run_oracle_heuristic(case, name, stream)
+            if not (np.array_equal(util, o_util) and np.array_equal(length, o_len)):
+                raise SystemExit("MISMATCH %s/%s\n ref %s %s\n ora %s %s" % (cname, name, util, length, o_util, o_len))
+            print("%-14s %-10s episodes=%d mean util %.4f mean length %.1f  oracle == reference" % (
+                cname, name, len(util), util.mean(), length.mean()))
+            out["util_" + name] = util
+            out["len_" + name] = length
+        np.savez_compressed(os.path.join(HERE, cname + ".npz"), meta=np.array(repr(case)), stream=stream, **out)
+
+
 def main():
     only = sys.argv[1:]  # optional name filters: regenerate only the matching cases
 
@@ -582,6 +656,7 @@ def main():
         return not only or any(o in name for o in only)
 
     dataset_cases(want)
+    heuristic_cases(want)
     if not only:
         known_answer_discrete_s2()
         known_answer_discrete_s1()

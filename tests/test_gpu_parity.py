@@ -475,3 +475,55 @@ def test_hip_expansion_schemes_match_oracle_many_small_items(lnes, setting):
     if lnes != "EV":
         assert most > 64, most
     env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["heur_s2_10", "heur_s1_10", "heur_s2_rect"])
+@pytest.mark.parametrize("heur", ["LSAH", "HM", "OnlineBPH", "DBL", "BR"])
+def test_hip_heuristics_match_reference_loops(name, heur):
+    """pct_step_heuristic against the per-episode results of the reference's own loops (heuristic.py)."""
+    c, z = load_case(name)
+    env = _pkg().PctVecEnv(1, setting=c["setting"], container_size=c["container"], item_set=item_set_range(c["lo"], c["hi"]),
+                           internal_node_holder=c["I"], leaf_node_holder=c["L"], item_stream=z["stream"], device="cuda:0")
+    env.reset()
+    util, length = [], []
+    while len(util) < c["episodes"]:
+        env.step_heuristic(heur, 1)
+        _, _, done, infos = env.step_wait()
+        if done[0]:
+            util.append(infos[0]["ratio"])
+            length.append(infos[0]["counter"])
+    assert np.array_equal(np.array(util), z["util_" + heur]), (util, z["util_" + heur])
+    assert np.array_equal(np.array(length, np.int32), z["len_" + heur])
+    assert not env.error_flags.any()
+    env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("setting", [2, 1, 3])
+@pytest.mark.parametrize("heur", ["LSAH", "HM", "OnlineBPH", "DBL", "BR"])
+def test_hip_heuristics_match_oracle_batched(heur, setting):
+    """Many envs, counter-based sampler: observations, rewards, dones step by step against the oracle;
+    evaluate_heuristic's statistics are those of the episodes seen."""
+    from oracle.oracle_lib import OracleVecEnv
+    from tests.common import HEUR_CODE
+    items = item_set_range(1, 5)
+    N = 128
+    kw = dict(setting=setting, container_size=(10, 9, 11), item_set=items, internal_node_holder=80, leaf_node_holder=30,
+              env_id_base=17)
+    ora = OracleVecEnv(N, **kw)
+    ora.set_sampler(5)
+    env = _pkg().PctVecEnv(N, seed=5, device="cuda:0", **kw)
+    ora.reset()
+    obs = env.reset()
+    for t in range(120):
+        assert np.array_equal(obs.cpu().numpy(), ora.obs.astype(np.float32)), (heur, t)
+        env.step_heuristic(heur, 1)
+        ora.step_heuristic(HEUR_CODE[heur], 1)
+        obs, reward, done, infos = env.step_wait()
+        assert np.array_equal(done.astype(np.uint8), ora.done), (heur, t)
+        assert np.array_equal(reward[:, 0].numpy(), ora.reward.astype(np.float32))
+        for i in np.nonzero(done)[0]:
+            assert infos[i]["ratio"] == ora.ratio[i] and infos[i]["counter"] == ora.counter[i]
+    assert not env.error_flags.any() and not ora.flags.any()
+    env.close()

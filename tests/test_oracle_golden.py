@@ -228,3 +228,25 @@ def test_shuffle_is_a_permutation_of_the_unshuffled_candidates():
         first = seqs[0][0].copy()  # same placement everywhere keeps the states identical
         for e in envs:
             e.step_rows(first[None])
+
+
+@pytest.mark.parametrize("name", ["heur_s2_10", "heur_s1_10", "heur_s2_rect"])
+@pytest.mark.parametrize("heur", ["LSAH", "HM", "OnlineBPH", "DBL", "BR"])
+def test_oracle_heuristics_match_reference_loops(name, heur):
+    """heuristic.py's loops (LASH, heightmap_min, OnlineBPH, DBL, BR) run on the unmodified reference:
+    per-episode utilisation and number of packed items of the same item stream."""
+    from tests.common import HEUR_CODE
+    c, z = load_case(name)
+    env = OracleVecEnv(1, setting=c["setting"], container_size=c["container"], item_set=item_set_range(c["lo"], c["hi"]),
+                       internal_node_holder=c["I"], leaf_node_holder=c["L"])
+    env.set_item_stream(z["stream"])
+    env.reset()
+    util, length = [], []
+    while len(util) < c["episodes"]:
+        env.step_heuristic(HEUR_CODE[heur], 1)
+        if env.done[0]:
+            util.append(float(env.ratio[0]))
+            length.append(int(env.counter[0]))
+    assert np.array_equal(np.array(util), z["util_" + heur])
+    assert np.array_equal(np.array(length, np.int32), z["len_" + heur])
+    assert not env.flags.any()
