@@ -170,7 +170,10 @@ int pct_set_shuffle_seed(pct_env* env, uint64_t seed);
 
 /* ---- outputs ------------------------------------------------------------------------ */
 /* Bind caller-owned device buffers (e.g. torch tensors).  Any pointer may be NULL to keep
- * the handle-owned buffer.  obs float32 [N,(I+L+1)*9]; reward float32 [N]; done uint8 [N];
+ * the handle-owned buffer.  The observation buffer belongs to the env between steps: a step only
+ * rewrites the rows that changed (the placed box's row, the leaf rows, the next-item row; every row
+ * when an episode ends), so the caller must treat it as read-only; binding a buffer makes the
+ * next launch rewrite it whole.  obs float32 [N,(I+L+1)*9]; reward float32 [N]; done uint8 [N];
  * counter int32 [N]; ratio float64 [N]; error_flags uint32 [N] (must be zero-filled). */
 int pct_bind_outputs(pct_env* env, float* obs, float* reward, uint8_t* done,
                      int32_t* counter, double* ratio, uint32_t* error_flags);

@@ -20,6 +20,7 @@ struct DiscreteParams {
   int setting, low_bound;
   int lnes; /* PCT_LNES_EMS / PCT_LNES_CP / PCT_LNES_FC */
   int shuffle;
+  int full_obs; /* 1: the observation buffer was (re)bound since the last launch -- rewrite every row */
   unsigned long long shuffle_seed;
   int ems_cap, cand_cap;
   int key_bytes; /* 4: six 5-bit coords (bins <= 31); 8: six 10-bit coords (<= 1023) */

@@ -65,6 +65,7 @@ struct EnvRegs {  // wave-uniform per-env scalars
   uint32_t flags;
   int traj;  // dataset mode: current trajectory (LoadBoxCreator.index)
   uint32_t oc;  // observations produced so far (shuffle key)
+  int box_from;  // placed boxes [box_from, n_boxes) are newer than the HBM copy
 };
 
 template <typename K, int BITS>
@@ -172,6 +173,7 @@ __device__ inline void space_reset(const DiscreteParams& p, Lds<K, BITS>& l, Env
   if (lane == 0) l.ems_a[0] = Pack<K, BITS>::pack(0, 0, 0, p.W, p.Ly, p.H);
   r.n_ems = 1;
   r.n_boxes = 0;
+  r.box_from = 0;
   r.vol = 0;
   if (p.source == PCT_ITEMS_DATASET) {  // LoadBoxCreator.reset (binCreator.py:51-62)
     r.traj++;
@@ -249,19 +251,47 @@ __device__ inline void genems(const DiscreteParams& p, Lds<K, BITS>& l, EnvRegs&
   // deleted.  Survivors are copied, children are tested against the whole list.
   for (int i = lane; i < (S < n ? S : n); i += 64) l.ems_a[i] = l.ems_b[i];
   int out = S < n ? S : n;
+  // 5-bit coordinates: containment as two packed subtractions.  A triple of 5-bit fields is spread to
+  // 6-bit spacing; with the guard bit G set in the minuend, (x | G) - y keeps G in a field iff
+  // x >= y there (no borrow crosses a field).  i inside j  <=>  lo(i) >= lo(j) and hi(j) >= hi(i)
+  // field by field; an entry always contains itself, so "some j != i" is "at least two j".
+  const bool swar = (BITS == 5) && (3 * n <= scap) && (out < n);
+  uint32_t* cmpw = reinterpret_cast<uint32_t*>(l.ems_b) + n;  // [n][2]: spread lo, spread hi | G
+  constexpr uint32_t G = 0x20820u;
+  auto spread = [](uint32_t t) { return (t & 0x1Fu) | ((t & 0x3E0u) << 1) | ((t & 0x7C00u) << 2); };
+  if (swar) {
+    for (int i = lane; i < n; i += 64) {
+      uint32_t kk = (uint32_t)l.ems_b[i];
+      cmpw[2 * i] = spread(kk & 0x7FFFu);
+      cmpw[2 * i + 1] = spread((kk >> 15) & 0x7FFFu) | G;
+    }
+    __syncthreads();
+  }
   for (int base = out; base < n; base += 64) {
     int i = base + lane;
     bool live = i < n;
     K k = live ? l.ems_b[i] : (K)0;
-    int a0 = P::get(k, 0), a1 = P::get(k, 1), a2 = P::get(k, 2), a3 = P::get(k, 3), a4 = P::get(k, 4),
-        a5 = P::get(k, 5);
     bool del = false;
-    for (int j = 0; j < n; j++) {
-      K kj = uniform_key<K>(l.ems_b[j]);
-      int b0 = P::get(kj, 0), b1 = P::get(kj, 1), b2 = P::get(kj, 2), b3 = P::get(kj, 3), b4 = P::get(kj, 4),
-          b5 = P::get(kj, 5);
-      bool inside = (a0 >= b0) & (a1 >= b1) & (a2 >= b2) & (a3 <= b3) & (a4 <= b4) & (a5 <= b5);
-      del |= inside & (j != i);
+    if (swar) {
+      const uint32_t alo_g = spread((uint32_t)k & 0x7FFFu) | G, ahi = spread(((uint32_t)k >> 15) & 0x7FFFu);
+      int cnt = 0;
+#pragma unroll 4
+      for (int j = 0; j < n; j++) {
+        const uint32_t blo = uniform_key<uint32_t>(cmpw[2 * j]), bhi_g = uniform_key<uint32_t>(cmpw[2 * j + 1]);
+        const uint32_t t = (alo_g - blo) & (bhi_g - ahi) & G;
+        cnt += (t == G) ? 1 : 0;
+      }
+      del = cnt >= 2;
+    } else {
+      int a0 = P::get(k, 0), a1 = P::get(k, 1), a2 = P::get(k, 2), a3 = P::get(k, 3), a4 = P::get(k, 4),
+          a5 = P::get(k, 5);
+      for (int j = 0; j < n; j++) {
+        K kj = uniform_key<K>(l.ems_b[j]);
+        int b0 = P::get(kj, 0), b1 = P::get(kj, 1), b2 = P::get(kj, 2), b3 = P::get(kj, 3), b4 = P::get(kj, 4),
+            b5 = P::get(kj, 5);
+        bool inside = (a0 >= b0) & (a1 >= b1) & (a2 >= b2) & (a3 <= b3) & (a4 <= b4) & (a5 <= b5);
+        del |= inside & (j != i);
+      }
     }
     bool keep = live && !del;
     uint64_t m = __ballot(keep);
@@ -723,13 +753,21 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
       if (npend >= 64) flush(64);
     }
   } else {
+    // rotations worth generating: not skipped by the reference's rule, and not a repeat of an
+    // earlier generated rotation with the same (sx, sy, sz) -- for one EMS that repeat yields the
+    // same four tuples right after the first, i.e. set.add no-ops
+    // (closed form of "first occurrence of (sx,sy,sz) among the rotations the reference generates")
+    const bool e01 = b0 == b1, e02 = b0 == b2, e12 = b1 == b2;
+    const bool g1 = !e01, g2 = !e12, g3 = !(e01 && e12) && !(g1 && e02) && !(g2 && e01);
+    const bool g4 = !e02 && !(g1 && e12), g5 = !e12 && !e02 && !(g4 && e01);
+    const uint32_t rotmask = 1u | (g1 ? 2u : 0u) | (g2 ? 4u : 0u) | (g3 ? 8u : 0u) | (g4 ? 16u : 0u) | (g5 ? 32u : 0u);
     for (int pbase = 0; pbase < NP && !cand_overflow; pbase += 64) {
       // which (EMS, rotation) pairs of this chunk can hold the item at all
       int q = pbase + lane;
       bool pv = q < NP;
       int ei = q / orient, rot = q - ei * orient;
       int sx, sy, sz;
-      bool skip = rot_size(rot, sx, sy, sz);
+      bool skip = rot_size(rot, sx, sy, sz) || !((rotmask >> rot) & 1u);
       K ek = pv ? l.ems_a[ei] : (K)0;
       pv = pv && !skip && (P::get(ek, 3) - P::get(ek, 0) >= sx) && (P::get(ek, 4) - P::get(ek, 1) >= sy) &&
            (P::get(ek, 5) - P::get(ek, 2) >= sz);
@@ -826,6 +864,23 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
     }
     nleaf = nf;
   } else {
+    if (size >= 512) {
+      // a big table is at most 60 % full (usually far less): squeeze the keys to the front, in slot
+      // order, so that the feasibility sweep below walks keys instead of slots (the table is not
+      // needed as a table any more; a chunk is read whole before it is written, leftwards)
+      uint32_t cnt = 0;
+      for (uint32_t sb = 0; sb < size; sb += 64) {
+        K k = tabs[toff + sb + lane];
+        bool occ = k != SlotWord<K>::EMPTY;
+        uint64_t m = __ballot(occ);
+        if (occ) tabs[toff + cnt + __popcll(m & lt)] = k;
+        cnt += (uint32_t)__popcll(m);
+      }
+      const uint32_t padded = (cnt + 63u) & ~63u;
+      if (cnt + lane < padded) tabs[toff + cnt + lane] = SlotWord<K>::EMPTY;
+      size = padded;
+      __syncthreads();
+    }
     for (uint32_t sb = 0; sb < size && nleaf < p.L; sb += 64) {
       uint32_t s2 = sb + lane;
       K k = (s2 < size) ? tabs[toff + s2] : SlotWord<K>::EMPTY;
@@ -845,8 +900,11 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
 
 // D/bin3D.py:70-93: the [I+L+1, 9] float32 observation, written once, coalesced
 template <typename K, int BITS>
+// `full` rewrites every row (reset, end of an episode, freshly bound buffer); otherwise the buffer
+// still holds this env's previous observation and only what changed is written: the row of the
+// box just placed (`new_row`, or -1), the L leaf rows and the next-item row.
 __device__ inline void write_obs(const DiscreteParams& p, int e, const Lds<K, BITS>& l, const EnvRegs& r, int lane,
-                                 float* __restrict__ obs) {
+                                 float* __restrict__ obs, bool full, int new_row) {
   typedef Pack<K, BITS> P;
   int a = r.item0, b = r.item1, c = r.item2, tmp;
   if (a > b) { tmp = a; a = b; b = tmp; }
@@ -859,7 +917,13 @@ __device__ inline void write_obs(const DiscreteParams& p, int e, const Lds<K, BI
   const bool dens = p.setting == 3;  // densities other than 1 (D/space.py:386, D/bin3D.py:91)
   const double* bden = p.st_den + (size_t)e * p.I;
   const float nden = dens ? (float)next_density(p, e, r.oc - 1, r.traj, r.cursor - 1) : 1.0f;
-  for (int rbase = 0; rbase < rows; rbase += 7) {
+  if (!full && new_row >= 0 && lane < 9) {
+    K k = l.box[new_row];
+    float v = lane < 6 ? (float)P::get(k, lane) : (lane == 7 ? 0.f : 1.0f);
+    if (dens && lane == 6) v = (float)bden[new_row];
+    obs[new_row * 9 + lane] = v;
+  }
+  for (int rbase = full ? 0 : p.I; rbase < rows; rbase += 7) {
     const int row = rbase + rsub;
     if (!lane_on || row >= rows) continue;
     float v = 0.f;
@@ -885,7 +949,8 @@ __device__ inline void write_obs(const DiscreteParams& p, int e, const Lds<K, BI
 }
 
 template <typename K, int BITS>
-__device__ inline void load_state(const DiscreteParams& p, int e, Lds<K, BITS>& l, EnvRegs& r, int lane) {
+__device__ inline void load_state(const DiscreteParams& p, int e, Lds<K, BITS>& l, EnvRegs& r, int lane,
+                                  bool need_boxes, bool need_leaves) {
   const K* g_ems = reinterpret_cast<const K*>(p.ems) + (size_t)e * p.ems_cap;
   const K* g_box = reinterpret_cast<const K*>(p.boxes) + (size_t)e * p.I;
   const K* g_leaf = reinterpret_cast<const K*>(p.leaves) + (size_t)e * p.L;
@@ -900,8 +965,11 @@ __device__ inline void load_state(const DiscreteParams& p, int e, Lds<K, BITS>& 
   r.traj = sc[12];
   r.oc = (uint32_t)sc[13];
   for (int i = lane; i < r.n_ems; i += 64) l.ems_a[i] = g_ems[i];
-  for (int i = lane; i < r.n_boxes; i += 64) l.box[i] = g_box[i];
-  for (int i = lane; i < r.n_leaf; i += 64) l.leaf[i] = g_leaf[i];
+  if (need_boxes)
+    for (int i = lane; i < r.n_boxes; i += 64) l.box[i] = g_box[i];
+  if (need_leaves)
+    for (int i = lane; i < r.n_leaf; i += 64) l.leaf[i] = g_leaf[i];
+  r.box_from = r.n_boxes;
   for (int i = lane; i < p.AA; i += 64) l.hmap[i] = (typename Lds<K, BITS>::HT)g_h[i];
   __syncthreads();
 }
@@ -914,7 +982,7 @@ __device__ inline void store_state(const DiscreteParams& p, int e, const Lds<K, 
   int16_t* g_h = p.hmap + (size_t)e * p.AA;
   int32_t* sc = p.scalars + (size_t)e * PCT_SCALARS;
   for (int i = lane; i < r.n_ems; i += 64) g_ems[i] = l.ems_a[i];
-  for (int i = lane; i < r.n_boxes; i += 64) g_box[i] = l.box[i];
+  for (int i = r.box_from + lane; i < r.n_boxes; i += 64) g_box[i] = l.box[i];
   for (int i = lane; i < r.n_leaf; i += 64) g_leaf[i] = l.leaf[i];
   for (int i = lane; i < p.AA; i += 64) g_h[i] = (int16_t)l.hmap[i];
   if (lane == 0) {
@@ -1146,7 +1214,7 @@ __device__ inline bool heur_choose(const DiscreteParams& p, int e, Lds<K, BITS>&
 // One transition of one env with the state resident in LDS (D/bin3D.py:151-188 plus the
 // VecEnv worker's auto-reset).  (flag, lx, ly) + (bx, by, bz) is the decoded action.
 template <typename K, int BITS, bool STAB, int SCHEME, typename TM>
-__device__ inline void transition(const DiscreteParams& p, int e, Lds<K, BITS>& l, EnvRegs& r, int lane, bool bad,
+__device__ inline bool transition(const DiscreteParams& p, int e, Lds<K, BITS>& l, EnvRegs& r, int lane, bool bad,
                                   int flag, int lx, int ly, int bx, int by, int bz, TM& tm, bool giveup = false) {
   typedef Pack<K, BITS> P;
   r.t++;
@@ -1255,6 +1323,7 @@ __device__ inline void transition(const DiscreteParams& p, int e, Lds<K, BITS>& 
     p.counter[e] = counter;
     p.ratio[e] = ratio;
   }
+  return done != 0;  // true: the episode ended and the env was reset
 }
 
 // D/bin3D.py:139-149 LeafNode2Action for a leaf given as six integers (zero row -> (0,0,0)
@@ -1301,7 +1370,10 @@ __global__ void __launch_bounds__(64) pct_discrete_kernel(DiscreteParams p, cons
   EnvRegs r;
   PhaseTimer<TIMED> tm;
   tm.start();
-  load_state<K, BITS>(p, e, l, r, lane);
+  // the placed-box list is only read by the stability check, the CP / EP schemes, LASH and a full
+  // rewrite of the observation; the leaf list only by the index / stand-in actions
+  const bool need_boxes = STAB || SCHEME != 0 || ACT == ACT_HEUR || p.full_obs != 0;
+  load_state<K, BITS>(p, e, l, r, lane, need_boxes, ACT == ACT_INDEX || ACT == ACT_HASH);
   tm.tick(PH_LOAD);
   float* obs = p.obs + (size_t)e * p.row_len;
 
@@ -1310,7 +1382,7 @@ __global__ void __launch_bounds__(64) pct_discrete_kernel(DiscreteParams p, cons
     __syncthreads();
     draw_item(p, e, r);
     leaf_nodes<K, BITS, STAB, SCHEME, SHUFFLE>(p, e, l, r, lane, tm);
-    write_obs<K, BITS>(p, e, l, r, lane, obs);
+    write_obs<K, BITS>(p, e, l, r, lane, obs, true, -1);
     store_state<K, BITS>(p, e, l, r, lane);
     return;
   }
@@ -1349,9 +1421,9 @@ __global__ void __launch_bounds__(64) pct_discrete_kernel(DiscreteParams p, cons
       decode_leaf(r, zero_row, P::get(k, 0), P::get(k, 1), P::get(k, 3), P::get(k, 4), bad, lx, ly, bx, by, bz);
     }
     if (bad) r.flags |= PCT_FLAG_BAD_ACTION;  // ValueError in list.remove, D/bin3D.py:144-145
-    transition<K, BITS, STAB, SCHEME>(p, e, l, r, lane, bad, flag, lx, ly, bx, by, bz, tm, giveup);
+    const bool ended = transition<K, BITS, STAB, SCHEME>(p, e, l, r, lane, bad, flag, lx, ly, bx, by, bz, tm, giveup);
     leaf_nodes<K, BITS, STAB, SCHEME, SHUFFLE>(p, e, l, r, lane, tm);
-    write_obs<K, BITS>(p, e, l, r, lane, obs);
+    write_obs<K, BITS>(p, e, l, r, lane, obs, ended || (p.full_obs != 0 && it == 0), ended ? -1 : r.n_boxes - 1);
     __syncthreads();
     tm.tick(PH_OBS);
   }

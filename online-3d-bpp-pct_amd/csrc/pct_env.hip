@@ -125,6 +125,7 @@ int launch(pct_env* h, int act, const void* actions, int row_len, int n_steps, c
     }
   } else {
     HIP_TRY(pct::launch_discrete(h->dp, act, actions, row_len, n_steps, ids, n_ids, s));
+    if (act != ACT_RESET || !ids) h->dp.full_obs = 0; /* every env has rewritten its rows */
   }
   if (h->profiling) HIP_TRY(hipEventRecord(h->ev_pool[slot].second, s));
   return PCT_OK;
@@ -464,6 +465,7 @@ int pct_set_sampler(pct_env* h, uint64_t seed) {
 int pct_bind_outputs(pct_env* h, float* obs, float* reward, uint8_t* done, int32_t* counter, double* ratio,
                      uint32_t* error_flags) {
   if (!h) return fail(PCT_ERR_INVALID_ARG, "null handle");
+  h->dp.full_obs = 1; /* the new buffer holds nobody's previous observation */
   h->dp.obs = obs ? obs : h->own_obs;
   h->dp.reward = reward ? reward : h->own_reward;
   h->dp.done = done ? done : h->own_done;

@@ -181,18 +181,33 @@ __device__ inline void pyset_match(K* tab, uint32_t mask, bool part, uint64_t ha
   while (true) {
     while (walking) {
       uint32_t cur = w.i + w.j;
-      K v = tab_ld<GT, K>(&tab[cur]);
-      if ((v & TAG) && v > mytag) {  // empty, or tentatively held by a later lane
+      if (GT) {
+        K v = tab_ld<GT, K>(&tab[cur]);
+        if ((v & TAG) && v > mytag) {  // empty, or tentatively held by a later lane
+          K old = lds_atomic_min(&tab[cur], mytag);
+          if (old > mytag) {
+            slot = cur;
+            placed = true;
+            walking = false;
+          }
+        } else if (check_found && same(v)) {
+          walking = false;  // already a member
+        } else {
+          w.next(mask);  // a different key, or an earlier lane's tentative hold
+        }
+      } else {
+        // LDS: propose straight away -- a real key (tag bit clear) or an earlier lane's tag is
+        // numerically smaller than mytag and stays, so the atomic doubles as the read
         K old = lds_atomic_min(&tab[cur], mytag);
-        if (old > mytag) {
+        if (old > mytag) {  // was empty, or tentatively held by a later lane
           slot = cur;
           placed = true;
           walking = false;
+        } else if (check_found && !(old & TAG) && same(old)) {
+          walking = false;  // already a member
+        } else {
+          w.next(mask);
         }
-      } else if (check_found && same(v)) {
-        walking = false;  // already a member
-      } else {
-        w.next(mask);  // a different key, or an earlier lane's tentative hold
       }
     }
     __syncthreads();
