@@ -108,9 +108,11 @@ typedef struct pct_config {
   int32_t lnes;                 /* PCT_LNES_* */
   int32_t env_id_base;          /* global id of local env 0 (multi-GPU sharding: env e of
                                    the job lives on rank e / num_envs) */
-  int32_t ems_capacity;         /* 0 = default (256) */
+  int32_t ems_capacity;         /* EMS kept per env after elimination; 0 = default (128 for discrete
+                                   bins up to 12 per axis, else 256); overflow -> PCT_FLAG_EMS_OVERFLOW */
   int32_t candidate_capacity;   /* hash-table slots for the leaf-candidate set;
-                                   0 = default (2048); power of two */
+                                   0 = default (2048; 8192 for discrete bins above 12 per axis);
+                                   8 * 4^k; overflow -> PCT_FLAG_CANDIDATE_OVERFLOW */
   int32_t shuffle;              /* 1: permute the candidate list before the first-L cut
                                    (bin3D.py:114-115 `--shuffle`); see pct_shuffle_priority */
   int32_t reserved[3];
@@ -132,7 +134,7 @@ int pct_set_item_set(pct_env* env, const int32_t* item_set, int32_t n);
  * (1e-3; the reference's integer bin sizes are multiples of 1000) and items are 3-decimal
  * sizes (C/bin3D.py:106-108).  Sampler bounds in lattice units (tools.py:178-181);
  * low_bound = left (C/bin3D.py:25-27).  The c-th draw of global env g is
- * left + pct_mix64(seed, g, 3c+d) % (right-left+1) for d = 0,1,2.  A float32 action row is
+ * left + pct_pick(seed, g, 3c+d, right-left+1) for d = 0,1,2.  A float32 action row is
  * matched back to the env's current leaf whose float32 cast it is and decoded from that
  * leaf's float64 values, i.e. exactly like the reference decodes the float64 row
  * (round(.,6), C/bin3D.py:153-173); a row matching no leaf is decoded from the widened
@@ -162,7 +164,7 @@ int pct_set_item_dataset(pct_env* env, const int32_t* items, const int32_t* leng
 int pct_set_density_stream(pct_env* env, const double* den, int64_t T);
 int pct_set_dataset_density(pct_env* env, const double* den);
 /* Counter-based sampler: the c-th draw of global env g is
- * item_set[pct_mix64(seed, g, c) % n] (discrete) -- see pct_mix64 below. */
+ * item_set[pct_pick(seed, g, c, n)] (discrete) -- see pct_pick below. */
 int pct_set_sampler(pct_env* env, uint64_t seed);
 
 /* Seed of the shuffle permutation (default 0). */
@@ -258,6 +260,11 @@ PCT_INLINE uint64_t pct_mix64(uint64_t seed, uint64_t env_global_id, uint64_t co
  * is visited in ascending (priority, i) order: a uniform random permutation keyed by (seed,
  * global env id, observation counter).  The oracle implements the same rule, so the HIP path is
  * still checked bit for bit; against the reference the comparison is distributional. */
+/* uniform index in [0, n): floor(u * n), u = the top 32 bits of pct_mix64 as a fraction of 2^32
+ * (a multiply instead of a 64-bit modulo on the device) */
+PCT_INLINE uint32_t pct_pick(uint64_t seed, uint64_t env_global_id, uint64_t counter, uint32_t n) {
+  return (uint32_t)(((pct_mix64(seed, env_global_id, counter) >> 32) * (uint64_t)n) >> 32);
+}
 PCT_INLINE uint32_t pct_shuffle_priority(uint64_t seed, uint64_t env_global_id, uint64_t obs_counter, uint32_t i) {
   return (uint32_t)(pct_mix64(seed ^ 0x5BD1E9955BD1E995ull, env_global_id, (obs_counter << 20) | (uint64_t)i) >> 32);
 }

@@ -140,9 +140,9 @@ __device__ inline void cdraw_item(const ContinuousParams& p, int e, CRegs& r) {
   } else {
     uint64_t g = (uint64_t)(p.env_id_base + e);
     uint64_t span = (uint64_t)(p.sample_right - p.sample_left + 1);
-    r.ik0 = p.sample_left + (int)(pct_mix64(p.seed, g, c * 3 + 0) % span);
-    r.ik1 = p.sample_left + (int)(pct_mix64(p.seed, g, c * 3 + 1) % span);
-    r.ik2 = p.sample_left + (int)(pct_mix64(p.seed, g, c * 3 + 2) % span);
+    r.ik0 = p.sample_left + (int)(pct_pick(p.seed, g, c * 3 + 0, (uint32_t)span));
+    r.ik1 = p.sample_left + (int)(pct_pick(p.seed, g, c * 3 + 1, (uint32_t)span));
+    r.ik2 = p.sample_left + (int)(pct_pick(p.seed, g, c * 3 + 2, (uint32_t)span));
   }
   // round(U(a,b), 3) (C/bin3D.py:106-108): the double nearest to k/1000
   r.b0 = (double)r.ik0 / 1000.0; r.b1 = (double)r.ik1 / 1000.0; r.b2 = (double)r.ik2 / 1000.0;

@@ -66,6 +66,9 @@ struct EnvRegs {  // wave-uniform per-env scalars
   int traj;  // dataset mode: current trajectory (LoadBoxCreator.index)
   uint32_t oc;  // observations produced so far (shuffle key)
   int box_from;  // placed boxes [box_from, n_boxes) are newer than the HBM copy
+  // the item that the draw number pre_cursor (of trajectory pre_traj) yields, fetched at kernel start
+  int pre0, pre1, pre2, pre_traj;
+  uint64_t pre_cursor;
 };
 
 template <typename K, int BITS>
@@ -159,7 +162,7 @@ __device__ inline void draw_item(const DiscreteParams& p, int e, EnvRegs& r) {
     it = p.stream + ((size_t)e * (size_t)p.T + (size_t)(c % (uint64_t)p.T)) * 3;
   } else {
     uint64_t g = (uint64_t)(p.env_id_base + e);
-    it = p.item_set + (size_t)(pct_mix64(p.seed, g, c) % (uint64_t)p.n_items) * 3;
+    it = p.item_set + (size_t)(pct_pick(p.seed, g, c, (uint32_t)p.n_items)) * 3;
   }
   r.item0 = it[0];
   r.item1 = it[1];
@@ -362,20 +365,22 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
     tm.sub_tick(PH_SET_DEDUP);
     while (true) {
       uint64_t pm = __ballot(pending);
-      if (!pm) break;
       // set_add_entry grows the table when fill*5 >= mask*3, checked right after each
       // insertion: at most thr - fill more keys go into this table
       uint32_t mask = size - 1;
       uint32_t thr = (mask * 3u + 4u) / 5u;
-      bool part = pending && (uint32_t)__popcll(pm & lt) < thr - fill;
-      bool placed;
-      uint32_t slot;
-      pyset_match<K>(tabs + toff, mask, part, hash, lane, true, placed, slot, [&](K w) { return w == key; });
-      if (placed) tabs[toff + slot] = key;
-      pending = pending && !part;
-      fill += (uint32_t)__popcll(__ballot(placed));
-      __syncthreads();
-      tm.sub_tick(PH_SET_MATCH);
+      if (fill < thr) {
+        if (!pm) break;
+        bool part = pending && (uint32_t)__popcll(pm & lt) < thr - fill;
+        bool placed;
+        uint32_t slot;
+        pyset_match<K>(tabs + toff, mask, part, hash, lane, true, placed, slot, [&](K w) { return w == key; });
+        if (placed) tabs[toff + slot] = key;
+        pending = pending && !part;
+        fill += (uint32_t)__popcll(__ballot(placed));
+        __syncthreads();
+        tm.sub_tick(PH_SET_MATCH);
+      }
       if (fill >= thr) {  // set_table_resize(used * 4): re-insert in old-slot order
         uint32_t newsize = 8;
         while (newsize <= fill * 4u) newsize <<= 1;
@@ -956,6 +961,13 @@ __device__ inline void load_state(const DiscreteParams& p, int e, Lds<K, BITS>& 
   const K* g_leaf = reinterpret_cast<const K*>(p.leaves) + (size_t)e * p.L;
   const int16_t* g_h = p.hmap + (size_t)e * p.AA;
   const int32_t* sc = p.scalars + (size_t)e * PCT_SCALARS;
+  // the first 128 EMS words and the heightmap do not wait for the scalars: their loads go out
+  // first (reading past n_ems stays inside the env's slice), so that one memory round trip covers
+  // the whole state
+  const K e0 = g_ems[lane];
+  const K e1 = (lane + 64 < p.ems_cap) ? g_ems[lane + 64] : (K)0;
+  const int16_t h0 = lane < p.AA ? g_h[lane] : (int16_t)0;
+  const int16_t h1 = lane + 64 < p.AA ? g_h[lane + 64] : (int16_t)0;
   r.n_ems = sc[0]; r.n_boxes = sc[1]; r.n_leaf = sc[2];
   r.item0 = sc[3]; r.item1 = sc[4]; r.item2 = sc[5];
   r.t = (uint32_t)sc[6];
@@ -964,13 +976,17 @@ __device__ inline void load_state(const DiscreteParams& p, int e, Lds<K, BITS>& 
   r.vol = (int64_t)(((uint64_t)(uint32_t)sc[11] << 32) | (uint32_t)sc[10]);
   r.traj = sc[12];
   r.oc = (uint32_t)sc[13];
-  for (int i = lane; i < r.n_ems; i += 64) l.ems_a[i] = g_ems[i];
+  if (lane < r.n_ems) l.ems_a[lane] = e0;
+  if (lane + 64 < r.n_ems) l.ems_a[lane + 64] = e1;
+  for (int i = 128 + lane; i < r.n_ems; i += 64) l.ems_a[i] = g_ems[i];
   if (need_boxes)
     for (int i = lane; i < r.n_boxes; i += 64) l.box[i] = g_box[i];
   if (need_leaves)
     for (int i = lane; i < r.n_leaf; i += 64) l.leaf[i] = g_leaf[i];
+  if (lane < p.AA) l.hmap[lane] = (typename Lds<K, BITS>::HT)h0;
+  if (lane + 64 < p.AA) l.hmap[lane + 64] = (typename Lds<K, BITS>::HT)h1;
   r.box_from = r.n_boxes;
-  for (int i = lane; i < p.AA; i += 64) l.hmap[i] = (typename Lds<K, BITS>::HT)g_h[i];
+  for (int i = 128 + lane; i < p.AA; i += 64) l.hmap[i] = (typename Lds<K, BITS>::HT)g_h[i];
   __syncthreads();
 }
 
@@ -1316,7 +1332,12 @@ __device__ inline bool transition(const DiscreteParams& p, int e, Lds<K, BITS>& 
     __syncthreads();
     tm.tick(PH_DROP);
   }
-  draw_item(p, e, r);
+  if (r.cursor == r.pre_cursor && r.traj == r.pre_traj) {  // the usual case: the prefetched draw
+    r.item0 = r.pre0; r.item1 = r.pre1; r.item2 = r.pre2;
+    r.cursor++;
+  } else {
+    draw_item(p, e, r);
+  }
   if (lane == 0) {
     p.reward[e] = reward;
     p.done[e] = done;
@@ -1372,8 +1393,22 @@ __global__ void __launch_bounds__(64) pct_discrete_kernel(DiscreteParams p, cons
   tm.start();
   // the placed-box list is only read by the stability check, the CP / EP schemes, LASH and a full
   // rewrite of the observation; the leaf list only by the index / stand-in actions
+  // the action row is fetched before the state so that both loads share one memory round trip
+  float act_v = 0.f;
+  if (ACT == ACT_ROWS) {
+    const float* row = reinterpret_cast<const float*>(actions) + (size_t)e * row_len;
+    act_v = lane < row_len ? row[lane] : 0.f;
+  }
   const bool need_boxes = STAB || SCHEME != 0 || ACT == ACT_HEUR || p.full_obs != 0;
   load_state<K, BITS>(p, e, l, r, lane, need_boxes, ACT == ACT_INDEX || ACT == ACT_HASH);
+  {  // the next draw of the item source does not depend on this step's outcome (except after a
+     // dataset reset): issue its loads now, use them at the end of the transition
+    EnvRegs nx = r;
+    draw_item(p, e, nx);
+    r.pre0 = nx.item0; r.pre1 = nx.item1; r.pre2 = nx.item2;
+    r.pre_cursor = r.cursor;
+    r.pre_traj = r.traj;
+  }
   tm.tick(PH_LOAD);
   float* obs = p.obs + (size_t)e * p.row_len;
 
@@ -1395,8 +1430,7 @@ __global__ void __launch_bounds__(64) pct_discrete_kernel(DiscreteParams p, cons
       giveup = !heur_choose<K, BITS, STAB>(p, e, l, r, lane, row_len, lx, ly, bx, by, bz, serr);
       if (STAB && __ballot(serr)) r.flags |= PCT_FLAG_STABILITY_OVERFLOW;
     } else if (ACT == ACT_ROWS) {
-      const float* row = reinterpret_cast<const float*>(actions) + (size_t)e * row_len;
-      float v = lane < row_len ? row[lane] : 0.f;
+      float v = act_v;
       float a0 = __shfl(v, 0, 64), a1 = __shfl(v, 1, 64), a2 = __shfl(v, 2, 64), a3 = __shfl(v, 3, 64),
             a4 = __shfl(v, 4, 64), a5 = __shfl(v, 5, 64);
       if (row_len == 3) {  // (flag, lx, ly) with the unrotated item, D/bin3D.py:152-153

@@ -164,9 +164,11 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
     return fail(PCT_ERR_UNSUPPORTED, "continuous container sizes must be whole bin units (multiples of 1000 lattice units)");
   /* discrete bins <= 31 per axis (32-bit keys): 128 EMS (82 is the most the 10^3 probes ever
    * held before elimination) keeps the env at 10 KB of LDS = 16 resident envs per CU */
-  int ems_cap = cfg->ems_capacity > 0 ? cfg->ems_capacity : ((!cont && maxdim <= 31) ? 128 : 256);
+  int ems_cap = cfg->ems_capacity > 0 ? cfg->ems_capacity : ((!cont && maxdim <= 12) ? 128 : 256);
   if (!cont && ems_cap < 64) return fail(PCT_ERR_INVALID_ARG, "ems_capacity must be >= 64");
-  int cand_cap = cfg->candidate_capacity > 0 ? cfg->candidate_capacity : 2048;
+  /* candidate table: 2048 slots (1228 distinct candidates) cover the 10^3-class bins with room to
+   * spare; larger discrete bins default to 8192 (4915) */
+  int cand_cap = cfg->candidate_capacity > 0 ? cfg->candidate_capacity : ((cont || maxdim <= 12) ? 2048 : 8192);
   if (!is_cand_cap_ok(cand_cap)) return fail(PCT_ERR_INVALID_ARG, "candidate_capacity must be 8*4^k (8,32,...,2048,8192)");
 
   int ndev = 0;

@@ -167,7 +167,7 @@ static void draw_item(const pcto_env* h, int e, oenv* s, int out[3]) {
     out[0] = p[0]; out[1] = p[1]; out[2] = p[2];
   } else {
     uint64_t g = (uint64_t)(h->cfg.env_id_base + e);
-    uint64_t idx = pct_mix64(h->seed, g, c) % (uint64_t)h->n_items;
+    uint64_t idx = pct_pick(h->seed, g, c, (uint32_t)h->n_items);
     out[0] = h->item_set[idx * 3 + 0];
     out[1] = h->item_set[idx * 3 + 1];
     out[2] = h->item_set[idx * 3 + 2];

@@ -164,7 +164,7 @@ static void draw_item(const struct pcto_env* h, int e, struct cenv* s, double ou
   } else {
     uint64_t g = (uint64_t)(h->cfg.env_id_base + e);
     uint64_t span = (uint64_t)(h->sample_right - h->sample_left + 1);
-    for (int d = 0; d < 3; d++) k[d] = h->sample_left + (int32_t)(pct_mix64(h->seed, g, c * 3 + (uint64_t)d) % span);
+    for (int d = 0; d < 3; d++) k[d] = h->sample_left + (int32_t)(pct_pick(h->seed, g, c * 3 + (uint64_t)d, (uint32_t)span));
   }
   for (int d = 0; d < 3; d++) out[d] = (double)k[d] / 1000.0;
 }

@@ -13,7 +13,7 @@ def header_functions():
     src = open(os.path.join(ROOT, "include", "pct_env.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     names = re.findall(r"\b(pct_[a-z0-9_]+)\s*\(", src)
-    return sorted(set(n for n in names if n not in ("pct_mix64", "pct_mix32", "pct_shuffle_priority", "pct_density")))  # inline helpers
+    return sorted(set(n for n in names if n not in ("pct_mix64", "pct_mix32", "pct_shuffle_priority", "pct_density", "pct_pick")))  # inline helpers
 
 
 def test_library_builds_and_exports_header_symbols():
