@@ -574,14 +574,18 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
 }
 
 // C/bin3D.py:78-100 observation rows, float32 (envs.py:180)
+// `full` rewrites every row; otherwise only what changed since this env's previous observation:
+// the row of the box just placed (`new_row`, or -1), the leaf rows and the next-item row
 __device__ inline void cwrite_obs(const ContinuousParams& p, int e, const CLds& l, const CRegs& r, int lane,
-                                  float* __restrict__ obs) {
+                                  float* __restrict__ obs, bool full, int new_row) {
   const float nden = (float)next_density(p, e, r.oc - 1, r.traj, r.cursor - 1);  // C/bin3D.py:81-90,98
   double a = r.b0, b = r.b1, c = r.b2, tmp;
   if (a > b) { tmp = a; a = b; b = tmp; }
   if (b > c) { tmp = b; b = c; c = tmp; }
   if (a > b) { tmp = a; a = b; b = tmp; }
-  for (int f = lane; f < p.row_len; f += 64) {
+  if (!full && new_row >= 0 && lane < 9)
+    obs[new_row * 9 + lane] = lane < 6 ? (float)l.box[lane * p.I + new_row] : (lane == 8 ? 1.0f : 0.f);
+  for (int f = lane + (full ? 0 : p.I * 9); f < p.row_len; f += 64) {
     int row = f / 9;
     int col = f - row * 9;
     float v = 0.f;
@@ -661,7 +665,7 @@ __device__ inline void cstore(const ContinuousParams& p, int e, const CLds& l, c
 // C/bin3D.py:169-207 step (+ the VecEnv worker's auto-reset).  a1/a2: raw position entries of
 // the action, (bx,by,bz): the item as LeafNode2Action returns it.
 template <bool STAB, typename TM>
-__device__ inline void ctransition(const ContinuousParams& p, int e, CLds& l, CRegs& r, int lane, int flag, double a1,
+__device__ inline bool ctransition(const ContinuousParams& p, int e, CLds& l, CRegs& r, int lane, int flag, double a1,
                                    double a2, double bx, double by, double bz, TM& tm) {
   r.t++;
   const double lx = around6(a1), ly = around6(a2);  // idx = [round(action[1], 6), round(action[2], 6)]
@@ -752,6 +756,7 @@ __device__ inline void ctransition(const ContinuousParams& p, int e, CLds& l, CR
     p.counter[e] = counter;
     p.ratio[e] = ratio;
   }
+  return done != 0;  // true: the episode ended and the env was reset
 }
 
 // C/bin3D.py:151-167 LeafNode2Action on a float64 row (a0,a1,_,a3,a4,_)
@@ -809,7 +814,7 @@ __global__ void __launch_bounds__(64) pct_continuous_kernel(ContinuousParams p, 
     cdraw_item(p, e, r);
     requeue = cleaf_nodes<GT, STAB>(p, e, l, r, lane, tm);
     if (!requeue) {
-      cwrite_obs(p, e, l, r, lane, obs);
+      cwrite_obs(p, e, l, r, lane, obs, true, -1);
       cstore(p, e, l, r, lane);
     }
   } else {
@@ -859,10 +864,10 @@ __global__ void __launch_bounds__(64) pct_continuous_kernel(ContinuousParams p, 
       }
       cdecode_leaf(r, zero_row, a0, a1, a3, a4, p1, p2, bx, by, bz);
     }
-    ctransition<STAB>(p, e, l, r, lane, flag, p1, p2, bx, by, bz, tm);
+    const bool ended = ctransition<STAB>(p, e, l, r, lane, flag, p1, p2, bx, by, bz, tm);
     requeue = cleaf_nodes<GT, STAB>(p, e, l, r, lane, tm);
     if (requeue) break;
-    cwrite_obs(p, e, l, r, lane, obs);
+    cwrite_obs(p, e, l, r, lane, obs, ended || (p.full_obs != 0 && it == 0), ended ? -1 : r.n_boxes - 1);
     __syncthreads();
     tm.tick(PH_OBS);
   }

@@ -64,6 +64,7 @@ struct DiscreteParams {
 // coordinate column is contiguous: ems[c][i], boxes[c][i], leaves[c][i]).
 struct ContinuousParams {
   int N, I, L, row_len, setting;
+  int full_obs; /* as in DiscreteParams */
   double W, Ly, H; /* container (integral values, as the reference's int64 plain_size) */
   double low_bound; /* C/bin3D.py:25-29 size_minimum */
   int shuffle;

@@ -110,6 +110,7 @@ int launch(pct_env* h, int act, const void* actions, int row_len, int n_steps, c
     if (rc) return rc;
   }
   if (h->continuous) {
+    h->cp.full_obs = h->dp.full_obs;
     if (h->has_retry) HIP_TRY(hipMemsetAsync(h->cp.retry_count, 0, sizeof(int), s));
     HIP_TRY(pct::launch_continuous(h->cp, act, actions, row_len, n_steps, ids, n_ids, s));
     if (h->has_retry) {
@@ -120,9 +121,10 @@ int launch(pct_env* h, int act, const void* actions, int row_len, int n_steps, c
       q.den_stream = c.den_stream; q.den_T = c.den_T; q.ds_den = c.ds_den;
       q.ds_ntraj = c.ds_ntraj; q.ds_maxlen = c.ds_maxlen; q.sample_left = c.sample_left; q.sample_right = c.sample_right;
       q.low_bound = c.low_bound; q.obs = c.obs; q.reward = c.reward; q.done = c.done; q.counter = c.counter;
-      q.ratio = c.ratio; q.flags = c.flags; q.timing = nullptr;
+      q.ratio = c.ratio; q.flags = c.flags; q.timing = nullptr; q.full_obs = c.full_obs;
       HIP_TRY(pct::launch_continuous(q, act, actions, row_len, n_steps, ids, h->cp_retry_blocks, s));
     }
+    if (act != ACT_RESET || !ids) h->dp.full_obs = 0;
   } else {
     HIP_TRY(pct::launch_discrete(h->dp, act, actions, row_len, n_steps, ids, n_ids, s));
     if (act != ACT_RESET || !ids) h->dp.full_obs = 0; /* every env has rewritten its rows */

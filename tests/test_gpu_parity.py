@@ -530,24 +530,29 @@ def test_hip_heuristics_match_oracle_batched(heur, setting):
 
 
 @pytest.mark.gpu
-def test_hip_observation_is_rewritten_in_full_after_rebinding_the_buffer():
+@pytest.mark.parametrize("kind", ["discrete", "continuous"])
+def test_hip_observation_is_rewritten_in_full_after_rebinding_the_buffer(kind):
     """Between steps the kernel only rewrites the rows that changed (new box row, leaf rows, next
     item); a buffer bound in mid-episode (pct_bind_outputs) holds nobody's previous observation and
     must be rewritten whole by the next step."""
+    from ctypes import c_void_p
     from oracle.oracle_lib import OracleVecEnv
-    items = item_set_range(1, 5)
     N = 64
-    stream = make_stream(5, N, 256, items)
-    kw = dict(setting=2, container_size=(10, 10, 10), item_set=items, internal_node_holder=80, leaf_node_holder=50)
-    ora = OracleVecEnv(N, **kw)
-    ora.set_item_stream(stream)
-    env = _pkg().PctVecEnv(N, item_stream=stream, device="cuda:0", **kw)
+    if kind == "discrete":
+        items = item_set_range(1, 5)
+        kw = dict(setting=2, container_size=(10, 10, 10), item_set=items, internal_node_holder=80, leaf_node_holder=50)
+        ora = OracleVecEnv(N, **kw)
+        env = _pkg().PctVecEnv(N, seed=9, device="cuda:0", **kw)
+    else:
+        kw = dict(setting=2, container_size=(10, 10, 10), internal_node_holder=80, leaf_node_holder=50)
+        ora = OracleVecEnv(N, env_kind=1, sample_bounds=(1.0, 5.0), **kw)
+        env = _pkg().PctVecEnv(N, continuous=True, sample_left_bound=1.0, sample_right_bound=5.0, seed=9, device="cuda:0", **kw)
+    ora.set_sampler(9)
     ora.reset()
     env.reset()
-    for t in range(40):
-        if t == 17:  # rebind the observation to a fresh (garbage-filled) tensor in mid-episode
+    for t in range(60):
+        if t in (17, 41):  # rebind the observation to a fresh (garbage-filled) tensor in mid-episode
             fresh = torch.full_like(env._obs, 7.0)
-            from ctypes import c_void_p
             assert env._L.pct_bind_outputs(env._h, c_void_p(fresh.data_ptr()), c_void_p(env._reward.data_ptr()),
                                            c_void_p(env._done.data_ptr()), c_void_p(env._counter.data_ptr()),
                                            c_void_p(env._ratio.data_ptr()), c_void_p(env._flags.data_ptr())) == 0
@@ -555,5 +560,6 @@ def test_hip_observation_is_rewritten_in_full_after_rebinding_the_buffer():
         env.step_hash_policy(1)
         ora.step_hash_policy(1)
         obs, reward, done, infos = env.step_wait()
-        assert np.array_equal(obs.cpu().numpy(), ora.obs.astype(np.float32)), t
+        assert np.array_equal(obs.cpu().numpy(), ora.obs.astype(np.float32)), (kind, t)
+    assert not env.error_flags.any()
     env.close()
