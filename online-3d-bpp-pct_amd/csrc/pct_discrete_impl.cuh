@@ -194,35 +194,14 @@ __device__ inline void genems(const DiscreteParams& p, Lds<K, BITS>& l, EnvRegs&
   const int scap = (int)table_words_compact((uint32_t)p.cand_cap);  // pre-elimination list capacity
   const int lb = p.low_bound <= 0 ? 1 : p.low_bound;
   const uint64_t lt = lanemask_lt(lane);
-  // sweep 1: survivors (EMS not intersected by the box) keep their order at the front
-  int S = 0;
-  for (int base = 0; base < E; base += 64) {
-    int i = base + lane;
-    bool live = i < E;
-    K k = live ? l.ems_a[i] : (K)0;
-    int x1 = P::get(k, 0), y1 = P::get(k, 1), z1 = P::get(k, 2), x2 = P::get(k, 3), y2 = P::get(k, 4),
-        z2 = P::get(k, 5);
-    int t1 = max(bx0, x1), u1 = max(by0, y1), v1 = max(bz0, z1);
-    int t2 = min(bx1, x2), u2 = min(by1, y2), v2 = min(bz1, z2);
-    bool inter = live && (t1 < t2) && (u1 < u2) && (v1 < v2);
-    bool surv = live && !inter;
-    uint64_t m = __ballot(surv);
-    if (surv) l.ems_b[S + __popcll(m & lt)] = k;
-    S += __popcll(m);
-  }
-  // sweep 2: children of every intersected EMS, by parent index then branch order
-  int C = 0;
-  bool overflow = false;
-  for (int base = 0; base < E; base += 64) {
-    int i = base + lane;
-    bool live = i < E;
-    K k = live ? l.ems_a[i] : (K)0;
+  // children of the intersected EMS held by this lane, written at `first` + (this lane's offset
+  // among the chunk's children): parent index, then branch order.  Returns the chunk's child count.
+  auto emit_children = [&](bool live, K k, int first) -> int {
     int x1 = P::get(k, 0), y1 = P::get(k, 1), z1 = P::get(k, 2), x2 = P::get(k, 3), y2 = P::get(k, 4),
         z2 = P::get(k, 5);
     int x3 = max(bx0, x1), y3 = max(by0, y1), z3 = max(bz0, z1);
     int x4 = min(bx1, x2), y4 = min(by1, y2), z4 = min(bz1, z2);
     bool inter = live && (x3 < x4) && (y3 < y4) && (z3 < z4);
-    (void)z3;
     bool ylz = (y2 - y1 >= lb) && (z2 - z1 >= lb);
     bool xlz = (x2 - x1 >= lb) && (z2 - z1 >= lb);
     bool c0 = inter && (x3 - x1 >= lb) && ylz;                       // [x1,y1,z1,x3,y2,z2]
@@ -231,14 +210,48 @@ __device__ inline void genems(const DiscreteParams& p, Lds<K, BITS>& l, EnvRegs&
     bool c3 = inter && (y2 - y4 >= lb) && xlz;                       // [x1,y4,z1,x2,y2,z2]
     bool c4 = inter && (z2 - z4 >= lb) && (x2 - x1 >= lb) && (y2 - y1 >= lb);  // [x1,y1,z4,x2,y2,z2]
     uint64_t m0 = __ballot(c0), m1 = __ballot(c1), m2 = __ballot(c2), m3 = __ballot(c3), m4 = __ballot(c4);
-    int pos = S + C + __popcll(m0 & lt) + __popcll(m1 & lt) + __popcll(m2 & lt) + __popcll(m3 & lt) +
+    int pos = first + __popcll(m0 & lt) + __popcll(m1 & lt) + __popcll(m2 & lt) + __popcll(m3 & lt) +
               __popcll(m4 & lt);
     if (c0) { if (pos < scap) l.ems_b[pos] = P::pack(x1, y1, z1, x3, y2, z2); pos++; }
     if (c1) { if (pos < scap) l.ems_b[pos] = P::pack(x4, y1, z1, x2, y2, z2); pos++; }
     if (c2) { if (pos < scap) l.ems_b[pos] = P::pack(x1, y1, z1, x2, y3, z2); pos++; }
     if (c3) { if (pos < scap) l.ems_b[pos] = P::pack(x1, y4, z1, x2, y2, z2); pos++; }
     if (c4) { if (pos < scap) l.ems_b[pos] = P::pack(x1, y1, z4, x2, y2, z2); pos++; }
-    C += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3) + __popcll(m4);
+    return __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3) + __popcll(m4);
+  };
+  auto intersects = [&](K k) -> bool {
+    int t1 = max(bx0, P::get(k, 0)), u1 = max(by0, P::get(k, 1)), v1 = max(bz0, P::get(k, 2));
+    int t2 = min(bx1, P::get(k, 3)), u2 = min(by1, P::get(k, 4)), v2 = min(bz1, P::get(k, 5));
+    return (t1 < t2) && (u1 < u2) && (v1 < v2);
+  };
+  // survivors (EMS not intersected by the box) keep their order at the front, then the children of
+  // every intersected EMS
+  int S = 0, C = 0;
+  bool overflow = false;
+  if (E <= 64) {  // the usual case: one read of the list serves both
+    bool live = lane < E;
+    K k = live ? l.ems_a[lane] : (K)0;
+    bool surv = live && !intersects(k);
+    uint64_t m = __ballot(surv);
+    if (surv) l.ems_b[__popcll(m & lt)] = k;
+    S = __popcll(m);
+    C = emit_children(live, k, S);
+  } else {
+    for (int base = 0; base < E; base += 64) {
+      int i = base + lane;
+      bool live = i < E;
+      K k = live ? l.ems_a[i] : (K)0;
+      bool surv = live && !intersects(k);
+      uint64_t m = __ballot(surv);
+      if (surv) l.ems_b[S + __popcll(m & lt)] = k;
+      S += __popcll(m);
+    }
+    for (int base = 0; base < E; base += 64) {
+      int i = base + lane;
+      bool live = i < E;
+      K k = live ? l.ems_a[i] : (K)0;
+      C += emit_children(live, k, S + C);
+    }
   }
   int n = S + C;
   if (n > scap) {
@@ -270,6 +283,29 @@ __device__ inline void genems(const DiscreteParams& p, Lds<K, BITS>& l, EnvRegs&
     }
     __syncthreads();
   }
+  if (swar && n - out <= 32) {
+    // few children: several lanes share a child and split the list between them
+    const int Cn = n - out;
+    int Cp = 1;
+    while (Cp < Cn) Cp <<= 1;
+    const int parts = 64 / Cp;
+    const int ci = lane & (Cp - 1), part = lane / Cp;
+    const bool live = ci < Cn;
+    const K k = live ? l.ems_b[out + ci] : (K)0;
+    const uint32_t alo_g = spread((uint32_t)k & 0x7FFFu) | G, ahi = spread(((uint32_t)k >> 15) & 0x7FFFu);
+    int cnt = 0;
+    for (int j = part; j < n; j += parts) {
+      const uint32_t blo = cmpw[2 * j], bhi_g = cmpw[2 * j + 1];
+      const uint32_t t = (alo_g - blo) & (bhi_g - ahi) & G;
+      cnt += (t == G) ? 1 : 0;
+    }
+    for (int off = Cp; off < 64; off <<= 1) cnt += __shfl_xor(cnt, off, 64);
+    const bool keep = live && part == 0 && cnt < 2;
+    const uint64_t m = __ballot(keep);
+    const int o = out + __popcll(m & lt);
+    if (keep && o < p.ems_cap) l.ems_a[o] = k;
+    out += __popcll(m);
+  } else
   for (int base = out; base < n; base += 64) {
     int i = base + lane;
     bool live = i < n;
