@@ -399,6 +399,86 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
     uint64_t hash = tuplehash6<K, BITS>(key);
     pending = pending && !batch_find_duplicates_reg<64, K>(dd, pending, key, hash, lane);
     tm.sub_tick(PH_SET_DEDUP);
+    if (sizeof(K) == 4 && fill == 0 && size == 8 && p.cand_cap >= 128) {
+      const uint64_t pm0 = __ballot(pending);
+      if (__popcll(pm0) >= 19) {
+        // Fast start of a fresh set with >= 19 new keys (every key of this batch is new to the empty
+        // table and to the rest of the batch).  CPython puts the first 5 into the 8-slot table, grows
+        // it to 32 slots (re-inserting in slot order), adds keys 6..19 and grows again to 128.  The
+        // two small tables are replayed on the scalar unit -- a table is a VGPR whose lane s holds
+        // the source lane of the key in slot s, occupancy is a scalar bit mask, hashes come over
+        // v_readlane -- and only their outcome is materialised: the 128-slot table receives, in ONE
+        // pass, the 19 keys in 32-table slot order followed by the rest of the batch.
+        uint64_t rem = pm0;
+        int t8 = 0xFF, t32 = 0xFF;  // per lane: source lane of the key in that slot
+        uint32_t occ8 = 0, occ32 = 0;
+        auto lane_hash = [&](int src) -> uint64_t {
+          uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)hash, src);
+          uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(hash >> 32), src);
+          return ((uint64_t)hi << 32) | lo;
+        };
+        for (int o = 0; o < 5; o++) {  // mask 7: no linear probes (i + 9 > mask)
+          const int src = __ffsll((unsigned long long)rem) - 1;
+          rem &= rem - 1;
+          const uint64_t h = lane_hash(src);
+          uint32_t i = (uint32_t)h & 7u;
+          uint64_t perturb = h;
+          while ((occ8 >> i) & 1u) {
+            perturb >>= 5;
+            i = (i * 5u + 1u + (uint32_t)perturb) & 7u;
+          }
+          occ8 |= 1u << i;
+          t8 = lane == (int)i ? src : t8;
+        }
+        auto insert32 = [&](int src) {  // set_insert_clean / set_add_entry on the 32-slot table
+          const uint64_t h = lane_hash(src);
+          uint32_t i = (uint32_t)h & 31u;
+          uint64_t perturb = h;
+          while (true) {
+            const uint32_t span = (i + 9u <= 31u) ? 10u : 1u;  // slot i, plus 9 linear probes if they fit
+            const uint32_t w = (~occ32 >> i) & ((1u << span) - 1u);
+            if (w) {
+              i += (uint32_t)__ffs((int)w) - 1u;
+              break;
+            }
+            perturb >>= 5;
+            i = (i * 5u + 1u + (uint32_t)perturb) & 31u;
+          }
+          occ32 |= 1u << i;
+          t32 = lane == (int)i ? src : t32;
+        };
+        for (uint32_t m8 = occ8; m8; m8 &= m8 - 1u) insert32(__builtin_amdgcn_readlane(t8, __ffs((int)m8) - 1));
+        for (int o = 5; o < 19; o++) {
+          const int src = __ffsll((unsigned long long)rem) - 1;
+          rem &= rem - 1;
+          insert32(src);
+        }
+        // insertion order into the 128-slot table: 32-table slot order, then the rest of the batch
+        K* fin = reinterpret_cast<K*>(dd);
+        const K from_slot = shfl_key<K>(key, t32 & 63);
+        const bool in32 = lane < 32 && ((occ32 >> lane) & 1u);
+        const bool later = (rem >> lane) & 1ull;
+        if (in32) fin[__popcll((uint64_t)occ32 & lt)] = from_slot;
+        if (later) fin[19 + __popcll(rem & lt)] = key;
+        const int total = 19 + __popcll(rem);
+        tabs[lane] = EMPTY;
+        tabs[64 + lane] = EMPTY;
+        __syncthreads();
+        const K mk = lane < total ? fin[lane] : (K)0;
+        __syncthreads();
+        dd[lane] = 0xFFFFFFFFu;  // back to the all-ones state the de-duplication expects
+        bool mplaced;
+        uint32_t mslot;
+        pyset_match<K>(tabs, 127u, lane < total, tuplehash6<K, BITS>(mk), lane, false, mplaced, mslot, [&](K) { return false; });
+        if (mplaced) tabs[mslot] = mk;
+        toff = 0;  // table_offset_compact(cap, 128) for every cap >= 128 that is not 128 itself; see below
+        size = 128;
+        fill = (uint32_t)total;
+        pending = false;
+        __syncthreads();
+        tm.sub_tick(PH_SET_MATCH);
+      }
+    }
     while (true) {
       uint64_t pm = __ballot(pending);
       // set_add_entry grows the table when fill*5 >= mask*3, checked right after each
@@ -1412,7 +1492,10 @@ __device__ inline void decode_leaf(const EnvRegs& r, bool zero_row, int xs, int 
 enum { ACT_ROWS = 0, ACT_INDEX = 1, ACT_HASH = 2, ACT_RESET = 3, ACT_HEUR = 4 /* row_len = PCT_HEUR_* */ };
 
 template <typename K, int BITS, int ACT, bool TIMED, bool STAB, int SCHEME, bool SHUFFLE>
-__global__ void __launch_bounds__(64) pct_discrete_kernel(DiscreteParams p, const void* __restrict__ actions,
+// the plain setting-2 kernels are held to 128 VGPRs (4 waves per SIMD = 16 resident envs per CU, the
+// occupancy the LDS layout is sized for); the float64 stability code and the timed build are not
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((STAB || TIMED) ? 1 : 4)))
+pct_discrete_kernel(DiscreteParams p, const void* __restrict__ actions,
                                                           int row_len, int n_steps,
                                                           const int32_t* __restrict__ env_ids, int n_ids) {
   extern __shared__ __align__(16) unsigned char smem[];
