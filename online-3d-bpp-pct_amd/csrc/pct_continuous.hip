@@ -224,7 +224,6 @@ __device__ inline StabState cstab_view(const ContinuousParams& p, int e) {
 __device__ inline void cgenems(const ContinuousParams& p, CLds& l, CRegs& r, int lane, const double loc[6]) {
   const int E = r.n_ems, cap = p.ems_cap;
   const double lb = p.low_bound;
-  const uint64_t lt = lanemask_lt(lane);
   const double n0 = -loc[0], n1 = -loc[1], n2 = -loc[2];
   int S = 0;
   for (int base = 0; base < E; base += 64) {
@@ -242,7 +241,7 @@ __device__ inline void cgenems(const ContinuousParams& p, CLds& l, CRegs& r, int
     bool surv = live && !inter;
     uint64_t m = __ballot(surv);
     if (surv) {
-      int o = S + __popcll(m & lt);
+      int o = S + rank_below(m);
       l.ems_b[0 * cap + o] = e0; l.ems_b[1 * cap + o] = e1; l.ems_b[2 * cap + o] = e2;
       l.ems_b[3 * cap + o] = e3; l.ems_b[4 * cap + o] = e4; l.ems_b[5 * cap + o] = e5;
     }
@@ -268,8 +267,8 @@ __device__ inline void cgenems(const ContinuousParams& p, CLds& l, CRegs& r, int
     bool c3 = inter && ux && (y2 - y4 + 1e-6 >= lb) && uz;  // [x1,y4,z1,x2,y2,z2]
     bool c4 = inter && ux && uy && (z2 - z4 + 1e-6 >= lb);  // [x1,y1,z4,x2,y2,z2]
     uint64_t m0 = __ballot(c0), m1 = __ballot(c1), m2 = __ballot(c2), m3 = __ballot(c3), m4 = __ballot(c4);
-    int pos = S + C + __popcll(m0 & lt) + __popcll(m1 & lt) + __popcll(m2 & lt) + __popcll(m3 & lt) +
-              __popcll(m4 & lt);
+    int pos = S + C + rank_below(m0) + rank_below(m1) + rank_below(m2) + rank_below(m3) +
+              rank_below(m4);
 #define PCT_PUT(A, B, Cc, D, Ee, F)                                                                   \
   do {                                                                                               \
     if (pos < cap) {                                                                                 \
@@ -316,7 +315,7 @@ __device__ inline void cgenems(const ContinuousParams& p, CLds& l, CRegs& r, int
     bool keep = live && !del;
     uint64_t m = __ballot(keep);
     if (keep) {
-      int o = out + __popcll(m & lt);
+      int o = out + rank_below(m);
       l.ems[0 * cap + o] = a0; l.ems[1 * cap + o] = a1; l.ems[2 * cap + o] = a2;
       l.ems[3 * cap + o] = a3; l.ems[4 * cap + o] = a4; l.ems[5 * cap + o] = a5;
     }
@@ -329,7 +328,6 @@ __device__ inline void cgenems(const ContinuousParams& p, CLds& l, CRegs& r, int
 // C/space.py:531-568 EMSPoint (CPython set order over float tuples) + C/bin3D.py:118-148
 template <bool GT, bool STAB, typename TM>
 __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CRegs& r, int lane, TM& tm) {
-  const uint64_t lt = lanemask_lt(lane);
   const int E = r.n_ems, cap = p.ems_cap;
   const int orient = (p.setting == 2) ? 6 : 2;
   const int NP = E * orient;
@@ -382,7 +380,7 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
       if (!pm) break;
       uint32_t mask = size - 1;
       uint32_t thr = (mask * 3u + 4u) / 5u;
-      bool part = pending && (uint32_t)__popcll(pm & lt) < thr - fill;
+      bool part = pending && (uint32_t)rank_below(pm) < thr - fill;
       bool placed;
       uint32_t slot;
       pyset_match<uint32_t, GT>(tabs + toff, mask, part, hash, lane, true, placed, slot, same);
@@ -434,7 +432,7 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
     }
     uint64_t pm = __ballot(pv);
     const int nt = 4 * __popcll(pm);
-    if (pv) l.vp[__popcll(pm & lt)] = (uint16_t)q;
+    if (pv) l.vp[rank_below(pm)] = (uint16_t)q;
     __syncthreads();
     for (int tb = 0; tb < nt && !cand_overflow; tb += 64) {
       int tt = tb + lane;
@@ -451,7 +449,7 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
         return tuple_eq(o, t);
       });
       uint64_t nm = __ballot(fresh);
-      if (fresh) l.pend[npend + __popcll(nm & lt)] = g;
+      if (fresh) l.pend[npend + rank_below(nm)] = g;
       npend += __popcll(nm);
       __syncthreads();
       if (npend >= 64) flush(64);
@@ -473,7 +471,7 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
     uint32_t s = sb + lane;
     uint32_t w = (s < size) ? tab_ld<GT, uint32_t>(&tabs[toff + s]) : EMPTY;
     uint64_t m = __ballot(w != EMPTY);
-    if (w != EMPTY) tab_st<GT, uint16_t>(&order[norder + __popcll(m & lt)], (uint16_t)(w & 0xFFFFu));
+    if (w != EMPTY) tab_st<GT, uint16_t>(&order[norder + rank_below(m)], (uint16_t)(w & 0xFFFFu));
     norder += __popcll(m);
   }
   __syncthreads();
@@ -523,7 +521,7 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
       cand_tuple(p, l, r, orient, g, t);
       bool ok = live && feasible(t);
       uint64_t m = __ballot(ok);
-      int o = nf + __popcll(m & lt);
+      int o = nf + rank_below(m);
       __syncthreads();
       if (ok) {
         tab_st<GT, uint16_t>(&order[o], (uint16_t)g);  // in-place compaction (o <= i)
@@ -557,7 +555,7 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
       cand_tuple(p, l, r, orient, live ? (uint32_t)tab_ld<GT, uint16_t>(&order[i]) : 0u, t);
       bool ok = live && feasible(t);
       uint64_t m = __ballot(ok);
-      int idx = nleaf + __popcll(m & lt);
+      int idx = nleaf + rank_below(m);
       if (ok && idx < p.L) {
 #pragma unroll
         for (int c2 = 0; c2 < 6; c2++) l.leaf[c2 * p.L + idx] = t[c2];

@@ -193,7 +193,6 @@ __device__ inline void genems(const DiscreteParams& p, Lds<K, BITS>& l, EnvRegs&
   const int E = r.n_ems;
   const int scap = (int)table_words_compact((uint32_t)p.cand_cap);  // pre-elimination list capacity
   const int lb = p.low_bound <= 0 ? 1 : p.low_bound;
-  const uint64_t lt = lanemask_lt(lane);
   // children of the intersected EMS held by this lane, written at `first` + (this lane's offset
   // among the chunk's children): parent index, then branch order.  Returns the chunk's child count.
   auto emit_children = [&](bool live, K k, int first) -> int {
@@ -210,8 +209,8 @@ __device__ inline void genems(const DiscreteParams& p, Lds<K, BITS>& l, EnvRegs&
     bool c3 = inter && (y2 - y4 >= lb) && xlz;                       // [x1,y4,z1,x2,y2,z2]
     bool c4 = inter && (z2 - z4 >= lb) && (x2 - x1 >= lb) && (y2 - y1 >= lb);  // [x1,y1,z4,x2,y2,z2]
     uint64_t m0 = __ballot(c0), m1 = __ballot(c1), m2 = __ballot(c2), m3 = __ballot(c3), m4 = __ballot(c4);
-    int pos = first + __popcll(m0 & lt) + __popcll(m1 & lt) + __popcll(m2 & lt) + __popcll(m3 & lt) +
-              __popcll(m4 & lt);
+    int pos = first + rank_below(m0) + rank_below(m1) + rank_below(m2) + rank_below(m3) +
+              rank_below(m4);
     if (c0) { if (pos < scap) l.ems_b[pos] = P::pack(x1, y1, z1, x3, y2, z2); pos++; }
     if (c1) { if (pos < scap) l.ems_b[pos] = P::pack(x4, y1, z1, x2, y2, z2); pos++; }
     if (c2) { if (pos < scap) l.ems_b[pos] = P::pack(x1, y1, z1, x2, y3, z2); pos++; }
@@ -233,7 +232,7 @@ __device__ inline void genems(const DiscreteParams& p, Lds<K, BITS>& l, EnvRegs&
     K k = live ? l.ems_a[lane] : (K)0;
     bool surv = live && !intersects(k);
     uint64_t m = __ballot(surv);
-    if (surv) l.ems_b[__popcll(m & lt)] = k;
+    if (surv) l.ems_b[rank_below(m)] = k;
     S = __popcll(m);
     C = emit_children(live, k, S);
   } else {
@@ -243,7 +242,7 @@ __device__ inline void genems(const DiscreteParams& p, Lds<K, BITS>& l, EnvRegs&
       K k = live ? l.ems_a[i] : (K)0;
       bool surv = live && !intersects(k);
       uint64_t m = __ballot(surv);
-      if (surv) l.ems_b[S + __popcll(m & lt)] = k;
+      if (surv) l.ems_b[S + rank_below(m)] = k;
       S += __popcll(m);
     }
     for (int base = 0; base < E; base += 64) {
@@ -302,7 +301,7 @@ __device__ inline void genems(const DiscreteParams& p, Lds<K, BITS>& l, EnvRegs&
     for (int off = Cp; off < 64; off <<= 1) cnt += __shfl_xor(cnt, off, 64);
     const bool keep = live && part == 0 && cnt < 2;
     const uint64_t m = __ballot(keep);
-    const int o = out + __popcll(m & lt);
+    const int o = out + rank_below(m);
     if (keep && o < p.ems_cap) l.ems_a[o] = k;
     out += __popcll(m);
   } else
@@ -334,7 +333,7 @@ __device__ inline void genems(const DiscreteParams& p, Lds<K, BITS>& l, EnvRegs&
     }
     bool keep = live && !del;
     uint64_t m = __ballot(keep);
-    int o = out + __popcll(m & lt);
+    int o = out + rank_below(m);
     if (keep && o < p.ems_cap) l.ems_a[o] = k;
     out += __popcll(m);
   }
@@ -351,7 +350,6 @@ __device__ inline void genems(const DiscreteParams& p, Lds<K, BITS>& l, EnvRegs&
 template <typename K, int BITS, bool STAB, int SCHEME, bool SHUFFLE, typename TM>
 __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& l, EnvRegs& r, int lane, TM& tm) {
   typedef Pack<K, BITS> P;
-  const uint64_t lt = lanemask_lt(lane);
   const int E = r.n_ems;
   const int b0 = r.item0, b1 = r.item1, b2 = r.item2;
   constexpr int orient = STAB ? 2 : 6;  // setting 2 <=> no stability check <=> 6 orientations (D/space.py:536-537)
@@ -458,8 +456,8 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
         const K from_slot = shfl_key<K>(key, t32 & 63);
         const bool in32 = lane < 32 && ((occ32 >> lane) & 1u);
         const bool later = (rem >> lane) & 1ull;
-        if (in32) fin[__popcll((uint64_t)occ32 & lt)] = from_slot;
-        if (later) fin[19 + __popcll(rem & lt)] = key;
+        if (in32) fin[rank_below((uint64_t)occ32)] = from_slot;
+        if (later) fin[19 + rank_below(rem)] = key;
         const int total = 19 + __popcll(rem);
         tabs[lane] = EMPTY;
         tabs[64 + lane] = EMPTY;
@@ -487,7 +485,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
       uint32_t thr = (mask * 3u + 4u) / 5u;
       if (fill < thr) {
         if (!pm) break;
-        bool part = pending && (uint32_t)__popcll(pm & lt) < thr - fill;
+        bool part = pending && (uint32_t)rank_below(pm) < thr - fill;
         bool placed;
         uint32_t slot;
         pyset_match<K>(tabs + toff, mask, part, hash, lane, true, placed, slot, [&](K w) { return w == key; });
@@ -575,7 +573,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
       uint64_t hash = tuplehash6<K, BITS>(key);
       bool fresh = valid && !pyset_contains<K>(tabs + toff, size - 1, hash, [&](K w) { return w == key; });
       uint64_t nm = __ballot(fresh);
-      if (fresh) pend[npend + __popcll(nm & lt)] = key;
+      if (fresh) pend[npend + rank_below(nm)] = key;
       npend += __popcll(nm);
       __syncthreads();
       if (npend >= 64) flush(64);
@@ -795,7 +793,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
             if (later && bx >= qx && bx < qxe && by >= qy && by < qye) keep_b = false;
           }
           uint64_t ma = __ballot(keep_a), mb = __ballot(keep_b);
-          int o = nc + __popcll(ma & lt) + __popcll(mb & lt);
+          int o = nc + rank_below(ma) + rank_below(mb);
           if (keep_a) cik[o] = ea;
           if (keep_b) cik[o + (keep_a ? 1 : 0)] = eb;
           nc += __popcll(ma) + __popcll(mb);
@@ -817,7 +815,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
           }
           bool ext = live && xe > run;
           uint64_t em_mask = __ballot(ext);
-          if (ext) cik[m + __popcll(em_mask & lt)] = (uint32_t)run | ((uint32_t)ye << 16);
+          if (ext) cik[m + rank_below(em_mask)] = (uint32_t)run | ((uint32_t)ye << 16);
           m += __popcll(em_mask);
           int passmax = wave_max_i32(live ? xe : 0);
           xmax = passmax > xmax ? passmax : xmax;
@@ -838,7 +836,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
         for (int q = 0; q < nlast; q++) seen = seen || (last[q] == v);
         bool add = live && (!seen || ep_empty);
         uint64_t m2 = __ballot(add);
-        int o = nCI + __popcll(m2 & lt);
+        int o = nCI + rank_below(m2);
         if (add) {
           if (o < ci_cap) CI[o] = (v & 0xFFFFu) | ((v >> 16) << 10) | ((uint32_t)k << 20);
           else ci_overflow = true;
@@ -868,7 +866,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
       uint64_t hash = tuplehash6<K, BITS>(key);
       bool fresh = valid && !pyset_contains<K>(tabs + toff, size - 1, hash, [&](K w) { return w == key; });
       uint64_t nm = __ballot(fresh);
-      if (fresh) pend[npend + __popcll(nm & lt)] = key;
+      if (fresh) pend[npend + rank_below(nm)] = key;
       npend += __popcll(nm);
       __syncthreads();
       if (npend >= 64) flush(64);
@@ -894,7 +892,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
            (P::get(ek, 5) - P::get(ek, 2) >= sz);
       uint64_t pm = __ballot(pv);
       const int nt = 4 * __popcll(pm);  // four bottom-corner placements per pair (:565-568)
-      if (pv) l.vp[__popcll(pm & lt)] = (uint16_t)q;
+      if (pv) l.vp[rank_below(pm)] = (uint16_t)q;
       __syncthreads();
       for (int tb = 0; tb < nt && !cand_overflow; tb += 64) {
         int tt = tb + lane;
@@ -911,7 +909,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
         uint64_t hash = tuplehash6<K, BITS>(key);
         bool fresh = valid && !pyset_contains<K>(tabs + toff, size - 1, hash, [&](K w) { return w == key; });
         uint64_t nm = __ballot(fresh);
-        if (fresh) pend[npend + __popcll(nm & lt)] = key;
+        if (fresh) pend[npend + rank_below(nm)] = key;
         npend += __popcll(nm);
         __syncthreads();
         if (npend >= 64) flush(64);
@@ -960,10 +958,10 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
       K k = (s2 < size) ? tabs[toff + s2] : SlotWord<K>::EMPTY;
       bool occ = k != SlotWord<K>::EMPTY;
       uint64_t om = __ballot(occ);
-      uint32_t li = (uint32_t)(nlist + __popcll(om & lt));
+      uint32_t li = (uint32_t)(nlist + rank_below(om));
       bool feas = occ && feasible(k);
       uint64_t fm = __ballot(feas);
-      int o = nf + __popcll(fm & lt);
+      int o = nf + rank_below(fm);
       if (feas) {
         l.fkey[o] = k;
         l.fpri[o] = pct_shuffle_priority(p.shuffle_seed, (uint64_t)(p.env_id_base + e), (uint64_t)r.oc, li);
@@ -994,7 +992,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
         K k = tabs[toff + sb + lane];
         bool occ = k != SlotWord<K>::EMPTY;
         uint64_t m = __ballot(occ);
-        if (occ) tabs[toff + cnt + __popcll(m & lt)] = k;
+        if (occ) tabs[toff + cnt + rank_below(m)] = k;
         cnt += (uint32_t)__popcll(m);
       }
       const uint32_t padded = (cnt + 63u) & ~63u;
@@ -1007,7 +1005,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
       K k = (s2 < size) ? tabs[toff + s2] : SlotWord<K>::EMPTY;
       bool feas = (k != SlotWord<K>::EMPTY) && feasible(k);
       uint64_t m = __ballot(feas);
-      int idx = nleaf + __popcll(m & lt);
+      int idx = nleaf + rank_below(m);
       if (feas && idx < p.L) l.leaf[idx] = k;
       nleaf += __popcll(m);
     }

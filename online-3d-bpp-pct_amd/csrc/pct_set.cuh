@@ -32,6 +32,11 @@ __device__ inline long long wave_sum_i64(long long v) {
   }
   return v;
 }
+// number of set bits of a wave-uniform mask below this lane (the rank of the lane among the set
+// lanes): v_mbcnt_lo/hi, no per-lane mask register needed
+__device__ inline int rank_below(uint64_t m) {
+  return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
 __device__ inline uint64_t lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
 __device__ inline uint64_t bcast_u64(uint64_t v, int src) {
   uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, src);
