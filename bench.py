@@ -76,6 +76,10 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--mode", choices=["rows", "fused"], default="rows",
                     help="rows: policy kernel + pct_step_rows per step (default); fused: pct_step_hash_policy(1)")
+    ap.add_argument("--pipelines", type=int, default=1,
+                    help="split each GPU's envs into this many independently stepped groups, one HIP stream each "
+                         "(1 = one batch per step, the headline configuration; 2 overlaps one group's tail with "
+                         "the other group's kernels)")
     ap.add_argument("--workload", choices=["c2", "c3", "c5"], default="c2",
                     help="c2: BASELINE configs[1] (discrete, the headline metric); c3: configs[2] (continuous setting 2)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -101,37 +105,52 @@ def main():
 
     pkg = importlib.import_module("online-3d-bpp-pct_amd")
     n_local = args.envs_per_gpu
-    if args.workload == "c5":  # BASELINE.json configs[4]: 100^3, 200/200, items U(5,25)
+    P = max(1, args.pipelines)
+    assert n_local % P == 0, "--envs-per-gpu must be a multiple of --pipelines"
+    n_grp = n_local // P
+
+    def make_env(g):
+        base = rank * n_local + g * n_grp
+        if args.workload == "c5":  # BASELINE.json configs[4]: 100^3, 200/200, items U(5,25)
+            return pkg.PctVecEnv(n_grp, setting=2, container_size=(100, 100, 100), continuous=True, sample_left_bound=5.0,
+                                 sample_right_bound=25.0, internal_node_holder=I_NODES, leaf_node_holder=L_NODES, seed=4,
+                                 env_id_base=base, device=dev, monitor=False, ems_capacity=768,
+                                 candidate_capacity=32768)
+        if args.workload == "c3":
+            return pkg.PctVecEnv(n_grp, setting=2, container_size=(10, 10, 10), continuous=True, sample_left_bound=1.0,
+                                 sample_right_bound=5.0, internal_node_holder=I_NODES, leaf_node_holder=L_NODES, seed=4,
+                                 env_id_base=base, device=dev, monitor=False)
+        return pkg.PctVecEnv(n_grp, setting=2, container_size=(10, 10, 10), item_set=item_set(),
+                             internal_node_holder=I_NODES, leaf_node_holder=L_NODES, seed=4,
+                             env_id_base=base, device=dev, monitor=False)
+
+    if args.workload == "c5":
         global I_NODES, L_NODES, ALG_BYTES_PER_STEP
         I_NODES, L_NODES = 200, 200
         ALG_BYTES_PER_STEP = 4 * 9 * (I_NODES + L_NODES + 1) + 36 + 4 + 1
-        env = pkg.PctVecEnv(n_local, setting=2, container_size=(100, 100, 100), continuous=True, sample_left_bound=5.0,
-                            sample_right_bound=25.0, internal_node_holder=I_NODES, leaf_node_holder=L_NODES, seed=4,
-                            env_id_base=rank * n_local, device=dev, monitor=False, ems_capacity=768,
-                            candidate_capacity=32768)
-    elif args.workload == "c3":
-        env = pkg.PctVecEnv(n_local, setting=2, container_size=(10, 10, 10), continuous=True, sample_left_bound=1.0,
-                            sample_right_bound=5.0, internal_node_holder=I_NODES, leaf_node_holder=L_NODES, seed=4,
-                            env_id_base=rank * n_local, device=dev, monitor=False)
-    else:
-        env = pkg.PctVecEnv(n_local, setting=2, container_size=(10, 10, 10), item_set=item_set(),
-                            internal_node_holder=I_NODES, leaf_node_holder=L_NODES, seed=4,
-                            env_id_base=rank * n_local, device=dev, monitor=False)
-    env.reset()
-    rows = torch.empty(n_local, 9, dtype=torch.float32, device=dev)
+    envs = [make_env(g) for g in range(P)]
+    env = envs[0]
+    streams = [torch.cuda.current_stream(dev)] if P == 1 else [torch.cuda.Stream(dev) for _ in range(P)]
+    rows = [torch.empty(n_grp, 9, dtype=torch.float32, device=dev) for _ in range(P)]
+    for ev in envs:
+        ev.reset()
+    torch.cuda.synchronize(dev)
 
     def one_step():
-        if args.mode == "rows":
-            env.policy_hash_rows(rows)
-            env.step_rows_device(rows)
-        else:
-            env.step_hash_policy(1)
+        for g in range(P):
+            with torch.cuda.stream(streams[g]):
+                if args.mode == "rows":
+                    envs[g].policy_hash_rows(rows[g])
+                    envs[g].step_rows_device(rows[g])
+                else:
+                    envs[g].step_hash_policy(1)
 
     for _ in range(args.warmup):
         one_step()
     torch.cuda.synchronize(dev)
-    env.profile_enable(True)
-    env.profile_read()
+    for ev in envs:
+        ev.profile_enable(True)
+        ev.profile_read()
 
     def barrier():
         if dist is not None:
@@ -145,10 +164,14 @@ def main():
     torch.cuda.synchronize(dev)
     barrier()
     elapsed = time.perf_counter() - t0
-    n_launch, kern_ms = env.profile_read()
-    env.profile_enable(False)
-    flags = env.error_flags
-    assert not flags.any(), "env error flags raised during the bench: %s" % flags[flags != 0][:8]
+    n_launch, kern_ms = 0, 0.0
+    for ev in envs:
+        nl, km = ev.profile_read()
+        n_launch += nl
+        kern_ms += km
+        ev.profile_enable(False)
+        flags = ev.error_flags
+        assert not flags.any(), "env error flags raised during the bench: %s" % flags[flags != 0][:8]
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -162,10 +185,10 @@ def main():
 
     total_steps = world * n_local * args.steps
     value = total_steps / elapsed
-    achieved_gbs = ALG_BYTES_PER_STEP * n_local / (kern_avg_ms * 1e-3) / 1e9
+    achieved_gbs = ALG_BYTES_PER_STEP * n_grp / (kern_avg_ms * 1e-3) / 1e9  # per launch (n_grp envs)
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc) and args.workload == "c2" and n_local == 4096:
+    if os.path.exists(pmc) and args.workload == "c2" and n_grp == 4096:
         try:
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         except Exception:
@@ -188,14 +211,15 @@ def main():
         "config": {
             "workload": ("PctDiscrete0 setting 2 (EMS leaves), bin 10x10x10, 80 internal / 50 leaf, %d batched envs per "
                          "MI355X (BASELINE.json configs[1]); items ~ U{(1..5)^3} from the on-device counter sampler; "
-                         "per step: policy kernel -> float32 [N,9] leaf rows -> transition kernel (full obs rewrite, "
-                         "auto-reset)" % n_local) if args.workload == "c2" else
+                         "per step: policy kernel -> float32 [N,9] leaf rows -> transition kernel (observation rows "
+                         "rewritten, auto-reset)" % n_local) if args.workload == "c2" else
                         ("PctContinuous0 setting 2, bin 10x10x10, 80 internal / 50 leaf, %d batched envs per MI355X "
                          "(BASELINE.json configs[2]); item sizes round(U(1,5),3) from the on-device counter sampler; "
                          "per step: policy kernel -> float32 [N,9] leaf rows -> float64 transition kernel" % n_local),
             "envs_per_gpu": n_local,
             "global_envs": world * n_local,
             "mode": args.mode,
+            "pipelines": P,
             "parallelism": "envs sharded by global id x%d, no collective on the step path" % world,
         },
         "roofline": {
@@ -223,7 +247,8 @@ def main():
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out))
-    env.close()
+    for ev in envs:
+        ev.close()
     if dist is not None:
         dist.destroy_process_group()
 
