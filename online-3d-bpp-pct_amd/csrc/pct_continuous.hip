@@ -368,6 +368,83 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
       return tuple_eq(o, t);
     });
     tm.sub_tick(PH_SET_DEDUP);
+    if (fill == 0 && size == 8 && p.cand_cap >= 128) {
+      const uint64_t pm0 = __ballot(pending);
+      if (__popcll(pm0) >= 19) {
+        // Fast start of a fresh set with >= 19 new keys, as in the discrete kernel
+        // (pct_discrete_impl.cuh): the 8- and 32-slot tables are replayed on the scalar unit, the
+        // 128-slot table receives the 19 keys in 32-table slot order and then the rest of the batch
+        // in one pass.  Generator ids and hashes travel through the (now idle) de-duplication arrays.
+        uint64_t rem = pm0;
+        int t8 = 0xFF, t32 = 0xFF;
+        uint32_t occ8 = 0, occ32 = 0;
+        auto lane_hash = [&](int src) -> uint64_t {
+          uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)hash, src);
+          uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(hash >> 32), src);
+          return ((uint64_t)hi << 32) | lo;
+        };
+        for (int o = 0; o < 5; o++) {
+          const int src = __ffsll((unsigned long long)rem) - 1;
+          rem &= rem - 1;
+          const uint64_t h = lane_hash(src);
+          uint32_t i = (uint32_t)h & 7u;
+          uint64_t perturb = h;
+          while ((occ8 >> i) & 1u) {
+            perturb >>= 5;
+            i = (i * 5u + 1u + (uint32_t)perturb) & 7u;
+          }
+          occ8 |= 1u << i;
+          t8 = lane == (int)i ? src : t8;
+        }
+        auto insert32 = [&](int src) {
+          const uint64_t h = lane_hash(src);
+          uint32_t i = (uint32_t)h & 31u;
+          uint64_t perturb = h;
+          while (true) {
+            const uint32_t span = (i + 9u <= 31u) ? 10u : 1u;
+            const uint32_t w = (~occ32 >> i) & ((1u << span) - 1u);
+            if (w) {
+              i += (uint32_t)__ffs((int)w) - 1u;
+              break;
+            }
+            perturb >>= 5;
+            i = (i * 5u + 1u + (uint32_t)perturb) & 31u;
+          }
+          occ32 |= 1u << i;
+          t32 = lane == (int)i ? src : t32;
+        };
+        for (uint32_t m8 = occ8; m8; m8 &= m8 - 1u) insert32(__builtin_amdgcn_readlane(t8, __ffs((int)m8) - 1));
+        for (int o = 5; o < 19; o++) {
+          const int src = __ffsll((unsigned long long)rem) - 1;
+          rem &= rem - 1;
+          insert32(src);
+        }
+        const uint32_t g_s = (uint32_t)__shfl((int)g, t32 & 63, 64);
+        const uint64_t h_s = shfl_key<uint64_t>(hash, t32 & 63);
+        const bool in32 = lane < 32 && ((occ32 >> lane) & 1u);
+        const bool later = (rem >> lane) & 1ull;
+        __syncthreads();
+        if (in32) { l.bg[rank_below((uint64_t)occ32)] = g_s; l.bhash[rank_below((uint64_t)occ32)] = h_s; }
+        if (later) { l.bg[19 + rank_below(rem)] = g; l.bhash[19 + rank_below(rem)] = hash; }
+        const int total = 19 + __popcll(rem);
+        const uint32_t noff = table_region(p.cand_cap, 128u);
+        tab_st<GT, uint32_t>(&tabs[noff + lane], EMPTY);
+        tab_st<GT, uint32_t>(&tabs[noff + 64 + lane], EMPTY);
+        __syncthreads();
+        const uint32_t mg = lane < total ? l.bg[lane] : 0u;
+        const uint64_t mh = lane < total ? l.bhash[lane] : 0ull;
+        bool mplaced;
+        uint32_t mslot;
+        pyset_match<uint32_t, GT>(tabs + noff, 127u, lane < total, mh, lane, false, mplaced, mslot, [&](uint32_t) { return false; });
+        if (mplaced) tab_st<GT, uint32_t>(&tabs[noff + mslot], cword(mh, mg));
+        toff = noff;
+        size = 128;
+        fill = (uint32_t)total;
+        pending = false;
+        __syncthreads();
+        tm.sub_tick(PH_SET_MATCH);
+      }
+    }
     const uint32_t word = cword(hash, g);
     auto same = [&](uint32_t w) -> bool {
       if ((w >> 16) != (word >> 16)) return false;  // different hash
