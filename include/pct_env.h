@@ -75,6 +75,8 @@ extern "C" {
 #define PCT_HEUR_OBPH 2 /* :364-425 OnlineBPH */
 #define PCT_HEUR_DBL 3  /* :431-498 DBL */
 #define PCT_HEUR_BR 4   /* :500-569 BR */
+#define PCT_HEUR_MACS 5 /* :11-136 MACS (bins up to 32 along y) */
+#define PCT_HEUR_RANDOM 6 /* :300-362 random; np.random.randint(0, n) -> pct_mix32(global env id, t) % n */
 
 /* item source */
 #define PCT_ITEMS_NONE 0
@@ -204,7 +206,7 @@ int pct_step_hash_policy(pct_env* env, int32_t n_steps, void* stream);
  * stability state, the chosen placement is stepped exactly as `env.next_box = [x,y,z];
  * env.step([0,lx,ly])`; an env whose heuristic finds no placement ends its episode WITHOUT a
  * step (done = 1, reward = 0, counter / ratio as at a failed step) and is reset, as the reference
- * loops do (e.g. heuristic.py:241-249,291-296).  MACS and RANDOM are not built. */
+ * loops do (e.g. heuristic.py:241-249,291-296). */
 int pct_step_heuristic(pct_env* env, int32_t kind, int32_t n_steps, void* stream);
 
 /* The stand-in policy as its own kernel (what a policy network would do between two

@@ -1178,7 +1178,7 @@ __device__ inline bool heur_choose(const DiscreteParams& p, int e, Lds<K, BITS>&
   };
   const uint64_t NONE = ~0ull;
   uint64_t best = NONE;
-  if (kind == PCT_HEUR_DBL || kind == PCT_HEUR_HM) {
+  if (kind == PCT_HEUR_DBL || kind == PCT_HEUR_HM || kind == PCT_HEUR_RANDOM) {
     // :431-498 / :232-298: every (lx, ly) the UNROTATED item fits at, every rotation
     long long total = 0;
     if (kind == PCT_HEUR_HM) {
@@ -1188,6 +1188,46 @@ __device__ inline bool heur_choose(const DiscreteParams& p, int e, Lds<K, BITS>&
     }
     const int nx = p.W - b0 + 1, ny = p.Ly - b1 + 1;
     const int NQ = (nx > 0 && ny > 0) ? nx * ny * orient : 0;
+    if (kind == PCT_HEUR_RANDOM) {
+      // :300-362 random: the pct_mix32(g, t) % n -th feasible placement of the same enumeration (the
+      // reference's np.random.randint(0, n)); the feasibility masks of the chunks wait in the scratch
+      int n = 0;
+      for (int base = 0; base < NQ; base += 64) {
+        int q = base + lane;
+        bool feas = false;
+        if (q < NQ) {
+          int rot = q % orient, cell = q / orient;
+          int lx = cell / ny, ly = cell - lx * ny;
+          int x, y, z, mh;
+          long long under;
+          heur_rot(b0, b1, b2, rot, x, y, z);
+          feas = probe(x, y, z, lx, ly, mh, under);
+        }
+        const uint64_t m = __ballot(feas);
+        if (lane == 0) { scratch[(base >> 6) * 2] = (uint32_t)m; scratch[(base >> 6) * 2 + 1] = (uint32_t)(m >> 32); }
+        n += __popcll(m);
+      }
+      __syncthreads();
+      if (n == 0) return false;
+      int pick = (int)(pct_mix32((uint32_t)(p.env_id_base + e), r.t) % (uint32_t)n);
+      int q = -1;
+      for (int base = 0; base < NQ && q < 0; base += 64) {
+        uint64_t m = ((uint64_t)scratch[(base >> 6) * 2 + 1] << 32) | scratch[(base >> 6) * 2];
+        int c = __popcll(m);
+        if (pick < c) {
+          for (int k2 = 0; k2 < pick; k2++) m &= m - 1;  // drop the `pick` lowest set bits
+          q = base + __ffsll((unsigned long long)m) - 1;
+        } else {
+          pick -= c;
+        }
+      }
+      __syncthreads();
+      int rot = q % orient, cell = q / orient;
+      olx = cell / ny;
+      oly = cell - olx * ny;
+      heur_rot(b0, b1, b2, rot, ox, oy, oz);
+      return true;
+    }
     for (int base = 0; base < NQ; base += 64) {
       int q = base + lane;
       if (q < NQ) {
@@ -1280,6 +1320,72 @@ __device__ inline bool heur_choose(const DiscreteParams& p, int e, Lds<K, BITS>&
     olx = P::get(ek, 0);
     oly = P::get(ek, 1);
     heur_rot(b0, b1, b2, rot, ox, oy, oz);
+    return true;
+  }
+  if (kind == PCT_HEUR_MACS) {
+    // :11-136 MACS: maximise the sum, over the levels below the item's base, of the largest empty
+    // rectangle of the level after the placement.  The heuristic's voxel container is nonzero exactly
+    // below the heightmap, so (i, j) is empty at level h iff hmap[i][j] <= h -- one row mask per
+    // (level, row), built once per step in the idle table region; the candidate's footprint is cleared
+    // from the rows it covers.  Largest rectangle of a level: for every band of rows i1..i2 the AND of
+    // their masks, times the longest run of ones (Ly <= 32, checked by the host).
+    uint32_t* rows = scratch;  // [H][W]
+    for (int c = lane; c < p.H * p.W; c += 64) {
+      const int lv = c / p.W, i = c - lv * p.W;
+      uint32_t m = 0;
+      for (int j = 0; j < p.Ly; j++) m |= ((int)l.hmap[i * p.A + j] <= lv) ? (1u << j) : 0u;
+      rows[c] = m;
+    }
+    __syncthreads();
+    const int NC = NQ * 4;
+    for (int base = 0; base < NC; base += 64) {
+      int qc = base + lane;
+      if (qc < NC) {
+        int q = qc >> 2, corner = qc & 3;
+        int ei = q / orient, rot = q - ei * orient;
+        K ek = l.ems_a[ei];
+        int dx = P::get(ek, 3) - P::get(ek, 0), dy = P::get(ek, 4) - P::get(ek, 1), dz = P::get(ek, 5) - P::get(ek, 2);
+        int x, y, z, mh;
+        long long under;
+        heur_rot(b0, b1, b2, rot, x, y, z);
+        int lx = (corner & 1) ? P::get(ek, 3) - x : P::get(ek, 0);
+        int ly = (corner & 2) ? P::get(ek, 4) - y : P::get(ek, 1);
+        if (dx >= x && dy >= y && dz >= z && probe(x, y, z, lx, ly, mh, under)) {
+          const uint32_t foot = ((y >= 32 ? 0u : (1u << y)) - 1u) << ly;
+          uint32_t score = 0;
+          for (int lv = 0; lv < mh; lv++) {
+            const uint32_t* rw = rows + lv * p.W;
+            uint32_t level_max = 0;
+            for (int i1 = 0; i1 < p.W; i1++) {
+              uint32_t band = 0xFFFFFFFFu;
+              for (int i2 = i1; i2 < p.W; i2++) {
+                uint32_t rm = rw[i2];
+                if (i2 >= lx && i2 < lx + x) rm &= ~foot;
+                band &= rm;
+                if (!band) break;
+                uint32_t t = band, run = 0;
+                while (t) { t &= t << 1; run++; }
+                const uint32_t area = run * (uint32_t)(i2 - i1 + 1);
+                level_max = area > level_max ? area : level_max;
+              }
+            }
+            score += level_max;
+          }
+          uint64_t key = ((uint64_t)(0xFFFFFFFFu - score) << 24) | (uint64_t)qc;
+          best = key < best ? key : best;
+        }
+      }
+    }
+    best = wave_min_u64(best);
+    __syncthreads();
+    if (best == NONE) return false;
+    int qc = (int)(best & 0xFFFFFFull);
+    int q = qc >> 2, corner = qc & 3;
+    int ei = q / orient, rot = q - ei * orient;
+    K ek = l.ems_a[ei];
+    heur_rot(b0, b1, b2, rot, ox, oy, oz);
+    olx = (corner & 1) ? P::get(ek, 3) - ox : P::get(ek, 0);
+    oly = (corner & 2) ? P::get(ek, 4) - oy : P::get(ek, 1);
     return true;
   }
   // :138-226 LASH: least surface area of the bounding box of everything packed so far

@@ -543,7 +543,13 @@ int pct_step_heuristic(pct_env* h, int32_t kind, int32_t n_steps, void* stream) 
   int rc = ready(h, true);
   if (rc) return rc;
   if (n_steps < 1) return fail(PCT_ERR_INVALID_ARG, "n_steps must be >= 1");
-  if (kind < PCT_HEUR_LSAH || kind > PCT_HEUR_BR) return fail(PCT_ERR_INVALID_ARG, "unknown heuristic");
+  if (kind < PCT_HEUR_LSAH || kind > PCT_HEUR_RANDOM) return fail(PCT_ERR_INVALID_ARG, "unknown heuristic");
+  if (kind == PCT_HEUR_MACS && (h->cfg.container[1] > 32 ||
+                                (size_t)h->cfg.container[0] * h->cfg.container[2] > (size_t)h->dp.cand_cap * (h->dp.key_bytes / 4)))
+    return fail(PCT_ERR_UNSUPPORTED, "MACS: the level masks need Ly <= 32 and W*H words of table scratch");
+  if (kind == PCT_HEUR_RANDOM && ((size_t)h->cfg.container[0] * h->cfg.container[1] * 6 / 64 + 1) * 2 >
+                                     (size_t)h->dp.cand_cap * (h->dp.key_bytes / 4))
+    return fail(PCT_ERR_UNSUPPORTED, "RANDOM: the feasibility masks do not fit the table scratch (raise candidate_capacity)");
   if (h->continuous || h->cfg.lnes != PCT_LNES_EMS)
     return fail(PCT_ERR_UNSUPPORTED, "the heuristics read the discrete env's heightmap and EMS list (LNES = EMS)");
   /* one launch per step when the stability state is live (see pct_step_hash_policy) */

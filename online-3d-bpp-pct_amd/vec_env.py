@@ -70,7 +70,7 @@ class VecEnv(ABC):
     @abstractmethod
     def step_heuristic(self, name, n_steps=1):
         """n_steps transitions with a heuristic baseline of heuristic.py as the in-env policy
-        (`name` in HEURISTICS: LSAH, HM, OnlineBPH, DBL, BR); follow with step_wait()."""
+        (`name` in HEURISTICS: LSAH, HM, OnlineBPH, DBL, BR, MACS, RANDOM); follow with step_wait()."""
         with torch.cuda.device(self._dev_index):
             _lib.check(self._L.pct_step_heuristic(self._h, HEURISTICS[name], int(n_steps), self._stream()))
         self.waiting_step = True
@@ -178,7 +178,7 @@ class LazyInfos(object):
 _LNES = {"EMS": _lib.LNES_EMS, "EV": _lib.LNES_EV, "EP": _lib.LNES_EP, "CP": _lib.LNES_CP, "FC": _lib.LNES_FC}
 
 
-HEURISTICS = {"LSAH": 0, "HM": 1, "OnlineBPH": 2, "DBL": 3, "BR": 4}  # include/pct_env.h PCT_HEUR_*
+HEURISTICS = {"LSAH": 0, "HM": 1, "OnlineBPH": 2, "DBL": 3, "BR": 4, "MACS": 5, "RANDOM": 6}  # include/pct_env.h PCT_HEUR_*
 
 
 class PctVecEnv(VecEnv):
@@ -381,7 +381,7 @@ class PctVecEnv(VecEnv):
 
     def step_heuristic(self, name, n_steps=1):
         """n_steps transitions with a heuristic baseline of heuristic.py as the in-env policy
-        (`name` in HEURISTICS: LSAH, HM, OnlineBPH, DBL, BR); follow with step_wait()."""
+        (`name` in HEURISTICS: LSAH, HM, OnlineBPH, DBL, BR, MACS, RANDOM); follow with step_wait()."""
         with torch.cuda.device(self._dev_index):
             _lib.check(self._L.pct_step_heuristic(self._h, HEURISTICS[name], int(n_steps), self._stream()))
         self.waiting_step = True

@@ -1096,7 +1096,7 @@ static void heur_rot(const int nb[3], int rot, int* x, int* y, int* z) {
 
 /* Picks the placement heuristic `kind` would step with.  Returns 0 if it finds none (the
  * reference loop then records the episode and resets the env WITHOUT stepping). */
-static int heur_choose(const pcto_env* h, const oenv* s, int kind, int* olx, int* oly, int* ox, int* oy, int* oz) {
+static int heur_choose(const pcto_env* h, int e, const oenv* s, int kind, int* olx, int* oly, int* ox, int* oy, int* oz) {
   const int W = h->cfg.container[0], L = h->cfg.container[1], H = h->cfg.container[2], A = h->A;
   const int orientation = h->cfg.setting == 2 ? 6 : 2;
   const int* nb = s->next_box;
@@ -1124,6 +1124,26 @@ static int heur_choose(const pcto_env* h, const oenv* s, int kind, int* olx, int
           if (!found || score < best) { best = score; found = 1; *olx = lx; *oly = ly; *ox = x; *oy = y; *oz = z; }
         }
     return found;
+  }
+  if (kind == PCT_HEUR_RANDOM) {
+    /* :300-362 random: uniform over the feasible (lx, ly, rotation) of the DBL / HM enumeration; the
+     * reference's np.random.randint(0, n) is the counter-keyed pct_mix32(global env id, t) % n */
+    int n = 0;
+    for (int pass = 0; pass < 2; pass++) {
+      int pick = pass ? (int)(pct_mix32((uint32_t)(h->cfg.env_id_base + e), s->t) % (uint32_t)n) : -1, c = 0;
+      for (int lx = 0; lx < W - nb[0] + 1; lx++)
+        for (int ly = 0; ly < L - nb[1] + 1; ly++)
+          for (int rot = 0; rot < orientation; rot++) {
+            int x, y, z;
+            heur_rot(nb, rot, &x, &y, &z);
+            int max_h = footprint_max(h, s, lx, ly, x, y);
+            if (max_h < 0 || !check_box(h, s, x, y, lx, ly, z, max_h, s->next_den, 1)) continue;
+            if (pass && c == pick) { *olx = lx; *oly = ly; *ox = x; *oy = y; *oz = z; return 1; }
+            c++;
+          }
+      if (!pass) { n = c; if (n == 0) return 0; }
+    }
+    return 0;
   }
   if (kind == PCT_HEUR_OBPH) {
     /* :364-425 OnlineBPH: EMS sorted by (z, y, x), stable; first feasible (EMS corner, rotation) */
@@ -1221,6 +1241,50 @@ static int heur_choose(const pcto_env* h, const oenv* s, int kind, int* olx, int
     }
     return found;
   }
+  if (kind == PCT_HEUR_MACS) {
+    /* :11-136 MACS: the placement (EMS, rotation, corner) maximising the sum, over the levels below the
+     * item's base, of the largest empty rectangle of the level AFTER the placement.  The heuristic's own
+     * voxel container (:47-52) is nonzero exactly below the heightmap (a placement fills its box and
+     * marks the empty cells under it), so cell (i, j) is empty at level h iff plain[i][j] <= h; for
+     * h < base the footprint of the candidate is not. */
+    int64_t best = 0;
+    for (int q = 0; q < s->n_ems; q++) {
+      const int64_t* e = s->ems + 6 * q;
+      int dx = (int)(e[3] - e[0]), dy = (int)(e[4] - e[1]), dz = (int)(e[5] - e[2]);
+      for (int rot = 0; rot < orientation; rot++) {
+        int x, y, z;
+        heur_rot(nb, rot, &x, &y, &z);
+        if (!(dx >= x && dy >= y && dz >= z)) continue;
+        for (int corner = 0; corner < 4; corner++) {
+          int lx = (corner & 1) ? (int)e[3] - x : (int)e[0];
+          int ly = (corner & 2) ? (int)e[4] - y : (int)e[1];
+          int height = footprint_max(h, s, lx, ly, x, y);
+          if (height < 0 || !check_box(h, s, x, y, lx, ly, z, height, s->next_den, 1)) continue;
+          int64_t score = 0;
+          for (int lv = 0; lv < height; lv++) {
+            int level_max = 0;
+            for (int i1 = 0; i1 < W; i1++)
+              for (int j1 = 0; j1 < L; j1++)
+                for (int i2 = i1; i2 < W; i2++)
+                  for (int j2 = j1; j2 < L; j2++) {
+                    int area = (i2 - i1 + 1) * (j2 - j1 + 1);
+                    if (area <= level_max) continue;
+                    int ok = 1;
+                    for (int i = i1; i <= i2 && ok; i++)
+                      for (int j = j1; j <= j2; j++) {
+                        int inside = i >= lx && i < lx + x && j >= ly && j < ly + y;
+                        if (inside || s->plain[i * A + j] > lv) { ok = 0; break; }
+                      }
+                    if (ok) level_max = area;
+                  }
+            score += level_max;
+          }
+          if (!found || score > best) { best = score; found = 1; *olx = lx; *oly = ly; *ox = x; *oy = y; *oz = z; }
+        }
+      }
+    }
+    return found;
+  }
   return 0;
 }
 
@@ -1229,14 +1293,14 @@ int pcto_step_heuristic(pcto_env* h, int32_t kind, int32_t n_steps) {
   if (rc) return rc;
   if (h->cfg.env_kind != PCT_ENV_DISCRETE || h->cfg.lnes != PCT_LNES_EMS)
     return fail(PCT_ERR_UNSUPPORTED, "the heuristics read the discrete env's heightmap and EMS list");
-  if (kind < PCT_HEUR_LSAH || kind > PCT_HEUR_BR) return fail(PCT_ERR_INVALID_ARG, "unknown heuristic");
+  if (kind < PCT_HEUR_LSAH || kind > PCT_HEUR_RANDOM) return fail(PCT_ERR_INVALID_ARG, "unknown heuristic");
 #pragma omp parallel for num_threads(g_threads) schedule(dynamic, 8)
   for (int e = 0; e < h->N; e++) {
     oenv* s = &h->envs[e];
     double* obs = h->obs + (size_t)e * h->row_len;
     for (int it = 0; it < n_steps; it++) {
       int lx = 0, ly = 0, x = 0, y = 0, z = 0;
-      if (heur_choose(h, s, kind, &lx, &ly, &x, &y, &z)) {
+      if (heur_choose(h, e, s, kind, &lx, &ly, &x, &y, &z)) {
         /* env.next_box = [x, y, z]; env.step([0, lx, ly]) == the 6-vector leaf form of the same placement */
         double row[6] = {(double)lx, (double)ly, 0.0, (double)(lx + x), (double)(ly + y), (double)z};
         any_step(h, e, row, 6, obs);

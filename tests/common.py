@@ -89,4 +89,5 @@ def dataset_trajectories(z):
 
 
 HEURISTIC_CASES = ["heur_s2_10", "heur_s1_10", "heur_s2_rect"]
-HEUR_CODE = {"LSAH": 0, "HM": 1, "OnlineBPH": 2, "DBL": 3, "BR": 4}
+MACS_CASES = ["heur_macs_s2_10", "heur_macs_s1_rect"]
+HEUR_CODE = {"LSAH": 0, "HM": 1, "OnlineBPH": 2, "DBL": 3, "BR": 4, "MACS": 5, "RANDOM": 6}

@@ -575,12 +575,18 @@ def dataset_cases(want=lambda name: True):
                             reward=ref["reward"], done=ref["done"], counter=ref["counter"])
 
 
-HEUR_CODE = {"LSAH": 0, "HM": 1, "OnlineBPH": 2, "DBL": 3, "BR": 4}
+HEUR_CODE = {"LSAH": 0, "HM": 1, "OnlineBPH": 2, "DBL": 3, "BR": 4, "MACS": 5, "RANDOM": 6}
+FAST_HEURISTICS = ["LSAH", "HM", "OnlineBPH", "DBL", "BR", "RANDOM"]
 HEURISTIC_CASES = {
     # heuristic.py baselines as in-env policies: per-episode utilisation and length of the reference loop
     "heur_s2_10": dict(setting=2, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, episodes=12, stream_T=4096, seed=61),
     "heur_s1_10": dict(setting=1, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, episodes=8, stream_T=4096, seed=62),
     "heur_s2_rect": dict(setting=2, container=(9, 12, 8), lo=1, hi=4, I=120, L=30, episodes=8, stream_T=4096, seed=63),
+    # MACS scores every candidate with Python loops over the voxel container (seconds per step): few episodes
+    "heur_macs_s2_10": dict(setting=2, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, episodes=16, stream_T=4096, seed=64,
+                            heuristics=["MACS"]),
+    "heur_macs_s1_rect": dict(setting=1, container=(8, 7, 9), lo=1, hi=4, I=80, L=30, episodes=16, stream_T=4096, seed=65,
+                              heuristics=["MACS"]),
 }
 
 
@@ -596,7 +602,7 @@ def run_reference_heuristic(case, name):
     env = PD(setting=c["setting"], container_size=list(c["container"]), item_set=item_set,
              internal_node_holder=c["I"], leaf_node_holder=c["L"], shuffle=False, LNES="EMS")
     env.box_creator = scripted_creator(stream[0])
-    fn = {"LSAH": H.LASH, "HM": H.heightmap_min, "OnlineBPH": H.OnlineBPH, "DBL": H.DBL, "BR": H.BR}[name]
+    fn = {"LSAH": H.LASH, "HM": H.heightmap_min, "OnlineBPH": H.OnlineBPH, "DBL": H.DBL, "BR": H.BR, "MACS": H.MACS, "RANDOM": H.random}[name]
     rec = []
     saved = builtins.print
 
@@ -606,11 +612,24 @@ def run_reference_heuristic(case, name):
             parts = a[0].replace(",", "").split()
             rec.append((float(parts[5]), int(parts[7])))
 
+    # heuristic.py:351 np.random.randint(0, n) -> the counter-keyed draw of include/pct_env.h:
+    # pct_mix32(global env id = 0, t) % n, t = the env's lifetime step counter (steps + ended episodes)
+    calls = [0]
+    saved_randint = np.random.randint
+
+    def scripted_randint(lo, hi=None, *a, **k):
+        t = calls[0] + len(rec)
+        calls[0] += 1
+        return int(mix32(0, t) % hi)
+
     builtins.print = capture
+    if name == "RANDOM":
+        np.random.randint = scripted_randint
     try:
         fn(env, c["episodes"])
     finally:
         builtins.print = saved
+        np.random.randint = saved_randint
     return stream, np.array([r[0] for r in rec], np.float64), np.array([r[1] for r in rec], np.int32)
 
 
@@ -637,7 +656,7 @@ def heuristic_cases(want=lambda name: True):
         if not want(cname):
             continue
         out = {}
-        for name in HEUR_CODE:
+        for name in case.get("heuristics", FAST_HEURISTICS):
             stream, util, length = run_reference_heuristic(case, name)
             o_util, o_len = run_oracle_heuristic(case, name, stream)
             if not (np.array_equal(util, o_util) and np.array_equal(length, o_len)):

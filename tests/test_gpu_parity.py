@@ -478,8 +478,9 @@ def test_hip_expansion_schemes_match_oracle_many_small_items(lnes, setting):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["heur_s2_10", "heur_s1_10", "heur_s2_rect"])
-@pytest.mark.parametrize("heur", ["LSAH", "HM", "OnlineBPH", "DBL", "BR"])
+@pytest.mark.parametrize("name,heur", [(n, h) for n in ["heur_s2_10", "heur_s1_10", "heur_s2_rect"]
+                                       for h in ["LSAH", "HM", "OnlineBPH", "DBL", "BR", "RANDOM"]] +
+                         [("heur_macs_s2_10", "MACS"), ("heur_macs_s1_rect", "MACS")])
 def test_hip_heuristics_match_reference_loops(name, heur):
     """pct_step_heuristic against the per-episode results of the reference's own loops (heuristic.py)."""
     c, z = load_case(name)
@@ -501,22 +502,22 @@ def test_hip_heuristics_match_reference_loops(name, heur):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("setting", [2, 1, 3])
-@pytest.mark.parametrize("heur", ["LSAH", "HM", "OnlineBPH", "DBL", "BR"])
+@pytest.mark.parametrize("heur", ["LSAH", "HM", "OnlineBPH", "DBL", "BR", "MACS", "RANDOM"])
 def test_hip_heuristics_match_oracle_batched(heur, setting):
     """Many envs, counter-based sampler: observations, rewards, dones step by step against the oracle;
     evaluate_heuristic's statistics are those of the episodes seen."""
     from oracle.oracle_lib import OracleVecEnv
     from tests.common import HEUR_CODE
     items = item_set_range(1, 5)
-    N = 128
+    N, steps = (128, 120) if heur != "MACS" else (32, 60)  # the oracle's MACS scoring is brute force
     kw = dict(setting=setting, container_size=(10, 9, 11), item_set=items, internal_node_holder=80, leaf_node_holder=30,
               env_id_base=17)
-    ora = OracleVecEnv(N, **kw)
+    ora = OracleVecEnv(N, threads=8, **kw)
     ora.set_sampler(5)
     env = _pkg().PctVecEnv(N, seed=5, device="cuda:0", **kw)
     ora.reset()
     obs = env.reset()
-    for t in range(120):
+    for t in range(steps):
         assert np.array_equal(obs.cpu().numpy(), ora.obs.astype(np.float32)), (heur, t)
         env.step_heuristic(heur, 1)
         ora.step_heuristic(HEUR_CODE[heur], 1)

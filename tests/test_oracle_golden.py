@@ -230,8 +230,9 @@ def test_shuffle_is_a_permutation_of_the_unshuffled_candidates():
             e.step_rows(first[None])
 
 
-@pytest.mark.parametrize("name", ["heur_s2_10", "heur_s1_10", "heur_s2_rect"])
-@pytest.mark.parametrize("heur", ["LSAH", "HM", "OnlineBPH", "DBL", "BR"])
+@pytest.mark.parametrize("name,heur", [(n, h) for n in ["heur_s2_10", "heur_s1_10", "heur_s2_rect"]
+                                       for h in ["LSAH", "HM", "OnlineBPH", "DBL", "BR", "RANDOM"]] +
+                         [("heur_macs_s2_10", "MACS"), ("heur_macs_s1_rect", "MACS")])
 def test_oracle_heuristics_match_reference_loops(name, heur):
     """heuristic.py's loops (LASH, heightmap_min, OnlineBPH, DBL, BR) run on the unmodified reference:
     per-episode utilisation and number of packed items of the same item stream."""
