@@ -74,8 +74,11 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
-    ap.add_argument("--mode", choices=["rows", "fused"], default="rows",
-                    help="rows: policy kernel + pct_step_rows per step (default); fused: pct_step_hash_policy(1)")
+    ap.add_argument("--mode", choices=["rows", "fused", "host"], default="rows",
+                    help="rows: policy kernel + pct_step_rows per step (default); fused: pct_step_hash_policy(1); "
+                         "host: the reference trainer's hand-over -- leaf rows to the host as numpy "
+                         "(train_tools.py:66-67), VecEnv.step(numpy), reward / done back on the host every step "
+                         "(PCIe and a stream sync inside the timed region; never the headline value)")
     ap.add_argument("--pipelines", type=int, default=1,
                     help="split each GPU's envs into this many independently stepped groups, one HIP stream each "
                          "(1 = one batch per step, the headline configuration; 2 overlaps one group's tail with "
@@ -142,6 +145,9 @@ def main():
                 if args.mode == "rows":
                     envs[g].policy_hash_rows(rows[g])
                     envs[g].step_rows_device(rows[g])
+                elif args.mode == "host":
+                    envs[g].policy_hash_rows(rows[g])
+                    envs[g].step(rows[g].cpu().numpy())  # obs (device), reward (CPU), done (numpy), infos
                 else:
                     envs[g].step_hash_policy(1)
 
@@ -230,7 +236,7 @@ def main():
             "frac": achieved_gbs / HBM_PEAK_GBS,
             "traffic": traffic,
             "kernel": ("pct_discrete_kernel<u32,5," if args.workload == "c2" else "pct_continuous_kernel<") +
-                      ("ACT_ROWS>" if args.mode == "rows" else "ACT_HASH>"),
+                      ("ACT_HASH>" if args.mode == "fused" else "ACT_ROWS>"),
             "kernel_avg_us": kern_avg_ms * 1e3,
             "launches_timed": n_launch,
             "alg_bytes_per_env_step": ALG_BYTES_PER_STEP,

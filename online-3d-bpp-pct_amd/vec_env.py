@@ -68,64 +68,6 @@ class VecEnv(ABC):
         pass
 
     @abstractmethod
-    def step_heuristic(self, name, n_steps=1):
-        """n_steps transitions with a heuristic baseline of heuristic.py as the in-env policy
-        (`name` in HEURISTICS: LSAH, HM, OnlineBPH, DBL, BR, MACS, RANDOM); follow with step_wait()."""
-        with torch.cuda.device(self._dev_index):
-            _lib.check(self._L.pct_step_heuristic(self._h, HEURISTICS[name], int(n_steps), self._stream()))
-        self.waiting_step = True
-
-    def current_obs(self):
-        """The handle's observation buffer (valid until the next transition)."""
-        return self._obs
-
-    def step_device(self, leaf_index):
-        """Device-resident step: `leaf_index` int64 [N] / [N,1] on the
-        device; returns (obs, reward float32 [N,1], mask = 1 - done float32 [N,1]) as DEVICE
-        tensors with no host synchronisation and no info dicts (terminal statistics stay
-        readable through `terminal_stats()`).  Replaces the D2H of the selected row, the host
-        `done` round trip and the CPU reward tensor of train_tools.py:66-70 / envs.py:181."""
-        idx = leaf_index.reshape(self.N).to(device=self.device, dtype=torch.int64).contiguous()
-        self._actions_keepalive = idx
-        with torch.cuda.device(self._dev_index):
-            _lib.check(self._L.pct_step_index(self._h, idx.data_ptr(), self._stream()))
-        return self._obs, self._reward.unsqueeze(1), (1 - self._done.to(torch.float32)).unsqueeze(1)
-
-    def terminal_stats(self):
-        """(done bool [N], counter int32 [N], ratio float64 [N]) of the last step (one sync)."""
-        return self._done.bool().cpu().numpy(), self._counter.cpu().numpy(), self._ratio.cpu().numpy()
-
-    def policy_hash_rows(self, out=None):
-        """Stand-in policy as its own kernel: float32 [N,9] leaf rows on the device."""
-        if out is None:
-            out = torch.empty(self.N, 9, dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self._dev_index):
-            _lib.check(self._L.pct_policy_hash_rows(self._h, out.data_ptr(), self._stream()))
-        return out
-
-    def step_rows_device(self, rows):
-        """Enqueue one step from device-resident float32 [N,9|6|3] rows; no host work."""
-        with torch.cuda.device(self._dev_index):
-            _lib.check(self._L.pct_step_rows(self._h, rows.data_ptr(), rows.shape[1], self._stream()))
-        self.waiting_step = True
-
-    def profile_enable(self, on=True):
-        _lib.check(self._L.pct_profile_enable(self._h, int(bool(on))))
-
-    def profile_read(self):
-        """(launches, total_ms) of the transition kernels since the last read (HIP events
-        recorded by the library on the launch stream)."""
-        n, ms = ctypes.c_int64(), ctypes.c_double()
-        _lib.check(self._L.pct_profile_read(self._h, ctypes.byref(n), ctypes.byref(ms)))
-        return n.value, ms.value
-
-    def phase_timing(self, on=True):
-        """Start/stop per-phase cycle accounting; returns the uint64 [N,16] gathered so far
-        (columns: load, drop, genems, set, feas, obs, store, steps, set-gen, set-dedup, set-match, set-rebuild)."""
-        out = np.zeros((self.N, 16), np.uint64)
-        _lib.check(self._L.pct_debug_phase_timing(self._h, int(bool(on)), out.ctypes.data))
-        return out
-
     def step_wait(self):
         pass
 
@@ -429,6 +371,13 @@ class PctVecEnv(VecEnv):
         n, ms = ctypes.c_int64(), ctypes.c_double()
         _lib.check(self._L.pct_profile_read(self._h, ctypes.byref(n), ctypes.byref(ms)))
         return n.value, ms.value
+
+    def phase_timing(self, on=True):
+        """Start/stop per-phase cycle accounting; returns the uint64 [N,16] gathered so far
+        (columns: load, drop, genems, set, feas, obs, store, steps, set-gen, set-dedup, set-match, set-rebuild)."""
+        out = np.zeros((self.N, 16), np.uint64)
+        _lib.check(self._L.pct_debug_phase_timing(self._h, int(bool(on)), out.ctypes.data))
+        return out
 
     def step_wait(self):
         # one small async D2H per output, then a single stream sync (envs.py:178-182)
