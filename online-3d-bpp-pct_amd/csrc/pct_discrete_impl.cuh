@@ -1042,7 +1042,30 @@ __device__ inline void write_obs(const DiscreteParams& p, int e, const Lds<K, BI
     if (dens && lane == 6) v = (float)bden[new_row];
     obs[new_row * 9 + lane] = v;
   }
-  for (int rbase = full ? 0 : p.I; rbase < rows; rbase += 7) {
+  if (!full) {
+    // incremental: lane = leaf row, nine strided stores per lane (far fewer instructions than the
+    // coalesced row-major sweep below; the launch is latency-bound, not store-bound), then the item row
+    for (int jb = 0; jb < p.L; jb += 64) {
+      const int j = jb + lane;
+      if (j < p.L) {
+        const bool on = j < r.n_leaf;
+        const K k = on ? l.leaf[j] : (K)0;
+        float* o = obs + (size_t)(p.I + j) * 9;
+        o[0] = (float)P::get(k, 0); o[1] = (float)P::get(k, 1); o[2] = (float)P::get(k, 2);
+        o[3] = (float)P::get(k, 3); o[4] = (float)P::get(k, 4);
+        o[5] = on ? (float)p.H : 0.f;
+        o[6] = 0.f; o[7] = 0.f;
+        o[8] = on ? 1.0f : 0.f;
+      }
+    }
+    if (lane < 9) {
+      const int col2 = lane;
+      obs[(size_t)(p.I + p.L) * 9 + col2] =
+          col2 == 0 ? nden : (col2 == 3 ? (float)a : (col2 == 4 ? (float)b : (col2 == 5 ? (float)c : (col2 == 8 ? 1.0f : 0.f))));
+    }
+    return;
+  }
+  for (int rbase = 0; rbase < rows; rbase += 7) {
     const int row = rbase + rsub;
     if (!lane_on || row >= rows) continue;
     float v = 0.f;
