@@ -35,19 +35,34 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, total, steps, out_dir):
+def _step(env, variant):
+    if variant == "heuristic":
+        env.step_heuristic(6, 1)  # PCT_HEUR_RANDOM: its pick is keyed by the global env id
+    else:
+        env.step_hash_policy(1)
+
+
+def _make(n, base, variant):
+    from oracle.oracle_lib import OracleVecEnv
+    from tests.common import item_set_range
+    if variant == "plain":
+        return OracleVecEnv(n, item_set=item_set_range(1, 5), env_id_base=base)
+    # setting 3 densities (pct_density), shuffled candidates (pct_shuffle_priority), sampled items
+    # (pct_pick): every counter-keyed stream takes the GLOBAL env id
+    return OracleVecEnv(n, setting=3, item_set=item_set_range(1, 5), env_id_base=base, shuffle=True, shuffle_seed=77)
+
+
+def _worker(rank, world, port, total, steps, out_dir, variant="plain"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from oracle.oracle_lib import OracleVecEnv
-    from tests.common import item_set_range
     base, n = sharding.shard_envs(total, rank, world)
-    env = OracleVecEnv(n, item_set=item_set_range(1, 5), env_id_base=base)
+    env = _make(n, base, variant)
     env.set_sampler(1234)
     env.reset()
     for _ in range(steps):
-        env.step_hash_policy(1)
+        _step(env, variant)
     local = torch.from_numpy(env.obs.astype(np.float32))
     full = sharding.gather_rollout(local)
     rew = sharding.gather_rollout(torch.from_numpy(env.reward.copy()))
@@ -68,5 +83,20 @@ def test_two_rank_shards_equal_one_batch(tmp_path):
     env.reset()
     for _ in range(steps):
         env.step_hash_policy(1)
+    assert np.array_equal(np.load(tmp_path / "obs.npy"), env.obs.astype(np.float32))
+    assert np.array_equal(np.load(tmp_path / "rew.npy"), env.reward)
+
+
+@pytest.mark.parametrize("variant", ["setting3_shuffle", "heuristic"])
+def test_two_rank_shards_equal_one_batch_counter_keyed_streams(tmp_path, variant):
+    """densities, shuffle priorities, item picks and the RANDOM heuristic's draw are all keyed by the
+    global env id: two shards reproduce the single batch"""
+    total, steps, world = 10, 30, 2
+    mp.spawn(_worker, args=(world, _free_port(), total, steps, str(tmp_path), variant), nprocs=world, join=True)
+    env = _make(total, 0, variant)
+    env.set_sampler(1234)
+    env.reset()
+    for _ in range(steps):
+        _step(env, variant)
     assert np.array_equal(np.load(tmp_path / "obs.npy"), env.obs.astype(np.float32))
     assert np.array_equal(np.load(tmp_path / "rew.npy"), env.reward)
