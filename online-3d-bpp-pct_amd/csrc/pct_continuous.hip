@@ -85,7 +85,6 @@ struct CLds {
   int32_t* bk;      // [4][I] lattice indices of (-lx,-ly,xe,ye)
   uint32_t* pend;   // [128] generator ids waiting for insertion
   uint32_t* bg;     // [64]
-  uint16_t* order;  // [order_cap] table iteration order (generator ids)
   uint16_t* vp;     // [64]
   uint32_t* fpri;   // [order_cap] shuffle priorities of the feasible candidates (shuffle only)
   uint32_t* dd;     // [128] bucket words of the batch de-duplication
@@ -108,16 +107,15 @@ __device__ inline CLds carve(const ContinuousParams& p, unsigned char* base) {
   l.bg = reinterpret_cast<uint32_t*>(q); q += 64;
   l.dd = reinterpret_cast<uint32_t*>(q); q += 128;
   uint16_t* h = reinterpret_cast<uint16_t*>(q);
-  l.order = h; h += p.table_global ? 0 : p.order_cap;
   l.vp = h; h += 64;
-  l.fpri = reinterpret_cast<uint32_t*>(h + ((p.table_global ? 0 : p.order_cap) & 1));
+  l.fpri = reinterpret_cast<uint32_t*>(h);
   return l;
 }
 
 size_t continuous_lds_bytes(const ContinuousParams& p) {
   size_t dbl = (size_t)6 * p.ems_cap + p.union_doubles + 9 * (size_t)p.I + 6 * (size_t)p.L + 64;
   size_t i32 = 4 * (size_t)p.I + 128 + 64 + 128;
-  size_t u16 = (size_t)(p.table_global ? 0 : p.order_cap) + 64 + 2;
+  size_t u16 = 64 + 2;
   if (p.shuffle && !p.table_global) u16 += 2 * (size_t)p.order_cap;
   return dbl * 8 + i32 * 4 + u16 * 2 + 16;
 }
@@ -222,31 +220,16 @@ __device__ inline StabState cstab_view(const ContinuousParams& p, int e) {
 
 // C/space.py:441-487 GENEMS + :510-528 EliminateInscribedEMS.  l.ems -> l.ems.
 __device__ inline void cgenems(const ContinuousParams& p, CLds& l, CRegs& r, int lane, const double loc[6]) {
-  const int E = r.n_ems, cap = p.ems_cap;
+  // Survivors (EMS the box does not intersect) stay where they are in l.ems until the end; only the
+  // children go to the scratch list (l.ems_b, [6][scap], aliasing the idle hash table).  The pre-GENEMS
+  // list is containment-free and a child lies inside its parent, so a survivor can neither be deleted
+  // nor sit inside a child: each child is tested against the survivors and the other children (exact
+  // float compares, non-strict, on the pre-deletion list: identical children delete each other).
+  const int E = r.n_ems, cap = p.ems_cap, scap = p.union_doubles / 6;
   const double lb = p.low_bound;
   const double n0 = -loc[0], n1 = -loc[1], n2 = -loc[2];
-  int S = 0;
-  for (int base = 0; base < E; base += 64) {
-    int i = base + lane;
-    bool live = i < E;
-    double e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0, e5 = 0;
-    if (live) {
-      e0 = l.ems[0 * cap + i]; e1 = l.ems[1 * cap + i]; e2 = l.ems[2 * cap + i];
-      e3 = l.ems[3 * cap + i]; e4 = l.ems[4 * cap + i]; e5 = l.ems[5 * cap + i];
-    }
-    // np.around(np.minimum(item, EMS), 6) decides on the lattice: compare indices
-    int k0 = min(klat(n0), klat(-e0)), k1 = min(klat(n1), klat(-e1)), k2 = min(klat(n2), klat(-e2));
-    int k3 = min(klat(loc[3]), klat(e3)), k4 = min(klat(loc[4]), klat(e4)), k5 = min(klat(loc[5]), klat(e5));
-    bool inter = live && (k0 + k3 > 0) && (k1 + k4 > 0) && (k2 + k5 > 0);
-    bool surv = live && !inter;
-    uint64_t m = __ballot(surv);
-    if (surv) {
-      int o = S + rank_below(m);
-      l.ems_b[0 * cap + o] = e0; l.ems_b[1 * cap + o] = e1; l.ems_b[2 * cap + o] = e2;
-      l.ems_b[3 * cap + o] = e3; l.ems_b[4 * cap + o] = e4; l.ems_b[5 * cap + o] = e5;
-    }
-    S += __popcll(m);
-  }
+  uint32_t* const smask = l.dd;       // [2 per 64-EMS chunk] survivor bits (the de-duplication buckets are idle)
+  uint32_t* const kmask = l.dd + 64;  // [2 per 64-child chunk] children that survive the elimination
   int C = 0;
   for (int base = 0; base < E; base += 64) {
     int i = base + lane;
@@ -256,9 +239,12 @@ __device__ inline void cgenems(const ContinuousParams& p, CLds& l, CRegs& r, int
       x1 = l.ems[0 * cap + i]; y1 = l.ems[1 * cap + i]; z1 = l.ems[2 * cap + i];
       x2 = l.ems[3 * cap + i]; y2 = l.ems[4 * cap + i]; z2 = l.ems[5 * cap + i];
     }
+    // np.around(np.minimum(item, EMS), 6): the rounded values decide (and give the child coordinates)
     double q0 = around6(fmin(n0, -x1)), q1 = around6(fmin(n1, -y1)), q2 = around6(fmin(n2, -z1));
     double q3 = around6(fmin(loc[3], x2)), q4 = around6(fmin(loc[4], y2)), q5 = around6(fmin(loc[5], z2));
     bool inter = live && (q0 + q3 > 0) && (q1 + q4 > 0) && (q2 + q5 > 0);
+    uint64_t ms = __ballot(live && !inter);
+    if (lane == 0) { smask[(base >> 6) * 2] = (uint32_t)ms; smask[(base >> 6) * 2 + 1] = (uint32_t)(ms >> 32); }
     double x3 = -q0, y3 = -q1, x4 = q3, y4 = q4, z4 = q5;  // intersect[:, 0:3] *= -1
     bool uy = (y2 - y1 + 1e-6 >= lb), uz = (z2 - z1 + 1e-6 >= lb), ux = (x2 - x1 + 1e-6 >= lb);
     bool c0 = inter && (x3 - x1 + 1e-6 >= lb) && uy && uz;  // [x1,y1,z1,x3,y2,z2]
@@ -267,13 +253,12 @@ __device__ inline void cgenems(const ContinuousParams& p, CLds& l, CRegs& r, int
     bool c3 = inter && ux && (y2 - y4 + 1e-6 >= lb) && uz;  // [x1,y4,z1,x2,y2,z2]
     bool c4 = inter && ux && uy && (z2 - z4 + 1e-6 >= lb);  // [x1,y1,z4,x2,y2,z2]
     uint64_t m0 = __ballot(c0), m1 = __ballot(c1), m2 = __ballot(c2), m3 = __ballot(c3), m4 = __ballot(c4);
-    int pos = S + C + rank_below(m0) + rank_below(m1) + rank_below(m2) + rank_below(m3) +
-              rank_below(m4);
+    int pos = C + rank_below(m0) + rank_below(m1) + rank_below(m2) + rank_below(m3) + rank_below(m4);
 #define PCT_PUT(A, B, Cc, D, Ee, F)                                                                   \
   do {                                                                                               \
-    if (pos < cap) {                                                                                 \
-      l.ems_b[0 * cap + pos] = (A); l.ems_b[1 * cap + pos] = (B); l.ems_b[2 * cap + pos] = (Cc);     \
-      l.ems_b[3 * cap + pos] = (D); l.ems_b[4 * cap + pos] = (Ee); l.ems_b[5 * cap + pos] = (F);     \
+    if (pos < scap) {                                                                                \
+      l.ems_b[0 * scap + pos] = (A); l.ems_b[1 * scap + pos] = (B); l.ems_b[2 * scap + pos] = (Cc);  \
+      l.ems_b[3 * scap + pos] = (D); l.ems_b[4 * scap + pos] = (Ee); l.ems_b[5 * scap + pos] = (F);  \
     }                                                                                                \
     pos++;                                                                                           \
   } while (0)
@@ -285,42 +270,80 @@ __device__ inline void cgenems(const ContinuousParams& p, CLds& l, CRegs& r, int
 #undef PCT_PUT
     C += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3) + __popcll(m4);
   }
-  int n = S + C;
-  if (n > cap) {
-    n = cap;
+  if (C > scap) {
+    C = scap;
     r.flags |= PCT_FLAG_EMS_OVERFLOW;
   }
   __syncthreads();
-  // survivors stay (the pre-GENEMS list is containment-free and a child lies inside its
-  // parent), children are tested against the whole list with exact float compares
-  int keepS = S < n ? S : n;
-  for (int i = lane; i < keepS; i += 64)
-    for (int c = 0; c < 6; c++) l.ems[c * cap + i] = l.ems_b[c * cap + i];
-  int out = keepS;
-  for (int base = keepS; base < n; base += 64) {
+  // which children survive
+  for (int base = 0; base < C; base += 64) {
     int i = base + lane;
-    bool live = i < n;
+    bool live = i < C;
     double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
     if (live) {
-      a0 = l.ems_b[0 * cap + i]; a1 = l.ems_b[1 * cap + i]; a2 = l.ems_b[2 * cap + i];
-      a3 = l.ems_b[3 * cap + i]; a4 = l.ems_b[4 * cap + i]; a5 = l.ems_b[5 * cap + i];
+      a0 = l.ems_b[0 * scap + i]; a1 = l.ems_b[1 * scap + i]; a2 = l.ems_b[2 * scap + i];
+      a3 = l.ems_b[3 * scap + i]; a4 = l.ems_b[4 * scap + i]; a5 = l.ems_b[5 * scap + i];
     }
     bool del = false;
-    for (int j = 0; j < n; j++) {
-      double b0 = l.ems_b[0 * cap + j], b1 = l.ems_b[1 * cap + j], b2 = l.ems_b[2 * cap + j];
-      double b3 = l.ems_b[3 * cap + j], b4 = l.ems_b[4 * cap + j], b5 = l.ems_b[5 * cap + j];
+    for (int j = 0; j < E; j++) {
+      if (!((smask[(j >> 6) * 2 + ((j >> 5) & 1)] >> (j & 31)) & 1u)) continue;  // not a survivor (wave-uniform)
+      double b0 = l.ems[0 * cap + j], b1 = l.ems[1 * cap + j], b2 = l.ems[2 * cap + j];
+      double b3 = l.ems[3 * cap + j], b4 = l.ems[4 * cap + j], b5 = l.ems[5 * cap + j];
+      del |= (a0 >= b0) & (a1 >= b1) & (a2 >= b2) & (a3 <= b3) & (a4 <= b4) & (a5 <= b5);
+    }
+    for (int j = 0; j < C; j++) {
+      double b0 = l.ems_b[0 * scap + j], b1 = l.ems_b[1 * scap + j], b2 = l.ems_b[2 * scap + j];
+      double b3 = l.ems_b[3 * scap + j], b4 = l.ems_b[4 * scap + j], b5 = l.ems_b[5 * scap + j];
       bool inside = (a0 >= b0) & (a1 >= b1) & (a2 >= b2) & (a3 <= b3) & (a4 <= b4) & (a5 <= b5);
       del |= inside & (j != i);
     }
-    bool keep = live && !del;
-    uint64_t m = __ballot(keep);
-    if (keep) {
-      int o = out + rank_below(m);
-      l.ems[0 * cap + o] = a0; l.ems[1 * cap + o] = a1; l.ems[2 * cap + o] = a2;
-      l.ems[3 * cap + o] = a3; l.ems[4 * cap + o] = a4; l.ems[5 * cap + o] = a5;
-    }
-    out += __popcll(m);
+    uint64_t mk = __ballot(live && !del);
+    if (lane == 0) { kmask[(base >> 6) * 2] = (uint32_t)mk; kmask[(base >> 6) * 2 + 1] = (uint32_t)(mk >> 32); }
   }
+  __syncthreads();
+  // survivors close ranks in place (a chunk is read whole before it is written, leftwards) ...
+  int out = 0;
+  for (int base = 0; base < E; base += 64) {
+    int i = base + lane;
+    const uint64_t ms = ((uint64_t)smask[(base >> 6) * 2 + 1] << 32) | smask[(base >> 6) * 2];
+    bool surv = (ms >> lane) & 1ull;
+    double e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0, e5 = 0;
+    if (surv) {
+      e0 = l.ems[0 * cap + i]; e1 = l.ems[1 * cap + i]; e2 = l.ems[2 * cap + i];
+      e3 = l.ems[3 * cap + i]; e4 = l.ems[4 * cap + i]; e5 = l.ems[5 * cap + i];
+    }
+    __syncthreads();
+    if (surv) {
+      int o = out + rank_below(ms);
+      l.ems[0 * cap + o] = e0; l.ems[1 * cap + o] = e1; l.ems[2 * cap + o] = e2;
+      l.ems[3 * cap + o] = e3; l.ems[4 * cap + o] = e4; l.ems[5 * cap + o] = e5;
+    }
+    out += __popcll(ms);
+    __syncthreads();
+  }
+  // ... and the surviving children follow, in order
+  bool over = false;
+  for (int base = 0; base < C; base += 64) {
+    int i = base + lane;
+    const uint64_t mk = ((uint64_t)kmask[(base >> 6) * 2 + 1] << 32) | kmask[(base >> 6) * 2];
+    bool keep = (mk >> lane) & 1ull;
+    if (keep) {
+      int o = out + rank_below(mk);
+      if (o < cap) {
+        for (int c = 0; c < 6; c++) l.ems[c * cap + o] = l.ems_b[c * scap + i];
+      } else {
+        over = true;
+      }
+    }
+    out += __popcll(mk);
+  }
+  if (__ballot(over) || out > cap) {  // the list that survives must fit the state array
+    out = out > cap ? cap : out;
+    r.flags |= PCT_FLAG_EMS_OVERFLOW;
+  }
+  __syncthreads();
+  l.dd[lane] = 0xFFFFFFFFu;       // hand the bucket words back to the de-duplication in their idle state
+  l.dd[lane + 64] = 0xFFFFFFFFu;
   r.n_ems = out;
   __syncthreads();
 }
@@ -336,7 +359,9 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
   // table and list(set) order: LDS, or this env's HBM slice when the capacity does not fit
   const size_t gslot = p.gt_by_block ? (size_t)blockIdx.x : (size_t)e;
   uint32_t* const tabs = GT ? p.gtab + gslot * (size_t)(p.cand_cap + p.cand_cap / 4) : l.tab;
-  uint16_t* const order = GT ? p.gorder + gslot * (size_t)p.order_cap : l.order;
+  // list(set) as 16-bit generator ids: HBM slice, or -- LDS table -- written over the front of the table
+  // region itself once the table is complete (entry k is written after slot k has been read)
+  uint16_t* const order = GT ? p.gorder + gslot * (size_t)p.order_cap : reinterpret_cast<uint16_t*>(l.tab);
   uint32_t toff = table_region(p.cand_cap, size);
   if (lane < 8) tab_st<GT, uint32_t>(&tabs[toff + lane], EMPTY);
   l.dd[lane] = 0xFFFFFFFFu;

@@ -166,7 +166,9 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
     return fail(PCT_ERR_UNSUPPORTED, "continuous container sizes must be whole bin units (multiples of 1000 lattice units)");
   /* discrete bins <= 31 per axis (32-bit keys): 128 EMS (82 is the most the 10^3 probes ever
    * held before elimination) keeps the env at 10 KB of LDS = 16 resident envs per CU */
-  int ems_cap = cfg->ems_capacity > 0 ? cfg->ems_capacity : ((!cont && maxdim <= 12) ? 128 : 256);
+  /* EMS kept after elimination: 128 covers the 10-unit bins of both envs with room to spare (most
+   * ever seen: 59 discrete, 81 continuous), larger bins default to 256 */
+  int ems_cap = cfg->ems_capacity > 0 ? cfg->ems_capacity : (((cont ? maxdim / 1000 : maxdim) <= 12) ? 128 : 256);
   if (!cont && ems_cap < 64) return fail(PCT_ERR_INVALID_ARG, "ems_capacity must be >= 64");
   /* candidate table: 2048 slots (1228 distinct candidates) cover the 10^3-class bins with room to
    * spare; larger discrete bins default to 8192 (4915) */
@@ -209,7 +211,10 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
     c.order_cap = (cand_cap * 3) / 5 + 8;
     c.table_global = cand_cap > 8192 ? 1 : 0; /* beyond 8192 slots the table cannot share LDS with the EMS */
     size_t tab_doubles = c.table_global ? 0 : ((size_t)(cand_cap + cand_cap / 4) * 4 + 7) / 8;
-    c.union_doubles = (int)(tab_doubles > (size_t)6 * ems_cap ? tab_doubles : (size_t)6 * ems_cap);
+    /* the region shared by the hash table and the GENEMS children scratch: 2 * ems_cap children when
+     * the table lives in LDS (225 pre-elimination entries were seen at C3), ems_cap otherwise */
+    size_t child_doubles = (size_t)6 * ems_cap * (c.table_global ? 1 : 2);
+    c.union_doubles = (int)(tab_doubles > child_doubles ? tab_doubles : child_doubles);
     c.env_id_base = cfg->env_id_base;
     c.source = PCT_ITEMS_NONE;
     if ((size_t)ems_cap * 24 + 23 > 65535) { delete h; return fail(PCT_ERR_INVALID_ARG, "ems_capacity too large for 16-bit generator ids"); }
