@@ -79,12 +79,12 @@ struct CLds {
   double* ems_b;  // [6][ems_cap] scratch during GENEMS (aliases the hash table)
   uint32_t* tab;  // [cand_cap + cand_cap/4] hash table regions (aliases ems_b)
   double* box;    // [6][I] lx,ly,lz,xe,ye,top
-  double* leaf;   // [6][L]
-  double* bsz;    // [3][I] item sizes as placed (x,y,z): (lx + x) - lx need not equal x
+  double* leaf;   // [5][L] xs,ys,zs,xe,ye (the sixth column of a leaf row is the constant H)
+  double* bsz;    // [3][I] item sizes as placed (x,y,z): (lx + x) - lx need not equal x (stability only)
   uint64_t* bhash;  // [64]
   int32_t* bk;      // [4][I] lattice indices of (-lx,-ly,xe,ye)
-  uint32_t* pend;   // [128] generator ids waiting for insertion
-  uint32_t* bg;     // [64]
+  uint16_t* pend;   // [128] generator ids waiting for insertion
+  uint16_t* bg;     // [64] generator ids of the batch
   uint16_t* vp;     // [64]
   uint32_t* fpri;   // [order_cap] shuffle priorities of the feasible candidates (shuffle only)
   uint32_t* dd;     // [128] bucket words of the batch de-duplication
@@ -98,24 +98,24 @@ __device__ inline CLds carve(const ContinuousParams& p, unsigned char* base) {
   l.tab = reinterpret_cast<uint32_t*>(d);
   d += p.union_doubles;
   l.box = d; d += 6 * p.I;
-  l.leaf = d; d += 6 * p.L;
-  l.bsz = d; d += 3 * p.I;
+  l.leaf = d; d += 5 * p.L;
+  l.bsz = d; d += (p.setting != 2) ? 3 * p.I : 0;
   l.bhash = reinterpret_cast<uint64_t*>(d); d += 64;
   int32_t* q = reinterpret_cast<int32_t*>(d);
   l.bk = q; q += 4 * p.I;
-  l.pend = reinterpret_cast<uint32_t*>(q); q += 128;
-  l.bg = reinterpret_cast<uint32_t*>(q); q += 64;
   l.dd = reinterpret_cast<uint32_t*>(q); q += 128;
   uint16_t* h = reinterpret_cast<uint16_t*>(q);
+  l.pend = h; h += 128;
+  l.bg = h; h += 64;
   l.vp = h; h += 64;
   l.fpri = reinterpret_cast<uint32_t*>(h);
   return l;
 }
 
 size_t continuous_lds_bytes(const ContinuousParams& p) {
-  size_t dbl = (size_t)6 * p.ems_cap + p.union_doubles + 9 * (size_t)p.I + 6 * (size_t)p.L + 64;
-  size_t i32 = 4 * (size_t)p.I + 128 + 64 + 128;
-  size_t u16 = 64 + 2;
+  size_t dbl = (size_t)6 * p.ems_cap + p.union_doubles + (p.setting != 2 ? 9 : 6) * (size_t)p.I + 5 * (size_t)p.L + 64;
+  size_t i32 = 4 * (size_t)p.I + 128;
+  size_t u16 = 128 + 64 + 64 + 2;
   if (p.shuffle && !p.table_global) u16 += 2 * (size_t)p.order_cap;
   return dbl * 8 + i32 * 4 + u16 * 2 + 16;
 }
@@ -373,8 +373,8 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
 
   auto flush = [&](int cnt) {
     bool pending = lane < cnt;
-    uint32_t g = pending ? l.pend[lane] : 0u;
-    uint32_t mv = (lane + 64 < npend) ? l.pend[lane + 64] : 0u;
+    uint32_t g = pending ? (uint32_t)l.pend[lane] : 0u;
+    uint16_t mv = (lane + 64 < npend) ? l.pend[lane + 64] : (uint16_t)0;
     __syncthreads();
     if (lane + 64 < npend) l.pend[lane] = mv;
     npend -= cnt;
@@ -383,7 +383,7 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
     cand_tuple(p, l, r, orient, g, t);
     uint64_t hash = tuplehash6d(t);
     l.bhash[lane] = hash;
-    l.bg[lane] = g;
+    l.bg[lane] = (uint16_t)g;
     __syncthreads();
     // exact in-batch de-duplication (first occurrence stays): equal hashes first, then the tuples
     pending = pending && !batch_find_duplicates<128>(l.dd, pending, hash, lane, cnt, [&](int w) -> bool {
@@ -449,8 +449,8 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
         const bool in32 = lane < 32 && ((occ32 >> lane) & 1u);
         const bool later = (rem >> lane) & 1ull;
         __syncthreads();
-        if (in32) { l.bg[rank_below((uint64_t)occ32)] = g_s; l.bhash[rank_below((uint64_t)occ32)] = h_s; }
-        if (later) { l.bg[19 + rank_below(rem)] = g; l.bhash[19 + rank_below(rem)] = hash; }
+        if (in32) { l.bg[rank_below((uint64_t)occ32)] = (uint16_t)g_s; l.bhash[rank_below((uint64_t)occ32)] = h_s; }
+        if (later) { l.bg[19 + rank_below(rem)] = (uint16_t)g; l.bhash[19 + rank_below(rem)] = hash; }
         const int total = 19 + __popcll(rem);
         const uint32_t noff = table_region(p.cand_cap, 128u);
         tab_st<GT, uint32_t>(&tabs[noff + lane], EMPTY);
@@ -551,7 +551,7 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
         return tuple_eq(o, t);
       });
       uint64_t nm = __ballot(fresh);
-      if (fresh) l.pend[npend + rank_below(nm)] = g;
+      if (fresh) l.pend[npend + rank_below(nm)] = (uint16_t)g;
       npend += __popcll(nm);
       __syncthreads();
       if (npend >= 64) flush(64);
@@ -645,7 +645,7 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
         double t[6];
         cand_tuple(p, l, r, orient, (uint32_t)tab_ld<GT, uint16_t>(&order[a2]), t);
 #pragma unroll
-        for (int c2 = 0; c2 < 6; c2++) l.leaf[c2 * p.L + rank] = t[c2];
+        for (int c2 = 0; c2 < 5; c2++) l.leaf[c2 * p.L + rank] = t[c2];
       }
     }
     nleaf = nf;
@@ -660,7 +660,7 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
       int idx = nleaf + rank_below(m);
       if (ok && idx < p.L) {
 #pragma unroll
-        for (int c2 = 0; c2 < 6; c2++) l.leaf[c2 * p.L + idx] = t[c2];
+        for (int c2 = 0; c2 < 5; c2++) l.leaf[c2 * p.L + idx] = t[c2];
       }
       nleaf += __popcll(m);
     }
@@ -720,12 +720,14 @@ __device__ inline void cload(const ContinuousParams& p, int e, CLds& l, CRegs& r
   const double* gb = p.boxes + (size_t)e * 6 * p.I;
   const double* gl = p.leaves + (size_t)e * 6 * p.L;
   const double* gs = p.bsz + (size_t)e * 3 * p.I;
-  for (int c = 0; c < 3; c++)
-    for (int i = lane; i < r.n_boxes; i += 64) l.bsz[c * p.I + i] = gs[c * p.I + i];
+  if (p.setting != 2)
+    for (int c = 0; c < 3; c++)
+      for (int i = lane; i < r.n_boxes; i += 64) l.bsz[c * p.I + i] = gs[c * p.I + i];
   for (int c = 0; c < 6; c++) {
     for (int i = lane; i < r.n_ems; i += 64) l.ems[c * p.ems_cap + i] = ge[c * p.ems_cap + i];
     for (int i = lane; i < r.n_boxes; i += 64) l.box[c * p.I + i] = gb[c * p.I + i];
-    for (int i = lane; i < r.n_leaf; i += 64) l.leaf[c * p.L + i] = gl[c * p.L + i];
+    if (c < 5)
+      for (int i = lane; i < r.n_leaf; i += 64) l.leaf[c * p.L + i] = gl[c * p.L + i];
   }
   __syncthreads();
   for (int i = lane; i < r.n_boxes; i += 64) {
@@ -743,12 +745,14 @@ __device__ inline void cstore(const ContinuousParams& p, int e, const CLds& l, c
   double* gb = p.boxes + (size_t)e * 6 * p.I;
   double* gl = p.leaves + (size_t)e * 6 * p.L;
   double* gs = p.bsz + (size_t)e * 3 * p.I;
-  for (int c = 0; c < 3; c++)
-    for (int i = lane; i < r.n_boxes; i += 64) gs[c * p.I + i] = l.bsz[c * p.I + i];
+  if (p.setting != 2)
+    for (int c = 0; c < 3; c++)
+      for (int i = lane; i < r.n_boxes; i += 64) gs[c * p.I + i] = l.bsz[c * p.I + i];
   for (int c = 0; c < 6; c++) {
     for (int i = lane; i < r.n_ems; i += 64) ge[c * p.ems_cap + i] = l.ems[c * p.ems_cap + i];
     for (int i = lane; i < r.n_boxes; i += 64) gb[c * p.I + i] = l.box[c * p.I + i];
-    for (int i = lane; i < r.n_leaf; i += 64) gl[c * p.L + i] = l.leaf[c * p.L + i];
+    if (c < 5)
+      for (int i = lane; i < r.n_leaf; i += 64) gl[c * p.L + i] = l.leaf[c * p.L + i];
   }
   if (lane == 0) {
     sc[0] = r.n_ems; sc[1] = r.n_boxes; sc[2] = r.n_leaf;
@@ -825,7 +829,7 @@ __device__ inline bool ctransition(const ContinuousParams& p, int e, CLds& l, CR
       l.box[3 * p.I + bi] = xe; l.box[4 * p.I + bi] = ye; l.box[5 * p.I + bi] = top;
       l.bk[0 * p.I + bi] = klat(-lx); l.bk[1 * p.I + bi] = klat(-ly);
       l.bk[2 * p.I + bi] = klat(xe); l.bk[3 * p.I + bi] = klat(ye);
-      l.bsz[0 * p.I + bi] = x; l.bsz[1 * p.I + bi] = y; l.bsz[2 * p.I + bi] = z;
+      if (STAB) { l.bsz[0 * p.I + bi] = x; l.bsz[1 * p.I + bi] = y; l.bsz[2 * p.I + bi] = z; }
     }
     r.n_boxes++;
     r.volsum = r.volsum + x * y * z;  // get_ratio's left fold (:316-321)
