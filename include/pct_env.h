@@ -10,7 +10,11 @@
  *   envs.py:75-116 make_vec_envs / envs.py:33-49 gym.make kwargs     -> pct_create(pct_config)
  *   givenData.py:4-14 item_size_set, binCreator.py:24-39             -> pct_set_item_set
  *   binCreator.py:41-72 LoadBoxCreator (scripted trajectories)       -> pct_set_item_stream
+ *   binCreator.py:41-72 LoadBoxCreator on a dataset (README.md:75-77) -> pct_set_item_dataset
  *   binCreator.py:37-39 RandomBoxCreator (on-the-fly sampling)       -> pct_set_sampler
+ *   bin3D.py:75-84 next_den (setting 3)                              -> pct_set_density_stream /
+ *                                                                      pct_set_dataset_density
+ *   bin3D.py:114-115 np.random.shuffle(allPostion)                   -> pct_config.shuffle
  *   wrapper/vec_env.py:48-58 VecEnv.reset,
  *   wrapper/shmem_vec_env.py:61-68,112-117 reset / reset_specific    -> pct_reset
  *   wrapper/vec_env.py:60-88 step_async/step_wait,
@@ -18,6 +22,7 @@
  *   pct_envs/PctDiscrete0/bin3D.py:151-188 PackingDiscrete.step      -> pct_step_rows
  *   train_tools.py:66-67 leaf_nodes[batchX, idx] gather              -> pct_step_index
  *   (benchmark-only stand-in policy)                 -> pct_step_hash_policy
+ *   heuristic.py:11-569 (the seven baselines' placement rules)       -> pct_step_heuristic
  *   envs.py:178-182 VecPyTorch.step_wait outputs                     -> pct_bind_outputs /
  *                                                                      pct_obs, pct_reward, ...
  *   bin3D.py:163-164,186-187 info dict                               -> pct_info_counter/ratio
