@@ -685,7 +685,27 @@ __device__ inline void cwrite_obs(const ContinuousParams& p, int e, const CLds& 
   if (a > b) { tmp = a; a = b; b = tmp; }
   if (!full && new_row >= 0 && lane < 9)
     obs[new_row * 9 + lane] = lane < 6 ? (float)l.box[lane * p.I + new_row] : (lane == 8 ? 1.0f : 0.f);
-  for (int f = lane + (full ? 0 : p.I * 9); f < p.row_len; f += 64) {
+  if (!full) {
+    // incremental: lane = leaf row (nine strided stores), then the item row -- as in the discrete kernel
+    for (int jb = 0; jb < p.L; jb += 64) {
+      const int j = jb + lane;
+      if (j < p.L) {
+        const bool on = j < r.n_leaf;
+        float* o = obs + (size_t)(p.I + j) * 9;
+        o[0] = on ? (float)l.leaf[0 * p.L + j] : 0.f; o[1] = on ? (float)l.leaf[1 * p.L + j] : 0.f;
+        o[2] = on ? (float)l.leaf[2 * p.L + j] : 0.f; o[3] = on ? (float)l.leaf[3 * p.L + j] : 0.f;
+        o[4] = on ? (float)l.leaf[4 * p.L + j] : 0.f;
+        o[5] = on ? (float)p.H : 0.f;
+        o[6] = 0.f; o[7] = 0.f;
+        o[8] = on ? 1.0f : 0.f;
+      }
+    }
+    if (lane < 9)
+      obs[(size_t)(p.I + p.L) * 9 + lane] =
+          lane == 0 ? nden : (lane == 3 ? (float)a : (lane == 4 ? (float)b : (lane == 5 ? (float)c : (lane == 8 ? 1.0f : 0.f))));
+    return;
+  }
+  for (int f = lane; f < p.row_len; f += 64) {
     int row = f / 9;
     int col = f - row * 9;
     float v = 0.f;
