@@ -42,9 +42,19 @@ def build_library(force=False, verbose=False):
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
 
+    # which headers a translation unit includes (a change elsewhere does not recompile it)
+    deps = {"pct_env.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh"],
+            "pct_discrete.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_discrete_impl.cuh"],
+            "pct_discrete_u64.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_discrete_impl.cuh"],
+            "pct_continuous.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh"]}
+
     def compile_one(src):
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
-        cmd = [_hipcc(), *flags, "-c", os.path.join(CSRC, src), "-o", obj]
+        srcs = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in deps[src]] + [
+            os.path.join(HERE, "..", "include", "pct_env.h")]
+        if not force and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in srcs):
+            return obj
+        cmd = [_hipcc(), *flags, "-Wno-pass-failed", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

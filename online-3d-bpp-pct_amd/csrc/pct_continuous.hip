@@ -544,7 +544,7 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
       cand_tuple(p, l, r, orient, g, t);
       uint64_t hash = tuplehash6d(t);
       const uint32_t fp = cword(hash, 0) >> 16;
-      bool fresh = valid && !pyset_contains<uint32_t, GT>(tabs + toff, size - 1, hash, [&](uint32_t w) -> bool {
+      bool fresh = valid && !pyset_contains<uint32_t, GT>(tabs + toff, size - 1, hash, valid, [&](uint32_t w) -> bool {
         if ((w >> 16) != fp) return false;
         double o[6];
         cand_tuple(p, l, r, orient, w & 0xFFFFu, o);
@@ -998,7 +998,7 @@ __global__ void __launch_bounds__(64) pct_continuous_kernel(ContinuousParams p, 
   if (!requeue) {
     cstore(p, e, l, r, lane);
     tm.tick(PH_STORE);
-    if (TIMED && lane == 0) tm.flush(p.timing + (size_t)e * 16, n_steps);
+    if (TIMED && lane == 0) tm.flush(p.timing + (size_t)e * PCT_TIMING_SLOTS, n_steps);
   }
   }  // step / reset
   if (requeue && lane == 0) p.retry_ids[atomicAdd(p.retry_count, 1)] = e;

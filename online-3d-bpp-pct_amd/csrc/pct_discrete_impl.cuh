@@ -368,6 +368,8 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
   __syncthreads();
   bool cand_overflow = false;
   int npend = 0;
+  int mstat[3] = {0, 0, 0};  // timed build only: match calls, outer rounds, sum over calls of the longest walk
+  int* const mst = TM::on ? mstat : nullptr;
   tm.sub_start();
 
   // rotation r of the item (D/space.py:540-562): extents and the skip rule
@@ -392,9 +394,12 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
     npend -= cnt;
     __syncthreads();
     tm.sub_tick(PH_SET_GEN);
+    tm.add(ST_FLUSHES, 1);
     // exact in-batch de-duplication: keep the first occurrence (set.add of a present key is a
     // no-op, and the first occurrence is inserted before the later ones in any case)
+    if (TM::on) asm volatile("" : "+v"(key));
     uint64_t hash = tuplehash6<K, BITS>(key);
+    if (TM::on) { asm volatile("" : "+v"(hash)); tm.sub_tick(PH_SET_HASH); }
     pending = pending && !batch_find_duplicates_reg<64, K>(dd, pending, key, hash, lane);
     tm.sub_tick(PH_SET_DEDUP);
     if (sizeof(K) == 4 && fill == 0 && size == 8 && p.cand_cap >= 128) {
@@ -467,7 +472,8 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
         dd[lane] = 0xFFFFFFFFu;  // back to the all-ones state the de-duplication expects
         bool mplaced;
         uint32_t mslot;
-        pyset_match<K>(tabs, 127u, lane < total, tuplehash6<K, BITS>(mk), lane, false, mplaced, mslot, [&](K) { return false; });
+        if (TM::on) tm.sub_tick(PH_FAST_START);
+        pyset_match<K>(tabs, 127u, lane < total, tuplehash6<K, BITS>(mk), lane, false, mplaced, mslot, [&](K) { return false; }, mst);
         if (mplaced) tabs[mslot] = mk;
         toff = 0;  // table_offset_compact(cap, 128) for every cap >= 128 that is not 128 itself; see below
         size = 128;
@@ -488,7 +494,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
         bool part = pending && (uint32_t)rank_below(pm) < thr - fill;
         bool placed;
         uint32_t slot;
-        pyset_match<K>(tabs + toff, mask, part, hash, lane, true, placed, slot, [&](K w) { return w == key; });
+        pyset_match<K>(tabs + toff, mask, part, hash, lane, true, placed, slot, [&](K w) { return w == key; }, mst);
         if (placed) tabs[toff + slot] = key;
         pending = pending && !part;
         fill += (uint32_t)__popcll(__ballot(placed));
@@ -503,6 +509,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
           break;
         }
         const uint32_t noff = table_offset_compact((uint32_t)p.cand_cap, newsize);
+        tm.add(ST_REBUILDS, 1);
         if (noff == toff) {
           // same region: lift the old table (<= 512 slots = 8 per lane) into registers, wipe, and
           // re-insert chunk by chunk in old-slot order
@@ -523,7 +530,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
               bool oplaced;
               uint32_t oslot;
               pyset_match<K>(tabs + noff, newsize - 1, opart, tuplehash6<K, BITS>(ok), lane, false, oplaced, oslot,
-                             [&](K) { return false; });
+                             [&](K) { return false; }, mst);
               if (oplaced) tabs[noff + oslot] = ok;
               __syncthreads();
             }
@@ -571,7 +578,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
       valid = valid && !skip && (px + sx <= p.W) && (py + sy <= p.Ly) && (pz + sz <= p.H);
       K key = P::pack(px, py, pz, px + sx, py + sy, pz + sz);
       uint64_t hash = tuplehash6<K, BITS>(key);
-      bool fresh = valid && !pyset_contains<K>(tabs + toff, size - 1, hash, [&](K w) { return w == key; });
+      bool fresh = valid && !pyset_contains<K>(tabs + toff, size - 1, hash, valid, [&](K w) { return w == key; });
       uint64_t nm = __ballot(fresh);
       if (fresh) pend[npend + rank_below(nm)] = key;
       npend += __popcll(nm);
@@ -864,7 +871,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
       valid = valid && !skip && (px + sx <= p.W) && (py + sy <= p.Ly) && (pz + sz <= p.H);
       K key = P::pack(px, py, pz, px + sx, py + sy, pz + sz);
       uint64_t hash = tuplehash6<K, BITS>(key);
-      bool fresh = valid && !pyset_contains<K>(tabs + toff, size - 1, hash, [&](K w) { return w == key; });
+      bool fresh = valid && !pyset_contains<K>(tabs + toff, size - 1, hash, valid, [&](K w) { return w == key; });
       uint64_t nm = __ballot(fresh);
       if (fresh) pend[npend + rank_below(nm)] = key;
       npend += __popcll(nm);
@@ -882,6 +889,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
     const uint32_t rotmask = 1u | (g1 ? 2u : 0u) | (g2 ? 4u : 0u) | (g3 ? 8u : 0u) | (g4 ? 16u : 0u) | (g5 ? 32u : 0u);
     for (int pbase = 0; pbase < NP && !cand_overflow; pbase += 64) {
       // which (EMS, rotation) pairs of this chunk can hold the item at all
+      const uint64_t tpair = tm.now();
       int q = pbase + lane;
       bool pv = q < NP;
       int ei = q / orient, rot = q - ei * orient;
@@ -893,7 +901,10 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
       uint64_t pm = __ballot(pv);
       const int nt = 4 * __popcll(pm);  // four bottom-corner placements per pair (:565-568)
       if (pv) l.vp[rank_below(pm)] = (uint16_t)q;
+      tm.add(ST_GENERATED, (uint64_t)nt);
       __syncthreads();
+      uint64_t tq = tm.now();
+      if (TM::on) tm.add(PH_GEN_PAIRS, tq - tpair);
       for (int tb = 0; tb < nt && !cand_overflow; tb += 64) {
         int tt = tb + lane;
         bool valid = tt < nt;
@@ -906,13 +917,20 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
         int xs = (corner & 1) ? x1 - sx : x0;
         int ys = (corner & 2) ? y1 - sy : y0;
         K key = P::pack(xs, ys, z0, xs + sx, ys + sy, z0 + sz);
+        if (TM::on) { asm volatile("" : "+v"(key)); uint64_t t = tm.now(); tm.add(PH_GEN_TUPLE, t - tq); tq = t; }
         uint64_t hash = tuplehash6<K, BITS>(key);
-        bool fresh = valid && !pyset_contains<K>(tabs + toff, size - 1, hash, [&](K w) { return w == key; });
+        if (TM::on) { asm volatile("" : "+v"(hash)); uint64_t t = tm.now(); tm.add(PH_GEN_HASH, t - tq); tq = t; }
+        int cprobes = 0;
+        bool fresh = valid && !pyset_contains<K>(tabs + toff, size - 1, hash, valid, [&](K w) { return w == key; }, TM::on ? &cprobes : nullptr);
+        if (TM::on) { int fr = fresh; asm volatile("" : "+v"(fr)); fresh = fr != 0; uint64_t t = tm.now(); tm.add(PH_GEN_CONTAINS, t - tq); tq = t; }
+        if (TM::on) { tm.add(ST_CONTAINS_CALLS, 1); tm.add(ST_CONTAINS_PROBES, (uint64_t)wave_max_i32(cprobes)); }
         uint64_t nm = __ballot(fresh);
         if (fresh) pend[npend + rank_below(nm)] = key;
         npend += __popcll(nm);
         __syncthreads();
+        if (TM::on) { uint64_t t = tm.now(); tm.add(PH_GEN_PEND, t - tq); tq = t; }
         if (npend >= 64) flush(64);
+        if (TM::on) tq = tm.now();
       }
       __syncthreads();
     }
@@ -920,6 +938,9 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
   while (npend > 0 && !cand_overflow) flush(npend < 64 ? npend : 64);
   if (cand_overflow) r.flags |= PCT_FLAG_CANDIDATE_OVERFLOW;
   __syncthreads();
+  tm.add(ST_EMS, (uint64_t)E);
+  tm.add(ST_DISTINCT, (uint64_t)fill);
+  if (TM::on) { tm.add(ST_MATCH_CALLS, (uint64_t)mstat[0]); tm.add(ST_MATCH_ROUNDS, (uint64_t)mstat[1]); tm.add(ST_MATCH_PROBES, (uint64_t)mstat[2]); }
   tm.sub_tick(PH_SET_GEN);
   tm.tick(PH_SET);
 
@@ -1621,7 +1642,7 @@ enum { ACT_ROWS = 0, ACT_INDEX = 1, ACT_HASH = 2, ACT_RESET = 3, ACT_HEUR = 4 /*
 template <typename K, int BITS, int ACT, bool TIMED, bool STAB, int SCHEME, bool SHUFFLE>
 // the plain setting-2 kernels are held to 128 VGPRs (4 waves per SIMD = 16 resident envs per CU, the
 // occupancy the LDS layout is sized for); the float64 stability code and the timed build are not
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((STAB || TIMED) ? 1 : 4)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STAB ? 1 : 4)))
 pct_discrete_kernel(DiscreteParams p, const void* __restrict__ actions,
                                                           int row_len, int n_steps,
                                                           const int32_t* __restrict__ env_ids, int n_ids) {
@@ -1709,7 +1730,7 @@ pct_discrete_kernel(DiscreteParams p, const void* __restrict__ actions,
   }
   store_state<K, BITS>(p, e, l, r, lane);
   tm.tick(PH_STORE);
-  if (TIMED && lane == 0) tm.flush(p.timing + (size_t)e * 16, n_steps);
+  if (TIMED && lane == 0) tm.flush(p.timing + (size_t)e * PCT_TIMING_SLOTS, n_steps);
 }
 
 }  // namespace pct

@@ -12,6 +12,7 @@
 
 #include "../../include/pct_env.h"
 #include "pct_device.h"
+#include "pct_set.cuh"
 #include "pct_stab.cuh"
 
 namespace {
@@ -168,11 +169,15 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
    * held before elimination) keeps the env at 10 KB of LDS = 16 resident envs per CU */
   /* EMS kept after elimination: 128 covers the 10-unit bins of both envs with room to spare (most
    * ever seen: 59 discrete, 81 continuous), larger bins default to 256 */
-  int ems_cap = cfg->ems_capacity > 0 ? cfg->ems_capacity : (((cont ? maxdim / 1000 : maxdim) <= 12) ? 128 : 256);
+  /* continuous bins beyond 12 units (BASELINE configs[4]: 100^3 with U(5,25) items holds up to ~260 live EMS and
+   * several thousand distinct candidates): 768 EMS and a 32768-slot candidate table, which lives in HBM */
+  int ems_cap = cfg->ems_capacity > 0 ? cfg->ems_capacity
+                                      : (((cont ? maxdim / 1000 : maxdim) <= 12) ? 128 : (cont ? 768 : 256));
   if (!cont && ems_cap < 64) return fail(PCT_ERR_INVALID_ARG, "ems_capacity must be >= 64");
   /* candidate table: 2048 slots (1228 distinct candidates) cover the 10^3-class bins with room to
    * spare; larger discrete bins default to 8192 (4915) */
-  int cand_cap = cfg->candidate_capacity > 0 ? cfg->candidate_capacity : ((cont || maxdim <= 12) ? 2048 : 8192);
+  int cand_cap = cfg->candidate_capacity > 0 ? cfg->candidate_capacity
+                                             : (cont ? (maxdim / 1000 <= 12 ? 2048 : 32768) : (maxdim <= 12 ? 2048 : 8192));
   if (!is_cand_cap_ok(cand_cap)) return fail(PCT_ERR_INVALID_ARG, "candidate_capacity must be 8*4^k (8,32,...,2048,8192)");
 
   int ndev = 0;
@@ -604,7 +609,7 @@ int pct_debug_phase_timing(pct_env* h, int32_t on, uint64_t* host_out) {
   if (!h) return fail(PCT_ERR_INVALID_ARG, "null handle");
   int rc = use_device(h);
   if (rc) return rc;
-  size_t bytes = (size_t)h->dp.N * 16 * sizeof(unsigned long long);
+  size_t bytes = (size_t)h->dp.N * PCT_TIMING_SLOTS * sizeof(unsigned long long);
   HIP_TRY(hipDeviceSynchronize());
   if (host_out && h->timing_buf) HIP_TRY(hipMemcpy(host_out, h->timing_buf, bytes, hipMemcpyDeviceToHost));
   if (on) {

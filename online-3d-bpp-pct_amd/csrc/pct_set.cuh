@@ -152,19 +152,38 @@ struct Walk {  // position on a key's probe path: slot = i + j
   }
 };
 
+// One step along a probe path, without branches: the next linear probe, or the next perturbed jump
+__device__ inline void walk_advance(uint32_t& i, int& j, uint64_t& perturb, uint32_t mask) {
+  const bool lin = j < ((i + 9u <= mask) ? 9 : 0);
+  const uint64_t pn = perturb >> 5;
+  const uint32_t in = (i * 5u + 1u + (uint32_t)pn) & mask;
+  j = lin ? j + 1 : 0;
+  i = lin ? i : in;
+  perturb = lin ? perturb : pn;
+}
+
 // Read-only membership test (no tags may be present).
 // `same(word)` decides whether the table entry `word` holds the caller's key (set_add_entry:
-// entry->hash == hash and the keys compare equal).
+// entry->hash == hash and the keys compare equal).  Wave-uniform loop, predicated body: the whole wave
+// runs as many iterations as its longest walk and an iteration is a handful of selects around one
+// LDS read.  All 64 lanes must call; a lane without a key passes active = false.
 template <typename K, bool GT = false, typename Same>
-__device__ inline bool pyset_contains(const K* tab, uint32_t mask, uint64_t hash, Same same) {
-  Walk w;
-  w.start(hash, mask);
-  while (true) {
-    K cur = tab_ld<GT, K>(&tab[w.i + w.j]);
-    if (cur == SlotWord<K>::EMPTY) return false;
-    if (same(cur)) return true;
-    w.next(mask);
+__device__ inline bool pyset_contains(const K* tab, uint32_t mask, uint64_t hash, bool active, Same same,
+                                      int* probes = nullptr) {
+  uint32_t i = (uint32_t)hash & mask;
+  int j = 0;
+  uint64_t perturb = hash;
+  bool found = false;
+  while (__ballot(active)) {
+    K cur = SlotWord<K>::EMPTY;
+    if (active) cur = tab_ld<GT, K>(&tab[i + (uint32_t)j]);
+    if (probes) (*probes)++;
+    const bool eq = active && cur != SlotWord<K>::EMPTY && same(cur);
+    found = found || eq;
+    active = active && cur != SlotWord<K>::EMPTY && !eq;
+    walk_advance(i, j, perturb, mask);
   }
+  return found;
 }
 
 // Matches the participating lanes' keys into the table in lane-priority order.  The
@@ -175,18 +194,21 @@ __device__ inline bool pyset_contains(const K* tab, uint32_t mask, uint64_t hash
 // table (check_found).  All 64 lanes must call.
 template <typename K, bool GT = false, typename Same>
 __device__ inline void pyset_match(K* tab, uint32_t mask, bool part, uint64_t hash, int lane, bool check_found,
-                                   bool& placed, uint32_t& slot, Same same) {
+                                   bool& placed, uint32_t& slot, Same same, int* stats = nullptr) {
   const K TAG = SlotWord<K>::TAG;
   const K mytag = TAG | (K)lane;
-  Walk w;
-  w.start(hash, mask);
-  bool walking = part;
   placed = false;
   slot = 0;
-  while (true) {
-    while (walking) {
-      uint32_t cur = w.i + w.j;
-      if (GT) {
+  bool walking = part;
+  int my_probes = 0;
+  if (GT) {
+    Walk w;
+    w.start(hash, mask);
+    while (true) {
+      if (stats) stats[1]++;
+      while (walking) {
+        my_probes++;
+        uint32_t cur = w.i + w.j;
         K v = tab_ld<GT, K>(&tab[cur]);
         if ((v & TAG) && v > mytag) {  // empty, or tentatively held by a later lane
           K old = lds_atomic_min(&tab[cur], mytag);
@@ -200,29 +222,49 @@ __device__ inline void pyset_match(K* tab, uint32_t mask, bool part, uint64_t ha
         } else {
           w.next(mask);  // a different key, or an earlier lane's tentative hold
         }
-      } else {
-        // LDS: propose straight away -- a real key (tag bit clear) or an earlier lane's tag is
-        // numerically smaller than mytag and stays, so the atomic doubles as the read
-        K old = lds_atomic_min(&tab[cur], mytag);
-        if (old > mytag) {  // was empty, or tentatively held by a later lane
-          slot = cur;
-          placed = true;
-          walking = false;
-        } else if (check_found && !(old & TAG) && same(old)) {
-          walking = false;  // already a member
-        } else {
-          w.next(mask);
-        }
       }
+      __syncthreads();
+      if (placed && tab_ld<GT, K>(&tab[slot]) != mytag) {  // evicted by an earlier lane: walk on
+        placed = false;
+        walking = true;
+        w.next(mask);
+      }
+      if (!__ballot(walking)) break;
     }
-    __syncthreads();
-    if (placed && tab_ld<GT, K>(&tab[slot]) != mytag) {  // evicted by an earlier lane: walk on
-      placed = false;
-      walking = true;
-      w.next(mask);
+  } else {
+    // LDS: propose straight away -- a real key (tag bit clear) or an earlier lane's tag is numerically
+    // smaller than mytag and stays, so the atomic doubles as the read.  Wave-uniform loops with a
+    // predicated body (an iteration = one LDS atomic and a handful of selects); a lane's position always
+    // moves past the slot it has just tried, so an evicted lane simply resumes.
+    uint32_t i = (uint32_t)hash & mask;
+    int j = 0;
+    uint64_t perturb = hash;
+    while (true) {
+      if (stats) stats[1]++;
+      while (__ballot(walking)) {
+        const uint32_t cur = i + (uint32_t)j;
+        K old = 0;
+        if (walking) {
+          old = lds_atomic_min(&tab[cur], mytag);
+          my_probes++;
+        }
+        const bool won = walking && old > mytag;  // was empty, or tentatively held by a later lane
+        const bool member = walking && check_found && !(old & TAG) && same(old);
+        slot = won ? cur : slot;
+        placed = placed || won;
+        const bool tried = walking;
+        walking = walking && !won && !member;
+        if (tried) walk_advance(i, j, perturb, mask);
+      }
+      __syncthreads();
+      if (placed && tab[slot] != mytag) {  // evicted by an earlier lane: walk on from the next slot
+        placed = false;
+        walking = true;
+      }
+      if (!__ballot(walking)) break;
     }
-    if (!__ballot(walking)) break;
   }
+  if (stats) { stats[0]++; stats[2] += wave_max_i32(my_probes); }
 }
 
 // Exact removal of duplicates inside a batch of <= 64 keys (lane = position in insertion order):
@@ -323,6 +365,7 @@ __device__ inline uint32_t table_region(uint32_t cap, uint32_t size) {
   return (lv & 1) ? cap : 0u;
 }
 
+#define PCT_TIMING_SLOTS 32
 // optional per-phase cycle accounting (pct_debug_phase_timing): s_memtime deltas per env.
 // The untimed specialisation is empty, so production kernels carry no extra registers.
 template <bool ON>
@@ -332,13 +375,19 @@ struct PhaseTimer {
   __device__ inline void flush(unsigned long long*, int) {}
   __device__ inline void sub_start() {}
   __device__ inline void sub_tick(int) {}
+  __device__ inline void add(int, uint64_t) {}
+  __device__ inline uint64_t now() { return 0; }
+  static constexpr bool on = false;
 };
 template <>
 struct PhaseTimer<true> {
+  static constexpr bool on = true;
   uint64_t last;
-  uint64_t acc[16];
+  uint64_t acc[PCT_TIMING_SLOTS];
+  __device__ inline void add(int i, uint64_t v) { acc[i] += v; }  // plain statistics (slots 12..)
+  __device__ inline uint64_t now() { return __builtin_readcyclecounter(); }
   __device__ inline void start() {
-    for (int i = 0; i < 16; i++) acc[i] = 0;
+    for (int i = 0; i < PCT_TIMING_SLOTS; i++) acc[i] = 0;
     last = __builtin_readcyclecounter();
   }
   __device__ inline void tick(int i) {
@@ -354,7 +403,7 @@ struct PhaseTimer<true> {
     sub_last = now;
   }
   __device__ inline void flush(unsigned long long* o, int n_steps) {
-    for (int i = 0; i < 16; i++)
+    for (int i = 0; i < PCT_TIMING_SLOTS; i++)
       if (i != 7) o[i] += acc[i];
     o[7] += (unsigned long long)n_steps;
   }
@@ -362,7 +411,11 @@ struct PhaseTimer<true> {
 enum { PH_LOAD = 0, PH_DROP = 1, PH_GENEMS = 2, PH_SET = 3, PH_FEAS = 4, PH_OBS = 5, PH_STORE = 6, PH_STEPS = 7,
        // detail of PH_SET (they sum to it): tuple generation + membership probes, batch de-duplication,
        // matching passes, table rebuilds
-       PH_SET_GEN = 8, PH_SET_DEDUP = 9, PH_SET_MATCH = 10, PH_SET_REBUILD = 11 };
+       PH_SET_GEN = 8, PH_SET_DEDUP = 9, PH_SET_MATCH = 10, PH_SET_REBUILD = 11,
+       // plain per-step statistics (not cycles)
+       ST_EMS = 12, ST_DISTINCT = 13, ST_GENERATED = 14, ST_MATCH_CALLS = 16, ST_MATCH_ROUNDS = 17, ST_MATCH_PROBES = 18,
+       ST_CONTAINS_CALLS = 19, ST_CONTAINS_PROBES = 20, ST_FLUSHES = 21, PH_FAST_START = 22, ST_REBUILDS = 23,
+       PH_SET_HASH = 24, PH_GEN_TUPLE = 25, PH_GEN_HASH = 26, PH_GEN_CONTAINS = 27, PH_GEN_PEND = 28, PH_GEN_PAIRS = 29 };
 
 
 }  // namespace pct

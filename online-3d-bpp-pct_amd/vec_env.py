@@ -375,7 +375,7 @@ class PctVecEnv(VecEnv):
     def phase_timing(self, on=True):
         """Start/stop per-phase cycle accounting; returns the uint64 [N,16] gathered so far
         (columns: load, drop, genems, set, feas, obs, store, steps, set-gen, set-dedup, set-match, set-rebuild)."""
-        out = np.zeros((self.N, 16), np.uint64)
+        out = np.zeros((self.N, 32), np.uint64)  # PCT_TIMING_SLOTS
         _lib.check(self._L.pct_debug_phase_timing(self._h, int(bool(on)), out.ctypes.data))
         return out
 

@@ -1,0 +1,60 @@
+"""GPU: per-STEP cycle distribution of the transition kernel (timed build, read back after every launch):
+how the slowest env of a launch -- which sets the launch time -- differs from the mean, and how the cycles
+scale with the EMS count, the generated tuples and the distinct candidates.
+python scripts/step_profile.py [envs] [steps] [c2|c3]"""
+import importlib, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("online-3d-bpp-pct_amd")
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+MODE = sys.argv[3] if len(sys.argv) > 3 else "c2"
+items = [(i, j, k) for i in range(1, 6) for j in range(1, 6) for k in range(1, 6)]
+if MODE == "c3":
+    env = pkg.PctVecEnv(N, continuous=True, sample_left_bound=1.0, sample_right_bound=5.0, seed=4, device="cuda:0", monitor=False)
+else:
+    env = pkg.PctVecEnv(N, item_set=items, seed=4, device="cuda:0", monitor=False)
+env.reset()
+rows = torch.empty(N, 9, dtype=torch.float32, device="cuda:0")
+for _ in range(200):
+    env.policy_hash_rows(rows); env.step_rows_device(rows)
+torch.cuda.synchronize()
+env.phase_timing(True)
+rec = np.zeros((K, N, 32))
+for s in range(K):
+    env.policy_hash_rows(rows); env.step_rows_device(rows)
+    rec[s] = env.phase_timing(True)
+env.phase_timing(False)
+names = ["load", "drop", "genems", "set", "feas", "obs", "store"]
+tot = rec[:, :, :7].sum(2)  # [K,N]
+print("%s: %d envs x %d steps, cycles per step (2.39 GHz shader clock)" % (MODE, N, K))
+print("  per-step total: mean %.0f  p50 %.0f  p90 %.0f  p99 %.0f  p99.9 %.0f  max %.0f" % (
+    tot.mean(), *np.percentile(tot, [50, 90, 99, 99.9]), tot.max()))
+mx = tot.max(1)
+print("  per-launch max over envs: mean %.0f (= %.1f us)  min %.0f  max %.0f ; ratio to mean step %.2f" % (
+    mx.mean(), mx.mean() / 2390, mx.min(), mx.max(), mx.mean() / tot.mean()))
+am = tot.argmax(1)
+worst = rec[np.arange(K), am]  # [K,16]
+print("  slowest env of each launch, mean phase cycles:")
+for i, n in enumerate(names):
+    print("    %-7s %8.0f   (all-env mean %8.0f)" % (n, worst[:, i].mean(), rec[:, :, i].mean()))
+for i, n in {8: "set.gen", 9: "set.dedup", 10: "set.match", 11: "set.rebuild"}.items():
+    print("      %-11s %8.0f   (all-env mean %8.0f)" % (n, worst[:, i].mean(), rec[:, :, i].mean()))
+print("    EMS %.1f (mean %.1f)  distinct %.1f (mean %.1f)  generated %.1f (mean %.1f)" % (
+    worst[:, 12].mean(), rec[:, :, 12].mean(), worst[:, 13].mean(), rec[:, :, 13].mean(), worst[:, 14].mean(), rec[:, :, 14].mean()))
+extra = {16: "match calls", 17: "match outer rounds", 18: "match longest-walk sum", 19: "contains calls (tuple chunks)",
+         20: "contains longest-walk sum", 21: "flushes", 22: "fast-start scalar replay cycles", 23: "rebuilds", 24: "flush hash cycles", 25: "gen: tuple build cycles", 26: "gen: hash cycles", 27: "gen: contains cycles", 28: "gen: pend/ballot cycles", 29: "gen: pair filter cycles"}
+for i, n in extra.items():
+    print("    %-34s %9.1f   (all-env mean %9.1f)" % (n, worst[:, i].mean(), rec[:, :, i].mean()))
+# least squares: total ~ a + b*E + c*generated + d*distinct
+X = np.stack([np.ones(K * N), rec[:, :, 12].ravel(), rec[:, :, 14].ravel(), rec[:, :, 13].ravel()], 1)
+coef, *_ = np.linalg.lstsq(X, tot.ravel(), rcond=None)
+print("  fit total ~ %.0f + %.1f*EMS + %.2f*generated + %.1f*distinct" % tuple(coef))
+d = rec[:, :, 13].ravel()
+t = tot.ravel()
+for lo, hi in [(0, 5), (5, 19), (19, 77), (77, 150), (150, 307), (307, 2000)]:
+    m = (d >= lo) & (d < hi)
+    if m.any():
+        print("  distinct in [%d,%d): %5.1f%% of steps, mean total %.0f, set %.0f" % (
+            lo, hi, 100 * m.mean(), t[m].mean(), rec[:, :, 3].ravel()[m].mean()))

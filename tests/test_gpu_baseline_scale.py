@@ -1,0 +1,120 @@
+"""GPU: the HIP path against the CPU oracle AT THE BASELINE.json SIZES, with the DEFAULT capacities
+(no ems_capacity / candidate_capacity overrides), on the on-device counter sampler and the fused
+stand-in policy:
+
+  C2  PctDiscrete0   setting 2, 10^3,  80/50,   4096 envs x 200 steps
+  C3  PctContinuous0 setting 2, 10^3,  80/50,   4096 envs x 120 steps
+  C5  PctContinuous0 setting 2, 100^3, 200/200, 256 envs x 300 steps, items U(5,25)
+  C1  PctDiscrete0   setting 1 (stability), 10^3, 80/50, 2048 envs x 120 steps
+
+Observations are compared every `every` steps (all envs, bit-exact), reward / done / counter every
+step.  Also here: the 6-vector action form of evaluation_tools.py:24 (bin3D.py:152-153) on the GPU.
+"""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.common import gather_rows, hash_policy_index, item_set_range, load_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _pkg():
+    return importlib.import_module("online-3d-bpp-pct_amd")
+
+
+def _threads():
+    return max(1, min(os.cpu_count() or 1, 64))
+
+
+def _run(env, ora, steps, every):
+    obs = env.reset()
+    ora.reset()
+    episodes = 0
+    for t in range(steps):
+        if t % every == 0:
+            o, ref = obs.cpu().numpy(), ora.obs.astype(np.float32)
+            assert np.array_equal(o, ref), (t, np.argwhere((o != ref).any(1))[:8].ravel())
+        env.step_hash_policy(1)
+        ora.step_hash_policy(1)
+        obs, reward, done, infos = env.step_wait()
+        assert np.array_equal(done.astype(np.uint8), ora.done), t
+        assert np.array_equal(reward[:, 0].numpy(), ora.reward.astype(np.float32)), t
+        assert np.array_equal(env._h_counter.numpy(), ora.counter), t
+        episodes += int(done.sum())
+    assert np.array_equal(obs.cpu().numpy(), ora.obs.astype(np.float32))
+    assert not env.error_flags.any(), np.unique(env.error_flags)
+    assert not ora.flags.any()
+    return episodes
+
+
+def test_c2_full_size_vs_oracle():
+    from oracle.oracle_lib import OracleVecEnv
+    N, items = 4096, item_set_range(1, 5)
+    env = _pkg().PctVecEnv(N, setting=2, container_size=(10, 10, 10), item_set=items, seed=4, device="cuda:0")
+    ora = OracleVecEnv(N, setting=2, container_size=(10, 10, 10), item_set=items, threads=_threads())
+    ora.set_sampler(4)
+    assert _run(env, ora, 200, 10) > 20000
+    env.close()
+
+
+def test_c3_full_size_vs_oracle():
+    from oracle.oracle_lib import OracleVecEnv
+    N = 4096
+    env = _pkg().PctVecEnv(N, setting=2, container_size=(10, 10, 10), continuous=True, sample_left_bound=1.0,
+                           sample_right_bound=5.0, seed=4, device="cuda:0")
+    ora = OracleVecEnv(N, setting=2, container_size=(10, 10, 10), env_kind=1, sample_bounds=(1.0, 5.0), threads=_threads())
+    ora.set_sampler(4)
+    assert _run(env, ora, 120, 10) > 10000
+    env.close()
+
+
+def test_c5_default_capacities_vs_oracle():
+    """100^3 bin, 200/200 nodes, U(5,25): ~140 boxes per episode, EMS lists of several hundred entries --
+    must run with the handle's own defaults (no capacity overrides) and raise no overflow flag."""
+    from oracle.oracle_lib import OracleVecEnv
+    N = 256
+    kw = dict(setting=2, container_size=(100, 100, 100), internal_node_holder=200, leaf_node_holder=200)
+    env = _pkg().PctVecEnv(N, continuous=True, sample_left_bound=5.0, sample_right_bound=25.0, seed=4, device="cuda:0", **kw)
+    ora = OracleVecEnv(N, env_kind=1, sample_bounds=(5.0, 25.0), threads=_threads(), **kw)
+    ora.set_sampler(4)
+    assert _run(env, ora, 300, 15) > 200
+    env.close()
+
+
+def test_c1_setting1_batched_vs_oracle():
+    from oracle.oracle_lib import OracleVecEnv
+    N, items = 2048, item_set_range(1, 5)
+    env = _pkg().PctVecEnv(N, setting=1, container_size=(10, 10, 10), item_set=items, seed=4, device="cuda:0")
+    ora = OracleVecEnv(N, setting=1, container_size=(10, 10, 10), item_set=items, threads=_threads())
+    ora.set_sampler(4)
+    assert _run(env, ora, 120, 10) > 5000
+    env.close()
+
+
+@pytest.mark.parametrize("name", ["discrete_s2_10_80_50", "discrete_s1_10_80_50", "continuous_s2_10_80_50"])
+def test_rows6_action_form_matches_reference_fixture(name):
+    """evaluation_tools.py:24 hands the env `selected_leaf_node[0:6]`; bin3D.py:152-153 takes any
+    len != 3 action through LeafNode2Action.  Same trajectory as the 9-vector form."""
+    c, z = load_case(name)
+    cont = name.startswith("continuous")
+    kw = dict(setting=c["setting"], container_size=c["container"], internal_node_holder=c["I"], leaf_node_holder=c["L"],
+              env_id_base=c["base"], item_stream=z["stream"], device="cuda:0")
+    if cont:
+        env = _pkg().PctVecEnv(c["N"], continuous=True, sample_left_bound=c["lo"], sample_right_bound=c["hi"], **kw)
+    else:
+        env = _pkg().PctVecEnv(c["N"], item_set=item_set_range(c["lo"], c["hi"]), **kw)
+    obs = env.reset()
+    for t in range(c["steps"]):
+        o = obs.cpu().numpy()
+        assert np.array_equal(o, z["obs"][t].astype(np.float32)), (name, t)
+        idx = hash_policy_index(o, c["I"], c["L"], c["base"], np.full(c["N"], t, np.uint64))
+        rows6 = np.ascontiguousarray(gather_rows(o, c["I"], idx)[:, :6])
+        obs, reward, done, infos = env.step(rows6)
+        assert np.array_equal(reward[:, 0].numpy(), z["reward"][t].astype(np.float32)), (name, t)
+        assert np.array_equal(done.astype(np.uint8), z["done"][t]), (name, t)
+    assert not env.error_flags.any()
+    env.close()
