@@ -1,26 +1,39 @@
 #!/usr/bin/env python
 """bench.py -- env-steps/sec of the batched PCT env hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload c2|c4|c3|c5|c1|c3s1]
     (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is ONE batched transition of the BASELINE.json configs[1] workload on every GPU:
-PctDiscrete0 setting 2 (EMS leaves), bin 10x10x10, 80 internal / 50 leaf nodes, 4096 envs
-per GPU, items drawn uniformly from (1..5)^3 by the on-device counter-based sampler.  Per
-step the stand-in policy kernel reads the leaf mask from the observation and writes one
-float32 leaf row per env ([N,9], what train_tools.py:66-67 hands the env), then
-pct_step_rows runs the transition kernel, which regenerates the full [131,9] float32
-observation, reward, done and info for every env (auto-reset included).  Everything stays
-in HBM; the host only enqueues.  Envs shard across GPUs by global env id with no collective
-on the step path ("scaling": "weak", per-GPU work fixed).
+A "step" is ONE batched transition of the workload on every GPU.  The default workload (c2) is
+BASELINE.json configs[1], the configuration the headline metric is quoted on: PctDiscrete0 setting 2
+(EMS leaves), bin 10x10x10, 80 internal / 50 leaf nodes, 4096 envs per GPU, items drawn uniformly from
+(1..5)^3 by the on-device counter-based sampler.  Per step the stand-in policy kernel reads the leaf mask
+from the observation and writes one float32 leaf row per env ([N,9], what train_tools.py:66-67 hands the
+env), then pct_step_rows runs the transition kernel, which regenerates the [I+L+1,9] float32
+observation, reward, done and info for every env (auto-reset included).  Everything stays in HBM; the
+host only enqueues.  Envs shard across GPUs by global env id with no collective on the step path
+("scaling": "weak", per-GPU work fixed).
+
+Other workloads (parity-test configurations of BASELINE.json, measurable with the same contract):
+  c4    the per-GPU slice of configs[3]: c2 with 8192 envs per GPU
+  c3    configs[2]: PctContinuous0 setting 2, 10^3, 80/50, 4096 envs per GPU (float64 kernel)
+  c5    configs[4]: PctContinuous0 setting 2, 100^3, 200/200, items U(5,25), 2048 envs per GPU
+  c1    configs[0]'s geometry on the GPU: PctDiscrete0 setting 1 (stability check), 10^3, 4096 envs
+  c3s1  PctContinuous0 setting 1 (stability) in the unit bin, items 2 x U(0.1,0.5) + z in {0.1..0.5}
 
 Printed JSON (one line, rank 0): the driver contract plus
-  roofline     -- the transition kernel against the HBM roof: algorithmic bytes per launch
-                  (4757 B per env-step x envs per launch) / its average
-                  duration measured with HIP events recorded by the library on the launch
-                  stream during the timed region;
-  cpu_baseline -- the CPU oracle (C restatement of the reference env, oracle/) timed on
-                  this box's host cores on a bounded sample of the same workload.
+  roofline        the transition kernel against the HBM roof: algorithmic bytes per launch
+                  (B(I,L) = 36 (I+L+1) + 41 per env-step x envs per launch) / its average
+                  duration measured with HIP events recorded by the library on the launch stream during
+                  the timed region; `traffic` = HBM bytes per launch from rocprofv3 PMC passes of the same
+                  command (a separate profiled run; `traffic_source` names the committed file);
+  roofline_issue  the same kernel against the instruction-issue rate of the chip (VALU + SALU wave
+                  instructions per launch from the committed PMC pass / the measured duration);
+  cpu_baseline    the CPU oracle (C restatement of the reference env, oracle/) timed on this box's host
+                  cores on a bounded sample of the same workload;
+  cpu_baseline_reference  the REFERENCE's own Python path (envs.make_vec_envs -> ShmemVecEnv(fork)),
+                  timed in the build container by scripts/time_reference_cpu.py (the reference tree does
+                  not travel to the GPU box) -- carried from profiles/cpu_reference_baseline.json.
 """
 import argparse
 import importlib
@@ -33,39 +46,109 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-I_NODES, L_NODES = 80, 50
-ALG_BYTES_PER_STEP = 4 * 9 * (I_NODES + L_NODES + 1) + 36 + 4 + 1  # 4757, SURVEY.md 8(d)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+# issue roof: 256 CUs x 2.4 GHz x (4 SIMD-32s x one wave64 VALU instruction per 2 cycles + one SALU
+# instruction per cycle on the CU's scalar unit) wave-instructions per second (MI355X_MICROARCH.md:
+# "v_fma_f32 (wave64) 2 cyc (SIMD-32)"; the scalar rate is the usual one-per-cycle-per-CU assumption)
+ISSUE_PEAK_GINST = 256 * 2.4 * (4 * 0.5 + 1.0)
 
 
 def item_set():
     return [(i, j, k) for i in range(1, 6) for j in range(1, 6) for k in range(1, 6)]
 
 
-def cpu_baseline(envs, budget_s, workload="c2"):
-    """The oracle on the host cores: same workload, bounded sample."""
+WORKLOADS = {
+    # name: (env kind, setting, container, I, L, envs/GPU, sample bounds, description, reference-baseline key)
+    "c2": dict(cont=False, setting=2, container=(10, 10, 10), I=80, L=50, envs=4096, bounds=None, ref="discrete_s2_shmem",
+               metric="env-steps/sec (whole node), discrete setting 2, 80 internal/50 leaf",
+               what="PctDiscrete0 setting 2 (EMS leaves), bin 10x10x10, 80 internal / 50 leaf, %d batched envs per MI355X "
+                    "(BASELINE.json configs[1]); items ~ U{(1..5)^3} from the on-device counter sampler"),
+    "c4": dict(cont=False, setting=2, container=(10, 10, 10), I=80, L=50, envs=8192, bounds=None, ref="discrete_s2_shmem",
+               metric="env-steps/sec (whole node), discrete setting 2, 80 internal/50 leaf, 8192 envs per GPU",
+               what="PctDiscrete0 setting 2, bin 10x10x10, 80/50, %d batched envs per MI355X (the per-GPU slice of "
+                    "BASELINE.json configs[3]: 65 536 envs over 8 GPUs)"),
+    "c3": dict(cont=True, setting=2, container=(10, 10, 10), I=80, L=50, envs=4096, bounds=(1.0, 5.0), ref="continuous_s2_shmem",
+               metric="env-steps/sec (whole node), continuous setting 2, 80 internal/50 leaf",
+               what="PctContinuous0 setting 2, bin 10x10x10, 80 internal / 50 leaf, %d batched envs per MI355X "
+                    "(BASELINE.json configs[2]); item sizes round(U(1,5),3) from the on-device counter sampler; float64 kernel"),
+    "c5": dict(cont=True, setting=2, container=(100, 100, 100), I=200, L=200, envs=2048, bounds=(5.0, 25.0), ref=None,
+               metric="env-steps/sec (whole node), continuous setting 2, 100^3 bin, 200 internal/200 leaf",
+               what="PctContinuous0 setting 2, bin 100^3, 200 internal / 200 leaf, %d batched envs per MI355X (the per-GPU "
+                    "slice of BASELINE.json configs[4]); item sizes round(U(5,25),3) (SURVEY.md 8(d))"),
+    "c1": dict(cont=False, setting=1, container=(10, 10, 10), I=80, L=50, envs=4096, bounds=None, ref="discrete_s1_dummy_1env",
+               metric="env-steps/sec (whole node), discrete setting 1 (stability check), 80 internal/50 leaf",
+               what="PctDiscrete0 setting 1 (stability check, two orientations), bin 10x10x10, 80/50, %d batched envs per "
+                    "MI355X (the geometry of BASELINE.json configs[0], batched on the GPU)"),
+    "c3s1": dict(cont=True, setting=1, container=(1, 1, 1), I=80, L=50, envs=4096, bounds=(0.1, 0.5), ref=None,
+                 metric="env-steps/sec (whole node), continuous setting 1 (stability check), unit bin, 80 internal/50 leaf",
+                 what="PctContinuous0 setting 1 (stability check), unit bin, 80/50, %d batched envs per MI355X; items "
+                      "2 x round(U(0.1,0.5),3) + z in {0.1..0.5} (C/bin3D.py:110-112)"),
+}
+
+
+def alg_bytes(w):
+    return 4 * 9 * (w["I"] + w["L"] + 1) + 36 + 4 + 1  # 4757 at 80/50, 14477 at 200/200
+
+
+def make_oracle(w, envs, threads):
     from oracle.oracle_lib import OracleVecEnv
+    kw = dict(setting=w["setting"], container_size=w["container"], internal_node_holder=w["I"], leaf_node_holder=w["L"],
+              threads=threads)
+    if w["cont"]:
+        return OracleVecEnv(envs, env_kind=1, sample_bounds=w["bounds"], **kw)
+    return OracleVecEnv(envs, item_set=item_set(), **kw)
+
+
+def cpu_baseline(w, budget_s):
+    """The oracle on the host cores: same workload (config, sampler, stand-in policy), bounded sample."""
     threads = max(1, min(os.cpu_count() or 1, 64))
-    if workload == "c3":
-        env = OracleVecEnv(envs, setting=2, container_size=(10, 10, 10), env_kind=1, sample_bounds=(1.0, 5.0),
-                           internal_node_holder=I_NODES, leaf_node_holder=L_NODES, threads=threads)
-    else:
-        env = OracleVecEnv(envs, setting=2, container_size=(10, 10, 10), item_set=item_set(),
-                           internal_node_holder=I_NODES, leaf_node_holder=L_NODES, threads=threads)
+    envs = 256 if w["I"] <= 80 else 64
+    env = make_oracle(w, envs, threads)
     env.set_sampler(4)
     env.reset()
     env.step_hash_policy(50)  # de-synchronise the episodes
     t0 = time.perf_counter()
     steps = 0
-    chunk = 20
+    chunk = 20 if w["I"] <= 80 else 4
     while time.perf_counter() - t0 < budget_s:
         env.step_hash_policy(chunk)
         steps += chunk
     dt = time.perf_counter() - t0
     env.close()
     return {"value": envs * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
-            "sample": "oracle/pct_oracle.c (C restatement of the reference env, OpenMP over envs), %d envs x %d "
-                      "batched steps after 50 warm-up steps, same config/sampler/policy, %.1f s" % (envs, steps, dt)}
+            "sample": "oracle/ (C restatement of the reference env, OpenMP over envs), %d envs x %d batched steps after 50 "
+                      "warm-up steps, same config / sampler / stand-in policy, %.1f s" % (envs, steps, dt)}
+
+
+def reference_baseline(w):
+    """The reference's own Python VecEnv path, timed in the build container (see scripts/time_reference_cpu.py)."""
+    path = os.path.join(ROOT, "profiles", "cpu_reference_baseline.json")
+    if w["ref"] is None or not os.path.exists(path):
+        return None
+    try:
+        z = json.load(open(path))
+        c = z["configs"][w["ref"]]
+    except Exception:
+        return None
+    return {"value": c["value"], "unit": "env-steps/s", "cores": c["workers"], "kind": "reference",
+            "measured_on": "build container (%d host cores; /root/reference does not travel to the GPU box), not in this run"
+                           % z["host"]["cores"],
+            "path": c["path"], "sample": "%d iterations over %.0f s; %s" % (c["iterations"], c["seconds"], z["recipe"]),
+            "source": "profiles/cpu_reference_baseline.json"}
+
+
+def pmc_profile(name, envs):
+    """Counter values per launch from the committed rocprofv3 PMC passes of this workload, or None."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_%s.json" % name)
+    if not os.path.exists(path):
+        return None, None
+    try:
+        z = json.load(open(path))
+        if int(z.get("envs_per_launch", -1)) != envs:
+            return None, None
+        return z, "profiles/r02_pmc_%s.json" % name
+    except Exception:
+        return None, None
 
 
 def main():
@@ -73,7 +156,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--envs-per-gpu", type=int, default=4096)
+    ap.add_argument("--envs-per-gpu", type=int, default=0, help="default: the workload's own size (4096 for c2)")
     ap.add_argument("--mode", choices=["rows", "fused", "host"], default="rows",
                     help="rows: policy kernel + pct_step_rows per step (default); fused: pct_step_hash_policy(1); "
                          "host: the reference trainer's hand-over -- leaf rows to the host as numpy "
@@ -81,13 +164,12 @@ def main():
                          "(PCIe and a stream sync inside the timed region; never the headline value)")
     ap.add_argument("--pipelines", type=int, default=1,
                     help="split each GPU's envs into this many independently stepped groups, one HIP stream each "
-                         "(1 = one batch per step, the headline configuration; 2 overlaps one group's tail with "
-                         "the other group's kernels)")
-    ap.add_argument("--workload", choices=["c2", "c3", "c5"], default="c2",
-                    help="c2: BASELINE configs[1] (discrete, the headline metric); c3: configs[2] (continuous setting 2)")
+                         "(1 = one batch per step, the headline configuration)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    w = WORKLOADS[args.workload]
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -107,32 +189,21 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     pkg = importlib.import_module("online-3d-bpp-pct_amd")
-    n_local = args.envs_per_gpu
+    n_local = args.envs_per_gpu or w["envs"]
     P = max(1, args.pipelines)
     assert n_local % P == 0, "--envs-per-gpu must be a multiple of --pipelines"
     n_grp = n_local // P
+    B = alg_bytes(w)
 
     def make_env(g):
         base = rank * n_local + g * n_grp
-        if args.workload == "c5":  # BASELINE.json configs[4]: 100^3, 200/200, items U(5,25)
-            return pkg.PctVecEnv(n_grp, setting=2, container_size=(100, 100, 100), continuous=True, sample_left_bound=5.0,
-                                 sample_right_bound=25.0, internal_node_holder=I_NODES, leaf_node_holder=L_NODES, seed=4,
-                                 env_id_base=base, device=dev, monitor=False, ems_capacity=768,
-                                 candidate_capacity=32768)
-        if args.workload == "c3":
-            return pkg.PctVecEnv(n_grp, setting=2, container_size=(10, 10, 10), continuous=True, sample_left_bound=1.0,
-                                 sample_right_bound=5.0, internal_node_holder=I_NODES, leaf_node_holder=L_NODES, seed=4,
-                                 env_id_base=base, device=dev, monitor=False)
-        return pkg.PctVecEnv(n_grp, setting=2, container_size=(10, 10, 10), item_set=item_set(),
-                             internal_node_holder=I_NODES, leaf_node_holder=L_NODES, seed=4,
-                             env_id_base=base, device=dev, monitor=False)
+        kw = dict(setting=w["setting"], container_size=w["container"], internal_node_holder=w["I"], leaf_node_holder=w["L"],
+                  seed=4, env_id_base=base, device=dev, monitor=False)
+        if w["cont"]:
+            return pkg.PctVecEnv(n_grp, continuous=True, sample_left_bound=w["bounds"][0], sample_right_bound=w["bounds"][1], **kw)
+        return pkg.PctVecEnv(n_grp, item_set=item_set(), **kw)
 
-    if args.workload == "c5":
-        global I_NODES, L_NODES, ALG_BYTES_PER_STEP
-        I_NODES, L_NODES = 200, 200
-        ALG_BYTES_PER_STEP = 4 * 9 * (I_NODES + L_NODES + 1) + 36 + 4 + 1
     envs = [make_env(g) for g in range(P)]
-    env = envs[0]
     streams = [torch.cuda.current_stream(dev)] if P == 1 else [torch.cuda.Stream(dev) for _ in range(P)]
     rows = [torch.empty(n_grp, 9, dtype=torch.float32, device=dev) for _ in range(P)]
     for ev in envs:
@@ -179,30 +250,28 @@ def main():
         flags = ev.error_flags
         assert not flags.any(), "env error flags raised during the bench: %s" % flags[flags != 0][:8]
 
+    kern_avg_ms = kern_ms / max(n_launch, 1)
+    per_rank_us = [kern_avg_ms * 1e3]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        k = torch.tensor([kern_ms / max(n_launch, 1)], dtype=torch.float64, device=dev)
-        dist.all_reduce(k, op=dist.ReduceOp.MAX)
-        kern_avg_ms = float(k.item())
-    else:
-        kern_avg_ms = kern_ms / max(n_launch, 1)
+        mine = torch.tensor([kern_avg_ms * 1e3], dtype=torch.float64, device=dev)
+        allk = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allk, mine)
+        per_rank_us = [float(x.item()) for x in allk]
+        kern_avg_ms = max(per_rank_us) / 1e3  # the slowest rank's kernel bounds the job
 
     total_steps = world * n_local * args.steps
     value = total_steps / elapsed
-    achieved_gbs = ALG_BYTES_PER_STEP * n_grp / (kern_avg_ms * 1e-3) / 1e9  # per launch (n_grp envs)
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc) and args.workload == "c2" and n_grp == 4096:
-        try:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    achieved_gbs = B * n_grp / (kern_avg_ms * 1e-3) / 1e9  # per launch (n_grp envs)
+    pmc, pmc_src = pmc_profile(args.workload, n_grp)
+    traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
+    kernel_name = ("pct_continuous_kernel<" if w["cont"] else "pct_discrete_kernel<u32,5,") + \
+                  ("ACT_HASH" if args.mode == "fused" else "ACT_ROWS") + (",stability>" if w["setting"] != 2 else ">")
 
     out = {
-        "metric": "env-steps/sec (whole node), discrete setting 2, 80 internal/50 leaf" if args.workload == "c2"
-                  else "env-steps/sec (whole node), continuous setting 2, 80 internal/50 leaf",
+        "metric": w["metric"],
         "value": value,
         "unit": "env-steps/s",
         "n_gpus": world,
@@ -212,16 +281,12 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "i32" if args.workload == "c2" else "f64",
+        "dtype": "f64" if w["cont"] else ("i32+f64" if w["setting"] != 2 else "i32"),
         "data": "synthetic",
         "config": {
-            "workload": ("PctDiscrete0 setting 2 (EMS leaves), bin 10x10x10, 80 internal / 50 leaf, %d batched envs per "
-                         "MI355X (BASELINE.json configs[1]); items ~ U{(1..5)^3} from the on-device counter sampler; "
-                         "per step: policy kernel -> float32 [N,9] leaf rows -> transition kernel (observation rows "
-                         "rewritten, auto-reset)" % n_local) if args.workload == "c2" else
-                        ("PctContinuous0 setting 2, bin 10x10x10, 80 internal / 50 leaf, %d batched envs per MI355X "
-                         "(BASELINE.json configs[2]); item sizes round(U(1,5),3) from the on-device counter sampler; "
-                         "per step: policy kernel -> float32 [N,9] leaf rows -> float64 transition kernel" % n_local),
+            "workload": (w["what"] % n_local) + "; per step: policy kernel -> float32 [N,9] leaf rows -> transition kernel "
+                        "(observation rows rewritten, auto-reset)",
+            "name": args.workload,
             "envs_per_gpu": n_local,
             "global_envs": world * n_local,
             "mode": args.mode,
@@ -235,22 +300,29 @@ def main():
             "unit": "GB/s",
             "frac": achieved_gbs / HBM_PEAK_GBS,
             "traffic": traffic,
-            "kernel": ("pct_discrete_kernel<u32,5," if args.workload == "c2" else "pct_continuous_kernel<") +
-                      ("ACT_HASH>" if args.mode == "fused" else "ACT_ROWS>"),
+            "traffic_source": (pmc_src + " (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of this command in a "
+                               "separate profiled run; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes)") if traffic else None,
+            "kernel": kernel_name,
             "kernel_avg_us": kern_avg_ms * 1e3,
+            "kernel_avg_us_per_rank": per_rank_us,
             "launches_timed": n_launch,
-            "alg_bytes_per_env_step": ALG_BYTES_PER_STEP,
+            "alg_bytes_per_env_step": B,
+            "envs_per_launch": n_grp,
         },
     }
-    if args.workload == "c5":
-        out["metric"] = "env-steps/sec (whole node), continuous setting 2, 100^3 bin, 200 internal/200 leaf"
-        out["config"]["workload"] = ("PctContinuous0 setting 2, bin 100^3, 200 internal / 200 leaf, %d batched envs per MI355X "
-                                     "(BASELINE.json configs[4]); item sizes round(U(5,25),3)" % n_local)
-        args.no_cpu_baseline = True
+    if pmc and pmc.get("valu_salu_insts_per_launch"):
+        ginst = pmc["valu_salu_insts_per_launch"] / (kern_avg_ms * 1e-3) / 1e9
+        out["roofline_issue"] = {"bound": "issue", "achieved": ginst, "peak": ISSUE_PEAK_GINST, "unit": "G wave-instructions/s",
+                                 "frac": ginst / ISSUE_PEAK_GINST, "insts_per_launch": pmc["valu_salu_insts_per_launch"],
+                                 "insts_source": pmc_src + " (SQ_INSTS_VALU + SQ_INSTS_SALU, separate profiled run)",
+                                 "peak_model": "256 CUs x 2.4 GHz x (4 SIMD-32 x 1 wave64 VALU / 2 cycles + 1 SALU / cycle)"}
+    else:
+        out["roofline_issue"] = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(256, args.cpu_seconds, args.workload)
+        out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)
     elif rank == 0:
         out["cpu_baseline"] = None
+    out["cpu_baseline_reference"] = reference_baseline(w)
     if rank == 0:
         print(json.dumps(out))
     for ev in envs:

@@ -141,7 +141,9 @@ int pct_set_item_set(pct_env* env, const int32_t* item_set, int32_t n);
  * (1e-3; the reference's integer bin sizes are multiples of 1000) and items are 3-decimal
  * sizes (C/bin3D.py:106-108).  Sampler bounds in lattice units (tools.py:178-181);
  * low_bound = left (C/bin3D.py:25-27).  The c-th draw of global env g is
- * left + pct_pick(seed, g, 3c+d, right-left+1) for d = 0,1,2.  A float32 action row is
+ * left + pct_pick(seed, g, 3c+d, right-left+1) for d = 0,1,2; under settings 1 and 3 the third size is
+ * 100 * (1 + pct_pick(seed, g, 3c+2, 5)) instead -- np.random.choice([0.1,...,0.5]), C/bin3D.py:110-112.
+ * A float32 action row is
  * matched back to the env's current leaf whose float32 cast it is and decoded from that
  * leaf's float64 values, i.e. exactly like the reference decodes the float64 row
  * (round(.,6), C/bin3D.py:153-173); a row matching no leaf is decoded from the widened

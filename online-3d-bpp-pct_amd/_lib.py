@@ -12,7 +12,7 @@ import os
 import torch  # noqa: F401  (must precede the dlopen, see above)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpct_hip.so")
+LIB_PATH = os.environ.get("PCT_HIP_LIB") or os.path.join(HERE, "libpct_hip.so")  # PCT_HIP_LIB: kernel experiments only
 
 PCT_OK = 0
 ENV_DISCRETE, ENV_CONTINUOUS = 0, 1

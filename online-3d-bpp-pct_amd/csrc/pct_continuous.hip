@@ -141,6 +141,8 @@ __device__ inline void cdraw_item(const ContinuousParams& p, int e, CRegs& r) {
     r.ik0 = p.sample_left + (int)(pct_pick(p.seed, g, c * 3 + 0, (uint32_t)span));
     r.ik1 = p.sample_left + (int)(pct_pick(p.seed, g, c * 3 + 1, (uint32_t)span));
     r.ik2 = p.sample_left + (int)(pct_pick(p.seed, g, c * 3 + 2, (uint32_t)span));
+    // C/bin3D.py:110-112: settings 1 and 3 take z from np.random.choice([0.1, 0.2, 0.3, 0.4, 0.5])
+    if (p.setting != 2) r.ik2 = 100 * (1 + (int)pct_pick(p.seed, g, c * 3 + 2, 5u));
   }
   // round(U(a,b), 3) (C/bin3D.py:106-108): the double nearest to k/1000
   r.b0 = (double)r.ik0 / 1000.0; r.b1 = (double)r.ik1 / 1000.0; r.b2 = (double)r.ik2 / 1000.0;

@@ -32,6 +32,15 @@
 #include "pct_set.cuh"
 #include "pct_stab.cuh"
 
+#ifndef PCT_SET_V
+#define PCT_SET_V 1   /* tuples per lane and insertion batch of the EMS expansion (measured on MI355X: 1 is fastest -- a lone
+                         wave is bound by its instruction issue, not by dependence latency, so wider batches only add
+                         predicated-off work; 2 and 4 are kept for experiments) */
+#endif
+#ifndef PCT_SET_RV
+#define PCT_SET_RV 1  /* old slots per lane and matching pass of a table rebuild (32-bit keys) */
+#endif
+
 namespace pct {
 
 // ----------------------------------------------------------------------------------------
@@ -77,8 +86,7 @@ struct Lds {
   K* tab0;     // candidate hash table(s): table_words_compact(cand_cap) key words
   K* ems_a;    // [ems_cap] current EMS list
   K* ems_b;    // GENEMS scratch list: aliases the table region (idle during GENEMS)
-  K* pend;     // [128] keys waiting for insertion
-  uint32_t* dd;  // [64] bucket words of the batch de-duplication
+  uint32_t* dd;  // [128] bucket words of the batch de-duplication
   K* box;
   K* leaf;
   HT* hmap;
@@ -94,7 +102,7 @@ __host__ __device__ inline int discrete_scheme_words(const DiscreteParams& p) {
   return 0;
 }
 __host__ __device__ inline int discrete_scratch_words(const DiscreteParams& p) {
-  return 128 + (int)(64 * sizeof(uint32_t) / p.key_bytes);  // pend[128] + dd[64 x u32]
+  return (int)(128 * sizeof(uint32_t) / p.key_bytes);  // dd[128 x u32], in key words
 }
 
 template <typename K, int BITS>
@@ -104,8 +112,7 @@ __device__ inline Lds<K, BITS> carve_lds(const DiscreteParams& p, unsigned char*
   l.tab0 = q; q += table_words_compact((uint32_t)p.cand_cap);
   l.ems_a = q; q += p.ems_cap;
   l.ems_b = l.tab0;
-  l.pend = q;
-  l.dd = reinterpret_cast<uint32_t*>(q + 128);
+  l.dd = reinterpret_cast<uint32_t*>(q);
   q += discrete_scratch_words(p);
   l.box = q; q += p.I;
   l.leaf = q; q += p.L;
@@ -345,6 +352,239 @@ __device__ inline void genems(const DiscreteParams& p, Lds<K, BITS>& l, EnvRegs&
   __syncthreads();
 }
 
+// The candidate set under construction: a CPython `set` whose table lives in LDS (l.tab0).
+template <typename K>
+struct SetState {
+  K* tabs;         // the table region
+  uint32_t* dd;    // [128] bucket words of the batch de-duplication, all ones between uses
+  uint32_t cap;    // candidate_capacity (largest table)
+  uint32_t toff, size, fill;
+  bool overflow;
+};
+
+// set.add of up to V*64 tuples, V per lane, in batch-position order (position of (v, lane) = v*64 + lane):
+// membership test against the table, exact in-batch de-duplication, then insertion exactly as CPython
+// would do it one key at a time -- growth when fill*5 >= mask*3 right after an insertion, re-insertion
+// in old-slot order (Objects/setobject.c set_add_entry / set_table_resize / set_insert_clean).
+// A table rebuild re-inserts RV*64 old slots per matching pass.
+template <typename K, int BITS, int V, typename TM>
+__device__ inline void set_insert(SetState<K>& st, const K (&key)[V], const bool (&valid)[V], int lane, TM& tm,
+                                  int* mst) {
+  const K EMPTY = SlotWord<K>::EMPTY;
+  K* const tabs = st.tabs;
+  uint32_t* const dd = st.dd;
+  bool pending[V];
+  uint64_t hash0 = 0;  // slice 0's hashes, for the fast start
+  {
+    uint64_t hash[V];
+#pragma unroll
+    for (int v = 0; v < V; v++) hash[v] = tuplehash6<K, BITS>(key[v]);
+    hash0 = hash[0];
+    bool found[V];
+    int cprobes = 0;
+    pyset_contains_v<V, K>(tabs + st.toff, st.size - 1, hash, key, valid, found, TM::on ? &cprobes : nullptr);
+    if (TM::on) { tm.add(ST_CONTAINS_CALLS, 1); tm.add(ST_CONTAINS_PROBES, (uint64_t)cprobes); }
+#pragma unroll
+    for (int v = 0; v < V; v++) pending[v] = valid[v] && !found[v];
+    tm.sub_tick(PH_SET_GEN);
+    if (!__ballot(any_of<V>(pending))) return;
+    tm.add(ST_FLUSHES, 1);
+    // set.add of a key that an earlier position of the batch holds is a no-op
+    bool dup[V];
+    batch_find_duplicates_v<V, 128, K>(dd, pending, key, hash, lane, dup);
+#pragma unroll
+    for (int v = 0; v < V; v++) pending[v] = pending[v] && !dup[v];
+  }
+  tm.sub_tick(PH_SET_DEDUP);
+  if (sizeof(K) == 4 && st.fill == 0 && st.size == 8 && st.cap >= 128) {
+    const uint64_t pm0 = __ballot(pending[0]);
+    if (__popcll(pm0) >= 19) {
+      // Fast start of a fresh set whose first 19 new keys sit in slice 0 (every key of this batch is new to
+      // the empty table and to the rest of the batch).  CPython puts the first 5 into the 8-slot table, grows
+      // it to 32 slots (re-inserting in slot order), adds keys 6..19 and grows again to 128.  The two small
+      // tables are replayed on the scalar unit -- a table is a VGPR whose lane s holds the source lane of the
+      // key in slot s, occupancy is a scalar bit mask, hashes come over v_readlane -- and only their outcome
+      // is materialised: the 128-slot table receives, in ONE pass, the 19 keys in 32-table slot order
+      // followed by the rest of slice 0 (at most 64 keys, below the 128-slot table's growth point of 77).
+      uint64_t rem = pm0;
+      int t8 = 0xFF, t32 = 0xFF;  // per lane: source lane of the key in that slot
+      uint32_t occ8 = 0, occ32 = 0;
+      const uint64_t h0 = hash0;
+      auto lane_hash = [&](int src) -> uint64_t {
+        uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)h0, src);
+        uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(h0 >> 32), src);
+        return ((uint64_t)hi << 32) | lo;
+      };
+      for (int o = 0; o < 5; o++) {  // mask 7: no linear probes (i + 9 > mask)
+        const int src = __ffsll((unsigned long long)rem) - 1;
+        rem &= rem - 1;
+        const uint64_t h = lane_hash(src);
+        uint32_t i = (uint32_t)h & 7u;
+        uint64_t perturb = h;
+        while ((occ8 >> i) & 1u) {
+          perturb >>= 5;
+          i = (i * 5u + 1u + (uint32_t)perturb) & 7u;
+        }
+        occ8 |= 1u << i;
+        t8 = lane == (int)i ? src : t8;
+      }
+      auto insert32 = [&](int src) {  // set_insert_clean / set_add_entry on the 32-slot table
+        const uint64_t h = lane_hash(src);
+        uint32_t i = (uint32_t)h & 31u;
+        uint64_t perturb = h;
+        while (true) {
+          const uint32_t span = (i + 9u <= 31u) ? 10u : 1u;  // slot i, plus 9 linear probes if they fit
+          const uint32_t w = (~occ32 >> i) & ((1u << span) - 1u);
+          if (w) {
+            i += (uint32_t)__ffs((int)w) - 1u;
+            break;
+          }
+          perturb >>= 5;
+          i = (i * 5u + 1u + (uint32_t)perturb) & 31u;
+        }
+        occ32 |= 1u << i;
+        t32 = lane == (int)i ? src : t32;
+      };
+      for (uint32_t m8 = occ8; m8; m8 &= m8 - 1u) insert32(__builtin_amdgcn_readlane(t8, __ffs((int)m8) - 1));
+      for (int o = 5; o < 19; o++) {
+        const int src = __ffsll((unsigned long long)rem) - 1;
+        rem &= rem - 1;
+        insert32(src);
+      }
+      // insertion order into the 128-slot table: 32-table slot order, then the rest of slice 0
+      K* fin = reinterpret_cast<K*>(dd);
+      const K from_slot = shfl_key<K>(key[0], t32 & 63);
+      const bool in32 = lane < 32 && ((occ32 >> lane) & 1u);
+      const bool later = (rem >> lane) & 1ull;
+      if (in32) fin[rank_below((uint64_t)occ32)] = from_slot;
+      if (later) fin[19 + rank_below(rem)] = key[0];
+      const int total = 19 + __popcll(rem);
+      tabs[lane] = EMPTY;
+      tabs[64 + lane] = EMPTY;
+      __syncthreads();
+      const K mk = lane < total ? fin[lane] : (K)0;
+      __syncthreads();
+      dd[lane] = 0xFFFFFFFFu;  // back to the all-ones state the de-duplication expects
+      if (sizeof(K) == 8) dd[64 + lane] = 0xFFFFFFFFu;
+      if (TM::on) tm.sub_tick(PH_FAST_START);
+      const bool mpart[1] = {lane < total};
+      const uint64_t mhash[1] = {tuplehash6<K, BITS>(mk)};
+      uint32_t mslot[1];
+      pyset_match_v<1, K>(tabs, 127u, mpart, mhash, lane, mslot, mst);
+      if (mpart[0]) tabs[mslot[0]] = mk;
+      st.toff = 0;  // table_offset_compact(cap, 128) for every cap >= 128
+      st.size = 128;
+      st.fill = (uint32_t)total;
+      pending[0] = false;
+      __syncthreads();
+      tm.sub_tick(PH_SET_MATCH);
+    }
+  }
+  while (true) {
+    uint64_t pm[V];
+    int total = 0;
+#pragma unroll
+    for (int v = 0; v < V; v++) {
+      pm[v] = __ballot(pending[v]);
+      total += __popcll(pm[v]);
+    }
+    // set_add_entry grows the table when fill*5 >= mask*3, checked right after each insertion: at most
+    // thr - fill more keys go into this table -- the first thr - fill pending positions
+    const uint32_t mask = st.size - 1;
+    const uint32_t thr = (mask * 3u + 4u) / 5u;
+    if (st.fill < thr) {
+      if (!total) break;
+      const int budget = (int)(thr - st.fill);
+      bool part[V];
+      int before = 0, npart = 0;
+#pragma unroll
+      for (int v = 0; v < V; v++) {
+        part[v] = pending[v] && before + rank_below(pm[v]) < budget;
+        before += __popcll(pm[v]);
+      }
+      npart = total < budget ? total : budget;
+      uint32_t slot[V];
+      uint64_t hash[V];  // recomputed here rather than kept live across a table rebuild
+#pragma unroll
+      for (int v = 0; v < V; v++) hash[v] = tuplehash6<K, BITS>(key[v]);
+      pyset_match_v<V, K>(tabs + st.toff, mask, part, hash, lane, slot, mst);
+#pragma unroll
+      for (int v = 0; v < V; v++) {
+        if (part[v]) tabs[st.toff + slot[v]] = key[v];
+        pending[v] = pending[v] && !part[v];
+      }
+      st.fill += (uint32_t)npart;
+      __syncthreads();
+      tm.sub_tick(PH_SET_MATCH);
+    }
+    if (st.fill >= thr) {  // set_table_resize(used * 4): re-insert in old-slot order
+      uint32_t newsize = 8;
+      while (newsize <= st.fill * 4u) newsize <<= 1;
+      if (newsize > st.cap) {
+        st.overflow = true;
+        break;
+      }
+      const uint32_t noff = table_offset_compact(st.cap, newsize);
+      tm.add(ST_REBUILDS, 1);
+      constexpr int RV = sizeof(K) == 4 ? PCT_SET_RV : 4;  // old slots re-inserted per lane and pass
+      if (noff == st.toff) {
+        // same region: lift the old table (<= 512 slots = 8 per lane) into registers, wipe, re-insert
+        K oldk[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+          const uint32_t s2 = (uint32_t)c * 64u + lane;
+          oldk[c] = (s2 < st.size) ? tabs[st.toff + s2] : EMPTY;
+        }
+        __syncthreads();
+        for (uint32_t s2 = lane; s2 < newsize; s2 += 64) tabs[noff + s2] = EMPTY;
+        __syncthreads();
+#pragma unroll
+        for (int c0 = 0; c0 < 8; c0 += RV) {
+          if ((uint32_t)c0 * 64u < st.size) {
+            bool opart[RV];
+            uint64_t ohash[RV];
+            uint32_t oslot[RV];
+#pragma unroll
+            for (int c = 0; c < RV; c++) {
+              opart[c] = oldk[c0 + c] != EMPTY;
+              ohash[c] = tuplehash6<K, BITS>(oldk[c0 + c]);
+            }
+            pyset_match_v<RV, K>(tabs + noff, newsize - 1, opart, ohash, lane, oslot, mst);
+#pragma unroll
+            for (int c = 0; c < RV; c++)
+              if (opart[c]) tabs[noff + oslot[c]] = oldk[c0 + c];
+            __syncthreads();
+          }
+        }
+      } else {
+        for (uint32_t s2 = lane; s2 < newsize; s2 += 64) tabs[noff + s2] = EMPTY;
+        __syncthreads();
+        for (uint32_t sb = 0; sb < st.size; sb += 64u * RV) {
+          K ok[RV];
+          bool opart[RV];
+          uint64_t ohash[RV];
+          uint32_t oslot[RV];
+#pragma unroll
+          for (int c = 0; c < RV; c++) {
+            const uint32_t s2 = sb + (uint32_t)c * 64u + lane;
+            ok[c] = (s2 < st.size) ? tabs[st.toff + s2] : EMPTY;
+            opart[c] = ok[c] != EMPTY;
+            ohash[c] = tuplehash6<K, BITS>(ok[c]);
+          }
+          pyset_match_v<RV, K>(tabs + noff, newsize - 1, opart, ohash, lane, oslot, mst);
+#pragma unroll
+          for (int c = 0; c < RV; c++)
+            if (opart[c]) tabs[noff + oslot[c]] = ok[c];
+          __syncthreads();
+        }
+      }
+      st.toff = noff;
+      st.size = newsize;
+      tm.sub_tick(PH_SET_REBUILD);
+    }
+  }
+}
+
 // D/space.py:534-570 EMSPoint (CPython-set order) + D/bin3D.py:100-136
 // get_possible_position: fills l.leaf[0..n_leaf) with the first <= L feasible candidates.
 template <typename K, int BITS, bool STAB, int SCHEME, bool SHUFFLE, typename TM>
@@ -357,17 +597,19 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
 
   // fresh set: PySet_MINSIZE = 8 slots
   const K EMPTY = SlotWord<K>::EMPTY;
-  uint32_t size = 8, fill = 0;
-  K* const tabs = l.tab0;  // both table regions, contiguous
-  uint32_t toff = table_offset_compact((uint32_t)p.cand_cap, size);
-  // ems_b is free outside GENEMS: the queue of keys waiting for insertion + the batch keys
-  K* const pend = l.pend;
-  uint32_t* const dd = l.dd;
-  if (lane < 8) tabs[toff + lane] = EMPTY;
-  dd[lane] = 0xFFFFFFFFu;
+  K* const tabs = l.tab0;
+  SetState<K> st;
+  st.tabs = l.tab0;
+  st.dd = l.dd;
+  st.cap = (uint32_t)p.cand_cap;
+  st.size = 8;
+  st.fill = 0;
+  st.toff = table_offset_compact((uint32_t)p.cand_cap, 8u);
+  st.overflow = false;
+  if (lane < 8) tabs[st.toff + lane] = EMPTY;
+  l.dd[lane] = 0xFFFFFFFFu;
+  l.dd[64 + lane] = 0xFFFFFFFFu;
   __syncthreads();
-  bool cand_overflow = false;
-  int npend = 0;
   int mstat[3] = {0, 0, 0};  // timed build only: match calls, outer rounds, sum over calls of the longest walk
   int* const mst = TM::on ? mstat : nullptr;
   tm.sub_start();
@@ -384,179 +626,6 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
     }
   };
 
-  // insert the first `cnt` (<= 64) queued keys, in queue order, exactly as set.add would
-  auto flush = [&](int cnt) {
-    bool pending = lane < cnt;
-    K key = pending ? pend[lane] : (K)0;
-    K mv = (lane + 64 < npend) ? pend[lane + 64] : (K)0;
-    __syncthreads();
-    if (lane + 64 < npend) pend[lane] = mv;
-    npend -= cnt;
-    __syncthreads();
-    tm.sub_tick(PH_SET_GEN);
-    tm.add(ST_FLUSHES, 1);
-    // exact in-batch de-duplication: keep the first occurrence (set.add of a present key is a
-    // no-op, and the first occurrence is inserted before the later ones in any case)
-    if (TM::on) asm volatile("" : "+v"(key));
-    uint64_t hash = tuplehash6<K, BITS>(key);
-    if (TM::on) { asm volatile("" : "+v"(hash)); tm.sub_tick(PH_SET_HASH); }
-    pending = pending && !batch_find_duplicates_reg<64, K>(dd, pending, key, hash, lane);
-    tm.sub_tick(PH_SET_DEDUP);
-    if (sizeof(K) == 4 && fill == 0 && size == 8 && p.cand_cap >= 128) {
-      const uint64_t pm0 = __ballot(pending);
-      if (__popcll(pm0) >= 19) {
-        // Fast start of a fresh set with >= 19 new keys (every key of this batch is new to the empty
-        // table and to the rest of the batch).  CPython puts the first 5 into the 8-slot table, grows
-        // it to 32 slots (re-inserting in slot order), adds keys 6..19 and grows again to 128.  The
-        // two small tables are replayed on the scalar unit -- a table is a VGPR whose lane s holds
-        // the source lane of the key in slot s, occupancy is a scalar bit mask, hashes come over
-        // v_readlane -- and only their outcome is materialised: the 128-slot table receives, in ONE
-        // pass, the 19 keys in 32-table slot order followed by the rest of the batch.
-        uint64_t rem = pm0;
-        int t8 = 0xFF, t32 = 0xFF;  // per lane: source lane of the key in that slot
-        uint32_t occ8 = 0, occ32 = 0;
-        auto lane_hash = [&](int src) -> uint64_t {
-          uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)hash, src);
-          uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(hash >> 32), src);
-          return ((uint64_t)hi << 32) | lo;
-        };
-        for (int o = 0; o < 5; o++) {  // mask 7: no linear probes (i + 9 > mask)
-          const int src = __ffsll((unsigned long long)rem) - 1;
-          rem &= rem - 1;
-          const uint64_t h = lane_hash(src);
-          uint32_t i = (uint32_t)h & 7u;
-          uint64_t perturb = h;
-          while ((occ8 >> i) & 1u) {
-            perturb >>= 5;
-            i = (i * 5u + 1u + (uint32_t)perturb) & 7u;
-          }
-          occ8 |= 1u << i;
-          t8 = lane == (int)i ? src : t8;
-        }
-        auto insert32 = [&](int src) {  // set_insert_clean / set_add_entry on the 32-slot table
-          const uint64_t h = lane_hash(src);
-          uint32_t i = (uint32_t)h & 31u;
-          uint64_t perturb = h;
-          while (true) {
-            const uint32_t span = (i + 9u <= 31u) ? 10u : 1u;  // slot i, plus 9 linear probes if they fit
-            const uint32_t w = (~occ32 >> i) & ((1u << span) - 1u);
-            if (w) {
-              i += (uint32_t)__ffs((int)w) - 1u;
-              break;
-            }
-            perturb >>= 5;
-            i = (i * 5u + 1u + (uint32_t)perturb) & 31u;
-          }
-          occ32 |= 1u << i;
-          t32 = lane == (int)i ? src : t32;
-        };
-        for (uint32_t m8 = occ8; m8; m8 &= m8 - 1u) insert32(__builtin_amdgcn_readlane(t8, __ffs((int)m8) - 1));
-        for (int o = 5; o < 19; o++) {
-          const int src = __ffsll((unsigned long long)rem) - 1;
-          rem &= rem - 1;
-          insert32(src);
-        }
-        // insertion order into the 128-slot table: 32-table slot order, then the rest of the batch
-        K* fin = reinterpret_cast<K*>(dd);
-        const K from_slot = shfl_key<K>(key, t32 & 63);
-        const bool in32 = lane < 32 && ((occ32 >> lane) & 1u);
-        const bool later = (rem >> lane) & 1ull;
-        if (in32) fin[rank_below((uint64_t)occ32)] = from_slot;
-        if (later) fin[19 + rank_below(rem)] = key;
-        const int total = 19 + __popcll(rem);
-        tabs[lane] = EMPTY;
-        tabs[64 + lane] = EMPTY;
-        __syncthreads();
-        const K mk = lane < total ? fin[lane] : (K)0;
-        __syncthreads();
-        dd[lane] = 0xFFFFFFFFu;  // back to the all-ones state the de-duplication expects
-        bool mplaced;
-        uint32_t mslot;
-        if (TM::on) tm.sub_tick(PH_FAST_START);
-        pyset_match<K>(tabs, 127u, lane < total, tuplehash6<K, BITS>(mk), lane, false, mplaced, mslot, [&](K) { return false; }, mst);
-        if (mplaced) tabs[mslot] = mk;
-        toff = 0;  // table_offset_compact(cap, 128) for every cap >= 128 that is not 128 itself; see below
-        size = 128;
-        fill = (uint32_t)total;
-        pending = false;
-        __syncthreads();
-        tm.sub_tick(PH_SET_MATCH);
-      }
-    }
-    while (true) {
-      uint64_t pm = __ballot(pending);
-      // set_add_entry grows the table when fill*5 >= mask*3, checked right after each
-      // insertion: at most thr - fill more keys go into this table
-      uint32_t mask = size - 1;
-      uint32_t thr = (mask * 3u + 4u) / 5u;
-      if (fill < thr) {
-        if (!pm) break;
-        bool part = pending && (uint32_t)rank_below(pm) < thr - fill;
-        bool placed;
-        uint32_t slot;
-        pyset_match<K>(tabs + toff, mask, part, hash, lane, true, placed, slot, [&](K w) { return w == key; }, mst);
-        if (placed) tabs[toff + slot] = key;
-        pending = pending && !part;
-        fill += (uint32_t)__popcll(__ballot(placed));
-        __syncthreads();
-        tm.sub_tick(PH_SET_MATCH);
-      }
-      if (fill >= thr) {  // set_table_resize(used * 4): re-insert in old-slot order
-        uint32_t newsize = 8;
-        while (newsize <= fill * 4u) newsize <<= 1;
-        if (newsize > (uint32_t)p.cand_cap) {
-          cand_overflow = true;
-          break;
-        }
-        const uint32_t noff = table_offset_compact((uint32_t)p.cand_cap, newsize);
-        tm.add(ST_REBUILDS, 1);
-        if (noff == toff) {
-          // same region: lift the old table (<= 512 slots = 8 per lane) into registers, wipe, and
-          // re-insert chunk by chunk in old-slot order
-          K oldk[8];
-#pragma unroll
-          for (int c = 0; c < 8; c++) {
-            uint32_t s2 = (uint32_t)c * 64u + lane;
-            oldk[c] = (s2 < size) ? tabs[toff + s2] : EMPTY;
-          }
-          __syncthreads();
-          for (uint32_t s2 = lane; s2 < newsize; s2 += 64) tabs[noff + s2] = EMPTY;
-          __syncthreads();
-#pragma unroll
-          for (int c = 0; c < 8; c++) {
-            if ((uint32_t)c * 64u < size) {
-              K ok = oldk[c];
-              bool opart = ok != EMPTY;
-              bool oplaced;
-              uint32_t oslot;
-              pyset_match<K>(tabs + noff, newsize - 1, opart, tuplehash6<K, BITS>(ok), lane, false, oplaced, oslot,
-                             [&](K) { return false; }, mst);
-              if (oplaced) tabs[noff + oslot] = ok;
-              __syncthreads();
-            }
-          }
-        } else {
-          for (uint32_t s2 = lane; s2 < newsize; s2 += 64) tabs[noff + s2] = EMPTY;
-          __syncthreads();
-          for (uint32_t sb = 0; sb < size; sb += 64) {
-            uint32_t s2 = sb + lane;
-            K ok = (s2 < size) ? tabs[toff + s2] : EMPTY;
-            bool opart = ok != EMPTY;
-            bool oplaced;
-            uint32_t oslot;
-            pyset_match<K>(tabs + noff, newsize - 1, opart, tuplehash6<K, BITS>(ok), lane, false, oplaced, oslot,
-                           [&](K) { return false; });
-            if (oplaced) tabs[noff + oslot] = ok;
-            __syncthreads();
-          }
-        }
-        toff = noff;
-        size = newsize;
-        tm.sub_tick(PH_SET_REBUILD);
-      }
-    }
-  };
-
   // SCHEME 1 = every expansion other than EMS, selected at run time (coverage paths)
   const bool FC = SCHEME == 1 && p.lnes == PCT_LNES_FC;
   const bool EV = SCHEME == 1 && p.lnes == PCT_LNES_EV;
@@ -566,7 +635,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
   if (FC) {
     // D/space.py:573-610 FullCoord: rotation-major, then lx, then ly; lz = the cell's own height
     const int NQ = orient * p.W * p.Ly;
-    for (int base = 0; base < NQ && !cand_overflow; base += 64) {
+    for (int base = 0; base < NQ && !st.overflow; base += 64) {
       int q = base + lane;
       bool valid = q < NQ;
       int rot = q / (p.W * p.Ly);
@@ -576,14 +645,10 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
       bool skip = rot_size(rot, sx, sy, sz);
       int pz = valid ? (int)l.hmap[px * p.A + py] : 0;
       valid = valid && !skip && (px + sx <= p.W) && (py + sy <= p.Ly) && (pz + sz <= p.H);
-      K key = P::pack(px, py, pz, px + sx, py + sy, pz + sz);
-      uint64_t hash = tuplehash6<K, BITS>(key);
-      bool fresh = valid && !pyset_contains<K>(tabs + toff, size - 1, hash, valid, [&](K w) { return w == key; });
-      uint64_t nm = __ballot(fresh);
-      if (fresh) pend[npend + rank_below(nm)] = key;
-      npend += __popcll(nm);
+      const K key1[1] = {P::pack(px, py, pz, px + sx, py + sy, pz + sz)};
+      const bool valid1[1] = {valid};
+      set_insert<K, BITS, 1>(st, key1, valid1, lane, tm, mst);
       __syncthreads();
-      if (npend >= 64) flush(64);
     }
   } else if (EV) {
     // D/space.py:613-693 EventPoint.  bin3D.py:171 runs GENEMS only under LNES == 'EMS', so under
@@ -662,8 +727,8 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
       int t[6];
       ev_tuple((int)id, t);
       __syncthreads();
-      size = 64;
-      toff = 0;
+      st.size = 64;
+      st.toff = 0;
       tabs[lane] = lane < n_ev ? P::pack(t[0], t[1], t[2], t[3], t[4], t[5]) : EMPTY;
       __syncthreads();
     }
@@ -672,8 +737,8 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
     // (unrotated, x/y swapped; no set, no in-bin test): slots 0 and 1 of the fresh 8-slot table hold
     // them in list order, duplicates included
     if (lane == 0) {
-      tabs[toff + 0] = P::pack(0, 0, 0, b0, b1, b2);
-      tabs[toff + 1] = P::pack(0, 0, 0, b1, b0, b2);
+      tabs[st.toff + 0] = P::pack(0, 0, 0, b0, b1, b2);
+      tabs[st.toff + 1] = P::pack(0, 0, 0, b1, b0, b2);
     }
     __syncthreads();
   } else if (CP) {
@@ -860,7 +925,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
     if (ci_overflow) r.flags |= PCT_FLAG_EMS_OVERFLOW;
     // candidates: corner x rotation, in-bin test (D/space.py:776-803), into the set
     const int NQ = nCI * orient;
-    for (int base = 0; base < NQ && !cand_overflow; base += 64) {
+    for (int base = 0; base < NQ && !st.overflow; base += 64) {
       int q = base + lane;
       bool valid = q < NQ;
       int ci = q / orient, rot = q - ci * orient;
@@ -869,14 +934,10 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
       uint32_t cv = valid ? CI[ci] : 0u;
       int px = (int)(cv & 0x3FFu), py = (int)((cv >> 10) & 0x3FFu), pz = (int)(cv >> 20);
       valid = valid && !skip && (px + sx <= p.W) && (py + sy <= p.Ly) && (pz + sz <= p.H);
-      K key = P::pack(px, py, pz, px + sx, py + sy, pz + sz);
-      uint64_t hash = tuplehash6<K, BITS>(key);
-      bool fresh = valid && !pyset_contains<K>(tabs + toff, size - 1, hash, valid, [&](K w) { return w == key; });
-      uint64_t nm = __ballot(fresh);
-      if (fresh) pend[npend + rank_below(nm)] = key;
-      npend += __popcll(nm);
+      const K key1[1] = {P::pack(px, py, pz, px + sx, py + sy, pz + sz)};
+      const bool valid1[1] = {valid};
+      set_insert<K, BITS, 1>(st, key1, valid1, lane, tm, mst);
       __syncthreads();
-      if (npend >= 64) flush(64);
     }
   } else {
     // rotations worth generating: not skipped by the reference's rule, and not a repeat of an
@@ -887,7 +948,8 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
     const bool g1 = !e01, g2 = !e12, g3 = !(e01 && e12) && !(g1 && e02) && !(g2 && e01);
     const bool g4 = !e02 && !(g1 && e12), g5 = !e12 && !e02 && !(g4 && e01);
     const uint32_t rotmask = 1u | (g1 ? 2u : 0u) | (g2 ? 4u : 0u) | (g3 ? 8u : 0u) | (g4 ? 16u : 0u) | (g5 ? 32u : 0u);
-    for (int pbase = 0; pbase < NP && !cand_overflow; pbase += 64) {
+    constexpr int V = PCT_SET_V;  // a chunk of 64 (EMS, rotation) pairs = up to 256 tuples = 4 / V batches, V tuples per lane
+    for (int pbase = 0; pbase < NP && !st.overflow; pbase += 64) {
       // which (EMS, rotation) pairs of this chunk can hold the item at all
       const uint64_t tpair = tm.now();
       int q = pbase + lane;
@@ -900,43 +962,37 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
            (P::get(ek, 5) - P::get(ek, 2) >= sz);
       uint64_t pm = __ballot(pv);
       const int nt = 4 * __popcll(pm);  // four bottom-corner placements per pair (:565-568)
+      if (!nt) continue;
       if (pv) l.vp[rank_below(pm)] = (uint16_t)q;
       tm.add(ST_GENERATED, (uint64_t)nt);
       __syncthreads();
-      uint64_t tq = tm.now();
-      if (TM::on) tm.add(PH_GEN_PAIRS, tq - tpair);
-      for (int tb = 0; tb < nt && !cand_overflow; tb += 64) {
-        int tt = tb + lane;
-        bool valid = tt < nt;
-        int qq = valid ? (int)l.vp[tt >> 2] : 0;
-        int corner = tt & 3;
-        int e2 = qq / orient;
-        rot_size(qq - e2 * orient, sx, sy, sz);
-        K k2 = l.ems_a[e2];
-        int x0 = P::get(k2, 0), y0 = P::get(k2, 1), z0 = P::get(k2, 2), x1 = P::get(k2, 3), y1 = P::get(k2, 4);
-        int xs = (corner & 1) ? x1 - sx : x0;
-        int ys = (corner & 2) ? y1 - sy : y0;
-        K key = P::pack(xs, ys, z0, xs + sx, ys + sy, z0 + sz);
-        if (TM::on) { asm volatile("" : "+v"(key)); uint64_t t = tm.now(); tm.add(PH_GEN_TUPLE, t - tq); tq = t; }
-        uint64_t hash = tuplehash6<K, BITS>(key);
-        if (TM::on) { asm volatile("" : "+v"(hash)); uint64_t t = tm.now(); tm.add(PH_GEN_HASH, t - tq); tq = t; }
-        int cprobes = 0;
-        bool fresh = valid && !pyset_contains<K>(tabs + toff, size - 1, hash, valid, [&](K w) { return w == key; }, TM::on ? &cprobes : nullptr);
-        if (TM::on) { int fr = fresh; asm volatile("" : "+v"(fr)); fresh = fr != 0; uint64_t t = tm.now(); tm.add(PH_GEN_CONTAINS, t - tq); tq = t; }
-        if (TM::on) { tm.add(ST_CONTAINS_CALLS, 1); tm.add(ST_CONTAINS_PROBES, (uint64_t)wave_max_i32(cprobes)); }
-        uint64_t nm = __ballot(fresh);
-        if (fresh) pend[npend + rank_below(nm)] = key;
-        npend += __popcll(nm);
-        __syncthreads();
-        if (TM::on) { uint64_t t = tm.now(); tm.add(PH_GEN_PEND, t - tq); tq = t; }
-        if (npend >= 64) flush(64);
-        if (TM::on) tq = tm.now();
+      if (TM::on) tm.add(PH_GEN_PAIRS, tm.now() - tpair);
+      for (int tb = 0; tb < nt && !st.overflow; tb += 64 * V) {
+      K key[V];
+      bool valid[V];
+#pragma unroll
+      for (int v = 0; v < V; v++) {
+        const int tt = tb + v * 64 + lane;  // batch position = generation order
+        valid[v] = tt < nt;
+        const int qq = valid[v] ? (int)l.vp[tt >> 2] : 0;
+        const int corner = tt & 3;
+        const int e2 = qq / orient;
+        int tx, ty, tz;
+        rot_size(qq - e2 * orient, tx, ty, tz);
+        const K k2 = l.ems_a[e2];
+        const int x0 = P::get(k2, 0), y0 = P::get(k2, 1), z0 = P::get(k2, 2), x1 = P::get(k2, 3), y1 = P::get(k2, 4);
+        const int xs = (corner & 1) ? x1 - tx : x0;
+        const int ys = (corner & 2) ? y1 - ty : y0;
+        key[v] = P::pack(xs, ys, z0, xs + tx, ys + ty, z0 + tz);
+      }
+      set_insert<K, BITS, V>(st, key, valid, lane, tm, mst);
       }
       __syncthreads();
     }
   }
-  while (npend > 0 && !cand_overflow) flush(npend < 64 ? npend : 64);
-  if (cand_overflow) r.flags |= PCT_FLAG_CANDIDATE_OVERFLOW;
+  if (st.overflow) r.flags |= PCT_FLAG_CANDIDATE_OVERFLOW;
+  uint32_t size = st.size;
+  const uint32_t toff = st.toff, fill = st.fill;
   __syncthreads();
   tm.add(ST_EMS, (uint64_t)E);
   tm.add(ST_DISTINCT, (uint64_t)fill);

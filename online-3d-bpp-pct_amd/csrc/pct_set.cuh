@@ -344,6 +344,169 @@ __device__ inline bool batch_find_duplicates_reg(uint32_t* dd, bool active, K ke
   return dup;
 }
 
+// ----------------------------------------------------------------------------------------
+// V keys per lane ("virtual lanes").  One wave alone on its SIMD waits ~7 cycles for a dependent VALU
+// result and ~100 for an LDS round trip; the probe loops are chains of exactly such dependences, so a
+// lane that carries V independent keys through the same loop gets V times the work done per iteration
+// at little more than the latency of one.  Batch position of (v, lane) is v * 64 + lane: slice 0 comes
+// first in insertion order, then slice 1, ...  LDS tables only (integer keys compared by value).
+// ----------------------------------------------------------------------------------------
+template <int V>
+__device__ inline bool any_of(const bool (&b)[V]) {
+  bool a = false;
+#pragma unroll
+  for (int v = 0; v < V; v++) a = a || b[v];
+  return a;
+}
+
+// Read-only membership test of V keys per lane (no tags may be present): found[v] for active[v] keys.
+template <int V, typename K>
+__device__ inline void pyset_contains_v(const K* tab, uint32_t mask, const uint64_t (&hash)[V], const K (&key)[V],
+                                        const bool (&valid)[V], bool (&found)[V], int* probes = nullptr) {
+  uint32_t i[V];
+  int j[V];
+  uint64_t perturb[V];
+  bool active[V];
+#pragma unroll
+  for (int v = 0; v < V; v++) {
+    i[v] = (uint32_t)hash[v] & mask;
+    j[v] = 0;
+    perturb[v] = hash[v];
+    active[v] = valid[v];
+    found[v] = false;
+  }
+  while (__ballot(any_of<V>(active))) {
+    K cur[V];
+#pragma unroll
+    for (int v = 0; v < V; v++) {
+      cur[v] = SlotWord<K>::EMPTY;
+      if (active[v]) cur[v] = tab[i[v] + (uint32_t)j[v]];
+    }
+    if (probes) (*probes)++;
+#pragma unroll
+    for (int v = 0; v < V; v++) {
+      const bool eq = active[v] && cur[v] == key[v];
+      found[v] = found[v] || eq;
+      active[v] = active[v] && cur[v] != SlotWord<K>::EMPTY && !eq;
+      walk_advance(i[v], j[v], perturb[v], mask);
+    }
+  }
+}
+
+// Matches the participating keys (pairwise distinct, none of them in the table yet) into the table in
+// batch-position order, exactly as sequential set.add calls would place them.  On return every
+// participating (v, lane) holds TAG | (v*64 + lane) in tab[slot[v]]; the caller overwrites the tags
+// with the keys.  All 64 lanes must call.
+template <int V, typename K>
+__device__ inline void pyset_match_v(K* tab, uint32_t mask, const bool (&part)[V], const uint64_t (&hash)[V], int lane,
+                                     uint32_t (&slot)[V], int* stats = nullptr) {
+  const K TAG = SlotWord<K>::TAG;
+  uint32_t i[V];
+  int j[V];
+  uint64_t perturb[V];
+  bool walking[V], placed[V];
+#define PCT_MYTAG(v) (TAG | (K)((v) * 64 + lane))
+#pragma unroll
+  for (int v = 0; v < V; v++) {
+    i[v] = (uint32_t)hash[v] & mask;
+    j[v] = 0;
+    perturb[v] = hash[v];
+    walking[v] = part[v];
+    placed[v] = false;
+    slot[v] = 0;
+  }
+  int my_probes = 0;
+  while (true) {
+    if (stats) stats[1]++;
+    while (__ballot(any_of<V>(walking))) {
+      K old[V];
+      uint32_t cur[V];
+#pragma unroll
+      for (int v = 0; v < V; v++) {  // V atomics in flight: a real key or an earlier position's tag is
+        cur[v] = i[v] + (uint32_t)j[v];  // numerically smaller and stays, so the atomic doubles as the read
+        old[v] = 0;
+        if (walking[v]) old[v] = lds_atomic_min(&tab[cur[v]], PCT_MYTAG(v));
+      }
+      my_probes++;
+#pragma unroll
+      for (int v = 0; v < V; v++) {
+        const bool won = walking[v] && old[v] > PCT_MYTAG(v);  // was empty, or tentatively held by a later position
+        slot[v] = won ? cur[v] : slot[v];
+        placed[v] = placed[v] || won;
+        if (walking[v]) walk_advance(i[v], j[v], perturb[v], mask);  // past the slot just tried: an evicted key resumes here
+        walking[v] = walking[v] && !won;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < V; v++) {
+      if (placed[v] && tab[slot[v]] != PCT_MYTAG(v)) {  // evicted by an earlier position: walk on
+        placed[v] = false;
+        walking[v] = true;
+      }
+    }
+    if (!__ballot(any_of<V>(walking))) break;
+  }
+  if (stats) { stats[0]++; stats[2] += wave_max_i32(my_probes); }
+#undef PCT_MYTAG
+}
+
+// Exact removal of duplicates inside a batch of V*64 keys held V per lane: dup[v] for a key that also sits
+// at an EARLIER active batch position.  Same bucket scatter as batch_find_duplicates_reg (the minimum
+// position of a bucket is the first holder of every key hashing there; others compare with it: equal ->
+// duplicate, different -> both stay for the next round, which uses other hash bits); the key of a position
+// comes over a cross-lane shuffle of the slice it lives in.  `dd` = NB words of LDS, all ones.
+template <int V, int NB, typename K>
+__device__ inline void batch_find_duplicates_v(uint32_t* dd, const bool (&active)[V], const K (&key)[V],
+                                               const uint64_t (&hash)[V], int lane, bool (&dup)[V]) {
+  bool unresolved[V];
+#pragma unroll
+  for (int v = 0; v < V; v++) {
+    unresolved[v] = active[v];
+    dup[v] = false;
+  }
+  for (int round = 0; round < 8; round++) {
+    if (!__ballot(any_of<V>(unresolved))) return;
+    uint32_t b[V], w[V];
+#pragma unroll
+    for (int v = 0; v < V; v++) {
+      b[v] = (uint32_t)(hash[v] >> (3 + 7 * round)) & (uint32_t)(NB - 1);
+      if (unresolved[v]) atomicMin(&dd[b[v]], (uint32_t)(v * 64 + lane));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < V; v++) w[v] = unresolved[v] ? dd[b[v]] : (uint32_t)(v * 64 + lane);
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < V; v++) {
+      K kw = shfl_key<K>(key[0], (int)(w[v] & 63u));
+#pragma unroll
+      for (int u = 1; u < V; u++) {
+        const K ku = shfl_key<K>(key[u], (int)(w[v] & 63u));
+        kw = ((w[v] >> 6) == (uint32_t)u) ? ku : kw;
+      }
+      if (unresolved[v]) {
+        dd[b[v]] = 0xFFFFFFFFu;
+        if (w[v] == (uint32_t)(v * 64 + lane)) unresolved[v] = false;
+        else if (kw == key[v]) { dup[v] = true; unresolved[v] = false; }
+      }
+    }
+    __syncthreads();
+  }
+  // eight rounds of pure collisions between distinct keys: exhaustive scan over the earlier positions
+#pragma unroll
+  for (int u = 0; u < V; u++) {
+    const uint64_t au = __ballot(active[u]);
+    for (int i = 0; i < 64; i++) {
+      const K ki = shfl_key<K>(key[u], i);
+      const bool ai = (au >> i) & 1ull;
+#pragma unroll
+      for (int v = 0; v < V; v++)
+        if (unresolved[v] && ai && (u * 64 + i) < (v * 64 + lane) && ki == key[v]) dup[v] = true;
+    }
+  }
+}
+
 // Tables of a set with capacity `cap` in ONE LDS region: every size up to 2048 slots starts at
 // offset 0 (a rebuild first lifts the <= 512 old slots into registers, then reuses the space);
 // only a final table larger than 2048 slots lives behind the quarter-size region it grows from.

@@ -165,6 +165,8 @@ static void draw_item(const struct pcto_env* h, int e, struct cenv* s, double ou
     uint64_t g = (uint64_t)(h->cfg.env_id_base + e);
     uint64_t span = (uint64_t)(h->sample_right - h->sample_left + 1);
     for (int d = 0; d < 3; d++) k[d] = h->sample_left + (int32_t)(pct_pick(h->seed, g, c * 3 + (uint64_t)d, (uint32_t)span));
+    /* C/bin3D.py:110-112: settings 1 and 3 take z from np.random.choice([0.1,0.2,0.3,0.4,0.5]) */
+    if (h->cfg.setting != 2) k[2] = 100 * (1 + (int32_t)pct_pick(h->seed, g, c * 3 + 2, 5u));
   }
   for (int d = 0; d < 3; d++) out[d] = (double)k[d] / 1000.0;
 }

@@ -1,43 +1,50 @@
-"""Turns the rocprofv3 rocpd databases under gpurun_out/prof_<tag>/ into the small text/JSON
-summaries committed under profiles/ (and profiles/pmc_traffic.json, which bench.py reads
-for roofline.traffic)."""
-import glob
+"""Turns the rocprofv3 rocpd databases under gpurun_out/prof_<tag>_<workload>/ into the small text / JSON
+summaries committed under profiles/:  <tag>_trace_<workload>.txt (kernel-trace stats) and
+<tag>_pmc_<workload>.json (counters per launch; bench.py reads hbm_bytes_per_launch and
+valu_salu_insts_per_launch from it for roofline.traffic / roofline_issue).
+    python scripts/collect_profiles.py <tag> <workload> <envs-per-launch> <alg-bytes-per-env-step>"""
 import json
 import os
 import sqlite3
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+tag, wl = sys.argv[1], sys.argv[2]
+envs = int(sys.argv[3])
+alg = int(sys.argv[4])
+src = os.path.join(ROOT, "gpurun_out", "prof_%s_%s" % (tag, wl))
 dst = os.path.join(ROOT, "profiles")
-os.makedirs(dst, exist_ok=True)
-KERNEL = "pct_discrete_kernel<unsigned int, 5, 0, false, false, 0"
+KERNEL = "pct_continuous_kernel" if wl in ("c3", "c5", "c3s1") else "pct_discrete_kernel"
 
-out = {"tag": tag, "command": "python bench.py --no-cpu-baseline --steps 2000 --warmup 200 (kernel trace); "
-                              "--steps 200 --warmup 50 for each --pmc pass"}
+out = {"tag": tag, "workload": wl, "envs_per_launch": envs,
+       "command": "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --workload %s --steps 2000 --warmup 200; "
+                  "--steps 100 --warmup 100 for each --pmc pass (scripts/profile_gpu.sh)" % wl}
 db = os.path.join(src, "trace", "trace_results.db")
-cur = sqlite3.connect(db).cursor()
-rows = list(cur.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration), "
-                        "max(lds_size), max(scratch_size), max(vgpr_count), max(sgpr_count), max(grid_x), max(workgroup_x) "
-                        "from kernels group by name order by sum(duration) desc"))
-tot = sum(r[2] for r in rows)
-lines = ["# rocprofv3 --kernel-trace --stats summary (%s): python bench.py --steps 2000 --warmup 200" % tag,
-         "%-100s %8s %12s %10s %10s %10s %6s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "pct")]
-ks = []
-for r in rows:
-    lines.append("%-100s %8d %12.1f %10.2f %10.2f %10.2f %6.2f" % (r[0][:100], r[1], r[2] / 1e3, r[3] / 1e3, r[4] / 1e3,
-                                                                 r[5] / 1e3, 100 * r[2] / tot))
-    ks.append(dict(name=r[0], calls=r[1], total_us=r[2] / 1e3, avg_us=r[3] / 1e3, min_us=r[4] / 1e3, max_us=r[5] / 1e3,
-                   lds_bytes=r[6], scratch=r[7], vgpr=r[8], sgpr=r[9], grid=r[10], block=r[11]))
-# steady-state average of the step kernel: the timed 2000 launches are the last 2000
-d = [x[0] for x in cur.execute("select duration from kernels where name like ? order by start", ("%" + KERNEL + "%",))]
-steady = d[-2000:]
-out["step_kernel_avg_us_timed_region"] = sum(steady) / len(steady) / 1e3
-lines.append("")
-lines.append("step kernel, last 2000 launches (= bench timed region): avg %.2f us" % out["step_kernel_avg_us_timed_region"])
-out["kernels"] = ks
-open(os.path.join(dst, "%s_kernel_trace_stats.txt" % tag), "w").write("\n".join(lines) + "\n")
+lines = []
+if os.path.exists(db):
+    cur = sqlite3.connect(db).cursor()
+    rows = list(cur.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration), "
+                            "max(lds_size), max(scratch_size), max(vgpr_count), max(sgpr_count), max(grid_x), max(workgroup_x) "
+                            "from kernels group by name order by sum(duration) desc"))
+    tot = sum(r[2] for r in rows)
+    lines = ["# rocprofv3 --kernel-trace --stats summary (%s, workload %s): python bench.py --workload %s --steps 2000 --warmup 200" % (tag, wl, wl),
+             "%-100s %8s %12s %10s %10s %10s %6s %7s %5s %5s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "pct", "lds_B", "vgpr", "sgpr")]
+    for r in rows[:8]:
+        lines.append("%-100s %8d %12.1f %10.2f %10.2f %10.2f %6.2f %7d %5d %5d" % (
+            r[0][:100], r[1], r[2] / 1e3, r[3] / 1e3, r[4] / 1e3, r[5] / 1e3, 100 * r[2] / tot, r[6], r[8], r[9]))
+    # steady-state average of the step kernel: the timed 2000 launches are the last 2000 of the main (non-retry) grid
+    d = [x[0] for x in cur.execute("select duration from kernels where name like ? and grid_x >= ? order by start",
+                                   ("%" + KERNEL + "%", envs * 64))]
+    steady = d[-2000:]
+    out["step_kernel_avg_us_timed_region"] = sum(steady) / max(len(steady), 1) / 1e3
+    lines += ["", "step kernel (grid = %d envs), last %d launches (= bench timed region): avg %.2f us" % (
+        envs, len(steady), out["step_kernel_avg_us_timed_region"])]
+    bj = os.path.join(src, "trace_bench.json")
+    if os.path.exists(bj):
+        for ln in open(bj):
+            if ln.startswith("{"):
+                lines += ["", "bench line of the traced run:", ln.strip()]
+    open(os.path.join(dst, "%s_trace_%s.txt" % (tag, wl)), "w").write("\n".join(lines) + "\n")
 
 pmc = {}
 for sub in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
@@ -49,25 +56,26 @@ for sub in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
                           ("%" + KERNEL + "%",)))
     if not rows:
         continue
-    maxd = max(r[1] for r in rows)
-    agg = {}
+    # steady state: the last 50 steps; with a retry pass every step has two dispatches of this kernel, so the
+    # counters are summed per step = per pair of consecutive dispatch ids of the policy/transition sequence
+    by_d = {}
     for n, did, v in rows:
-        if did > maxd - 200:  # steady state: last 100 steps (2 kernels per step)
-            agg.setdefault(n, []).append(v)
-    for n, v in agg.items():
-        pmc[n] = sum(v) / len(v)
-out["pmc_per_launch_4096_envs"] = pmc
+        by_d.setdefault(n, {})[did] = v
+    for n, dv in by_d.items():
+        ids = sorted(dv)
+        per_step = len(ids) / 200.0  # 100 warm-up + 100 timed steps (+ reset)
+        k = max(1, int(round(per_step)))
+        last = ids[-50 * k:]
+        pmc[n] = sum(dv[i] for i in last) / 50.0
+out["pmc_per_launch"] = pmc
+if "SQ_INSTS_VALU" in pmc and "SQ_INSTS_SALU" in pmc:
+    out["valu_salu_insts_per_launch"] = pmc["SQ_INSTS_VALU"] + pmc["SQ_INSTS_SALU"]
 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
-    # MI355X_MICROARCH.md "HBM": counters are in KiB; on gfx950 FETCH_SIZE reports half the
-    # bytes of a wide coalesced read stream -> doubled (conservative for our narrow reads);
-    # WRITE_SIZE is taken as reported.
-    fetch = pmc["FETCH_SIZE"] * 1024
-    write = pmc["WRITE_SIZE"] * 1024
-    traffic = {"fetch_bytes_raw": fetch, "fetch_bytes_corrected_x2": 2 * fetch, "write_bytes": write,
-               "hbm_bytes_per_launch": 2 * fetch + write, "envs_per_launch": 4096,
-               "algorithmic_bytes_per_launch": 4757 * 4096, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, " + tag}
-    json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
-    out["traffic"] = traffic
-json.dump(out, open(os.path.join(dst, "%s_profile_summary.json" % tag), "w"), indent=1)
-print("\n".join(lines[:6]))
-print(json.dumps(out.get("traffic"), indent=1))
+    # MI355X_MICROARCH.md "HBM": counters are in KiB; on gfx950 FETCH_SIZE reports half the bytes of a wide
+    # coalesced read stream -> doubled (conservative for our narrow reads); WRITE_SIZE is taken as reported.
+    fetch, write = pmc["FETCH_SIZE"] * 1024, pmc["WRITE_SIZE"] * 1024
+    out.update({"fetch_bytes_raw": fetch, "fetch_bytes_corrected_x2": 2 * fetch, "write_bytes": write,
+                "hbm_bytes_per_launch": 2 * fetch + write, "algorithmic_bytes_per_launch": alg * envs})
+json.dump(out, open(os.path.join(dst, "%s_pmc_%s.json" % (tag, wl)), "w"), indent=1)
+print("\n".join(lines[:5]))
+print(json.dumps({k: v for k, v in out.items() if k != "pmc_per_launch"}, indent=1))

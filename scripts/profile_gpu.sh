@@ -1,22 +1,24 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): rocprofv3 kernel-trace stats + separate PMC passes of
-# the default bench workload.  Outputs under gpurun_out/prof_<tag>/ ; summaries are copied
-# into profiles/ by scripts/collect_profiles.py afterwards.
-TAG=${1:-r01}
-OUT=$PWD/gpurun_out/prof_$TAG
+# Runs on the GPU box (via gpurun): rocprofv3 kernel-trace stats + separate PMC passes of one bench workload.
+# Outputs under gpurun_out/prof_<tag>_<workload>/ ; summaries are copied into profiles/ by
+# scripts/collect_profiles.py afterwards.   scripts/profile_gpu.sh <tag> <workload> [trace-steps]
+TAG=${1:-r02}
+WL=${2:-c2}
+TSTEPS=${3:-2000}
+OUT=$PWD/gpurun_out/prof_${TAG}_${WL}
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python $PWD/bench.py --no-cpu-baseline"
+BENCH="python $PWD/bench.py --no-cpu-baseline --workload $WL"
 cd /tmp
-# 1. kernel trace + stats over the same command as the default bench line
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH --steps 2000 --warmup 200 > $OUT/trace_bench.json 2> $OUT/trace.err
+# 1. kernel trace + stats over the same command as the bench line
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH --steps $TSTEPS --warmup 200 > $OUT/trace_bench.json 2> $OUT/trace.err
 # 2. PMC passes (own runs, kernel-trace only)
-timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU -d $OUT/pmc_sq -o pmc -- $BENCH --steps 200 --warmup 50 > $OUT/pmc_sq.json 2> $OUT/pmc_sq.err
-timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR -d $OUT/pmc_sq2 -o pmc -- $BENCH --steps 200 --warmup 50 > $OUT/pmc_sq2.json 2> $OUT/pmc_sq2.err
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $BENCH --steps 200 --warmup 50 > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
-timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $BENCH --steps 200 --warmup 50 > $OUT/pmc_write.json 2> $OUT/pmc_write.err
+PSTEPS=100
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU -d $OUT/pmc_sq -o pmc -- $BENCH --steps $PSTEPS --warmup 100 > $OUT/pmc_sq.json 2> $OUT/pmc_sq.err
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_BRANCH SQ_THREAD_CYCLES_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR -d $OUT/pmc_sq2 -o pmc -- $BENCH --steps $PSTEPS --warmup 100 > $OUT/pmc_sq2.json 2> $OUT/pmc_sq2.err
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $BENCH --steps $PSTEPS --warmup 100 > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $BENCH --steps $PSTEPS --warmup 100 > $OUT/pmc_write.json 2> $OUT/pmc_write.err
 cd $OUT
-find . -name "*.csv" | head -50
+# keep the merge-back small: drop anything over 12 MB (the trace db of a 2000-step run is ~5 MB)
+find . -size +12M -delete
 du -sh .
-# keep the merge-back small: drop raw per-dispatch traces over 20 MB
-find . -size +20M -delete

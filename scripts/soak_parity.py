@@ -16,9 +16,11 @@ items = item_set_range(1, 5)
 threads = min(os.cpu_count() or 1, 64)
 if which.startswith("continuous"):
     setting = 1 if which.endswith("s1") else 2
-    env = pkg.PctVecEnv(N, setting=setting, container_size=(10, 10, 10), continuous=True, sample_left_bound=1.0,
-                        sample_right_bound=5.0, seed=17, device="cuda:0", strict=False)
-    ora = OracleVecEnv(N, setting=setting, container_size=(10, 10, 10), env_kind=1, sample_bounds=(1.0, 5.0), threads=threads)
+    # setting 1 draws z from {0.1..0.5} (C/bin3D.py:110-112), which is meant for the unit bin (givenData.py:5)
+    bin_, lo, hi = ((1, 1, 1), 0.1, 0.5) if setting == 1 else ((10, 10, 10), 1.0, 5.0)
+    env = pkg.PctVecEnv(N, setting=setting, container_size=bin_, continuous=True, sample_left_bound=lo,
+                        sample_right_bound=hi, seed=17, device="cuda:0", strict=False)
+    ora = OracleVecEnv(N, setting=setting, container_size=bin_, env_kind=1, sample_bounds=(lo, hi), threads=threads)
 else:
     setting = 1 if which == "discrete_s1" else 2
     lnes = {"cp": ("CP", 3), "fc": ("FC", 4)}.get(which, ("EMS", 0))

@@ -118,3 +118,23 @@ def test_rows6_action_form_matches_reference_fixture(name):
         assert np.array_equal(done.astype(np.uint8), z["done"][t]), (name, t)
     assert not env.error_flags.any()
     env.close()
+
+
+@pytest.mark.parametrize("setting", [1, 3])
+def test_continuous_stability_settings_on_device_sampler_vs_oracle(setting):
+    """C/bin3D.py:110-112: under settings 1 and 3 the sampled item's z comes from {0.1,...,0.5} (unit bin,
+    givenData.py:5) -- the on-device sampler and the oracle's draw the same stream, and the multi-supporter
+    stability paths it exercises agree."""
+    from oracle.oracle_lib import OracleVecEnv
+    N = 512
+    kw = dict(setting=setting, container_size=(1, 1, 1), internal_node_holder=80, leaf_node_holder=50)
+    env = _pkg().PctVecEnv(N, continuous=True, sample_left_bound=0.1, sample_right_bound=0.5, seed=9, device="cuda:0", **kw)
+    ora = OracleVecEnv(N, env_kind=1, sample_bounds=(0.1, 0.5), threads=_threads(), **kw)
+    ora.set_sampler(9)
+    obs = env.reset()
+    ora.reset()
+    z = obs.view(N, -1, 9)[:, -1, 3:6].cpu().numpy().astype(np.float64)  # sorted sizes of the next item
+    lattice = np.round(z * 1000).astype(np.int64)
+    assert (np.isin(lattice, [100, 200, 300, 400, 500]).any(1)).all()
+    assert _run(env, ora, 150, 10) > 500
+    env.close()
