@@ -188,6 +188,12 @@ int pct_set_shuffle_seed(pct_env* env, uint64_t seed);
  * counter int32 [N]; ratio float64 [N]; error_flags uint32 [N] (must be zero-filled). */
 int pct_bind_outputs(pct_env* env, float* obs, float* reward, uint8_t* done,
                      int32_t* counter, double* ratio, uint32_t* error_flags);
+/* Device-resident rollout edge (storage.py:33-39 PCTRolloutStorage.insert fused into the transition): the
+ * NEXT launch writes its observation -- every row -- into `obs_next` (float32 [N,(I+L+1)*9], e.g.
+ * rollout.obs[t+1]), its reward into `reward` (float32 [N], e.g. rollout.rewards[t]; NULL keeps the current
+ * buffer) and 1 - done into `mask` (float32 [N], e.g. rollout.masks[t+1]; NULL: not written).  The binding
+ * stays until the next pct_bind_rollout_slot / pct_bind_outputs; the caller re-binds once per step. */
+int pct_bind_rollout_slot(pct_env* env, float* obs_next, float* reward, float* mask);
 float* pct_obs(pct_env* env);
 float* pct_reward(pct_env* env);
 uint8_t* pct_done(pct_env* env);

@@ -24,7 +24,7 @@ FLAG_STABILITY_OVERFLOW, FLAG_DATASET_EXHAUSTED = 16, 32
 ABI_SYMBOLS = [
     "pct_abi_version", "pct_last_error", "pct_create", "pct_destroy", "pct_set_item_set",
     "pct_set_sample_bounds", "pct_set_item_stream", "pct_set_item_dataset", "pct_set_sampler", "pct_set_shuffle_seed",
-    "pct_set_density_stream", "pct_set_dataset_density", "pct_bind_outputs", "pct_obs",
+    "pct_set_density_stream", "pct_set_dataset_density", "pct_bind_outputs", "pct_bind_rollout_slot", "pct_obs",
     "pct_reward", "pct_done", "pct_info_counter", "pct_info_ratio", "pct_error_flags", "pct_obs_row_len",
     "pct_reset", "pct_step_rows", "pct_step_index", "pct_step_hash_policy", "pct_step_heuristic", "pct_debug_state",
     "pct_policy_hash_rows", "pct_profile_enable", "pct_profile_read", "pct_debug_phase_timing", "pct_debug_state_f64",
@@ -78,6 +78,7 @@ def load():
     L.pct_set_density_stream.argtypes = [vp, vp, i64]
     L.pct_set_dataset_density.argtypes = [vp, vp]
     L.pct_bind_outputs.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.pct_bind_rollout_slot.argtypes = [vp, vp, vp, vp]
     for name in ("pct_obs", "pct_reward", "pct_done", "pct_info_counter", "pct_info_ratio", "pct_error_flags"):
         getattr(L, name).argtypes = [vp]
         getattr(L, name).restype = vp

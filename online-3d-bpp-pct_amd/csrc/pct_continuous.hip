@@ -137,12 +137,18 @@ __device__ inline void cdraw_item(const ContinuousParams& p, int e, CRegs& r) {
     r.ik0 = it[0]; r.ik1 = it[1]; r.ik2 = it[2];
   } else {
     uint64_t g = (uint64_t)(p.env_id_base + e);
-    uint64_t span = (uint64_t)(p.sample_right - p.sample_left + 1);
-    r.ik0 = p.sample_left + (int)(pct_pick(p.seed, g, c * 3 + 0, (uint32_t)span));
-    r.ik1 = p.sample_left + (int)(pct_pick(p.seed, g, c * 3 + 1, (uint32_t)span));
-    r.ik2 = p.sample_left + (int)(pct_pick(p.seed, g, c * 3 + 2, (uint32_t)span));
-    // C/bin3D.py:110-112: settings 1 and 3 take z from np.random.choice([0.1, 0.2, 0.3, 0.4, 0.5])
-    if (p.setting != 2) r.ik2 = 100 * (1 + (int)pct_pick(p.seed, g, c * 3 + 2, 5u));
+    if (p.sample_right <= 0) {
+      // not sample_from_distribution: RandomBoxCreator(item_set) (C/bin3D.py:36-39,113; binCreator.py:37-39)
+      const int32_t* it = p.item_set + 3 * (size_t)pct_pick(p.seed, g, c, (uint32_t)p.n_items);
+      r.ik0 = it[0]; r.ik1 = it[1]; r.ik2 = it[2];
+    } else {
+      uint64_t span = (uint64_t)(p.sample_right - p.sample_left + 1);
+      r.ik0 = p.sample_left + (int)(pct_pick(p.seed, g, c * 3 + 0, (uint32_t)span));
+      r.ik1 = p.sample_left + (int)(pct_pick(p.seed, g, c * 3 + 1, (uint32_t)span));
+      r.ik2 = p.sample_left + (int)(pct_pick(p.seed, g, c * 3 + 2, (uint32_t)span));
+      // C/bin3D.py:110-112: settings 1 and 3 take z from np.random.choice([0.1, 0.2, 0.3, 0.4, 0.5])
+      if (p.setting != 2) r.ik2 = 100 * (1 + (int)pct_pick(p.seed, g, c * 3 + 2, 5u));
+    }
   }
   // round(U(a,b), 3) (C/bin3D.py:106-108): the double nearest to k/1000
   r.b0 = (double)r.ik0 / 1000.0; r.b1 = (double)r.ik1 / 1000.0; r.b2 = (double)r.ik2 / 1000.0;
@@ -217,6 +223,7 @@ __device__ inline StabState cstab_view(const ContinuousParams& p, int e) {
   st.npoly = p.st_npoly + (size_t)e * p.I;
   st.poly = p.st_poly + (size_t)e * p.I * STAB_PMAX * 2;
   st.den = p.st_den + (size_t)e * p.I;
+  st.alias = p.st_alias + (size_t)e * p.I;
   return st;
 }
 
@@ -881,6 +888,7 @@ __device__ inline bool ctransition(const ContinuousParams& p, int e, CLds& l, CR
     p.done[e] = done;
     p.counter[e] = counter;
     p.ratio[e] = ratio;
+    if (p.mask) p.mask[e] = done ? 0.f : 1.f;  // train_tools.py:70 masks = 1 - done
   }
   return done != 0;  // true: the episode ended and the env was reset
 }

@@ -48,6 +48,7 @@ struct DiscreteParams {
   int* st_npoly;    /* [N,I] */
   double* st_poly;  /* [N,I,STAB_PMAX,2] scaled support polygon */
   double* st_den;   /* [N,I] density of each placed box (1.0 unless setting 3) */
+  int* st_alias;    /* [N,I] supporter index holding the box's stack by reference, or -1 (pct_stab.cuh) */
   // setting 3 density source (include/pct_env.h pct_set_density_stream / pct_set_dataset_density)
   const double* den_stream; /* [N,den_T] or null */
   long long den_T;
@@ -58,6 +59,7 @@ struct DiscreteParams {
   uint8_t* done;    /* [N] */
   int32_t* counter; /* [N] */
   double* ratio;    /* [N] */
+  float* mask;      /* [N] 1 - done as float32 (storage.py masks), or null */
 };
 
 // HBM layout of the continuous env state (float64, SoA over envs; within an env every
@@ -71,7 +73,9 @@ struct ContinuousParams {
   unsigned long long shuffle_seed;
   int ems_cap, cand_cap, order_cap, union_doubles;
   int source, env_id_base;
-  int sample_left, sample_right; /* lattice 1e-3 */
+  int sample_left, sample_right; /* lattice 1e-3; right <= 0: items come from item_set instead */
+  const int32_t* item_set;       /* [n_items,3] lattice 1e-3 (not sample_from_distribution, C/bin3D.py:36-39) */
+  int n_items;
   long long T;
   unsigned long long seed;
   const int32_t* stream; /* [N,T,3] lattice 1e-3; dataset mode: [n_traj,max_len,3] */
@@ -89,6 +93,7 @@ struct ContinuousParams {
   int* st_npoly;
   double* st_poly;
   double* st_den;
+  int* st_alias;
   const double* den_stream; /* setting 3 density source, as in DiscreteParams */
   long long den_T;
   const double* ds_den;
@@ -108,6 +113,7 @@ struct ContinuousParams {
   uint8_t* done;
   int32_t* counter;
   double* ratio;
+  float* mask; /* as in DiscreteParams */
 };
 
 // D/bin3D.py:75-84 next_den of the observation number `oc` (the env's life-long observation

@@ -148,6 +148,7 @@ __device__ inline StabState stab_view(const DiscreteParams& p, int e) {
   st.npoly = p.st_npoly + (size_t)e * p.I;
   st.poly = p.st_poly + (size_t)e * p.I * STAB_PMAX * 2;
   st.den = p.st_den + (size_t)e * p.I;
+  st.alias = p.st_alias + (size_t)e * p.I;
   return st;
 }
 
@@ -1663,6 +1664,7 @@ __device__ inline bool transition(const DiscreteParams& p, int e, Lds<K, BITS>& 
     p.done[e] = done;
     p.counter[e] = counter;
     p.ratio[e] = ratio;
+    if (p.mask) p.mask[e] = done ? 0.f : 1.f;  // train_tools.py:70 masks = 1 - done
   }
   return done != 0;  // true: the episode ended and the env was reset
 }

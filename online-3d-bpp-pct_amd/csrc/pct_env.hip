@@ -70,6 +70,18 @@ int dev_alloc(pct_env* h, void** p, size_t bytes, bool zero) {
   if (zero) HIP_TRY(hipMemset(*p, 0, bytes ? bytes : 16));
   return PCT_OK;
 }
+// a source buffer that is being replaced: wait for the kernels that may still read it, then free it
+int release_owned(pct_env* h, const void* old) {
+  if (!old) return PCT_OK;
+  for (size_t i = 0; i < h->owned.size(); i++)
+    if (h->owned[i] == old) {
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipFree(h->owned[i]));
+      h->owned.erase(h->owned.begin() + (long)i);
+      break;
+    }
+  return PCT_OK;
+}
 int use_device(const pct_env* h) {
   HIP_TRY(hipSetDevice(h->device));
   return PCT_OK;
@@ -121,8 +133,9 @@ int launch(pct_env* h, int act, const void* actions, int row_len, int n_steps, c
       q.source = c.source; q.stream = c.stream; q.T = c.T; q.seed = c.seed; q.ds_len = c.ds_len;
       q.den_stream = c.den_stream; q.den_T = c.den_T; q.ds_den = c.ds_den;
       q.ds_ntraj = c.ds_ntraj; q.ds_maxlen = c.ds_maxlen; q.sample_left = c.sample_left; q.sample_right = c.sample_right;
+      q.item_set = c.item_set; q.n_items = c.n_items;
       q.low_bound = c.low_bound; q.obs = c.obs; q.reward = c.reward; q.done = c.done; q.counter = c.counter;
-      q.ratio = c.ratio; q.flags = c.flags; q.timing = nullptr; q.full_obs = c.full_obs;
+      q.ratio = c.ratio; q.flags = c.flags; q.timing = nullptr; q.full_obs = c.full_obs; q.mask = c.mask;
       HIP_TRY(pct::launch_continuous(q, act, actions, row_len, n_steps, ids, h->cp_retry_blocks, s));
     }
     if (act != ACT_RESET || !ids) h->dp.full_obs = 0;
@@ -244,6 +257,7 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
       CALLOC_(c.st_npoly, Nn * c.I * sizeof(int));
       CALLOC_(c.st_poly, Nn * c.I * pct::STAB_PMAX * 2 * sizeof(double));
       CALLOC_(c.st_den, Nn * c.I * sizeof(double));
+      CALLOC_(c.st_alias, Nn * c.I * sizeof(int));
     }
     if (c.table_global) {
       CALLOC_(c.gtab, Nn * (size_t)(cand_cap + cand_cap / 4) * sizeof(uint32_t));
@@ -327,6 +341,7 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
     ALLOC(p.st_npoly, N * p.I * sizeof(int));
     ALLOC(p.st_poly, N * p.I * pct::STAB_PMAX * 2 * sizeof(double));
     ALLOC(p.st_den, N * p.I * sizeof(double));
+    ALLOC(p.st_alias, N * p.I * sizeof(int));
   }
   ALLOC(h->own_flags, N * sizeof(uint32_t));
   ALLOC(h->own_obs, N * p.row_len * sizeof(float));
@@ -357,7 +372,6 @@ int pct_destroy(pct_env* h) {
 
 int pct_set_item_set(pct_env* h, const int32_t* item_set, int32_t n) {
   if (!h || !item_set || n < 1) return fail(PCT_ERR_INVALID_ARG, "bad item set");
-  if (h->continuous) return fail(PCT_ERR_UNSUPPORTED, "the continuous env takes pct_set_sample_bounds");
   int rc = use_device(h);
   if (rc) return rc;
   int mn = item_set[0], mx = item_set[0];
@@ -367,6 +381,9 @@ int pct_set_item_set(pct_env* h, const int32_t* item_set, int32_t n) {
   }
   if (mn < 1) return fail(PCT_ERR_INVALID_ARG, "item sizes must be >= 1 lattice unit");
   (void)mx;
+  rc = release_owned(h, h->d_item_set);
+  if (rc) return rc;
+  h->d_item_set = nullptr;
   void* d = nullptr;
   rc = dev_alloc(h, &d, sizeof(int32_t) * 3 * (size_t)n, false);
   if (rc) return rc;
@@ -375,6 +392,15 @@ int pct_set_item_set(pct_env* h, const int32_t* item_set, int32_t n) {
   h->dp.item_set = h->d_item_set;
   h->dp.n_items = n;
   h->dp.low_bound = mn; /* bin3D.py:23 size_minimum */
+  if (h->continuous) { /* C/bin3D.py:29,36-39: items from the set (lattice 1e-3), size_minimum = its smallest entry */
+    h->cp.item_set = h->d_item_set;
+    h->cp.n_items = n;
+    h->cp.sample_left = 0;
+    h->cp.sample_right = 0;
+    h->cp.low_bound = (double)mn / 1000.0;
+    h->cp_retry.item_set = h->d_item_set;
+    h->cp_retry.n_items = n;
+  }
   h->have_items = true;
   return PCT_OK;
 }
@@ -394,6 +420,10 @@ int pct_set_item_stream(pct_env* h, const int32_t* items, int64_t T) {
   int rc = use_device(h);
   if (rc) return rc;
   size_t n = (size_t)h->dp.N * (size_t)T * 3;
+  rc = release_owned(h, h->dp.stream);  /* a replaced stream / dataset (synchronises: kernels may still read it) */
+  if (rc) return rc;
+  if (h->dp.ds_len) { rc = release_owned(h, h->dp.ds_len); if (rc) return rc; }
+  h->dp.stream = nullptr; h->dp.ds_len = nullptr; h->cp.stream = nullptr; h->cp.ds_len = nullptr;
   void* d = nullptr;
   rc = dev_alloc(h, &d, sizeof(int32_t) * n, false);
   if (rc) return rc;
@@ -413,6 +443,10 @@ int pct_set_item_dataset(pct_env* h, const int32_t* items, const int32_t* length
     return fail(PCT_ERR_INVALID_ARG, "bad dataset (at least 2 trajectories: the first episode plays trajectory 1)");
   int rc = use_device(h);
   if (rc) return rc;
+  rc = release_owned(h, h->dp.stream);
+  if (rc) return rc;
+  if (h->dp.ds_len) { rc = release_owned(h, h->dp.ds_len); if (rc) return rc; }
+  h->dp.stream = nullptr; h->dp.ds_len = nullptr; h->cp.stream = nullptr; h->cp.ds_len = nullptr;
   void* d = nullptr;
   void* dl = nullptr;
   size_t n = (size_t)n_traj * (size_t)max_len * 3;
@@ -433,6 +467,9 @@ int pct_set_density_stream(pct_env* h, const double* den, int64_t T) {
   if (!h || !den || T < 1) return fail(PCT_ERR_INVALID_ARG, "bad density stream");
   int rc = use_device(h);
   if (rc) return rc;
+  rc = release_owned(h, h->dp.den_stream);
+  if (rc) return rc;
+  h->dp.den_stream = nullptr; h->cp.den_stream = nullptr;
   void* d = nullptr;
   size_t n = (size_t)h->cfg.num_envs * (size_t)T;
   rc = dev_alloc(h, &d, sizeof(double) * n, false);
@@ -448,6 +485,9 @@ int pct_set_dataset_density(pct_env* h, const double* den) {
   if (h->dp.source != PCT_ITEMS_DATASET) return fail(PCT_ERR_STATE, "pct_set_item_dataset must come first");
   int rc = use_device(h);
   if (rc) return rc;
+  rc = release_owned(h, h->dp.ds_den);
+  if (rc) return rc;
+  h->dp.ds_den = nullptr; h->cp.ds_den = nullptr;
   void* d = nullptr;
   size_t n = (size_t)h->dp.ds_ntraj * (size_t)h->dp.ds_maxlen;
   rc = dev_alloc(h, &d, sizeof(double) * n, false);
@@ -486,8 +526,21 @@ int pct_bind_outputs(pct_env* h, float* obs, float* reward, uint8_t* done, int32
   h->dp.counter = counter ? counter : h->own_counter;
   h->dp.ratio = ratio ? ratio : h->own_ratio;
   h->dp.flags = error_flags ? error_flags : h->own_flags;
+  h->dp.mask = nullptr;
+  h->cp.mask = nullptr;
   h->cp.obs = h->dp.obs; h->cp.reward = h->dp.reward; h->cp.done = h->dp.done; h->cp.counter = h->dp.counter;
   h->cp.ratio = h->dp.ratio; h->cp.flags = h->dp.flags;
+  return PCT_OK;
+}
+
+int pct_bind_rollout_slot(pct_env* h, float* obs_next, float* reward, float* mask) {
+  if (!h) return fail(PCT_ERR_INVALID_ARG, "null handle");
+  if (!obs_next) return fail(PCT_ERR_INVALID_ARG, "null observation slot");
+  h->dp.full_obs = 1; /* the slot does not hold this env's previous observation: every row is written */
+  h->dp.obs = obs_next;
+  if (reward) h->dp.reward = reward;
+  h->dp.mask = mask;
+  h->cp.obs = h->dp.obs; h->cp.reward = h->dp.reward; h->cp.mask = h->dp.mask;
   return PCT_OK;
 }
 

@@ -12,6 +12,12 @@
 //   * S.up_edges (a dict keyed by boxes, iterated in insertion order) == the boxes that list S
 //     as a supporter, in ascending id (a key is first inserted when that box is committed), so
 //     calculate_new_com(S) is a scan over the boxes above S reading share[B][idx(S)];
+//   * up_edges entries shared BY REFERENCE: with one supporter, or for the "direct" supporter, the reference
+//     stores the box's own thisStack OBJECT in the supporter's up_edges (D/space.py:80,96) and
+//     calculate_new_com later mutates it in place (:67-71) -- such an entry always reads as the box's
+//     CURRENT committed stack.  `alias[b]` = index of the supporter that holds b's stack by reference (or -1);
+//     stab_com reads stack[b] instead of share[b][alias[b]].  This only matters inside a commit walk (a box
+//     with >= 2 supporters recomputes all of them before it visits the first), where it changes verdicts;
 //   * of S.up_virtual_edges only the entry of the currently `involved` parent is ever read and
 //     it is written just before; `involved` == "on the active path";
 //   * a supporter's virtual stack is recomputed when it is visited instead of when its parent
@@ -51,6 +57,7 @@ struct StabState {
   int* npoly;      // [I]
   double* poly;    // [I][STAB_PMAX][2]
   double* den;     // [I] density of each placed box (setting 3; 1.0 otherwise), D/space.py:38
+  int* alias;      // [I] supporter index whose up_edges entry is this box's thisStack object itself, or -1
 };
 
 struct StabBox {  // a box being examined (candidate or placed), with its supporters
@@ -207,6 +214,9 @@ PCT_SD void stab_lstsq(const double* A, const double* b, int M, int N, double* x
 }
 
 PCT_SD double stab_around6(double x) { return rint(x * 1e6) / 1e6; }
+// np.dot of two 2-vectors as NumPy's BLAS computes it (OpenBLAS ddot on x86 cores with FMA): acc = x0*y0;
+// acc = fma(x1, y1, acc) -- see oracle/pct_oracle_stab.c dot2 (v_fma_f64 on the GPU: the same IEEE operation)
+PCT_SD double stab_dot2(double x0, double x1, double y0, double y1) { return fma(x1, y1, x0 * y0); }
 
 // contact rectangle of box `b` with placed box geometry `t`, or false if `t` does not support it.
 // Discrete (D/space.py:358-376): same top, non-degenerate overlap.  Continuous
@@ -268,10 +278,12 @@ PCT_SD void stab_load_box(const Geo& geo, const StabState& st, int id, StabBox& 
 // `own_centre` is the box's own centre (the virtual flavour's zero-mass shares use it).
 template <bool CONT>
 PCT_SD bool stab_shares(const StabBox& b, const double stk[4], const double own_centre[3], bool virtual_,
-                        double out[STAB_SMAX][4]) {
+                        double out[STAB_SMAX][4], int* alias = nullptr) {
   const int k = b.nsup;
+  if (alias) *alias = -1;
   if (k == 1) {
     out[0][0] = stk[0]; out[0][1] = stk[1]; out[0][2] = stk[2]; out[0][3] = stk[3];
+    if (alias) *alias = 0;  // up_edges[self] = self.thisStack: the object itself
     return true;
   }
   int direct = -1;
@@ -282,6 +294,7 @@ PCT_SD bool stab_shares(const StabBox& b, const double stk[4], const double own_
     if (inside) { direct = i; break; }
   }
   if (direct >= 0) {
+    if (alias) *alias = direct;
     for (int i = 0; i < k; i++) {
       if (i == direct) { out[i][0] = stk[0]; out[i][1] = stk[1]; out[i][2] = stk[2]; out[i][3] = stk[3]; }
       else {
@@ -295,13 +308,13 @@ PCT_SD bool stab_shares(const StabBox& b, const double stk[4], const double own_
     const double* e0 = b.c2[0];
     const double* e1 = b.c2[1];
     double t0 = e0[0] - e1[0], t1 = e0[1] - e1[1];
-    double len = sqrt(t0 * t0 + t1 * t1);
+    double len = sqrt(stab_dot2(t0, t1, t0, t1));
     // tri_base_len ** 2: NumPy calls libm pow(len, 2.0); a correctly rounded square is len*len
     // (glibc's pow agrees except for rare near-midpoint roundings; the device pow does not)
     double l2 = len * len;
     t0 /= l2; t1 /= l2;
-    double r0 = fabs((stk[0] - e1[0]) * t0 + (stk[1] - e1[1]) * t1);
-    double r1 = fabs((stk[0] - e0[0]) * t0 + (stk[1] - e0[1]) * t1);
+    double r0 = fabs(stab_dot2(stk[0] - e1[0], stk[1] - e1[1], t0, t1));
+    double r1 = fabs(stab_dot2(stk[0] - e0[0], stk[1] - e0[1], t0, t1));
     out[0][0] = e0[0]; out[0][1] = e0[1]; out[0][2] = stk[2]; out[0][3] = stk[3] * r0;
     out[1][0] = e1[0]; out[1][1] = e1[1]; out[1][2] = stk[2]; out[1][3] = stk[3] * r1;
     return true;
@@ -317,9 +330,9 @@ PCT_SD bool stab_shares(const StabBox& b, const double stk[4], const double own_
       const double* ei = b.c2[i];
       const double* ej = b.c2[j];
       double t0 = ei[0] - ej[0], t1 = ei[1] - ej[1];
-      double mol = (stk[0] - ei[0]) * t0 + (stk[1] - ei[1]) * t1;
+      double mol = stab_dot2(stk[0] - ei[0], stk[1] - ei[1], t0, t1);
       if (mol != 0) {
-        double rr = fabs((stk[0] - ej[0]) * t0 + (stk[1] - ej[1]) * t1) / mol;
+        double rr = fabs(stab_dot2(stk[0] - ej[0], stk[1] - ej[1], t0, t1)) / mol;
         A[row * k + i] = 1;
         A[row * k + j] = -rr;
       }
@@ -352,7 +365,8 @@ PCT_SD void stab_com(const Geo& geo, const StabState& st, int n, int S, const in
     const int ns = st.nsup[B];
     for (int k = 0; k < ns; k++)
       if (st.sup[B * STAB_SMAX + k] == S) {
-        const double* e = st.share + ((size_t)B * STAB_SMAX + k) * 4;
+        // an entry held by reference reads as B's current committed stack (see the header)
+        const double* e = (st.alias[B] == k) ? st.stack + (size_t)B * 4 : st.share + ((size_t)B * STAB_SMAX + k) * 4;
         c0 += e[0] * e[3]; c1 += e[1] * e[3]; c2 += e[2] * e[3];
         m += e[3];
       }
@@ -439,6 +453,7 @@ PCT_SD bool stab_commit(const Geo& geo, StabState& st, int n, double density, bo
     s[0] = b.g[0] + sx / 2; s[1] = b.g[1] + sy / 2; s[2] = b.g[2] + sz / 2; s[3] = sx * sy * sz * density;
   }
   st.nsup[n] = b.nsup;
+  st.alias[n] = -1;
   for (int k = 0; k < b.nsup; k++) st.sup[n * STAB_SMAX + k] = b.sup[k];
   st.npoly[n] = 0;
   if (b.nsup > 0) {
@@ -472,7 +487,9 @@ PCT_SD bool stab_commit(const Geo& geo, StabState& st, int n, double density, bo
       if (!stab_pip(stk, poly, np)) return false;
       // distribute to every supporter first (up_edges[self] = share; calculate_new_com())
       double own[3] = {stk[0], stk[1], stk[2]};
-      if (!stab_shares<CONT>(b, stk, own, false, shares)) { err = true; return false; }
+      int alias_k;
+      if (!stab_shares<CONT>(b, stk, own, false, shares, &alias_k)) { err = true; return false; }
+      st.alias[id] = alias_k;
       for (int k = 0; k < b.nsup; k++) {
         double* e = st.share + ((size_t)id * STAB_SMAX + k) * 4;
         e[0] = shares[k][0]; e[1] = shares[k][1]; e[2] = shares[k][2]; e[3] = shares[k][3];

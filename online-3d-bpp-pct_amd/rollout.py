@@ -1,10 +1,14 @@
 """Device-resident rollout edge.
 
-The reference collects n-step rollouts through the host: `selected_leaf_node.cpu().numpy()`
-(D2H), `envs.step`, `torch.tensor(1-done)` (H2D) and `PCTRolloutStorage.insert`
-(train_tools.py:63-70, storage.py:4-50, tools.py:70-73).  Here the same tensors never leave
-the GPU: the env takes the leaf INDEX the policy sampled (pct_step_index), reward / done stay
-device tensors, and the storage below has the reference's shapes and update rules.
+The reference collects n-step rollouts through the host: `selected_leaf_node.cpu().numpy()` (D2H),
+`envs.step`, `torch.tensor(1-done)` (H2D) and `PCTRolloutStorage.insert`, five `copy_` calls per step
+(train_tools.py:63-70, storage.py:33-39, tools.py:70-73).  Here the insert is FUSED into the transition: the
+env takes the leaf INDEX the policy sampled and the transition kernel itself writes step t's new observation
+into `obs[t + 1]`, its reward into `rewards[t]` and 1 - done into `masks[t + 1]` (PctVecEnv.step_into ->
+pct_bind_rollout_slot + pct_step_index): one launch per step, no copy kernels, nothing leaves the GPU.  What
+the policy produces (action index, log-probability) is the caller's to keep; `RolloutSlots.record` stores
+them.  The tensor names and shapes are the trainer's contract (storage.py:5-11); the update rules
+`after_update` / `compute_returns` are storage.py:41-50, restated.
 """
 import torch
 
@@ -16,28 +20,36 @@ def get_leaf_nodes(observation, internal_node_holder, leaf_node_holder):
     return unify_obs, leaf_nodes
 
 
-class DeviceRollout(object):
-    """storage.py:4-50 PCTRolloutStorage with every tensor on `device`."""
+class RolloutSlots(object):
+    """The trainer's rollout tensors (storage.py:5-11), every one on `device`, laid out so that slot t of each
+    is a contiguous block the transition kernel can write directly."""
 
     def __init__(self, num_steps, num_processes, obs_shape, gamma, device):
         dev = torch.device(device)
-        self.obs = torch.zeros(num_steps + 1, num_processes, *obs_shape, device=dev)
-        self.rewards = torch.zeros(num_steps, num_processes, 1, device=dev)
-        self.returns = torch.zeros(num_steps + 1, num_processes, 1, device=dev)
-        self.action_log_probs = torch.zeros(num_steps, num_processes, 1, device=dev)
-        self.actions = torch.zeros(num_steps, num_processes, 1, dtype=torch.long, device=dev)
-        self.masks = torch.ones(num_steps + 1, num_processes, 1, device=dev)
-        self.num_steps = num_steps
-        self.gamma = gamma
+        T, N = num_steps, num_processes
+        self.obs = torch.zeros(T + 1, N, *obs_shape, device=dev)
+        self.rewards = torch.zeros(T, N, 1, device=dev)
+        self.returns = torch.zeros(T + 1, N, 1, device=dev)
+        self.action_log_probs = torch.zeros(T, N, 1, device=dev)
+        self.actions = torch.zeros(T, N, 1, dtype=torch.long, device=dev)
+        self.masks = torch.ones(T + 1, N, 1, device=dev)
+        self.num_steps, self.gamma, self.step = T, gamma, 0
+
+    def begin(self, envs):
+        """Slot 0 <- the env's current observation (storage.py:41-43 does this with obs[-1] after an update)."""
+        self.obs[0].copy_(envs.current_obs().view_as(self.obs[0]))
         self.step = 0
 
-    def insert(self, obs, actions, action_log_probs, rewards, masks):  # storage.py:33-39
-        self.obs[self.step + 1].copy_(obs)
-        self.actions[self.step].copy_(actions)
-        self.action_log_probs[self.step].copy_(action_log_probs)
-        self.rewards[self.step].copy_(rewards)
-        self.masks[self.step + 1].copy_(masks)
-        self.step = (self.step + 1) % self.num_steps
+    def step_env(self, envs, leaf_index, action_log_probs=None):
+        """One env step written in place: obs[t+1], rewards[t], masks[t+1] by the transition kernel; the policy's
+        own outputs are recorded beside them.  Returns the new observation view obs[t+1]."""
+        t = self.step
+        envs.step_into(leaf_index, self.obs[t + 1], self.rewards[t], self.masks[t + 1])
+        self.actions[t].copy_(leaf_index.view_as(self.actions[t]))
+        if action_log_probs is not None:
+            self.action_log_probs[t].copy_(action_log_probs)
+        self.step = (t + 1) % self.num_steps
+        return self.obs[t + 1]
 
     def after_update(self):  # storage.py:41-43
         self.obs[0].copy_(self.obs[-1])
@@ -58,17 +70,17 @@ class DeviceRollout(object):
         return out
 
 
-def collect(envs, policy, rollout, all_nodes=None):
-    """train_tools.py:63-70 without host round trips.  `policy(all_nodes) -> (log_prob [N,1],
-    leaf_index int64 [N,1])`; `envs` is a PctVecEnv.  Returns the last observation view."""
-    I, L = envs.I, envs.Lh
-    if all_nodes is None:
-        all_nodes, _ = get_leaf_nodes(envs.current_obs(), I, L)
-        rollout.obs[0].copy_(all_nodes)
+DeviceRollout = RolloutSlots  # round-1 name
+
+
+def collect(envs, policy, rollout):
+    """train_tools.py:63-70 without host round trips and without copy kernels: per step the policy and ONE
+    transition launch.  `policy(all_nodes [N,I+L+1,9]) -> (log_prob [N,1], leaf_index int64 [N,1])`; `envs` is a
+    PctVecEnv whose current observation is the rollout's slot 0 (`rollout.begin(envs)` if it is not yet).
+    Returns the last observation view."""
+    all_nodes = rollout.obs[rollout.step]
     for _ in range(rollout.num_steps):
         with torch.no_grad():
             log_prob, idx = policy(all_nodes)
-        obs, reward, mask = envs.step_device(idx)
-        all_nodes, _ = get_leaf_nodes(obs, I, L)
-        rollout.insert(all_nodes, idx, log_prob, reward, mask)
+        all_nodes = rollout.step_env(envs, idx, log_prob)
     return all_nodes

@@ -14,7 +14,8 @@ import torch
 
 
 def shard_envs(total_envs, rank, world_size):
-    """(env_id_base, local_num_envs) of `rank`; the last rank takes the remainder."""
+    """(env_id_base, local_num_envs) of `rank`; the last rank takes the remainder (gather_rollout copes with
+    unequal shards by padding)."""
     if world_size < 1 or not (0 <= rank < world_size):
         raise ValueError("bad rank/world_size")
     per = total_envs // world_size
@@ -26,12 +27,24 @@ def shard_envs(total_envs, rank, world_size):
 
 
 def gather_rollout(local, group=None):
-    """All-gather equal-sized shards along dim 0: [n_local, ...] -> [world*n_local, ...]."""
+    """All-gather the ranks' shards along dim 0: [n_rank, ...] -> [sum of n_rank, ...], rank order.  Shards may
+    differ in length (shard_envs gives the last rank the remainder): the lengths are exchanged first and the
+    shards are padded to the longest for the one all_gather_into_tensor."""
     import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_available() or not dist.is_initialized():
         return local
     world = dist.get_world_size(group)
     local = local.contiguous()
-    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    sizes = torch.empty(world, dtype=torch.int64, device=local.device)
+    dist.all_gather_into_tensor(sizes, n, group=group)
+    sizes = [int(x) for x in sizes.tolist()]
+    nmax = max(sizes)
+    if local.shape[0] < nmax:
+        pad = torch.zeros((nmax - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        local = torch.cat([local, pad], 0)
+    out = torch.empty((world * nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local, group=group)
-    return out
+    if all(s == nmax for s in sizes):
+        return out
+    return torch.cat([out[r * nmax:r * nmax + sizes[r]] for r in range(world)], 0)

@@ -142,8 +142,20 @@ class PctVecEnv(VecEnv):
                 raise ValueError("load_test_data=True needs data_name (a torch.save'd list of trajectories)")
             self._dataset = [np.asarray(t, dtype=np.float64) for t in torch.load(data_name)]  # binCreator.py:48-49; [len, 3 or 4]
         self.continuous = bool(continuous)
-        if self.continuous and (sample_left_bound is None or sample_right_bound is None):
-            raise ValueError("the continuous env needs sample_left_bound / sample_right_bound (tools.py:178-181)")
+        # continuous env: items ~ U(a,b) on the 1e-3 lattice when sample_from_distribution (C/bin3D.py:24-27,103-112;
+        # bounds default to 0.1 / 0.5 of the smallest bin side, tools.py:178-181), else drawn from item_set by
+        # RandomBoxCreator (C/bin3D.py:29,36-39).  Giving bounds implies sampling from the distribution.
+        self._cont_from_set = False
+        if self.continuous and sample_left_bound is None and sample_right_bound is None:
+            if sample_from_distribution:
+                sample_left_bound = 0.1 * min(container_size)
+                sample_right_bound = 0.5 * min(container_size)
+            elif item_set is not None and not load_test_data:
+                self._cont_from_set = True
+            elif not load_test_data:
+                raise ValueError("the continuous env needs sample bounds (sample_from_distribution) or an item_set")
+            else:
+                sample_left_bound, sample_right_bound = 0.1 * min(container_size), 0.5 * min(container_size)
         if LNES not in _LNES:
             raise NotImplementedError("LNES=%r" % (LNES,))
         self._L = _lib.load()
@@ -175,7 +187,11 @@ class PctVecEnv(VecEnv):
         self.env_id_base = int(env_id_base)
         self.strict = strict
 
-        if self.continuous:
+        if self.continuous and self._cont_from_set:
+            items = np.ascontiguousarray(np.rint(np.asarray(item_set, dtype=np.float64).reshape(-1, 3) * 1000).astype(np.int32))
+            _lib.check(self._L.pct_set_item_set(self._h, items.ctypes.data, items.shape[0]))
+            self.item_set = items
+        elif self.continuous:
             _lib.check(self._L.pct_set_sample_bounds(self._h, int(round(sample_left_bound * 1000)),
                                                      int(round(sample_right_bound * 1000))))
             self.item_set = None
@@ -344,6 +360,29 @@ class PctVecEnv(VecEnv):
             _lib.check(self._L.pct_step_index(self._h, idx.data_ptr(), self._stream()))
         return self._obs, self._reward.unsqueeze(1), (1 - self._done.to(torch.float32)).unsqueeze(1)
 
+    def step_into(self, leaf_index, obs_next, reward=None, mask=None):
+        """Fused rollout edge (storage.py:33-39 + train_tools.py:66-70 in ONE launch): steps every env with the
+        device int64 leaf index and has the transition kernel write the new observation (every row) straight
+        into `obs_next` (float32, N * (I+L+1) * 9 contiguous elements, e.g. rollout.obs[t + 1]), the reward into
+        `reward` (float32 [N] / [N,1]) and 1 - done into `mask` (float32 [N] / [N,1]).  No host synchronisation,
+        no copy kernels; `current_obs()` then refers to `obs_next`."""
+        idx = leaf_index.reshape(self.N).to(device=self.device, dtype=torch.int64).contiguous()
+        for t in (obs_next, reward, mask):
+            if t is not None and not (t.is_contiguous() and t.dtype == torch.float32 and t.device == self.device):
+                raise ValueError("rollout slots must be contiguous float32 tensors on the env's device")
+        if obs_next.numel() != self.N * self.row_len:
+            raise ValueError("obs_next must hold N x (I+L+1) x 9 floats")
+        self._actions_keepalive = (idx, obs_next, reward, mask)
+        with torch.cuda.device(self._dev_index):
+            _lib.check(self._L.pct_bind_rollout_slot(self._h, obs_next.data_ptr(),
+                                                     reward.data_ptr() if reward is not None else None,
+                                                     mask.data_ptr() if mask is not None else None))
+            _lib.check(self._L.pct_step_index(self._h, idx.data_ptr(), self._stream()))
+        self._obs = obs_next.view(self.N, self.row_len)
+        if reward is not None:
+            self._reward = reward.view(self.N)
+        return self._obs
+
     def terminal_stats(self):
         """(done bool [N], counter int32 [N], ratio float64 [N]) of the last step (one sync)."""
         return self._done.bool().cpu().numpy(), self._counter.cpu().numpy(), self._ratio.cpu().numpy()
@@ -465,17 +504,21 @@ def make_vec_envs(args, log_dir=None, allow_early_resets=True):
 
 
 def evaluate_heuristic(env, name, episodes):
-    """heuristic.py's evaluation loop on the batched env: runs heuristic `name` on every env of `env`
-    until `episodes` episodes have finished in total (counted in completion order) and returns
-    (mean utilisation, variance of the utilisation, mean number of packed items) -- what
+    """heuristic.py's evaluation loop on the batched env: runs heuristic `name` until every env has finished its
+    quota of ceil(episodes / num_envs) episodes -- each env contributes the same number, its FIRST ones, so short
+    episodes are not over-represented the way "first `episodes` completions overall" would -- and returns (mean
+    utilisation, variance of the utilisation, mean number of packed items) over those, what
     heuristic.py:226,298,425,498,569 return for one env.  Observations are not read."""
+    quota = -(-int(episodes) // env.num_envs)
+    got = np.zeros(env.num_envs, np.int64)
     util, length = [], []
     env.reset()
-    while len(util) < episodes:
+    while (got < quota).any():
         env.step_heuristic(name, 1)
         _, _, done, infos = env.step_wait()
-        for i in np.nonzero(done)[0]:
+        for i in np.nonzero(done & (got < quota))[0]:
             util.append(infos[i]["ratio"])
             length.append(infos[i]["counter"])
-    util, length = np.asarray(util[:episodes]), np.asarray(length[:episodes])
+            got[i] += 1
+    util, length = np.asarray(util), np.asarray(length)
     return float(util.mean()), float(util.var()), float(length.mean())

@@ -109,9 +109,12 @@ class OracleVecEnv(object):
         self._check(L.pcto_create(ctypes.byref(cfg), ctypes.byref(self._h)))
         L.pcto_set_num_threads(threads)
         L.pcto_set_shuffle_seed(self._h, ctypes.c_uint64(shuffle_seed))
-        if env_kind == 1:
+        if env_kind == 1 and sample_bounds is not None:
             lo, hi = sample_bounds
             self._check(L.pcto_set_sample_bounds(self._h, int(round(lo * 1000)), int(round(hi * 1000))))
+        elif env_kind == 1:  # not sample_from_distribution: items from item_set (bin units -> 1e-3 lattice)
+            items = np.ascontiguousarray(np.rint(np.asarray(item_set, dtype=np.float64).reshape(-1, 3) * 1000).astype(np.int32))
+            self._check(L.pcto_set_item_set(self._h, items.ctypes.data, items.shape[0]))
         else:
             items = np.ascontiguousarray(np.asarray(item_set, dtype=np.int32).reshape(-1, 3))
             self._check(L.pcto_set_item_set(self._h, items.ctypes.data, items.shape[0]))

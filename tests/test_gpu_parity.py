@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.common import (case_density, LNES_CODE, CONT_CASES, DATASET_CASES, GOLDEN, GOLDEN_CASES, dataset_trajectories, gather_rows, hash_policy_index, item_set_range, load_case,
+from tests.common import (case_items, case_density, LNES_CODE, CONT_CASES, DATASET_CASES, GOLDEN, GOLDEN_CASES, dataset_trajectories, gather_rows, hash_policy_index, item_set_range, load_case,
                           make_stream)
 
 pytestmark = pytest.mark.gpu
@@ -21,7 +21,7 @@ def _pkg():
 
 def _make(c, stream, **kw):
     return _pkg().PctVecEnv(c["N"], setting=c["setting"], container_size=c["container"],
-                            item_set=item_set_range(c["lo"], c["hi"]), internal_node_holder=c["I"],
+                            item_set=case_items(c), internal_node_holder=c["I"],
                             leaf_node_holder=c["L"], env_id_base=c["base"], item_stream=stream, device="cuda:0",
                             LNES=c.get("lnes", "EMS"), **kw)
 
@@ -388,7 +388,7 @@ def test_hip_dataset_semantics_match_reference(name, tmp_path):
     kw = dict(setting=c["setting"], container_size=c["container"], internal_node_holder=c["I"], leaf_node_holder=c["L"],
               env_id_base=c["base"], data_name=path, load_test_data=True, device="cuda:0")
     if c["kind"] == "discrete":
-        env = _pkg().PctVecEnv(c["N"], item_set=item_set_range(c["lo"], c["hi"]), **kw)
+        env = _pkg().PctVecEnv(c["N"], item_set=case_items(c), **kw)
     else:
         env = _pkg().PctVecEnv(c["N"], continuous=True, sample_left_bound=c["lo"], sample_right_bound=c["hi"], **kw)
     obs = env.reset()
@@ -484,7 +484,7 @@ def test_hip_expansion_schemes_match_oracle_many_small_items(lnes, setting):
 def test_hip_heuristics_match_reference_loops(name, heur):
     """pct_step_heuristic against the per-episode results of the reference's own loops (heuristic.py)."""
     c, z = load_case(name)
-    env = _pkg().PctVecEnv(1, setting=c["setting"], container_size=c["container"], item_set=item_set_range(c["lo"], c["hi"]),
+    env = _pkg().PctVecEnv(1, setting=c["setting"], container_size=c["container"], item_set=case_items(c),
                            internal_node_holder=c["I"], leaf_node_holder=c["L"], item_stream=z["stream"], device="cuda:0")
     env.reset()
     util, length = [], []

@@ -10,14 +10,14 @@ import numpy as np
 import pytest
 
 from oracle.oracle_lib import OracleVecEnv, pyset_order
-from tests.common import case_density, LNES_CODE, CONT_CASES, DATASET_CASES, GOLDEN_CASES, ORACLE_ONLY_CASES, dataset_trajectories, gather_rows, hash_policy_index, item_set_range, load_case, GOLDEN
+from tests.common import case_items, case_density, LNES_CODE, CONT_CASES, DATASET_CASES, GOLDEN_CASES, ORACLE_ONLY_CASES, dataset_trajectories, gather_rows, hash_policy_index, item_set_range, load_case, GOLDEN
 
 
 @pytest.mark.parametrize("name", GOLDEN_CASES + ORACLE_ONLY_CASES)
 def test_oracle_matches_reference_fixture_fused_policy(name):
     c, z = load_case(name)
     env = OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"],
-                       item_set=item_set_range(c["lo"], c["hi"]), internal_node_holder=c["I"],
+                       item_set=case_items(c), internal_node_holder=c["I"],
                        leaf_node_holder=c["L"], env_id_base=c["base"], lnes=LNES_CODE[c.get("lnes", "EMS")])
     env.set_item_stream(z["stream"])
     if case_density(z) is not None:
@@ -41,7 +41,7 @@ def test_oracle_action_forms_agree(mode):
     name = "discrete_s2_rect_60_30"
     c, z = load_case(name)
     env = OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"],
-                       item_set=item_set_range(c["lo"], c["hi"]), internal_node_holder=c["I"],
+                       item_set=case_items(c), internal_node_holder=c["I"],
                        leaf_node_holder=c["L"], env_id_base=c["base"])
     env.set_item_stream(z["stream"])
     env.reset()
@@ -193,7 +193,7 @@ def test_oracle_dataset_semantics_match_reference(name):
     trajs = dataset_trajectories(z)
     dens = [t[:, 3] for t in trajs] if c["setting"] == 3 else None
     if c["kind"] == "discrete":
-        env = OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"], item_set=item_set_range(c["lo"], c["hi"]),
+        env = OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"], item_set=case_items(c),
                            internal_node_holder=c["I"], leaf_node_holder=c["L"], env_id_base=c["base"])
         env.set_item_dataset([t[:, :3].astype(np.int32) for t in trajs], dens)
     else:
@@ -238,7 +238,7 @@ def test_oracle_heuristics_match_reference_loops(name, heur):
     per-episode utilisation and number of packed items of the same item stream."""
     from tests.common import HEUR_CODE
     c, z = load_case(name)
-    env = OracleVecEnv(1, setting=c["setting"], container_size=c["container"], item_set=item_set_range(c["lo"], c["hi"]),
+    env = OracleVecEnv(1, setting=c["setting"], container_size=c["container"], item_set=case_items(c),
                        internal_node_holder=c["I"], leaf_node_holder=c["L"])
     env.set_item_stream(z["stream"])
     env.reset()

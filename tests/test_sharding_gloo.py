@@ -91,7 +91,7 @@ def test_two_rank_shards_equal_one_batch(tmp_path):
 def test_two_rank_shards_equal_one_batch_counter_keyed_streams(tmp_path, variant):
     """densities, shuffle priorities, item picks and the RANDOM heuristic's draw are all keyed by the
     global env id: two shards reproduce the single batch"""
-    total, steps, world = 10, 30, 2
+    total, steps, world = 11, 30, 2  # 5 + 6: unequal shards go through the padded gather
     mp.spawn(_worker, args=(world, _free_port(), total, steps, str(tmp_path), variant), nprocs=world, join=True)
     env = _make(total, 0, variant)
     env.set_sampler(1234)

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import oracle.oracle_lib as ol
-from tests.common import case_density, CONT_STAB_CASES, GOLDEN, STAB_CASES, item_set_range, load_case, make_stream
+from tests.common import case_items, case_density, CONT_STAB_CASES, GOLDEN, STAB_CASES, item_set_range, load_case, make_stream
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 VARIANT = os.path.join(HERE, "host", "libpct_oracle_prodstab.so")
@@ -34,7 +34,7 @@ class _Variant(object):
 def test_product_stability_matches_reference_fixture(name):
     c, z = load_case(name)
     with _Variant():
-        env = ol.OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"], item_set=item_set_range(c["lo"], c["hi"]),
+        env = ol.OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"], item_set=case_items(c),
                               internal_node_holder=c["I"], leaf_node_holder=c["L"], env_id_base=c["base"])
         env.set_item_stream(z["stream"])
         if case_density(z) is not None:
