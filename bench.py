@@ -166,6 +166,10 @@ def main():
                     help="split each GPU's envs into this many independently stepped groups, one HIP stream each "
                          "(1 = one batch per step, the headline configuration)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
+    ap.add_argument("--no-overflow-retry", action="store_true",
+                    help="discrete env: do not enqueue the large-capacity retry pass behind every transition (the product "
+                         "default enqueues it: an env that outgrows its LDS lists is re-run instead of terminated; costs one "
+                         "more, usually empty, kernel launch per step)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -198,7 +202,7 @@ def main():
     def make_env(g):
         base = rank * n_local + g * n_grp
         kw = dict(setting=w["setting"], container_size=w["container"], internal_node_holder=w["I"], leaf_node_holder=w["L"],
-                  seed=4, env_id_base=base, device=dev, monitor=False)
+                  seed=4, env_id_base=base, device=dev, monitor=False, overflow_retry=not args.no_overflow_retry)
         if w["cont"]:
             return pkg.PctVecEnv(n_grp, continuous=True, sample_left_bound=w["bounds"][0], sample_right_bound=w["bounds"][1], **kw)
         return pkg.PctVecEnv(n_grp, item_set=item_set(), **kw)
@@ -291,6 +295,7 @@ def main():
             "global_envs": world * n_local,
             "mode": args.mode,
             "pipelines": P,
+            "overflow_retry_pass": not args.no_overflow_retry,
             "parallelism": "envs sharded by global id x%d, no collective on the step path" % world,
         },
         "roofline": {

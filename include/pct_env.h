@@ -115,15 +115,23 @@ typedef struct pct_config {
   int32_t lnes;                 /* PCT_LNES_* */
   int32_t env_id_base;          /* global id of local env 0 (multi-GPU sharding: env e of
                                    the job lives on rank e / num_envs) */
-  int32_t ems_capacity;         /* EMS kept per env after elimination; 0 = default (128 for discrete
-                                   bins up to 12 per axis, else 256); overflow -> PCT_FLAG_EMS_OVERFLOW */
-  int32_t candidate_capacity;   /* hash-table slots for the leaf-candidate set;
-                                   0 = default (2048; 8192 for discrete bins above 12 per axis);
-                                   8 * 4^k; overflow -> PCT_FLAG_CANDIDATE_OVERFLOW */
+  int32_t ems_capacity;         /* EMS kept per env after elimination (the LDS list of the normal pass); 0 =
+                                   default (128 for bins up to 12 per axis, else 256 discrete / 768 continuous) */
+  int32_t candidate_capacity;   /* hash-table slots for the leaf-candidate set (LDS table of the normal pass);
+                                   0 = default (2048; 8192 for discrete / 32768, in HBM, for continuous bins above
+                                   12 per axis); 8 * 4^k.
+                                   An env that outgrows either list is NOT terminated: it is handed, state untouched,
+                                   to a large-capacity retry pass enqueued right behind the normal one (setting 2:
+                                   discrete 4x the EMS list and, LDS permitting, 4x the table; continuous a 32768-slot
+                                   table in HBM).  Only what outgrows the retry pass too raises
+                                   PCT_FLAG_EMS_OVERFLOW / PCT_FLAG_CANDIDATE_OVERFLOW. */
   int32_t shuffle;              /* 1: permute the candidate list before the first-L cut
                                    (bin3D.py:114-115 `--shuffle`); see pct_shuffle_priority */
-  int32_t reserved[3];
+  int32_t reserved[3];          /* [0]: PCT_OVERFLOW_RETRY_* (discrete env); others 0 */
 } pct_config;
+#define PCT_OVERFLOW_RETRY_ON 0  /* default: the retry pass is enqueued with every transition (a 16-block kernel that
+                                    exits at once when no env overflowed: about 3 us per step on MI355X) */
+#define PCT_OVERFLOW_RETRY_OFF 1 /* no retry pass: an overflow raises its flag and terminates the env */
 
 typedef struct pct_env pct_env;
 

@@ -22,7 +22,12 @@ struct DiscreteParams {
   int shuffle;
   int full_obs; /* 1: the observation buffer was (re)bound since the last launch -- rewrite every row */
   unsigned long long shuffle_seed;
-  int ems_cap, cand_cap;
+  int ems_cap, cand_cap; /* capacities of THIS launch's LDS lists (the retry pass has larger ones) */
+  int ems_stride;        /* row stride of the HBM EMS state = the largest ems_cap of any pass */
+  int retry_mode;        /* != 0: this launch is the large-capacity retry pass (value = offset, +1 / -1, of the
+                            other counter of the ping-pong pair, which it zeroes for the next step) */
+  int* retry_count;      /* this step's counter of envs queued by the normal pass, or null: no retry pass */
+  int* retry_ids;        /* [N] */
   int key_bytes; /* 4: six 5-bit coords (bins <= 31); 8: six 10-bit coords (<= 1023) */
   // item source
   int source, n_items, env_id_base;

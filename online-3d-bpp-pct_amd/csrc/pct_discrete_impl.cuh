@@ -1171,7 +1171,7 @@ __device__ inline void write_obs(const DiscreteParams& p, int e, const Lds<K, BI
 template <typename K, int BITS>
 __device__ inline void load_state(const DiscreteParams& p, int e, Lds<K, BITS>& l, EnvRegs& r, int lane,
                                   bool need_boxes, bool need_leaves) {
-  const K* g_ems = reinterpret_cast<const K*>(p.ems) + (size_t)e * p.ems_cap;
+  const K* g_ems = reinterpret_cast<const K*>(p.ems) + (size_t)e * p.ems_stride;
   const K* g_box = reinterpret_cast<const K*>(p.boxes) + (size_t)e * p.I;
   const K* g_leaf = reinterpret_cast<const K*>(p.leaves) + (size_t)e * p.L;
   const int16_t* g_h = p.hmap + (size_t)e * p.AA;
@@ -1180,7 +1180,7 @@ __device__ inline void load_state(const DiscreteParams& p, int e, Lds<K, BITS>& 
   // first (reading past n_ems stays inside the env's slice), so that one memory round trip covers
   // the whole state
   const K e0 = g_ems[lane];
-  const K e1 = (lane + 64 < p.ems_cap) ? g_ems[lane + 64] : (K)0;
+  const K e1 = (lane + 64 < p.ems_stride) ? g_ems[lane + 64] : (K)0;
   const int16_t h0 = lane < p.AA ? g_h[lane] : (int16_t)0;
   const int16_t h1 = lane + 64 < p.AA ? g_h[lane + 64] : (int16_t)0;
   r.n_ems = sc[0]; r.n_boxes = sc[1]; r.n_leaf = sc[2];
@@ -1191,9 +1191,10 @@ __device__ inline void load_state(const DiscreteParams& p, int e, Lds<K, BITS>& 
   r.vol = (int64_t)(((uint64_t)(uint32_t)sc[11] << 32) | (uint32_t)sc[10]);
   r.traj = sc[12];
   r.oc = (uint32_t)sc[13];
-  if (lane < r.n_ems) l.ems_a[lane] = e0;
-  if (lane + 64 < r.n_ems) l.ems_a[lane + 64] = e1;
-  for (int i = 128 + lane; i < r.n_ems; i += 64) l.ems_a[i] = g_ems[i];
+  const int n_fit = r.n_ems < p.ems_cap ? r.n_ems : p.ems_cap;  // a longer list belongs to the retry pass (caller checks)
+  if (lane < n_fit) l.ems_a[lane] = e0;
+  if (lane + 64 < n_fit) l.ems_a[lane + 64] = e1;
+  for (int i = 128 + lane; i < n_fit; i += 64) l.ems_a[i] = g_ems[i];
   if (need_boxes)
     for (int i = lane; i < r.n_boxes; i += 64) l.box[i] = g_box[i];
   if (need_leaves)
@@ -1207,7 +1208,7 @@ __device__ inline void load_state(const DiscreteParams& p, int e, Lds<K, BITS>& 
 
 template <typename K, int BITS>
 __device__ inline void store_state(const DiscreteParams& p, int e, const Lds<K, BITS>& l, const EnvRegs& r, int lane) {
-  K* g_ems = reinterpret_cast<K*>(p.ems) + (size_t)e * p.ems_cap;
+  K* g_ems = reinterpret_cast<K*>(p.ems) + (size_t)e * p.ems_stride;
   K* g_box = reinterpret_cast<K*>(p.boxes) + (size_t)e * p.I;
   K* g_leaf = reinterpret_cast<K*>(p.leaves) + (size_t)e * p.L;
   int16_t* g_h = p.hmap + (size_t)e * p.AA;
@@ -1697,21 +1698,11 @@ __device__ inline void decode_leaf(const EnvRegs& r, bool zero_row, int xs, int 
 
 enum { ACT_ROWS = 0, ACT_INDEX = 1, ACT_HASH = 2, ACT_RESET = 3, ACT_HEUR = 4 /* row_len = PCT_HEUR_* */ };
 
+// one env, one launch's worth of transitions (the body of the kernel below)
 template <typename K, int BITS, int ACT, bool TIMED, bool STAB, int SCHEME, bool SHUFFLE>
-// the plain setting-2 kernels are held to 128 VGPRs (4 waves per SIMD = 16 resident envs per CU, the
-// occupancy the LDS layout is sized for); the float64 stability code and the timed build are not
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STAB ? 1 : 4)))
-pct_discrete_kernel(DiscreteParams p, const void* __restrict__ actions,
-                                                          int row_len, int n_steps,
-                                                          const int32_t* __restrict__ env_ids, int n_ids) {
-  extern __shared__ __align__(16) unsigned char smem[];
+__device__ inline void discrete_env_steps(const DiscreteParams& p, const void* __restrict__ actions, int row_len, int n_steps,
+                                          int e, unsigned char* smem) {
   const int lane = threadIdx.x;
-  int e = blockIdx.x;
-  if (ACT == ACT_RESET && env_ids) {
-    if (e >= n_ids) return;
-    e = env_ids[e];
-    if (e < 0 || e >= p.N) return;
-  }
   Lds<K, BITS> l = carve_lds<K, BITS>(p, smem);
   EnvRegs r;
   PhaseTimer<TIMED> tm;
@@ -1736,12 +1727,29 @@ pct_discrete_kernel(DiscreteParams p, const void* __restrict__ actions,
   }
   tm.tick(PH_LOAD);
   float* obs = p.obs + (size_t)e * p.row_len;
+  // An env whose EMS list or candidate set outgrows this launch's LDS capacities is handed, state untouched,
+  // to the large-capacity retry pass (if there is one) instead of being flagged and terminated: nothing of
+  // its state is stored here, and whatever outputs it already wrote are written again, identically up to the
+  // point of the overflow and correctly beyond, by the retry.
+  const uint32_t flags_in = r.flags;
+  const bool can_retry = p.retry_count != nullptr && !p.retry_mode && !STAB;
+  auto overflowed = [&]() -> bool {
+    return can_retry && ((r.flags & ~flags_in) & (PCT_FLAG_EMS_OVERFLOW | PCT_FLAG_CANDIDATE_OVERFLOW)) != 0;
+  };
+  if (can_retry && r.n_ems > p.ems_cap && ACT != ACT_RESET) {
+    if (lane == 0) p.retry_ids[atomicAdd(p.retry_count, 1)] = e;
+    return;
+  }
 
   if (ACT == ACT_RESET) {
     space_reset<K, BITS>(p, l, r, lane);
     __syncthreads();
     draw_item(p, e, r);
     leaf_nodes<K, BITS, STAB, SCHEME, SHUFFLE>(p, e, l, r, lane, tm);
+    if (overflowed()) {
+      if (lane == 0) p.retry_ids[atomicAdd(p.retry_count, 1)] = e;
+      return;
+    }
     write_obs<K, BITS>(p, e, l, r, lane, obs, true, -1);
     store_state<K, BITS>(p, e, l, r, lane);
     return;
@@ -1782,6 +1790,10 @@ pct_discrete_kernel(DiscreteParams p, const void* __restrict__ actions,
     if (bad) r.flags |= PCT_FLAG_BAD_ACTION;  // ValueError in list.remove, D/bin3D.py:144-145
     const bool ended = transition<K, BITS, STAB, SCHEME>(p, e, l, r, lane, bad, flag, lx, ly, bx, by, bz, tm, giveup);
     leaf_nodes<K, BITS, STAB, SCHEME, SHUFFLE>(p, e, l, r, lane, tm);
+    if (overflowed()) {
+      if (lane == 0) p.retry_ids[atomicAdd(p.retry_count, 1)] = e;
+      return;
+    }
     write_obs<K, BITS>(p, e, l, r, lane, obs, ended || (p.full_obs != 0 && it == 0), ended ? -1 : r.n_boxes - 1);
     __syncthreads();
     tm.tick(PH_OBS);
@@ -1789,6 +1801,35 @@ pct_discrete_kernel(DiscreteParams p, const void* __restrict__ actions,
   store_state<K, BITS>(p, e, l, r, lane);
   tm.tick(PH_STORE);
   if (TIMED && lane == 0) tm.flush(p.timing + (size_t)e * PCT_TIMING_SLOTS, n_steps);
+}
+
+template <typename K, int BITS, int ACT, bool TIMED, bool STAB, int SCHEME, bool SHUFFLE>
+// the plain setting-2 kernels are held to 128 VGPRs (4 waves per SIMD = 16 resident envs per CU, the
+// occupancy the LDS layout is sized for); the float64 stability code and the timed build are not
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STAB ? 1 : 4)))
+pct_discrete_kernel(DiscreteParams p, const void* __restrict__ actions,
+                                                          int row_len, int n_steps,
+                                                          const int32_t* __restrict__ env_ids, int n_ids) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  if (p.retry_mode) {
+    // large-capacity pass: a small grid strides over the envs the normal pass queued (usually none)
+    // p.retry_count points at this step's counter of a ping-pong pair; the other one (used by the next step's
+    // normal pass, which cannot start before this kernel ends) is zeroed here -- no memset between launches
+    const int limit = *p.retry_count;
+    if (blockIdx.x == 0 && threadIdx.x == 0) p.retry_count[p.retry_mode] = 0;  // retry_mode = +1 / -1: offset of the other
+    for (int w = blockIdx.x; w < limit; w += gridDim.x) {
+      discrete_env_steps<K, BITS, ACT, TIMED, STAB, SCHEME, SHUFFLE>(p, actions, row_len, n_steps, p.retry_ids[w], smem);
+      __syncthreads();
+    }
+    return;
+  }
+  int e = blockIdx.x;
+  if (ACT == ACT_RESET && env_ids) {
+    if (e >= n_ids) return;
+    e = env_ids[e];
+    if (e < 0 || e >= p.N) return;
+  }
+  discrete_env_steps<K, BITS, ACT, TIMED, STAB, SCHEME, SHUFFLE>(p, actions, row_len, n_steps, e, smem);
 }
 
 }  // namespace pct
@@ -1814,7 +1855,7 @@ inline hipError_t launch_typed(const DiscreteParams& p, int act, const void* act
   const bool timed = p.timing != nullptr && act != ACT_RESET;
   const bool stab = p.setting != 2;
   const int scheme = p.lnes == PCT_LNES_EMS ? 0 : 1;  // 1: every other expansion, dispatched inside the kernel
-  int grid = (act == ACT_RESET && env_ids) ? n_ids : p.N;
+  int grid = p.retry_mode ? n_ids : ((act == ACT_RESET && env_ids) ? n_ids : p.N);
   if (grid <= 0) return hipSuccess;
 #define PCT_KERN(A, T, S, C) (p.shuffle ? pct_discrete_kernel<K, BITS, A, false, S, C, true> : pct_discrete_kernel<K, BITS, A, T, S, C, false>)
 #define PCT_LAUNCH(A)                                                                                        \

@@ -41,6 +41,10 @@ struct pct_env {
   pct::ContinuousParams cp_retry; /* large-capacity HBM-table pass for envs whose candidate set outgrew LDS */
   bool has_retry;
   int cp_retry_blocks;
+  bool has_dretry;      /* discrete env: large-capacity retry pass for envs that outgrow the LDS lists */
+  int d_retry_ems, d_retry_cand;
+  int* d_retry_base;    /* [2] ping-pong queue counters */
+  int d_retry_parity;
   bool continuous;
   // owned device memory
   std::vector<void*> owned;
@@ -140,7 +144,21 @@ int launch(pct_env* h, int act, const void* actions, int row_len, int n_steps, c
     }
     if (act != ACT_RESET || !ids) h->dp.full_obs = 0;
   } else {
+    if (h->has_dretry) { /* ping-pong pair of queue counters: this step's is h->d_retry_base[parity] */
+      h->dp.retry_count = h->d_retry_base + h->d_retry_parity;
+    }
     HIP_TRY(pct::launch_discrete(h->dp, act, actions, row_len, n_steps, ids, n_ids, s));
+    if (h->has_dretry) {
+      /* the same step again, with larger LDS lists, for the envs the normal pass queued (usually none: the
+       * small grid then exits at once) */
+      pct::DiscreteParams q = h->dp;
+      q.ems_cap = h->d_retry_ems;
+      q.cand_cap = h->d_retry_cand;
+      q.retry_mode = h->d_retry_parity ? -1 : 1;
+      q.timing = nullptr;
+      HIP_TRY(pct::launch_discrete(q, act, actions, row_len, n_steps, nullptr, 16, s));
+      h->d_retry_parity ^= 1;
+    }
     if (act != ACT_RESET || !ids) h->dp.full_obs = 0; /* every env has rewritten its rows */
   }
   if (h->profiling) HIP_TRY(hipEventRecord(h->ev_pool[slot].second, s));
@@ -211,6 +229,7 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
   h->prof_ms = 0.0;
   h->timing_buf = nullptr;
   h->continuous = cont;
+  h->has_dretry = false;
   memset(&h->cp, 0, sizeof h->cp);
   int rc = use_device(h);
   if (rc) { delete h; return rc; }
@@ -316,6 +335,22 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
   p.ems_cap = ems_cap;
   p.cand_cap = cand_cap;
   p.key_bytes = maxdim <= 31 ? 4 : 8;
+  /* retry pass: four times the EMS list (up to 1024) and, while it still fits the 160 KB of LDS, four times
+   * the candidate table; the HBM EMS rows are as long as the longest list any pass may leave behind.  The
+   * stability settings keep per-box state beyond the lists and run without it (overflow -> flag). */
+  h->d_retry_ems = ems_cap * 4 < 1024 ? ems_cap * 4 : (ems_cap > 1024 ? ems_cap : 1024);
+  h->d_retry_cand = cand_cap;
+  {
+    pct::DiscreteParams t = p;
+    t.ems_cap = h->d_retry_ems;
+    t.cand_cap = cand_cap * 4;
+    if (pct::discrete_lds_bytes(t) <= 160 * 1024) h->d_retry_cand = cand_cap * 4;
+    t.cand_cap = h->d_retry_cand;
+    if (pct::discrete_lds_bytes(t) > 160 * 1024) h->d_retry_ems = ems_cap;
+  }
+  h->has_dretry = cfg->setting == 2 && cfg->reserved[0] != PCT_OVERFLOW_RETRY_OFF &&
+                  (h->d_retry_ems > ems_cap || h->d_retry_cand > cand_cap);
+  p.ems_stride = h->has_dretry ? h->d_retry_ems : ems_cap;
   p.env_id_base = cfg->env_id_base;
   p.source = PCT_ITEMS_NONE;
 
@@ -329,7 +364,7 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
     if (rc) { pct_destroy(h); return rc; }                  \
   } while (0)
   ALLOC(p.hmap, N * p.AA * sizeof(int16_t));
-  ALLOC(p.ems, N * p.ems_cap * p.key_bytes);
+  ALLOC(p.ems, N * p.ems_stride * p.key_bytes);
   ALLOC(p.boxes, N * p.I * p.key_bytes);
   ALLOC(p.leaves, N * p.L * p.key_bytes);
   ALLOC(p.scalars, N * PCT_SCALARS * sizeof(int32_t));
@@ -342,6 +377,12 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
     ALLOC(p.st_poly, N * p.I * pct::STAB_PMAX * 2 * sizeof(double));
     ALLOC(p.st_den, N * p.I * sizeof(double));
     ALLOC(p.st_alias, N * p.I * sizeof(int));
+  }
+  if (h->has_dretry) {
+    ALLOC(h->d_retry_base, 2 * sizeof(int));
+    p.retry_count = h->d_retry_base;
+    h->d_retry_parity = 0;
+    ALLOC(p.retry_ids, N * sizeof(int));
   }
   ALLOC(h->own_flags, N * sizeof(uint32_t));
   ALLOC(h->own_obs, N * p.row_len * sizeof(float));
@@ -697,8 +738,8 @@ int pct_debug_state(pct_env* h, int32_t e, int32_t* heightmap, int32_t* ems, int
   }
   if (ems) {
     int n = sc[0];
-    std::vector<unsigned char> raw((size_t)p.ems_cap * p.key_bytes);
-    HIP_TRY(hipMemcpy(raw.data(), (const char*)p.ems + (size_t)e * p.ems_cap * p.key_bytes, raw.size(),
+    std::vector<unsigned char> raw((size_t)p.ems_stride * p.key_bytes);
+    HIP_TRY(hipMemcpy(raw.data(), (const char*)p.ems + (size_t)e * p.ems_stride * p.key_bytes, raw.size(),
                       hipMemcpyDeviceToHost));
     int bits = p.key_bytes == 4 ? 5 : 10;
     for (int i = 0; i < n && i < cap_ems; i++) {

@@ -130,7 +130,7 @@ class PctVecEnv(VecEnv):
                  load_test_data=False, internal_node_holder=80, leaf_node_holder=50, LNES="EMS", shuffle=False,
                  sample_from_distribution=False, sample_left_bound=None, sample_right_bound=None,
                  device="cuda:0", seed=0, env_id_base=0, item_stream=None, continuous=False, monitor=True,
-                 strict=True, ems_capacity=0, candidate_capacity=0):
+                 strict=True, ems_capacity=0, candidate_capacity=0, overflow_retry=True):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise PctEnvError("PctVecEnv runs on an AMD GPU only (device=%r); there is no CPU path" % (device,))
@@ -175,6 +175,7 @@ class PctVecEnv(VecEnv):
         cfg.shuffle = 1 if shuffle else 0  # bin3D.py:114-115; see include/pct_env.h pct_shuffle_priority
         cfg.ems_capacity = int(ems_capacity)
         cfg.candidate_capacity = int(candidate_capacity)
+        cfg.reserved[0] = 0 if overflow_retry else 1  # include/pct_env.h PCT_OVERFLOW_RETRY_*
         self._h = ctypes.c_void_p()
         with torch.cuda.device(dev_index):
             torch.cuda.init()

@@ -171,3 +171,24 @@ def test_evaluate_heuristic_gives_every_env_the_same_quota():
     assert len(util) == 256 and abs(np.mean(util) - mean) < 1e-12
     env.close()
     env2.close()
+
+
+@pytest.mark.parametrize("name,ems,cand", [("discrete_s2_10_80_50", 64, 512), ("discrete_s2_20_120_400", 64, 2048),
+                                           ("discrete_s2_cp_10_80_50", 64, 512)])
+def test_discrete_overflow_is_rerun_with_larger_lists(name, ems, cand):
+    """Capacities far too small for the config: every env that outgrows the LDS lists is handed, state untouched,
+    to the large-capacity retry pass, so the trajectory still equals the reference fixture and no overflow flag
+    is raised (the discrete counterpart of the continuous env's HBM-table retry)."""
+    c, z = load_case(name)
+    env = _pkg().PctVecEnv(c["N"], setting=c["setting"], container_size=c["container"], item_set=case_items(c),
+                           internal_node_holder=c["I"], leaf_node_holder=c["L"], env_id_base=c["base"], item_stream=z["stream"],
+                           LNES=c.get("lnes", "EMS"), device="cuda:0", ems_capacity=ems, candidate_capacity=cand)
+    obs = env.reset()
+    for t in range(c["steps"]):
+        assert np.array_equal(obs.cpu().numpy(), z["obs"][t]), (name, t)
+        env.step_hash_policy(1)
+        obs, reward, done, infos = env.step_wait()
+        assert np.array_equal(done.astype(np.uint8), z["done"][t]), (name, t)
+        assert np.array_equal(reward[:, 0].numpy().astype(np.float64), z["reward"][t].astype(np.float32).astype(np.float64))
+    assert not env.error_flags.any(), np.unique(env.error_flags)
+    env.close()
