@@ -30,6 +30,14 @@ namespace pct {
 
 __device__ inline double around6(double x) { return rint(x * 1e6) / 1e6; }  // np.around(x, 6)
 __device__ inline int klat(double x) { return (int)rint(x * 1e6); }
+// An EMS coordinate is always the result of np.around(., 6) (or a bin size, or 0): the double nearest to k / 1e6
+// for an integer k.  The lists hold k (int32: half the LDS and HBM of the double); lat2d gives the double back
+// EXACTLY -- one Newton step on k * RN(1e-6) with fused residuals equals the correctly rounded quotient for
+// every |k| <= 2e8 (checked exhaustively on the host), at three instructions instead of a float64 division.
+__device__ inline double lat2d(int k) {
+  const double a = (double)k, q1 = a * 1e-6;
+  return fma(fma(-1e6, q1, a), 1e-6, q1);
+}
 __device__ inline double wave_max_f64(double v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
@@ -75,47 +83,50 @@ struct CRegs {  // wave-uniform per-env scalars
 };
 
 struct CLds {
-  double* ems;    // [6][ems_cap] SoA current EMS list
-  double* ems_b;  // [6][ems_cap] scratch during GENEMS (aliases the hash table)
-  uint32_t* tab;  // [cand_cap + cand_cap/4] hash table regions (aliases ems_b)
-  double* box;    // [6][I] lx,ly,lz,xe,ye,top
-  double* leaf;   // [5][L] xs,ys,zs,xe,ye (the sixth column of a leaf row is the constant H)
+  int32_t* emsk;  // [6][ems_cap] SoA current EMS list, lattice 1e-6 (see lat2d)
+  int32_t* emsb;  // [6][scap] children of the step's GENEMS (aliases the idle hash table)
+  uint32_t* tab;  // hash table region (aliases emsb)
+  double* box;    // [6][I] lx,ly,lz,xe,ye,top (stability settings only; setting 2 keeps bk / top)
   double* bsz;    // [3][I] item sizes as placed (x,y,z): (lx + x) - lx need not equal x (stability only)
-  uint64_t* bhash;  // [64]
-  int32_t* bk;      // [4][I] lattice indices of (-lx,-ly,xe,ye)
+  double* top;    // [I] tops of the placed boxes (= box + 5 I under the stability settings)
+  int32_t* bk;    // [4][I] lattice indices of (-lx,-ly,xe,ye)
+  uint16_t* leafg;  // [L] generator ids of the current leaf nodes (the 6-tuples are recomputed from the EMS list)
   uint16_t* pend;   // [128] generator ids waiting for insertion
-  uint16_t* bg;     // [64] generator ids of the batch
   uint16_t* vp;     // [64]
   uint32_t* fpri;   // [order_cap] shuffle priorities of the feasible candidates (shuffle only)
   uint32_t* dd;     // [128] bucket words of the batch de-duplication
 };
 
+// words of the region shared by the hash table and the GENEMS children scratch
+__host__ __device__ inline int cunion_words(const ContinuousParams& p) { return p.union_words; }
+
 __device__ inline CLds carve(const ContinuousParams& p, unsigned char* base) {
   CLds l;
   double* d = reinterpret_cast<double*>(base);
-  l.ems = d; d += 6 * p.ems_cap;
-  l.ems_b = d;
-  l.tab = reinterpret_cast<uint32_t*>(d);
-  d += p.union_doubles;
-  l.box = d; d += 6 * p.I;
-  l.leaf = d; d += 5 * p.L;
-  l.bsz = d; d += (p.setting != 2) ? 3 * p.I : 0;
-  l.bhash = reinterpret_cast<uint64_t*>(d); d += 64;
+  const bool stab = p.setting != 2;
+  l.box = d; d += stab ? 6 * p.I : 0;
+  l.bsz = d; d += stab ? 3 * p.I : 0;
+  l.top = stab ? l.box + 5 * p.I : d; d += stab ? 0 : p.I;
   int32_t* q = reinterpret_cast<int32_t*>(d);
+  l.emsk = q; q += 6 * p.ems_cap;
+  l.emsb = q;
+  l.tab = reinterpret_cast<uint32_t*>(q);
+  q += p.union_words;
   l.bk = q; q += 4 * p.I;
   l.dd = reinterpret_cast<uint32_t*>(q); q += 128;
   uint16_t* h = reinterpret_cast<uint16_t*>(q);
   l.pend = h; h += 128;
-  l.bg = h; h += 64;
   l.vp = h; h += 64;
+  l.leafg = h; h += (p.L + 1) & ~1;
   l.fpri = reinterpret_cast<uint32_t*>(h);
   return l;
 }
 
 size_t continuous_lds_bytes(const ContinuousParams& p) {
-  size_t dbl = (size_t)6 * p.ems_cap + p.union_doubles + (p.setting != 2 ? 9 : 6) * (size_t)p.I + 5 * (size_t)p.L + 64;
-  size_t i32 = 4 * (size_t)p.I + 128;
-  size_t u16 = 128 + 64 + 64 + 2;
+  const bool stab = p.setting != 2;
+  size_t dbl = stab ? 9 * (size_t)p.I : (size_t)p.I;
+  size_t i32 = 6 * (size_t)p.ems_cap + (size_t)p.union_words + 4 * (size_t)p.I + 128;
+  size_t u16 = 128 + 64 + (((size_t)p.L + 1) & ~(size_t)1);
   if (p.shuffle && !p.table_global) u16 += 2 * (size_t)p.order_cap;
   return dbl * 8 + i32 * 4 + u16 * 2 + 16;
 }
@@ -157,8 +168,8 @@ __device__ inline void cdraw_item(const ContinuousParams& p, int e, CRegs& r) {
 // C/space.py:281-303 reset
 __device__ inline void cspace_reset(const ContinuousParams& p, CLds& l, CRegs& r, int lane) {
   if (lane == 0) {
-    l.ems[0 * p.ems_cap] = 0.0; l.ems[1 * p.ems_cap] = 0.0; l.ems[2 * p.ems_cap] = 0.0;
-    l.ems[3 * p.ems_cap] = p.W; l.ems[4 * p.ems_cap] = p.Ly; l.ems[5 * p.ems_cap] = p.H;
+    l.emsk[0 * p.ems_cap] = 0; l.emsk[1 * p.ems_cap] = 0; l.emsk[2 * p.ems_cap] = 0;
+    l.emsk[3 * p.ems_cap] = klat(p.W); l.emsk[4 * p.ems_cap] = klat(p.Ly); l.emsk[5 * p.ems_cap] = klat(p.H);
   }
   r.n_ems = 1;
   r.n_boxes = 0;
@@ -190,8 +201,8 @@ __device__ inline void cand_tuple(const ContinuousParams& p, const CLds& l, cons
   int ei = q / orient, rot = q - ei * orient;
   double sx, sy, sz;
   crot_size(r, rot, sx, sy, sz);
-  double x0 = l.ems[0 * p.ems_cap + ei], y0 = l.ems[1 * p.ems_cap + ei], z0 = l.ems[2 * p.ems_cap + ei];
-  double x1 = l.ems[3 * p.ems_cap + ei], y1 = l.ems[4 * p.ems_cap + ei];
+  double x0 = lat2d(l.emsk[0 * p.ems_cap + ei]), y0 = lat2d(l.emsk[1 * p.ems_cap + ei]), z0 = lat2d(l.emsk[2 * p.ems_cap + ei]);
+  double x1 = lat2d(l.emsk[3 * p.ems_cap + ei]), y1 = lat2d(l.emsk[4 * p.ems_cap + ei]);
   if (corner & 1) { t[0] = x1 - sx; t[3] = x1; } else { t[0] = x0; t[3] = x0 + sx; }
   if (corner & 2) { t[1] = y1 - sy; t[4] = y1; } else { t[1] = y0; t[4] = y0 + sy; }
   t[2] = z0;
@@ -227,14 +238,16 @@ __device__ inline StabState cstab_view(const ContinuousParams& p, int e) {
   return st;
 }
 
-// C/space.py:441-487 GENEMS + :510-528 EliminateInscribedEMS.  l.ems -> l.ems.
+// C/space.py:441-487 GENEMS + :510-528 EliminateInscribedEMS.  l.emsk -> l.emsk.
 __device__ inline void cgenems(const ContinuousParams& p, CLds& l, CRegs& r, int lane, const double loc[6]) {
-  // Survivors (EMS the box does not intersect) stay where they are in l.ems until the end; only the
-  // children go to the scratch list (l.ems_b, [6][scap], aliasing the idle hash table).  The pre-GENEMS
+  // Survivors (EMS the box does not intersect) stay where they are in l.emsk until the end; only the
+  // children go to the scratch list (l.emsb, [6][scap], aliasing the idle hash table).  The pre-GENEMS
   // list is containment-free and a child lies inside its parent, so a survivor can neither be deleted
-  // nor sit inside a child: each child is tested against the survivors and the other children (exact
-  // float compares, non-strict, on the pre-deletion list: identical children delete each other).
-  const int E = r.n_ems, cap = p.ems_cap, scap = p.union_doubles / 6;
+  // nor sit inside a child: each child is tested against the survivors and the other children (non-strict,
+  // on the pre-deletion list: identical children delete each other).  The reference compares the float64
+  // coordinates; they are all of the form lat2d(k), strictly increasing in k, so the lattice integers compare
+  // the same way.  The intersection and usability tests keep the reference's float64 arithmetic.
+  const int E = r.n_ems, cap = p.ems_cap, scap = p.union_words / 6;
   const double lb = p.low_bound;
   const double n0 = -loc[0], n1 = -loc[1], n2 = -loc[2];
   uint32_t* const smask = l.dd;       // [2 per 64-EMS chunk] survivor bits (the de-duplication buckets are idle)
@@ -243,11 +256,12 @@ __device__ inline void cgenems(const ContinuousParams& p, CLds& l, CRegs& r, int
   for (int base = 0; base < E; base += 64) {
     int i = base + lane;
     bool live = i < E;
-    double x1 = 0, y1 = 0, z1 = 0, x2 = 0, y2 = 0, z2 = 0;
+    int k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0, k5 = 0;
     if (live) {
-      x1 = l.ems[0 * cap + i]; y1 = l.ems[1 * cap + i]; z1 = l.ems[2 * cap + i];
-      x2 = l.ems[3 * cap + i]; y2 = l.ems[4 * cap + i]; z2 = l.ems[5 * cap + i];
+      k0 = l.emsk[0 * cap + i]; k1 = l.emsk[1 * cap + i]; k2 = l.emsk[2 * cap + i];
+      k3 = l.emsk[3 * cap + i]; k4 = l.emsk[4 * cap + i]; k5 = l.emsk[5 * cap + i];
     }
+    const double x1 = lat2d(k0), y1 = lat2d(k1), z1 = lat2d(k2), x2 = lat2d(k3), y2 = lat2d(k4), z2 = lat2d(k5);
     // np.around(np.minimum(item, EMS), 6): the rounded values decide (and give the child coordinates)
     double q0 = around6(fmin(n0, -x1)), q1 = around6(fmin(n1, -y1)), q2 = around6(fmin(n2, -z1));
     double q3 = around6(fmin(loc[3], x2)), q4 = around6(fmin(loc[4], y2)), q5 = around6(fmin(loc[5], z2));
@@ -263,19 +277,20 @@ __device__ inline void cgenems(const ContinuousParams& p, CLds& l, CRegs& r, int
     bool c4 = inter && ux && uy && (z2 - z4 + 1e-6 >= lb);  // [x1,y1,z4,x2,y2,z2]
     uint64_t m0 = __ballot(c0), m1 = __ballot(c1), m2 = __ballot(c2), m3 = __ballot(c3), m4 = __ballot(c4);
     int pos = C + rank_below(m0) + rank_below(m1) + rank_below(m2) + rank_below(m3) + rank_below(m4);
-#define PCT_PUT(A, B, Cc, D, Ee, F)                                                                   \
-  do {                                                                                               \
-    if (pos < scap) {                                                                                \
-      l.ems_b[0 * scap + pos] = (A); l.ems_b[1 * scap + pos] = (B); l.ems_b[2 * scap + pos] = (Cc);  \
-      l.ems_b[3 * scap + pos] = (D); l.ems_b[4 * scap + pos] = (Ee); l.ems_b[5 * scap + pos] = (F);  \
-    }                                                                                                \
-    pos++;                                                                                           \
+    const int kx3 = klat(x3), ky3 = klat(y3), kx4 = klat(x4), ky4 = klat(y4), kz4 = klat(z4);  // the rounded values' own k
+#define PCT_PUT(A, B, Cc, D, Ee, F)                                                                \
+  do {                                                                                            \
+    if (pos < scap) {                                                                             \
+      l.emsb[0 * scap + pos] = (A); l.emsb[1 * scap + pos] = (B); l.emsb[2 * scap + pos] = (Cc);  \
+      l.emsb[3 * scap + pos] = (D); l.emsb[4 * scap + pos] = (Ee); l.emsb[5 * scap + pos] = (F);  \
+    }                                                                                             \
+    pos++;                                                                                        \
   } while (0)
-    if (c0) PCT_PUT(x1, y1, z1, x3, y2, z2);
-    if (c1) PCT_PUT(x4, y1, z1, x2, y2, z2);
-    if (c2) PCT_PUT(x1, y1, z1, x2, y3, z2);
-    if (c3) PCT_PUT(x1, y4, z1, x2, y2, z2);
-    if (c4) PCT_PUT(x1, y1, z4, x2, y2, z2);
+    if (c0) PCT_PUT(k0, k1, k2, kx3, k4, k5);
+    if (c1) PCT_PUT(kx4, k1, k2, k3, k4, k5);
+    if (c2) PCT_PUT(k0, k1, k2, k3, ky3, k5);
+    if (c3) PCT_PUT(k0, ky4, k2, k3, k4, k5);
+    if (c4) PCT_PUT(k0, k1, kz4, k3, k4, k5);
 #undef PCT_PUT
     C += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3) + __popcll(m4);
   }
@@ -288,21 +303,21 @@ __device__ inline void cgenems(const ContinuousParams& p, CLds& l, CRegs& r, int
   for (int base = 0; base < C; base += 64) {
     int i = base + lane;
     bool live = i < C;
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
+    int a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
     if (live) {
-      a0 = l.ems_b[0 * scap + i]; a1 = l.ems_b[1 * scap + i]; a2 = l.ems_b[2 * scap + i];
-      a3 = l.ems_b[3 * scap + i]; a4 = l.ems_b[4 * scap + i]; a5 = l.ems_b[5 * scap + i];
+      a0 = l.emsb[0 * scap + i]; a1 = l.emsb[1 * scap + i]; a2 = l.emsb[2 * scap + i];
+      a3 = l.emsb[3 * scap + i]; a4 = l.emsb[4 * scap + i]; a5 = l.emsb[5 * scap + i];
     }
     bool del = false;
     for (int j = 0; j < E; j++) {
       if (!((smask[(j >> 6) * 2 + ((j >> 5) & 1)] >> (j & 31)) & 1u)) continue;  // not a survivor (wave-uniform)
-      double b0 = l.ems[0 * cap + j], b1 = l.ems[1 * cap + j], b2 = l.ems[2 * cap + j];
-      double b3 = l.ems[3 * cap + j], b4 = l.ems[4 * cap + j], b5 = l.ems[5 * cap + j];
+      int b0 = l.emsk[0 * cap + j], b1 = l.emsk[1 * cap + j], b2 = l.emsk[2 * cap + j];
+      int b3 = l.emsk[3 * cap + j], b4 = l.emsk[4 * cap + j], b5 = l.emsk[5 * cap + j];
       del |= (a0 >= b0) & (a1 >= b1) & (a2 >= b2) & (a3 <= b3) & (a4 <= b4) & (a5 <= b5);
     }
     for (int j = 0; j < C; j++) {
-      double b0 = l.ems_b[0 * scap + j], b1 = l.ems_b[1 * scap + j], b2 = l.ems_b[2 * scap + j];
-      double b3 = l.ems_b[3 * scap + j], b4 = l.ems_b[4 * scap + j], b5 = l.ems_b[5 * scap + j];
+      int b0 = l.emsb[0 * scap + j], b1 = l.emsb[1 * scap + j], b2 = l.emsb[2 * scap + j];
+      int b3 = l.emsb[3 * scap + j], b4 = l.emsb[4 * scap + j], b5 = l.emsb[5 * scap + j];
       bool inside = (a0 >= b0) & (a1 >= b1) & (a2 >= b2) & (a3 <= b3) & (a4 <= b4) & (a5 <= b5);
       del |= inside & (j != i);
     }
@@ -316,16 +331,16 @@ __device__ inline void cgenems(const ContinuousParams& p, CLds& l, CRegs& r, int
     int i = base + lane;
     const uint64_t ms = ((uint64_t)smask[(base >> 6) * 2 + 1] << 32) | smask[(base >> 6) * 2];
     bool surv = (ms >> lane) & 1ull;
-    double e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0, e5 = 0;
+    int e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0, e5 = 0;
     if (surv) {
-      e0 = l.ems[0 * cap + i]; e1 = l.ems[1 * cap + i]; e2 = l.ems[2 * cap + i];
-      e3 = l.ems[3 * cap + i]; e4 = l.ems[4 * cap + i]; e5 = l.ems[5 * cap + i];
+      e0 = l.emsk[0 * cap + i]; e1 = l.emsk[1 * cap + i]; e2 = l.emsk[2 * cap + i];
+      e3 = l.emsk[3 * cap + i]; e4 = l.emsk[4 * cap + i]; e5 = l.emsk[5 * cap + i];
     }
     __syncthreads();
     if (surv) {
       int o = out + rank_below(ms);
-      l.ems[0 * cap + o] = e0; l.ems[1 * cap + o] = e1; l.ems[2 * cap + o] = e2;
-      l.ems[3 * cap + o] = e3; l.ems[4 * cap + o] = e4; l.ems[5 * cap + o] = e5;
+      l.emsk[0 * cap + o] = e0; l.emsk[1 * cap + o] = e1; l.emsk[2 * cap + o] = e2;
+      l.emsk[3 * cap + o] = e3; l.emsk[4 * cap + o] = e4; l.emsk[5 * cap + o] = e5;
     }
     out += __popcll(ms);
     __syncthreads();
@@ -339,7 +354,7 @@ __device__ inline void cgenems(const ContinuousParams& p, CLds& l, CRegs& r, int
     if (keep) {
       int o = out + rank_below(mk);
       if (o < cap) {
-        for (int c = 0; c < 6; c++) l.ems[c * cap + o] = l.ems_b[c * scap + i];
+        for (int c = 0; c < 6; c++) l.emsk[c * cap + o] = l.emsb[c * scap + i];
       } else {
         over = true;
       }
@@ -371,7 +386,10 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
   // list(set) as 16-bit generator ids: HBM slice, or -- LDS table -- written over the front of the table
   // region itself once the table is complete (entry k is written after slot k has been read)
   uint16_t* const order = GT ? p.gorder + gslot * (size_t)p.order_cap : reinterpret_cast<uint16_t*>(l.tab);
-  uint32_t toff = table_region(p.cand_cap, size);
+  // LDS table: every size starts at offset 0 (a rebuild first lifts the old table into registers); HBM table:
+  // two regions, ping-pong
+  auto region = [&](uint32_t sz) -> uint32_t { return GT ? table_region(p.cand_cap, sz) : 0u; };
+  uint32_t toff = region(size);
   if (lane < 8) tab_st<GT, uint32_t>(&tabs[toff + lane], EMPTY);
   l.dd[lane] = 0xFFFFFFFFu;
   l.dd[lane + 64] = 0xFFFFFFFFu;
@@ -391,18 +409,17 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
     double t[6];
     cand_tuple(p, l, r, orient, g, t);
     uint64_t hash = tuplehash6d(t);
-    l.bhash[lane] = hash;
-    l.bg[lane] = (uint16_t)g;
     __syncthreads();
-    // exact in-batch de-duplication (first occurrence stays): equal hashes first, then the tuples
-    pending = pending && !batch_find_duplicates<128>(l.dd, pending, hash, lane, cnt, [&](int w) -> bool {
-      if (l.bhash[w] != hash) return false;
+    // exact in-batch de-duplication (first occurrence stays): equal hashes first, then the tuples; the other
+    // lane's hash and generator id come over a shuffle
+    pending = pending && !batch_find_duplicates_shfl<128>(l.dd, pending, hash, g, lane, [&](uint64_t hw, uint32_t gw) -> bool {
+      if (hw != hash) return false;
       double o[6];
-      cand_tuple(p, l, r, orient, l.bg[w], o);
+      cand_tuple(p, l, r, orient, gw, o);
       return tuple_eq(o, t);
     });
     tm.sub_tick(PH_SET_DEDUP);
-    if (fill == 0 && size == 8 && p.cand_cap >= 128) {
+    if (fill == 0 && size == 8 && p.cand_cap >= 512) {
       const uint64_t pm0 = __ballot(pending);
       if (__popcll(pm0) >= 19) {
         // Fast start of a fresh set with >= 19 new keys, as in the discrete kernel
@@ -458,15 +475,24 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
         const bool in32 = lane < 32 && ((occ32 >> lane) & 1u);
         const bool later = (rem >> lane) & 1ull;
         __syncthreads();
-        if (in32) { l.bg[rank_below((uint64_t)occ32)] = (uint16_t)g_s; l.bhash[rank_below((uint64_t)occ32)] = h_s; }
-        if (later) { l.bg[19 + rank_below(rem)] = (uint16_t)g; l.bhash[19 + rank_below(rem)] = hash; }
+        // the reordered batch travels through LDS: hashes in the (idle) bucket words, ids behind the 128 slots
+        // of the new table in the table region (LDS table) or in the pair list's upper half... the ids need
+        // 64 x 2 bytes: the 32 words after the table's first 128
+        uint64_t* const sh = reinterpret_cast<uint64_t*>(l.dd);
+        uint16_t* const sg = reinterpret_cast<uint16_t*>(l.tab + 128);
+        if (in32) { sg[rank_below((uint64_t)occ32)] = (uint16_t)g_s; sh[rank_below((uint64_t)occ32)] = h_s; }
+        if (later) { sg[19 + rank_below(rem)] = (uint16_t)g; sh[19 + rank_below(rem)] = hash; }
         const int total = 19 + __popcll(rem);
-        const uint32_t noff = table_region(p.cand_cap, 128u);
+        const uint32_t noff = region(128u);
         tab_st<GT, uint32_t>(&tabs[noff + lane], EMPTY);
         tab_st<GT, uint32_t>(&tabs[noff + 64 + lane], EMPTY);
         __syncthreads();
-        const uint32_t mg = lane < total ? l.bg[lane] : 0u;
-        const uint64_t mh = lane < total ? l.bhash[lane] : 0ull;
+        const uint32_t mg = lane < total ? sg[lane] : 0u;
+        const uint64_t mh = lane < total ? sh[lane] : 0ull;
+        __syncthreads();
+        l.dd[lane] = 0xFFFFFFFFu;  // back to the all-ones state the de-duplication expects
+        l.dd[lane + 64] = 0xFFFFFFFFu;
+        __syncthreads();
         bool mplaced;
         uint32_t mslot;
         pyset_match<uint32_t, GT>(tabs + noff, 127u, lane < total, mh, lane, false, mplaced, mslot, [&](uint32_t) { return false; });
@@ -507,12 +533,8 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
           cand_overflow = true;
           break;
         }
-        const uint32_t noff = table_region(p.cand_cap, newsize);
-        for (uint32_t s2 = lane; s2 < newsize; s2 += 64) tab_st<GT, uint32_t>(&tabs[noff + s2], EMPTY);
-        __syncthreads();
-        for (uint32_t sb = 0; sb < size; sb += 64) {
-          uint32_t s2 = sb + lane;
-          uint32_t ow = (s2 < size) ? tab_ld<GT, uint32_t>(&tabs[toff + s2]) : EMPTY;
+        const uint32_t noff = region(newsize);
+        auto reinsert = [&](uint32_t ow) {  // one chunk of old slots into the new table, in old-slot order
           bool opart = ow != EMPTY;
           double o[6];
           cand_tuple(p, l, r, orient, opart ? (ow & 0xFFFFu) : 0u, o);
@@ -522,6 +544,50 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
                                     [&](uint32_t) { return false; });
           if (oplaced) tab_st<GT, uint32_t>(&tabs[noff + oslot], ow);
           __syncthreads();
+        };
+        if (!GT && size <= 512) {
+          // same LDS region: lift the old table (<= 512 slots = 8 words per lane) into registers, wipe, re-insert
+          uint32_t oldw[8];
+#pragma unroll
+          for (int c = 0; c < 8; c++) {
+            const uint32_t s2 = (uint32_t)c * 64u + lane;
+            oldw[c] = (s2 < size) ? tabs[toff + s2] : EMPTY;
+          }
+          __syncthreads();
+          for (uint32_t s2 = lane; s2 < newsize; s2 += 64) tabs[noff + s2] = EMPTY;
+          __syncthreads();
+#pragma unroll
+          for (int c = 0; c < 8; c++)
+            if ((uint32_t)c * 64u < size) reinsert(oldw[c]);
+        } else if (!GT) {
+          // an LDS table of 2048 slots growing to 8192: the new table sits behind the old one's region
+          // (cand_cap 8192: table words = 8192 + 2048), the only case of two LDS regions
+          const uint32_t noff2 = size;  // old table at [0, size), new at [size, size + newsize)
+          for (uint32_t s2 = lane; s2 < newsize; s2 += 64) tabs[noff2 + s2] = EMPTY;
+          __syncthreads();
+          for (uint32_t sb = 0; sb < size; sb += 64) {
+            const uint32_t ow = tabs[toff + sb + lane];
+            bool opart = ow != EMPTY;
+            double o[6];
+            cand_tuple(p, l, r, orient, opart ? (ow & 0xFFFFu) : 0u, o);
+            bool oplaced;
+            uint32_t oslot;
+            pyset_match<uint32_t, GT>(tabs + noff2, newsize - 1, opart, tuplehash6d(o), lane, false, oplaced, oslot,
+                                      [&](uint32_t) { return false; });
+            if (oplaced) tabs[noff2 + oslot] = ow;
+            __syncthreads();
+          }
+          toff = noff2;
+          size = newsize;
+          tm.sub_tick(PH_SET_REBUILD);
+          continue;
+        } else {
+          for (uint32_t s2 = lane; s2 < newsize; s2 += 64) tab_st<GT, uint32_t>(&tabs[noff + s2], EMPTY);
+          __syncthreads();
+          for (uint32_t sb = 0; sb < size; sb += 64) {
+            uint32_t s2 = sb + lane;
+            reinsert((s2 < size) ? tab_ld<GT, uint32_t>(&tabs[toff + s2]) : EMPTY);
+          }
         }
         toff = noff;
         size = newsize;
@@ -537,8 +603,8 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
     double sx, sy, sz;
     bool skip = crot_size(r, rot, sx, sy, sz);
     if (pv) {
-      double x0 = l.ems[0 * cap + ei], y0 = l.ems[1 * cap + ei], z0 = l.ems[2 * cap + ei];
-      double x1 = l.ems[3 * cap + ei], y1 = l.ems[4 * cap + ei], z1 = l.ems[5 * cap + ei];
+      double x0 = lat2d(l.emsk[0 * cap + ei]), y0 = lat2d(l.emsk[1 * cap + ei]), z0 = lat2d(l.emsk[2 * cap + ei]);
+      double x1 = lat2d(l.emsk[3 * cap + ei]), y1 = lat2d(l.emsk[4 * cap + ei]), z1 = lat2d(l.emsk[5 * cap + ei]);
       pv = !skip && (x1 - x0 + 1e-6 >= sx) && (y1 - y0 + 1e-6 >= sy) && (z1 - z0 + 1e-6 >= sz);
     }
     uint64_t pm = __ballot(pv);
@@ -606,7 +672,7 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
     for (int b2 = 0; b2 < nb; b2++) {
       int u0 = l.bk[0 * p.I + b2], u1 = l.bk[1 * p.I + b2], u2 = l.bk[2 * p.I + b2], u3 = l.bk[3 * p.I + b2];
       bool ov = (min(c0, u0) + min(c2, u2) > 0) && (min(c1, u1) + min(c3, u3) > 0);
-      double top = l.box[5 * p.I + b2];
+      double top = l.top[b2];
       max_h = (ov && top > max_h) ? top : max_h;
     }
     if (max_h + z - 1e-6 > p.H) ok = false;
@@ -650,12 +716,7 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
         uint32_t pj = tab_ld<GT, uint32_t>(&fpri[j]);
         rank += (pj < pa || (pj == pa && j < a2)) ? 1 : 0;
       }
-      if (live && rank < p.L) {
-        double t[6];
-        cand_tuple(p, l, r, orient, (uint32_t)tab_ld<GT, uint16_t>(&order[a2]), t);
-#pragma unroll
-        for (int c2 = 0; c2 < 5; c2++) l.leaf[c2 * p.L + rank] = t[c2];
-      }
+      if (live && rank < p.L) l.leafg[rank] = tab_ld<GT, uint16_t>(&order[a2]);
     }
     nleaf = nf;
   } else {
@@ -663,14 +724,12 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
       int i = base + lane;
       bool live = i < norder;
       double t[6];
-      cand_tuple(p, l, r, orient, live ? (uint32_t)tab_ld<GT, uint16_t>(&order[i]) : 0u, t);
+      const uint32_t gid = live ? (uint32_t)tab_ld<GT, uint16_t>(&order[i]) : 0u;
+      cand_tuple(p, l, r, orient, gid, t);
       bool ok = live && feasible(t);
       uint64_t m = __ballot(ok);
       int idx = nleaf + rank_below(m);
-      if (ok && idx < p.L) {
-#pragma unroll
-        for (int c2 = 0; c2 < 5; c2++) l.leaf[c2 * p.L + idx] = t[c2];
-      }
+      if (ok && idx < p.L) l.leafg[idx] = (uint16_t)gid;
       nleaf += __popcll(m);
     }
   }
@@ -686,24 +745,31 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
 // `full` rewrites every row; otherwise only what changed since this env's previous observation:
 // the row of the box just placed (`new_row`, or -1), the leaf rows and the next-item row
 __device__ inline void cwrite_obs(const ContinuousParams& p, int e, const CLds& l, const CRegs& r, int lane,
-                                  float* __restrict__ obs, bool full, int new_row) {
+                                  float* __restrict__ obs, bool full, int new_row, const double newbox[6]) {
   const float nden = (float)next_density(p, e, r.oc - 1, r.traj, r.cursor - 1);  // C/bin3D.py:81-90,98
+  const int orient = (p.setting == 2) ? 6 : 2;
   double a = r.b0, b = r.b1, c = r.b2, tmp;
   if (a > b) { tmp = a; a = b; b = tmp; }
   if (b > c) { tmp = b; b = c; c = tmp; }
   if (a > b) { tmp = a; a = b; b = tmp; }
-  if (!full && new_row >= 0 && lane < 9)
-    obs[new_row * 9 + lane] = lane < 6 ? (float)l.box[lane * p.I + new_row] : (lane == 8 ? 1.0f : 0.f);
+  if (!full && new_row >= 0 && lane < 9) {
+    double v = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) v = lane == k ? newbox[k] : v;
+    obs[new_row * 9 + lane] = lane < 6 ? (float)v : (lane == 8 ? 1.0f : 0.f);
+  }
   if (!full) {
-    // incremental: lane = leaf row (nine strided stores), then the item row -- as in the discrete kernel
+    // incremental: lane = leaf row (nine strided stores), then the item row -- as in the discrete kernel; a
+    // leaf's 6-tuple is recomputed from its generator id (the EMS list and the item it was made from are
+    // the ones in LDS / in the registers)
     for (int jb = 0; jb < p.L; jb += 64) {
       const int j = jb + lane;
       if (j < p.L) {
         const bool on = j < r.n_leaf;
+        double t[6] = {0, 0, 0, 0, 0, 0};
+        if (on) cand_tuple(p, l, r, orient, (uint32_t)l.leafg[j], t);
         float* o = obs + (size_t)(p.I + j) * 9;
-        o[0] = on ? (float)l.leaf[0 * p.L + j] : 0.f; o[1] = on ? (float)l.leaf[1 * p.L + j] : 0.f;
-        o[2] = on ? (float)l.leaf[2 * p.L + j] : 0.f; o[3] = on ? (float)l.leaf[3 * p.L + j] : 0.f;
-        o[4] = on ? (float)l.leaf[4 * p.L + j] : 0.f;
+        o[0] = (float)t[0]; o[1] = (float)t[1]; o[2] = (float)t[2]; o[3] = (float)t[3]; o[4] = (float)t[4];
         o[5] = on ? (float)p.H : 0.f;
         o[6] = 0.f; o[7] = 0.f;
         o[8] = on ? 1.0f : 0.f;
@@ -714,24 +780,44 @@ __device__ inline void cwrite_obs(const ContinuousParams& p, int e, const CLds& 
           lane == 0 ? nden : (lane == 3 ? (float)a : (lane == 4 ? (float)b : (lane == 5 ? (float)c : (lane == 8 ? 1.0f : 0.f))));
     return;
   }
-  for (int f = lane; f < p.row_len; f += 64) {
-    int row = f / 9;
-    int col = f - row * 9;
-    float v = 0.f;
+  // full rewrite: the placed boxes come from their HBM rows (written when they were placed; the one placed by
+  // this very step from `newbox`), lane = row for the box and leaf parts
+  const double* gb = p.boxes + (size_t)e * 6 * p.I;
+  for (int rb = 0; rb < p.I; rb += 64) {
+    const int row = rb + lane;
     if (row < p.I) {
-      if (row < r.n_boxes) {
-        v = col < 6 ? (float)l.box[col * p.I + row] : (col == 8 ? 1.0f : 0.f);  // density column is 0 (:372-373)
-      } else if (row == 0 && col == 8) {
-        v = 1.0f;
+      float* o = obs + (size_t)row * 9;
+      const bool on = row < r.n_boxes;
+      double g[6] = {0, 0, 0, 0, 0, 0};
+      if (on && row != new_row) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) g[k] = gb[k * p.I + row];
+      } else if (on) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) g[k] = newbox[k];
       }
-    } else if (row < p.I + p.L) {
-      int j = row - p.I;
-      if (j < r.n_leaf) v = col < 5 ? (float)l.leaf[col * p.L + j] : (col == 5 ? (float)p.H : (col == 8 ? 1.0f : 0.f));
-    } else {
-      v = col == 0 ? nden : (col == 3 ? (float)a : (col == 4 ? (float)b : (col == 5 ? (float)c : (col == 8 ? 1.0f : 0.f))));
+#pragma unroll
+      for (int k = 0; k < 6; k++) o[k] = (float)g[k];
+      o[6] = 0.f; o[7] = 0.f;  // density column is 0 (:372-373)
+      o[8] = (on || row == 0) ? 1.0f : 0.f;  // row 0: the dummy valid node after reset (C/space.py:285-286)
     }
-    obs[f] = v;
   }
+  for (int jb = 0; jb < p.L; jb += 64) {
+    const int j = jb + lane;
+    if (j < p.L) {
+      const bool on = j < r.n_leaf;
+      double t[6] = {0, 0, 0, 0, 0, 0};
+      if (on) cand_tuple(p, l, r, orient, (uint32_t)l.leafg[j], t);
+      float* o = obs + (size_t)(p.I + j) * 9;
+      o[0] = (float)t[0]; o[1] = (float)t[1]; o[2] = (float)t[2]; o[3] = (float)t[3]; o[4] = (float)t[4];
+      o[5] = on ? (float)p.H : 0.f;
+      o[6] = 0.f; o[7] = 0.f;
+      o[8] = on ? 1.0f : 0.f;
+    }
+  }
+  if (lane < 9)
+    obs[(size_t)(p.I + p.L) * 9 + lane] =
+        lane == 0 ? nden : (lane == 3 ? (float)a : (lane == 4 ? (float)b : (lane == 5 ? (float)c : (lane == 8 ? 1.0f : 0.f))));
 }
 
 __device__ inline void cload(const ContinuousParams& p, int e, CLds& l, CRegs& r, int lane) {
@@ -745,44 +831,53 @@ __device__ inline void cload(const ContinuousParams& p, int e, CLds& l, CRegs& r
   r.volsum = p.volsum[e];
   r.traj = sc[12];
   r.oc = (uint32_t)sc[13];
-  const double* ge = p.ems + (size_t)e * 6 * p.ems_cap;
+  const int32_t* ge = p.ems + (size_t)e * 6 * p.ems_cap;
   const double* gb = p.boxes + (size_t)e * 6 * p.I;
-  const double* gl = p.leaves + (size_t)e * 6 * p.L;
-  const double* gs = p.bsz + (size_t)e * 3 * p.I;
-  if (p.setting != 2)
-    for (int c = 0; c < 3; c++)
-      for (int i = lane; i < r.n_boxes; i += 64) l.bsz[c * p.I + i] = gs[c * p.I + i];
-  for (int c = 0; c < 6; c++) {
-    for (int i = lane; i < r.n_ems; i += 64) l.ems[c * p.ems_cap + i] = ge[c * p.ems_cap + i];
-    for (int i = lane; i < r.n_boxes; i += 64) l.box[c * p.I + i] = gb[c * p.I + i];
-    if (c < 5)
-      for (int i = lane; i < r.n_leaf; i += 64) l.leaf[c * p.L + i] = gl[c * p.L + i];
-  }
-  __syncthreads();
+  const uint16_t* gl = p.leafg + (size_t)e * p.L;
+  const bool stab = p.setting != 2;
+  for (int c = 0; c < 6; c++)
+    for (int i = lane; i < r.n_ems; i += 64) l.emsk[c * p.ems_cap + i] = ge[c * p.ems_cap + i];
+  for (int i = lane; i < r.n_leaf; i += 64) l.leafg[i] = gl[i];
+  // placed boxes: the footprint on the lattice and the top for the per-candidate scan; the full rows (and the
+  // sizes as placed) only where the stability check needs them
   for (int i = lane; i < r.n_boxes; i += 64) {
-    l.bk[0 * p.I + i] = klat(-l.box[0 * p.I + i]);
-    l.bk[1 * p.I + i] = klat(-l.box[1 * p.I + i]);
-    l.bk[2 * p.I + i] = klat(l.box[3 * p.I + i]);
-    l.bk[3 * p.I + i] = klat(l.box[4 * p.I + i]);
+    const double lx = gb[0 * p.I + i], ly = gb[1 * p.I + i], xe = gb[3 * p.I + i], ye = gb[4 * p.I + i], top = gb[5 * p.I + i];
+    l.bk[0 * p.I + i] = klat(-lx);
+    l.bk[1 * p.I + i] = klat(-ly);
+    l.bk[2 * p.I + i] = klat(xe);
+    l.bk[3 * p.I + i] = klat(ye);
+    l.top[i] = top;
+    if (stab) {
+      l.box[0 * p.I + i] = lx; l.box[1 * p.I + i] = ly; l.box[2 * p.I + i] = gb[2 * p.I + i];
+      l.box[3 * p.I + i] = xe; l.box[4 * p.I + i] = ye;
+      const double* gs = p.bsz + (size_t)e * 3 * p.I;
+      l.bsz[0 * p.I + i] = gs[0 * p.I + i]; l.bsz[1 * p.I + i] = gs[1 * p.I + i]; l.bsz[2 * p.I + i] = gs[2 * p.I + i];
+    }
   }
   __syncthreads();
 }
 
+// the box just placed goes to its HBM row at once (rows are only ever appended; the row count lives in the
+// scalars, which cstore writes): lane 0, six strided stores
+__device__ inline void cstore_box(const ContinuousParams& p, int e, int bi, const double g[6], const double sz[3], int lane) {
+  if (lane == 0) {
+    double* gb = p.boxes + (size_t)e * 6 * p.I;
+#pragma unroll
+    for (int k = 0; k < 6; k++) gb[k * p.I + bi] = g[k];
+    if (p.setting != 2) {
+      double* gs = p.bsz + (size_t)e * 3 * p.I;
+      gs[0 * p.I + bi] = sz[0]; gs[1 * p.I + bi] = sz[1]; gs[2 * p.I + bi] = sz[2];
+    }
+  }
+}
+
 __device__ inline void cstore(const ContinuousParams& p, int e, const CLds& l, const CRegs& r, int lane) {
   int32_t* sc = p.scalars + (size_t)e * PCT_SCALARS;
-  double* ge = p.ems + (size_t)e * 6 * p.ems_cap;
-  double* gb = p.boxes + (size_t)e * 6 * p.I;
-  double* gl = p.leaves + (size_t)e * 6 * p.L;
-  double* gs = p.bsz + (size_t)e * 3 * p.I;
-  if (p.setting != 2)
-    for (int c = 0; c < 3; c++)
-      for (int i = lane; i < r.n_boxes; i += 64) gs[c * p.I + i] = l.bsz[c * p.I + i];
-  for (int c = 0; c < 6; c++) {
-    for (int i = lane; i < r.n_ems; i += 64) ge[c * p.ems_cap + i] = l.ems[c * p.ems_cap + i];
-    for (int i = lane; i < r.n_boxes; i += 64) gb[c * p.I + i] = l.box[c * p.I + i];
-    if (c < 5)
-      for (int i = lane; i < r.n_leaf; i += 64) gl[c * p.L + i] = l.leaf[c * p.L + i];
-  }
+  int32_t* ge = p.ems + (size_t)e * 6 * p.ems_cap;
+  uint16_t* gl = p.leafg + (size_t)e * p.L;
+  for (int c = 0; c < 6; c++)
+    for (int i = lane; i < r.n_ems; i += 64) ge[c * p.ems_cap + i] = l.emsk[c * p.ems_cap + i];
+  for (int i = lane; i < r.n_leaf; i += 64) gl[i] = l.leafg[i];
   if (lane == 0) {
     sc[0] = r.n_ems; sc[1] = r.n_boxes; sc[2] = r.n_leaf;
     sc[3] = r.ik0; sc[4] = r.ik1; sc[5] = r.ik2;
@@ -799,7 +894,7 @@ __device__ inline void cstore(const ContinuousParams& p, int e, const CLds& l, c
 // the action, (bx,by,bz): the item as LeafNode2Action returns it.
 template <bool STAB, typename TM>
 __device__ inline bool ctransition(const ContinuousParams& p, int e, CLds& l, CRegs& r, int lane, int flag, double a1,
-                                   double a2, double bx, double by, double bz, TM& tm) {
+                                   double a2, double bx, double by, double bz, TM& tm, double newbox[6]) {
   r.t++;
   const double lx = around6(a1), ly = around6(a2);  // idx = [round(action[1], 6), round(action[2], 6)]
   const double x = flag ? by : bx, y = flag ? bx : by, z = bz;  // C/space.py:330-333
@@ -813,7 +908,7 @@ __device__ inline bool ctransition(const ContinuousParams& p, int e, CLds& l, CR
     for (int b = lane; b < r.n_boxes; b += 64) {
       int u0 = l.bk[0 * p.I + b], u1 = l.bk[1 * p.I + b], u2 = l.bk[2 * p.I + b], u3 = l.bk[3 * p.I + b];
       bool ov = (min(c0, u0) + min(c2, u2) > 0) && (min(c1, u1) + min(c3, u3) > 0);
-      double top = l.box[5 * p.I + b];
+      double top = l.top[b];
       m = (ov && top > m) ? top : m;
     }
     max_h = wave_max_f64(m);
@@ -853,12 +948,20 @@ __device__ inline bool ctransition(const ContinuousParams& p, int e, CLds& l, CR
   if (ok) {
     const double top = max_h + z, xe = lx + x, ye = ly + y;
     const int bi = r.n_boxes;
+    newbox[0] = lx; newbox[1] = ly; newbox[2] = max_h; newbox[3] = xe; newbox[4] = ye; newbox[5] = top;
     if (lane == 0) {
-      l.box[0 * p.I + bi] = lx; l.box[1 * p.I + bi] = ly; l.box[2 * p.I + bi] = max_h;
-      l.box[3 * p.I + bi] = xe; l.box[4 * p.I + bi] = ye; l.box[5 * p.I + bi] = top;
+      if (STAB) {
+        l.box[0 * p.I + bi] = lx; l.box[1 * p.I + bi] = ly; l.box[2 * p.I + bi] = max_h;
+        l.box[3 * p.I + bi] = xe; l.box[4 * p.I + bi] = ye;
+        l.bsz[0 * p.I + bi] = x; l.bsz[1 * p.I + bi] = y; l.bsz[2 * p.I + bi] = z;
+      }
+      l.top[bi] = top;
       l.bk[0 * p.I + bi] = klat(-lx); l.bk[1 * p.I + bi] = klat(-ly);
       l.bk[2 * p.I + bi] = klat(xe); l.bk[3 * p.I + bi] = klat(ye);
-      if (STAB) { l.bsz[0 * p.I + bi] = x; l.bsz[1 * p.I + bi] = y; l.bsz[2 * p.I + bi] = z; }
+    }
+    {
+      const double sz[3] = {x, y, z};
+      cstore_box(p, e, bi, newbox, sz, lane);
     }
     r.n_boxes++;
     r.volsum = r.volsum + x * y * z;  // get_ratio's left fold (:316-321)
@@ -921,7 +1024,11 @@ __device__ inline void cdecode_leaf(const CRegs& r, bool zero_row, double a0, do
 enum { CACT_ROWS = 0, CACT_INDEX = 1, CACT_HASH = 2, CACT_RESET = 3 };
 
 template <int ACT, bool TIMED, bool GT, bool STAB>
-__global__ void __launch_bounds__(64) pct_continuous_kernel(ContinuousParams p, const void* __restrict__ actions,
+#ifndef PCT_CONT_WAVES
+#define PCT_CONT_WAVES 3 /* waves per SIMD the plain kernel is compiled for: 168 VGPRs with 68 spilled to scratch measures slightly faster (C3 250 vs 254 us at 4096 envs, 356 vs 379 us at 8192) than 256 VGPRs at 2 waves */
+#endif
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((STAB || TIMED) ? 1 : PCT_CONT_WAVES)))
+pct_continuous_kernel(ContinuousParams p, const void* __restrict__ actions,
                                                             int row_len, int n_steps,
                                                             const int32_t* __restrict__ env_ids, int n_ids) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -948,10 +1055,12 @@ __global__ void __launch_bounds__(64) pct_continuous_kernel(ContinuousParams p, 
     cdraw_item(p, e, r);
     requeue = cleaf_nodes<GT, STAB>(p, e, l, r, lane, tm);
     if (!requeue) {
-      cwrite_obs(p, e, l, r, lane, obs, true, -1);
+      const double nobox[6] = {0, 0, 0, 0, 0, 0};
+      cwrite_obs(p, e, l, r, lane, obs, true, -1, nobox);
       cstore(p, e, l, r, lane);
     }
   } else {
+  const int orient0 = (p.setting == 2) ? 6 : 2;
   for (int it = 0; it < n_steps; it++) {
     int flag = 0;
     double p1 = 0, p2 = 0, bx = 0, by = 0, bz = 0;
@@ -973,15 +1082,17 @@ __global__ void __launch_bounds__(64) pct_continuous_kernel(ContinuousParams p, 
         int match = -1;
         for (int base = 0; base < r.n_leaf && match < 0; base += 64) {
           int j = base + lane;
-          bool eq = j < r.n_leaf && (float)l.leaf[0 * p.L + j] == (float)a0 && (float)l.leaf[1 * p.L + j] == (float)a1 &&
-                    (float)l.leaf[2 * p.L + j] == (float)a2 && (float)l.leaf[3 * p.L + j] == (float)a3 &&
-                    (float)l.leaf[4 * p.L + j] == (float)a4;
+          double t[6] = {0, 0, 0, 0, 0, 0};
+          if (j < r.n_leaf) cand_tuple(p, l, r, orient0, (uint32_t)l.leafg[j], t);
+          bool eq = j < r.n_leaf && (float)t[0] == (float)a0 && (float)t[1] == (float)a1 && (float)t[2] == (float)a2 &&
+                    (float)t[3] == (float)a3 && (float)t[4] == (float)a4;
           uint64_t m = __ballot(eq);
           if (m) match = base + __ffsll((unsigned long long)m) - 1;
         }
         if (match >= 0 && sum != 0.0) {
-          a0 = l.leaf[0 * p.L + match]; a1 = l.leaf[1 * p.L + match];
-          a3 = l.leaf[3 * p.L + match]; a4 = l.leaf[4 * p.L + match];
+          double t[6];
+          cand_tuple(p, l, r, orient0, (uint32_t)l.leafg[match], t);
+          a0 = t[0]; a1 = t[1]; a3 = t[3]; a4 = t[4];
         }
         cdecode_leaf(r, sum == 0.0, a0, a1, a3, a4, p1, p2, bx, by, bz);
       }
@@ -990,18 +1101,20 @@ __global__ void __launch_bounds__(64) pct_continuous_kernel(ContinuousParams p, 
       if (ACT == CACT_INDEX) li = reinterpret_cast<const int64_t*>(actions)[e];
       else li = r.n_leaf > 0 ? (int64_t)(pct_mix32((uint32_t)(p.env_id_base + e), r.t) % (uint32_t)r.n_leaf) : 0;
       bool zero_row = !(li >= 0 && li < r.n_leaf);
-      int q = zero_row ? 0 : (int)li;
-      double a0 = l.leaf[0 * p.L + q], a1 = l.leaf[1 * p.L + q], a3 = l.leaf[3 * p.L + q], a4 = l.leaf[4 * p.L + q];
+      double t[6] = {0, 0, 0, 0, 0, 0};
+      if (!zero_row) cand_tuple(p, l, r, orient0, (uint32_t)l.leafg[(int)li], t);
+      double a0 = t[0], a1 = t[1], a3 = t[3], a4 = t[4];
       if (!zero_row) {  // a valid leaf row sums to > 0 unless it is the all-zero row
-        double sum = ((((a0 + a1) + l.leaf[2 * p.L + q]) + a3) + a4) + p.H;
+        double sum = ((((a0 + a1) + t[2]) + a3) + a4) + p.H;
         zero_row = (sum == 0.0);
       }
       cdecode_leaf(r, zero_row, a0, a1, a3, a4, p1, p2, bx, by, bz);
     }
-    const bool ended = ctransition<STAB>(p, e, l, r, lane, flag, p1, p2, bx, by, bz, tm);
+    double newbox[6] = {0, 0, 0, 0, 0, 0};
+    const bool ended = ctransition<STAB>(p, e, l, r, lane, flag, p1, p2, bx, by, bz, tm, newbox);
     requeue = cleaf_nodes<GT, STAB>(p, e, l, r, lane, tm);
     if (requeue) break;
-    cwrite_obs(p, e, l, r, lane, obs, ended || (p.full_obs != 0 && it == 0), ended ? -1 : r.n_boxes - 1);
+    cwrite_obs(p, e, l, r, lane, obs, ended || (p.full_obs != 0 && it == 0), ended ? -1 : r.n_boxes - 1, newbox);
     __syncthreads();
     tm.tick(PH_OBS);
   }

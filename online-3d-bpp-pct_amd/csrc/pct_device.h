@@ -76,7 +76,7 @@ struct ContinuousParams {
   double low_bound; /* C/bin3D.py:25-29 size_minimum */
   int shuffle;
   unsigned long long shuffle_seed;
-  int ems_cap, cand_cap, order_cap, union_doubles;
+  int ems_cap, cand_cap, order_cap, union_words; /* union_words: LDS words shared by the hash table and the GENEMS children */
   int source, env_id_base;
   int sample_left, sample_right; /* lattice 1e-3; right <= 0: items come from item_set instead */
   const int32_t* item_set;       /* [n_items,3] lattice 1e-3 (not sample_from_distribution, C/bin3D.py:36-39) */
@@ -86,9 +86,9 @@ struct ContinuousParams {
   const int32_t* stream; /* [N,T,3] lattice 1e-3; dataset mode: [n_traj,max_len,3] */
   const int32_t* ds_len;
   int ds_ntraj, ds_maxlen;
-  double* ems;      /* [N,6,ems_cap] */
-  double* boxes;    /* [N,6,I] lx,ly,lz,xe,ye,top */
-  double* leaves;   /* [N,6,L] */
+  int32_t* ems;     /* [N,6,ems_cap] EMS coordinates on the 1e-6 lattice (every one is an np.around(., 6) result) */
+  double* boxes;    /* [N,6,I] lx,ly,lz,xe,ye,top; a row is written when its box is placed */
+  uint16_t* leafg;  /* [N,L] generator ids (EMS, rotation, corner) of the current leaf nodes */
   double* volsum;   /* [N] running sum of placed volumes (get_ratio) */
   double* bsz;      /* [N,3,I] placed sizes x,y,z */
   double* st_stack; /* stability state, as in DiscreteParams (settings 1/3 only) */

@@ -247,11 +247,15 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
     c.cand_cap = cand_cap;
     c.order_cap = (cand_cap * 3) / 5 + 8;
     c.table_global = cand_cap > 8192 ? 1 : 0; /* beyond 8192 slots the table cannot share LDS with the EMS */
-    size_t tab_doubles = c.table_global ? 0 : ((size_t)(cand_cap + cand_cap / 4) * 4 + 7) / 8;
-    /* the region shared by the hash table and the GENEMS children scratch: 2 * ems_cap children when
-     * the table lives in LDS (225 pre-elimination entries were seen at C3), ems_cap otherwise */
-    size_t child_doubles = (size_t)6 * ems_cap * (c.table_global ? 1 : 2);
-    c.union_doubles = (int)(tab_doubles > child_doubles ? tab_doubles : child_doubles);
+    /* the LDS region shared by the hash table (one region for every table size up to 2048 slots; a 8192-slot
+     * table sits behind the 2048-slot one it grows from) and the GENEMS children scratch (6 int32 words per
+     * child): 2 * ems_cap children when the table lives in LDS (225 pre-elimination entries were seen at C3),
+     * ems_cap otherwise */
+    size_t tab_words = c.table_global ? 0 : (size_t)(cand_cap > 2048 ? cand_cap + cand_cap / 4 : cand_cap);
+    size_t child_words = (size_t)6 * ems_cap * (c.table_global ? 1 : 2);
+    c.union_words = (int)(tab_words > child_words ? tab_words : child_words);
+    if (c.union_words < 192) c.union_words = 192; /* the fast start parks 64 generator ids behind a 128-slot table */
+    if (maxdim / 1000 > 2000) { delete h; return fail(PCT_ERR_UNSUPPORTED, "continuous bins are limited to 2000 units per axis (int32 lattice 1e-6)"); }
     c.env_id_base = cfg->env_id_base;
     c.source = PCT_ITEMS_NONE;
     if ((size_t)ems_cap * 24 + 23 > 65535) { delete h; return fail(PCT_ERR_INVALID_ARG, "ems_capacity too large for 16-bit generator ids"); }
@@ -263,9 +267,9 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
     rc = dev_alloc(h, (void**)&(ptr), (bytes), true);        \
     if (rc) { pct_destroy(h); return rc; }                   \
   } while (0)
-    CALLOC_(c.ems, Nn * 6 * c.ems_cap * sizeof(double));
+    CALLOC_(c.ems, Nn * 6 * c.ems_cap * sizeof(int32_t));
     CALLOC_(c.boxes, Nn * 6 * c.I * sizeof(double));
-    CALLOC_(c.leaves, Nn * 6 * c.L * sizeof(double));
+    CALLOC_(c.leafg, Nn * c.L * sizeof(uint16_t));
     CALLOC_(c.volsum, Nn * sizeof(double));
     CALLOC_(c.bsz, Nn * 3 * c.I * sizeof(double));
     if (cfg->setting != 2) {
@@ -306,7 +310,7 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
       q.gt_by_block = 1;
       q.cand_cap = big;
       q.order_cap = (big * 3) / 5 + 8;
-      q.union_doubles = 6 * ems_cap;
+      q.union_words = 12 * ems_cap > 192 ? 12 * ems_cap : 192; /* children scratch only: 2 * ems_cap of them, as in the normal pass */
       CALLOC_(q.gtab, (size_t)RB * (size_t)(big + big / 4) * sizeof(uint32_t));
       CALLOC_(q.gorder, (size_t)RB * (size_t)q.order_cap * sizeof(uint16_t));
       if (c.shuffle) CALLOC_(q.gfpri, (size_t)RB * (size_t)q.order_cap * sizeof(uint32_t));
@@ -764,10 +768,10 @@ int pct_debug_state_f64(pct_env* h, int32_t e, double* ems, int32_t cap_ems, int
   int32_t sc[PCT_SCALARS];
   HIP_TRY(hipMemcpy(sc, c.scalars + (size_t)e * PCT_SCALARS, sizeof sc, hipMemcpyDeviceToHost));
   if (ems) {
-    std::vector<double> raw((size_t)6 * c.ems_cap);
-    HIP_TRY(hipMemcpy(raw.data(), c.ems + (size_t)e * 6 * c.ems_cap, raw.size() * sizeof(double), hipMemcpyDeviceToHost));
+    std::vector<int32_t> raw((size_t)6 * c.ems_cap);
+    HIP_TRY(hipMemcpy(raw.data(), c.ems + (size_t)e * 6 * c.ems_cap, raw.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
     for (int i = 0; i < sc[0] && i < cap_ems; i++)
-      for (int k = 0; k < 6; k++) ems[6 * i + k] = raw[(size_t)k * c.ems_cap + i];
+      for (int k = 0; k < 6; k++) ems[6 * i + k] = (double)raw[(size_t)k * c.ems_cap + i] / 1e6; /* the double the lattice index stands for */
   }
   if (n_ems) *n_ems = sc[0];
   if (n_boxes) *n_boxes = sc[1];

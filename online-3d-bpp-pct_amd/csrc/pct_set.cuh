@@ -302,6 +302,44 @@ __device__ inline bool batch_find_duplicates(uint32_t* dd, bool active, uint64_t
   return dup;
 }
 
+// Same as batch_find_duplicates, but the earlier lane's hash and payload (e.g. a generator id the key can be
+// rebuilt from) come over cross-lane shuffles instead of an LDS copy of the batch: `same(hash_w, payload_w)`.
+template <int NB, typename Same>
+__device__ inline bool batch_find_duplicates_shfl(uint32_t* dd, bool active, uint64_t hash, uint32_t payload, int lane,
+                                                  Same same) {
+  bool unresolved = active, dup = false;
+  for (int round = 0; round < 8; round++) {
+    if (!__ballot(unresolved)) return dup;
+    const uint32_t b = (uint32_t)(hash >> (3 + 7 * round)) & (uint32_t)(NB - 1);
+    if (unresolved) atomicMin(&dd[b], (uint32_t)lane);
+    __syncthreads();
+    const uint32_t w = unresolved ? dd[b] : (uint32_t)lane;
+    __syncthreads();
+    const uint32_t hlo = (uint32_t)__shfl((int)(uint32_t)hash, (int)(w & 63u), 64);
+    const uint32_t hhi = (uint32_t)__shfl((int)(uint32_t)(hash >> 32), (int)(w & 63u), 64);
+    const uint32_t pw = (uint32_t)__shfl((int)payload, (int)(w & 63u), 64);
+    if (unresolved) {
+      dd[b] = 0xFFFFFFFFu;
+      if (w == (uint32_t)lane) {
+        unresolved = false;
+      } else if (same(((uint64_t)hhi << 32) | hlo, pw)) {
+        dup = true;
+        unresolved = false;
+      }
+    }
+    __syncthreads();
+  }
+  // eight rounds of pure collisions between distinct keys: exhaustive scan over the earlier lanes
+  const uint64_t am = __ballot(active);
+  for (int i = 0; i < 64; i++) {
+    const uint32_t hlo = (uint32_t)__shfl((int)(uint32_t)hash, i, 64);
+    const uint32_t hhi = (uint32_t)__shfl((int)(uint32_t)(hash >> 32), i, 64);
+    const uint32_t pw = (uint32_t)__shfl((int)payload, i, 64);
+    if (unresolved && ((am >> i) & 1ull) && i < lane && same(((uint64_t)hhi << 32) | hlo, pw)) dup = true;
+  }
+  return dup;
+}
+
 template <typename K>
 __device__ inline K shfl_key(K v, int src);
 template <>

@@ -156,60 +156,57 @@ PCT_SD bool stab_pip(const double* pt, const double (*co)[2], int n) {
   return odd;
 }
 
-// minimum-norm least squares for the >= 3 supporter case (stands in for np.linalg.lstsq /
-// LAPACK gelsd: Jacobi eigen-decomposition of A^T A; same method as the oracle)
+// minimum-norm least squares for the >= 3 supporter case (stands in for np.linalg.lstsq / LAPACK dgelsd):
+// one-sided Jacobi (Hestenes) SVD of A itself, x = sum_j V_j (U_j . b) / sigma_j^2 over sigma_j > eps * max(M,N) *
+// sigma_max -- the same method, operation for operation, as the oracle's lstsq_min_norm (see there for why not A^T A)
 PCT_SD void stab_lstsq(const double* A, const double* b, int M, int N, double* x) {
-  double G[STAB_LSQ * STAB_LSQ], V[STAB_LSQ * STAB_LSQ], g[STAB_LSQ];
-  for (int i = 0; i < N; i++) {
-    g[i] = 0;
-    for (int r = 0; r < M; r++) g[i] += A[r * N + i] * b[r];
-    for (int j = 0; j < N; j++) {
-      double s = 0;
-      for (int r = 0; r < M; r++) s += A[r * N + i] * A[r * N + j];
-      G[i * N + j] = s;
-      V[i * N + j] = (i == j) ? 1.0 : 0.0;
-    }
-  }
+  double U[(STAB_LSQ * (STAB_LSQ - 1) / 2 + 1) * STAB_LSQ], V[STAB_LSQ * STAB_LSQ];
+  for (int i = 0; i < M * N; i++) U[i] = A[i];
+  for (int i = 0; i < N; i++)
+    for (int j = 0; j < N; j++) V[i * N + j] = (i == j) ? 1.0 : 0.0;
   for (int sweep = 0; sweep < 60; sweep++) {
-    double off = 0;
-    for (int p = 0; p < N; p++)
-      for (int q = p + 1; q < N; q++) off += G[p * N + q] * G[p * N + q];
-    if (off < 1e-300) break;
+    bool rotated = false;
     for (int p = 0; p < N; p++)
       for (int q = p + 1; q < N; q++) {
-        if (fabs(G[p * N + q]) < 1e-300) continue;
-        double theta = (G[q * N + q] - G[p * N + p]) / (2 * G[p * N + q]);
-        double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
-        double c = 1 / sqrt(t * t + 1), sn = t * c;
-        for (int k = 0; k < N; k++) {
-          double gkp = G[k * N + p], gkq = G[k * N + q];
-          G[k * N + p] = c * gkp - sn * gkq;
-          G[k * N + q] = sn * gkp + c * gkq;
+        double alpha = 0, beta = 0, gamma = 0;
+        for (int r = 0; r < M; r++) {
+          alpha += U[r * N + p] * U[r * N + p];
+          beta += U[r * N + q] * U[r * N + q];
+          gamma += U[r * N + p] * U[r * N + q];
         }
-        for (int k = 0; k < N; k++) {
-          double gpk = G[p * N + k], gqk = G[q * N + k];
-          G[p * N + k] = c * gpk - sn * gqk;
-          G[q * N + k] = sn * gpk + c * gqk;
+        if (gamma == 0 || fabs(gamma) <= 2.220446049250313e-16 * sqrt(alpha * beta)) continue;
+        rotated = true;
+        double zeta = (beta - alpha) / (2 * gamma);
+        double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1 + zeta * zeta));
+        double c = 1 / sqrt(1 + t * t), sn = c * t;
+        for (int r = 0; r < M; r++) {
+          double up = U[r * N + p], uq = U[r * N + q];
+          U[r * N + p] = c * up - sn * uq;
+          U[r * N + q] = sn * up + c * uq;
         }
-        for (int k = 0; k < N; k++) {
-          double vkp = V[k * N + p], vkq = V[k * N + q];
-          V[k * N + p] = c * vkp - sn * vkq;
-          V[k * N + q] = sn * vkp + c * vkq;
+        for (int r = 0; r < N; r++) {
+          double vp = V[r * N + p], vq = V[r * N + q];
+          V[r * N + p] = c * vp - sn * vq;
+          V[r * N + q] = sn * vp + c * vq;
         }
       }
+    if (!rotated) break;
   }
-  double smax = 0;
-  for (int i = 0; i < N; i++)
-    if (G[i * N + i] > smax) smax = G[i * N + i];
-  double rc = 2.220446049250313e-16 * (M > N ? M : N);
+  double s2[STAB_LSQ], smax2 = 0;
+  for (int j = 0; j < N; j++) {
+    double a2 = 0;
+    for (int r = 0; r < M; r++) a2 += U[r * N + j] * U[r * N + j];
+    s2[j] = a2;
+    if (a2 > smax2) smax2 = a2;
+  }
+  const double rc = 2.220446049250313e-16 * (M > N ? M : N);
   for (int i = 0; i < N; i++) x[i] = 0;
-  for (int k = 0; k < N; k++) {
-    double lam = G[k * N + k];
-    if (lam <= 0 || sqrt(lam) <= rc * sqrt(smax)) continue;
+  for (int j = 0; j < N; j++) {
+    if (s2[j] <= 0 || sqrt(s2[j]) <= rc * sqrt(smax2)) continue;
     double proj = 0;
-    for (int i = 0; i < N; i++) proj += V[i * N + k] * g[i];
-    proj /= lam;
-    for (int i = 0; i < N; i++) x[i] += V[i * N + k] * proj;
+    for (int r = 0; r < M; r++) proj += U[r * N + j] * b[r];
+    proj /= s2[j];
+    for (int i = 0; i < N; i++) x[i] += V[i * N + j] * proj;
   }
 }
 

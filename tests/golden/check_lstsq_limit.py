@@ -1,7 +1,7 @@
 """How far the >= 3-supporter split of the stability check can be pinned (build container; needs /root/reference).
 
 The reference solves that split with np.linalg.lstsq = LAPACK dgelsd inside NumPy's OpenBLAS; the oracle and the
-kernels run a Jacobi eigen-solve of A^T A (same minimum-norm solution, last bits differ: max |difference| ~ 4e-15).
+kernels run a one-sided Jacobi SVD of A (the same minimum-norm solution; the last bits differ).
 With integer geometry the tests downstream are often EXACTLY degenerate (a stack centre on the line through a
 polygon edge -> point_in_polygen returns False on `cross == 0`, convex_hull.py:104-105), so that last bit decides
 placements.  This script measures it on the adversarial "flat" item sets of gen_golden.py (every item of height 1:
@@ -28,61 +28,56 @@ import gen_golden as g  # noqa: E402
 
 
 def jacobi_lstsq(A, b):
-    """oracle/pct_oracle_stab.c lstsq_min_norm, operation for operation"""
+    """oracle/pct_oracle_stab.c lstsq_min_norm (one-sided Jacobi SVD), operation for operation"""
     A = np.asarray(A, float)
     b = np.asarray(b, float).reshape(-1)
     M, N = A.shape
-    G, V, gg = np.zeros((N, N)), np.eye(N), np.zeros(N)
-    for i in range(N):
-        s = 0.0
-        for r in range(M):
-            s += A[r, i] * b[r]
-        gg[i] = s
-        for j in range(N):
-            s = 0.0
-            for r in range(M):
-                s += A[r, i] * A[r, j]
-            G[i, j] = s
+    U, V = A.copy(), np.eye(N)
+    eps = 2.220446049250313e-16
     for _ in range(60):
-        off = 0.0
+        rotated = False
         for p in range(N):
             for q in range(p + 1, N):
-                off += G[p, q] * G[p, q]
-        if off < 1e-300:
-            break
-        for p in range(N):
-            for q in range(p + 1, N):
-                if abs(G[p, q]) < 1e-300:
+                alpha = beta = gamma = 0.0
+                for r in range(M):
+                    alpha += U[r, p] * U[r, p]
+                    beta += U[r, q] * U[r, q]
+                    gamma += U[r, p] * U[r, q]
+                if gamma == 0 or abs(gamma) <= eps * math.sqrt(alpha * beta):
                     continue
-                theta = (G[q, q] - G[p, p]) / (2 * G[p, q])
-                t = (1.0 if theta >= 0 else -1.0) / (abs(theta) + math.sqrt(theta * theta + 1))
-                c = 1 / math.sqrt(t * t + 1)
-                sn = t * c
-                for k in range(N):
-                    gkp, gkq = G[k, p], G[k, q]
-                    G[k, p] = c * gkp - sn * gkq
-                    G[k, q] = sn * gkp + c * gkq
-                for k in range(N):
-                    gpk, gqk = G[p, k], G[q, k]
-                    G[p, k] = c * gpk - sn * gqk
-                    G[q, k] = sn * gpk + c * gqk
-                for k in range(N):
-                    vkp, vkq = V[k, p], V[k, q]
-                    V[k, p] = c * vkp - sn * vkq
-                    V[k, q] = sn * vkp + c * vkq
-    smax = max(G[i, i] for i in range(N))
-    rc = 2.220446049250313e-16 * max(M, N)
+                rotated = True
+                zeta = (beta - alpha) / (2 * gamma)
+                t = (1.0 if zeta >= 0 else -1.0) / (abs(zeta) + math.sqrt(1 + zeta * zeta))
+                c = 1 / math.sqrt(1 + t * t)
+                sn = c * t
+                for r in range(M):
+                    up, uq = U[r, p], U[r, q]
+                    U[r, p] = c * up - sn * uq
+                    U[r, q] = sn * up + c * uq
+                for r in range(N):
+                    vp, vq = V[r, p], V[r, q]
+                    V[r, p] = c * vp - sn * vq
+                    V[r, q] = sn * vp + c * vq
+        if not rotated:
+            break
+    s2 = []
+    for j in range(N):
+        a2 = 0.0
+        for r in range(M):
+            a2 += U[r, j] * U[r, j]
+        s2.append(a2)
+    smax2 = max(s2)
+    rc = eps * max(M, N)
     x = np.zeros(N)
-    for k in range(N):
-        lam = G[k, k]
-        if lam <= 0 or math.sqrt(lam) <= rc * math.sqrt(smax):
+    for j in range(N):
+        if s2[j] <= 0 or math.sqrt(s2[j]) <= rc * math.sqrt(smax2):
             continue
         proj = 0.0
+        for r in range(M):
+            proj += U[r, j] * b[r]
+        proj /= s2[j]
         for i in range(N):
-            proj += V[i, k] * gg[i]
-        proj /= lam
-        for i in range(N):
-            x[i] += V[i, k] * proj
+            x[i] += V[i, j] * proj
     return x.reshape(-1, 1)
 
 
