@@ -184,6 +184,17 @@ int pct_set_dataset_density(pct_env* env, const double* den);
  * item_set[pct_pick(seed, g, c, n)] (discrete) -- see pct_pick below. */
 int pct_set_sampler(pct_env* env, uint64_t seed);
 
+/* Strict NumPy-stream mode (discrete env, LNES = EMS, bins up to 31 per axis; before the first reset).  Env e then
+ * consumes the MT19937 stream that np.random.seed(seed + env_id_base + e) starts, exactly as the env's worker process
+ * does under ShmemVecEnv(fork) (envs.py:49 env.seed(seed + rank); bin3D.py:47-54): the item is
+ * item_set[np.random.randint(0, n)] (binCreator.py:37-39), the setting-3 density np.random.random() redrawn while 0
+ * (bin3D.py:82-84), and -- with pct_config.shuffle -- the candidate list goes through np.random.shuffle
+ * (bin3D.py:114-115; Fisher-Yates from the back on random_interval draws), including the extra shuffle and density
+ * draw of the discarded observation of a failed step (bin3D.py:165).  Given the same seed and actions the env then
+ * reproduces the reference's trajectory bit for bit with the CLI's defaults (tools.py:136 shuffle=True,
+ * RandomBoxCreator).  The heuristic policies are not available in this mode. */
+int pct_set_numpy_rng(pct_env* env, uint32_t seed);
+
 /* Seed of the shuffle permutation (default 0). */
 int pct_set_shuffle_seed(pct_env* env, uint64_t seed);
 

@@ -831,12 +831,13 @@ __device__ inline void cload(const ContinuousParams& p, int e, CLds& l, CRegs& r
   r.volsum = p.volsum[e];
   r.traj = sc[12];
   r.oc = (uint32_t)sc[13];
-  const int32_t* ge = p.ems + (size_t)e * 6 * p.ems_cap;
+  const int32_t* ge = p.ems + (size_t)e * 6 * p.ems_stride;
   const double* gb = p.boxes + (size_t)e * 6 * p.I;
   const uint16_t* gl = p.leafg + (size_t)e * p.L;
   const bool stab = p.setting != 2;
+  const int n_fit = r.n_ems < p.ems_cap ? r.n_ems : p.ems_cap;  // a longer list belongs to the retry pass (caller checks)
   for (int c = 0; c < 6; c++)
-    for (int i = lane; i < r.n_ems; i += 64) l.emsk[c * p.ems_cap + i] = ge[c * p.ems_cap + i];
+    for (int i = lane; i < n_fit; i += 64) l.emsk[c * p.ems_cap + i] = ge[c * p.ems_stride + i];
   for (int i = lane; i < r.n_leaf; i += 64) l.leafg[i] = gl[i];
   // placed boxes: the footprint on the lattice and the top for the per-candidate scan; the full rows (and the
   // sizes as placed) only where the stability check needs them
@@ -873,10 +874,10 @@ __device__ inline void cstore_box(const ContinuousParams& p, int e, int bi, cons
 
 __device__ inline void cstore(const ContinuousParams& p, int e, const CLds& l, const CRegs& r, int lane) {
   int32_t* sc = p.scalars + (size_t)e * PCT_SCALARS;
-  int32_t* ge = p.ems + (size_t)e * 6 * p.ems_cap;
+  int32_t* ge = p.ems + (size_t)e * 6 * p.ems_stride;
   uint16_t* gl = p.leafg + (size_t)e * p.L;
   for (int c = 0; c < 6; c++)
-    for (int i = lane; i < r.n_ems; i += 64) ge[c * p.ems_cap + i] = l.emsk[c * p.ems_cap + i];
+    for (int i = lane; i < r.n_ems; i += 64) ge[c * p.ems_stride + i] = l.emsk[c * p.ems_cap + i];
   for (int i = lane; i < r.n_leaf; i += 64) gl[i] = l.leafg[i];
   if (lane == 0) {
     sc[0] = r.n_ems; sc[1] = r.n_boxes; sc[2] = r.n_leaf;
@@ -1037,6 +1038,9 @@ pct_continuous_kernel(ContinuousParams p, const void* __restrict__ actions,
   // large-capacity retry pass -- the envs the normal pass queued, grid-strided
   const bool listed = (ACT == CACT_RESET && env_ids != nullptr);
   const int limit = p.retry_mode ? *p.retry_count : (listed ? n_ids : p.N);
+  // retry pass: p.retry_count is this step's counter of a ping-pong pair; the other one (the next step's) is
+  // zeroed here, so that no memset sits between the launches (retry_mode = +1 / -1: offset of the other)
+  if (p.retry_mode && blockIdx.x == 0 && threadIdx.x == 0) p.retry_count[p.retry_mode] = 0;
   for (int work = blockIdx.x; work < limit; work += gridDim.x) {
   const int e = p.retry_mode ? p.retry_ids[work] : (listed ? env_ids[work] : work);
   if (e < 0 || e >= p.N) continue;
@@ -1047,7 +1051,16 @@ pct_continuous_kernel(ContinuousParams p, const void* __restrict__ actions,
   cload(p, e, l, r, lane);
   tm.tick(PH_LOAD);
   float* obs = p.obs + (size_t)e * p.row_len;
-  bool requeue = false;
+  // an env whose EMS list outgrows this launch's LDS list -- already at load, or in this step's GENEMS -- goes,
+  // state untouched, to the large-capacity pass, like one whose candidate set outgrows the table
+  const bool can_retry = p.retry_ids != nullptr && !p.retry_mode;
+  const uint32_t flags_in = r.flags;
+  bool requeue = can_retry && ACT != CACT_RESET && r.n_ems > p.ems_cap;
+  if (requeue) {
+    if (lane == 0) p.retry_ids[atomicAdd(p.retry_count, 1)] = e;
+    __syncthreads();
+    continue;
+  }
 
   if (ACT == CACT_RESET) {
     cspace_reset(p, l, r, lane);
@@ -1112,6 +1125,7 @@ pct_continuous_kernel(ContinuousParams p, const void* __restrict__ actions,
     }
     double newbox[6] = {0, 0, 0, 0, 0, 0};
     const bool ended = ctransition<STAB>(p, e, l, r, lane, flag, p1, p2, bx, by, bz, tm, newbox);
+    if (can_retry && ((r.flags & ~flags_in) & PCT_FLAG_EMS_OVERFLOW)) { requeue = true; break; }
     requeue = cleaf_nodes<GT, STAB>(p, e, l, r, lane, tm);
     if (requeue) break;
     cwrite_obs(p, e, l, r, lane, obs, ended || (p.full_obs != 0 && it == 0), ended ? -1 : r.n_boxes - 1, newbox);

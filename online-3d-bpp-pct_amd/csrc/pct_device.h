@@ -31,6 +31,10 @@ struct DiscreteParams {
   int key_bytes; /* 4: six 5-bit coords (bins <= 31); 8: six 10-bit coords (<= 1023) */
   // item source
   int source, n_items, env_id_base;
+  int rng_numpy;     /* 1: strict NumPy-stream mode -- item picks, setting-3 densities and the candidate shuffle consume
+                        the env's own MT19937 stream exactly as the reference's worker process does */
+  uint32_t* mt;      /* [N,624] MT19937 state words of every env (position: scalars[7]) */
+  double* mt_den;    /* [N] density drawn for the current observation (setting 3) */
   long long T;
   unsigned long long seed;
   const int32_t* item_set; /* [n_items,3] */
@@ -76,6 +80,7 @@ struct ContinuousParams {
   double low_bound; /* C/bin3D.py:25-29 size_minimum */
   int shuffle;
   unsigned long long shuffle_seed;
+  int ems_stride; /* row stride of the HBM EMS state = the retry pass's ems_cap */
   int ems_cap, cand_cap, order_cap, union_words; /* union_words: LDS words shared by the hash table and the GENEMS children */
   int source, env_id_base;
   int sample_left, sample_right; /* lattice 1e-3; right <= 0: items come from item_set instead */

@@ -78,6 +78,10 @@ struct EnvRegs {  // wave-uniform per-env scalars
   // the item that the draw number pre_cursor (of trajectory pre_traj) yields, fetched at kernel start
   int pre0, pre1, pre2, pre_traj;
   uint64_t pre_cursor;
+  // strict NumPy-stream mode: position in the MT19937 block, the density drawn for the current observation, and the
+  // number of candidates of the current observation (a failed step shuffles that list once more, D/bin3D.py:165)
+  int mt_pos, n_cand;
+  double den_cur;
 };
 
 template <typename K, int BITS>
@@ -94,6 +98,7 @@ struct Lds {
   uint32_t* cp; /* scheme scratch: CP / EP levels (6 arrays of I+2 words), EV tables (288 words) */
   K* fkey;       /* shuffle: feasible candidates in list order ... */
   uint32_t* fpri; /* ... and their priorities (only when shuffle) */
+  uint32_t* mt;   /* [624] the env's MT19937 state (strict NumPy-stream mode only) */
 };
 
 __host__ __device__ inline int discrete_scheme_words(const DiscreteParams& p) {
@@ -124,6 +129,8 @@ __device__ inline Lds<K, BITS> carve_lds(const DiscreteParams& p, unsigned char*
   const int fcap = (p.cand_cap * 3) / 5 + 2;
   l.fpri = after_cp;
   l.fkey = reinterpret_cast<K*>(after_cp + fcap + (fcap & 1));
+  // the MT19937 words sit behind the shuffle arrays (counter-keyed shuffle) or directly behind the scheme scratch
+  l.mt = (p.shuffle && !p.rng_numpy) ? reinterpret_cast<uint32_t*>(l.fkey + fcap + (fcap & 1)) : after_cp;
   return l;
 }
 
@@ -152,6 +159,59 @@ __device__ inline StabState stab_view(const DiscreteParams& p, int e) {
   return st;
 }
 
+// ---- NumPy's legacy RandomState on MT19937, one stream per env, state in LDS (strict NumPy-stream mode) ----------
+// All 64 lanes call these with wave-uniform arguments and get wave-uniform results; the 624-word block is
+// regenerated by the whole wave (numpy/random/src/mt19937/mt19937.c mt19937_gen: word kk needs the OLD kk, kk+1
+// and -- below 227 -- the old kk+397, from 227 on the NEW kk-227: chunks of 64 in ascending order keep that).
+template <typename L>
+__device__ inline uint32_t mt_next(L& l, EnvRegs& r, int lane) {
+  if (r.mt_pos >= 624) {
+    for (int base = 0; base < 624; base += 64) {
+      const int kk = base + lane;
+      uint32_t v = 0;
+      if (kk < 624) {
+        const uint32_t u0 = l.mt[kk], u1 = l.mt[kk == 623 ? 0 : kk + 1];
+        const uint32_t m = l.mt[kk < 227 ? kk + 397 : kk - 227];
+        const uint32_t y = (u0 & 0x80000000u) | (u1 & 0x7fffffffu);
+        v = m ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      }
+      __syncthreads();
+      if (kk < 624) l.mt[kk] = v;
+      __syncthreads();
+    }
+    r.mt_pos = 0;
+  }
+  uint32_t y = __builtin_amdgcn_readfirstlane(l.mt[r.mt_pos]);
+  r.mt_pos++;
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return y;
+}
+// random_interval(max) / the masked rejection of the legacy randint(0, max + 1)
+template <typename L>
+__device__ inline uint32_t mt_interval(L& l, EnvRegs& r, int lane, uint32_t max) {
+  if (max == 0) return 0;
+  uint32_t mask = max;
+  mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+  uint32_t v;
+  while ((v = (mt_next(l, r, lane) & mask)) > max) {}
+  return v;
+}
+// np.random.random(): 53 bits from two words; D/bin3D.py:82-84 redraws while it is 0
+template <typename L>
+__device__ inline double mt_density(L& l, EnvRegs& r, int lane) {
+  double d;
+  do {
+    const uint32_t a = mt_next(l, r, lane) >> 5, b = mt_next(l, r, lane) >> 6;
+    d = ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+  } while (d == 0);
+  return d;
+}
+// Word kk == 623 of a regenerated block needs the NEW word 0: the chunk loop above reads l.mt[0] for it after the
+// first chunk has been written, which is exactly that.
+
 __device__ inline void draw_item(const DiscreteParams& p, int e, EnvRegs& r) {
   // binCreator.py:37-39 generate_box_size, through the scripted / counter-based sources
   uint64_t c = r.cursor++;
@@ -172,6 +232,17 @@ __device__ inline void draw_item(const DiscreteParams& p, int e, EnvRegs& r) {
     uint64_t g = (uint64_t)(p.env_id_base + e);
     it = p.item_set + (size_t)(pct_pick(p.seed, g, c, (uint32_t)p.n_items)) * 3;
   }
+  r.item0 = it[0];
+  r.item1 = it[1];
+  r.item2 = it[2];
+}
+
+// binCreator.py:37-39 in strict NumPy-stream mode: idx = np.random.randint(0, len(box_set))
+template <typename L>
+__device__ inline void draw_item_mt(const DiscreteParams& p, L& l, EnvRegs& r, int lane) {
+  r.cursor++;
+  const uint32_t idx = mt_interval(l, r, lane, (uint32_t)p.n_items - 1u);
+  const int32_t* it = p.item_set + (size_t)idx * 3;
   r.item0 = it[0];
   r.item1 = it[1];
   r.item2 = it[2];
@@ -588,9 +659,14 @@ __device__ inline void set_insert(SetState<K>& st, const K (&key)[V], const bool
 
 // D/space.py:534-570 EMSPoint (CPython-set order) + D/bin3D.py:100-136
 // get_possible_position: fills l.leaf[0..n_leaf) with the first <= L feasible candidates.
-template <typename K, int BITS, bool STAB, int SCHEME, bool SHUFFLE, typename TM>
+// RNG: bit 0 = the candidate list is shuffled before the first-L cut, bit 1 = strict NumPy-stream mode (the shuffle, the
+// item picks and the densities consume the env's MT19937 stream; otherwise they are counter-keyed)
+template <typename K, int BITS, bool STAB, int SCHEME, int RNG, typename TM>
 __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& l, EnvRegs& r, int lane, TM& tm) {
   typedef Pack<K, BITS> P;
+  constexpr bool SHUFFLE = (RNG & 1) != 0, MT = (RNG & 2) != 0;
+  // strict mode: the observation's density is drawn first (D/bin3D.py:80-84), the shuffle draws follow below
+  if (MT && p.setting == 3) r.den_cur = mt_density(l, r, lane);
   const int E = r.n_ems;
   const int b0 = r.item0, b1 = r.item1, b2 = r.item2;
   constexpr int orient = STAB ? 2 : 6;  // setting 2 <=> no stability check <=> 6 orientations (D/space.py:536-537)
@@ -1005,7 +1081,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
   int nleaf = 0;
   bool stab_err = false;
   // D/bin3D.py:75-84: the density drawn for this observation (setting 3), else 1
-  const double next_den = STAB ? next_density(p, e, r.oc, r.traj, r.cursor - 1) : 1.0;
+  const double next_den = !STAB ? 1.0 : (MT ? (p.setting == 3 ? r.den_cur : 1.0) : next_density(p, e, r.oc, r.traj, r.cursor - 1));
   auto feasible = [&](K k) -> bool {
     int xs = P::get(k, 0), ys = P::get(k, 1), xe = P::get(k, 3), ye = P::get(k, 4);
     int z = P::get(k, 5) - P::get(k, 2);
@@ -1027,7 +1103,43 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
     }
     return feas;
   };
-  if (SHUFFLE) {
+  if (SHUFFLE && MT) {
+    // bin3D.py:114-115 np.random.shuffle(allPostion), draw for draw: the keys are squeezed to the front of the table
+    // region in slot order (= the array the reference shuffles), then Fisher-Yates from the back with
+    // j = random_interval(i) (legacy RandomState.shuffle), then the plain first-L sweep over the permuted list
+    uint32_t cnt = 0;
+    for (uint32_t sb = 0; sb < size; sb += 64) {
+      K k = tabs[toff + sb + lane];
+      bool occ = (sb + lane < size) && k != SlotWord<K>::EMPTY;
+      uint64_t m = __ballot(occ);
+      __syncthreads();
+      if (occ) tabs[toff + cnt + rank_below(m)] = k;
+      cnt += (uint32_t)__popcll(m);
+      __syncthreads();
+    }
+    r.n_cand = (int)cnt;
+    for (int i = (int)cnt - 1; i >= 1; i--) {
+      const int j = (int)mt_interval(l, r, lane, (uint32_t)i);
+      if (j != i && lane == 0) {
+        const K a = tabs[toff + i], b = tabs[toff + j];
+        tabs[toff + i] = b;
+        tabs[toff + j] = a;
+      }
+    }
+    __syncthreads();
+    const uint32_t padded = (cnt + 63u) & ~63u;
+    if (cnt + lane < padded) tabs[toff + cnt + lane] = SlotWord<K>::EMPTY;
+    size = padded;
+    __syncthreads();
+    for (uint32_t sb = 0; sb < size && nleaf < p.L; sb += 64) {
+      K k = tabs[toff + sb + lane];
+      bool feas = (k != SlotWord<K>::EMPTY) && feasible(k);
+      uint64_t m = __ballot(feas);
+      int idx = nleaf + rank_below(m);
+      if (feas && idx < p.L) l.leaf[idx] = k;
+      nleaf += __popcll(m);
+    }
+  } else if (SHUFFLE) {
     // bin3D.py:114-115 np.random.shuffle(allPostion) -> pct_shuffle_priority: every candidate is
     // tested, the feasible ones are ranked by (priority, list index), the first L ranks are kept
     int nlist = 0, nf = 0;
@@ -1113,7 +1225,7 @@ __device__ inline void write_obs(const DiscreteParams& p, int e, const Lds<K, BI
   const int rows = p.I + p.L + 1;
   const bool dens = p.setting == 3;  // densities other than 1 (D/space.py:386, D/bin3D.py:91)
   const double* bden = p.st_den + (size_t)e * p.I;
-  const float nden = dens ? (float)next_density(p, e, r.oc - 1, r.traj, r.cursor - 1) : 1.0f;
+  const float nden = !dens ? 1.0f : (p.rng_numpy ? (float)r.den_cur : (float)next_density(p, e, r.oc - 1, r.traj, r.cursor - 1));
   if (!full && new_row >= 0 && lane < 9) {
     K k = l.box[new_row];
     float v = lane < 6 ? (float)P::get(k, lane) : (lane == 7 ? 0.f : 1.0f);
@@ -1191,6 +1303,14 @@ __device__ inline void load_state(const DiscreteParams& p, int e, Lds<K, BITS>& 
   r.vol = (int64_t)(((uint64_t)(uint32_t)sc[11] << 32) | (uint32_t)sc[10]);
   r.traj = sc[12];
   r.oc = (uint32_t)sc[13];
+  r.mt_pos = sc[7];
+  r.n_cand = sc[14];
+  r.den_cur = 1.0;
+  if (p.rng_numpy) {
+    const uint32_t* gm = p.mt + (size_t)e * 624;
+    for (int i = lane; i < 624; i += 64) l.mt[i] = gm[i];
+    if (p.setting == 3) r.den_cur = p.mt_den[e];
+  }
   const int n_fit = r.n_ems < p.ems_cap ? r.n_ems : p.ems_cap;  // a longer list belongs to the retry pass (caller checks)
   if (lane < n_fit) l.ems_a[lane] = e0;
   if (lane + 64 < n_fit) l.ems_a[lane + 64] = e1;
@@ -1217,11 +1337,17 @@ __device__ inline void store_state(const DiscreteParams& p, int e, const Lds<K, 
   for (int i = r.box_from + lane; i < r.n_boxes; i += 64) g_box[i] = l.box[i];
   for (int i = lane; i < r.n_leaf; i += 64) g_leaf[i] = l.leaf[i];
   for (int i = lane; i < p.AA; i += 64) g_h[i] = (int16_t)l.hmap[i];
+  if (p.rng_numpy) {
+    uint32_t* gm = p.mt + (size_t)e * 624;
+    for (int i = lane; i < 624; i += 64) gm[i] = l.mt[i];
+  }
   if (lane == 0) {
     sc[0] = r.n_ems; sc[1] = r.n_boxes; sc[2] = r.n_leaf;
     sc[3] = r.item0; sc[4] = r.item1; sc[5] = r.item2;
     sc[6] = (int32_t)r.t;
-    sc[7] = 0;
+    sc[7] = r.mt_pos;
+    sc[14] = r.n_cand;
+    if (p.rng_numpy && p.setting == 3) p.mt_den[e] = r.den_cur;
     p.flags[e] = r.flags;
     sc[8] = (int32_t)(uint32_t)r.cursor; sc[9] = (int32_t)(uint32_t)(r.cursor >> 32);
     sc[10] = (int32_t)(uint32_t)(uint64_t)r.vol; sc[11] = (int32_t)(uint32_t)((uint64_t)r.vol >> 32);
@@ -1551,16 +1677,17 @@ __device__ inline bool heur_choose(const DiscreteParams& p, int e, Lds<K, BITS>&
 
 // One transition of one env with the state resident in LDS (D/bin3D.py:151-188 plus the
 // VecEnv worker's auto-reset).  (flag, lx, ly) + (bx, by, bz) is the decoded action.
-template <typename K, int BITS, bool STAB, int SCHEME, typename TM>
+template <typename K, int BITS, bool STAB, int SCHEME, int RNG, typename TM>
 __device__ inline bool transition(const DiscreteParams& p, int e, Lds<K, BITS>& l, EnvRegs& r, int lane, bool bad,
                                   int flag, int lx, int ly, int bx, int by, int bz, TM& tm, bool giveup = false) {
   typedef Pack<K, BITS> P;
+  constexpr bool SHUFFLE = (RNG & 1) != 0, MT = (RNG & 2) != 0;
   r.t++;
   int x = flag ? by : bx, y = flag ? bx : by, z = bz;  // D/space.py:348-351
   bool ok = !bad && !giveup;  // giveup: a heuristic found no placement -- the episode ends without a step()
   int max_h = 0;
   // the density shown with the observation this action answers (D/bin3D.py:158 self.next_den)
-  const double item_den = STAB ? next_density(p, e, r.oc - 1, r.traj, r.cursor - 1) : 1.0;
+  const double item_den = !STAB ? 1.0 : (MT ? (p.setting == 3 ? r.den_cur : 1.0) : next_density(p, e, r.oc - 1, r.traj, r.cursor - 1));
   if (ok) {
     // np.max(plain[lx:lx+x, ly:ly+y]) with Python slice normalisation (D/space.py:354-355)
     int xa = lx, xb = lx + x, ya = ly, yb = ly + y;
@@ -1649,12 +1776,21 @@ __device__ inline bool transition(const DiscreteParams& p, int e, Lds<K, BITS>& 
     counter = r.n_boxes;
     ratio = (double)r.vol / binvol;  // D/space.py:334-339
     if (!giveup) r.oc++;  // the terminal step's own (discarded) observation consumed a shuffle too (D/bin3D.py:165)
+    if (MT && !giveup) {
+      // ... and in strict NumPy-stream mode its draws: cur_observation() of the unchanged bin and item redraws the
+      // density (setting 3) and shuffles the same candidate list once more -- n_cand - 1 random_interval draws
+      if (p.setting == 3) (void)mt_density(l, r, lane);
+      if (SHUFFLE)
+        for (int i = r.n_cand - 1; i >= 1; i--) (void)mt_interval(l, r, lane, (uint32_t)i);
+    }
     __syncthreads();
     space_reset<K, BITS>(p, l, r, lane);  // shmem_vec_env.py:141-143 -> D/bin3D.py:61-67
     __syncthreads();
     tm.tick(PH_DROP);
   }
-  if (r.cursor == r.pre_cursor && r.traj == r.pre_traj) {  // the usual case: the prefetched draw
+  if (MT) {
+    draw_item_mt(p, l, r, lane);  // np.random.randint(0, len(box_set)): after a success and after the reset alike
+  } else if (r.cursor == r.pre_cursor && r.traj == r.pre_traj) {  // the usual case: the prefetched draw
     r.item0 = r.pre0; r.item1 = r.pre1; r.item2 = r.pre2;
     r.cursor++;
   } else {
@@ -1699,7 +1835,7 @@ __device__ inline void decode_leaf(const EnvRegs& r, bool zero_row, int xs, int 
 enum { ACT_ROWS = 0, ACT_INDEX = 1, ACT_HASH = 2, ACT_RESET = 3, ACT_HEUR = 4 /* row_len = PCT_HEUR_* */ };
 
 // one env, one launch's worth of transitions (the body of the kernel below)
-template <typename K, int BITS, int ACT, bool TIMED, bool STAB, int SCHEME, bool SHUFFLE>
+template <typename K, int BITS, int ACT, bool TIMED, bool STAB, int SCHEME, int RNG>
 __device__ inline void discrete_env_steps(const DiscreteParams& p, const void* __restrict__ actions, int row_len, int n_steps,
                                           int e, unsigned char* smem) {
   const int lane = threadIdx.x;
@@ -1720,7 +1856,7 @@ __device__ inline void discrete_env_steps(const DiscreteParams& p, const void* _
   {  // the next draw of the item source does not depend on this step's outcome (except after a
      // dataset reset): issue its loads now, use them at the end of the transition
     EnvRegs nx = r;
-    draw_item(p, e, nx);
+    if (!(RNG & 2)) draw_item(p, e, nx);  // (the NumPy stream is consumed strictly in order: no look-ahead)
     r.pre0 = nx.item0; r.pre1 = nx.item1; r.pre2 = nx.item2;
     r.pre_cursor = r.cursor;
     r.pre_traj = r.traj;
@@ -1744,8 +1880,9 @@ __device__ inline void discrete_env_steps(const DiscreteParams& p, const void* _
   if (ACT == ACT_RESET) {
     space_reset<K, BITS>(p, l, r, lane);
     __syncthreads();
-    draw_item(p, e, r);
-    leaf_nodes<K, BITS, STAB, SCHEME, SHUFFLE>(p, e, l, r, lane, tm);
+    if (RNG & 2) draw_item_mt(p, l, r, lane);
+    else draw_item(p, e, r);
+    leaf_nodes<K, BITS, STAB, SCHEME, RNG>(p, e, l, r, lane, tm);
     if (overflowed()) {
       if (lane == 0) p.retry_ids[atomicAdd(p.retry_count, 1)] = e;
       return;
@@ -1788,8 +1925,8 @@ __device__ inline void discrete_env_steps(const DiscreteParams& p, const void* _
       decode_leaf(r, zero_row, P::get(k, 0), P::get(k, 1), P::get(k, 3), P::get(k, 4), bad, lx, ly, bx, by, bz);
     }
     if (bad) r.flags |= PCT_FLAG_BAD_ACTION;  // ValueError in list.remove, D/bin3D.py:144-145
-    const bool ended = transition<K, BITS, STAB, SCHEME>(p, e, l, r, lane, bad, flag, lx, ly, bx, by, bz, tm, giveup);
-    leaf_nodes<K, BITS, STAB, SCHEME, SHUFFLE>(p, e, l, r, lane, tm);
+    const bool ended = transition<K, BITS, STAB, SCHEME, RNG>(p, e, l, r, lane, bad, flag, lx, ly, bx, by, bz, tm, giveup);
+    leaf_nodes<K, BITS, STAB, SCHEME, RNG>(p, e, l, r, lane, tm);
     if (overflowed()) {
       if (lane == 0) p.retry_ids[atomicAdd(p.retry_count, 1)] = e;
       return;
@@ -1803,7 +1940,7 @@ __device__ inline void discrete_env_steps(const DiscreteParams& p, const void* _
   if (TIMED && lane == 0) tm.flush(p.timing + (size_t)e * PCT_TIMING_SLOTS, n_steps);
 }
 
-template <typename K, int BITS, int ACT, bool TIMED, bool STAB, int SCHEME, bool SHUFFLE>
+template <typename K, int BITS, int ACT, bool TIMED, bool STAB, int SCHEME, int RNG>
 // the plain setting-2 kernels are held to 128 VGPRs (4 waves per SIMD = 16 resident envs per CU, the
 // occupancy the LDS layout is sized for); the float64 stability code and the timed build are not
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STAB ? 1 : 4)))
@@ -1818,7 +1955,7 @@ pct_discrete_kernel(DiscreteParams p, const void* __restrict__ actions,
     const int limit = *p.retry_count;
     if (blockIdx.x == 0 && threadIdx.x == 0) p.retry_count[p.retry_mode] = 0;  // retry_mode = +1 / -1: offset of the other
     for (int w = blockIdx.x; w < limit; w += gridDim.x) {
-      discrete_env_steps<K, BITS, ACT, TIMED, STAB, SCHEME, SHUFFLE>(p, actions, row_len, n_steps, p.retry_ids[w], smem);
+      discrete_env_steps<K, BITS, ACT, TIMED, STAB, SCHEME, RNG>(p, actions, row_len, n_steps, p.retry_ids[w], smem);
       __syncthreads();
     }
     return;
@@ -1829,7 +1966,7 @@ pct_discrete_kernel(DiscreteParams p, const void* __restrict__ actions,
     e = env_ids[e];
     if (e < 0 || e >= p.N) return;
   }
-  discrete_env_steps<K, BITS, ACT, TIMED, STAB, SCHEME, SHUFFLE>(p, actions, row_len, n_steps, e, smem);
+  discrete_env_steps<K, BITS, ACT, TIMED, STAB, SCHEME, RNG>(p, actions, row_len, n_steps, e, smem);
 }
 
 }  // namespace pct
@@ -1844,7 +1981,8 @@ inline size_t discrete_lds_bytes_impl(const DiscreteParams& p) {
   size_t n = (size_t)table_words_compact((uint32_t)p.cand_cap) + p.ems_cap + discrete_scratch_words(p) + p.I + p.L;
   size_t hb = ((size_t)p.AA * (k == 4 ? 1 : 2) + 3) & ~(size_t)3;
   size_t cp = (size_t)discrete_scheme_words(p) * sizeof(uint32_t);
-  if (p.shuffle) cp += ((size_t)(p.cand_cap * 3) / 5 + 4) * (sizeof(uint32_t) + k);
+  if (p.shuffle && !p.rng_numpy) cp += ((size_t)(p.cand_cap * 3) / 5 + 4) * (sizeof(uint32_t) + k);
+  if (p.rng_numpy) cp += 624 * sizeof(uint32_t);
   return n * k + hb + 64 * sizeof(uint16_t) + cp;
 }
 
@@ -1857,7 +1995,9 @@ inline hipError_t launch_typed(const DiscreteParams& p, int act, const void* act
   const int scheme = p.lnes == PCT_LNES_EMS ? 0 : 1;  // 1: every other expansion, dispatched inside the kernel
   int grid = p.retry_mode ? n_ids : ((act == ACT_RESET && env_ids) ? n_ids : p.N);
   if (grid <= 0) return hipSuccess;
-#define PCT_KERN(A, T, S, C) (p.shuffle ? pct_discrete_kernel<K, BITS, A, false, S, C, true> : pct_discrete_kernel<K, BITS, A, T, S, C, false>)
+  // RNG mode: bit 0 shuffle, bit 1 strict NumPy stream (EMS expansion with 32-bit keys only; checked by the host)
+#define PCT_KERN_MT(A, S, C) ((sizeof(K) == 4 && (C) == 0 && p.rng_numpy) ? (p.shuffle ? pct_discrete_kernel<K, BITS, A, false, S, 0, (sizeof(K) == 4 ? 3 : 1)> : pct_discrete_kernel<K, BITS, A, false, S, 0, (sizeof(K) == 4 ? 2 : 0)>) : nullptr)
+#define PCT_KERN(A, T, S, C) (PCT_KERN_MT(A, S, C) ? PCT_KERN_MT(A, S, C) : (p.shuffle ? pct_discrete_kernel<K, BITS, A, false, S, C, 1> : pct_discrete_kernel<K, BITS, A, T, S, C, 0>))
 #define PCT_LAUNCH(A)                                                                                        \
   do {                                                                                                       \
     void (*kern)(DiscreteParams, const void*, int, int, const int32_t*, int);                                \
@@ -1873,10 +2013,10 @@ inline hipError_t launch_typed(const DiscreteParams& p, int act, const void* act
   } while (0)
   if (act == ACT_HEUR) {  // heuristic policies read the EMS list: LNES == EMS only (checked by the caller)
     void (*kern)(DiscreteParams, const void*, int, int, const int32_t*, int);
-    if (stab) kern = p.shuffle ? pct_discrete_kernel<K, BITS, ACT_HEUR, false, true, 0, true>
-                               : pct_discrete_kernel<K, BITS, ACT_HEUR, false, true, 0, false>;
-    else kern = p.shuffle ? pct_discrete_kernel<K, BITS, ACT_HEUR, false, false, 0, true>
-                          : pct_discrete_kernel<K, BITS, ACT_HEUR, false, false, 0, false>;
+    if (stab) kern = p.shuffle ? pct_discrete_kernel<K, BITS, ACT_HEUR, false, true, 0, 1>
+                               : pct_discrete_kernel<K, BITS, ACT_HEUR, false, true, 0, 0>;
+    else kern = p.shuffle ? pct_discrete_kernel<K, BITS, ACT_HEUR, false, false, 0, 1>
+                          : pct_discrete_kernel<K, BITS, ACT_HEUR, false, false, 0, 0>;
     if (lds > 48 * 1024) {
       hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (er != hipSuccess) return er;

@@ -45,6 +45,8 @@ struct pct_env {
   int d_retry_ems, d_retry_cand;
   int* d_retry_base;    /* [2] ping-pong queue counters */
   int d_retry_parity;
+  int* c_retry_base;    /* continuous env: the same */
+  int c_retry_parity;
   bool continuous;
   // owned device memory
   std::vector<void*> owned;
@@ -128,7 +130,7 @@ int launch(pct_env* h, int act, const void* actions, int row_len, int n_steps, c
   }
   if (h->continuous) {
     h->cp.full_obs = h->dp.full_obs;
-    if (h->has_retry) HIP_TRY(hipMemsetAsync(h->cp.retry_count, 0, sizeof(int), s));
+    if (h->has_retry) h->cp.retry_count = h->c_retry_base + h->c_retry_parity; /* ping-pong pair of queue counters */
     HIP_TRY(pct::launch_continuous(h->cp, act, actions, row_len, n_steps, ids, n_ids, s));
     if (h->has_retry) {
       /* keep the retry pass in step with everything that may have changed on the handle */
@@ -140,6 +142,9 @@ int launch(pct_env* h, int act, const void* actions, int row_len, int n_steps, c
       q.item_set = c.item_set; q.n_items = c.n_items;
       q.low_bound = c.low_bound; q.obs = c.obs; q.reward = c.reward; q.done = c.done; q.counter = c.counter;
       q.ratio = c.ratio; q.flags = c.flags; q.timing = nullptr; q.full_obs = c.full_obs; q.mask = c.mask;
+      q.retry_count = c.retry_count;
+      q.retry_mode = h->c_retry_parity ? -1 : 1;
+      h->c_retry_parity ^= 1;
       HIP_TRY(pct::launch_continuous(q, act, actions, row_len, n_steps, ids, h->cp_retry_blocks, s));
     }
     if (act != ACT_RESET || !ids) h->dp.full_obs = 0;
@@ -201,9 +206,10 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
   /* EMS kept after elimination: 128 covers the 10-unit bins of both envs with room to spare (most
    * ever seen: 59 discrete, 81 continuous), larger bins default to 256 */
   /* continuous bins beyond 12 units (BASELINE configs[4]: 100^3 with U(5,25) items holds up to ~260 live EMS and
-   * several thousand distinct candidates): 768 EMS and a 32768-slot candidate table, which lives in HBM */
+   * several thousand distinct candidates): a 384-EMS LDS list (longer lists go through the retry pass, up to 1536)
+   * and a 32768-slot candidate table, which lives in HBM */
   int ems_cap = cfg->ems_capacity > 0 ? cfg->ems_capacity
-                                      : (((cont ? maxdim / 1000 : maxdim) <= 12) ? 128 : (cont ? 768 : 256));
+                                      : (((cont ? maxdim / 1000 : maxdim) <= 12) ? 128 : (cont ? 384 : 256));
   if (!cont && ems_cap < 64) return fail(PCT_ERR_INVALID_ARG, "ems_capacity must be >= 64");
   /* candidate table: 2048 slots (1228 distinct candidates) cover the 10^3-class bins with room to
    * spare; larger discrete bins default to 8192 (4915) */
@@ -267,7 +273,24 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
     rc = dev_alloc(h, (void**)&(ptr), (bytes), true);        \
     if (rc) { pct_destroy(h); return rc; }                   \
   } while (0)
-    CALLOC_(c.ems, Nn * 6 * c.ems_cap * sizeof(int32_t));
+    /* the retry pass keeps four times the EMS list (its LDS permitting, and below the 16-bit generator-id limit of
+     * 2729 EMS); the HBM rows are as long as the longest list any pass may leave behind */
+    c.ems_stride = ems_cap;
+    if (!c.table_global || true) {
+      int big = ems_cap * 4;
+      if (big > 2560) big = 2560;
+      pct::ContinuousParams t = c;
+      t.ems_cap = big;
+      t.table_global = 1;
+      t.union_words = 12 * big;
+      while (big > ems_cap && pct::continuous_lds_bytes(t) > 150 * 1024) {
+        big -= ems_cap;
+        t.ems_cap = big;
+        t.union_words = 12 * big;
+      }
+      if (big > ems_cap) c.ems_stride = big;
+    }
+    CALLOC_(c.ems, Nn * 6 * c.ems_stride * sizeof(int32_t));
     CALLOC_(c.boxes, Nn * 6 * c.I * sizeof(double));
     CALLOC_(c.leafg, Nn * c.L * sizeof(uint16_t));
     CALLOC_(c.volsum, Nn * sizeof(double));
@@ -295,11 +318,14 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
     CALLOC_(h->own_counter, Nn * sizeof(int32_t));
     CALLOC_(h->own_ratio, Nn * sizeof(double));
     h->has_retry = false;
-    if (!c.table_global) {
-      /* normal pass: table in LDS; envs that need more are re-run by a small grid-strided pass
-       * with 32768-slot tables in HBM (covers ems_capacity * 24 candidates up to 19660) */
+    {
+      /* normal pass: table in LDS (or, beyond 8192 slots, already in HBM); envs that need more -- a larger
+       * candidate table or a longer EMS list -- are re-run by a small grid-strided pass with 32768-slot tables in
+       * HBM (covers ems_capacity * 24 candidates up to 19660) and ems_stride EMS */
       const int RB = 128, big = 32768;
-      CALLOC_(c.retry_count, sizeof(int));
+      CALLOC_(h->c_retry_base, 2 * sizeof(int));
+      c.retry_count = h->c_retry_base;
+      h->c_retry_parity = 0;
       CALLOC_(c.retry_ids, Nn * sizeof(int));
       h->has_retry = true;
       h->cp_retry_blocks = RB;
@@ -310,7 +336,8 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
       q.gt_by_block = 1;
       q.cand_cap = big;
       q.order_cap = (big * 3) / 5 + 8;
-      q.union_words = 12 * ems_cap > 192 ? 12 * ems_cap : 192; /* children scratch only: 2 * ems_cap of them, as in the normal pass */
+      q.ems_cap = c.ems_stride;
+      q.union_words = 12 * q.ems_cap > 192 ? 12 * q.ems_cap : 192; /* children scratch only: 2 * ems_cap of them */
       CALLOC_(q.gtab, (size_t)RB * (size_t)(big + big / 4) * sizeof(uint32_t));
       CALLOC_(q.gorder, (size_t)RB * (size_t)q.order_cap * sizeof(uint16_t));
       if (c.shuffle) CALLOC_(q.gfpri, (size_t)RB * (size_t)q.order_cap * sizeof(uint32_t));
@@ -551,6 +578,41 @@ int pct_set_shuffle_seed(pct_env* h, uint64_t seed) {
   return PCT_OK;
 }
 
+int pct_set_numpy_rng(pct_env* h, uint32_t seed) {
+  if (!h) return fail(PCT_ERR_INVALID_ARG, "null handle");
+  if (h->continuous || h->dp.key_bytes != 4 || h->cfg.lnes != PCT_LNES_EMS)
+    return fail(PCT_ERR_UNSUPPORTED, "NumPy-stream mode: discrete env, bins up to 31 per axis, LNES = EMS");
+  if (!h->have_items) return fail(PCT_ERR_STATE, "pct_set_item_set must come first");
+  if (h->was_reset) return fail(PCT_ERR_STATE, "pct_set_numpy_rng must precede the first reset");
+  int rc = use_device(h);
+  if (rc) return rc;
+  const size_t N = (size_t)h->dp.N;
+  if (!h->dp.mt) {
+    rc = dev_alloc(h, (void**)&h->dp.mt, N * 624 * sizeof(uint32_t), false);
+    if (rc) return rc;
+    rc = dev_alloc(h, (void**)&h->dp.mt_den, N * sizeof(double), true);
+    if (rc) return rc;
+  }
+  /* np.random.seed(seed + rank) in every worker (envs.py:49, bin3D.py:47-54): mt19937_seed == init_genrand */
+  std::vector<uint32_t> st(N * 624);
+  for (size_t e = 0; e < N; e++) {
+    uint32_t sd = seed + (uint32_t)h->cfg.env_id_base + (uint32_t)e;
+    for (int i = 0; i < 624; i++) {
+      st[e * 624 + i] = sd;
+      sd = 1812433253u * (sd ^ (sd >> 30)) + (uint32_t)i + 1u;
+    }
+  }
+  HIP_TRY(hipMemcpy(h->dp.mt, st.data(), st.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  /* position 624: the first draw regenerates the block (scalars[7] of every env) */
+  std::vector<int32_t> pos(N, 624);
+  HIP_TRY(hipMemcpy2D(h->dp.scalars + 7, PCT_SCALARS * sizeof(int32_t), pos.data(), sizeof(int32_t), sizeof(int32_t), N,
+                      hipMemcpyHostToDevice));
+  h->dp.rng_numpy = 1;
+  h->dp.source = PCT_ITEMS_SAMPLER;
+  if (pct::discrete_lds_bytes(h->dp) > 160 * 1024) return fail(PCT_ERR_INVALID_ARG, "capacities + MT19937 state exceed the LDS");
+  return PCT_OK;
+}
+
 int pct_set_sampler(pct_env* h, uint64_t seed) {
   if (!h) return fail(PCT_ERR_INVALID_ARG, "null handle");
   if (!h->have_items) return fail(PCT_ERR_STATE, "pct_set_item_set must come first");
@@ -768,10 +830,10 @@ int pct_debug_state_f64(pct_env* h, int32_t e, double* ems, int32_t cap_ems, int
   int32_t sc[PCT_SCALARS];
   HIP_TRY(hipMemcpy(sc, c.scalars + (size_t)e * PCT_SCALARS, sizeof sc, hipMemcpyDeviceToHost));
   if (ems) {
-    std::vector<int32_t> raw((size_t)6 * c.ems_cap);
-    HIP_TRY(hipMemcpy(raw.data(), c.ems + (size_t)e * 6 * c.ems_cap, raw.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    std::vector<int32_t> raw((size_t)6 * c.ems_stride);
+    HIP_TRY(hipMemcpy(raw.data(), c.ems + (size_t)e * 6 * c.ems_stride, raw.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
     for (int i = 0; i < sc[0] && i < cap_ems; i++)
-      for (int k = 0; k < 6; k++) ems[6 * i + k] = (double)raw[(size_t)k * c.ems_cap + i] / 1e6; /* the double the lattice index stands for */
+      for (int k = 0; k < 6; k++) ems[6 * i + k] = (double)raw[(size_t)k * c.ems_stride + i] / 1e6; /* the double the lattice index stands for */
   }
   if (n_ems) *n_ems = sc[0];
   if (n_boxes) *n_boxes = sc[1];

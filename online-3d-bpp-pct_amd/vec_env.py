@@ -130,7 +130,7 @@ class PctVecEnv(VecEnv):
                  load_test_data=False, internal_node_holder=80, leaf_node_holder=50, LNES="EMS", shuffle=False,
                  sample_from_distribution=False, sample_left_bound=None, sample_right_bound=None,
                  device="cuda:0", seed=0, env_id_base=0, item_stream=None, continuous=False, monitor=True,
-                 strict=True, ems_capacity=0, candidate_capacity=0, overflow_retry=True):
+                 strict=True, ems_capacity=0, candidate_capacity=0, overflow_retry=True, rng="counter"):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise PctEnvError("PctVecEnv runs on an AMD GPU only (device=%r); there is no CPU path" % (device,))
@@ -202,10 +202,16 @@ class PctVecEnv(VecEnv):
             items = np.ascontiguousarray(np.asarray(item_set, dtype=np.int32).reshape(-1, 3))
             _lib.check(self._L.pct_set_item_set(self._h, items.ctypes.data, items.shape[0]))
             self.item_set = items
+        if rng not in ("counter", "numpy"):
+            raise ValueError("rng must be 'counter' (counter-keyed draws, the default) or 'numpy' (the reference's own "
+                             "per-env MT19937 stream, np.random.seed(seed + rank))")
+        self.rng = rng
         if self._dataset is not None:
             self.set_item_dataset(self._dataset)
         elif item_stream is not None:
             self.set_item_stream(item_stream)
+        elif rng == "numpy":
+            _lib.check(self._L.pct_set_numpy_rng(self._h, int(seed) & 0xFFFFFFFF))
         else:
             _lib.check(self._L.pct_set_sampler(self._h, int(seed)))
 

@@ -54,6 +54,7 @@ def lib():
         L.pcto_set_sample_bounds.argtypes = [vp, ctypes.c_int32, ctypes.c_int32]
         L.pcto_set_item_dataset.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int32]
         L.pcto_set_sampler.argtypes = [vp, ctypes.c_uint64]
+        L.pcto_set_numpy_rng.argtypes = [vp, ctypes.c_uint32]
         L.pcto_set_shuffle_seed.argtypes = [vp, ctypes.c_uint64]
         L.pcto_step_heuristic.argtypes = [vp, ctypes.c_int32, ctypes.c_int32]
         L.pcto_set_density_stream.argtypes = [vp, vp, ctypes.c_int64]
@@ -155,6 +156,10 @@ class OracleVecEnv(object):
 
     def set_sampler(self, seed):
         self._check(lib().pcto_set_sampler(self._h, seed))
+
+    def set_numpy_rng(self, seed):
+        """strict NumPy-stream mode: env e consumes np.random.seed(seed + env_id_base + e)'s MT19937 stream"""
+        self._check(lib().pcto_set_numpy_rng(self._h, int(seed) & 0xFFFFFFFF))
 
     def reset(self, env_ids=None):
         if env_ids is None:

@@ -167,7 +167,8 @@ static void draw_item(const pcto_env* h, int e, oenv* s, int out[3]) {
     out[0] = p[0]; out[1] = p[1]; out[2] = p[2];
   } else {
     uint64_t g = (uint64_t)(h->cfg.env_id_base + e);
-    uint64_t idx = pct_pick(h->seed, g, c, (uint32_t)h->n_items);
+    uint64_t idx = h->rng_numpy ? npmt_interval(s->mt, &s->mt_pos, (uint32_t)h->n_items - 1u) /* np.random.randint(0, n), binCreator.py:38 */
+                                : pct_pick(h->seed, g, c, (uint32_t)h->n_items);
     out[0] = h->item_set[idx * 3 + 0];
     out[1] = h->item_set[idx * 3 + 1];
     out[2] = h->item_set[idx * 3 + 2];
@@ -740,7 +741,15 @@ static void get_possible_position(const pcto_env* h, int e, oenv* s, double* lea
           : h->cfg.lnes == PCT_LNES_FC ? full_coord(h, s, &pos)
           : h->cfg.lnes == PCT_LNES_EP ? extreme_point(h, s, &pos)
           : h->cfg.lnes == PCT_LNES_EV ? event_point(h, s, &pos) : ems_point(h, s, &pos);
-  if (h->cfg.shuffle) shuffle_rows_i64(h, e, s->oc, pos, n); /* D/bin3D.py:114-115 */
+  if (h->cfg.shuffle && h->rng_numpy) {
+    /* np.random.shuffle(allPostion) on the [n,6] array (legacy RandomState.shuffle: Fisher-Yates from the back,
+     * j = random_interval(i), rows swapped) */
+    for (int i = n - 1; i >= 1; i--) {
+      int j = (int)npmt_interval(s->mt, &s->mt_pos, (uint32_t)i);
+      if (j == i) continue;
+      for (int c = 0; c < 6; c++) { int64_t t_ = pos[6 * i + c]; pos[6 * i + c] = pos[6 * j + c]; pos[6 * j + c] = t_; }
+    }
+  } else if (h->cfg.shuffle) shuffle_rows_i64(h, e, s->oc, pos, n); /* D/bin3D.py:114-115 */
   s->oc++;
   int idx = 0;
   for (int i = 0; i < n; i++) {
@@ -767,6 +776,9 @@ static void cur_observation(const pcto_env* h, int e, oenv* s, double* obs) {
   }
   s->next_box[0] = s->queue_item[0]; s->next_box[1] = s->queue_item[1]; s->next_box[2] = s->queue_item[2];
   s->next_den = pcto_next_density(h, e, s->oc, s->traj, s->cursor - 1); /* :75-84 */
+  if (h->rng_numpy && h->cfg.setting == 3 && h->source != PCT_ITEMS_DATASET) { /* np.random.random(), redrawn while 0 (:82-84) */
+    do { s->next_den = npmt_double(s->mt, &s->mt_pos); } while (s->next_den == 0);
+  }
   memcpy(obs, s->box_vec, sizeof(double) * 9 * h->I);
   get_possible_position(h, e, s, obs + 9 * h->I);
   int a = s->next_box[0], b = s->next_box[1], c = s->next_box[2], tmp;
@@ -985,6 +997,18 @@ int pcto_set_shuffle_seed(pcto_env* h, uint64_t seed) {
   h->shuffle_seed = seed;
   return PCT_OK;
 }
+/* strict NumPy-stream mode: env e consumes the MT19937 stream np.random.seed(seed + env_id_base + e) starts
+ * (every worker of ShmemVecEnv(fork) seeds its own process-global RandomState: envs.py:49, bin3D.py:47-54);
+ * items come from the item set through np.random.randint.  Discrete env. */
+int pcto_set_numpy_rng(pcto_env* h, uint32_t seed) {
+  if (!h || !h->item_set) return fail(PCT_ERR_STATE, "set the item set first");
+  if (h->cfg.env_kind != PCT_ENV_DISCRETE) return fail(PCT_ERR_UNSUPPORTED, "NumPy-stream mode: discrete env only");
+  h->rng_numpy = 1;
+  h->source = PCT_ITEMS_SAMPLER;
+  for (int e = 0; e < h->N; e++) npmt_seed(h->envs[e].mt, &h->envs[e].mt_pos, seed + (uint32_t)h->cfg.env_id_base + (uint32_t)e);
+  return PCT_OK;
+}
+
 int pcto_set_sampler(pcto_env* h, uint64_t seed) {
   if (!h || !h->item_set) return fail(PCT_ERR_STATE, "set the item set / sample bounds first");
   h->seed = seed;

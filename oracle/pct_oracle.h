@@ -36,6 +36,8 @@ int pcto_set_sample_bounds(pcto_env* env, int32_t left, int32_t right);
 int pcto_set_item_stream(pcto_env* env, const int32_t* items, int64_t T);
 int pcto_set_item_dataset(pcto_env* env, const int32_t* items, const int32_t* lengths, int32_t n_traj, int32_t max_len);
 int pcto_set_sampler(pcto_env* env, uint64_t seed);
+/* strict NumPy-stream mode (discrete env): env e consumes the MT19937 stream of np.random.seed(seed + env_id_base + e) */
+int pcto_set_numpy_rng(pcto_env* env, uint32_t seed);
 int pcto_step_heuristic(pcto_env* env, int32_t kind, int32_t n_steps);
 int pcto_set_density_stream(pcto_env* env, const double* den, int64_t T);
 int pcto_set_dataset_density(pcto_env* env, const double* den);

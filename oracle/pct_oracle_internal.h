@@ -29,6 +29,10 @@ typedef struct {
   struct stab* stab; /* stability state (settings 1 / 3), pct_oracle_stab.c */
   int traj;          /* dataset mode: LoadBoxCreator.index (binCreator.py:46,54-55) */
   uint64_t oc;       /* observations produced so far (shuffle key) */
+  /* strict NumPy-stream mode (pcto_set_numpy_rng): this env's MT19937 state, as np.random.seed(seed + rank)
+   * leaves it in the env's worker process (bin3D.py:47-54, envs.py:49) */
+  uint32_t mt[624];
+  int mt_pos;
 } oenv;
 
 struct cenv; /* continuous per-env state, pct_oracle_cont.c */
@@ -50,6 +54,7 @@ struct pcto_env {
   double* ds_den;     /* setting 3, dataset mode: [n_traj,max_len] fourth column, or NULL */
   uint64_t seed;
   uint64_t shuffle_seed;
+  int rng_numpy; /* 1: item picks, densities and the candidate shuffle consume the env's NumPy MT19937 stream */
   int source;
   oenv* envs;
   double* obs;
@@ -60,6 +65,52 @@ struct pcto_env {
   uint32_t* flags;
 };
 
+
+/* ---- NumPy's legacy RandomState on MT19937 (numpy/random/src/mt19937/mt19937.c, legacy-distributions.c,
+ * distributions.c; the module-level np.random.* functions the reference calls) --------------------------- */
+static inline void npmt_seed(uint32_t* mt, int* pos, uint32_t seed) { /* mt19937_seed == init_genrand */
+  for (int i = 0; i < 624; i++) {
+    mt[i] = seed;
+    seed = 1812433253u * (seed ^ (seed >> 30)) + (uint32_t)i + 1u;
+  }
+  *pos = 624;
+}
+static inline uint32_t npmt_next32(uint32_t* mt, int* pos) { /* mt19937_next: regenerate all 624 words, then temper */
+  if (*pos >= 624) {
+    int kk = 0;
+    for (; kk < 624 - 397; kk++) {
+      uint32_t y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu);
+      mt[kk] = mt[kk + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    for (; kk < 623; kk++) {
+      uint32_t y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu);
+      mt[kk] = mt[kk + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    uint32_t y = (mt[623] & 0x80000000u) | (mt[0] & 0x7fffffffu);
+    mt[623] = mt[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    *pos = 0;
+  }
+  uint32_t y = mt[(*pos)++];
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return y;
+}
+/* random_interval(max) / the masked rejection of legacy randint(0, max + 1): smallest bit mask >= max, draw
+ * 32-bit words until (word & mask) <= max */
+static inline uint32_t npmt_interval(uint32_t* mt, int* pos, uint32_t max) {
+  if (max == 0) return 0;
+  uint32_t mask = max;
+  mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+  uint32_t v;
+  while ((v = (npmt_next32(mt, pos) & mask)) > max) {}
+  return v;
+}
+static inline double npmt_double(uint32_t* mt, int* pos) { /* random_sample: 53 bits from two words */
+  uint32_t a = npmt_next32(mt, pos) >> 5, b = npmt_next32(mt, pos) >> 6;
+  return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+}
 
 /* D/bin3D.py:75-84 next_den of observation number `oc`; `traj`/`item_index` locate the previewed
  * item in dataset mode */

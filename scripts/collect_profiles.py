@@ -12,30 +12,35 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, wl = sys.argv[1], sys.argv[2]
 envs = int(sys.argv[3])
 alg = int(sys.argv[4])
+tsteps = int(sys.argv[5]) if len(sys.argv) > 5 else 2000  # timed steps of the traced run
+psteps = int(sys.argv[6]) if len(sys.argv) > 6 else 100   # timed (= warm-up) steps of each PMC run
 src = os.path.join(ROOT, "gpurun_out", "prof_%s_%s" % (tag, wl))
-dst = os.path.join(ROOT, "profiles")
+dst = os.environ.get("PCT_PROFILE_DST") or os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
 KERNEL = "pct_continuous_kernel" if wl in ("c3", "c5", "c3s1") else "pct_discrete_kernel"
 
 out = {"tag": tag, "workload": wl, "envs_per_launch": envs,
-       "command": "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --workload %s --steps 2000 --warmup 200; "
-                  "--steps 100 --warmup 100 for each --pmc pass (scripts/profile_gpu.sh)" % wl}
+       "command": "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --workload %s --steps %d --warmup 200; "
+                  "--steps %d --warmup 100 for each --pmc pass (scripts/profile_gpu.sh)" % (wl, tsteps, psteps)}
 db = os.path.join(src, "trace", "trace_results.db")
 lines = []
 if os.path.exists(db):
     cur = sqlite3.connect(db).cursor()
-    rows = list(cur.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration), "
-                            "max(lds_size), max(scratch_size), max(vgpr_count), max(sgpr_count), max(grid_x), max(workgroup_x) "
-                            "from kernels group by name order by sum(duration) desc"))
+    # one row per (kernel, grid): the small-grid retry pass is the same kernel template as the normal pass
+    rows = list(cur.execute("select name || ' [grid ' || (grid_x / workgroup_x) || ']', count(*), sum(duration), avg(duration), "
+                            "min(duration), max(duration), max(lds_size), max(scratch_size), max(vgpr_count), max(sgpr_count), "
+                            "max(grid_x), max(workgroup_x) from kernels group by name, grid_x order by sum(duration) desc"))
     tot = sum(r[2] for r in rows)
     lines = ["# rocprofv3 --kernel-trace --stats summary (%s, workload %s): python bench.py --workload %s --steps 2000 --warmup 200" % (tag, wl, wl),
              "%-100s %8s %12s %10s %10s %10s %6s %7s %5s %5s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "pct", "lds_B", "vgpr", "sgpr")]
     for r in rows[:8]:
+        nm = r[0] if len(r[0]) <= 100 else r[0][:84] + ".." + r[0][-14:]
         lines.append("%-100s %8d %12.1f %10.2f %10.2f %10.2f %6.2f %7d %5d %5d" % (
-            r[0][:100], r[1], r[2] / 1e3, r[3] / 1e3, r[4] / 1e3, r[5] / 1e3, 100 * r[2] / tot, r[6], r[8], r[9]))
+            nm, r[1], r[2] / 1e3, r[3] / 1e3, r[4] / 1e3, r[5] / 1e3, 100 * r[2] / tot, r[6], r[8], r[9]))
     # steady-state average of the step kernel: the timed 2000 launches are the last 2000 of the main (non-retry) grid
     d = [x[0] for x in cur.execute("select duration from kernels where name like ? and grid_x >= ? order by start",
                                    ("%" + KERNEL + "%", envs * 64))]
-    steady = d[-2000:]
+    steady = d[-tsteps:]
     out["step_kernel_avg_us_timed_region"] = sum(steady) / max(len(steady), 1) / 1e3
     lines += ["", "step kernel (grid = %d envs), last %d launches (= bench timed region): avg %.2f us" % (
         envs, len(steady), out["step_kernel_avg_us_timed_region"])]
@@ -63,10 +68,11 @@ for sub in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
         by_d.setdefault(n, {})[did] = v
     for n, dv in by_d.items():
         ids = sorted(dv)
-        per_step = len(ids) / 200.0  # 100 warm-up + 100 timed steps (+ reset)
+        per_step = len(ids) / (2.0 * psteps)  # warm-up + timed steps (+ reset)
         k = max(1, int(round(per_step)))
-        last = ids[-50 * k:]
-        pmc[n] = sum(dv[i] for i in last) / 50.0
+        m = max(1, psteps // 2)
+        last = ids[-m * k:]
+        pmc[n] = sum(dv[i] for i in last) / float(m)
 out["pmc_per_launch"] = pmc
 if "SQ_INSTS_VALU" in pmc and "SQ_INSTS_SALU" in pmc:
     out["valu_salu_insts_per_launch"] = pmc["SQ_INSTS_VALU"] + pmc["SQ_INSTS_SALU"]

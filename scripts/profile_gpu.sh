@@ -5,6 +5,8 @@
 TAG=${1:-r02}
 WL=${2:-c2}
 TSTEPS=${3:-2000}
+PSTEPS=${4:-100}
+REPO=$PWD
 OUT=$PWD/gpurun_out/prof_${TAG}_${WL}
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -13,12 +15,16 @@ cd /tmp
 # 1. kernel trace + stats over the same command as the bench line
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH --steps $TSTEPS --warmup 200 > $OUT/trace_bench.json 2> $OUT/trace.err
 # 2. PMC passes (own runs, kernel-trace only)
-PSTEPS=100
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU -d $OUT/pmc_sq -o pmc -- $BENCH --steps $PSTEPS --warmup 100 > $OUT/pmc_sq.json 2> $OUT/pmc_sq.err
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_BRANCH SQ_THREAD_CYCLES_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR -d $OUT/pmc_sq2 -o pmc -- $BENCH --steps $PSTEPS --warmup 100 > $OUT/pmc_sq2.json 2> $OUT/pmc_sq2.err
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $BENCH --steps $PSTEPS --warmup 100 > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $BENCH --steps $PSTEPS --warmup 100 > $OUT/pmc_write.json 2> $OUT/pmc_write.err
+# summaries are made here, on the GPU box (the databases are too large to travel back whole)
+cd $REPO
+ENVS=$(python -c "import bench; print(bench.WORKLOADS['$WL']['envs'])")
+ALG=$(python -c "import bench; print(bench.alg_bytes(bench.WORKLOADS['$WL']))")
+PCT_PROFILE_DST=$REPO/gpurun_out/profiles_$TAG python scripts/collect_profiles.py $TAG $WL $ENVS $ALG $TSTEPS $PSTEPS > $OUT/collect.log 2>&1
 cd $OUT
 # keep the merge-back small: drop anything over 12 MB (the trace db of a 2000-step run is ~5 MB)
-find . -size +12M -delete
+find . -size +4M -delete
 du -sh .

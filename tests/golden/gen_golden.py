@@ -710,6 +710,79 @@ def heuristic_cases(want=lambda name: True):
         np.savez_compressed(os.path.join(HERE, cname + ".npz"), meta=np.array(repr(case)), stream=stream, **out)
 
 
+# Strict NumPy-stream mode: the reference run with the CLI's own defaults -- shuffle=True (tools.py:136), items from
+# RandomBoxCreator (np.random.randint), setting-3 densities from np.random.random -- and every env's process-global
+# RandomState seeded seed + rank as envs.py:49 / bin3D.py:47-54 do under ShmemVecEnv(fork).  Nothing is scripted.
+NUMPY_STREAM_CASES = {
+    "discrete_s2_numpy_stream": dict(setting=2, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, N=6, steps=250, seed=4, base=0),
+    "discrete_s1_numpy_stream": dict(setting=1, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, N=4, steps=200, seed=11, base=5),
+    "discrete_s3_numpy_stream": dict(setting=3, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, N=4, steps=200, seed=12, base=2),
+}
+
+
+def run_reference_numpy_stream(c):
+    PD, PC, _ = ref_shim.load_reference_envs()
+    items = item_set_range(c["lo"], c["hi"])
+    N, I, L, T = c["N"], c["I"], c["L"], c["steps"]
+    out = dict(obs=np.zeros((T + 1, N, (I + L + 1) * 9), np.float32), reward=np.zeros((T, N)), done=np.zeros((T, N), np.uint8),
+               counter=np.zeros((T, N), np.int32), ratio=np.zeros((T, N)))
+    for e in range(N):
+        np.random.seed(c["seed"] + c["base"] + e)  # env.seed(seed + rank): one process, one stream per env
+        env = PD(setting=c["setting"], container_size=list(c["container"]), item_set=items, internal_node_holder=I,
+                 leaf_node_holder=L, LNES="EMS", shuffle=True)
+        obs = env.reset()
+        g = c["base"] + e
+        for t in range(T):
+            out["obs"][t, e] = obs.astype(np.float32)
+            leaf = obs.reshape(-1, 9)[I:I + L]
+            k = int((leaf[:, 8] != 0).sum())
+            li = mix32(g, t) % k if k > 0 else 0
+            obs, r, d, info = env.step(out["obs"][t, e].reshape(-1, 9)[I + li].copy())
+            out["reward"][t, e], out["done"][t, e], out["counter"][t, e] = r, d, info["counter"]
+            out["ratio"][t, e] = info.get("ratio", 0.0)
+            if d:
+                obs = env.reset()
+        out["obs"][T, e] = obs.astype(np.float32)
+    return out
+
+
+def run_oracle_numpy_stream(c):
+    from oracle.oracle_lib import OracleVecEnv
+    N, I, L, T = c["N"], c["I"], c["L"], c["steps"]
+    env = OracleVecEnv(N, setting=c["setting"], container_size=c["container"], item_set=item_set_range(c["lo"], c["hi"]),
+                       internal_node_holder=I, leaf_node_holder=L, env_id_base=c["base"], shuffle=True)
+    env.set_numpy_rng(c["seed"])
+    out = dict(obs=np.zeros((T + 1, N, (I + L + 1) * 9), np.float32), reward=np.zeros((T, N)), done=np.zeros((T, N), np.uint8),
+               counter=np.zeros((T, N), np.int32), ratio=np.zeros((T, N)))
+    env.reset()
+    for t in range(T):
+        out["obs"][t] = env.obs.astype(np.float32)
+        env.step_hash_policy(1)
+        out["reward"][t], out["done"][t], out["counter"][t], out["ratio"][t] = env.reward, env.done, env.counter, env.ratio
+    out["obs"][T] = env.obs.astype(np.float32)
+    assert not env.flags.any()
+    env.close()
+    return out
+
+
+def numpy_stream_cases(want=lambda name: True):
+    for name, case in NUMPY_STREAM_CASES.items():
+        if not want(name):
+            continue
+        ref = run_reference_numpy_stream(case)
+        ora = run_oracle_numpy_stream(case)
+        for key in ("obs", "reward", "done", "counter", "ratio"):
+            a, b = ref[key], ora[key]
+            if key == "ratio":
+                a, b = a * (ref["done"] != 0), b * (ora["done"] != 0)
+            if not np.array_equal(a, b):
+                raise SystemExit("MISMATCH %s/%s first at %s" % (name, key, np.argwhere(a != b)[0]))
+        print("%-28s steps=%d envs=%d episodes=%d  oracle (NumPy-stream mode) == reference (shuffle=True, np.random.seed(seed + rank))" % (
+            name, case["steps"], case["N"], int(ref["done"].sum())))
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), meta=np.array(repr(case)), obs=ref["obs"], reward=ref["reward"],
+                            done=ref["done"], counter=ref["counter"], ratio=ref["ratio"] * (ref["done"] != 0))
+
+
 def main():
     only = sys.argv[1:]  # optional name filters: regenerate only the matching cases
 
@@ -718,6 +791,7 @@ def main():
 
     dataset_cases(want)
     heuristic_cases(want)
+    numpy_stream_cases(want)
     if not only:
         known_answer_discrete_s2()
         known_answer_discrete_s1()
