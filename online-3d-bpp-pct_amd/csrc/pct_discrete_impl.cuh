@@ -447,17 +447,15 @@ __device__ inline void set_insert(SetState<K>& st, const K (&key)[V], const bool
   uint32_t* const dd = st.dd;
   bool pending[V];
   uint64_t hash0 = 0;  // slice 0's hashes, for the fast start
+  uint64_t hash[V];    // (V > 1: recomputed per matching pass below rather than kept live across a table rebuild)
   {
-    uint64_t hash[V];
 #pragma unroll
     for (int v = 0; v < V; v++) hash[v] = tuplehash6<K, BITS>(key[v]);
     hash0 = hash[0];
-    bool found[V];
-    int cprobes = 0;
-    pyset_contains_v<V, K>(tabs + st.toff, st.size - 1, hash, key, valid, found, TM::on ? &cprobes : nullptr);
-    if (TM::on) { tm.add(ST_CONTAINS_CALLS, 1); tm.add(ST_CONTAINS_PROBES, (uint64_t)cprobes); }
+    // no separate membership pass: a key that is already in the table ends its matching walk at its own entry
+    // (pyset_match_v CHECK) -- one probe walk per key instead of two
 #pragma unroll
-    for (int v = 0; v < V; v++) pending[v] = valid[v] && !found[v];
+    for (int v = 0; v < V; v++) pending[v] = valid[v];
     tm.sub_tick(PH_SET_GEN);
     if (!__ballot(any_of<V>(pending))) return;
     tm.add(ST_FLUSHES, 1);
@@ -566,26 +564,29 @@ __device__ inline void set_insert(SetState<K>& st, const K (&key)[V], const bool
     const uint32_t thr = (mask * 3u + 4u) / 5u;
     if (st.fill < thr) {
       if (!total) break;
+      // the first thr - fill pending positions: even if every one of them is new the table does not outgrow its
+      // threshold inside this pass (those that turn out to be members already leave room for a further pass)
       const int budget = (int)(thr - st.fill);
-      bool part[V];
-      int before = 0, npart = 0;
+      bool part[V], placed[V];
+      int before = 0, nplaced = 0;
 #pragma unroll
       for (int v = 0; v < V; v++) {
         part[v] = pending[v] && before + rank_below(pm[v]) < budget;
         before += __popcll(pm[v]);
       }
-      npart = total < budget ? total : budget;
       uint32_t slot[V];
-      uint64_t hash[V];  // recomputed here rather than kept live across a table rebuild
+      if (V > 1) {
 #pragma unroll
-      for (int v = 0; v < V; v++) hash[v] = tuplehash6<K, BITS>(key[v]);
-      pyset_match_v<V, K>(tabs + st.toff, mask, part, hash, lane, slot, mst);
+        for (int v = 0; v < V; v++) hash[v] = tuplehash6<K, BITS>(key[v]);
+      }
+      pyset_match_v<V, K, true>(tabs + st.toff, mask, part, hash, lane, slot, mst, key, placed);
 #pragma unroll
       for (int v = 0; v < V; v++) {
-        if (part[v]) tabs[st.toff + slot[v]] = key[v];
+        if (placed[v]) tabs[st.toff + slot[v]] = key[v];
         pending[v] = pending[v] && !part[v];
+        nplaced += __popcll(__ballot(placed[v]));
       }
-      st.fill += (uint32_t)npart;
+      st.fill += (uint32_t)nplaced;
       __syncthreads();
       tm.sub_tick(PH_SET_MATCH);
     }

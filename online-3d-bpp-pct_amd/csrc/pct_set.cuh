@@ -435,9 +435,12 @@ __device__ inline void pyset_contains_v(const K* tab, uint32_t mask, const uint6
 // batch-position order, exactly as sequential set.add calls would place them.  On return every
 // participating (v, lane) holds TAG | (v*64 + lane) in tab[slot[v]]; the caller overwrites the tags
 // with the keys.  All 64 lanes must call.
-template <int V, typename K>
+// With `key` (CHECK): a participating key may already be a member of the table -- its walk then ends at its own
+// entry and it is not placed (set.add of a member is a no-op); placed[v] tells the two outcomes apart.
+template <int V, typename K, bool CHECK = false>
 __device__ inline void pyset_match_v(K* tab, uint32_t mask, const bool (&part)[V], const uint64_t (&hash)[V], int lane,
-                                     uint32_t (&slot)[V], int* stats = nullptr) {
+                                     uint32_t (&slot)[V], int* stats = nullptr, const K* key = nullptr,
+                                     bool* placed_out = nullptr) {
   const K TAG = SlotWord<K>::TAG;
   uint32_t i[V];
   int j[V];
@@ -469,10 +472,11 @@ __device__ inline void pyset_match_v(K* tab, uint32_t mask, const bool (&part)[V
 #pragma unroll
       for (int v = 0; v < V; v++) {
         const bool won = walking[v] && old[v] > PCT_MYTAG(v);  // was empty, or tentatively held by a later position
+        const bool member = CHECK && walking[v] && !(old[v] & TAG) && old[v] == key[v];
         slot[v] = won ? cur[v] : slot[v];
         placed[v] = placed[v] || won;
         if (walking[v]) walk_advance(i[v], j[v], perturb[v], mask);  // past the slot just tried: an evicted key resumes here
-        walking[v] = walking[v] && !won;
+        walking[v] = walking[v] && !won && !member;
       }
     }
     __syncthreads();
@@ -486,6 +490,10 @@ __device__ inline void pyset_match_v(K* tab, uint32_t mask, const bool (&part)[V
     if (!__ballot(any_of<V>(walking))) break;
   }
   if (stats) { stats[0]++; stats[2] += wave_max_i32(my_probes); }
+  if (CHECK) {
+#pragma unroll
+    for (int v = 0; v < V; v++) placed_out[v] = placed[v];
+  }
 #undef PCT_MYTAG
 }
 
