@@ -615,16 +615,9 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
       int tt = tb + lane;
       bool valid = tt < nt;
       uint32_t g = valid ? ((uint32_t)l.vp[tt >> 2] << 2 | (uint32_t)(tt & 3)) : 0u;
-      double t[6];
-      cand_tuple(p, l, r, orient, g, t);
-      uint64_t hash = tuplehash6d(t);
-      const uint32_t fp = cword(hash, 0) >> 16;
-      bool fresh = valid && !pyset_contains<uint32_t, GT>(tabs + toff, size - 1, hash, valid, [&](uint32_t w) -> bool {
-        if ((w >> 16) != fp) return false;
-        double o[6];
-        cand_tuple(p, l, r, orient, w & 0xFFFFu, o);
-        return tuple_eq(o, t);
-      });
+      // no separate membership pass: every generated tuple is queued, and one that is already in the set ends
+      // its matching walk at its own entry (check_found in the flush) -- one probe walk per tuple instead of two
+      bool fresh = valid;
       uint64_t nm = __ballot(fresh);
       if (fresh) l.pend[npend + rank_below(nm)] = (uint16_t)g;
       npend += __popcll(nm);

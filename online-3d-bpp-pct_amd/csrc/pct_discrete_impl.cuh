@@ -37,6 +37,9 @@
                          wave is bound by its instruction issue, not by dependence latency, so wider batches only add
                          predicated-off work; 2 and 4 are kept for experiments) */
 #endif
+#ifndef PCT_STAB_WAVES
+#define PCT_STAB_WAVES 1 /* waves per SIMD the stability-check kernels are compiled for */
+#endif
 #ifndef PCT_SET_RV
 #define PCT_SET_RV 1  /* old slots per lane and matching pass of a table rebuild (32-bit keys) */
 #endif
@@ -1944,7 +1947,7 @@ __device__ inline void discrete_env_steps(const DiscreteParams& p, const void* _
 template <typename K, int BITS, int ACT, bool TIMED, bool STAB, int SCHEME, int RNG>
 // the plain setting-2 kernels are held to 128 VGPRs (4 waves per SIMD = 16 resident envs per CU, the
 // occupancy the LDS layout is sized for); the float64 stability code and the timed build are not
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STAB ? 1 : 4)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STAB ? PCT_STAB_WAVES : 4)))
 pct_discrete_kernel(DiscreteParams p, const void* __restrict__ actions,
                                                           int row_len, int n_steps,
                                                           const int32_t* __restrict__ env_ids, int n_ids) {
