@@ -11,7 +11,10 @@
  *   givenData.py:4-14 item_size_set, binCreator.py:24-39             -> pct_set_item_set
  *   binCreator.py:41-72 LoadBoxCreator (scripted trajectories)       -> pct_set_item_stream
  *   binCreator.py:41-72 LoadBoxCreator on a dataset (README.md:75-77) -> pct_set_item_dataset
- *   binCreator.py:37-39 RandomBoxCreator (on-the-fly sampling)       -> pct_set_sampler
+ *   binCreator.py:37-39 RandomBoxCreator (on-the-fly sampling)       -> pct_set_sampler (counter-keyed draws)
+ *   envs.py:49 env.seed(seed + rank) -> bin3D.py:47-54 np.random.seed;
+ *   binCreator.py:38 randint, bin3D.py:82-84 random, :114-115 shuffle -> pct_set_numpy_rng (the env's own MT19937
+ *                                                                      stream, draw for draw)
  *   bin3D.py:75-84 next_den (setting 3)                              -> pct_set_density_stream /
  *                                                                      pct_set_dataset_density
  *   bin3D.py:114-115 np.random.shuffle(allPostion)                   -> pct_config.shuffle
@@ -25,6 +28,8 @@
  *   heuristic.py:11-569 (the seven baselines' placement rules)       -> pct_step_heuristic
  *   envs.py:178-182 VecPyTorch.step_wait outputs                     -> pct_bind_outputs /
  *                                                                      pct_obs, pct_reward, ...
+ *   storage.py:33-39 PCTRolloutStorage.insert, train_tools.py:70     -> pct_bind_rollout_slot (the transition kernel
+ *                                                                      writes obs[t+1], rewards[t], masks[t+1])
  *   bin3D.py:163-164,186-187 info dict                               -> pct_info_counter/ratio
  *   wrapper/vec_env.py:90-99 close                                   -> pct_destroy
  *
@@ -184,7 +189,8 @@ int pct_set_dataset_density(pct_env* env, const double* den);
  * item_set[pct_pick(seed, g, c, n)] (discrete) -- see pct_pick below. */
 int pct_set_sampler(pct_env* env, uint64_t seed);
 
-/* Strict NumPy-stream mode (discrete env, LNES = EMS, bins up to 31 per axis; before the first reset).  Env e then
+/* Strict NumPy-stream mode (discrete env with LNES = EMS and bins up to 31 per axis, or the continuous env -- see
+ * pct_set_numpy_item_count below; before the first reset).  Env e then
  * consumes the MT19937 stream that np.random.seed(seed + env_id_base + e) starts, exactly as the env's worker process
  * does under ShmemVecEnv(fork) (envs.py:49 env.seed(seed + rank); bin3D.py:47-54): the item is
  * item_set[np.random.randint(0, n)] (binCreator.py:37-39), the setting-3 density np.random.random() redrawn while 0
@@ -194,6 +200,14 @@ int pct_set_sampler(pct_env* env, uint64_t seed);
  * reproduces the reference's trajectory bit for bit with the CLI's defaults (tools.py:136 shuffle=True,
  * RandomBoxCreator).  The heuristic policies are not available in this mode. */
 int pct_set_numpy_rng(pct_env* env, uint32_t seed);
+
+/* The same for the continuous env in its sampling mode (pct_set_sample_bounds; C/bin3D.py:14-16
+ * sample_from_distribution=True, the CLI's --continuous default): every observation -- the discarded one of a failed
+ * step included -- draws its item as round(np.random.uniform(a, b), 3) per edge (C/bin3D.py:103-113; settings 1/3:
+ * two edges and np.random.choice of five heights), then the setting-3 density, then np.random.shuffle of the candidate
+ * positions; reset() and every successful step also spend the RandomBoxCreator's randint over the item set nobody
+ * reads (C/bin3D.py:73,202) -- `n` is that set's length (default 125 = len(givenData.item_size_set)). */
+int pct_set_numpy_item_count(pct_env* env, int32_t n);
 
 /* Seed of the shuffle permutation (default 0). */
 int pct_set_shuffle_seed(pct_env* env, uint64_t seed);

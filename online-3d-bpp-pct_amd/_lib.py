@@ -23,7 +23,7 @@ FLAG_STABILITY_OVERFLOW, FLAG_DATASET_EXHAUSTED = 16, 32
 # every symbol include/pct_env.h declares
 ABI_SYMBOLS = [
     "pct_abi_version", "pct_last_error", "pct_create", "pct_destroy", "pct_set_item_set",
-    "pct_set_sample_bounds", "pct_set_item_stream", "pct_set_item_dataset", "pct_set_sampler", "pct_set_numpy_rng",
+    "pct_set_sample_bounds", "pct_set_item_stream", "pct_set_item_dataset", "pct_set_sampler", "pct_set_numpy_rng", "pct_set_numpy_item_count",
     "pct_set_shuffle_seed",
     "pct_set_density_stream", "pct_set_dataset_density", "pct_bind_outputs", "pct_bind_rollout_slot", "pct_obs",
     "pct_reward", "pct_done", "pct_info_counter", "pct_info_ratio", "pct_error_flags", "pct_obs_row_len",
@@ -75,6 +75,7 @@ def load():
     L.pct_set_item_dataset.argtypes = [vp, vp, vp, i32, i32]
     L.pct_set_sampler.argtypes = [vp, u64]
     L.pct_set_numpy_rng.argtypes = [vp, ctypes.c_uint32]
+    L.pct_set_numpy_item_count.argtypes = [vp, ctypes.c_int32]
     L.pct_set_shuffle_seed.argtypes = [vp, u64]
     L.pct_step_heuristic.argtypes = [vp, i32, i32, vp]
     L.pct_set_density_stream.argtypes = [vp, vp, i64]

@@ -25,6 +25,7 @@
 #include "pct_device.h"
 #include "pct_set.cuh"
 #include "pct_stab.cuh"
+#include "pct_mt.cuh"
 
 namespace pct {
 
@@ -80,6 +81,9 @@ struct CRegs {  // wave-uniform per-env scalars
   uint32_t flags;
   int traj;
   uint32_t oc;  // observations produced so far (shuffle key)
+  int mt_pos;      // strict NumPy-stream mode: position in this env's MT19937 block (LDS)
+  bool mt_dirty;   // the block was regenerated in this launch
+  double den_cur;  // density drawn for the current observation (setting 3, NumPy-stream mode)
 };
 
 struct CLds {
@@ -95,6 +99,7 @@ struct CLds {
   uint16_t* vp;     // [64]
   uint32_t* fpri;   // [order_cap] shuffle priorities of the feasible candidates (shuffle only)
   uint32_t* dd;     // [128] bucket words of the batch de-duplication
+  uint32_t* mt;     // [624] MT19937 state of this env (strict NumPy-stream mode only)
 };
 
 // words of the region shared by the hash table and the GENEMS children scratch
@@ -114,6 +119,7 @@ __device__ inline CLds carve(const ContinuousParams& p, unsigned char* base) {
   q += p.union_words;
   l.bk = q; q += 4 * p.I;
   l.dd = reinterpret_cast<uint32_t*>(q); q += 128;
+  l.mt = reinterpret_cast<uint32_t*>(q); q += p.rng_numpy ? 624 : 0;
   uint16_t* h = reinterpret_cast<uint16_t*>(q);
   l.pend = h; h += 128;
   l.vp = h; h += 64;
@@ -122,14 +128,16 @@ __device__ inline CLds carve(const ContinuousParams& p, unsigned char* base) {
   return l;
 }
 
+#ifndef PCT_CONT_MT
 size_t continuous_lds_bytes(const ContinuousParams& p) {
   const bool stab = p.setting != 2;
   size_t dbl = stab ? 9 * (size_t)p.I : (size_t)p.I;
-  size_t i32 = 6 * (size_t)p.ems_cap + (size_t)p.union_words + 4 * (size_t)p.I + 128;
+  size_t i32 = 6 * (size_t)p.ems_cap + (size_t)p.union_words + 4 * (size_t)p.I + 128 + (p.rng_numpy ? 624 : 0);
   size_t u16 = 128 + 64 + (((size_t)p.L + 1) & ~(size_t)1);
   if (p.shuffle && !p.table_global) u16 += 2 * (size_t)p.order_cap;
   return dbl * 8 + i32 * 4 + u16 * 2 + 16;
 }
+#endif
 
 __device__ inline void cdraw_item(const ContinuousParams& p, int e, CRegs& r) {
   uint64_t c = r.cursor++;
@@ -163,6 +171,53 @@ __device__ inline void cdraw_item(const ContinuousParams& p, int e, CRegs& r) {
   }
   // round(U(a,b), 3) (C/bin3D.py:106-108): the double nearest to k/1000
   r.b0 = (double)r.ik0 / 1000.0; r.b1 = (double)r.ik1 / 1000.0; r.b2 = (double)r.ik2 / 1000.0;
+}
+
+// ---- strict NumPy-stream mode (include/pct_env.h pct_set_numpy_rng) --------------------------------------------
+// Python's round(x, 3) of a positive double as the lattice index k (the result is the double nearest k/1000):
+// correctly rounded on the exact binary value of x, ties to even.  x = m 2^e2 is compared with the midpoints
+// (2k +- 1)/2000 in integers: m 2000 < 2^64.
+__device__ inline int cmp_x_mid(double x, long long twok1) {  // sign of x * 2000 - twok1
+  if (twok1 <= 0) return 1;
+  const uint64_t bits = (uint64_t)__double_as_longlong(x);
+  const int e2 = (int)((bits >> 52) & 0x7FFu) - 1075;
+  const uint64_t A = ((bits & 0xFFFFFFFFFFFFFull) | (1ull << 52)) * 2000ull, B = (uint64_t)twok1;
+  if (e2 >= 0) return 1;
+  const int sft = -e2;
+  if (sft >= 64) return -1;
+  const uint64_t hi = A >> sft;
+  if (hi != B) return hi > B ? 1 : -1;
+  return (A & ((1ull << sft) - 1ull)) ? 1 : 0;
+}
+__device__ inline int round3_lattice(double x) {
+  long long k = (long long)(x * 1000.0 + 0.5);
+  for (int it = 0; it < 3; it++) {
+    const int up = cmp_x_mid(x, 2 * k + 1), dn = cmp_x_mid(x, 2 * k - 1);
+    if (up > 0 || (up == 0 && (k & 1))) { k++; continue; }
+    if (dn < 0 || (dn == 0 && (k & 1))) { k--; continue; }
+    break;
+  }
+  return (int)k;
+}
+// C/bin3D.py:103-113 gen_next_box, sampling mode: round(np.random.uniform(a, b), 3) (legacy uniform: a + (b - a) *
+// random_sample(), no contraction), and np.random.choice of five heights (-> randint(0, 5)) under settings 1 / 3;
+// then cur_observation's density draw (:88-90)
+__device__ inline void cdraw_item_mt(const ContinuousParams& p, CLds& l, CRegs& r, int lane) {
+  r.cursor++;
+  const double a = (double)p.sample_left / 1000.0, b = (double)p.sample_right / 1000.0;
+  const double span = __dsub_rn(b, a);
+  int k[3];
+  const int nu = p.setting == 2 ? 3 : 2;
+  for (int d = 0; d < nu; d++) k[d] = round3_lattice(__dadd_rn(a, __dmul_rn(span, mt_double(l, r, lane))));
+  if (nu == 2) k[2] = 100 * (1 + (int)mt_interval(l, r, lane, 4u));
+  r.ik0 = k[0]; r.ik1 = k[1]; r.ik2 = k[2];
+  r.b0 = (double)r.ik0 / 1000.0; r.b1 = (double)r.ik1 / 1000.0; r.b2 = (double)r.ik2 / 1000.0;
+  if (p.setting == 3) r.den_cur = mt_density(l, r, lane);
+}
+// box_creator.generate_box_size() (C/bin3D.py:73,202; binCreator.py:37-39): a randint over the item set that the
+// sampling mode never reads
+__device__ inline void cskip_creator_mt(const ContinuousParams& p, CLds& l, CRegs& r, int lane) {
+  (void)mt_interval(l, r, lane, (uint32_t)p.np_items - 1u);
 }
 
 // C/space.py:281-303 reset
@@ -373,7 +428,10 @@ __device__ inline void cgenems(const ContinuousParams& p, CLds& l, CRegs& r, int
 }
 
 // C/space.py:531-568 EMSPoint (CPython set order over float tuples) + C/bin3D.py:118-148
-template <bool GT, bool STAB, typename TM>
+// MT: strict NumPy-stream mode (np.random.shuffle drawn from the env's MT19937).  COUNT_ONLY (MT): the observation
+// a failed step builds and discards (C/bin3D.py:183) -- only its draws matter: the set is built for its size, the
+// shuffle's draws are consumed, nothing is written.
+template <bool GT, bool STAB, bool MT, bool COUNT_ONLY, typename TM>
 __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CRegs& r, int lane, TM& tm) {
   const int E = r.n_ems, cap = p.ems_cap;
   const int orient = (p.setting == 2) ? 6 : 2;
@@ -634,6 +692,11 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
     r.flags |= PCT_FLAG_CANDIDATE_OVERFLOW;
   }
   __syncthreads();
+  if (MT && COUNT_ONLY) {
+    if (p.shuffle)
+      for (int i = (int)fill - 1; i >= 1; i--) (void)mt_interval(l, r, lane, (uint32_t)i);
+    return false;
+  }
 
   // list(set): generator ids in slot order
   int norder = 0;
@@ -652,7 +715,7 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
   int nleaf = 0;
   bool stab_err = false;
   const int nb = r.n_boxes;
-  const double next_den = STAB ? next_density(p, e, r.oc, r.traj, r.cursor - 1) : 1.0;  // C/bin3D.py:81-90
+  const double next_den = !STAB ? 1.0 : (MT ? (p.setting == 3 ? r.den_cur : 1.0) : next_density(p, e, r.oc, r.traj, r.cursor - 1));  // C/bin3D.py:81-90
   auto feasible = [&](const double t[6]) -> bool {
     double lx = t[0], ly = t[1];
     double x = t[3] - t[0], y = t[4] - t[1], z = t[5] - t[2];
@@ -678,7 +741,20 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
     }
     return ok;
   };
-  if (p.shuffle) {
+  if (MT && p.shuffle) {
+    // C/bin3D.py:126-127 np.random.shuffle(allPostion), draw for draw: Fisher-Yates from the back with
+    // j = random_interval(i) (legacy RandomState.shuffle) on the list(set) order; the plain sweep below follows
+    for (int i = norder - 1; i >= 1; i--) {
+      const int j = (int)mt_interval(l, r, lane, (uint32_t)i);
+      if (j != i && lane == 0) {
+        const uint16_t a = tab_ld<GT, uint16_t>(&order[i]), b = tab_ld<GT, uint16_t>(&order[j]);
+        tab_st<GT, uint16_t>(&order[i], b);
+        tab_st<GT, uint16_t>(&order[j], a);
+      }
+    }
+    __syncthreads();
+  }
+  if (!MT && p.shuffle) {
     // C/bin3D.py:126-127 np.random.shuffle -> pct_shuffle_priority: every candidate is tested,
     // the feasible ones are ranked by (priority, list index), the first L ranks are kept
     uint32_t* const fpri = GT ? p.gfpri + gslot * (size_t)p.order_cap : l.fpri;
@@ -739,7 +815,8 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
 // the row of the box just placed (`new_row`, or -1), the leaf rows and the next-item row
 __device__ inline void cwrite_obs(const ContinuousParams& p, int e, const CLds& l, const CRegs& r, int lane,
                                   float* __restrict__ obs, bool full, int new_row, const double newbox[6]) {
-  const float nden = (float)next_density(p, e, r.oc - 1, r.traj, r.cursor - 1);  // C/bin3D.py:81-90,98
+  const float nden = p.rng_numpy ? (float)(p.setting == 3 ? r.den_cur : 1.0)
+                                 : (float)next_density(p, e, r.oc - 1, r.traj, r.cursor - 1);  // C/bin3D.py:81-90,98
   const int orient = (p.setting == 2) ? 6 : 2;
   double a = r.b0, b = r.b1, c = r.b2, tmp;
   if (a > b) { tmp = a; a = b; b = tmp; }
@@ -824,6 +901,14 @@ __device__ inline void cload(const ContinuousParams& p, int e, CLds& l, CRegs& r
   r.volsum = p.volsum[e];
   r.traj = sc[12];
   r.oc = (uint32_t)sc[13];
+  r.mt_pos = sc[7];
+  r.mt_dirty = false;
+  r.den_cur = 1.0;
+  if (p.rng_numpy) {
+    const uint32_t* gm = p.mt + (size_t)e * 624;
+    for (int i = lane; i < 624; i += 64) l.mt[i] = gm[i];
+    if (p.setting == 3) r.den_cur = p.mt_den[e];
+  }
   const int32_t* ge = p.ems + (size_t)e * 6 * p.ems_stride;
   const double* gb = p.boxes + (size_t)e * 6 * p.I;
   const uint16_t* gl = p.leafg + (size_t)e * p.L;
@@ -872,7 +957,15 @@ __device__ inline void cstore(const ContinuousParams& p, int e, const CLds& l, c
   for (int c = 0; c < 6; c++)
     for (int i = lane; i < r.n_ems; i += 64) ge[c * p.ems_stride + i] = l.emsk[c * p.ems_cap + i];
   for (int i = lane; i < r.n_leaf; i += 64) gl[i] = l.leafg[i];
+  if (p.rng_numpy && r.mt_dirty) {
+    uint32_t* gm = p.mt + (size_t)e * 624;
+    for (int i = lane; i < 624; i += 64) gm[i] = l.mt[i];
+  }
   if (lane == 0) {
+    if (p.rng_numpy) {
+      sc[7] = r.mt_pos;
+      if (p.setting == 3) p.mt_den[e] = r.den_cur;
+    }
     sc[0] = r.n_ems; sc[1] = r.n_boxes; sc[2] = r.n_leaf;
     sc[3] = r.ik0; sc[4] = r.ik1; sc[5] = r.ik2;
     sc[6] = (int32_t)r.t;
@@ -886,8 +979,10 @@ __device__ inline void cstore(const ContinuousParams& p, int e, const CLds& l, c
 
 // C/bin3D.py:169-207 step (+ the VecEnv worker's auto-reset).  a1/a2: raw position entries of
 // the action, (bx,by,bz): the item as LeafNode2Action returns it.
-template <bool STAB, typename TM>
-__device__ inline bool ctransition(const ContinuousParams& p, int e, CLds& l, CRegs& r, int lane, int flag, double a1,
+// returns 0: the episode goes on, 1: it ended and the env was reset, 2 (NumPy-stream mode): the discarded
+// observation's candidate set outgrew this launch's table -- requeue
+template <bool GT, bool STAB, bool MT, typename TM>
+__device__ inline int ctransition(const ContinuousParams& p, int e, CLds& l, CRegs& r, int lane, int flag, double a1,
                                    double a2, double bx, double by, double bz, TM& tm, double newbox[6]) {
   r.t++;
   const double lx = around6(a1), ly = around6(a2);  // idx = [round(action[1], 6), round(action[2], 6)]
@@ -923,7 +1018,8 @@ __device__ inline bool ctransition(const ContinuousParams& p, int e, CLds& l, CR
       CGeo geo{l.box, l.bsz, p.I};
       StabState st = cstab_view(p, e);
       bool err;
-      verdict = stab_commit<true>(geo, st, bi, next_density(p, e, r.oc - 1, r.traj, r.cursor - 1), err) ? 1 : 0;
+      const double den = MT ? (p.setting == 3 ? r.den_cur : 1.0) : next_density(p, e, r.oc - 1, r.traj, r.cursor - 1);
+      verdict = stab_commit<true>(geo, st, bi, den, err) ? 1 : 0;
       serr = err ? 1 : 0;
     }
     verdict = __shfl(verdict, 0, 64);
@@ -975,11 +1071,22 @@ __device__ inline bool ctransition(const ContinuousParams& p, int e, CLds& l, CR
     ratio = r.volsum / mx;
     r.oc++;  // the terminal step's own (discarded) observation (C/bin3D.py:183)
     __syncthreads();
+    if (MT) {
+      // that observation draws a NEW item, a density, and shuffles the new item's candidates on the final packing
+      cdraw_item_mt(p, l, r, lane);
+      if (cleaf_nodes<GT, STAB, true, true>(p, e, l, r, lane, tm)) return 2;
+      __syncthreads();
+    }
     cspace_reset(p, l, r, lane);
     __syncthreads();
     tm.tick(PH_DROP);
   }
-  cdraw_item(p, e, r);
+  if (MT) {
+    cskip_creator_mt(p, l, r, lane);  // generate_box_size() after a success (:202) / in reset() (:73)
+    cdraw_item_mt(p, l, r, lane);
+  } else {
+    cdraw_item(p, e, r);
+  }
   if (lane == 0) {
     p.reward[e] = reward;
     p.done[e] = done;
@@ -987,7 +1094,7 @@ __device__ inline bool ctransition(const ContinuousParams& p, int e, CLds& l, CR
     p.ratio[e] = ratio;
     if (p.mask) p.mask[e] = done ? 0.f : 1.f;  // train_tools.py:70 masks = 1 - done
   }
-  return done != 0;  // true: the episode ended and the env was reset
+  return done != 0 ? 1 : 0;
 }
 
 // C/bin3D.py:151-167 LeafNode2Action on a float64 row (a0,a1,_,a3,a4,_)
@@ -1017,7 +1124,7 @@ __device__ inline void cdecode_leaf(const CRegs& r, bool zero_row, double a0, do
 
 enum { CACT_ROWS = 0, CACT_INDEX = 1, CACT_HASH = 2, CACT_RESET = 3 };
 
-template <int ACT, bool TIMED, bool GT, bool STAB>
+template <int ACT, bool TIMED, bool GT, bool STAB, bool MT>
 #ifndef PCT_CONT_WAVES
 #define PCT_CONT_WAVES 3 /* waves per SIMD the plain kernel is compiled for: 168 VGPRs with 68 spilled to scratch measures slightly faster (C3 250 vs 254 us at 4096 envs, 356 vs 379 us at 8192) than 256 VGPRs at 2 waves */
 #endif
@@ -1058,8 +1165,13 @@ pct_continuous_kernel(ContinuousParams p, const void* __restrict__ actions,
   if (ACT == CACT_RESET) {
     cspace_reset(p, l, r, lane);
     __syncthreads();
-    cdraw_item(p, e, r);
-    requeue = cleaf_nodes<GT, STAB>(p, e, l, r, lane, tm);
+    if (MT) {
+      cskip_creator_mt(p, l, r, lane);
+      cdraw_item_mt(p, l, r, lane);
+    } else {
+      cdraw_item(p, e, r);
+    }
+    requeue = cleaf_nodes<GT, STAB, MT, false>(p, e, l, r, lane, tm);
     if (!requeue) {
       const double nobox[6] = {0, 0, 0, 0, 0, 0};
       cwrite_obs(p, e, l, r, lane, obs, true, -1, nobox);
@@ -1117,9 +1229,11 @@ pct_continuous_kernel(ContinuousParams p, const void* __restrict__ actions,
       cdecode_leaf(r, zero_row, a0, a1, a3, a4, p1, p2, bx, by, bz);
     }
     double newbox[6] = {0, 0, 0, 0, 0, 0};
-    const bool ended = ctransition<STAB>(p, e, l, r, lane, flag, p1, p2, bx, by, bz, tm, newbox);
+    const int tr = ctransition<GT, STAB, MT>(p, e, l, r, lane, flag, p1, p2, bx, by, bz, tm, newbox);
+    if (tr == 2) { requeue = true; break; }
+    const bool ended = tr != 0;
     if (can_retry && ((r.flags & ~flags_in) & PCT_FLAG_EMS_OVERFLOW)) { requeue = true; break; }
-    requeue = cleaf_nodes<GT, STAB>(p, e, l, r, lane, tm);
+    requeue = cleaf_nodes<GT, STAB, MT, false>(p, e, l, r, lane, tm);
     if (requeue) break;
     cwrite_obs(p, e, l, r, lane, obs, ended || (p.full_obs != 0 && it == 0), ended ? -1 : r.n_boxes - 1, newbox);
     __syncthreads();
@@ -1136,6 +1250,7 @@ pct_continuous_kernel(ContinuousParams p, const void* __restrict__ actions,
   }  // work items
 }
 
+#ifndef PCT_CONT_MT
 // stand-in policy kernel on the float32 observation (same as the discrete one)
 __global__ void __launch_bounds__(64) pct_cpolicy_hash_rows_kernel(ContinuousParams p, float* __restrict__ rows_out) {
   const int lane = threadIdx.x;
@@ -1157,20 +1272,35 @@ hipError_t launch_cpolicy_hash_rows(const ContinuousParams& p, float* rows_out, 
   return hipGetLastError();
 }
 
-hipError_t launch_continuous(const ContinuousParams& p, int act, const void* actions, int row_len, int n_steps,
-                             const int32_t* env_ids, int n_ids, hipStream_t stream) {
+#endif  // !PCT_CONT_MT
+
+// This file is compiled twice: as is (counter-based streams), and through pct_continuous_mt.hip with PCT_CONT_MT
+// defined (strict NumPy-stream mode: the MT19937 variants of the same kernels, launch_continuous_mt).
+#ifdef PCT_CONT_MT
+#define PCT_CONT_LAUNCH launch_continuous_mt
+#define PCT_CONT_MTV true
+#else
+#define PCT_CONT_LAUNCH launch_continuous
+#define PCT_CONT_MTV false
+#endif
+hipError_t PCT_CONT_LAUNCH(const ContinuousParams& p, int act, const void* actions, int row_len, int n_steps,
+                           const int32_t* env_ids, int n_ids, hipStream_t stream) {
+#ifndef PCT_CONT_MT
+  if (p.rng_numpy) return launch_continuous_mt(p, act, actions, row_len, n_steps, env_ids, n_ids, stream);
+#endif
   size_t lds = continuous_lds_bytes(p);
-  const bool timed = p.timing != nullptr && act != CACT_RESET;
+  const bool timed = !PCT_CONT_MTV && p.timing != nullptr && act != CACT_RESET;
   const bool stab = p.setting != 2;
   int grid = p.retry_mode ? n_ids : ((act == CACT_RESET && env_ids) ? n_ids : p.N);
   if (grid <= 0) return hipSuccess;
 #define PCT_CLAUNCH(A)                                                                                         \
   do {                                                                                                         \
     void (*kern)(ContinuousParams, const void*, int, int, const int32_t*, int);                                \
-    if (stab) kern = p.table_global ? pct_continuous_kernel<A, false, true, true>                              \
-                                    : pct_continuous_kernel<A, false, false, true>;                            \
-    else if (p.table_global) kern = pct_continuous_kernel<A, false, true, false>;                              \
-    else kern = timed ? pct_continuous_kernel<A, true, false, false> : pct_continuous_kernel<A, false, false, false>; \
+    if (stab) kern = p.table_global ? pct_continuous_kernel<A, false, true, true, PCT_CONT_MTV>                \
+                                    : pct_continuous_kernel<A, false, false, true, PCT_CONT_MTV>;              \
+    else if (p.table_global) kern = pct_continuous_kernel<A, false, true, false, PCT_CONT_MTV>;                \
+    else kern = timed ? pct_continuous_kernel<A, !PCT_CONT_MTV, false, false, PCT_CONT_MTV>                    \
+                      : pct_continuous_kernel<A, false, false, false, PCT_CONT_MTV>;                           \
     if (lds > 48 * 1024) {                                                                                     \
       hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                 \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \

@@ -112,6 +112,10 @@ struct ContinuousParams {
   uint16_t* gorder; /* [N, order_cap] */
   uint32_t* gfpri;  /* [N, order_cap] shuffle priorities (HBM-table variant + shuffle) */
   int gt_by_block;  /* HBM table slices indexed by blockIdx (retry pass) instead of env */
+  int rng_numpy;    /* 1: strict NumPy-stream mode (pct_set_numpy_rng), as in DiscreteParams */
+  int np_items;     /* len(item_set) behind RandomBoxCreator's unread randint draws (sampling mode) */
+  uint32_t* mt;     /* [N,624] MT19937 state words (position: scalars[7]) */
+  double* mt_den;   /* [N] density drawn for the current observation (setting 3) */
   int retry_mode;   /* this launch is the large-capacity retry pass */
   int* retry_count; /* [1] envs queued by the normal pass (zeroed before it) */
   int* retry_ids;   /* [N] */
@@ -142,6 +146,8 @@ __device__ inline double next_density(const Params& p, int e, uint32_t oc, int t
 
 size_t continuous_lds_bytes(const ContinuousParams& p);
 hipError_t launch_cpolicy_hash_rows(const ContinuousParams& p, float* rows_out, hipStream_t stream);
+hipError_t launch_continuous_mt(const ContinuousParams& p, int act, const void* actions, int row_len, int n_steps,
+                                const int32_t* env_ids, int n_ids, hipStream_t stream);
 hipError_t launch_continuous(const ContinuousParams& p, int act, const void* actions, int row_len, int n_steps,
                              const int32_t* env_ids, int n_ids, hipStream_t stream);
 

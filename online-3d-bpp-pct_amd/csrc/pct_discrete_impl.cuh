@@ -31,6 +31,7 @@
 
 #include "pct_set.cuh"
 #include "pct_stab.cuh"
+#include "pct_mt.cuh"
 
 #ifndef PCT_SET_V
 #define PCT_SET_V 1   /* tuples per lane and insertion batch of the EMS expansion (measured on MI355X: 1 is fastest -- a lone
@@ -161,59 +162,6 @@ __device__ inline StabState stab_view(const DiscreteParams& p, int e) {
   st.alias = p.st_alias + (size_t)e * p.I;
   return st;
 }
-
-// ---- NumPy's legacy RandomState on MT19937, one stream per env, state in LDS (strict NumPy-stream mode) ----------
-// All 64 lanes call these with wave-uniform arguments and get wave-uniform results; the 624-word block is
-// regenerated by the whole wave (numpy/random/src/mt19937/mt19937.c mt19937_gen: word kk needs the OLD kk, kk+1
-// and -- below 227 -- the old kk+397, from 227 on the NEW kk-227: chunks of 64 in ascending order keep that).
-template <typename L>
-__device__ inline uint32_t mt_next(L& l, EnvRegs& r, int lane) {
-  if (r.mt_pos >= 624) {
-    for (int base = 0; base < 624; base += 64) {
-      const int kk = base + lane;
-      uint32_t v = 0;
-      if (kk < 624) {
-        const uint32_t u0 = l.mt[kk], u1 = l.mt[kk == 623 ? 0 : kk + 1];
-        const uint32_t m = l.mt[kk < 227 ? kk + 397 : kk - 227];
-        const uint32_t y = (u0 & 0x80000000u) | (u1 & 0x7fffffffu);
-        v = m ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-      }
-      __syncthreads();
-      if (kk < 624) l.mt[kk] = v;
-      __syncthreads();
-    }
-    r.mt_pos = 0;
-  }
-  uint32_t y = __builtin_amdgcn_readfirstlane(l.mt[r.mt_pos]);
-  r.mt_pos++;
-  y ^= y >> 11;
-  y ^= (y << 7) & 0x9d2c5680u;
-  y ^= (y << 15) & 0xefc60000u;
-  y ^= y >> 18;
-  return y;
-}
-// random_interval(max) / the masked rejection of the legacy randint(0, max + 1)
-template <typename L>
-__device__ inline uint32_t mt_interval(L& l, EnvRegs& r, int lane, uint32_t max) {
-  if (max == 0) return 0;
-  uint32_t mask = max;
-  mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-  uint32_t v;
-  while ((v = (mt_next(l, r, lane) & mask)) > max) {}
-  return v;
-}
-// np.random.random(): 53 bits from two words; D/bin3D.py:82-84 redraws while it is 0
-template <typename L>
-__device__ inline double mt_density(L& l, EnvRegs& r, int lane) {
-  double d;
-  do {
-    const uint32_t a = mt_next(l, r, lane) >> 5, b = mt_next(l, r, lane) >> 6;
-    d = ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
-  } while (d == 0);
-  return d;
-}
-// Word kk == 623 of a regenerated block needs the NEW word 0: the chunk loop above reads l.mt[0] for it after the
-// first chunk has been written, which is exactly that.
 
 __device__ inline void draw_item(const DiscreteParams& p, int e, EnvRegs& r) {
   // binCreator.py:37-39 generate_box_size, through the scripted / counter-based sources

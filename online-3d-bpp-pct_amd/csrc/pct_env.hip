@@ -140,6 +140,7 @@ int launch(pct_env* h, int act, const void* actions, int row_len, int n_steps, c
       q.den_stream = c.den_stream; q.den_T = c.den_T; q.ds_den = c.ds_den;
       q.ds_ntraj = c.ds_ntraj; q.ds_maxlen = c.ds_maxlen; q.sample_left = c.sample_left; q.sample_right = c.sample_right;
       q.item_set = c.item_set; q.n_items = c.n_items;
+      q.rng_numpy = c.rng_numpy; q.np_items = c.np_items; q.mt = c.mt; q.mt_den = c.mt_den;
       q.low_bound = c.low_bound; q.obs = c.obs; q.reward = c.reward; q.done = c.done; q.counter = c.counter;
       q.ratio = c.ratio; q.flags = c.flags; q.timing = nullptr; q.full_obs = c.full_obs; q.mask = c.mask;
       q.retry_count = c.retry_count;
@@ -580,9 +581,11 @@ int pct_set_shuffle_seed(pct_env* h, uint64_t seed) {
 
 int pct_set_numpy_rng(pct_env* h, uint32_t seed) {
   if (!h) return fail(PCT_ERR_INVALID_ARG, "null handle");
-  if (h->continuous || h->dp.key_bytes != 4 || h->cfg.lnes != PCT_LNES_EMS)
-    return fail(PCT_ERR_UNSUPPORTED, "NumPy-stream mode: discrete env, bins up to 31 per axis, LNES = EMS");
-  if (!h->have_items) return fail(PCT_ERR_STATE, "pct_set_item_set must come first");
+  if (!h->continuous && (h->dp.key_bytes != 4 || h->cfg.lnes != PCT_LNES_EMS))
+    return fail(PCT_ERR_UNSUPPORTED, "NumPy-stream mode: discrete env with bins up to 31 per axis and LNES = EMS, or the continuous env");
+  if (h->continuous && h->cp.sample_right <= 0)
+    return fail(PCT_ERR_UNSUPPORTED, "NumPy-stream mode, continuous env: items sampled from U(a, b) (pct_set_sample_bounds)");
+  if (!h->have_items) return fail(PCT_ERR_STATE, "pct_set_item_set / pct_set_sample_bounds must come first");
   if (h->was_reset) return fail(PCT_ERR_STATE, "pct_set_numpy_rng must precede the first reset");
   int rc = use_device(h);
   if (rc) return rc;
@@ -593,6 +596,8 @@ int pct_set_numpy_rng(pct_env* h, uint32_t seed) {
     rc = dev_alloc(h, (void**)&h->dp.mt_den, N * sizeof(double), true);
     if (rc) return rc;
   }
+  h->cp.mt = h->dp.mt;
+  h->cp.mt_den = h->dp.mt_den;
   /* np.random.seed(seed + rank) in every worker (envs.py:49, bin3D.py:47-54): mt19937_seed == init_genrand */
   std::vector<uint32_t> st(N * 624);
   for (size_t e = 0; e < N; e++) {
@@ -605,11 +610,29 @@ int pct_set_numpy_rng(pct_env* h, uint32_t seed) {
   HIP_TRY(hipMemcpy(h->dp.mt, st.data(), st.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   /* position 624: the first draw regenerates the block (scalars[7] of every env) */
   std::vector<int32_t> pos(N, 624);
-  HIP_TRY(hipMemcpy2D(h->dp.scalars + 7, PCT_SCALARS * sizeof(int32_t), pos.data(), sizeof(int32_t), sizeof(int32_t), N,
+  int32_t* scalars = h->continuous ? h->cp.scalars : h->dp.scalars;
+  HIP_TRY(hipMemcpy2D(scalars + 7, PCT_SCALARS * sizeof(int32_t), pos.data(), sizeof(int32_t), sizeof(int32_t), N,
                       hipMemcpyHostToDevice));
+  if (h->continuous) {
+    h->cp.rng_numpy = 1;
+    h->cp.source = PCT_ITEMS_SAMPLER;
+    if (h->cp.np_items < 1) h->cp.np_items = 125; /* givenData.py:13-18 item_size_set, what main.py hands the env */
+    pct::ContinuousParams q = h->cp_retry;
+    q.rng_numpy = 1;
+    if (pct::continuous_lds_bytes(h->cp) > 160 * 1024 || (h->has_retry && pct::continuous_lds_bytes(q) > 160 * 1024))
+      return fail(PCT_ERR_INVALID_ARG, "capacities + MT19937 state exceed the LDS");
+    return PCT_OK;
+  }
   h->dp.rng_numpy = 1;
   h->dp.source = PCT_ITEMS_SAMPLER;
   if (pct::discrete_lds_bytes(h->dp) > 160 * 1024) return fail(PCT_ERR_INVALID_ARG, "capacities + MT19937 state exceed the LDS");
+  return PCT_OK;
+}
+
+int pct_set_numpy_item_count(pct_env* h, int32_t n) {
+  if (!h || n < 1) return fail(PCT_ERR_INVALID_ARG, "bad count");
+  if (!h->continuous) return fail(PCT_ERR_UNSUPPORTED, "continuous env only (the discrete env draws from its item set)");
+  h->cp.np_items = n;
   return PCT_OK;
 }
 

@@ -211,6 +211,11 @@ class PctVecEnv(VecEnv):
         elif item_stream is not None:
             self.set_item_stream(item_stream)
         elif rng == "numpy":
+            if self.continuous:
+                # the RandomBoxCreator behind the sampling mode still draws (and ignores) an index into the item_set
+                # the env was handed (C/bin3D.py:36-39,73,202): only its length matters
+                n_set = len(np.asarray(item_set).reshape(-1, 3)) if item_set is not None else 125
+                _lib.check(self._L.pct_set_numpy_item_count(self._h, int(n_set)))
             _lib.check(self._L.pct_set_numpy_rng(self._h, int(seed) & 0xFFFFFFFF))
         else:
             _lib.check(self._L.pct_set_sampler(self._h, int(seed)))
@@ -507,6 +512,7 @@ def make_vec_envs(args, log_dir=None, allow_early_resets=True):
         seed=getattr(args, "seed", 0),
         continuous=kind.startswith("PctContinuous"),
         item_stream=getattr(args, "item_stream", None),
+        rng=getattr(args, "rng", "counter"),  # "numpy": the reference's own per-env MT19937 stream (discrete env)
     )
 
 

@@ -55,6 +55,7 @@ def lib():
         L.pcto_set_item_dataset.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int32]
         L.pcto_set_sampler.argtypes = [vp, ctypes.c_uint64]
         L.pcto_set_numpy_rng.argtypes = [vp, ctypes.c_uint32]
+        L.pcto_set_numpy_item_count.argtypes = [vp, ctypes.c_int32]
         L.pcto_set_shuffle_seed.argtypes = [vp, ctypes.c_uint64]
         L.pcto_step_heuristic.argtypes = [vp, ctypes.c_int32, ctypes.c_int32]
         L.pcto_set_density_stream.argtypes = [vp, vp, ctypes.c_int64]
@@ -157,8 +158,11 @@ class OracleVecEnv(object):
     def set_sampler(self, seed):
         self._check(lib().pcto_set_sampler(self._h, seed))
 
-    def set_numpy_rng(self, seed):
-        """strict NumPy-stream mode: env e consumes np.random.seed(seed + env_id_base + e)'s MT19937 stream"""
+    def set_numpy_rng(self, seed, n_item_set=125):
+        """strict NumPy-stream mode: env e consumes np.random.seed(seed + env_id_base + e)'s MT19937 stream
+        (continuous env: n_item_set = len(item_set) behind RandomBoxCreator's unused randint draws)"""
+        if self.cfg.env_kind == 1:
+            self._check(lib().pcto_set_numpy_item_count(self._h, int(n_item_set)))
         self._check(lib().pcto_set_numpy_rng(self._h, int(seed) & 0xFFFFFFFF))
 
     def reset(self, env_ids=None):

@@ -1000,12 +1000,24 @@ int pcto_set_shuffle_seed(pcto_env* h, uint64_t seed) {
 /* strict NumPy-stream mode: env e consumes the MT19937 stream np.random.seed(seed + env_id_base + e) starts
  * (every worker of ShmemVecEnv(fork) seeds its own process-global RandomState: envs.py:49, bin3D.py:47-54);
  * items come from the item set through np.random.randint.  Discrete env. */
+void pctc_set_numpy_rng(struct pcto_env* h, uint32_t seed);
 int pcto_set_numpy_rng(pcto_env* h, uint32_t seed) {
-  if (!h || !h->item_set) return fail(PCT_ERR_STATE, "set the item set first");
-  if (h->cfg.env_kind != PCT_ENV_DISCRETE) return fail(PCT_ERR_UNSUPPORTED, "NumPy-stream mode: discrete env only");
+  if (!h || !h->item_set) return fail(PCT_ERR_STATE, "set the item set / sample bounds first");
   h->rng_numpy = 1;
   h->source = PCT_ITEMS_SAMPLER;
+  if (h->cfg.env_kind != PCT_ENV_DISCRETE) {
+    if (h->sample_right <= 0) return fail(PCT_ERR_UNSUPPORTED, "NumPy-stream mode, continuous env: sampling from U(a,b) only");
+    pctc_set_numpy_rng(h, seed);
+    return PCT_OK;
+  }
   for (int e = 0; e < h->N; e++) npmt_seed(h->envs[e].mt, &h->envs[e].mt_pos, seed + (uint32_t)h->cfg.env_id_base + (uint32_t)e);
+  return PCT_OK;
+}
+/* continuous NumPy-stream mode: len(item_set) of the RandomBoxCreator whose randint draws are consumed but unused */
+int pcto_set_numpy_item_count(pcto_env* h, int32_t n) {
+  if (!h || n < 1) return fail(PCT_ERR_INVALID_ARG, "bad count");
+  if (h->cfg.env_kind == PCT_ENV_DISCRETE) return fail(PCT_ERR_UNSUPPORTED, "continuous env only");
+  h->n_items = n;
   return PCT_OK;
 }
 

@@ -38,6 +38,7 @@ int pcto_set_item_dataset(pcto_env* env, const int32_t* items, const int32_t* le
 int pcto_set_sampler(pcto_env* env, uint64_t seed);
 /* strict NumPy-stream mode (discrete env): env e consumes the MT19937 stream of np.random.seed(seed + env_id_base + e) */
 int pcto_set_numpy_rng(pcto_env* env, uint32_t seed);
+int pcto_set_numpy_item_count(pcto_env* env, int32_t n); /* continuous env: len(item_set) behind the unused randint draws */
 int pcto_step_heuristic(pcto_env* env, int32_t kind, int32_t n_steps);
 int pcto_set_density_stream(pcto_env* env, const double* den, int64_t T);
 int pcto_set_dataset_density(pcto_env* env, const double* den);

@@ -40,6 +40,8 @@ struct cenv {
   int traj;
   struct stab* stab; /* settings 1 / 3 */
   uint64_t oc;       /* observations produced so far (shuffle key) */
+  uint32_t mt[624];  /* strict NumPy-stream mode: this env's MT19937 state (pct_oracle_internal.h npmt_*) */
+  int mt_pos;
 };
 
 static double around6(double x) { return rint(x * 1e6) / 1e6; }
@@ -141,6 +143,40 @@ static void dset_add(dset* s, const double* keys, int32_t k) {
     perturb >>= 5;
     i = (i * 5 + 1 + perturb) & mask;
   }
+}
+
+/* ---- strict NumPy-stream mode ------------------------------------------------------------- */
+/* Python's round(x, 3) of a positive float as a lattice index k (the result is the double nearest to k / 1000):
+ * correctly rounded on the EXACT binary value of x, ties to even (float.__round__ -> _Py_dg_dtoa mode 3).
+ * x is compared with the midpoints (2k +- 1) / 2000 in integer arithmetic: x = m * 2^e, so x * 2000 = (m * 2000) * 2^e. */
+static int cmp_x_mid(double x, int64_t twok1) { /* sign of x * 2000 - twok1 */
+  int ex;
+  double fr = frexp(x, &ex);                      /* x = fr * 2^ex, fr in [0.5, 1) */
+  uint64_t m = (uint64_t)ldexp(fr, 53);           /* 53-bit integer mantissa */
+  int e2 = ex - 53;                               /* x = m * 2^e2 */
+  unsigned __int128 A = (unsigned __int128)m * 2000u, B = (unsigned __int128)(uint64_t)twok1;
+  if (e2 >= 0) A <<= e2; else B <<= -e2;
+  return A > B ? 1 : (A < B ? -1 : 0);
+}
+static int32_t round3_lattice(double x) {
+  int64_t k = (int64_t)(x * 1000.0 + 0.5);
+  for (int it = 0; it < 3; it++) {
+    int up = cmp_x_mid(x, 2 * k + 1), dn = cmp_x_mid(x, 2 * k - 1);
+    if (up > 0 || (up == 0 && (k & 1))) { k++; continue; }          /* above the upper midpoint (tie -> even) */
+    if (dn < 0 || (dn == 0 && (k & 1))) { k--; continue; }          /* below the lower midpoint (tie -> even) */
+    break;
+  }
+  return (int32_t)k;
+}
+/* C/bin3D.py:103-113 gen_next_box in sampling mode: round(np.random.uniform(a, b), 3) three times, or twice plus
+ * np.random.choice([0.1, ..., 0.5]) (legacy choice -> randint(0, 5)) under settings 1 / 3 */
+static void draw_item_numpy(const struct pcto_env* h, struct cenv* s, double out[3]) {
+  const double a = (double)h->sample_left / 1000.0, b = (double)h->sample_right / 1000.0;
+  int32_t k[3];
+  const int nu = h->cfg.setting == 2 ? 3 : 2;
+  for (int d = 0; d < nu; d++) k[d] = round3_lattice(a + (b - a) * npmt_double(s->mt, &s->mt_pos));
+  if (nu == 2) k[2] = 100 * (1 + (int32_t)npmt_interval(s->mt, &s->mt_pos, 4u));
+  for (int d = 0; d < 3; d++) out[d] = (double)k[d] / 1000.0;
 }
 
 /* ---- item source ------------------------------------------------------------------------ */
@@ -370,7 +406,13 @@ static void get_possible_position(const struct pcto_env* h, int e, struct cenv* 
   memset(leaf, 0, sizeof(double) * 9 * h->L);
   double* pos = NULL;
   int n = ems_point(h, s, &pos), idx = 0;
-  if (h->cfg.shuffle && n > 1) { /* C/bin3D.py:126-127 -> include/pct_env.h pct_shuffle_priority */
+  if (h->cfg.shuffle && h->rng_numpy) { /* np.random.shuffle(allPostion), legacy Fisher-Yates on random_interval */
+    for (int i = n - 1; i >= 1; i--) {
+      int j = (int)npmt_interval(s->mt, &s->mt_pos, (uint32_t)i);
+      if (j == i) continue;
+      for (int c = 0; c < 6; c++) { double t_ = pos[6 * i + c]; pos[6 * i + c] = pos[6 * j + c]; pos[6 * j + c] = t_; }
+    }
+  } else if (h->cfg.shuffle && n > 1) { /* C/bin3D.py:126-127 -> include/pct_env.h pct_shuffle_priority */
     uint32_t* pr = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)n);
     int* ord = (int*)malloc(sizeof(int) * (size_t)n);
     for (int i = 0; i < n; i++) { pr[i] = pct_shuffle_priority(h->shuffle_seed, (uint64_t)(h->cfg.env_id_base + e), s->oc, (uint32_t)i); ord[i] = i; }
@@ -397,9 +439,17 @@ static void get_possible_position(const struct pcto_env* h, int e, struct cenv* 
 
 /* C/bin3D.py:78-100 cur_observation (scripted items: sample_from_distribution=False path) */
 static void cur_observation(const struct pcto_env* h, int e, struct cenv* s, double* obs) {
+  if (h->rng_numpy) {
+    /* sampling mode draws a NEW item inside EVERY cur_observation (C/bin3D.py:81,103-113) -- also inside the
+     * discarded observation of a failed step -- and ignores the BoxCreator queue */
+    draw_item_numpy(h, s, s->next_box);
+    s->next_den = 1.0;
+    if (h->cfg.setting == 3) { do { s->next_den = npmt_double(s->mt, &s->mt_pos); } while (s->next_den == 0); }
+  } else {
   if (s->queue_len < 1) { draw_item(h, e, s, s->queue_item); s->queue_len = 1; }
   memcpy(s->next_box, s->queue_item, sizeof s->next_box);
   s->next_den = pcto_next_density(h, e, s->oc, s->traj, s->cursor - 1); /* C/bin3D.py:81-90 */
+  }
   memcpy(obs, s->box_vec, sizeof(double) * 9 * h->I);
   get_possible_position(h, e, s, obs + 9 * h->I);
   double a = s->next_box[0], b = s->next_box[1], c = s->next_box[2], t;
@@ -426,7 +476,8 @@ void pctc_reset(struct pcto_env* h, int e, double* obs) {
     if (s->traj >= h->ds_ntraj) h->flags[e] |= PCT_FLAG_DATASET_EXHAUSTED;
   }
   space_reset(h, s);
-  draw_item(h, e, s, s->queue_item);
+  if (h->rng_numpy) (void)npmt_interval(s->mt, &s->mt_pos, (uint32_t)h->n_items - 1u); /* box_creator.generate_box_size(): a randint nobody reads */
+  else draw_item(h, e, s, s->queue_item);
   s->queue_len = 1;
   cur_observation(h, e, s, obs);
 }
@@ -472,7 +523,8 @@ void pctc_step(struct pcto_env* h, int e, const double* act, int len, double* ob
   double mx = (double)((int64_t)(h->cfg.container[0] / 1000) * (h->cfg.container[1] / 1000) * (h->cfg.container[2] / 1000));
   double box_ratio = (s->next_box[0] * s->next_box[1] * s->next_box[2]) / mx;
   s->queue_len = 0;
-  draw_item(h, e, s, s->queue_item);
+  if (h->rng_numpy) (void)npmt_interval(s->mt, &s->mt_pos, (uint32_t)h->n_items - 1u); /* generate_box_size() */
+  else draw_item(h, e, s, s->queue_item);
   s->queue_len = 1;
   *reward = box_ratio * 10;
   *done = 0;
@@ -514,4 +566,10 @@ int pctc_debug_state(struct pcto_env* h, int e, double* ems, int cap_ems, int* n
   if (next_item) memcpy(next_item, s->next_box, 3 * sizeof(double));
   if (cursor) *cursor = (int64_t)s->cursor;
   return 0;
+}
+
+/* strict NumPy-stream mode for the continuous env (sampling from U(a,b)): `n_item_set` = len(item_set) the
+ * reference's RandomBoxCreator draws its (unused) index from (givenData.item_size_set: 125) */
+void pctc_set_numpy_rng(struct pcto_env* h, uint32_t seed) {
+  for (int e = 0; e < h->N; e++) npmt_seed(h->cenvs[e].mt, &h->cenvs[e].mt_pos, seed + (uint32_t)h->cfg.env_id_base + (uint32_t)e);
 }

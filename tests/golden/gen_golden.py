@@ -717,23 +717,39 @@ NUMPY_STREAM_CASES = {
     "discrete_s2_numpy_stream": dict(setting=2, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, N=6, steps=250, seed=4, base=0),
     "discrete_s1_numpy_stream": dict(setting=1, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, N=4, steps=200, seed=11, base=5),
     "discrete_s3_numpy_stream": dict(setting=3, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, N=4, steps=200, seed=12, base=2),
+    # continuous env, sample_from_distribution=True (the CLI's --continuous default, main.py / arguments.py):
+    # items round(np.random.uniform(a, b), 3), z from np.random.choice under settings 1 / 3, the RandomBoxCreator's
+    # unread randint over givenData.item_size_set (125 entries), np.random.shuffle of the float positions
+    "continuous_s2_numpy_stream": dict(kind=1, setting=2, container=(10, 10, 10), lo=1.0, hi=5.0, I=80, L=50, N=5, steps=220, seed=31, base=0),
+    "continuous_s1_numpy_stream": dict(kind=1, setting=1, container=(1, 1, 1), lo=0.1, hi=0.5, I=80, L=50, N=4, steps=180, seed=32, base=3),
+    "continuous_s3_numpy_stream": dict(kind=1, setting=3, container=(1, 1, 1), lo=0.1, hi=0.5, I=80, L=50, N=4, steps=180, seed=33, base=7),
 }
+
+
+GIVEN_ITEM_SET = [(i, j, k) for i in range(1, 6) for j in range(1, 6) for k in range(1, 6)]  # givenData.py:13-18
 
 
 def run_reference_numpy_stream(c):
     PD, PC, _ = ref_shim.load_reference_envs()
-    items = item_set_range(c["lo"], c["hi"])
+    cont = c.get("kind", 0) == 1
+    items = GIVEN_ITEM_SET if cont else item_set_range(c["lo"], c["hi"])
     N, I, L, T = c["N"], c["I"], c["L"], c["steps"]
-    out = dict(obs=np.zeros((T + 1, N, (I + L + 1) * 9), np.float32), reward=np.zeros((T, N)), done=np.zeros((T, N), np.uint8),
+    dt = np.float64 if cont else np.float32
+    out = dict(obs=np.zeros((T + 1, N, (I + L + 1) * 9), dt), reward=np.zeros((T, N)), done=np.zeros((T, N), np.uint8),
                counter=np.zeros((T, N), np.int32), ratio=np.zeros((T, N)))
     for e in range(N):
         np.random.seed(c["seed"] + c["base"] + e)  # env.seed(seed + rank): one process, one stream per env
-        env = PD(setting=c["setting"], container_size=list(c["container"]), item_set=items, internal_node_holder=I,
-                 leaf_node_holder=L, LNES="EMS", shuffle=True)
+        if cont:
+            env = PC(setting=c["setting"], container_size=list(c["container"]), item_set=items, internal_node_holder=I,
+                     leaf_node_holder=L, LNES="EMS", shuffle=True, sample_from_distribution=True,
+                     sample_left_bound=c["lo"], sample_right_bound=c["hi"])
+        else:
+            env = PD(setting=c["setting"], container_size=list(c["container"]), item_set=items, internal_node_holder=I,
+                     leaf_node_holder=L, LNES="EMS", shuffle=True)
         obs = env.reset()
         g = c["base"] + e
         for t in range(T):
-            out["obs"][t, e] = obs.astype(np.float32)
+            out["obs"][t, e] = obs.astype(dt)
             leaf = obs.reshape(-1, 9)[I:I + L]
             k = int((leaf[:, 8] != 0).sum())
             li = mix32(g, t) % k if k > 0 else 0
@@ -742,24 +758,31 @@ def run_reference_numpy_stream(c):
             out["ratio"][t, e] = info.get("ratio", 0.0)
             if d:
                 obs = env.reset()
-        out["obs"][T, e] = obs.astype(np.float32)
+        out["obs"][T, e] = obs.astype(dt)
     return out
 
 
 def run_oracle_numpy_stream(c):
     from oracle.oracle_lib import OracleVecEnv
     N, I, L, T = c["N"], c["I"], c["L"], c["steps"]
-    env = OracleVecEnv(N, setting=c["setting"], container_size=c["container"], item_set=item_set_range(c["lo"], c["hi"]),
-                       internal_node_holder=I, leaf_node_holder=L, env_id_base=c["base"], shuffle=True)
-    env.set_numpy_rng(c["seed"])
-    out = dict(obs=np.zeros((T + 1, N, (I + L + 1) * 9), np.float32), reward=np.zeros((T, N)), done=np.zeros((T, N), np.uint8),
+    cont = c.get("kind", 0) == 1
+    dt = np.float64 if cont else np.float32
+    if cont:
+        env = OracleVecEnv(N, setting=c["setting"], container_size=c["container"], env_kind=1, sample_bounds=(c["lo"], c["hi"]),
+                           internal_node_holder=I, leaf_node_holder=L, env_id_base=c["base"], shuffle=True)
+        env.set_numpy_rng(c["seed"], n_item_set=len(GIVEN_ITEM_SET))
+    else:
+        env = OracleVecEnv(N, setting=c["setting"], container_size=c["container"], item_set=item_set_range(c["lo"], c["hi"]),
+                           internal_node_holder=I, leaf_node_holder=L, env_id_base=c["base"], shuffle=True)
+        env.set_numpy_rng(c["seed"])
+    out = dict(obs=np.zeros((T + 1, N, (I + L + 1) * 9), dt), reward=np.zeros((T, N)), done=np.zeros((T, N), np.uint8),
                counter=np.zeros((T, N), np.int32), ratio=np.zeros((T, N)))
     env.reset()
     for t in range(T):
-        out["obs"][t] = env.obs.astype(np.float32)
+        out["obs"][t] = env.obs.astype(dt)
         env.step_hash_policy(1)
         out["reward"][t], out["done"][t], out["counter"][t], out["ratio"][t] = env.reward, env.done, env.counter, env.ratio
-    out["obs"][T] = env.obs.astype(np.float32)
+    out["obs"][T] = env.obs.astype(dt)
     assert not env.flags.any()
     env.close()
     return out
