@@ -1150,6 +1150,7 @@ pct_continuous_kernel(ContinuousParams p, const void* __restrict__ actions,
   tm.start();
   cload(p, e, l, r, lane);
   tm.tick(PH_LOAD);
+  wave_priority(r.n_ems, p.prio_t);
   float* obs = p.obs + (size_t)e * p.row_len;
   // an env whose EMS list outgrows this launch's LDS list -- already at load, or in this step's GENEMS -- goes,
   // state untouched, to the large-capacity pass, like one whose candidate set outgrows the table

@@ -31,6 +31,8 @@ struct DiscreteParams {
   int key_bytes; /* 4: six 5-bit coords (bins <= 31); 8: six 10-bit coords (<= 1023) */
   // item source
   int source, n_items, env_id_base;
+  int prio_t[3];     /* wave_priority thresholds on the EMS count (0: off) */
+  int heavy_t;       /* > 0: envs with at least this many EMS build their candidate set with four waves (pct_discrete_mw.cuh) */
   int rng_numpy;     /* 1: strict NumPy-stream mode -- item picks, setting-3 densities and the candidate shuffle consume
                         the env's own MT19937 stream exactly as the reference's worker process does */
   uint32_t* mt;      /* [N,624] MT19937 state words of every env (position: scalars[7]) */
@@ -112,6 +114,7 @@ struct ContinuousParams {
   uint16_t* gorder; /* [N, order_cap] */
   uint32_t* gfpri;  /* [N, order_cap] shuffle priorities (HBM-table variant + shuffle) */
   int gt_by_block;  /* HBM table slices indexed by blockIdx (retry pass) instead of env */
+  int prio_t[3];    /* wave_priority thresholds on the EMS count (0: off) */
   int rng_numpy;    /* 1: strict NumPy-stream mode (pct_set_numpy_rng), as in DiscreteParams */
   int np_items;     /* len(item_set) behind RandomBoxCreator's unread randint draws (sampling mode) */
   uint32_t* mt;     /* [N,624] MT19937 state words (position: scalars[7]) */
@@ -132,6 +135,18 @@ struct ContinuousParams {
 
 // D/bin3D.py:75-84 next_den of the observation number `oc` (the env's life-long observation
 // counter); traj / item_index locate the previewed item in dataset mode.
+// A launch lasts as long as its slowest env, and an env's work grows with its EMS count: waves of EMS-rich envs
+// take a higher issue priority (s_setprio) so that they run at a lone wave's pace from the start while the light
+// waves of the same SIMD fill the gaps, instead of crawling at a quarter of it until the light ones are gone.
+// prio_t: ascending EMS-count thresholds of priorities 1..3 (0: off).
+__device__ inline void wave_priority(int n_ems, const int prio_t[3]) {
+  if (prio_t[0] <= 0) return;
+  if (n_ems >= prio_t[2]) __builtin_amdgcn_s_setprio(3);
+  else if (n_ems >= prio_t[1]) __builtin_amdgcn_s_setprio(2);
+  else if (n_ems >= prio_t[0]) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+}
+
 template <typename Params>
 __device__ inline double next_density(const Params& p, int e, uint32_t oc, int traj, unsigned long long item_index) {
   if (p.setting != 3) return 1.0;
@@ -153,6 +168,7 @@ hipError_t launch_continuous(const ContinuousParams& p, int act, const void* act
 
 size_t discrete_lds_bytes(const DiscreteParams& p);
 hipError_t launch_policy_hash_rows(const DiscreteParams& p, float* rows_out, hipStream_t stream);
+hipError_t launch_discrete_mw(const DiscreteParams& p, int act, const void* actions, int row_len, int n_steps, hipStream_t stream);
 hipError_t launch_discrete(const DiscreteParams& p, int act, const void* actions, int row_len, int n_steps,
                            const int32_t* env_ids, int n_ids, hipStream_t stream);
 
