@@ -10,9 +10,9 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpct_hip.so")
-SOURCES = ["pct_env.hip", "pct_discrete.hip", "pct_discrete_u64.hip", "pct_continuous.hip", "pct_continuous_mt.hip", "pct_discrete_mw.hip"]
+SOURCES = ["pct_env.hip", "pct_discrete.hip", "pct_discrete_u64.hip", "pct_continuous.hip", "pct_continuous_mt.hip"]
 HEADERS = [os.path.join(CSRC, "pct_device.h"), os.path.join(CSRC, "pct_set.cuh"), os.path.join(CSRC, "pct_stab.cuh"),
-           os.path.join(CSRC, "pct_discrete_impl.cuh"), os.path.join(CSRC, "pct_mt.cuh"), os.path.join(CSRC, "pct_discrete_mw.cuh"),
+           os.path.join(CSRC, "pct_discrete_impl.cuh"), os.path.join(CSRC, "pct_mt.cuh"),
            os.path.join(HERE, "..", "include", "pct_env.h")]
 
 
@@ -46,7 +46,6 @@ def build_library(force=False, verbose=False):
     deps = {"pct_env.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh"],
             "pct_discrete.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_mt.cuh", "pct_discrete_impl.cuh"],
             "pct_discrete_u64.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_mt.cuh", "pct_discrete_impl.cuh"],
-            "pct_discrete_mw.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_mt.cuh", "pct_discrete_impl.cuh", "pct_discrete_mw.cuh"],
             "pct_continuous.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_mt.cuh"],
             "pct_continuous_mt.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_mt.cuh", "pct_continuous.hip"]}
 

@@ -32,7 +32,6 @@ struct DiscreteParams {
   // item source
   int source, n_items, env_id_base;
   int prio_t[3];     /* wave_priority thresholds on the EMS count (0: off) */
-  int heavy_t;       /* > 0: envs with at least this many EMS build their candidate set with four waves (pct_discrete_mw.cuh) */
   int rng_numpy;     /* 1: strict NumPy-stream mode -- item picks, setting-3 densities and the candidate shuffle consume
                         the env's own MT19937 stream exactly as the reference's worker process does */
   uint32_t* mt;      /* [N,624] MT19937 state words of every env (position: scalars[7]) */
@@ -137,8 +136,8 @@ struct ContinuousParams {
 // counter); traj / item_index locate the previewed item in dataset mode.
 // A launch lasts as long as its slowest env, and an env's work grows with its EMS count: waves of EMS-rich envs
 // take a higher issue priority (s_setprio) so that they run at a lone wave's pace from the start while the light
-// waves of the same SIMD fill the gaps, instead of crawling at a quarter of it until the light ones are gone.
-// prio_t: ascending EMS-count thresholds of priorities 1..3 (0: off).
+// waves of the same SIMD fill the gaps, instead of crawling at a quarter of it until the light ones are gone
+// (C2: 75.4 -> 71.2 us per launch).  prio_t: ascending EMS-count thresholds of priorities 1..3 (0: off).
 __device__ inline void wave_priority(int n_ems, const int prio_t[3]) {
   if (prio_t[0] <= 0) return;
   if (n_ems >= prio_t[2]) __builtin_amdgcn_s_setprio(3);
@@ -168,7 +167,6 @@ hipError_t launch_continuous(const ContinuousParams& p, int act, const void* act
 
 size_t discrete_lds_bytes(const DiscreteParams& p);
 hipError_t launch_policy_hash_rows(const DiscreteParams& p, float* rows_out, hipStream_t stream);
-hipError_t launch_discrete_mw(const DiscreteParams& p, int act, const void* actions, int row_len, int n_steps, hipStream_t stream);
 hipError_t launch_discrete(const DiscreteParams& p, int act, const void* actions, int row_len, int n_steps,
                            const int32_t* env_ids, int n_ids, hipStream_t stream);
 

@@ -36,11 +36,6 @@ hipError_t launch_policy_hash_rows(const DiscreteParams& p, float* rows_out, hip
 
 hipError_t launch_discrete(const DiscreteParams& p, int act, const void* actions, int row_len, int n_steps,
                            const int32_t* env_ids, int n_ids, hipStream_t stream) {
-  // the multi-wave kernel: plain setting-2 step launches over all envs (not the retry pass, not the timed build)
-  if (p.heavy_t > 0 && p.key_bytes == 4 && p.setting == 2 && p.lnes == PCT_LNES_EMS && !p.shuffle && !p.rng_numpy &&
-      !p.retry_mode && p.timing == nullptr && p.cand_cap >= 128 && p.cand_cap <= 2048 &&
-      (act == ACT_ROWS || act == ACT_INDEX || act == ACT_HASH) && discrete_lds_bytes_impl(p) <= 48 * 1024)
-    return launch_discrete_mw(p, act, actions, row_len, n_steps, stream);
   if (p.key_bytes == 4) return launch_typed<uint32_t, 5>(p, act, actions, row_len, n_steps, env_ids, n_ids, stream);
   return launch_discrete_u64(p, act, actions, row_len, n_steps, env_ids, n_ids, stream);
 }

@@ -95,7 +95,6 @@ struct Lds {
   K* ems_a;    // [ems_cap] current EMS list
   K* ems_b;    // GENEMS scratch list: aliases the table region (idle during GENEMS)
   uint32_t* dd;  // [128] bucket words of the batch de-duplication
-  uint32_t* ctl; // [8] control words of the multi-wave set build (pct_discrete_mw.cuh; only when p.heavy_t > 0)
   K* box;
   K* leaf;
   HT* hmap;
@@ -124,8 +123,6 @@ __device__ inline Lds<K, BITS> carve_lds(const DiscreteParams& p, unsigned char*
   l.ems_b = l.tab0;
   l.dd = reinterpret_cast<uint32_t*>(q);
   q += discrete_scratch_words(p);
-  l.ctl = reinterpret_cast<uint32_t*>(q);
-  q += p.heavy_t > 0 ? (int)(8 * sizeof(uint32_t) / sizeof(K)) : 0;
   l.box = q; q += p.I;
   l.leaf = q; q += p.L;
   l.hmap = reinterpret_cast<typename Lds<K, BITS>::HT*>(q);
@@ -291,7 +288,7 @@ __device__ inline void genems(const DiscreteParams& p, Lds<K, BITS>& l, EnvRegs&
     n = scap;
   }
   if (overflow) r.flags |= PCT_FLAG_EMS_OVERFLOW;
-  PCT_SYNC();
+  __syncthreads();
   // elimination: i is deleted iff some j != i contains it (non-strict, pre-deletion list).
   // The list before GENEMS is containment-free (it is the output of the previous
   // elimination, or the single initial EMS), and a child is a subset of its intersected
@@ -313,7 +310,7 @@ __device__ inline void genems(const DiscreteParams& p, Lds<K, BITS>& l, EnvRegs&
       cmpw[2 * i] = spread(kk & 0x7FFFu);
       cmpw[2 * i + 1] = spread((kk >> 15) & 0x7FFFu) | G;
     }
-    PCT_SYNC();
+    __syncthreads();
   }
   if (swar && n - out <= 32) {
     // few children: several lanes share a child and split the list between them
@@ -375,7 +372,7 @@ __device__ inline void genems(const DiscreteParams& p, Lds<K, BITS>& l, EnvRegs&
     r.flags |= PCT_FLAG_EMS_OVERFLOW;
   }
   r.n_ems = out;
-  PCT_SYNC();
+  __syncthreads();
 }
 
 // The candidate set under construction: a CPython `set` whose table lives in LDS (l.tab0).
@@ -485,9 +482,9 @@ __device__ inline void set_insert(SetState<K>& st, const K (&key)[V], const bool
       const int total = 19 + __popcll(rem);
       tabs[lane] = EMPTY;
       tabs[64 + lane] = EMPTY;
-      PCT_SYNC();
+      __syncthreads();
       const K mk = lane < total ? fin[lane] : (K)0;
-      PCT_SYNC();
+      __syncthreads();
       dd[lane] = 0xFFFFFFFFu;  // back to the all-ones state the de-duplication expects
       if (sizeof(K) == 8) dd[64 + lane] = 0xFFFFFFFFu;
       if (TM::on) tm.sub_tick(PH_FAST_START);
@@ -500,7 +497,7 @@ __device__ inline void set_insert(SetState<K>& st, const K (&key)[V], const bool
       st.size = 128;
       st.fill = (uint32_t)total;
       pending[0] = false;
-      PCT_SYNC();
+      __syncthreads();
       tm.sub_tick(PH_SET_MATCH);
     }
   }
@@ -541,7 +538,7 @@ __device__ inline void set_insert(SetState<K>& st, const K (&key)[V], const bool
         nplaced += __popcll(__ballot(placed[v]));
       }
       st.fill += (uint32_t)nplaced;
-      PCT_SYNC();
+      __syncthreads();
       tm.sub_tick(PH_SET_MATCH);
     }
     if (st.fill >= thr) {  // set_table_resize(used * 4): re-insert in old-slot order
@@ -562,9 +559,9 @@ __device__ inline void set_insert(SetState<K>& st, const K (&key)[V], const bool
           const uint32_t s2 = (uint32_t)c * 64u + lane;
           oldk[c] = (s2 < st.size) ? tabs[st.toff + s2] : EMPTY;
         }
-        PCT_SYNC();
+        __syncthreads();
         for (uint32_t s2 = lane; s2 < newsize; s2 += 64) tabs[noff + s2] = EMPTY;
-        PCT_SYNC();
+        __syncthreads();
 #pragma unroll
         for (int c0 = 0; c0 < 8; c0 += RV) {
           if ((uint32_t)c0 * 64u < st.size) {
@@ -580,12 +577,12 @@ __device__ inline void set_insert(SetState<K>& st, const K (&key)[V], const bool
 #pragma unroll
             for (int c = 0; c < RV; c++)
               if (opart[c]) tabs[noff + oslot[c]] = oldk[c0 + c];
-            PCT_SYNC();
+            __syncthreads();
           }
         }
       } else {
         for (uint32_t s2 = lane; s2 < newsize; s2 += 64) tabs[noff + s2] = EMPTY;
-        PCT_SYNC();
+        __syncthreads();
         for (uint32_t sb = 0; sb < st.size; sb += 64u * RV) {
           K ok[RV];
           bool opart[RV];
@@ -602,7 +599,7 @@ __device__ inline void set_insert(SetState<K>& st, const K (&key)[V], const bool
 #pragma unroll
           for (int c = 0; c < RV; c++)
             if (opart[c]) tabs[noff + oslot[c]] = ok[c];
-          PCT_SYNC();
+          __syncthreads();
         }
       }
       st.toff = noff;
@@ -612,16 +609,11 @@ __device__ inline void set_insert(SetState<K>& st, const K (&key)[V], const bool
   }
 }
 
-}  // namespace pct
-#include "pct_discrete_mw.cuh"
-namespace pct {
-
 // D/space.py:534-570 EMSPoint (CPython-set order) + D/bin3D.py:100-136
 // get_possible_position: fills l.leaf[0..n_leaf) with the first <= L feasible candidates.
 // RNG: bit 0 = the candidate list is shuffled before the first-L cut, bit 1 = strict NumPy-stream mode (the shuffle, the
 // item picks and the densities consume the env's MT19937 stream; otherwise they are counter-keyed)
-// MW: this is wave 0 of an EMS-rich env in the multi-wave kernel -- the set is built together with the helper waves
-template <typename K, int BITS, bool STAB, int SCHEME, int RNG, bool MW = false, typename TM>
+template <typename K, int BITS, bool STAB, int SCHEME, int RNG, typename TM>
 __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& l, EnvRegs& r, int lane, TM& tm) {
   typedef Pack<K, BITS> P;
   constexpr bool SHUFFLE = (RNG & 1) != 0, MT = (RNG & 2) != 0;
@@ -646,7 +638,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
   if (lane < 8) tabs[st.toff + lane] = EMPTY;
   l.dd[lane] = 0xFFFFFFFFu;
   l.dd[64 + lane] = 0xFFFFFFFFu;
-  PCT_SYNC();
+  __syncthreads();
   int mstat[3] = {0, 0, 0};  // timed build only: match calls, outer rounds, sum over calls of the longest walk
   int* const mst = TM::on ? mstat : nullptr;
   tm.sub_start();
@@ -685,7 +677,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
       const K key1[1] = {P::pack(px, py, pz, px + sx, py + sy, pz + sz)};
       const bool valid1[1] = {valid};
       set_insert<K, BITS, 1>(st, key1, valid1, lane, tm, mst);
-      PCT_SYNC();
+      __syncthreads();
     }
   } else if (EV) {
     // D/space.py:613-693 EventPoint.  bin3D.py:171 runs GENEMS only under LNES == 'EMS', so under
@@ -756,18 +748,18 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
       }
       ord[31] = (uint32_t)m;
     }
-    PCT_SYNC();
+    __syncthreads();
     n_ev = (int)l.cp[256 + 31];
     // the ordered survivors become the "table": slot i of a fresh region holds candidate i
     {
       uint32_t id = lane < n_ev ? l.cp[256 + lane] : 0u;
       int t[6];
       ev_tuple((int)id, t);
-      PCT_SYNC();
+      __syncthreads();
       st.size = 64;
       st.toff = 0;
       tabs[lane] = lane < n_ev ? P::pack(t[0], t[1], t[2], t[3], t[4], t[5]) : EMPTY;
-      PCT_SYNC();
+      __syncthreads();
     }
   } else if (CP && r.n_boxes == 0) {
     // D/space.py:756-757 (and :700-701 for EP): an empty bin yields a plain two-element LIST
@@ -777,7 +769,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
       tabs[st.toff + 0] = P::pack(0, 0, 0, b0, b1, b2);
       tabs[st.toff + 1] = P::pack(0, 0, 0, b1, b0, b2);
     }
-    PCT_SYNC();
+    __syncthreads();
   } else if (CP) {
     // D/space.py:758-774 + D/PctTools.py:137-158 (CP) / :696-716 + PctTools.py:114-136 (EP): per level
     // k (sorted distinct tops, 0 first) the corner / extreme points of the boxes reaching above k,
@@ -800,7 +792,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
       for (int j = 0; j < n; j++) first = first && !(j < i && P::get(uniform_key<K>(l.box[j]), 5) == top);
       if (i < n) cik[i] = first ? 1u : 0u;
     }
-    PCT_SYNC();
+    __syncthreads();
     for (int base = 0; base < n; base += 64) {
       int i = base + lane;
       int top = i < n ? P::get(l.box[i], 5) : 0;
@@ -811,7 +803,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
       if (first) T[1 + less] = (uint32_t)top;
       nT += __popcll(__ballot(first));
     }
-    PCT_SYNC();
+    __syncthreads();
     int nCI = 0, nlast = 0;
     bool ci_overflow = false;
     for (int ti = 0; ti < nT; ti++) {
@@ -836,7 +828,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
         if (act) srt[rank] = (uint32_t)i;
         nact += __popcll(__ballot(act));
       }
-      PCT_SYNC();
+      __syncthreads();
       int nc = 0;
       if (nact == 0) {
         if (lane == 0) cik[0] = 0;  // corners2D([]) == [(0, 0)]; extreme2D([]) == [(0, 0, 0)]
@@ -933,7 +925,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
         if (lane == 0) cik[m] = (uint32_t)xmax;
         nc = m + 1;
       }
-      PCT_SYNC();
+      __syncthreads();
       // CI += points not present at the previous level (order kept).  EP: the empty level's point is
       // the 3-tuple (0,0,0), which no 2-tuple of the previous level equals (and vice versa)
       const bool ep_empty = EP && nact == 0;
@@ -954,10 +946,10 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
       }
       ci_overflow = __ballot(ci_overflow) != 0;
       if (nCI > ci_cap) nCI = ci_cap;
-      PCT_SYNC();
+      __syncthreads();
       for (int c = lane; c < nc; c += 64) last[c] = cik[c];
       nlast = ep_empty ? 0 : nc;
-      PCT_SYNC();
+      __syncthreads();
     }
     if (ci_overflow) r.flags |= PCT_FLAG_EMS_OVERFLOW;
     // candidates: corner x rotation, in-bin test (D/space.py:776-803), into the set
@@ -974,18 +966,8 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
       const K key1[1] = {P::pack(px, py, pz, px + sx, py + sy, pz + sz)};
       const bool valid1[1] = {valid};
       set_insert<K, BITS, 1>(st, key1, valid1, lane, tm, mst);
-      PCT_SYNC();
+      __syncthreads();
     }
-  } else if (MW) {
-    MwCtl c{l.ctl, 0u};
-    if (lane == 0) {
-      c.w[1] = (uint32_t)E;
-      c.w[2] = (uint32_t)b0 | ((uint32_t)b1 << 10) | ((uint32_t)b2 << 20);
-      c.w[3] = 0u; c.w[4] = 0u; c.w[5] = 0u;
-      c.w[0] = MW_CMD_BUILD;
-    }
-    __syncthreads();  // the helper waves are waiting here (pct_discrete_kernel_mw)
-    mw_build_set<K, BITS>(p, l, c, 0, lane, st);
   } else {
     // rotations worth generating: not skipped by the reference's rule, and not a repeat of an
     // earlier generated rotation with the same (sx, sy, sz) -- for one EMS that repeat yields the
@@ -1012,7 +994,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
       if (!nt) continue;
       if (pv) l.vp[rank_below(pm)] = (uint16_t)q;
       tm.add(ST_GENERATED, (uint64_t)nt);
-      PCT_SYNC();
+      __syncthreads();
       if (TM::on) tm.add(PH_GEN_PAIRS, tm.now() - tpair);
       for (int tb = 0; tb < nt && !st.overflow; tb += 64 * V) {
       K key[V];
@@ -1034,13 +1016,13 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
       }
       set_insert<K, BITS, V>(st, key, valid, lane, tm, mst);
       }
-      PCT_SYNC();
+      __syncthreads();
     }
   }
   if (st.overflow) r.flags |= PCT_FLAG_CANDIDATE_OVERFLOW;
   uint32_t size = st.size;
   const uint32_t toff = st.toff, fill = st.fill;
-  PCT_SYNC();
+  __syncthreads();
   tm.add(ST_EMS, (uint64_t)E);
   tm.add(ST_DISTINCT, (uint64_t)fill);
   if (TM::on) { tm.add(ST_MATCH_CALLS, (uint64_t)mstat[0]); tm.add(ST_MATCH_ROUNDS, (uint64_t)mstat[1]); tm.add(ST_MATCH_PROBES, (uint64_t)mstat[2]); }
@@ -1082,10 +1064,10 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
       K k = tabs[toff + sb + lane];
       bool occ = (sb + lane < size) && k != SlotWord<K>::EMPTY;
       uint64_t m = __ballot(occ);
-      PCT_SYNC();
+      __syncthreads();
       if (occ) tabs[toff + cnt + rank_below(m)] = k;
       cnt += (uint32_t)__popcll(m);
-      PCT_SYNC();
+      __syncthreads();
     }
     r.n_cand = (int)cnt;
     for (int i = (int)cnt - 1; i >= 1; i--) {
@@ -1096,11 +1078,11 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
         tabs[toff + j] = a;
       }
     }
-    PCT_SYNC();
+    __syncthreads();
     const uint32_t padded = (cnt + 63u) & ~63u;
     if (cnt + lane < padded) tabs[toff + cnt + lane] = SlotWord<K>::EMPTY;
     size = padded;
-    PCT_SYNC();
+    __syncthreads();
     for (uint32_t sb = 0; sb < size && nleaf < p.L; sb += 64) {
       K k = tabs[toff + sb + lane];
       bool feas = (k != SlotWord<K>::EMPTY) && feasible(k);
@@ -1129,7 +1111,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
       nlist += __popcll(om);
       nf += __popcll(fm);
     }
-    PCT_SYNC();
+    __syncthreads();
     for (int base = 0; base < nf; base += 64) {
       int a2 = base + lane;
       bool live = a2 < nf;
@@ -1158,7 +1140,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
       const uint32_t padded = (cnt + 63u) & ~63u;
       if (cnt + lane < padded) tabs[toff + cnt + lane] = SlotWord<K>::EMPTY;
       size = padded;
-      PCT_SYNC();
+      __syncthreads();
     }
     for (uint32_t sb = 0; sb < size && nleaf < p.L; sb += 64) {
       uint32_t s2 = sb + lane;
@@ -1173,7 +1155,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
   r.oc++;
   if (STAB && __ballot(stab_err)) r.flags |= PCT_FLAG_STABILITY_OVERFLOW;
   r.n_leaf = nleaf < p.L ? nleaf : p.L;
-  PCT_SYNC();
+  __syncthreads();
   tm.tick(PH_FEAS);
 }
 
@@ -1293,7 +1275,7 @@ __device__ inline void load_state(const DiscreteParams& p, int e, Lds<K, BITS>& 
   if (lane + 64 < p.AA) l.hmap[lane + 64] = (typename Lds<K, BITS>::HT)h1;
   r.box_from = r.n_boxes;
   for (int i = 128 + lane; i < p.AA; i += 64) l.hmap[i] = (typename Lds<K, BITS>::HT)g_h[i];
-  PCT_SYNC();
+  __syncthreads();
 }
 
 template <typename K, int BITS>
@@ -1405,7 +1387,7 @@ __device__ inline bool heur_choose(const DiscreteParams& p, int e, Lds<K, BITS>&
         if (lane == 0) { scratch[(base >> 6) * 2] = (uint32_t)m; scratch[(base >> 6) * 2 + 1] = (uint32_t)(m >> 32); }
         n += __popcll(m);
       }
-      PCT_SYNC();
+      __syncthreads();
       if (n == 0) return false;
       int pick = (int)(pct_mix32((uint32_t)(p.env_id_base + e), r.t) % (uint32_t)n);
       int q = -1;
@@ -1419,7 +1401,7 @@ __device__ inline bool heur_choose(const DiscreteParams& p, int e, Lds<K, BITS>&
           pick -= c;
         }
       }
-      PCT_SYNC();
+      __syncthreads();
       int rot = q % orient, cell = q / orient;
       olx = cell / ny;
       oly = cell - olx * ny;
@@ -1493,7 +1475,7 @@ __device__ inline bool heur_choose(const DiscreteParams& p, int e, Lds<K, BITS>&
         scratch[ei] = (uint32_t)(dx * dy * dz + fits + (fits == p.n_items ? 10 : 0));
       }
     }
-    PCT_SYNC();
+    __syncthreads();
     for (int base = 0; base < NQ; base += 64) {
       int q = base + lane;
       if (q < NQ) {
@@ -1510,7 +1492,7 @@ __device__ inline bool heur_choose(const DiscreteParams& p, int e, Lds<K, BITS>&
       }
     }
     best = wave_min_u64(best);
-    PCT_SYNC();
+    __syncthreads();
     if (best == NONE) return false;
     int q = (int)(best & 0xFFFFFFull);
     int ei = q / orient, rot = q - ei * orient;
@@ -1534,7 +1516,7 @@ __device__ inline bool heur_choose(const DiscreteParams& p, int e, Lds<K, BITS>&
       for (int j = 0; j < p.Ly; j++) m |= ((int)l.hmap[i * p.A + j] <= lv) ? (1u << j) : 0u;
       rows[c] = m;
     }
-    PCT_SYNC();
+    __syncthreads();
     const int NC = NQ * 4;
     for (int base = 0; base < NC; base += 64) {
       int qc = base + lane;
@@ -1575,7 +1557,7 @@ __device__ inline bool heur_choose(const DiscreteParams& p, int e, Lds<K, BITS>&
       }
     }
     best = wave_min_u64(best);
-    PCT_SYNC();
+    __syncthreads();
     if (best == NONE) return false;
     int qc = (int)(best & 0xFFFFFFull);
     int q = qc >> 2, corner = qc & 3;
@@ -1615,7 +1597,7 @@ __device__ inline bool heur_choose(const DiscreteParams& p, int e, Lds<K, BITS>&
     smin = sc < smin ? sc : smin;
   }
   smin = (uint32_t)(wave_min_u64((uint64_t)smin));
-  PCT_SYNC();
+  __syncthreads();
   bool found = false;
   if (smin < init) {  // a score equal to the initial bound is never taken (:195-199 needs a best already)
     int bd0 = 0, bd1 = 0, bd2 = 0;
@@ -1641,7 +1623,7 @@ __device__ inline bool heur_choose(const DiscreteParams& p, int e, Lds<K, BITS>&
       }
     }
   }
-  PCT_SYNC();
+  __syncthreads();
   return found;
 }
 
@@ -1690,7 +1672,7 @@ __device__ inline bool transition(const DiscreteParams& p, int e, Lds<K, BITS>& 
     // check_box :450-451: box_now.calculated_impact() -- one lane walks the support graph and
     // commits the new shares / stacks (the box is only kept if the verdict is True)
     if (lane == 0) l.box[r.n_boxes] = P::pack(lx, ly, max_h, lx + x, ly + y, max_h + z);
-    PCT_SYNC();
+    __syncthreads();
     int verdict = 1, serr = 0;
     if (lane == 0) {
       BoxGeo<K, BITS> geo{l.box};
@@ -1705,7 +1687,7 @@ __device__ inline bool transition(const DiscreteParams& p, int e, Lds<K, BITS>& 
   } else if (STAB && ok && r.n_boxes < p.I) {
     // resting on the floor: no supporters, stack = own (still recorded for later checks)
     if (lane == 0) l.box[r.n_boxes] = P::pack(lx, ly, max_h, lx + x, ly + y, max_h + z);
-    PCT_SYNC();
+    __syncthreads();
     if (lane == 0) {
       BoxGeo<K, BITS> geo{l.box};
       StabState st = stab_view(p, e);
@@ -1732,7 +1714,7 @@ __device__ inline bool transition(const DiscreteParams& p, int e, Lds<K, BITS>& 
     if (lane == 0) l.box[r.n_boxes] = P::pack(lx, ly, max_h, lx + x, ly + y, top);
     r.n_boxes++;
     r.vol += (int64_t)x * y * z;
-    PCT_SYNC();
+    __syncthreads();
     tm.tick(PH_DROP);
     if (SCHEME == 0) genems<K, BITS>(p, l, r, lane, lx, ly, max_h, lx + x, ly + y, top);  // D/bin3D.py:172-175
     tm.tick(PH_GENEMS);
@@ -1753,9 +1735,9 @@ __device__ inline bool transition(const DiscreteParams& p, int e, Lds<K, BITS>& 
       if (SHUFFLE)
         for (int i = r.n_cand - 1; i >= 1; i--) (void)mt_interval(l, r, lane, (uint32_t)i);
     }
-    PCT_SYNC();
+    __syncthreads();
     space_reset<K, BITS>(p, l, r, lane);  // shmem_vec_env.py:141-143 -> D/bin3D.py:61-67
-    PCT_SYNC();
+    __syncthreads();
     tm.tick(PH_DROP);
   }
   if (MT) {
@@ -1805,10 +1787,10 @@ __device__ inline void decode_leaf(const EnvRegs& r, bool zero_row, int xs, int 
 enum { ACT_ROWS = 0, ACT_INDEX = 1, ACT_HASH = 2, ACT_RESET = 3, ACT_HEUR = 4 /* row_len = PCT_HEUR_* */ };
 
 // one env, one launch's worth of transitions (the body of the kernel below)
-template <typename K, int BITS, int ACT, bool TIMED, bool STAB, int SCHEME, int RNG, bool MW = false>
+template <typename K, int BITS, int ACT, bool TIMED, bool STAB, int SCHEME, int RNG>
 __device__ inline void discrete_env_steps(const DiscreteParams& p, const void* __restrict__ actions, int row_len, int n_steps,
                                           int e, unsigned char* smem) {
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x;
   Lds<K, BITS> l = carve_lds<K, BITS>(p, smem);
   EnvRegs r;
   PhaseTimer<TIMED> tm;
@@ -1850,7 +1832,7 @@ __device__ inline void discrete_env_steps(const DiscreteParams& p, const void* _
 
   if (ACT == ACT_RESET) {
     space_reset<K, BITS>(p, l, r, lane);
-    PCT_SYNC();
+    __syncthreads();
     if (RNG & 2) draw_item_mt(p, l, r, lane);
     else draw_item(p, e, r);
     leaf_nodes<K, BITS, STAB, SCHEME, RNG>(p, e, l, r, lane, tm);
@@ -1897,13 +1879,13 @@ __device__ inline void discrete_env_steps(const DiscreteParams& p, const void* _
     }
     if (bad) r.flags |= PCT_FLAG_BAD_ACTION;  // ValueError in list.remove, D/bin3D.py:144-145
     const bool ended = transition<K, BITS, STAB, SCHEME, RNG>(p, e, l, r, lane, bad, flag, lx, ly, bx, by, bz, tm, giveup);
-    leaf_nodes<K, BITS, STAB, SCHEME, RNG, MW>(p, e, l, r, lane, tm);
+    leaf_nodes<K, BITS, STAB, SCHEME, RNG>(p, e, l, r, lane, tm);
     if (overflowed()) {
       if (lane == 0) p.retry_ids[atomicAdd(p.retry_count, 1)] = e;
       return;
     }
     write_obs<K, BITS>(p, e, l, r, lane, obs, ended || (p.full_obs != 0 && it == 0), ended ? -1 : r.n_boxes - 1);
-    PCT_SYNC();
+    __syncthreads();
     tm.tick(PH_OBS);
   }
   store_state<K, BITS>(p, e, l, r, lane);
@@ -1927,7 +1909,7 @@ pct_discrete_kernel(DiscreteParams p, const void* __restrict__ actions,
     if (blockIdx.x == 0 && threadIdx.x == 0) p.retry_count[p.retry_mode] = 0;  // retry_mode = +1 / -1: offset of the other
     for (int w = blockIdx.x; w < limit; w += gridDim.x) {
       discrete_env_steps<K, BITS, ACT, TIMED, STAB, SCHEME, RNG>(p, actions, row_len, n_steps, p.retry_ids[w], smem);
-      PCT_SYNC();
+      __syncthreads();
     }
     return;
   }
@@ -1950,7 +1932,6 @@ namespace pct {
 inline size_t discrete_lds_bytes_impl(const DiscreteParams& p) {
   size_t k = p.key_bytes;
   size_t n = (size_t)table_words_compact((uint32_t)p.cand_cap) + p.ems_cap + discrete_scratch_words(p) + p.I + p.L;
-  if (p.heavy_t > 0) n += 8 * sizeof(uint32_t) / k;  // multi-wave control words
   size_t hb = ((size_t)p.AA * (k == 4 ? 1 : 2) + 3) & ~(size_t)3;
   size_t cp = (size_t)discrete_scheme_words(p) * sizeof(uint32_t);
   if (p.shuffle && !p.rng_numpy) cp += ((size_t)(p.cand_cap * 3) / 5 + 4) * (sizeof(uint32_t) + k);

@@ -182,8 +182,8 @@ extern "C" {
 int pct_abi_version(void) { return PCT_ABI_VERSION; }
 const char* pct_last_error(void) { return g_err; }
 
-/* wave_priority thresholds (pct_device.h): compiled-in defaults per env kind, PCT_WAVE_PRIO="t1,t2,t3" overrides
- * ("0" switches the priorities off) -- a tuning knob, not part of the ABI */
+/* wave_priority thresholds (pct_device.h) on the env's live EMS count: defaults measured on C2 / C3
+ * (profiles/r02_prio_sweep.txt); PCT_WAVE_PRIO="t1,t2,t3" overrides ("0": off) -- a tuning knob, not ABI */
 static void prio_thresholds(int out[3], int d1, int d2, int d3) {
   out[0] = d1; out[1] = d2; out[2] = d3;
   const char* s = getenv("PCT_WAVE_PRIO");
@@ -361,7 +361,7 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
     h->dp.N = c.N; h->dp.row_len = c.row_len; h->dp.I = c.I; h->dp.L = c.L;
     h->dp.obs = c.obs; h->dp.reward = c.reward; h->dp.done = c.done; h->dp.counter = c.counter;
     h->dp.ratio = c.ratio; h->dp.flags = c.flags;
-    prio_thresholds(c.prio_t, 0, 0, 0);
+    prio_thresholds(c.prio_t, 24, 36, 48);
     if (h->has_retry) memcpy(h->cp_retry.prio_t, c.prio_t, sizeof c.prio_t);
     *out = h;
     return PCT_OK;
@@ -381,21 +381,6 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
   p.ems_cap = ems_cap;
   p.cand_cap = cand_cap;
   p.key_bytes = maxdim <= 31 ? 4 : 8;
-  {
-    /* multi-wave set build for the EMS-rich envs of a launch (pct_discrete_mw.hip): envs with at least this many
-     * EMS; PCT_HEAVY_EMS overrides (0: off).  Its 8 control words come out of the default EMS list (128 -> 120:
-     * the most the 10^3 probes ever held is 82, and a longer list goes to the retry pass), so that the env still
-     * takes 1/16 of a CU's LDS. */
-    const char* s = getenv("PCT_HEAVY_EMS");
-    const int ht = s ? atoi(s) : 0;
-    if (ht > 0 && p.key_bytes == 4 && p.setting == 2 && p.lnes == PCT_LNES_EMS && cand_cap >= 128 && cand_cap <= 2048) {
-      p.heavy_t = ht;
-      if (cfg->ems_capacity <= 0 && ems_cap >= 72) {
-        ems_cap -= 8;
-        p.ems_cap = ems_cap;
-      }
-    }
-  }
   /* retry pass: four times the EMS list (up to 1024) and, while it still fits the 160 KB of LDS, four times
    * the candidate table; the HBM EMS rows are as long as the longest list any pass may leave behind.  The
    * stability settings keep per-box state beyond the lists and run without it (overflow -> flag). */
@@ -458,7 +443,7 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
   p.counter = h->own_counter;
   p.ratio = h->own_ratio;
   p.flags = h->own_flags;
-  prio_thresholds(p.prio_t, 0, 0, 0);
+  prio_thresholds(p.prio_t, 16, 22, 28);
   *out = h;
   return PCT_OK;
 }

@@ -115,17 +115,6 @@ __device__ inline uint64_t lds_atomic_min(uint64_t* p, uint64_t v) {
   return (uint64_t)atomicMin(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v);
 }
 
-// One wavefront = one env: every "barrier" of the env code orders the LDS traffic of that one wave.  In a
-// 64-thread workgroup __syncthreads() compiles to exactly this (the backend drops the s_barrier); spelled out,
-// it stays wave-local inside the 256-thread multi-wave kernel too, where __syncthreads() is a real barrier
-// reserved for the cooperative sections (pct_discrete_mw.cuh).
-#define PCT_SYNC()                                            \
-  do {                                                        \
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");    \
-    __builtin_amdgcn_wave_barrier();                          \
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");    \
-  } while (0)
-
 #define PCT_PEND_SLOTS 128
 // Table accessors.  GT == false: the table is in LDS (plain accesses).  GT == true: the table
 // is a per-env slice of HBM (capacities that do not fit in LDS): every access goes to L2
@@ -234,7 +223,7 @@ __device__ inline void pyset_match(K* tab, uint32_t mask, bool part, uint64_t ha
           w.next(mask);  // a different key, or an earlier lane's tentative hold
         }
       }
-      PCT_SYNC();
+      __syncthreads();
       if (placed && tab_ld<GT, K>(&tab[slot]) != mytag) {  // evicted by an earlier lane: walk on
         placed = false;
         walking = true;
@@ -267,7 +256,7 @@ __device__ inline void pyset_match(K* tab, uint32_t mask, bool part, uint64_t ha
         walking = walking && !won && !member;
         if (tried) walk_advance(i, j, perturb, mask);
       }
-      PCT_SYNC();
+      __syncthreads();
       if (placed && tab[slot] != mytag) {  // evicted by an earlier lane: walk on from the next slot
         placed = false;
         walking = true;
@@ -293,9 +282,9 @@ __device__ inline bool batch_find_duplicates(uint32_t* dd, bool active, uint64_t
     if (!__ballot(unresolved)) return dup;
     const uint32_t b = (uint32_t)(hash >> (3 + 7 * round)) & (uint32_t)(NB - 1);
     if (unresolved) atomicMin(&dd[b], (uint32_t)lane);
-    PCT_SYNC();
+    __syncthreads();
     const uint32_t w = unresolved ? dd[b] : (uint32_t)lane;
-    PCT_SYNC();
+    __syncthreads();
     if (unresolved) {
       dd[b] = 0xFFFFFFFFu;
       if (w == (uint32_t)lane) {
@@ -305,7 +294,7 @@ __device__ inline bool batch_find_duplicates(uint32_t* dd, bool active, uint64_t
         unresolved = false;
       }
     }
-    PCT_SYNC();
+    __syncthreads();
   }
   // eight rounds of pure collisions between distinct keys: fall back to the exhaustive scan
   for (int i = 0; i < cnt; i++)
@@ -323,9 +312,9 @@ __device__ inline bool batch_find_duplicates_shfl(uint32_t* dd, bool active, uin
     if (!__ballot(unresolved)) return dup;
     const uint32_t b = (uint32_t)(hash >> (3 + 7 * round)) & (uint32_t)(NB - 1);
     if (unresolved) atomicMin(&dd[b], (uint32_t)lane);
-    PCT_SYNC();
+    __syncthreads();
     const uint32_t w = unresolved ? dd[b] : (uint32_t)lane;
-    PCT_SYNC();
+    __syncthreads();
     const uint32_t hlo = (uint32_t)__shfl((int)(uint32_t)hash, (int)(w & 63u), 64);
     const uint32_t hhi = (uint32_t)__shfl((int)(uint32_t)(hash >> 32), (int)(w & 63u), 64);
     const uint32_t pw = (uint32_t)__shfl((int)payload, (int)(w & 63u), 64);
@@ -338,7 +327,7 @@ __device__ inline bool batch_find_duplicates_shfl(uint32_t* dd, bool active, uin
         unresolved = false;
       }
     }
-    PCT_SYNC();
+    __syncthreads();
   }
   // eight rounds of pure collisions between distinct keys: exhaustive scan over the earlier lanes
   const uint64_t am = __ballot(active);
@@ -373,16 +362,16 @@ __device__ inline bool batch_find_duplicates_reg(uint32_t* dd, bool active, K ke
     if (!__ballot(unresolved)) return dup;
     const uint32_t b = (uint32_t)(hash >> (3 + 6 * round)) & (uint32_t)(NB - 1);
     if (unresolved) atomicMin(&dd[b], (uint32_t)lane);
-    PCT_SYNC();
+    __syncthreads();
     const uint32_t w = unresolved ? dd[b] : (uint32_t)lane;
-    PCT_SYNC();
+    __syncthreads();
     const K kw = shfl_key<K>(key, (int)(w & 63u));
     if (unresolved) {
       dd[b] = 0xFFFFFFFFu;
       if (w == (uint32_t)lane) unresolved = false;
       else if (kw == key) { dup = true; unresolved = false; }
     }
-    PCT_SYNC();
+    __syncthreads();
   }
   // nine rounds of pure collisions between distinct keys: exhaustive scan
   for (int i = 0; i < 64; i++) {
@@ -490,7 +479,7 @@ __device__ inline void pyset_match_v(K* tab, uint32_t mask, const bool (&part)[V
         walking[v] = walking[v] && !won && !member;
       }
     }
-    PCT_SYNC();
+    __syncthreads();
 #pragma unroll
     for (int v = 0; v < V; v++) {
       if (placed[v] && tab[slot[v]] != PCT_MYTAG(v)) {  // evicted by an earlier position: walk on
@@ -530,10 +519,10 @@ __device__ inline void batch_find_duplicates_v(uint32_t* dd, const bool (&active
       b[v] = (uint32_t)(hash[v] >> (3 + 7 * round)) & (uint32_t)(NB - 1);
       if (unresolved[v]) atomicMin(&dd[b[v]], (uint32_t)(v * 64 + lane));
     }
-    PCT_SYNC();
+    __syncthreads();
 #pragma unroll
     for (int v = 0; v < V; v++) w[v] = unresolved[v] ? dd[b[v]] : (uint32_t)(v * 64 + lane);
-    PCT_SYNC();
+    __syncthreads();
 #pragma unroll
     for (int v = 0; v < V; v++) {
       K kw = shfl_key<K>(key[0], (int)(w[v] & 63u));
@@ -548,7 +537,7 @@ __device__ inline void batch_find_duplicates_v(uint32_t* dd, const bool (&active
         else if (kw == key[v]) { dup[v] = true; unresolved[v] = false; }
       }
     }
-    PCT_SYNC();
+    __syncthreads();
   }
   // eight rounds of pure collisions between distinct keys: exhaustive scan over the earlier positions
 #pragma unroll
