@@ -667,6 +667,7 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
     }
     uint64_t pm = __ballot(pv);
     const int nt = 4 * __popcll(pm);
+    tm.add(ST_GENERATED, (uint64_t)nt);
     if (pv) l.vp[rank_below(pm)] = (uint16_t)q;
     __syncthreads();
     for (int tb = 0; tb < nt && !cand_overflow; tb += 64) {
@@ -708,6 +709,8 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
     norder += __popcll(m);
   }
   __syncthreads();
+  tm.add(ST_EMS, (uint64_t)E);
+  tm.add(ST_DISTINCT, (uint64_t)fill);
   tm.sub_tick(PH_SET_GEN);
   tm.tick(PH_SET);
 
