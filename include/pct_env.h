@@ -262,8 +262,9 @@ int pct_step_heuristic(pct_env* env, int32_t kind, int32_t n_steps, void* stream
 int pct_policy_hash_rows(pct_env* env, float* rows_out, void* stream);
 
 /* ---- kernel timing ------------------------------------------------------------------- */
-/* When enabled, every transition launch (reset / step_*) is bracketed by a pair of
- * hipEvents recorded on the launch stream.  pct_profile_read synchronises on the recorded
+/* When enabled, the transition kernel of every launch (reset / step_*) is bracketed by a pair of
+ * hipEvents recorded on the launch stream -- the step kernel itself, not the small large-capacity retry
+ * pass that may follow it.  pct_profile_read synchronises on the recorded
  * events, returns the number of launches and their summed duration since the last read,
  * and clears the accumulator. */
 int pct_profile_enable(pct_env* env, int32_t on);

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pkg = importlib.import_module("online-3d-bpp-pct_amd")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-for ems, cand in ((0, 0), (384, 32768), (768, 8192), (384, 8192), (384, 2048)):
+for ems, cand in ((0, 0), (448, 32768), (512, 32768), (640, 32768), (320, 32768)):
     env = pkg.PctVecEnv(N, continuous=True, container_size=(100, 100, 100), internal_node_holder=200, leaf_node_holder=200,
                         sample_left_bound=5.0, sample_right_bound=25.0, seed=4, device="cuda:0", monitor=False, strict=False,
                         ems_capacity=ems, candidate_capacity=cand)
