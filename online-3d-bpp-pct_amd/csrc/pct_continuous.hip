@@ -1129,7 +1129,9 @@ enum { CACT_ROWS = 0, CACT_INDEX = 1, CACT_HASH = 2, CACT_RESET = 3 };
 
 template <int ACT, bool TIMED, bool GT, bool STAB, bool MT>
 #ifndef PCT_CONT_WAVES
-#define PCT_CONT_WAVES 3 /* waves per SIMD the plain kernel is compiled for: 168 VGPRs with 68 spilled to scratch measures slightly faster (C3 250 vs 254 us at 4096 envs, 356 vs 379 us at 8192) than 256 VGPRs at 2 waves */
+#define PCT_CONT_WAVES 2 /* waves per SIMD the plain kernel is compiled for.  3 (168 VGPRs, 68 of them spilled to scratch) is
+                            as fast at 4096 envs (211.1 vs 211.7 us, C3) and 4.5 % faster at 8192, but its spill traffic makes
+                            162 MB of HBM traffic per launch out of 19.5 MB of algorithmic bytes; 2 (no spills): 37 MB */
 #endif
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((STAB || TIMED) ? 1 : PCT_CONT_WAVES)))
 pct_continuous_kernel(ContinuousParams p, const void* __restrict__ actions,

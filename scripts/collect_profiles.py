@@ -31,7 +31,7 @@ if os.path.exists(db):
                             "min(duration), max(duration), max(lds_size), max(scratch_size), max(vgpr_count), max(sgpr_count), "
                             "max(grid_x), max(workgroup_x) from kernels group by name, grid_x order by sum(duration) desc"))
     tot = sum(r[2] for r in rows)
-    lines = ["# rocprofv3 --kernel-trace --stats summary (%s, workload %s): python bench.py --workload %s --steps 2000 --warmup 200" % (tag, wl, wl),
+    lines = ["# rocprofv3 --kernel-trace --stats summary (%s, workload %s): python bench.py --workload %s --steps %d --warmup 200" % (tag, wl, wl, tsteps),
              "%-100s %8s %12s %10s %10s %10s %6s %7s %5s %5s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "pct", "lds_B", "vgpr", "sgpr")]
     for r in rows[:8]:
         nm = r[0] if len(r[0]) <= 100 else r[0][:84] + ".." + r[0][-14:]
