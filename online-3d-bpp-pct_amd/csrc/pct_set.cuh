@@ -243,18 +243,22 @@ __device__ inline void pyset_match(K* tab, uint32_t mask, bool part, uint64_t ha
       if (stats) stats[1]++;
       while (__ballot(walking)) {
         const uint32_t cur = i + (uint32_t)j;
-        K old = 0;
-        if (walking) {
-          old = lds_atomic_min(&tab[cur], mytag);
-          my_probes++;
-        }
-        const bool won = walking && old > mytag;  // was empty, or tentatively held by a later lane
+        // every lane issues the atomic: one that is not walking proposes the all-ones word (EMPTY), which changes
+        // no slot, and stays where it is -- no exec-mask juggling around the LDS operation
+        const K old = lds_atomic_min(&tab[cur], walking ? mytag : SlotWord<K>::EMPTY);
+        my_probes++;
+        const bool won = walking & (old > mytag);  // was empty, or tentatively held by a later lane
         const bool member = walking && check_found && !(old & TAG) && same(old);
         slot = won ? cur : slot;
-        placed = placed || won;
-        const bool tried = walking;
-        walking = walking && !won && !member;
-        if (tried) walk_advance(i, j, perturb, mask);
+        placed = placed | won;
+        uint32_t ni = i;
+        int nj = j;
+        uint64_t np = perturb;
+        walk_advance(ni, nj, np, mask);
+        i = walking ? ni : i;
+        j = walking ? nj : j;
+        perturb = walking ? np : perturb;
+        walking = walking & !won & !member;
       }
       __syncthreads();
       if (placed && tab[slot] != mytag) {  // evicted by an earlier lane: walk on from the next slot
@@ -464,19 +468,28 @@ __device__ inline void pyset_match_v(K* tab, uint32_t mask, const bool (&part)[V
       uint32_t cur[V];
 #pragma unroll
       for (int v = 0; v < V; v++) {  // V atomics in flight: a real key or an earlier position's tag is
-        cur[v] = i[v] + (uint32_t)j[v];  // numerically smaller and stays, so the atomic doubles as the read
-        old[v] = 0;
-        if (walking[v]) old[v] = lds_atomic_min(&tab[cur[v]], PCT_MYTAG(v));
+        cur[v] = i[v] + (uint32_t)j[v];  // numerically smaller and stays, so the atomic doubles as the read.
+        // Straight-line body: EVERY lane issues the atomic -- one that is not walking proposes the all-ones word
+        // (EMPTY), which changes no slot -- so the step needs no exec-mask juggling around the LDS operation
+        old[v] = lds_atomic_min(&tab[cur[v]], walking[v] ? PCT_MYTAG(v) : SlotWord<K>::EMPTY);
       }
       my_probes++;
 #pragma unroll
       for (int v = 0; v < V; v++) {
-        const bool won = walking[v] && old[v] > PCT_MYTAG(v);  // was empty, or tentatively held by a later position
-        const bool member = CHECK && walking[v] && !(old[v] & TAG) && old[v] == key[v];
+        const bool won = walking[v] & (old[v] > PCT_MYTAG(v));  // was empty, or tentatively held by a later position
+        const bool member = CHECK && (walking[v] & !(old[v] & TAG) & (old[v] == key[v]));
         slot[v] = won ? cur[v] : slot[v];
-        placed[v] = placed[v] || won;
-        if (walking[v]) walk_advance(i[v], j[v], perturb[v], mask);  // past the slot just tried: an evicted key resumes here
-        walking[v] = walking[v] && !won && !member;
+        placed[v] = placed[v] | won;
+        // past the slot just tried: an evicted key resumes here.  A lane that has stopped walking is not moved (its
+        // position must stay inside the table for the no-op proposals above; its placed slot is kept in slot[v])
+        uint32_t ni = i[v];
+        int nj = j[v];
+        uint64_t np = perturb[v];
+        walk_advance(ni, nj, np, mask);
+        i[v] = walking[v] ? ni : i[v];
+        j[v] = walking[v] ? nj : j[v];
+        perturb[v] = walking[v] ? np : perturb[v];
+        walking[v] = walking[v] & !won & !member;
       }
     }
     __syncthreads();
