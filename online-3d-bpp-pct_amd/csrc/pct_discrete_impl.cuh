@@ -560,11 +560,31 @@ __device__ inline void set_insert(SetState<K>& st, const K (&key)[V], const bool
           oldk[c] = (s2 < st.size) ? tabs[st.toff + s2] : EMPTY;
         }
         __syncthreads();
+        uint32_t nchunks = (st.size + 63u) / 64u;
+        if (st.size == 512u) {
+          // 512 -> 2048: the 307 keys sit in 8 sparse chunks of 64 slots; squeezed (slot order kept) they are 5 dense
+          // chunks = 5 matching passes instead of 8.  The dense list goes through the old table's own words.
+          uint32_t base = 0;
+#pragma unroll
+          for (int c = 0; c < 8; c++) {
+            const uint64_t m = __ballot(oldk[c] != EMPTY);
+            if (oldk[c] != EMPTY) tabs[noff + base + (uint32_t)rank_below(m)] = oldk[c];
+            base += (uint32_t)__popcll(m);
+          }
+          __syncthreads();
+#pragma unroll
+          for (int c = 0; c < 8; c++) {
+            const uint32_t q = (uint32_t)c * 64u + lane;
+            oldk[c] = q < base ? tabs[noff + q] : EMPTY;
+          }
+          nchunks = (base + 63u) / 64u;
+          __syncthreads();
+        }
         for (uint32_t s2 = lane; s2 < newsize; s2 += 64) tabs[noff + s2] = EMPTY;
         __syncthreads();
 #pragma unroll
         for (int c0 = 0; c0 < 8; c0 += RV) {
-          if ((uint32_t)c0 * 64u < st.size) {
+          if ((uint32_t)c0 < nchunks) {
             bool opart[RV];
             uint64_t ohash[RV];
             uint32_t oslot[RV];
