@@ -592,15 +592,44 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
           break;
         }
         const uint32_t noff = region(newsize);
-        auto reinsert = [&](uint32_t ow) {  // one chunk of old slots into the new table, in old-slot order
+        // Old slots arrive sparse (at most 3/5 of a table are occupied): they are queued, in slot order, in the (idle)
+        // de-duplication words and go into the new table 64 at a time -- 60 % of the matching passes of a
+        // chunk-by-chunk re-insertion, each of which recomputes and re-hashes its tuples.
+        int nq = 0;
+        auto reinsert = [&](uint32_t ow, uint32_t off) {  // up to 64 old entries into the new table at `off`
           bool opart = ow != EMPTY;
           double o[6];
           cand_tuple(p, l, r, orient, opart ? (ow & 0xFFFFu) : 0u, o);
           bool oplaced;
           uint32_t oslot;
-          pyset_match<uint32_t, GT>(tabs + noff, newsize - 1, opart, tuplehash6d(o), lane, false, oplaced, oslot,
+          pyset_match<uint32_t, GT>(tabs + off, newsize - 1, opart, tuplehash6d(o), lane, false, oplaced, oslot,
                                     [&](uint32_t) { return false; });
-          if (oplaced) tab_st<GT, uint32_t>(&tabs[noff + oslot], ow);
+          if (oplaced) tab_st<GT, uint32_t>(&tabs[off + oslot], ow);
+          __syncthreads();
+        };
+        auto push = [&](uint32_t ow, uint32_t off) {  // one chunk of old slots
+          const uint64_t m = __ballot(ow != EMPTY);
+          if (ow != EMPTY) l.dd[nq + rank_below(m)] = ow;
+          nq += __popcll(m);
+          __syncthreads();
+          if (nq >= 64) {
+            const uint32_t w = l.dd[lane];
+            const uint32_t mv = l.dd[lane + 64];
+            __syncthreads();
+            l.dd[lane] = mv;
+            nq -= 64;
+            __syncthreads();
+            reinsert(w, off);
+          }
+        };
+        auto drain = [&](uint32_t off) {
+          if (nq > 0) {
+            const uint32_t w = lane < nq ? l.dd[lane] : EMPTY;
+            __syncthreads();
+            reinsert(w, off);
+          }
+          l.dd[lane] = 0xFFFFFFFFu;  // back to the all-ones state the de-duplication expects
+          l.dd[lane + 64] = 0xFFFFFFFFu;
           __syncthreads();
         };
         if (!GT && size <= 512) {
@@ -612,29 +641,39 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
             oldw[c] = (s2 < size) ? tabs[toff + s2] : EMPTY;
           }
           __syncthreads();
+          uint32_t nchunks = (size + 63u) / 64u;
+          if (size == 512u) {
+            // 512 -> 2048: squeeze the 8 sparse chunks into 5 dense ones (slot order kept), through the old table's
+            // own words, as the discrete kernel does
+            uint32_t base = 0;
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+              const uint64_t m = __ballot(oldw[c] != EMPTY);
+              if (oldw[c] != EMPTY) tabs[noff + base + (uint32_t)rank_below(m)] = oldw[c];
+              base += (uint32_t)__popcll(m);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+              const uint32_t q2 = (uint32_t)c * 64u + lane;
+              oldw[c] = q2 < base ? tabs[noff + q2] : EMPTY;
+            }
+            nchunks = (base + 63u) / 64u;
+            __syncthreads();
+          }
           for (uint32_t s2 = lane; s2 < newsize; s2 += 64) tabs[noff + s2] = EMPTY;
           __syncthreads();
 #pragma unroll
           for (int c = 0; c < 8; c++)
-            if ((uint32_t)c * 64u < size) reinsert(oldw[c]);
+            if ((uint32_t)c < nchunks) reinsert(oldw[c], noff);
         } else if (!GT) {
           // an LDS table of 2048 slots growing to 8192: the new table sits behind the old one's region
           // (cand_cap 8192: table words = 8192 + 2048), the only case of two LDS regions
           const uint32_t noff2 = size;  // old table at [0, size), new at [size, size + newsize)
           for (uint32_t s2 = lane; s2 < newsize; s2 += 64) tabs[noff2 + s2] = EMPTY;
           __syncthreads();
-          for (uint32_t sb = 0; sb < size; sb += 64) {
-            const uint32_t ow = tabs[toff + sb + lane];
-            bool opart = ow != EMPTY;
-            double o[6];
-            cand_tuple(p, l, r, orient, opart ? (ow & 0xFFFFu) : 0u, o);
-            bool oplaced;
-            uint32_t oslot;
-            pyset_match<uint32_t, GT>(tabs + noff2, newsize - 1, opart, tuplehash6d(o), lane, false, oplaced, oslot,
-                                      [&](uint32_t) { return false; });
-            if (oplaced) tabs[noff2 + oslot] = ow;
-            __syncthreads();
-          }
+          for (uint32_t sb = 0; sb < size; sb += 64) push(tabs[toff + sb + lane], noff2);
+          drain(noff2);
           toff = noff2;
           size = newsize;
           tm.sub_tick(PH_SET_REBUILD);
@@ -644,8 +683,9 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
           __syncthreads();
           for (uint32_t sb = 0; sb < size; sb += 64) {
             uint32_t s2 = sb + lane;
-            reinsert((s2 < size) ? tab_ld<GT, uint32_t>(&tabs[toff + s2]) : EMPTY);
+            push((s2 < size) ? tab_ld<GT, uint32_t>(&tabs[toff + s2]) : EMPTY, noff);
           }
+          drain(noff);
         }
         toff = noff;
         size = newsize;
