@@ -1974,7 +1974,8 @@ inline hipError_t launch_typed(const DiscreteParams& p, int act, const void* act
 #define PCT_LAUNCH(A)                                                                                        \
   do {                                                                                                       \
     void (*kern)(DiscreteParams, const void*, int, int, const int32_t*, int);                                \
-    if (stab) kern = scheme == 1 ? PCT_KERN(A, false, true, 1) : PCT_KERN(A, false, true, 0);                \
+    if (stab) kern = scheme == 1 ? PCT_KERN(A, false, true, 1)                                               \
+                                 : (timed ? PCT_KERN(A, true, true, 0) : PCT_KERN(A, false, true, 0));       \
     else if (scheme == 1) kern = PCT_KERN(A, false, false, 1);                                               \
     else kern = timed ? PCT_KERN(A, true, false, 0) : PCT_KERN(A, false, false, 0);                          \
     if (lds > 48 * 1024) {                                                                                   \

@@ -215,6 +215,105 @@ PCT_SD double stab_around6(double x) { return rint(x * 1e6) / 1e6; }
 // acc = fma(x1, y1, acc) -- see oracle/pct_oracle_stab.c dot2 (v_fma_f64 on the GPU: the same IEEE operation)
 PCT_SD double stab_dot2(double x0, double x1, double y0, double y1) { return fma(x1, y1, x0 * y0); }
 
+// The same solve with every extent a compile-time constant (N supporters, M = N(N-1)/2 + 1 rows) and every loop over
+// rows, columns and column pairs unrolled: U and V are then registers, not dynamically indexed private arrays in
+// scratch memory (where one rotation costs dozens of dependent HBM-latency round trips: a lane in the generic solve
+// held its whole wave, and with it the launch, for milliseconds).  Operation for operation the generic routine.
+template <int N>
+PCT_SD void stab_lstsq_fixed(const double (&A)[(N * (N - 1) / 2 + 1) * N], double (&x)[N]) {
+  constexpr int M = N * (N - 1) / 2 + 1;
+  double U[M * N], V[N * N];
+#pragma unroll
+  for (int i = 0; i < M * N; i++) U[i] = A[i];
+#pragma unroll
+  for (int i = 0; i < N; i++)
+#pragma unroll
+    for (int j = 0; j < N; j++) V[i * N + j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 60; sweep++) {
+    bool rotated = false;
+#pragma unroll
+    for (int p = 0; p < N; p++)
+#pragma unroll
+      for (int q = p + 1; q < N; q++) {
+        double alpha = 0, beta = 0, gamma = 0;
+#pragma unroll
+        for (int r = 0; r < M; r++) {
+          alpha += U[r * N + p] * U[r * N + p];
+          beta += U[r * N + q] * U[r * N + q];
+          gamma += U[r * N + p] * U[r * N + q];
+        }
+        if (gamma == 0 || fabs(gamma) <= 2.220446049250313e-16 * sqrt(alpha * beta)) continue;
+        rotated = true;
+        double zeta = (beta - alpha) / (2 * gamma);
+        double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1 + zeta * zeta));
+        double c = 1 / sqrt(1 + t * t), sn = c * t;
+#pragma unroll
+        for (int r = 0; r < M; r++) {
+          double up = U[r * N + p], uq = U[r * N + q];
+          U[r * N + p] = c * up - sn * uq;
+          U[r * N + q] = sn * up + c * uq;
+        }
+#pragma unroll
+        for (int r = 0; r < N; r++) {
+          double vp = V[r * N + p], vq = V[r * N + q];
+          V[r * N + p] = c * vp - sn * vq;
+          V[r * N + q] = sn * vp + c * vq;
+        }
+      }
+    if (!rotated) break;
+  }
+  double s2[N], smax2 = 0;
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    double a2 = 0;
+#pragma unroll
+    for (int r = 0; r < M; r++) a2 += U[r * N + j] * U[r * N + j];
+    s2[j] = a2;
+    if (a2 > smax2) smax2 = a2;
+  }
+  const double rc = 2.220446049250313e-16 * (M > N ? M : N);
+#pragma unroll
+  for (int i = 0; i < N; i++) x[i] = 0;
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    if (s2[j] <= 0 || sqrt(s2[j]) <= rc * sqrt(smax2)) continue;
+    double proj = 0;
+#pragma unroll
+    for (int r = 0; r < M; r++) proj += U[r * N + j] * (r == M - 1 ? 1.0 : 0.0);  // rhs = e_{M-1}
+    proj /= s2[j];
+#pragma unroll
+    for (int i = 0; i < N; i++) x[i] += V[i * N + j] * proj;
+  }
+}
+// the >= 3 supporter system of stab_shares for N supporters with contact centres c2 (D/space.py:118-150): one row
+// per supporter pair, a closing row of ones; solved into the shares xr
+template <int N>
+PCT_SD void stab_split_fixed(const double (*c2)[2], const double stk[4], double (&xr)[N]) {
+  constexpr int M = N * (N - 1) / 2 + 1;
+  double A[M * N];
+#pragma unroll
+  for (int i = 0; i < M * N; i++) A[i] = 0;
+  int row = 0;
+#pragma unroll
+  for (int i = 0; i < N - 1; i++)
+#pragma unroll
+    for (int j = i + 1; j < N; j++) {
+      const double ei0 = c2[i][0], ei1 = c2[i][1], ej0 = c2[j][0], ej1 = c2[j][1];
+      double t0 = ei0 - ej0, t1 = ei1 - ej1;
+      double mol = stab_dot2(stk[0] - ei0, stk[1] - ei1, t0, t1);
+      if (mol != 0) {
+        double rr = fabs(stab_dot2(stk[0] - ej0, stk[1] - ej1, t0, t1)) / mol;
+        A[row * N + i] = 1;
+        A[row * N + j] = -rr;
+      }
+      row++;
+    }
+#pragma unroll
+  for (int j = 0; j < N; j++) A[(M - 1) * N + j] = 1;
+  stab_lstsq_fixed<N>(A, xr);
+}
+
+
 // contact rectangle of box `b` with placed box geometry `t`, or false if `t` does not support it.
 // Discrete (D/space.py:358-376): same top, non-degenerate overlap.  Continuous
 // (C/space.py:305-314,351-357): overlap decided on the np.around(.,6) of the negated-min
@@ -317,6 +416,16 @@ PCT_SD bool stab_shares(const StabBox& b, const double stk[4], const double own_
     return true;
   }
   if (k > STAB_LSQ) return false;
+  if (k <= 5) {  // 99.99 % of the solves (k = 3: 94 %, 4: 6 %, 5: 0.1 %): register-resident
+    double x5[5] = {0, 0, 0, 0, 0};
+    if (k == 3) { double x3[3]; stab_split_fixed<3>(b.c2, stk, x3); x5[0] = x3[0]; x5[1] = x3[1]; x5[2] = x3[2]; }
+    else if (k == 4) { double x4[4]; stab_split_fixed<4>(b.c2, stk, x4); x5[0] = x4[0]; x5[1] = x4[1]; x5[2] = x4[2]; x5[3] = x4[3]; }
+    else stab_split_fixed<5>(b.c2, stk, x5);
+    for (int i = 0; i < k; i++) {
+      out[i][0] = b.c2[i][0]; out[i][1] = b.c2[i][1]; out[i][2] = stk[2]; out[i][3] = stk[3] * x5[i];
+    }
+    return true;
+  }
   const int M = k * (k - 1) / 2 + 1;
   double A[(STAB_LSQ * (STAB_LSQ - 1) / 2 + 1) * STAB_LSQ], rhs[STAB_LSQ * (STAB_LSQ - 1) / 2 + 1], xr[STAB_LSQ];
   for (int i = 0; i < M * k; i++) A[i] = 0;

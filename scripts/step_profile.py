@@ -1,7 +1,7 @@
 """GPU: per-STEP cycle distribution of the transition kernel (timed build, read back after every launch):
 how the slowest env of a launch -- which sets the launch time -- differs from the mean, and how the cycles
 scale with the EMS count, the generated tuples and the distinct candidates.
-python scripts/step_profile.py [envs] [steps] [c2|c3|c5]"""
+python scripts/step_profile.py [envs] [steps] [c2|c3|c5|c1]"""
 import importlib, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,6 +15,8 @@ if MODE == "c5":
     env = pkg.PctVecEnv(N, continuous=True, container_size=(100, 100, 100), internal_node_holder=200, leaf_node_holder=200,
                         sample_left_bound=5.0, sample_right_bound=25.0, seed=4, device="cuda:0", monitor=False,
                         ems_capacity=384, candidate_capacity=8192)
+elif MODE == "c1":
+    env = pkg.PctVecEnv(N, setting=1, item_set=items, seed=4, device="cuda:0", monitor=False)
 elif MODE == "c3":
     env = pkg.PctVecEnv(N, continuous=True, sample_left_bound=1.0, sample_right_bound=5.0, seed=4, device="cuda:0", monitor=False)
 else:
