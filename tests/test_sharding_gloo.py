@@ -42,11 +42,23 @@ def _step(env, variant):
         env.step_hash_policy(1)
 
 
+def _seed(env, variant):
+    if variant.startswith("numpy"):
+        env.set_numpy_rng(1234)
+    else:
+        env.set_sampler(1234)
+
+
 def _make(n, base, variant):
     from oracle.oracle_lib import OracleVecEnv
     from tests.common import item_set_range
     if variant == "plain":
         return OracleVecEnv(n, item_set=item_set_range(1, 5), env_id_base=base)
+    if variant == "numpy_discrete":  # strict mode: env g consumes np.random.seed(seed + g)'s stream wherever it lives
+        return OracleVecEnv(n, setting=3, item_set=item_set_range(1, 5), env_id_base=base, shuffle=True)
+    if variant == "numpy_continuous":
+        return OracleVecEnv(n, setting=1, container_size=(1, 1, 1), env_kind=1, sample_bounds=(0.1, 0.5), env_id_base=base,
+                            shuffle=True)
     # setting 3 densities (pct_density), shuffled candidates (pct_shuffle_priority), sampled items
     # (pct_pick): every counter-keyed stream takes the GLOBAL env id
     return OracleVecEnv(n, setting=3, item_set=item_set_range(1, 5), env_id_base=base, shuffle=True, shuffle_seed=77)
@@ -59,7 +71,7 @@ def _worker(rank, world, port, total, steps, out_dir, variant="plain"):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     base, n = sharding.shard_envs(total, rank, world)
     env = _make(n, base, variant)
-    env.set_sampler(1234)
+    _seed(env, variant)
     env.reset()
     for _ in range(steps):
         _step(env, variant)
@@ -87,14 +99,15 @@ def test_two_rank_shards_equal_one_batch(tmp_path):
     assert np.array_equal(np.load(tmp_path / "rew.npy"), env.reward)
 
 
-@pytest.mark.parametrize("variant", ["setting3_shuffle", "heuristic"])
+@pytest.mark.parametrize("variant", ["setting3_shuffle", "heuristic", "numpy_discrete", "numpy_continuous"])
 def test_two_rank_shards_equal_one_batch_counter_keyed_streams(tmp_path, variant):
     """densities, shuffle priorities, item picks and the RANDOM heuristic's draw are all keyed by the
-    global env id: two shards reproduce the single batch"""
+    global env id -- and so are the strict mode's MT19937 seeds (seed + global id, as envs.py:49 seeds worker `rank`):
+    two shards reproduce the single batch"""
     total, steps, world = 11, 30, 2  # 5 + 6: unequal shards go through the padded gather
     mp.spawn(_worker, args=(world, _free_port(), total, steps, str(tmp_path), variant), nprocs=world, join=True)
     env = _make(total, 0, variant)
-    env.set_sampler(1234)
+    _seed(env, variant)
     env.reset()
     for _ in range(steps):
         _step(env, variant)
