@@ -763,6 +763,10 @@ int pct_step_heuristic(pct_env* h, int32_t kind, int32_t n_steps, void* stream) 
     return fail(PCT_ERR_UNSUPPORTED, "RANDOM: the feasibility masks do not fit the table scratch (raise candidate_capacity)");
   if (h->continuous || h->cfg.lnes != PCT_LNES_EMS)
     return fail(PCT_ERR_UNSUPPORTED, "the heuristics read the discrete env's heightmap and EMS list (LNES = EMS)");
+  /* strict NumPy-stream mode has no heuristic kernels: the ACT_HEUR templates draw from the counter-keyed sources and
+   * the LDS layout of that mode carries the MT19937 state where their shuffle arrays would lie (include/pct_env.h) */
+  if (h->dp.rng_numpy)
+    return fail(PCT_ERR_UNSUPPORTED, "the heuristic policies are not available in strict NumPy-stream mode (pct_set_numpy_rng)");
   /* one launch per step when the stability state is live (see pct_step_hash_policy) */
   const int per = h->cfg.setting != 2 ? 1 : n_steps;
   for (int done = 0; done < n_steps; done += per) {

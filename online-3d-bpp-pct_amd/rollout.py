@@ -6,8 +6,8 @@ The reference collects n-step rollouts through the host: `selected_leaf_node.cpu
 env takes the leaf INDEX the policy sampled and the transition kernel itself writes step t's new observation
 into `obs[t + 1]`, its reward into `rewards[t]` and 1 - done into `masks[t + 1]` (PctVecEnv.step_into ->
 pct_bind_rollout_slot + pct_step_index): one launch per step, no copy kernels, nothing leaves the GPU.  What
-the policy produces (action index, log-probability) is the caller's to keep; `RolloutSlots.record` stores
-them.  The tensor names and shapes are the trainer's contract (storage.py:5-11); the update rules
+the policy produces (action index, log-probability) is the caller's to keep; `RolloutSlots.step_env` records
+them beside the slot.  The tensor names and shapes are the trainer's contract (storage.py:5-11); the update rules
 `after_update` / `compute_returns` are storage.py:41-50, restated.
 """
 import torch
@@ -51,6 +51,17 @@ class RolloutSlots(object):
         self.step = (t + 1) % self.num_steps
         return self.obs[t + 1]
 
+    def insert(self, obs, actions, action_log_probs, rewards, masks):
+        """storage.py:33-39, for callers that step the env themselves (round-1 DeviceRollout pattern): five device
+        copies instead of the fused write of step_env."""
+        t = self.step
+        self.obs[t + 1].copy_(obs.view_as(self.obs[t + 1]))
+        self.actions[t].copy_(actions.view_as(self.actions[t]))
+        self.action_log_probs[t].copy_(action_log_probs.view_as(self.action_log_probs[t]))
+        self.rewards[t].copy_(rewards.view_as(self.rewards[t]))
+        self.masks[t + 1].copy_(masks.view_as(self.masks[t + 1]))
+        self.step = (t + 1) % self.num_steps
+
     def after_update(self):  # storage.py:41-43
         self.obs[0].copy_(self.obs[-1])
         self.masks[0].copy_(self.masks[-1])
@@ -76,11 +87,17 @@ DeviceRollout = RolloutSlots  # round-1 name
 def collect(envs, policy, rollout):
     """train_tools.py:63-70 without host round trips and without copy kernels: per step the policy and ONE
     transition launch.  `policy(all_nodes [N,I+L+1,9]) -> (log_prob [N,1], leaf_index int64 [N,1])`; `envs` is a
-    PctVecEnv whose current observation is the rollout's slot 0 (`rollout.begin(envs)` if it is not yet).
+    PctVecEnv; if its current observation is not the rollout's current slot yet, the slot is seeded from it.
     Returns the last observation view."""
-    all_nodes = rollout.obs[rollout.step]
+    cur = envs.current_obs()
+    slot = rollout.obs[rollout.step]
+    if cur.data_ptr() != slot.data_ptr():
+        # the env's current observation is not this slot yet (first collection, or the env was stepped / reset outside
+        # the rollout): seed the slot from it, as storage.py:41-43 / main.py's obs[0].copy_ do
+        slot.copy_(cur.view_as(slot))
+    all_nodes = slot
     for _ in range(rollout.num_steps):
         with torch.no_grad():
-            log_prob, idx = policy(all_nodes)
+            log_prob, idx = policy(all_nodes.view(all_nodes.shape[0], -1, 9))  # tools.py:70-73 unify_obs
         all_nodes = rollout.step_env(envs, idx, log_prob)
     return all_nodes

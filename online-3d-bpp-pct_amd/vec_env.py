@@ -230,9 +230,9 @@ class PctVecEnv(VecEnv):
         self._counter = torch.zeros(self.N, dtype=torch.int32, device=dev)
         self._ratio = torch.zeros(self.N, dtype=torch.float64, device=dev)
         self._flags = torch.zeros(self.N, dtype=torch.int32, device=dev)
-        _lib.check(self._L.pct_bind_outputs(self._h, self._obs.data_ptr(), self._reward.data_ptr(),
-                                            self._done.data_ptr(), self._counter.data_ptr(), self._ratio.data_ptr(),
-                                            self._flags.data_ptr()))
+        self._own = (self._obs, self._reward)
+        self._slot_keepalive = None
+        self._bind_own_views()
         # pinned host mirrors for the small per-step outputs
         self._h_reward = torch.zeros(self.N, dtype=torch.float32).pin_memory()
         self._h_done = torch.zeros(self.N, dtype=torch.uint8).pin_memory()
@@ -352,6 +352,8 @@ class PctVecEnv(VecEnv):
     def step_heuristic(self, name, n_steps=1):
         """n_steps transitions with a heuristic baseline of heuristic.py as the in-env policy
         (`name` in HEURISTICS: LSAH, HM, OnlineBPH, DBL, BR, MACS, RANDOM); follow with step_wait()."""
+        if self.rng == "numpy":
+            raise PctEnvError("the heuristic policies are not available in strict NumPy-stream mode (rng='numpy')")
         with torch.cuda.device(self._dev_index):
             _lib.check(self._L.pct_step_heuristic(self._h, HEURISTICS[name], int(n_steps), self._stream()))
         self.waiting_step = True
@@ -384,7 +386,11 @@ class PctVecEnv(VecEnv):
                 raise ValueError("rollout slots must be contiguous float32 tensors on the env's device")
         if obs_next.numel() != self.N * self.row_len:
             raise ValueError("obs_next must hold N x (I+L+1) x 9 floats")
-        self._actions_keepalive = (idx, obs_next, reward, mask)
+        self._actions_keepalive = idx
+        # the binding outlives this step (pct_bind_rollout_slot: until the next bind): later plain steps keep writing the
+        # observation / reward / mask into these tensors, so they stay alive in their own attribute until
+        # unbind_rollout_slot() or the next step_into()
+        self._slot_keepalive = (obs_next, reward, mask)
         with torch.cuda.device(self._dev_index):
             _lib.check(self._L.pct_bind_rollout_slot(self._h, obs_next.data_ptr(),
                                                      reward.data_ptr() if reward is not None else None,
@@ -394,6 +400,21 @@ class PctVecEnv(VecEnv):
         if reward is not None:
             self._reward = reward.view(self.N)
         return self._obs
+
+    def _bind_own_views(self):
+        """(re)binds the handle's outputs to this object's own tensors"""
+        self._obs, self._reward = self._own
+        _lib.check(self._L.pct_bind_outputs(self._h, self._obs.data_ptr(), self._reward.data_ptr(),
+                                            self._done.data_ptr(), self._counter.data_ptr(), self._ratio.data_ptr(),
+                                            self._flags.data_ptr()))
+
+    def unbind_rollout_slot(self):
+        """Back to the handle's own observation / reward buffers (and no mask output) after a run of step_into()
+        calls: the next transition rewrites every observation row there.  RolloutSlots may be dropped afterwards."""
+        with torch.cuda.device(self._dev_index):
+            torch.cuda.current_stream(self.device).synchronize()
+        self._bind_own_views()
+        self._slot_keepalive = None
 
     def terminal_stats(self):
         """(done bool [N], counter int32 [N], ratio float64 [N]) of the last step (one sync)."""

@@ -78,8 +78,8 @@ def test_fused_collect_matches_reference_fixture(name):
         idx = torch.where(k > 0, h % torch.clamp(k, min=1), torch.zeros_like(k))
         return torch.zeros(N, 1, device=all_nodes.device), idx.unsqueeze(1)
 
-    ro = pkg.RolloutSlots(T, N, (I + L + 1, 9), 1.0, "cuda:0")
-    ro.begin(env)
+    # the trainer's flat observation shape (main.py obs_shape = (obs_len,)); no begin(): collect() seeds slot 0 itself
+    ro = pkg.RolloutSlots(T, N, ((I + L + 1) * 9,), 1.0, "cuda:0")
     last = pkg.collect(env, policy, ro)
     assert last.data_ptr() == ro.obs[T].data_ptr()
     obs = ro.obs.reshape(T + 1, N, -1).cpu().numpy()
@@ -90,4 +90,11 @@ def test_fused_collect_matches_reference_fixture(name):
     # after the fused steps the plain VecEnv surface still works on the same handle (incremental rows again)
     o2, r2, d2, _ = env.step(torch.zeros(N, dtype=torch.int64))
     assert o2.data_ptr() == ro.obs[T].data_ptr()
+    # ... and after unbind_rollout_slot() the handle writes its own buffers again: the slots may be dropped
+    keep = ro.obs[T].clone()
+    env.unbind_rollout_slot()
+    del ro
+    o3, r3, d3, _ = env.step(torch.zeros(N, dtype=torch.int64))
+    assert o3.data_ptr() == env.current_obs().data_ptr() and o3.data_ptr() != keep.data_ptr()
+    assert o3.shape == (N, (I + L + 1) * 9)
     env.close()
