@@ -15,7 +15,9 @@ host only enqueues.  Envs shard across GPUs by global env id with no collective 
 ("scaling": "weak", per-GPU work fixed).
 
 Other workloads (parity-test configurations of BASELINE.json, measurable with the same contract):
-  c4    the per-GPU slice of configs[3]: c2 with 8192 envs per GPU
+  c4    the per-GPU slice of configs[3] (65 536 envs over 8 GPUs): c2 with 8192 envs per GPU --
+        `bench.py --gpus 8 --workload c4` under torch.distributed.run IS the configs[3] line (the default
+        `--gpus N` line shards configs[1]'s 4096 envs per GPU)
   c3    configs[2]: PctContinuous0 setting 2, 10^3, 80/50, 4096 envs per GPU (float64 kernel)
   c5    configs[4]: PctContinuous0 setting 2, 100^3, 200/200, items U(5,25), 2048 envs per GPU
   c1    configs[0]'s geometry on the GPU: PctDiscrete0 setting 1 (stability check), 10^3, 4096 envs
@@ -139,16 +141,19 @@ def reference_baseline(w):
 
 def pmc_profile(name, envs):
     """Counter values per launch from the committed rocprofv3 PMC passes of this workload, or None."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_%s.json" % name)
-    if not os.path.exists(path):
-        return None, None
-    try:
-        z = json.load(open(path))
-        if int(z.get("envs_per_launch", -1)) != envs:
-            return None, None
-        return z, "profiles/r02_pmc_%s.json" % name
-    except Exception:
-        return None, None
+    for tag in ("r03", "r02"):  # the newest committed profile of this workload
+        rel = "profiles/%s_pmc_%s.json" % (tag, name)
+        path = os.path.join(ROOT, rel)
+        if not os.path.exists(path):
+            continue
+        try:
+            z = json.load(open(path))
+            if int(z.get("envs_per_launch", -1)) != envs:
+                continue
+            return z, rel
+        except Exception:
+            continue
+    return None, None
 
 
 def main():

@@ -99,8 +99,16 @@ extern "C" {
                                             raises IndexError at space.py:385 */
 #define PCT_FLAG_EMS_OVERFLOW 0x2u       /* EMS list exceeded ems_capacity */
 #define PCT_FLAG_CANDIDATE_OVERFLOW 0x4u /* leaf-candidate set exceeded candidate_capacity */
-#define PCT_FLAG_STABILITY_OVERFLOW 0x10u /* stability check: more supporters / hull vertices /
-                                             support-graph depth than the kernel keeps */
+#define PCT_FLAG_STABILITY_OVERFLOW 0x10u /* stability check (settings 1 / 3): the share / polygon pools, the hull
+                                             workspace or the walk queue were exceeded in the retry pass too (the
+                                             normal pass requeues such an env, state untouched), or a box rests on
+                                             more than 8 supporters none of which holds its centre of mass */
+#define PCT_FLAG_ILL_CONDITIONED 0x40u   /* NON-FATAL notice (the env is not terminated, PctVecEnv(strict=True) does not
+                                            raise): a >= 3-supporter load split (np.linalg.lstsq, space.py:134-163)
+                                            took its rank decision within a factor 1000 of the rcond cut -- the
+                                            reference's own verdict then depends on the rounding noise of its LAPACK
+                                            build (dgelsd), and so may differ from this library's from that step on
+                                            (profiles/r02_lstsq_limit.txt, r03_lstsq_limit.txt) */
 #define PCT_FLAG_DATASET_EXHAUSTED 0x20u /* LoadBoxCreator ran past its last trajectory: the
                                             reference raises IndexError at binCreator.py:58 */
 #define PCT_FLAG_BAD_ACTION 0x8u         /* malformed action: reference raises ValueError at

@@ -19,6 +19,8 @@ ENV_DISCRETE, ENV_CONTINUOUS = 0, 1
 LNES_EMS, LNES_EV, LNES_EP, LNES_CP, LNES_FC = 0, 1, 2, 3, 4
 FLAG_INTERNAL_OVERFLOW, FLAG_EMS_OVERFLOW, FLAG_CANDIDATE_OVERFLOW, FLAG_BAD_ACTION = 1, 2, 4, 8
 FLAG_STABILITY_OVERFLOW, FLAG_DATASET_EXHAUSTED = 16, 32
+FLAG_ILL_CONDITIONED = 64  # non-fatal notice (include/pct_env.h)
+FLAG_ERROR_MASK = 0xFFFFFFFF & ~FLAG_ILL_CONDITIONED
 
 # every symbol include/pct_env.h declares
 ABI_SYMBOLS = [

@@ -6,11 +6,13 @@ to the GPU box with the repo snapshot (it is git-ignored, not gpurun-ignored).
 import os
 import shutil
 import subprocess
+import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpct_hip.so")
-SOURCES = ["pct_env.hip", "pct_discrete.hip", "pct_discrete_u64.hip", "pct_continuous.hip", "pct_continuous_mt.hip"]
+SOURCES = ["pct_env.hip", "pct_discrete.hip", "pct_discrete_stab.hip", "pct_discrete_u64.hip", "pct_discrete_u64_stab.hip",
+           "pct_continuous.hip", "pct_continuous_mt.hip"]
 HEADERS = [os.path.join(CSRC, "pct_device.h"), os.path.join(CSRC, "pct_set.cuh"), os.path.join(CSRC, "pct_stab.cuh"),
            os.path.join(CSRC, "pct_discrete_impl.cuh"), os.path.join(CSRC, "pct_mt.cuh"),
            os.path.join(HERE, "..", "include", "pct_env.h")]
@@ -38,27 +40,36 @@ def build_library(force=False, verbose=False):
     from concurrent.futures import ThreadPoolExecutor
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
              # the continuous env mirrors the reference's float64 operation order: no FMA contraction
-             "-ffp-contract=off"]
+             "-ffp-contract=off",
+             # no real calls inside a kernel: every device function is inlined (profiles/r03_fault_root_cause.txt: this
+             # hipcc mis-places AGPR split copies around a call under a narrowed exec mask); scripts/check_no_calls.py
+             # verifies the built library
+             "-mllvm", "-amdgpu-function-calls=false"]
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
 
     # which headers a translation unit includes (a change elsewhere does not recompile it)
     deps = {"pct_env.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh"],
             "pct_discrete.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_mt.cuh", "pct_discrete_impl.cuh"],
+            "pct_discrete_stab.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_mt.cuh", "pct_discrete_impl.cuh"],
             "pct_discrete_u64.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_mt.cuh", "pct_discrete_impl.cuh"],
+            "pct_discrete_u64_stab.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_mt.cuh", "pct_discrete_impl.cuh"],
             "pct_continuous.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_mt.cuh"],
             "pct_continuous_mt.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_mt.cuh", "pct_continuous.hip"]}
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         srcs = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in deps[src]] + [
-            os.path.join(HERE, "..", "include", "pct_env.h")]
+            os.path.join(HERE, "..", "include", "pct_env.h"), os.path.abspath(__file__)]  # (this file holds the flags)
         if not force and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in srcs):
             return obj
         cmd = [_hipcc(), *flags, "-Wno-pass-failed", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
+        t0 = time.time()
         subprocess.check_call(cmd)
+        if verbose:
+            print("%s: %.0f s" % (src, time.time() - t0))
         return obj
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:

@@ -84,6 +84,8 @@ struct CRegs {  // wave-uniform per-env scalars
   int mt_pos;      // strict NumPy-stream mode: position in this env's MT19937 block (LDS)
   bool mt_dirty;   // the block was regenerated in this launch
   double den_cur;  // density drawn for the current observation (setting 3, NumPy-stream mode)
+  int poly_from;   // stability settings: polygon-pool vertices from this one on are newer than the HBM copy
+  uint32_t stab_over;  // STAB_WHY_* bits: a stability capacity (pools, workspace, queue) was exceeded -- the step belongs to the retry pass
 };
 
 struct CLds {
@@ -100,10 +102,22 @@ struct CLds {
   uint32_t* fpri;   // [order_cap] shuffle priorities of the feasible candidates (shuffle only)
   uint32_t* dd;     // [128] bucket words of the batch de-duplication
   uint32_t* mt;     // [624] MT19937 state of this env (strict NumPy-stream mode only)
+  StabState st;     // settings 1 / 3: the env's stability state, resident for the whole transition (pct_stab.cuh) ...
+  StabWave sw;      // ... and the wave's hull workspace + task queue
 };
 
 // words of the region shared by the hash table and the GENEMS children scratch
 __host__ __device__ inline int cunion_words(const ContinuousParams& p) { return p.union_words; }
+
+// LDS bytes of everything but the stability state (which follows, 16-byte aligned)
+__host__ __device__ inline size_t continuous_lds_base_bytes(const ContinuousParams& p) {
+  const bool stab = p.setting != 2;
+  size_t dbl = stab ? 9 * (size_t)p.I : (size_t)p.I;
+  size_t i32 = 6 * (size_t)p.ems_cap + (size_t)p.union_words + 4 * (size_t)p.I + 128 + (p.rng_numpy ? 624 : 0);
+  size_t u16 = 128 + 64 + (((size_t)p.L + 1) & ~(size_t)1);
+  if (p.shuffle && !p.table_global) u16 += 2 * (size_t)p.order_cap;
+  return (dbl * 8 + i32 * 4 + u16 * 2 + 16 + 15) & ~(size_t)15;
+}
 
 __device__ inline CLds carve(const ContinuousParams& p, unsigned char* base) {
   CLds l;
@@ -125,17 +139,19 @@ __device__ inline CLds carve(const ContinuousParams& p, unsigned char* base) {
   l.vp = h; h += 64;
   l.leafg = h; h += (p.L + 1) & ~1;
   l.fpri = reinterpret_cast<uint32_t*>(h);
+  if (stab) {
+    unsigned char* sbase = base + continuous_lds_base_bytes(p);
+    l.st = stab_carve(sbase, p.I, p.sb.caps);
+    l.sw = stab_wave_carve(sbase + ((stab_state_bytes(p.I, p.sb.caps) + 15) & ~(size_t)15), p.sb.caps);
+  }
   return l;
 }
 
 #ifndef PCT_CONT_MT
 size_t continuous_lds_bytes(const ContinuousParams& p) {
-  const bool stab = p.setting != 2;
-  size_t dbl = stab ? 9 * (size_t)p.I : (size_t)p.I;
-  size_t i32 = 6 * (size_t)p.ems_cap + (size_t)p.union_words + 4 * (size_t)p.I + 128 + (p.rng_numpy ? 624 : 0);
-  size_t u16 = 128 + 64 + (((size_t)p.L + 1) & ~(size_t)1);
-  if (p.shuffle && !p.table_global) u16 += 2 * (size_t)p.order_cap;
-  return dbl * 8 + i32 * 4 + u16 * 2 + 16;
+  size_t b = continuous_lds_base_bytes(p);
+  if (p.setting != 2) b += ((stab_state_bytes(p.I, p.sb.caps) + 15) & ~(size_t)15) + stab_wave_bytes(p.sb.caps);
+  return b;
 }
 #endif
 
@@ -229,6 +245,9 @@ __device__ inline void cspace_reset(const ContinuousParams& p, CLds& l, CRegs& r
   r.n_ems = 1;
   r.n_boxes = 0;
   r.volsum = 0.0;
+  l.st.n_ent = 0;
+  l.st.n_poly = 0;
+  r.poly_from = 0;
   if (p.source == PCT_ITEMS_DATASET) {
     r.traj++;
     r.cursor = 0;
@@ -279,20 +298,6 @@ struct CGeo {  // placed-box geometry for the stability code
     g[6] = bsz[0 * I + i]; g[7] = bsz[1 * I + i]; g[8] = bsz[2 * I + i];
   }
 };
-__device__ inline StabState cstab_view(const ContinuousParams& p, int e) {
-  StabState st;
-  st.I = p.I;
-  st.stack = p.st_stack + (size_t)e * p.I * 4;
-  st.nsup = p.st_nsup + (size_t)e * p.I;
-  st.sup = p.st_sup + (size_t)e * p.I * STAB_SMAX;
-  st.share = p.st_share + (size_t)e * p.I * STAB_SMAX * 4;
-  st.npoly = p.st_npoly + (size_t)e * p.I;
-  st.poly = p.st_poly + (size_t)e * p.I * STAB_PMAX * 2;
-  st.den = p.st_den + (size_t)e * p.I;
-  st.alias = p.st_alias + (size_t)e * p.I;
-  return st;
-}
-
 // C/space.py:441-487 GENEMS + :510-528 EliminateInscribedEMS.  l.emsk -> l.emsk.
 __device__ inline void cgenems(const ContinuousParams& p, CLds& l, CRegs& r, int lane, const double loc[6]) {
   // Survivors (EMS the box does not intersect) stay where they are in l.emsk until the end; only the
@@ -756,31 +761,44 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
 
   // feasibility in list order (C/space.py:380-425 drop_box_virtual), first L kept
   int nleaf = 0;
-  bool stab_err = false;
+  uint32_t stab_err = 0;
   const int nb = r.n_boxes;
   const double next_den = !STAB ? 1.0 : (MT ? (p.setting == 3 ? r.den_cur : 1.0) : next_density(p, e, r.oc, r.traj, r.cursor - 1));  // C/bin3D.py:81-90
-  auto feasible = [&](const double t[6]) -> bool {
+  // ALL 64 lanes call (`live`: this lane holds a candidate): the stability check of the lanes that need one is a
+  // wave-cooperative task walk (pct_stab.cuh stab_virtual_wave)
+  bool stab_ill = false;
+  bool unknown = false;  // the last call left this lane's candidate undecided (a capacity of its own was exceeded)
+  auto feasible = [&](bool live, const double t[6]) -> bool {
+    unknown = false;
     double lx = t[0], ly = t[1];
     double x = t[3] - t[0], y = t[4] - t[1], z = t[5] - t[2];
-    bool ok = true;
+    bool ok = live;
     if (lx + x - 1e-6 > p.W || ly + y - 1e-6 > p.Ly) ok = false;
     if (lx + 1e-6 < 0 || ly + 1e-6 < 0) ok = false;
     // interSect2D (:305-314) on lattice indices; tops stay float64
     int c0 = klat(-lx), c1 = klat(-ly), c2 = klat(lx + x), c3 = klat(ly + y);
     double max_h = 0.0;
-    for (int b2 = 0; b2 < nb; b2++) {
-      int u0 = l.bk[0 * p.I + b2], u1 = l.bk[1 * p.I + b2], u2 = l.bk[2 * p.I + b2], u3 = l.bk[3 * p.I + b2];
-      bool ov = (min(c0, u0) + min(c2, u2) > 0) && (min(c1, u1) + min(c3, u3) > 0);
-      double top = l.top[b2];
-      max_h = (ov && top > max_h) ? top : max_h;
-    }
+    if (live)
+      for (int b2 = 0; b2 < nb; b2++) {
+        int u0 = l.bk[0 * p.I + b2], u1 = l.bk[1 * p.I + b2], u2 = l.bk[2 * p.I + b2], u3 = l.bk[3 * p.I + b2];
+        bool ov = (min(c0, u0) + min(c2, u2) > 0) && (min(c1, u1) + min(c3, u3) > 0);
+        double top = l.top[b2];
+        max_h = (ov && top > max_h) ? top : max_h;
+      }
     if (max_h + z - 1e-6 > p.H) ok = false;
-    if (STAB && ok && !(fabs(max_h) < 1e-6)) {  // C/space.py:432-439 calculated_impact_virtual(True)
-      const double cand[9] = {lx, ly, max_h, lx + x, ly + y, max_h + z, x, y, z};
-      CGeo geo{l.box, l.bsz, p.I};
-      bool err;
-      ok = stab_virtual<true>(geo, cstab_view(p, e), nb, cand, next_den, err);
-      if (err) stab_err = true;
+    if (STAB) {  // C/space.py:432-439 calculated_impact_virtual(True)
+      const bool need = ok && !(fabs(max_h) < 1e-6);
+      if (__ballot(need)) {
+        const double cand[9] = {lx, ly, max_h, lx + x, ly + y, max_h + z, x, y, z};
+        CGeo geo{l.box, l.bsz, p.I};
+        uint32_t cap = 0;
+        bool ill = false, lerr = false;
+        const bool stable = stab_virtual_wave<true>(geo, l.st, nb, need, cand, next_den, l.sw, lane, cap, lerr, ill);
+        if (need) ok = stable && !cap;
+        stab_err |= cap;
+        unknown = need && lerr;
+        if (__ballot(ill)) stab_ill = true;
+      }
     }
     return ok;
   };
@@ -808,7 +826,8 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
       uint32_t g = live ? (uint32_t)tab_ld<GT, uint16_t>(&order[i]) : 0u;
       double t[6];
       cand_tuple(p, l, r, orient, g, t);
-      bool ok = live && feasible(t);
+      bool ok = feasible(live, t);
+      if (STAB && __ballot(unknown)) stab_err |= STAB_WHY_SPLIT;
       uint64_t m = __ballot(ok);
       int o = nf + rank_below(m);
       __syncthreads();
@@ -838,15 +857,17 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
       double t[6];
       const uint32_t gid = live ? (uint32_t)tab_ld<GT, uint16_t>(&order[i]) : 0u;
       cand_tuple(p, l, r, orient, gid, t);
-      bool ok = live && feasible(t);
+      bool ok = feasible(live, t);
       uint64_t m = __ballot(ok);
       int idx = nleaf + rank_below(m);
+      if (STAB && __ballot(unknown && idx < p.L)) stab_err |= STAB_WHY_SPLIT;  // (beyond the L-th feasible one the reference never looks)
       if (ok && idx < p.L) l.leafg[idx] = (uint16_t)gid;
       nleaf += __popcll(m);
     }
   }
   r.oc++;
-  if (STAB && __ballot(stab_err)) r.flags |= PCT_FLAG_STABILITY_OVERFLOW;
+  if (STAB) r.stab_over |= stab_err;  // (wave-uniform)
+  if (STAB && stab_ill) r.flags |= PCT_FLAG_ILL_CONDITIONED;
   r.n_leaf = nleaf < p.L ? nleaf : p.L;
   __syncthreads();
   tm.tick(PH_FEAS);
@@ -947,6 +968,13 @@ __device__ inline void cload(const ContinuousParams& p, int e, CLds& l, CRegs& r
   r.mt_pos = sc[7];
   r.mt_dirty = false;
   r.den_cur = 1.0;
+  r.stab_over = 0;
+  r.poly_from = 0;
+  if (p.setting != 2) {  // the stability state: the used part of the pools (word 15: entries | vertices << 16)
+    const uint32_t pw = (uint32_t)sc[15];
+    r.stab_over = stab_load(p.sb, p.I, e, r.n_boxes, (int)(pw & 0xFFFFu), (int)(pw >> 16), l.st, lane) ? 0u : STAB_WHY_LOAD;
+    r.poly_from = l.st.n_poly;
+  }
   if (p.rng_numpy) {
     const uint32_t* gm = p.mt + (size_t)e * 624;
     for (int i = lane; i < 624; i += 64) l.mt[i] = gm[i];
@@ -1004,7 +1032,9 @@ __device__ inline void cstore(const ContinuousParams& p, int e, const CLds& l, c
     uint32_t* gm = p.mt + (size_t)e * 624;
     for (int i = lane; i < 624; i += 64) gm[i] = l.mt[i];
   }
+  if (p.setting != 2) stab_store(p.sb, p.I, e, r.n_boxes, l.st, r.poly_from, lane);
   if (lane == 0) {
+    if (p.setting != 2) sc[15] = (int32_t)((uint32_t)l.st.n_ent | ((uint32_t)l.st.n_poly << 16));
     if (p.rng_numpy) {
       sc[7] = r.mt_pos;
       if (p.setting == 3) p.mt_den[e] = r.den_cur;
@@ -1056,18 +1086,23 @@ __device__ inline int ctransition(const ContinuousParams& p, int e, CLds& l, CRe
       l.bsz[0 * p.I + bi] = x; l.bsz[1 * p.I + bi] = y; l.bsz[2 * p.I + bi] = z;
     }
     __syncthreads();
-    int verdict = 1, serr = 0;
+    int rc = 1, ne = 0, npv = 0, ill_i = 0;
     if (lane == 0) {
       CGeo geo{l.box, l.bsz, p.I};
-      StabState st = cstab_view(p, e);
-      bool err;
+      bool ill = false;
       const double den = MT ? (p.setting == 3 ? r.den_cur : 1.0) : next_density(p, e, r.oc - 1, r.traj, r.cursor - 1);
-      verdict = stab_commit<true>(geo, st, bi, den, err) ? 1 : 0;
-      serr = err ? 1 : 0;
+      rc = stab_commit<true>(geo, l.st, bi, den, l.sw.hull, l.sw.hull_bytes, ill);
+      ne = l.st.n_ent;
+      npv = l.st.n_poly;
+      ill_i = ill ? 1 : 0;
     }
-    verdict = __shfl(verdict, 0, 64);
-    if (__shfl(serr, 0, 64)) r.flags |= PCT_FLAG_STABILITY_OVERFLOW;
-    ok = verdict != 0;
+    rc = __shfl(rc, 0, 64);
+    l.st.n_ent = __shfl(ne, 0, 64);
+    l.st.n_poly = __shfl(npv, 0, 64);
+    if (__shfl(ill_i, 0, 64)) r.flags |= PCT_FLAG_ILL_CONDITIONED;
+    if (rc < 0) r.stab_over |= STAB_WHY_COMMIT;
+    ok = rc == 1;
+    __syncthreads();
   }
   if (ok && r.n_boxes >= p.I) {  // IndexError at C/space.py:371
     ok = false;
@@ -1201,7 +1236,7 @@ pct_continuous_kernel(ContinuousParams p, const void* __restrict__ actions,
   // state untouched, to the large-capacity pass, like one whose candidate set outgrows the table
   const bool can_retry = p.retry_ids != nullptr && !p.retry_mode;
   const uint32_t flags_in = r.flags;
-  bool requeue = can_retry && ACT != CACT_RESET && r.n_ems > p.ems_cap;
+  bool requeue = can_retry && ACT != CACT_RESET && (r.n_ems > p.ems_cap || r.stab_over);
   if (requeue) {
     if (lane == 0) p.retry_ids[atomicAdd(p.retry_count, 1)] = e;
     __syncthreads();
@@ -1218,6 +1253,10 @@ pct_continuous_kernel(ContinuousParams p, const void* __restrict__ actions,
       cdraw_item(p, e, r);
     }
     requeue = cleaf_nodes<GT, STAB, MT, false>(p, e, l, r, lane, tm);
+    if (STAB && r.stab_over) {
+      if (can_retry) requeue = true;
+      else r.flags |= PCT_FLAG_STABILITY_OVERFLOW | r.stab_over;
+    }
     if (!requeue) {
       const double nobox[6] = {0, 0, 0, 0, 0, 0};
       cwrite_obs(p, e, l, r, lane, obs, true, -1, nobox);
@@ -1280,6 +1319,12 @@ pct_continuous_kernel(ContinuousParams p, const void* __restrict__ actions,
     const bool ended = tr != 0;
     if (can_retry && ((r.flags & ~flags_in) & PCT_FLAG_EMS_OVERFLOW)) { requeue = true; break; }
     requeue = cleaf_nodes<GT, STAB, MT, false>(p, e, l, r, lane, tm);
+    // a stability capacity exceeded (pools, workspace, queue -- in the commit or in a virtual check): the step goes, state
+    // untouched (the stability state is LDS-resident, nothing of it has been stored), to the large-capacity pass
+    if (STAB && r.stab_over) {
+      if (can_retry) requeue = true;
+      else { r.flags |= PCT_FLAG_STABILITY_OVERFLOW | r.stab_over; r.stab_over = 0; }
+    }
     if (requeue) break;
     cwrite_obs(p, e, l, r, lane, obs, ended || (p.full_obs != 0 && it == 0), ended ? -1 : r.n_boxes - 1, newbox);
     __syncthreads();

@@ -6,7 +6,9 @@
 #include <stddef.h>
 #include <stdint.h>
 
-#define PCT_SCALARS 16 /* int32 words of per-env scalar state */
+#include "pct_stab.cuh"
+
+#define PCT_SCALARS 16 /* int32 words of per-env scalar state (word 15: stability pools in use, entries | vertices << 16) */
 
 namespace pct {
 
@@ -50,15 +52,8 @@ struct DiscreteParams {
   int32_t* scalars; /* [N,PCT_SCALARS]: n_ems,n_boxes,n_leaf,item[3],t,-,cursor lo/hi,vol lo/hi */
   uint32_t* flags;  /* [N] sticky PCT_FLAG_* */
   unsigned long long* timing; /* [N,16] per-phase cycle accumulators, or null */
-  // stability state (settings 1/3 only; csrc/pct_stab.cuh): per env and placed box
-  double* st_stack; /* [N,I,4] committed stack: centre xyz, mass */
-  int* st_nsup;     /* [N,I] */
-  int* st_sup;      /* [N,I,STAB_SMAX] supporters in bottom_edges order */
-  double* st_share; /* [N,I,STAB_SMAX,4] share handed to each supporter */
-  int* st_npoly;    /* [N,I] */
-  double* st_poly;  /* [N,I,STAB_PMAX,2] scaled support polygon */
-  double* st_den;   /* [N,I] density of each placed box (1.0 unless setting 3) */
-  int* st_alias;    /* [N,I] supporter index holding the box's stack by reference, or -1 (pct_stab.cuh) */
+  // stability state (settings 1/3 only): compact pooled layout, LDS-resident during a transition (csrc/pct_stab.cuh)
+  StabHbm sb;
   // setting 3 density source (include/pct_env.h pct_set_density_stream / pct_set_dataset_density)
   const double* den_stream; /* [N,den_T] or null */
   long long den_T;
@@ -97,14 +92,7 @@ struct ContinuousParams {
   uint16_t* leafg;  /* [N,L] generator ids (EMS, rotation, corner) of the current leaf nodes */
   double* volsum;   /* [N] running sum of placed volumes (get_ratio) */
   double* bsz;      /* [N,3,I] placed sizes x,y,z */
-  double* st_stack; /* stability state, as in DiscreteParams (settings 1/3 only) */
-  int* st_nsup;
-  int* st_sup;
-  double* st_share;
-  int* st_npoly;
-  double* st_poly;
-  double* st_den;
-  int* st_alias;
+  StabHbm sb;       /* stability state, as in DiscreteParams (settings 1/3 only) */
   const double* den_stream; /* setting 3 density source, as in DiscreteParams */
   long long den_T;
   const double* ds_den;

@@ -1,14 +1,19 @@
-// pct_discrete.hip -- instantiates the discrete-env kernels for 32-bit keys (bins <= 31 per
+// pct_discrete.hip -- instantiates the setting-2 discrete-env kernels for 32-bit keys (bins <= 31 per
 // axis: six 5-bit coordinates) and hosts the launch dispatcher; the kernels themselves are in
-// pct_discrete_impl.cuh, the 64-bit-key instantiation in pct_discrete_u64.hip.
+// pct_discrete_impl.cuh, the other instantiations in pct_discrete_stab.hip, pct_discrete_u64.hip, pct_discrete_u64_stab.hip.
 #include "pct_discrete_impl.cuh"
 
 namespace pct {
 
 size_t discrete_lds_bytes(const DiscreteParams& p) { return discrete_lds_bytes_impl(p); }
 
+// the other translation units of the discrete env (keys x plain / stability kernels)
 hipError_t launch_discrete_u64(const DiscreteParams& p, int act, const void* actions, int row_len, int n_steps,
                                const int32_t* env_ids, int n_ids, hipStream_t stream);
+hipError_t launch_discrete_u64_stab(const DiscreteParams& p, int act, const void* actions, int row_len, int n_steps,
+                                    const int32_t* env_ids, int n_ids, hipStream_t stream);
+hipError_t launch_discrete_u32_stab(const DiscreteParams& p, int act, const void* actions, int row_len, int n_steps,
+                                    const int32_t* env_ids, int n_ids, hipStream_t stream);
 
 // Stand-in policy kernel: one wave per env reads the leaf-mask column (col 8 of rows
 // I..I+L-1, tools.py:103) of the observation, k = number of valid leaves, picks
@@ -36,8 +41,12 @@ hipError_t launch_policy_hash_rows(const DiscreteParams& p, float* rows_out, hip
 
 hipError_t launch_discrete(const DiscreteParams& p, int act, const void* actions, int row_len, int n_steps,
                            const int32_t* env_ids, int n_ids, hipStream_t stream) {
-  if (p.key_bytes == 4) return launch_typed<uint32_t, 5>(p, act, actions, row_len, n_steps, env_ids, n_ids, stream);
-  return launch_discrete_u64(p, act, actions, row_len, n_steps, env_ids, n_ids, stream);
+  const bool stab = p.setting != 2;
+  if (p.key_bytes == 4)
+    return stab ? launch_discrete_u32_stab(p, act, actions, row_len, n_steps, env_ids, n_ids, stream)
+                : launch_typed<uint32_t, 5, false>(p, act, actions, row_len, n_steps, env_ids, n_ids, stream);
+  return stab ? launch_discrete_u64_stab(p, act, actions, row_len, n_steps, env_ids, n_ids, stream)
+              : launch_discrete_u64(p, act, actions, row_len, n_steps, env_ids, n_ids, stream);
 }
 
 }  // namespace pct

@@ -79,6 +79,8 @@ struct EnvRegs {  // wave-uniform per-env scalars
   int traj;  // dataset mode: current trajectory (LoadBoxCreator.index)
   uint32_t oc;  // observations produced so far (shuffle key)
   int box_from;  // placed boxes [box_from, n_boxes) are newer than the HBM copy
+  int poly_from;  // ... and so are the polygon-pool vertices from this one on (stability settings)
+  uint32_t stab_over;  // STAB_WHY_* bits: a stability capacity (pools, workspace, queue) was exceeded -- the step belongs to the retry pass
   // the item that the draw number pre_cursor (of trajectory pre_traj) yields, fetched at kernel start
   int pre0, pre1, pre2, pre_traj;
   uint64_t pre_cursor;
@@ -103,6 +105,8 @@ struct Lds {
   K* fkey;       /* shuffle: feasible candidates in list order ... */
   uint32_t* fpri; /* ... and their priorities (only when shuffle) */
   uint32_t* mt;   /* [624] the env's MT19937 state (strict NumPy-stream mode only) */
+  StabState st;   /* settings 1 / 3: the env's stability state, resident for the whole transition (pct_stab.cuh) ... */
+  StabWave sw;    /* ... and the wave's hull workspace + task queue */
 };
 
 __host__ __device__ inline int discrete_scheme_words(const DiscreteParams& p) {
@@ -112,6 +116,17 @@ __host__ __device__ inline int discrete_scheme_words(const DiscreteParams& p) {
 }
 __host__ __device__ inline int discrete_scratch_words(const DiscreteParams& p) {
   return (int)(128 * sizeof(uint32_t) / p.key_bytes);  // dd[128 x u32], in key words
+}
+
+// LDS bytes of everything but the stability state (which follows, 16-byte aligned)
+__host__ __device__ inline size_t discrete_lds_base_bytes(const DiscreteParams& p) {
+  size_t k = p.key_bytes;
+  size_t n = (size_t)table_words_compact((uint32_t)p.cand_cap) + p.ems_cap + discrete_scratch_words(p) + p.I + p.L;
+  size_t hb = ((size_t)p.AA * (k == 4 ? 1 : 2) + 3) & ~(size_t)3;
+  size_t cp = (size_t)discrete_scheme_words(p) * sizeof(uint32_t);
+  if (p.shuffle && !p.rng_numpy) cp += ((size_t)(p.cand_cap * 3) / 5 + 4) * (sizeof(uint32_t) + k);
+  if (p.rng_numpy) cp += 624 * sizeof(uint32_t);
+  return (n * k + hb + 64 * sizeof(uint16_t) + cp + 15) & ~(size_t)15;
 }
 
 template <typename K, int BITS>
@@ -135,6 +150,11 @@ __device__ inline Lds<K, BITS> carve_lds(const DiscreteParams& p, unsigned char*
   l.fkey = reinterpret_cast<K*>(after_cp + fcap + (fcap & 1));
   // the MT19937 words sit behind the shuffle arrays (counter-keyed shuffle) or directly behind the scheme scratch
   l.mt = (p.shuffle && !p.rng_numpy) ? reinterpret_cast<uint32_t*>(l.fkey + fcap + (fcap & 1)) : after_cp;
+  if (p.setting != 2) {
+    unsigned char* sbase = base + discrete_lds_base_bytes(p);
+    l.st = stab_carve(sbase, p.I, p.sb.caps);
+    l.sw = stab_wave_carve(sbase + ((stab_state_bytes(p.I, p.sb.caps) + 15) & ~(size_t)15), p.sb.caps);
+  }
   return l;
 }
 
@@ -149,20 +169,6 @@ struct BoxGeo {
     g[6] = g[3] - g[0]; g[7] = g[4] - g[1]; g[8] = g[5] - g[2];  // exact for integers
   }
 };
-__device__ inline StabState stab_view(const DiscreteParams& p, int e) {
-  StabState st;
-  st.I = p.I;
-  st.stack = p.st_stack + (size_t)e * p.I * 4;
-  st.nsup = p.st_nsup + (size_t)e * p.I;
-  st.sup = p.st_sup + (size_t)e * p.I * STAB_SMAX;
-  st.share = p.st_share + (size_t)e * p.I * STAB_SMAX * 4;
-  st.npoly = p.st_npoly + (size_t)e * p.I;
-  st.poly = p.st_poly + (size_t)e * p.I * STAB_PMAX * 2;
-  st.den = p.st_den + (size_t)e * p.I;
-  st.alias = p.st_alias + (size_t)e * p.I;
-  return st;
-}
-
 __device__ inline void draw_item(const DiscreteParams& p, int e, EnvRegs& r) {
   // binCreator.py:37-39 generate_box_size, through the scripted / counter-based sources
   uint64_t c = r.cursor++;
@@ -208,6 +214,9 @@ __device__ inline void space_reset(const DiscreteParams& p, Lds<K, BITS>& l, Env
   r.n_boxes = 0;
   r.box_from = 0;
   r.vol = 0;
+  l.st.n_ent = 0;
+  l.st.n_poly = 0;
+  r.poly_from = 0;
   if (p.source == PCT_ITEMS_DATASET) {  // LoadBoxCreator.reset (binCreator.py:51-62)
     r.traj++;
     r.cursor = 0;
@@ -1051,27 +1060,41 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
 
   // iterate the table in slot order (= list(set)), test feasibility, keep the first L
   int nleaf = 0;
-  bool stab_err = false;
+  uint32_t stab_err = 0;
   // D/bin3D.py:75-84: the density drawn for this observation (setting 3), else 1
   const double next_den = !STAB ? 1.0 : (MT ? (p.setting == 3 ? r.den_cur : 1.0) : next_density(p, e, r.oc, r.traj, r.cursor - 1));
+  // feasibility of the candidate every lane holds (EMPTY: none).  All 64 lanes call: the stability check of the lanes
+  // that need one is a wave-cooperative task walk (pct_stab.cuh stab_virtual_wave).
+  bool stab_ill = false;
+  bool unknown = false;  // the last call left this lane's candidate undecided (a capacity of its own was exceeded)
   auto feasible = [&](K k) -> bool {
+    unknown = false;
+    const bool occ = k != SlotWord<K>::EMPTY;
     int xs = P::get(k, 0), ys = P::get(k, 1), xe = P::get(k, 3), ye = P::get(k, 4);
     int z = P::get(k, 5) - P::get(k, 2);
     int mh = 0;  // D/space.py:400-401 footprint maximum (candidate's own zs is ignored)
-    for (int x = xs; x < xe; x++)
-      for (int y = ys; y < ye; y++) {
-        int h = l.hmap[x * p.A + y];
-        mh = h > mh ? h : mh;
-      }
+    if (occ)
+      for (int x = xs; x < xe; x++)
+        for (int y = ys; y < ye; y++) {
+          int h = l.hmap[x * p.A + y];
+          mh = h > mh ? h : mh;
+        }
     // check_box :436-446: EMS candidates are inside the bin by construction
-    bool feas = (xe <= p.W) && (ye <= p.Ly) && (mh + z <= p.H);
-    if (STAB && feas && mh != 0) {  // :447-454 calculated_impact_virtual(first=True)
-      const double cand[9] = {(double)xs, (double)ys, (double)mh, (double)xe, (double)ye, (double)(mh + z),
-                              (double)(xe - xs), (double)(ye - ys), (double)z};
-      BoxGeo<K, BITS> geo{l.box};
-      bool err;
-      feas = stab_virtual<false>(geo, stab_view(p, e), r.n_boxes, cand, next_den, err);
-      if (err) stab_err = true;
+    bool feas = occ && (xe <= p.W) && (ye <= p.Ly) && (mh + z <= p.H);
+    if (STAB) {  // :447-454 calculated_impact_virtual(first=True)
+      const bool need = feas && mh != 0;
+      if (__ballot(need)) {
+        const double cand[9] = {(double)xs, (double)ys, (double)mh, (double)xe, (double)ye, (double)(mh + z),
+                                (double)(xe - xs), (double)(ye - ys), (double)z};
+        BoxGeo<K, BITS> geo{l.box};
+        uint32_t cap = 0;
+        bool ill = false, lerr = false;
+        const bool stable = stab_virtual_wave<false>(geo, l.st, r.n_boxes, need, cand, next_den, l.sw, lane, cap, lerr, ill);
+        if (need) feas = stable && !cap;
+        stab_err |= cap;
+        unknown = need && lerr;
+        if (__ballot(ill)) stab_ill = true;
+      }
     }
     return feas;
   };
@@ -1105,10 +1128,11 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
     __syncthreads();
     for (uint32_t sb = 0; sb < size && nleaf < p.L; sb += 64) {
       K k = tabs[toff + sb + lane];
-      bool feas = (k != SlotWord<K>::EMPTY) && feasible(k);
+      bool feas = feasible(k);
       uint64_t m = __ballot(feas);
       int idx = nleaf + rank_below(m);
       if (feas && idx < p.L) l.leaf[idx] = k;
+      if (STAB && __ballot(unknown && idx < p.L)) stab_err |= STAB_WHY_SPLIT;  // (beyond the L-th feasible one the reference never looks)
       nleaf += __popcll(m);
     }
   } else if (SHUFFLE) {
@@ -1121,7 +1145,8 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
       bool occ = k != SlotWord<K>::EMPTY;
       uint64_t om = __ballot(occ);
       uint32_t li = (uint32_t)(nlist + rank_below(om));
-      bool feas = occ && feasible(k);
+      bool feas = feasible(k);
+      if (STAB && __ballot(unknown)) stab_err |= STAB_WHY_SPLIT;
       uint64_t fm = __ballot(feas);
       int o = nf + rank_below(fm);
       if (feas) {
@@ -1165,15 +1190,17 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
     for (uint32_t sb = 0; sb < size && nleaf < p.L; sb += 64) {
       uint32_t s2 = sb + lane;
       K k = (s2 < size) ? tabs[toff + s2] : SlotWord<K>::EMPTY;
-      bool feas = (k != SlotWord<K>::EMPTY) && feasible(k);
+      bool feas = feasible(k);
       uint64_t m = __ballot(feas);
       int idx = nleaf + rank_below(m);
       if (feas && idx < p.L) l.leaf[idx] = k;
+      if (STAB && __ballot(unknown && idx < p.L)) stab_err |= STAB_WHY_SPLIT;  // (beyond the L-th feasible one the reference never looks)
       nleaf += __popcll(m);
     }
   }
   r.oc++;
-  if (STAB && __ballot(stab_err)) r.flags |= PCT_FLAG_STABILITY_OVERFLOW;
+  if (STAB) r.stab_over |= stab_err;  // (wave-uniform)
+  if (STAB && stab_ill) r.flags |= PCT_FLAG_ILL_CONDITIONED;
   r.n_leaf = nleaf < p.L ? nleaf : p.L;
   __syncthreads();
   tm.tick(PH_FEAS);
@@ -1196,7 +1223,7 @@ __device__ inline void write_obs(const DiscreteParams& p, int e, const Lds<K, BI
   const bool lane_on = lane < 63;
   const int rows = p.I + p.L + 1;
   const bool dens = p.setting == 3;  // densities other than 1 (D/space.py:386, D/bin3D.py:91)
-  const double* bden = p.st_den + (size_t)e * p.I;
+  const double* bden = l.st.den;  // the LDS-resident stability state (only read under setting 3)
   const float nden = !dens ? 1.0f : (p.rng_numpy ? (float)r.den_cur : (float)next_density(p, e, r.oc - 1, r.traj, r.cursor - 1));
   if (!full && new_row >= 0 && lane < 9) {
     K k = l.box[new_row];
@@ -1295,6 +1322,13 @@ __device__ inline void load_state(const DiscreteParams& p, int e, Lds<K, BITS>& 
   if (lane + 64 < p.AA) l.hmap[lane + 64] = (typename Lds<K, BITS>::HT)h1;
   r.box_from = r.n_boxes;
   for (int i = 128 + lane; i < p.AA; i += 64) l.hmap[i] = (typename Lds<K, BITS>::HT)g_h[i];
+  r.stab_over = 0;
+  r.poly_from = 0;
+  if (p.setting != 2) {  // the stability state: the used part of the pools (word 15: entries | vertices << 16)
+    const uint32_t pw = (uint32_t)sc[15];
+    r.stab_over = stab_load(p.sb, p.I, e, r.n_boxes, (int)(pw & 0xFFFFu), (int)(pw >> 16), l.st, lane) ? 0u : STAB_WHY_LOAD;
+    r.poly_from = l.st.n_poly;
+  }
   __syncthreads();
 }
 
@@ -1313,7 +1347,9 @@ __device__ inline void store_state(const DiscreteParams& p, int e, const Lds<K, 
     uint32_t* gm = p.mt + (size_t)e * 624;
     for (int i = lane; i < 624; i += 64) gm[i] = l.mt[i];
   }
+  if (p.setting != 2) stab_store(p.sb, p.I, e, r.n_boxes, l.st, r.poly_from, lane);
   if (lane == 0) {
+    if (p.setting != 2) sc[15] = (int32_t)((uint32_t)l.st.n_ent | ((uint32_t)l.st.n_poly << 16));
     sc[0] = r.n_ems; sc[1] = r.n_boxes; sc[2] = r.n_leaf;
     sc[3] = r.item0; sc[4] = r.item1; sc[5] = r.item2;
     sc[6] = (int32_t)r.t;
@@ -1347,7 +1383,7 @@ __device__ inline void heur_rot(int b0, int b1, int b2, int rot, int& x, int& y,
 // "replace on strictly better" leaves.  Returns false if there is no feasible placement.
 template <typename K, int BITS, bool STAB>
 __device__ inline bool heur_choose(const DiscreteParams& p, int e, Lds<K, BITS>& l, const EnvRegs& r, int lane, int kind,
-                                   int& olx, int& oly, int& ox, int& oy, int& oz, bool& stab_err) {
+                                   int& olx, int& oly, int& ox, int& oy, int& oz, uint32_t& stab_err) {
   typedef Pack<K, BITS> P;
   const int orient = STAB ? 2 : 6;
   const int b0 = r.item0, b1 = r.item1, b2 = r.item2;
@@ -1355,24 +1391,33 @@ __device__ inline bool heur_choose(const DiscreteParams& p, int e, Lds<K, BITS>&
   uint32_t* scratch = reinterpret_cast<uint32_t*>(l.tab0);  // the table region is idle between observations
   // drop_box_virtual (D/space.py:393-433) of size (x,y,z) at (lx,ly): feasibility, height, and the sum of
   // the heightmap under the footprint (NumPy clips the slice to the array)
-  auto probe = [&](int x, int y, int z, int lx, int ly, int& mh, long long& under) -> bool {
+  // ALL 64 lanes call (`go`: this lane has a placement to test): the stability check is wave-cooperative
+  auto probe = [&](bool go, int x, int y, int z, int lx, int ly, int& mh, long long& under) -> bool {
     mh = 0;
     under = 0;
-    const int xe = min(lx + x, p.A), ye = min(ly + y, p.A);
-    for (int cx = lx; cx < xe; cx++)
-      for (int cy = ly; cy < ye; cy++) {
-        int hh = l.hmap[cx * p.A + cy];
-        mh = hh > mh ? hh : mh;
-        under += hh;
+    if (go) {
+      const int xe = min(lx + x, p.A), ye = min(ly + y, p.A);
+      for (int cx = lx; cx < xe; cx++)
+        for (int cy = ly; cy < ye; cy++) {
+          int hh = l.hmap[cx * p.A + cy];
+          mh = hh > mh ? hh : mh;
+          under += hh;
+        }
+    }
+    bool feas = go && (lx + x <= p.W) && (ly + y <= p.Ly) && (mh + z <= p.H);
+    if (STAB) {
+      const bool need = feas && mh != 0;
+      if (__ballot(need)) {
+        const double cand[9] = {(double)lx, (double)ly, (double)mh, (double)(lx + x), (double)(ly + y), (double)(mh + z),
+                                (double)x, (double)y, (double)z};
+        BoxGeo<K, BITS> geo{l.box};
+        uint32_t cap = 0;
+        bool ill = false, lerr = false;
+        const bool stable = stab_virtual_wave<false>(geo, l.st, r.n_boxes, need, cand, den, l.sw, lane, cap, lerr, ill);
+        if (need) feas = stable && !cap;
+        stab_err |= cap;
+        if (__ballot(need && lerr)) stab_err |= STAB_WHY_SPLIT;
       }
-    bool feas = (lx + x <= p.W) && (ly + y <= p.Ly) && (mh + z <= p.H);
-    if (STAB && feas && mh != 0) {
-      const double cand[9] = {(double)lx, (double)ly, (double)mh, (double)(lx + x), (double)(ly + y), (double)(mh + z),
-                              (double)x, (double)y, (double)z};
-      BoxGeo<K, BITS> geo{l.box};
-      bool err;
-      feas = stab_virtual<false>(geo, stab_view(p, e), r.n_boxes, cand, den, err);
-      if (err) stab_err = true;
     }
     return feas;
   };
@@ -1395,13 +1440,13 @@ __device__ inline bool heur_choose(const DiscreteParams& p, int e, Lds<K, BITS>&
       for (int base = 0; base < NQ; base += 64) {
         int q = base + lane;
         bool feas = false;
-        if (q < NQ) {
+        {
           int rot = q % orient, cell = q / orient;
           int lx = cell / ny, ly = cell - lx * ny;
           int x, y, z, mh;
           long long under;
           heur_rot(b0, b1, b2, rot, x, y, z);
-          feas = probe(x, y, z, lx, ly, mh, under);
+          feas = probe(q < NQ, x, y, z, lx, ly, mh, under);
         }
         const uint64_t m = __ballot(feas);
         if (lane == 0) { scratch[(base >> 6) * 2] = (uint32_t)m; scratch[(base >> 6) * 2 + 1] = (uint32_t)(m >> 32); }
@@ -1430,13 +1475,13 @@ __device__ inline bool heur_choose(const DiscreteParams& p, int e, Lds<K, BITS>&
     }
     for (int base = 0; base < NQ; base += 64) {
       int q = base + lane;
-      if (q < NQ) {
+      {
         int rot = q % orient, cell = q / orient;
         int lx = cell / ny, ly = cell - lx * ny;
         int x, y, z, mh;
         long long under;
         heur_rot(b0, b1, b2, rot, x, y, z);
-        if (probe(x, y, z, lx, ly, mh, under)) {
+        if (probe(q < NQ, x, y, z, lx, ly, mh, under)) {
           long long score = kind == PCT_HEUR_DBL ? (long long)(lx + ly) + 100ll * mh
                                                  : (long long)(lx + ly) + 100ll * (total - under + (long long)(mh + z) * x * y);
           uint64_t key = ((uint64_t)score << 24) | (uint64_t)q;
@@ -1459,13 +1504,14 @@ __device__ inline bool heur_choose(const DiscreteParams& p, int e, Lds<K, BITS>&
     // :364-425: EMS in (z, y, x) order (stable), first feasible (corner, rotation); no fit-in-EMS test
     for (int base = 0; base < NQ; base += 64) {
       int q = base + lane;
-      if (q < NQ) {
+      {
+        const bool live = q < NQ;
         int ei = q / orient, rot = q - ei * orient;
-        K ek = l.ems_a[ei];
+        K ek = live ? l.ems_a[ei] : (K)0;
         int x, y, z, mh;
         long long under;
         heur_rot(b0, b1, b2, rot, x, y, z);
-        if (probe(x, y, z, P::get(ek, 0), P::get(ek, 1), mh, under)) {
+        if (probe(live, x, y, z, P::get(ek, 0), P::get(ek, 1), mh, under)) {
           uint64_t key = ((uint64_t)P::get(ek, 2) << 50) | ((uint64_t)P::get(ek, 1) << 40) | ((uint64_t)P::get(ek, 0) << 30) |
                          (uint64_t)q;
           best = key < best ? key : best;
@@ -1498,15 +1544,16 @@ __device__ inline bool heur_choose(const DiscreteParams& p, int e, Lds<K, BITS>&
     __syncthreads();
     for (int base = 0; base < NQ; base += 64) {
       int q = base + lane;
-      if (q < NQ) {
+      {
+        const bool live = q < NQ;
         int ei = q / orient, rot = q - ei * orient;
-        K ek = l.ems_a[ei];
+        K ek = live ? l.ems_a[ei] : (K)0;
         int dx = P::get(ek, 3) - P::get(ek, 0), dy = P::get(ek, 4) - P::get(ek, 1), dz = P::get(ek, 5) - P::get(ek, 2);
         int x, y, z, mh;
         long long under;
         heur_rot(b0, b1, b2, rot, x, y, z);
-        if (dx >= x && dy >= y && dz >= z && probe(x, y, z, P::get(ek, 0), P::get(ek, 1), mh, under)) {
-          uint64_t key = ((uint64_t)(0xFFFFFFFFu - scratch[ei]) << 24) | (uint64_t)q;
+        if (probe(live && dx >= x && dy >= y && dz >= z, x, y, z, P::get(ek, 0), P::get(ek, 1), mh, under)) {
+          uint64_t key = ((uint64_t)(0xFFFFFFFFu - scratch[live ? ei : 0]) << 24) | (uint64_t)q;
           best = key < best ? key : best;
         }
       }
@@ -1540,17 +1587,18 @@ __device__ inline bool heur_choose(const DiscreteParams& p, int e, Lds<K, BITS>&
     const int NC = NQ * 4;
     for (int base = 0; base < NC; base += 64) {
       int qc = base + lane;
-      if (qc < NC) {
+      {
+        const bool live = qc < NC;
         int q = qc >> 2, corner = qc & 3;
         int ei = q / orient, rot = q - ei * orient;
-        K ek = l.ems_a[ei];
+        K ek = live ? l.ems_a[ei] : (K)0;
         int dx = P::get(ek, 3) - P::get(ek, 0), dy = P::get(ek, 4) - P::get(ek, 1), dz = P::get(ek, 5) - P::get(ek, 2);
         int x, y, z, mh;
         long long under;
         heur_rot(b0, b1, b2, rot, x, y, z);
         int lx = (corner & 1) ? P::get(ek, 3) - x : P::get(ek, 0);
         int ly = (corner & 2) ? P::get(ek, 4) - y : P::get(ek, 1);
-        if (dx >= x && dy >= y && dz >= z && probe(x, y, z, lx, ly, mh, under)) {
+        if (probe(live && dx >= x && dy >= y && dz >= z, x, y, z, lx, ly, mh, under)) {
           const uint32_t foot = ((y >= 32 ? 0u : (1u << y)) - 1u) << ly;
           uint32_t score = 0;
           for (int lv = 0; lv < mh; lv++) {
@@ -1600,19 +1648,20 @@ __device__ inline bool heur_choose(const DiscreteParams& p, int e, Lds<K, BITS>&
   for (int base = 0; base < NQ; base += 64) {
     int q = base + lane;
     uint32_t sc = 0xFFFFFFFFu;
-    if (q < NQ) {
+    {
+      const bool live = q < NQ;
       int ei = q / orient, rot = q - ei * orient;
-      K ek = l.ems_a[ei];
+      K ek = live ? l.ems_a[ei] : (K)0;
       int dx = P::get(ek, 3) - P::get(ek, 0), dy = P::get(ek, 4) - P::get(ek, 1), dz = P::get(ek, 5) - P::get(ek, 2);
       int x, y, z, mh;
       long long under;
       heur_rot(b0, b1, b2, rot, x, y, z);
       int lx = P::get(ek, 0), ly = P::get(ek, 1);
-      if (dx >= x && dy >= y && dz >= z && probe(x, y, z, lx, ly, mh, under)) {
+      if (probe(live && dx >= x && dy >= y && dz >= z, x, y, z, lx, ly, mh, under)) {
         int ex = max(lx + x, maxX) - min(lx, minX), ey = max(ly + y, maxY) - min(ly, minY);
         sc = (uint32_t)(ex * ey + (mh + z) * ey + (mh + z) * ex);
       }
-      scratch[q] = sc;
+      if (live) scratch[q] = sc;
     }
     smin = sc < smin ? sc : smin;
   }
@@ -1688,32 +1737,28 @@ __device__ inline bool transition(const DiscreteParams& p, int e, Lds<K, BITS>& 
       ok = !(lx + x > p.W || ly + y > p.Ly) && !(max_h + z > p.H);
     }
   }
-  if (STAB && ok && r.n_boxes < p.I && max_h != 0) {
-    // check_box :450-451: box_now.calculated_impact() -- one lane walks the support graph and
-    // commits the new shares / stacks (the box is only kept if the verdict is True)
+  if (STAB && ok && r.n_boxes < p.I) {
+    // check_box :447-454: box_now.calculated_impact() -- one lane records the new box in the LDS-resident stability
+    // state, walks the support graph and commits the new shares / stacks (the box is only kept if the verdict is True;
+    // a box on the floor is recorded and accepted without a walk)
     if (lane == 0) l.box[r.n_boxes] = P::pack(lx, ly, max_h, lx + x, ly + y, max_h + z);
     __syncthreads();
-    int verdict = 1, serr = 0;
+    int rc = 1, ne = 0, npv = 0, ill_i = 0;
     if (lane == 0) {
       BoxGeo<K, BITS> geo{l.box};
-      StabState st = stab_view(p, e);
-      bool err;
-      verdict = stab_commit<false>(geo, st, r.n_boxes, item_den, err) ? 1 : 0;
-      serr = err ? 1 : 0;
+      bool ill = false;
+      rc = stab_commit<false>(geo, l.st, r.n_boxes, item_den, l.sw.hull, l.sw.hull_bytes, ill);
+      ne = l.st.n_ent;
+      npv = l.st.n_poly;
+      ill_i = ill ? 1 : 0;
     }
-    verdict = __shfl(verdict, 0, 64);
-    if (__shfl(serr, 0, 64)) r.flags |= PCT_FLAG_STABILITY_OVERFLOW;
-    ok = verdict != 0;
-  } else if (STAB && ok && r.n_boxes < p.I) {
-    // resting on the floor: no supporters, stack = own (still recorded for later checks)
-    if (lane == 0) l.box[r.n_boxes] = P::pack(lx, ly, max_h, lx + x, ly + y, max_h + z);
+    rc = __shfl(rc, 0, 64);
+    l.st.n_ent = __shfl(ne, 0, 64);
+    l.st.n_poly = __shfl(npv, 0, 64);
+    if (__shfl(ill_i, 0, 64)) r.flags |= PCT_FLAG_ILL_CONDITIONED;
+    if (rc < 0) r.stab_over |= STAB_WHY_COMMIT;
+    ok = rc == 1;
     __syncthreads();
-    if (lane == 0) {
-      BoxGeo<K, BITS> geo{l.box};
-      StabState st = stab_view(p, e);
-      bool err;
-      stab_commit<false>(geo, st, r.n_boxes, item_den, err);
-    }
   }
   if (ok && r.n_boxes >= p.I) {  // IndexError at D/space.py:385
     ok = false;
@@ -1841,11 +1886,18 @@ __device__ inline void discrete_env_steps(const DiscreteParams& p, const void* _
   // its state is stored here, and whatever outputs it already wrote are written again, identically up to the
   // point of the overflow and correctly beyond, by the retry.
   const uint32_t flags_in = r.flags;
-  const bool can_retry = p.retry_count != nullptr && !p.retry_mode && !STAB;
+  // (The stability settings take part since round 3: their state is LDS-resident during the transition, so a requeued
+  // env has left nothing of a half-done commit behind.  A stability capacity -- pools, hull workspace, task queue --
+  // that is exceeded requeues the env likewise; only where no larger pass exists does it raise the flag.)
+  const bool can_retry = p.retry_count != nullptr && !p.retry_mode;
   auto overflowed = [&]() -> bool {
-    return can_retry && ((r.flags & ~flags_in) & (PCT_FLAG_EMS_OVERFLOW | PCT_FLAG_CANDIDATE_OVERFLOW)) != 0;
+    if (STAB && r.stab_over && !can_retry) {
+      r.flags |= PCT_FLAG_STABILITY_OVERFLOW | r.stab_over;
+      r.stab_over = 0;
+    }
+    return can_retry && ((((r.flags & ~flags_in) & (PCT_FLAG_EMS_OVERFLOW | PCT_FLAG_CANDIDATE_OVERFLOW)) != 0) || (STAB && r.stab_over));
   };
-  if (can_retry && r.n_ems > p.ems_cap && ACT != ACT_RESET) {
+  if (can_retry && ((r.n_ems > p.ems_cap && ACT != ACT_RESET) || (STAB && r.stab_over && ACT != ACT_RESET))) {
     if (lane == 0) p.retry_ids[atomicAdd(p.retry_count, 1)] = e;
     return;
   }
@@ -1869,9 +1921,9 @@ __device__ inline void discrete_env_steps(const DiscreteParams& p, const void* _
     bool bad = false, zero_row = false, giveup = false;
     int flag = 0, lx = 0, ly = 0, bx = 0, by = 0, bz = 0;
     if (ACT == ACT_HEUR) {
-      bool serr = false;
+      uint32_t serr = 0;
       giveup = !heur_choose<K, BITS, STAB>(p, e, l, r, lane, row_len, lx, ly, bx, by, bz, serr);
-      if (STAB && __ballot(serr)) r.flags |= PCT_FLAG_STABILITY_OVERFLOW;
+      if (STAB) r.stab_over |= serr;
     } else if (ACT == ACT_ROWS) {
       float v = act_v;
       float a0 = __shfl(v, 0, 64), a1 = __shfl(v, 1, 64), a2 = __shfl(v, 2, 64), a3 = __shfl(v, 3, 64),
@@ -1950,21 +2002,19 @@ pct_discrete_kernel(DiscreteParams p, const void* __restrict__ actions,
 namespace pct {
 
 inline size_t discrete_lds_bytes_impl(const DiscreteParams& p) {
-  size_t k = p.key_bytes;
-  size_t n = (size_t)table_words_compact((uint32_t)p.cand_cap) + p.ems_cap + discrete_scratch_words(p) + p.I + p.L;
-  size_t hb = ((size_t)p.AA * (k == 4 ? 1 : 2) + 3) & ~(size_t)3;
-  size_t cp = (size_t)discrete_scheme_words(p) * sizeof(uint32_t);
-  if (p.shuffle && !p.rng_numpy) cp += ((size_t)(p.cand_cap * 3) / 5 + 4) * (sizeof(uint32_t) + k);
-  if (p.rng_numpy) cp += 624 * sizeof(uint32_t);
-  return n * k + hb + 64 * sizeof(uint16_t) + cp;
+  size_t b = discrete_lds_base_bytes(p);
+  if (p.setting != 2) b += ((stab_state_bytes(p.I, p.sb.caps) + 15) & ~(size_t)15) + stab_wave_bytes(p.sb.caps);
+  return b;
 }
 
-template <typename K, int BITS>
+// STAB selects the half of the instantiations a translation unit carries: the setting-2 kernels (false) or the
+// stability-check kernels of settings 1 / 3 (true) -- four translation units (u32 / u64 keys x plain / stability)
+// compile in parallel
+template <typename K, int BITS, bool STAB>
 inline hipError_t launch_typed(const DiscreteParams& p, int act, const void* actions, int row_len, int n_steps,
                                const int32_t* env_ids, int n_ids, hipStream_t stream) {
   size_t lds = discrete_lds_bytes_impl(p);
   const bool timed = p.timing != nullptr && act != ACT_RESET;
-  const bool stab = p.setting != 2;
   const int scheme = p.lnes == PCT_LNES_EMS ? 0 : 1;  // 1: every other expansion, dispatched inside the kernel
   int grid = p.retry_mode ? n_ids : ((act == ACT_RESET && env_ids) ? n_ids : p.N);
   if (grid <= 0) return hipSuccess;
@@ -1974,10 +2024,8 @@ inline hipError_t launch_typed(const DiscreteParams& p, int act, const void* act
 #define PCT_LAUNCH(A)                                                                                        \
   do {                                                                                                       \
     void (*kern)(DiscreteParams, const void*, int, int, const int32_t*, int);                                \
-    if (stab) kern = scheme == 1 ? PCT_KERN(A, false, true, 1)                                               \
-                                 : (timed ? PCT_KERN(A, true, true, 0) : PCT_KERN(A, false, true, 0));       \
-    else if (scheme == 1) kern = PCT_KERN(A, false, false, 1);                                               \
-    else kern = timed ? PCT_KERN(A, true, false, 0) : PCT_KERN(A, false, false, 0);                          \
+    if (scheme == 1) kern = PCT_KERN(A, false, STAB, 1);                                                     \
+    else kern = timed ? PCT_KERN(A, true, STAB, 0) : PCT_KERN(A, false, STAB, 0);                            \
     if (lds > 48 * 1024) {                                                                                   \
       hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                               \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
@@ -1987,10 +2035,8 @@ inline hipError_t launch_typed(const DiscreteParams& p, int act, const void* act
   } while (0)
   if (act == ACT_HEUR) {  // heuristic policies read the EMS list: LNES == EMS only (checked by the caller)
     void (*kern)(DiscreteParams, const void*, int, int, const int32_t*, int);
-    if (stab) kern = p.shuffle ? pct_discrete_kernel<K, BITS, ACT_HEUR, false, true, 0, 1>
-                               : pct_discrete_kernel<K, BITS, ACT_HEUR, false, true, 0, 0>;
-    else kern = p.shuffle ? pct_discrete_kernel<K, BITS, ACT_HEUR, false, false, 0, 1>
-                          : pct_discrete_kernel<K, BITS, ACT_HEUR, false, false, 0, 0>;
+    kern = p.shuffle ? pct_discrete_kernel<K, BITS, ACT_HEUR, false, STAB, 0, 1>
+                     : pct_discrete_kernel<K, BITS, ACT_HEUR, false, STAB, 0, 0>;
     if (lds > 48 * 1024) {
       hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (er != hipSuccess) return er;

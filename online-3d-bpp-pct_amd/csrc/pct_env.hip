@@ -43,6 +43,7 @@ struct pct_env {
   int cp_retry_blocks;
   bool has_dretry;      /* discrete env: large-capacity retry pass for envs that outgrow the LDS lists */
   int d_retry_ems, d_retry_cand;
+  pct::StabCaps d_retry_stab; /* stability pools / workspace / queue of the retry pass (settings 1 / 3) */
   int* d_retry_base;    /* [2] ping-pong queue counters */
   int d_retry_parity;
   int* c_retry_base;    /* continuous env: the same */
@@ -163,6 +164,7 @@ int launch(pct_env* h, int act, const void* actions, int row_len, int n_steps, c
       pct::DiscreteParams q = h->dp;
       q.ems_cap = h->d_retry_ems;
       q.cand_cap = h->d_retry_cand;
+      q.sb.caps = h->d_retry_stab;
       q.retry_mode = h->d_retry_parity ? -1 : 1;
       q.timing = nullptr;
       HIP_TRY(pct::launch_discrete(q, act, actions, row_len, n_steps, nullptr, 16, s));
@@ -171,6 +173,31 @@ int launch(pct_env* h, int act, const void* actions, int row_len, int n_steps, c
     if (act != ACT_RESET || !ids) h->dp.full_obs = 0; /* every env has rewritten its rows */
   }
   return PCT_OK;
+}
+/* Stability capacities (pct_stab.cuh).  Normal pass: what the episodes of the reference's item domains need with a
+ * margin (measured: at most 2.1 pool entries and 4.4 polygon vertices per placed box at 80 boxes), a hull workspace for
+ * 32 two-supporter candidates per round and a queue of 160 walk tasks (half of it the reserve of the depth-first mode) -- sized so that a 10^3 / 80-box env stays below
+ * 40 KiB of LDS (four resident envs per CU).  Retry pass: eight entries / sixteen vertices per box, a workspace that
+ * takes a box on 120 supporters and 512 tasks. */
+void stab_default_caps(int I, pct::StabCaps& normal, pct::StabCaps& retry) {
+  normal.SP = (5 * I) / 2 < 64 ? 64 : (5 * I) / 2;
+  normal.PP = 5 * I < 128 ? 128 : 5 * I;
+  normal.ws_bytes = 32 * pct::stab_ws_need(2);
+  normal.queue = 160;
+  retry.SP = 8 * I < 4094 ? 8 * I : 4094;
+  retry.PP = 16 * I < 65535 ? 16 * I : 65535;
+  retry.ws_bytes = 16 * 1024;
+  retry.queue = 512;
+  /* kernel experiments only: PCT_STAB_SP / _PP / _WS / _Q override the normal pass */
+  const char* e;
+  if ((e = getenv("PCT_STAB_SP"))) normal.SP = atoi(e);
+  if ((e = getenv("PCT_STAB_PP"))) normal.PP = atoi(e);
+  if ((e = getenv("PCT_STAB_WS"))) normal.ws_bytes = atoi(e);
+  if ((e = getenv("PCT_STAB_Q"))) normal.queue = atoi(e);
+  if (retry.SP < normal.SP) retry.SP = normal.SP;
+  if (retry.PP < normal.PP) retry.PP = normal.PP;
+  if (retry.ws_bytes < normal.ws_bytes) retry.ws_bytes = normal.ws_bytes;
+  if (retry.queue < normal.queue) retry.queue = normal.queue;
 }
 bool is_cand_cap_ok(int c) {
   for (int s = 8; s <= (1 << 20); s <<= 2)
@@ -281,6 +308,12 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
     c.env_id_base = cfg->env_id_base;
     c.source = PCT_ITEMS_NONE;
     if ((size_t)ems_cap * 24 + 23 > 65535) { delete h; return fail(PCT_ERR_INVALID_ARG, "ems_capacity too large for 16-bit generator ids"); }
+    pct::StabCaps retry_stab = c.sb.caps;
+    if (cfg->setting != 2) {
+      stab_default_caps(c.I, c.sb.caps, retry_stab);
+      c.sb.sp_stride = retry_stab.SP;
+      c.sb.pp_stride = retry_stab.PP;
+    }
     size_t clds = pct::continuous_lds_bytes(c);
     if (clds > 160 * 1024) { delete h; return fail(PCT_ERR_INVALID_ARG, "capacities need %zu B of LDS (> 160 KiB)", clds); }
     size_t Nn = (size_t)c.N;
@@ -312,14 +345,13 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
     CALLOC_(c.volsum, Nn * sizeof(double));
     CALLOC_(c.bsz, Nn * 3 * c.I * sizeof(double));
     if (cfg->setting != 2) {
-      CALLOC_(c.st_stack, Nn * c.I * 4 * sizeof(double));
-      CALLOC_(c.st_nsup, Nn * c.I * sizeof(int));
-      CALLOC_(c.st_sup, Nn * c.I * pct::STAB_SMAX * sizeof(int));
-      CALLOC_(c.st_share, Nn * c.I * pct::STAB_SMAX * 4 * sizeof(double));
-      CALLOC_(c.st_npoly, Nn * c.I * sizeof(int));
-      CALLOC_(c.st_poly, Nn * c.I * pct::STAB_PMAX * 2 * sizeof(double));
-      CALLOC_(c.st_den, Nn * c.I * sizeof(double));
-      CALLOC_(c.st_alias, Nn * c.I * sizeof(int));
+      CALLOC_(c.sb.stk, Nn * c.I * 4 * sizeof(double));
+      CALLOC_(c.sb.den, Nn * c.I * sizeof(double));
+      CALLOC_(c.sb.share, Nn * c.sb.sp_stride * 4 * sizeof(double));
+      CALLOC_(c.sb.poly, Nn * c.sb.pp_stride * 2 * sizeof(double));
+      CALLOC_(c.sb.meta, Nn * c.I * 2 * sizeof(uint32_t));
+      CALLOC_(c.sb.up, Nn * c.I * sizeof(uint32_t));
+      CALLOC_(c.sb.ent, Nn * c.sb.sp_stride * sizeof(uint32_t));
     }
     if (c.table_global) {
       CALLOC_(c.gtab, Nn * (size_t)(cand_cap + cand_cap / 4) * sizeof(uint32_t));
@@ -354,6 +386,15 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
       q.order_cap = (big * 3) / 5 + 8;
       q.ems_cap = c.ems_stride;
       q.union_words = 12 * q.ems_cap > 192 ? 12 * q.ems_cap : 192; /* children scratch only: 2 * ems_cap of them */
+      if (cfg->setting != 2) { /* larger stability pools / workspace / queue, as far as the LDS of that pass goes */
+        q.sb.caps = retry_stab;
+        while (pct::continuous_lds_bytes(q) > 160 * 1024 && q.sb.caps.SP > c.sb.caps.SP) {
+          q.sb.caps.SP = (q.sb.caps.SP * 3) / 4 > c.sb.caps.SP ? (q.sb.caps.SP * 3) / 4 : c.sb.caps.SP;
+          q.sb.caps.PP = (q.sb.caps.PP * 3) / 4 > c.sb.caps.PP ? (q.sb.caps.PP * 3) / 4 : c.sb.caps.PP;
+          q.sb.caps.queue = (q.sb.caps.queue * 3) / 4 > c.sb.caps.queue ? (q.sb.caps.queue * 3) / 4 : c.sb.caps.queue;
+        }
+        if (pct::continuous_lds_bytes(q) > 160 * 1024) { pct_destroy(h); return fail(PCT_ERR_INVALID_ARG, "the retry pass does not fit the LDS"); }
+      }
       CALLOC_(q.gtab, (size_t)RB * (size_t)(big + big / 4) * sizeof(uint32_t));
       CALLOC_(q.gorder, (size_t)RB * (size_t)q.order_cap * sizeof(uint16_t));
       if (c.shuffle) CALLOC_(q.gfpri, (size_t)RB * (size_t)q.order_cap * sizeof(uint32_t));
@@ -397,8 +438,27 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
     t.cand_cap = h->d_retry_cand;
     if (pct::discrete_lds_bytes(t) > 160 * 1024) h->d_retry_ems = ems_cap;
   }
-  h->has_dretry = cfg->setting == 2 && cfg->reserved[0] != PCT_OVERFLOW_RETRY_OFF &&
-                  (h->d_retry_ems > ems_cap || h->d_retry_cand > cand_cap);
+  /* stability settings: pool / workspace / queue capacities of the normal pass and of the retry pass (pct_stab.cuh) */
+  h->d_retry_stab = p.sb.caps;
+  if (cfg->setting != 2) {
+    stab_default_caps(p.I, p.sb.caps, h->d_retry_stab);
+    pct::DiscreteParams t = p;
+    t.ems_cap = h->d_retry_ems;
+    t.cand_cap = h->d_retry_cand;
+    t.sb.caps = h->d_retry_stab;
+    while (pct::discrete_lds_bytes(t) > 160 * 1024 && t.sb.caps.SP > p.sb.caps.SP) {  /* shrink until the pass fits */
+      t.sb.caps.SP = (t.sb.caps.SP * 3) / 4 > p.sb.caps.SP ? (t.sb.caps.SP * 3) / 4 : p.sb.caps.SP;
+      t.sb.caps.PP = (t.sb.caps.PP * 3) / 4 > p.sb.caps.PP ? (t.sb.caps.PP * 3) / 4 : p.sb.caps.PP;
+      t.sb.caps.queue = (t.sb.caps.queue * 3) / 4 > p.sb.caps.queue ? (t.sb.caps.queue * 3) / 4 : p.sb.caps.queue;
+    }
+    if (pct::discrete_lds_bytes(t) > 160 * 1024) { h->d_retry_ems = ems_cap; h->d_retry_cand = cand_cap; t.sb.caps = p.sb.caps; }
+    h->d_retry_stab = t.sb.caps;
+    p.sb.sp_stride = h->d_retry_stab.SP;
+    p.sb.pp_stride = h->d_retry_stab.PP;
+  }
+  h->has_dretry = cfg->reserved[0] != PCT_OVERFLOW_RETRY_OFF &&
+                  (h->d_retry_ems > ems_cap || h->d_retry_cand > cand_cap ||
+                   (cfg->setting != 2 && (h->d_retry_stab.SP > p.sb.caps.SP || h->d_retry_stab.queue > p.sb.caps.queue)));
   p.ems_stride = h->has_dretry ? h->d_retry_ems : ems_cap;
   p.env_id_base = cfg->env_id_base;
   p.source = PCT_ITEMS_NONE;
@@ -418,14 +478,13 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
   ALLOC(p.leaves, N * p.L * p.key_bytes);
   ALLOC(p.scalars, N * PCT_SCALARS * sizeof(int32_t));
   if (cfg->setting != 2) {
-    ALLOC(p.st_stack, N * p.I * 4 * sizeof(double));
-    ALLOC(p.st_nsup, N * p.I * sizeof(int));
-    ALLOC(p.st_sup, N * p.I * pct::STAB_SMAX * sizeof(int));
-    ALLOC(p.st_share, N * p.I * pct::STAB_SMAX * 4 * sizeof(double));
-    ALLOC(p.st_npoly, N * p.I * sizeof(int));
-    ALLOC(p.st_poly, N * p.I * pct::STAB_PMAX * 2 * sizeof(double));
-    ALLOC(p.st_den, N * p.I * sizeof(double));
-    ALLOC(p.st_alias, N * p.I * sizeof(int));
+    ALLOC(p.sb.stk, N * p.I * 4 * sizeof(double));
+    ALLOC(p.sb.den, N * p.I * sizeof(double));
+    ALLOC(p.sb.share, N * p.sb.sp_stride * 4 * sizeof(double));
+    ALLOC(p.sb.poly, N * p.sb.pp_stride * 2 * sizeof(double));
+    ALLOC(p.sb.meta, N * p.I * 2 * sizeof(uint32_t));
+    ALLOC(p.sb.up, N * p.I * sizeof(uint32_t));
+    ALLOC(p.sb.ent, N * p.sb.sp_stride * sizeof(uint32_t));
   }
   if (h->has_dretry) {
     ALLOC(h->d_retry_base, 2 * sizeof(int));
@@ -738,15 +797,7 @@ int pct_step_hash_policy(pct_env* h, int32_t n_steps, void* stream) {
   int rc = ready(h, true);
   if (rc) return rc;
   if (n_steps < 1) return fail(PCT_ERR_INVALID_ARG, "n_steps must be >= 1");
-  if (h->cfg.setting != 2) {
-    /* the stability state is written by one lane and read by the others through HBM: one
-     * launch per step keeps those reads behind a kernel boundary */
-    for (int i = 0; i < n_steps; i++) {
-      rc = launch(h, ACT_HASH, nullptr, 0, 1, nullptr, 0, stream);
-      if (rc) return rc;
-    }
-    return PCT_OK;
-  }
+  /* (the stability state is LDS-resident during a launch since round 3: n steps in one launch under every setting) */
   return launch(h, ACT_HASH, nullptr, 0, n_steps, nullptr, 0, stream);
 }
 
@@ -767,13 +818,7 @@ int pct_step_heuristic(pct_env* h, int32_t kind, int32_t n_steps, void* stream) 
    * the LDS layout of that mode carries the MT19937 state where their shuffle arrays would lie (include/pct_env.h) */
   if (h->dp.rng_numpy)
     return fail(PCT_ERR_UNSUPPORTED, "the heuristic policies are not available in strict NumPy-stream mode (pct_set_numpy_rng)");
-  /* one launch per step when the stability state is live (see pct_step_hash_policy) */
-  const int per = h->cfg.setting != 2 ? 1 : n_steps;
-  for (int done = 0; done < n_steps; done += per) {
-    rc = launch(h, ACT_HEUR, nullptr, kind, per, nullptr, 0, stream);
-    if (rc) return rc;
-  }
-  return PCT_OK;
+  return launch(h, ACT_HEUR, nullptr, kind, n_steps, nullptr, 0, stream);
 }
 
 int pct_policy_hash_rows(pct_env* h, float* rows_out, void* stream) {

@@ -1,86 +1,125 @@
-// pct_stab.cuh -- the reference's stability check (settings 1 / 3) restructured for one GPU
-// lane per candidate: no recursion, no per-box dictionaries, no hidden state.
+// pct_stab.cuh -- the reference's stability check (settings 1 / 3) restructured for a 64-lane wavefront that owns one
+// environment: no recursion, no per-box dictionaries, no per-lane walk stacks.
 //
-// Reference (D/ = pct_envs/PctDiscrete0/): Box.calculate_new_com D/space.py:51-71,
-// calculated_impact :73-164, calculated_impact_virtual :166-267, scale_down :341-345, supporter
-// search :358-379 / :405-426, check_box :447-454; ConvexHull / Line2D.orientation /
-// point_in_polygen D/convex_hull.py:4-112.
+// Reference (D/ = pct_envs/PctDiscrete0/): Box.calculate_new_com D/space.py:51-71, calculated_impact :73-164,
+// calculated_impact_virtual :166-267, scale_down :341-345, supporter search :358-379 / :405-426, check_box :447-454;
+// ConvexHull / Line2D.orientation / point_in_polygen D/convex_hull.py:4-112.  (C/ = PctContinuous0: the same code with
+// 1e-6 margins and rounded contact rectangles.)
 //
-// What is stored per placed box b (HBM, per env): its committed stack `stack[b]` (centre xyz,
-// mass), its supporters `sup[b][i]` in bottom_edges order, the share it hands each of them
-// `share[b][i]` and its scaled support polygon.  Everything else is recomputed:
-//   * S.up_edges (a dict keyed by boxes, iterated in insertion order) == the boxes that list S
-//     as a supporter, in ascending id (a key is first inserted when that box is committed), so
-//     calculate_new_com(S) is a scan over the boxes above S reading share[B][idx(S)];
-//   * up_edges entries shared BY REFERENCE: with one supporter, or for the "direct" supporter, the reference
-//     stores the box's own thisStack OBJECT in the supporter's up_edges (D/space.py:80,96) and
-//     calculate_new_com later mutates it in place (:67-71) -- such an entry always reads as the box's
-//     CURRENT committed stack.  `alias[b]` = index of the supporter that holds b's stack by reference (or -1);
-//     stab_com reads stack[b] instead of share[b][alias[b]].  This only matters inside a commit walk (a box
-//     with >= 2 supporters recomputes all of them before it visits the first), where it changes verdicts;
-//   * of S.up_virtual_edges only the entry of the currently `involved` parent is ever read and
-//     it is written just before; `involved` == "on the active path";
-//   * a supporter's virtual stack is recomputed when it is visited instead of when its parent
-//     distributes: nothing it depends on can change in between (siblings' subtrees lie strictly
-//     below the parent and never contain a sibling).
-// The control flow (first False anywhere aborts everything) makes the recursion an iterative
-// depth-first walk with a small explicit stack.
+// Round 3 layout.  The per-env stability state is COMPACT and LDS-RESIDENT for the whole transition (loaded from /
+// stored to its HBM mirror by the kernels): per placed box b its committed stack `stk[b]` (centre xyz, mass), its
+// density, a supporter list and a scaled support polygon of exactly the lengths it needs in two append-only POOLS, and
+// -- what replaces the reference's `up_edges` dictionaries -- for every (box B, supporter S) pair one pool ENTRY that
+// carries the share B hands S and is chained into S's UP-LIST in the order the entries are created.  A key is first
+// inserted into S.up_edges when box B is committed, so that order is ascending B: iterating S's up-list IS iterating
+// the dict, and calculate_new_com(S) costs as many steps as S carries boxes, not a scan over every box above it.
+//   * up_edges entries shared BY REFERENCE: with one supporter, or for the "direct" supporter, the reference stores the
+//     box's own thisStack OBJECT in the supporter's up_edges (D/space.py:80,96) and calculate_new_com later mutates it
+//     in place (:67-71) -- such an entry always reads as the box's CURRENT committed stack.  `alias(b)` = index of the
+//     supporter that holds b's stack by reference (or none); stab_com reads stk[b] instead of the entry's share.
+//   * of S.up_virtual_edges only the entry of the currently `involved` parent is ever read and it is written just
+//     before.  Among the boxes on the active path only the PARENT can appear in S's up-list (an ancestor further up
+//     rests strictly higher than S's top), so "skip the involved boxes" is "skip the parent's entry".
+//   * the virtual check of a candidate (calculated_impact_virtual(first=True)) has no side effect and its verdict is the
+//     AND of one point-in-polygon test per visited (path, box): the visits are independent TASKS -- (candidate, box S,
+//     parent P, the virtual stack S receives) -- that a wave pops 64 at a time from an LDS queue; every task pushes one
+//     child per supporter of S.  The level-0 task of a candidate finds its supporters, builds its hull in a small
+//     per-lane LDS workspace and pushes its children.  Nothing of a walk lives in scratch memory.
+//   * the commit of the placed box (calculated_impact) is order dependent and stays sequential (one lane), on the same
+//     LDS state, its depth-first stack and hull workspace in LDS as well.
+// Capacities (pool entries, polygon vertices, workspace, queue) are run-time parameters of a launch; exceeding one
+// makes the caller requeue the env -- state untouched, because nothing is stored before the transition is complete --
+// for the large-capacity retry pass.
 //
-// The same source compiles for the host (tests/host/stab_host.cpp) so that the restructured
-// algorithm is checked against the oracle and the reference fixtures on the CPU as well.
+// The same source compiles for the host (tests/host/stab_host.cpp) so that the restructured algorithm is checked
+// against the oracle and the reference fixtures on the CPU as well.
 #ifndef PCT_STAB_CUH
 #define PCT_STAB_CUH
 #include <math.h>
 #include <stdint.h>
 
 #if defined(__HIPCC__)
-#define PCT_SD __device__ inline
+#define PCT_SD __device__ __forceinline__
+#define PCT_HD __host__ __device__ inline
+#define PCT_SM __device__ __forceinline__
 #else
 #define PCT_SD static inline
-#endif
-
-// 1: the least-squares split of up to five supporters runs fully unrolled in registers (stab_lstsq_fixed).  The strict
-// NumPy-stream build of the continuous kernels (pct_continuous_mt.hip) sets 0 and keeps the generic solve: with the
-// unrolled one its setting-1 kernel died with a GPU fault that the other builds of the same code do not show (round 2,
-// profiles/r02_stability_experiments.txt); same results either way.
-#ifndef PCT_STAB_FIXED_SOLVE
-#define PCT_STAB_FIXED_SOLVE 1
+#define PCT_HD static inline
+#define PCT_SM inline
 #endif
 
 namespace pct {
 
-constexpr int STAB_SMAX = 16;   // supporters per box kept (more -> PCT_FLAG_STABILITY_OVERFLOW)
-constexpr int STAB_LSQ = 8;     // supporters the least-squares split handles
-constexpr int STAB_PMAX = 24;   // hull vertices kept
-constexpr int STAB_DEPTH = 24;  // explicit stack depth
+constexpr int STAB_LSQ = 8;          // supporters the least-squares split handles (more: capacity error)
+constexpr int STAB_NSUP_MAX = 255;   // supporters per box (8-bit count)
+constexpr uint32_t STAB_END = 0xFFFu;  // end of an up-list / "no parent"
+constexpr uint32_t STAB_NOBOX = 0x3FFu;
+// why a capacity error was raised (kept in the env's flag word next to PCT_FLAG_STABILITY_OVERFLOW, include/pct_env.h)
+constexpr uint32_t STAB_WHY_QUEUE = 0x100u;     // one task's children do not fit the walk queue
+constexpr uint32_t STAB_WHY_WS = 0x200u;        // a candidate's hull does not fit the workspace / > 255 supporters
+constexpr uint32_t STAB_WHY_HULL = 0x400u;      // a hull of more than 255 vertices
+constexpr uint32_t STAB_WHY_SPLIT = 0x800u;     // more than STAB_LSQ supporters and none of them direct
+constexpr uint32_t STAB_WHY_COMMIT = 0x1000u;   // the commit: pools, workspace or depth-first stack
+constexpr uint32_t STAB_WHY_LOAD = 0x2000u;     // the stored state does not fit this launch's pools
 
-// per-env view of the stability state; geometry via `geo(i, g)` -> lx,ly,lz,xe,ye,ze,sx,sy,sz
-// (the sizes are carried explicitly: in float64 (lx + x) - lx need not equal x)
-struct StabState {
-  int I;           // internal_node_holder (row stride)
-  double* stack;   // [I][4]
-  int* nsup;       // [I]
-  int* sup;        // [I][STAB_SMAX]
-  double* share;   // [I][STAB_SMAX][4]
-  int* npoly;      // [I]
-  double* poly;    // [I][STAB_PMAX][2]
-  double* den;     // [I] density of each placed box (setting 3; 1.0 otherwise), D/space.py:38
-  int* alias;      // [I] supporter index whose up_edges entry is this box's thisStack object itself, or -1
+// capacities of one launch (LDS sizes follow from them: stab_state_bytes / stab_ws_bytes)
+struct StabCaps {
+  int SP;       // share / supporter pool entries (sum of supporter counts over the placed boxes), <= 4094
+  int PP;       // polygon pool vertices
+  int ws_bytes;  // hull workspace (level-0 candidates of a round / the commit's hull and depth-first stack)
+  int queue;     // walk tasks the LDS queue holds
 };
 
-struct StabBox {  // a box being examined (candidate or placed), with its supporters
-  double g[9];    // lx,ly,lz,xe,ye,ze,sx,sy,sz
-  int nsup;
-  int sup[STAB_SMAX];
-  // the contact rectangle with supporter k is recomputed where it is needed (stab_area: two box rows from LDS and a
-  // dozen flops) rather than carried here: per-lane arrays that are indexed at run time live in scratch memory, and
-  // every access to them is a memory round trip
+// per-env stability state: pointers into LDS (device) or host memory
+struct StabState {
+  double* stk;     // [I][4] committed stack of every placed box
+  double* den;     // [I] density (setting 3; 1.0 otherwise), D/space.py:38
+  uint32_t* meta;  // [I][2]: [0] = nsup | (alias + 1) << 8 | npoly << 16, [1] = soff | poff << 16
+  uint32_t* up;    // [I] up-list head | tail << 16 (STAB_END: empty)
+  uint32_t* ent;   // [SP] supporter S | owner B << 10 | next << 20
+  double* share;   // [SP][4] the share entry j hands its supporter
+  double* poly;    // [PP][2] scaled support polygons
+  int SP, PP;
+  int n_ent, n_poly;  // used pool entries / vertices
+};
+PCT_SD int stab_nsup(const StabState& st, int b) { return (int)(st.meta[2 * b] & 0xFFu); }
+PCT_SD int stab_alias(const StabState& st, int b) { return (int)((st.meta[2 * b] >> 8) & 0xFFu) - 1; }
+PCT_SD int stab_npoly(const StabState& st, int b) { return (int)((st.meta[2 * b] >> 16) & 0xFFu); }
+PCT_SD int stab_soff(const StabState& st, int b) { return (int)(st.meta[2 * b + 1] & 0xFFFFu); }
+PCT_SD int stab_poff(const StabState& st, int b) { return (int)(st.meta[2 * b + 1] >> 16); }
+
+PCT_HD size_t stab_state_bytes(int I, const StabCaps& c) {
+  return (size_t)I * (4 + 1) * sizeof(double) + (size_t)I * 3 * sizeof(uint32_t) + (size_t)c.SP * (sizeof(uint32_t) + 4 * sizeof(double)) +
+         (size_t)c.PP * 2 * sizeof(double);
+}
+// carve the state out of a 16-byte aligned region (doubles first)
+PCT_SD StabState stab_carve(unsigned char* base, int I, const StabCaps& c) {
+  StabState st;
+  double* d = reinterpret_cast<double*>(base);
+  st.stk = d; d += (size_t)I * 4;
+  st.den = d; d += I;
+  st.share = d; d += (size_t)c.SP * 4;
+  st.poly = d; d += (size_t)c.PP * 2;
+  uint32_t* w = reinterpret_cast<uint32_t*>(d);
+  st.meta = w; w += (size_t)I * 2;
+  st.up = w; w += I;
+  st.ent = w;
+  st.SP = c.SP; st.PP = c.PP;
+  st.n_ent = 0; st.n_poly = 0;
+  return st;
+}
+
+// supporter ids of a box: the low 10 bits of consecutive 32-bit words -- the pool entries of a placed box, or the id
+// list a box under examination keeps in its workspace
+struct StabSup {
+  const uint32_t* w;
+  PCT_SM int operator()(int i) const { return (int)(w[i] & 0x3FFu); }
 };
 
 // ---- D/convex_hull.py ---------------------------------------------------------------------
-PCT_SD double stab_slope(const double* p1, const double* p2) {
-  if (p2[0] != p1[0]) return (p2[1] - p1[1]) / (p2[0] - p1[0]);
-  return (p2[1] - p1[1]) * INFINITY;
+PCT_SD double stab_slope(double p1x, double p1y, double p2x, double p2y) {
+  if (p2x != p1x) return (p2y - p1y) / (p2x - p1x);
+  return (p2y - p1y) * INFINITY;
 }
 PCT_SD int stab_orientation(double s1, double s2) {
   if (fabs(s1) == INFINITY && fabs(s2) == INFINITY) return 0;
@@ -89,24 +128,26 @@ PCT_SD int stab_orientation(double s1, double s2) {
   else if (diff == 0) return 0;
   return 1;
 }
-// one chain of ConvexHull (:50-63 / :66-83), stale line slopes and collapse-break included
+// one chain of ConvexHull (:50-63 / :66-83), stale line slopes and collapse-break included.  `hull` may be `sorted`
+// itself for the forward chain (the chain never holds more points than it has consumed).
 PCT_SD int stab_chain(const double (*sorted)[2], int n, bool reverse, double (*hull)[2]) {
   int len = 0;
   double s1 = 0, s2 = 0;
   for (int q = 0; q < n; q++) {
-    const double* point = sorted[reverse ? n - 1 - q : q];
+    const int src = reverse ? n - 1 - q : q;
+    const double px = sorted[src][0], py = sorted[src][1];
     if (len >= 2) {
-      s1 = stab_slope(hull[len - 2], hull[len - 1]);
-      s2 = stab_slope(hull[len - 1], point);
+      s1 = stab_slope(hull[len - 2][0], hull[len - 2][1], hull[len - 1][0], hull[len - 1][1]);
+      s2 = stab_slope(hull[len - 1][0], hull[len - 1][1], px, py);
     }
     while (len >= 2 && stab_orientation(s1, s2) != -1) {
       len--;
       if (hull[0][0] == hull[len - 1][0] && hull[0][1] == hull[len - 1][1]) break;
-      s1 = stab_slope(hull[len - 2], hull[len - 1]);
-      s2 = stab_slope(hull[len - 1], point);
+      s1 = stab_slope(hull[len - 2][0], hull[len - 2][1], hull[len - 1][0], hull[len - 1][1]);
+      s2 = stab_slope(hull[len - 1][0], hull[len - 1][1], px, py);
     }
-    hull[len][0] = point[0];
-    hull[len][1] = point[1];
+    hull[len][0] = px;
+    hull[len][1] = py;
     len++;
   }
   return len;
@@ -133,24 +174,24 @@ PCT_SD bool stab_contact(const double* bg, const double* t, double area[4]) {
   area[0] = x1; area[1] = y1; area[2] = x2; area[3] = y2;
   return true;
 }
-
-// contact rectangle of `b` with its k-th supporter
+// contact rectangle of the box with geometry `bg` with placed box `s` (a supporter of it): recomputed where it is
+// needed -- two box rows from LDS and a dozen flops -- rather than carried per box
 template <bool CONT, typename Geo>
-PCT_SD void stab_area(const Geo& geo, const StabBox& b, int k, double area[4]) {
+PCT_SD void stab_area(const Geo& geo, const double bg[9], int s, double area[4]) {
   double t[9];
-  geo(b.sup[k], t);
-  stab_contact<CONT>(b.g, t, area);
+  geo(s, t);
+  stab_contact<CONT>(bg, t, area);
 }
 
-// ConvexHull + scale_down of the 4*nsup contact corners of `b`; returns the vertex count
-// (<= STAB_PMAX, else -1)
-template <bool CONT, typename Geo>
-PCT_SD int stab_polygon(const Geo& geo, const StabBox& b, double (*out)[2]) {
-  double pts[4 * STAB_SMAX][2];
+// ConvexHull of the 4 * k contact corners of the box `bg` with its supporters, in the workspace: the sorted points (and,
+// in place, the lower chain) in pts[4k], the upper chain in up[4k + 1].  The polygon is lower[0..nl) then upper[0..nu).
+template <bool CONT, typename Geo, typename Sup>
+PCT_SD void stab_hull(const Geo& geo, const double bg[9], int k, const Sup& sup, double (*pts)[2], double (*up)[2], int& nl,
+                      int& nu) {
   int n = 0;
-  for (int i = 0; i < b.nsup; i++) {
+  for (int i = 0; i < k; i++) {
     double a[4];
-    stab_area<CONT>(geo, b, i, a);
+    stab_area<CONT>(geo, bg, sup(i), a);
     pts[n][0] = a[0]; pts[n][1] = a[1]; n++;
     pts[n][0] = a[0]; pts[n][1] = a[3]; n++;
     pts[n][0] = a[2]; pts[n][1] = a[1]; n++;
@@ -163,45 +204,70 @@ PCT_SD int stab_polygon(const Geo& geo, const StabBox& b, double (*out)[2]) {
     while (j > 0 && pts[j - 1][0] > v0) { pts[j][0] = pts[j - 1][0]; pts[j][1] = pts[j - 1][1]; j--; }
     pts[j][0] = v0; pts[j][1] = v1;
   }
-  double lo[4 * STAB_SMAX + 1][2], up[4 * STAB_SMAX + 1][2];
-  int nl = stab_chain(pts, n, false, lo) - 1;
-  int nu = stab_chain(pts, n, true, up) - 1;
-  if (nl + nu > STAB_PMAX) return -1;
-  int m = 0;
-  for (int i = 0; i < nl; i++) { out[m][0] = lo[i][0]; out[m][1] = lo[i][1]; m++; }
-  for (int i = 0; i < nu; i++) { out[m][0] = up[i][0]; out[m][1] = up[i][1]; m++; }
-  double cx = 0, cy = 0;
-  for (int i = 0; i < m; i++) { cx += out[i][0]; cy += out[i][1]; }
-  cx /= (double)m; cy /= (double)m;
-  for (int i = 0; i < m; i++) {
-    out[i][0] -= (out[i][0] - cx) * 0.1;
-    out[i][1] -= (out[i][1] - cy) * 0.1;
-  }
-  return m;
+  nu = stab_chain(pts, n, true, up) - 1;   // the upper chain first: it reads the sorted points ...
+  nl = stab_chain(pts, n, false, pts) - 1;  // ... which the lower chain then overwrites in place
 }
-// point_in_polygen :97-112
+// centroid of the hull vertices (scale_down D/space.py:341-345 shrinks every vertex towards it by a tenth)
+PCT_SD void stab_hull_centroid(const double (*lo)[2], int nl, const double (*up)[2], int nu, double& cx, double& cy) {
+  cx = 0; cy = 0;
+  for (int i = 0; i < nl; i++) { cx += lo[i][0]; cy += lo[i][1]; }
+  for (int i = 0; i < nu; i++) { cx += up[i][0]; cy += up[i][1]; }
+  const double m = (double)(nl + nu);
+  cx /= m; cy /= m;
+}
+PCT_SD void stab_hull_vertex(const double (*lo)[2], int nl, const double (*up)[2], int i, double cx, double cy, double& vx,
+                             double& vy) {
+  const double* v = i < nl ? lo[i] : up[i - nl];
+  vx = v[0]; vy = v[1];
+  vx -= (vx - cx) * 0.1;
+  vy -= (vy - cy) * 0.1;
+}
+// one edge of point_in_polygen :97-112: vertex i (cx, cy) against the previous vertex j
+PCT_SD bool stab_pip_edge(double lat, double lon, double ix, double iy, double jx, double jy, bool& odd) {
+  double a0 = ix - lat, a1 = iy - lon;
+  double b0 = lat - jx, b1 = lon - jy;
+  double cp = a0 * b1;
+  cp -= a1 * b0;
+  if (cp == 0) return false;
+  if ((iy < lon && jy >= lon) || (jy < lon && iy >= lon)) {
+    if ((ix + (lon - iy) / (jy - iy) * (jx - ix)) < lat) odd = !odd;
+  }
+  return true;
+}
+// point_in_polygen on stored (scaled) vertices
 PCT_SD bool stab_pip(const double* pt, const double (*co)[2], int n) {
-  double lat = pt[0], lon = pt[1];
-  int j = n - 1;
   bool odd = false;
+  int j = n - 1;
   for (int i = 0; i < n; i++) {
-    double a0 = co[i][0] - pt[0], a1 = co[i][1] - pt[1];
-    double b0 = pt[0] - co[j][0], b1 = pt[1] - co[j][1];
-    double cp = a0 * b1;
-    cp -= a1 * b0;
-    if (cp == 0) return false;
-    if ((co[i][1] < lon && co[j][1] >= lon) || (co[j][1] < lon && co[i][1] >= lon)) {
-      if ((co[i][0] + (lon - co[i][1]) / (co[j][1] - co[i][1]) * (co[j][0] - co[i][0])) < lat) odd = !odd;
-    }
+    if (!stab_pip_edge(pt[0], pt[1], co[i][0], co[i][1], co[j][0], co[j][1], odd)) return false;
     j = i;
+  }
+  return odd;
+}
+// ... and on a hull still in the workspace (vertices scaled on the fly)
+PCT_SD bool stab_pip_hull(const double* pt, const double (*lo)[2], int nl, const double (*up)[2], int nu) {
+  const int n = nl + nu;
+  double cx, cy;
+  stab_hull_centroid(lo, nl, up, nu, cx, cy);
+  bool odd = false;
+  double jx = 0, jy = 0;
+  if (n > 0) stab_hull_vertex(lo, nl, up, n - 1, cx, cy, jx, jy);
+  for (int i = 0; i < n; i++) {
+    double ix, iy;
+    stab_hull_vertex(lo, nl, up, i, cx, cy, ix, iy);
+    if (!stab_pip_edge(pt[0], pt[1], ix, iy, jx, jy, odd)) return false;
+    jx = ix; jy = iy;
   }
   return odd;
 }
 
 // minimum-norm least squares for the >= 3 supporter case (stands in for np.linalg.lstsq / LAPACK dgelsd):
 // one-sided Jacobi (Hestenes) SVD of A itself, x = sum_j V_j (U_j . b) / sigma_j^2 over sigma_j > eps * max(M,N) *
-// sigma_max -- the same method, operation for operation, as the oracle's lstsq_min_norm (see there for why not A^T A)
-PCT_SD void stab_lstsq(const double* A, const double* b, int M, int N, double* x) {
+// sigma_max -- the same method, operation for operation, as the oracle's lstsq_min_norm (see there for why not A^T A).
+// `ill` reports a rank decision taken within a factor STAB_ILL_BAND of the cut: there the reference's own verdict
+// depends on the rounding noise of its LAPACK build (profiles/r02_lstsq_limit.txt, r03_lstsq_limit.txt).
+constexpr double STAB_ILL_BAND = 1e3;
+PCT_SD void stab_lstsq(const double* A, const double* b, int M, int N, double* x, bool& ill) {
   double U[(STAB_LSQ * (STAB_LSQ - 1) / 2 + 1) * STAB_LSQ], V[STAB_LSQ * STAB_LSQ];
   for (int i = 0; i < M * N; i++) U[i] = A[i];
   for (int i = 0; i < N; i++)
@@ -244,7 +310,9 @@ PCT_SD void stab_lstsq(const double* A, const double* b, int M, int N, double* x
   const double rc = 2.220446049250313e-16 * (M > N ? M : N);
   for (int i = 0; i < N; i++) x[i] = 0;
   for (int j = 0; j < N; j++) {
-    if (s2[j] <= 0 || sqrt(s2[j]) <= rc * sqrt(smax2)) continue;
+    const double sj = sqrt(s2[j]), cut = rc * sqrt(smax2);
+    if (s2[j] > 0 && sj > cut / STAB_ILL_BAND && sj < cut * STAB_ILL_BAND) ill = true;
+    if (s2[j] <= 0 || sj <= cut) continue;
     double proj = 0;
     for (int r = 0; r < M; r++) proj += U[r * N + j] * b[r];
     proj /= s2[j];
@@ -258,10 +326,9 @@ PCT_SD double stab_dot2(double x0, double x1, double y0, double y1) { return fma
 
 // The same solve with every extent a compile-time constant (N supporters, M = N(N-1)/2 + 1 rows) and every loop over
 // rows, columns and column pairs unrolled: U and V are then registers, not dynamically indexed private arrays in
-// scratch memory (where one rotation costs dozens of dependent HBM-latency round trips: a lane in the generic solve
-// held its whole wave, and with it the launch, for milliseconds).  Operation for operation the generic routine.
+// scratch memory.  Operation for operation the generic routine.
 template <int N>
-PCT_SD void stab_lstsq_fixed(const double (&A)[(N * (N - 1) / 2 + 1) * N], double (&x)[N]) {
+PCT_SD void stab_lstsq_fixed(const double (&A)[(N * (N - 1) / 2 + 1) * N], double (&x)[N], bool& ill) {
   constexpr int M = N * (N - 1) / 2 + 1;
   double U[M * N], V[N * N];
 #pragma unroll
@@ -317,7 +384,9 @@ PCT_SD void stab_lstsq_fixed(const double (&A)[(N * (N - 1) / 2 + 1) * N], doubl
   for (int i = 0; i < N; i++) x[i] = 0;
 #pragma unroll
   for (int j = 0; j < N; j++) {
-    if (s2[j] <= 0 || sqrt(s2[j]) <= rc * sqrt(smax2)) continue;
+    const double sj = sqrt(s2[j]), cut = rc * sqrt(smax2);
+    if (s2[j] > 0 && sj > cut / STAB_ILL_BAND && sj < cut * STAB_ILL_BAND) ill = true;
+    if (s2[j] <= 0 || sj <= cut) continue;
     double proj = 0;
 #pragma unroll
     for (int r = 0; r < M; r++) proj += U[r * N + j] * (r == M - 1 ? 1.0 : 0.0);  // rhs = e_{M-1}
@@ -326,10 +395,10 @@ PCT_SD void stab_lstsq_fixed(const double (&A)[(N * (N - 1) / 2 + 1) * N], doubl
     for (int i = 0; i < N; i++) x[i] += V[i * N + j] * proj;
   }
 }
-// the >= 3 supporter system of stab_shares for N supporters with contact centres c2 (D/space.py:118-150): one row
-// per supporter pair, a closing row of ones; solved into the shares xr
+// the >= 3 supporter system for N supporters with contact centres c2 (D/space.py:118-150): one row per supporter pair,
+// a closing row of ones; solved into the shares xr
 template <int N>
-PCT_SD void stab_split_fixed(const double (*c2)[2], const double stk[4], double (&xr)[N]) {
+PCT_SD void stab_split_fixed(const double (*c2)[2], const double stk[4], double (&xr)[N], bool& ill) {
   constexpr int M = N * (N - 1) / 2 + 1;
   double A[M * N];
 #pragma unroll
@@ -351,117 +420,79 @@ PCT_SD void stab_split_fixed(const double (*c2)[2], const double stk[4], double 
     }
 #pragma unroll
   for (int j = 0; j < N; j++) A[(M - 1) * N + j] = 1;
-  stab_lstsq_fixed<N>(A, xr);
+  stab_lstsq_fixed<N>(A, xr, ill);
 }
 
-
-// supporters of `b` among the first n placed boxes, in box order.  False if > STAB_SMAX.
-template <bool CONT, typename Geo>
-PCT_SD bool stab_find_supporters(const Geo& geo, int n, StabBox& b) {
-  b.nsup = 0;
-  for (int i = 0; i < n; i++) {
-    double t[9], area[4];
-    geo(i, t);
-    if (!stab_contact<CONT>(b.g, t, area)) continue;
-    if (b.nsup == STAB_SMAX) return false;
-    b.sup[b.nsup++] = i;
-  }
-  return true;
-}
-// a placed box again as a StabBox, from its stored supporter ids
-template <bool CONT, typename Geo>
-PCT_SD void stab_load_box(const Geo& geo, const StabState& st, int id, StabBox& b) {
-  geo(id, b.g);
-  b.nsup = st.nsup[id];
-  for (int k = 0; k < b.nsup; k++) b.sup[k] = st.sup[id * STAB_SMAX + k];
-}
-
-// How `b` with stack (c, m) splits over its supporters (D/space.py:88-160 / :182-256): the share handed to supporter
-// `want` (0 <= want < nsup) -- what one step of the virtual walk needs -- or, with want < 0, every share into
-// out_all (the commit).  `own_centre` is the box's own centre (the virtual flavour's zero-mass shares use it).
-// Cases: one supporter (everything), a supporter whose contact rectangle holds the centre of mass ("direct":
-// everything, the others zero), two supporters (lever rule on the line through the contact centres), three and
-// more (least squares over all pairs).
-template <bool CONT, typename Geo>
-PCT_SD bool stab_shares(const Geo& geo, const StabBox& b, const double stk[4], const double own_centre[3], bool virtual_,
-                        int want, double out_one[4], double (*out_all)[4], int* alias = nullptr) {
-  const int k = b.nsup;
-  if (alias) *alias = -1;
-#define put(i_, c0_, c1_, c2_, m_)                                                                        \
-  do {                                                                                                    \
-    if (want < 0) { out_all[i_][0] = (c0_); out_all[i_][1] = (c1_); out_all[i_][2] = (c2_); out_all[i_][3] = (m_); } \
-    else if ((i_) == want) { out_one[0] = (c0_); out_one[1] = (c1_); out_one[2] = (c2_); out_one[3] = (m_); }        \
-  } while (0)
-  if (k == 1) {
-    put(0, stk[0], stk[1], stk[2], stk[3]);
-    if (alias) *alias = 0;  // up_edges[self] = self.thisStack: the object itself
-    return true;
-  }
-  int direct = -1;
+// How a box with stack `stk` splits over its k supporters (D/space.py:88-160 / :182-256).
+//   mode 0: one supporter (everything; the entry IS the box's stack object)
+//   mode 1: a supporter whose contact rectangle holds the centre of mass ("direct": everything, the others a zero-mass
+//           share; that entry is the stack object too)
+//   mode 2: two supporters (lever rule on the line through the contact centres)
+//   mode 3: three and more (least squares over all pairs)
+// f[i]: the fraction of the mass supporter i receives (modes 2, 3; i < 5 -- more than five supporters keep theirs in fx)
+struct StabSplit {
+  int mode, direct;
+  double f[5];
+  double fx[STAB_LSQ];  // k > 5 only (a run-time indexed private array: scratch memory, 0.01 % of the splits)
+  bool ill;
+};
+template <bool CONT, typename Geo, typename Sup>
+PCT_SD bool stab_split(const Geo& geo, const double bg[9], int k, const Sup& sup, const double stk[4], StabSplit& sp) {
+  sp.mode = 0; sp.direct = -1; sp.ill = false;
+#pragma unroll
+  for (int i = 0; i < 5; i++) sp.f[i] = 0;
+  if (k == 1) return true;
   for (int i = 0; i < k; i++) {
     double a[4];
-    stab_area<CONT>(geo, b, i, a);
+    stab_area<CONT>(geo, bg, sup(i), a);
     bool inside = CONT ? (stk[0] - a[0] > 1e-6 && a[2] - stk[0] > 1e-6 && stk[1] - a[1] > 1e-6 && a[3] - stk[1] > 1e-6)
                        : (stk[0] > a[0] && stk[0] < a[2] && stk[1] > a[1] && stk[1] < a[3]);
-    if (inside) { direct = i; break; }
+    if (inside) { sp.direct = i; break; }
   }
-  if (direct >= 0) {
-    if (alias) *alias = direct;
-    const double* cc = virtual_ ? own_centre : stk;
-    for (int i = 0; i < k; i++) {
-      if (i == direct) put(i, stk[0], stk[1], stk[2], stk[3]);
-      else put(i, cc[0], cc[1], cc[2], 0);
-    }
-    return true;
-  }
+  if (sp.direct >= 0) { sp.mode = 1; return true; }
   if (k > STAB_LSQ) return false;
-  // contact centres: static indices (registers) up to five supporters, a run-time loop beyond
-  double c2[STAB_LSQ][2];
   if (k <= 5) {
+    // contact centres with static indices (registers)
+    double c2[5][2];
 #pragma unroll
     for (int i = 0; i < 5; i++) {
       c2[i][0] = 0; c2[i][1] = 0;
       if (i < k) {
         double a[4];
-        stab_area<CONT>(geo, b, i, a);
+        stab_area<CONT>(geo, bg, sup(i), a);
         c2[i][0] = (a[0] + a[2]) / 2;
         c2[i][1] = (a[1] + a[3]) / 2;
       }
     }
-  } else {
-    for (int i = 0; i < k; i++) {
-      double a[4];
-      stab_area<CONT>(geo, b, i, a);
-      c2[i][0] = (a[0] + a[2]) / 2;
-      c2[i][1] = (a[1] + a[3]) / 2;
+    if (k == 2) {
+      const double e00 = c2[0][0], e01 = c2[0][1], e10 = c2[1][0], e11 = c2[1][1];
+      double t0 = e00 - e10, t1 = e01 - e11;
+      double len = sqrt(stab_dot2(t0, t1, t0, t1));
+      // tri_base_len ** 2: NumPy calls libm pow(len, 2.0); a correctly rounded square is len*len
+      // (glibc's pow agrees except for rare near-midpoint roundings; the device pow does not)
+      double l2 = len * len;
+      t0 /= l2; t1 /= l2;
+      sp.f[0] = fabs(stab_dot2(stk[0] - e10, stk[1] - e11, t0, t1));
+      sp.f[1] = fabs(stab_dot2(stk[0] - e00, stk[1] - e01, t0, t1));
+      sp.mode = 2;
+      return true;
     }
-  }
-  if (k == 2) {
-    const double e00 = c2[0][0], e01 = c2[0][1], e10 = c2[1][0], e11 = c2[1][1];
-    double t0 = e00 - e10, t1 = e01 - e11;
-    double len = sqrt(stab_dot2(t0, t1, t0, t1));
-    // tri_base_len ** 2: NumPy calls libm pow(len, 2.0); a correctly rounded square is len*len
-    // (glibc's pow agrees except for rare near-midpoint roundings; the device pow does not)
-    double l2 = len * len;
-    t0 /= l2; t1 /= l2;
-    double r0 = fabs(stab_dot2(stk[0] - e10, stk[1] - e11, t0, t1));
-    double r1 = fabs(stab_dot2(stk[0] - e00, stk[1] - e01, t0, t1));
-    put(0, e00, e01, stk[2], stk[3] * r0);
-    put(1, e10, e11, stk[2], stk[3] * r1);
+    sp.mode = 3;
+    if (k == 3) { double x3[3]; stab_split_fixed<3>(c2, stk, x3, sp.ill); sp.f[0] = x3[0]; sp.f[1] = x3[1]; sp.f[2] = x3[2]; }
+    else if (k == 4) { double x4[4]; stab_split_fixed<4>(c2, stk, x4, sp.ill); sp.f[0] = x4[0]; sp.f[1] = x4[1]; sp.f[2] = x4[2]; sp.f[3] = x4[3]; }
+    else stab_split_fixed<5>(c2, stk, sp.f, sp.ill);
     return true;
   }
-  if (PCT_STAB_FIXED_SOLVE && k <= 5) {  // 99.99 % of the solves (k = 3: 94 %, 4: 6 %, 5: 0.1 %): register-resident
-    double x5[5] = {0, 0, 0, 0, 0};
-    if (k == 3) { double x3[3]; stab_split_fixed<3>(c2, stk, x3); x5[0] = x3[0]; x5[1] = x3[1]; x5[2] = x3[2]; }
-    else if (k == 4) { double x4[4]; stab_split_fixed<4>(c2, stk, x4); x5[0] = x4[0]; x5[1] = x4[1]; x5[2] = x4[2]; x5[3] = x4[3]; }
-    else stab_split_fixed<5>(c2, stk, x5);
-#pragma unroll
-    for (int i = 0; i < 5; i++)
-      if (i < k) put(i, c2[i][0], c2[i][1], stk[2], stk[3] * x5[i]);
-    return true;
+  sp.mode = 3;
+  double c2[STAB_LSQ][2];
+  for (int i = 0; i < k; i++) {
+    double a[4];
+    stab_area<CONT>(geo, bg, sup(i), a);
+    c2[i][0] = (a[0] + a[2]) / 2;
+    c2[i][1] = (a[1] + a[3]) / 2;
   }
   const int M = k * (k - 1) / 2 + 1;
-  double A[(STAB_LSQ * (STAB_LSQ - 1) / 2 + 1) * STAB_LSQ], rhs[STAB_LSQ * (STAB_LSQ - 1) / 2 + 1], xr[STAB_LSQ];
+  double A[(STAB_LSQ * (STAB_LSQ - 1) / 2 + 1) * STAB_LSQ], rhs[STAB_LSQ * (STAB_LSQ - 1) / 2 + 1];
   for (int i = 0; i < M * k; i++) A[i] = 0;
   for (int i = 0; i < M; i++) rhs[i] = 0;
   int row = 0;
@@ -480,35 +511,58 @@ PCT_SD bool stab_shares(const Geo& geo, const StabBox& b, const double stk[4], c
     }
   for (int j = 0; j < k; j++) A[(M - 1) * k + j] = 1;
   rhs[M - 1] = 1;
-  stab_lstsq(A, rhs, M, k, xr);
-  for (int i = 0; i < k; i++) put(i, c2[i][0], c2[i][1], stk[2], stk[3] * xr[i]);
+  stab_lstsq(A, rhs, M, k, sp.fx, sp.ill);
   return true;
-#undef put
+}
+// the share supporter i receives.  `own_centre`: the box's own centre, which the VIRTUAL flavour puts into the zero-mass
+// shares of a direct split (the commit uses the stack's centre there)
+template <bool CONT, typename Geo, typename Sup>
+PCT_SD void stab_share_of(const Geo& geo, const double bg[9], int k, const Sup& sup, const double stk[4],
+                          const double own_centre[3], bool virtual_, const StabSplit& sp, int i, double out[4]) {
+  if (sp.mode == 0 || (sp.mode == 1 && i == sp.direct)) {
+    out[0] = stk[0]; out[1] = stk[1]; out[2] = stk[2]; out[3] = stk[3];
+    return;
+  }
+  if (sp.mode == 1) {
+    const double* cc = virtual_ ? own_centre : stk;
+    out[0] = cc[0]; out[1] = cc[1]; out[2] = cc[2]; out[3] = 0;
+    return;
+  }
+  double a[4];
+  stab_area<CONT>(geo, bg, sup(i), a);
+  double f = sp.f[0];
+  f = i == 1 ? sp.f[1] : f;
+  f = i == 2 ? sp.f[2] : f;
+  f = i == 3 ? sp.f[3] : f;
+  f = i == 4 ? sp.f[4] : f;
+  if (k > 5) f = sp.fx[i];
+  out[0] = (a[0] + a[2]) / 2;
+  out[1] = (a[1] + a[3]) / 2;
+  out[2] = stk[2];
+  out[3] = stk[3] * f;
 }
 
-// calculate_new_com (D/space.py:51-71) of placed box S: own + the committed shares of the
-// boxes resting on it that are not on the active path (ascending id) + `extra` (the involved
-// parent's virtual share, or null).  n = number of placed boxes to consider.
+// calculate_new_com (D/space.py:51-71) of placed box S: own + the committed shares of the boxes resting on it (its
+// up-list, in insertion order) except the one of the involved parent `skip` (or none: STAB_NOBOX) + `extra` (the
+// parent's virtual share, or null).
 template <typename Geo>
-PCT_SD void stab_com(const Geo& geo, const StabState& st, int n, int S, const int* path, int npath,
-                     const double* extra, double out[4]) {
+PCT_SD void stab_com(const Geo& geo, const StabState& st, int S, int skip, const double* extra, double out[4]) {
   double g[9];
   geo(S, g);
   double sx = g[6], sy = g[7], sz = g[8];
   double mass = sx * sy * sz * st.den[S];
   double c0 = (g[0] + sx / 2) * mass, c1 = (g[1] + sy / 2) * mass, c2 = (g[2] + sz / 2) * mass, m = mass;
-  for (int B = S + 1; B < n; B++) {
-    bool inv = false;
-    for (int q = 0; q < npath; q++) inv = inv || (path[q] == B);
-    if (inv) continue;
-    const int ns = st.nsup[B];
-    for (int k = 0; k < ns; k++)
-      if (st.sup[B * STAB_SMAX + k] == S) {
-        // an entry held by reference reads as B's current committed stack (see the header)
-        const double* e = (st.alias[B] == k) ? st.stack + (size_t)B * 4 : st.share + ((size_t)B * STAB_SMAX + k) * 4;
-        c0 += e[0] * e[3]; c1 += e[1] * e[3]; c2 += e[2] * e[3];
-        m += e[3];
-      }
+  for (uint32_t j = st.up[S] & 0xFFFFu; j != STAB_END; ) {
+    const uint32_t w = st.ent[j];
+    const int B = (int)((w >> 10) & 0x3FFu);
+    if (B != skip) {
+      // an entry held by reference reads as B's current committed stack (see the header)
+      const int kk = (int)j - stab_soff(st, B);
+      const double* e = (stab_alias(st, B) == kk) ? st.stk + (size_t)B * 4 : st.share + (size_t)j * 4;
+      c0 += e[0] * e[3]; c1 += e[1] * e[3]; c2 += e[2] * e[3];
+      m += e[3];
+    }
+    j = w >> 20;
   }
   if (extra) {
     c0 += extra[0] * extra[3]; c1 += extra[1] * extra[3]; c2 += extra[2] * extra[3];
@@ -517,123 +571,455 @@ PCT_SD void stab_com(const Geo& geo, const StabState& st, int n, int S, const in
   out[0] = c0 / m; out[1] = c1 / m; out[2] = c2 / m; out[3] = m;
 }
 
-// calculated_impact_virtual(first=True) for a candidate (D/space.py:166-267): is it stable?
-// err is set if a capacity (supporters, hull vertices, depth) was exceeded.
-template <bool CONT, typename Geo>
-PCT_SD bool stab_virtual(const Geo& geo, const StabState& st, int n, const double cand[9], double density, bool& err) {
-  err = false;
-  StabBox b;
-  for (int i = 0; i < 9; i++) b.g[i] = cand[i];
-  if (!stab_find_supporters<CONT>(geo, n, b)) { err = true; return false; }
-  if (b.nsup == 0) return true;
-  // explicit depth-first walk: frame = (box id or -1, its virtual stack, next supporter)
-  int fid[STAB_DEPTH], fnext[STAB_DEPTH];
-  double fstk[STAB_DEPTH][4];
-  int path[STAB_DEPTH];  // ids of the placed boxes on the active path (frames 1..depth-1)
-  int depth = 0;
-  {
-    double sx = cand[6], sy = cand[7], sz = cand[8];
-    fid[0] = -1; fnext[0] = 0;
-    fstk[0][0] = cand[0] + sx / 2; fstk[0][1] = cand[1] + sy / 2; fstk[0][2] = cand[2] + sz / 2;
-    fstk[0][3] = sx * sy * sz * density * 1.0;
-    depth = 1;
-  }
-  while (depth > 0) {
-    const int d = depth - 1;
-    if (fid[d] >= 0) stab_load_box<CONT>(geo, st, fid[d], b);
-    else { for (int i = 0; i < 9; i++) b.g[i] = cand[i]; stab_find_supporters<CONT>(geo, n, b); }
-    if (fnext[d] == 0) {
-      if (b.nsup == 0) { depth--; continue; }
-      if (fid[d] >= 0) {  // a placed box: its stored polygon, read where it lies
-        const double (*gp)[2] = reinterpret_cast<const double (*)[2]>(st.poly + (size_t)fid[d] * STAB_PMAX * 2);
-        if (!stab_pip(fstk[d], gp, st.npoly[fid[d]])) return false;
-      } else {
-        double poly[STAB_PMAX][2];
-        const int np = stab_polygon<CONT>(geo, b, poly);
-        if (np < 0) { err = true; return false; }
-        if (!stab_pip(fstk[d], poly, np)) return false;
-      }
-    }
-    if (fnext[d] >= b.nsup) { depth--; continue; }
-    const int i = fnext[d]++;
-    double own[3] = {b.g[0] + b.g[6] / 2, b.g[1] + b.g[7] / 2, b.g[2] + b.g[8] / 2};
-    double share[4];
-    if (!stab_shares<CONT>(geo, b, fstk[d], own, true, i, share, nullptr)) { err = true; return false; }
-    if (depth >= STAB_DEPTH) { err = true; return false; }
-    const int S = b.sup[i];
-    // path = placed boxes currently involved: frames 1..d (the candidate has no id)
-    int np2 = 0;
-    for (int q = 1; q <= d; q++) path[np2++] = fid[q];
-    stab_com(geo, st, n, S, path, np2, share, fstk[depth]);
-    fid[depth] = S;
-    fnext[depth] = 0;
-    depth++;
+// ---- the virtual check as tasks ---------------------------------------------------------------------------------
+// The children of a box under examination (geometry bg, k supporters `sup`, stack `stk`): its stack is split over the
+// supporters and every supporter Si gets the virtual stack it would then carry -- calculate_new_com of Si with the
+// parent's committed entry (`skip`: the parent's id, STAB_NOBOX for a candidate) replaced by the virtual share.
+// `emit(Si, child_stack)` is called once per supporter, in order.  False: a capacity was exceeded.
+template <bool CONT, typename Geo, typename Emit>
+PCT_SD bool stab_children(const Geo& geo, const StabState& st, const double bg[9], int k, const StabSup& sup, const double stk[4],
+                          int skip, bool& ill, Emit emit) {
+  StabSplit sp;
+  if (!stab_split<CONT>(geo, bg, k, sup, stk, sp)) return false;
+  ill = ill || sp.ill;
+  const double own[3] = {bg[0] + bg[6] / 2, bg[1] + bg[7] / 2, bg[2] + bg[8] / 2};
+  for (int i = 0; i < k; i++) {
+    double share[4], child[4];
+    stab_share_of<CONT>(geo, bg, k, sup, stk, own, true, sp, i, share);
+    const int Si = sup(i);
+    stab_com(geo, st, Si, skip, share, child);
+    emit(Si, child);
   }
   return true;
 }
-
-// calculated_impact() of the box just placed as id `n` (geometry already visible through
-// geo(n, .)): records its supporters / polygon / stack, propagates the shares downward and
-// re-checks every box on the way (D/space.py:73-164).  Returns the stability verdict.
+// One walk task: placed box S receives the virtual stack `vstk` from its parent on some candidate's path.
+// Returns 0: the candidate is unstable (S's polygon does not hold the stack), 1: fine, -1: a capacity was exceeded.
+template <bool CONT, typename Geo, typename Emit>
+PCT_SD int stab_visit(const Geo& geo, const StabState& st, int S, const double vstk[4], bool& ill, Emit emit) {
+  const int k = stab_nsup(st, S);
+  if (k == 0) return 1;
+  const double (*gp)[2] = reinterpret_cast<const double (*)[2]>(st.poly + (size_t)stab_poff(st, S) * 2);
+  if (!stab_pip(vstk, gp, stab_npoly(st, S))) return 0;
+  double bg[9];
+  geo(S, bg);
+  StabSup sup{st.ent + stab_soff(st, S)};
+  return stab_children<CONT>(geo, st, bg, k, sup, vstk, S, ill, emit) ? 1 : -1;
+}
+// workspace bytes the hull of a box with up to k supporters needs (points, upper chain, supporter ids)
+PCT_HD int stab_ws_need(int k) { return (4 * k) * 16 + (4 * k + 1) * 16 + ((4 * k + 7) & ~7); }
+struct StabWsView {
+  double (*pts)[2];
+  double (*up)[2];
+  uint32_t* ids;
+};
+PCT_SD StabWsView stab_ws_view(unsigned char* base, int kcap) {
+  StabWsView v;
+  v.pts = reinterpret_cast<double (*)[2]>(base);
+  v.up = reinterpret_cast<double (*)[2]>(base + (size_t)(4 * kcap) * 16);
+  v.ids = reinterpret_cast<uint32_t*>(base + (size_t)(4 * kcap) * 16 + (size_t)(4 * kcap + 1) * 16);
+  return v;
+}
+// supporters of the box `bg` among the first n placed boxes, in box order: the count, and the first `cap` ids
 template <bool CONT, typename Geo>
-PCT_SD bool stab_commit(const Geo& geo, StabState& st, int n, double density, bool& err) {
-  err = false;
-  StabBox b;
-  geo(n, b.g);
-  if (!stab_find_supporters<CONT>(geo, n, b)) { err = true; return false; }
-  st.den[n] = density;
-  {
-    double sx = b.g[6], sy = b.g[7], sz = b.g[8];
-    double* s = st.stack + (size_t)n * 4;
-    s[0] = b.g[0] + sx / 2; s[1] = b.g[1] + sy / 2; s[2] = b.g[2] + sz / 2; s[3] = sx * sy * sz * density;
+PCT_SD int stab_find_supporters(const Geo& geo, int n, const double bg[9], uint32_t* ids, int cap) {
+  int k = 0;
+  for (int i = 0; i < n; i++) {
+    double t[9], area[4];
+    geo(i, t);
+    if (!stab_contact<CONT>(bg, t, area)) continue;
+    if (k < cap) ids[k] = (uint32_t)i;
+    k++;
   }
-  st.nsup[n] = b.nsup;
-  st.alias[n] = -1;
-  for (int k = 0; k < b.nsup; k++) st.sup[n * STAB_SMAX + k] = b.sup[k];
-  st.npoly[n] = 0;
-  if (b.nsup > 0) {
-    double poly[STAB_PMAX][2];
-    int np = stab_polygon<CONT>(geo, b, poly);
-    if (np < 0) { err = true; return false; }
-    st.npoly[n] = np;
-    for (int i = 0; i < np; i++) {
-      st.poly[((size_t)n * STAB_PMAX + i) * 2 + 0] = poly[i][0];
-      st.poly[((size_t)n * STAB_PMAX + i) * 2 + 1] = poly[i][1];
+  return k;
+}
+// the stack a candidate starts with: its own centre and mass (D/space.py:38-45; the virtual flavour's `* 1.0`)
+PCT_SD void stab_cand_stack(const double cand[9], double density, double cstk[4]) {
+  const double sx = cand[6], sy = cand[7], sz = cand[8];
+  cstk[0] = cand[0] + sx / 2; cstk[1] = cand[1] + sy / 2; cstk[2] = cand[2] + sz / 2;
+  cstk[3] = sx * sy * sz * density * 1.0;
+}
+// The first half of a candidate's level-0 task (calculated_impact_virtual(first=True), D/space.py:166-267): its hull
+// in the workspace (supporters already listed in w.ids[0..k)) and the point-in-polygon test of its own stack.
+// 0: unstable, 1: go on to the children, -1: capacity.
+template <bool CONT, typename Geo>
+PCT_SD int stab_level0_pip(const Geo& geo, const double cand[9], const double cstk[4], int k, const StabWsView& w) {
+  StabSup sup{w.ids};
+  int nl, nu;
+  stab_hull<CONT>(geo, cand, k, sup, w.pts, w.up, nl, nu);
+  if (nl + nu > 255) return -1;
+  return stab_pip_hull(cstk, w.pts, nl, w.up, nu) ? 1 : 0;
+}
+// the whole level-0 task.  Same return values and `emit` as stab_visit.
+template <bool CONT, typename Geo, typename Emit>
+PCT_SD int stab_level0(const Geo& geo, const StabState& st, const double cand[9], double density, int k, const StabWsView& w,
+                       bool& ill, Emit emit) {
+  if (k == 0) return 1;
+  double cstk[4];
+  stab_cand_stack(cand, density, cstk);
+  const int rc = stab_level0_pip<CONT>(geo, cand, cstk, k, w);
+  if (rc != 1) return rc;
+  StabSup sup{w.ids};
+  return stab_children<CONT>(geo, st, cand, k, sup, cstk, (int)STAB_NOBOX, ill, emit) ? 1 : -1;
+}
+
+// HBM mirror of the per-env stability state (struct-of-arrays over envs; the pool rows are as long as the largest
+// capacities of any pass, the LDS copies as long as THIS launch's)
+struct StabHbm {
+  StabCaps caps;             // this launch's LDS capacities
+  int sp_stride, pp_stride;  // HBM row lengths of the share / entry and the polygon pools
+  double* stk;     // [N][I][4]
+  double* den;     // [N][I]
+  double* share;   // [N][sp_stride][4]
+  double* poly;    // [N][pp_stride][2]
+  uint32_t* meta;  // [N][I][2]
+  uint32_t* up;    // [N][I]
+  uint32_t* ent;   // [N][sp_stride]
+};
+
+#if defined(__HIPCC__)
+// ---- the wave-cooperative driver ----------------------------------------------------------------------------------
+// LDS workspace of a wave: the hull workspace (shared by the level-0 tasks of a round) and the task queue.
+struct StabWave {
+  unsigned char* hull;
+  int hull_bytes;
+  uint32_t* ctl;    // [6] queue count, failed candidates (lanes 0..31, 32..63), global capacity error (STAB_WHY_*),
+                    //     candidates with a capacity error of their own (lanes 0..31, 32..63)
+  uint32_t* qmeta;  // [qcap] candidate lane | S << 6
+  double* qstk;     // [qcap][4]
+  int qcap;
+};
+PCT_HD size_t stab_wave_bytes(const StabCaps& c) { return (size_t)c.ws_bytes + (size_t)c.queue * (4 * sizeof(double) + sizeof(uint32_t)) + 32; }
+// carve: the queue's doubles first (8-byte aligned base), then the hull workspace, then the words
+PCT_SD StabWave stab_wave_carve(unsigned char* base, const StabCaps& c) {
+  StabWave w;
+  w.qstk = reinterpret_cast<double*>(base);
+  w.hull = base + (size_t)c.queue * 4 * sizeof(double);
+  w.hull_bytes = c.ws_bytes;
+  w.qmeta = reinterpret_cast<uint32_t*>(w.hull + c.ws_bytes);
+  w.ctl = w.qmeta + c.queue;
+  w.qcap = c.queue;
+  return w;
+}
+// (a box on more than STAB_NSUP_MAX supporters gets a class no workspace holds: a capacity error)
+__device__ __forceinline__ int stab_wave_incl_sum(int v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(v, off, 64);
+    if (lane >= off) v += t;
+  }
+  return v;
+}
+// slots of the walk queue kept free for the depth-first descent of a single candidate (see stab_virtual_wave)
+PCT_HD int stab_queue_reserve(int qcap) { return qcap / 2 < 96 ? qcap / 2 : 96; }
+PCT_SD int stab_class(int k) { return k <= 2 ? 2 : (k <= 8 ? 8 : (k <= 32 ? 32 : (k <= STAB_NSUP_MAX ? STAB_NSUP_MAX : (1 << 20)))); }
+
+// calculated_impact_virtual(first=True) of up to 64 candidates at once: lane = candidate (`need`: this lane carries
+// one, geometry `cand`, resting on boxes -- the caller has dealt with the floor case).  Returns the lane's verdict.
+// All 64 lanes must call.  Rounds: the pending candidates of one supporter-count class share the hull workspace for
+// their level-0 tasks (as many as fit), then the queue is drained -- 64 tasks per pass, last in first out -- before
+// the next round starts.  cap_err: STAB_WHY_* bits of a capacity of the WAVE (the queue) that was exceeded -- every
+// verdict is then void.  lane_err: a capacity of THIS lane's candidate (hull workspace, hull vertices, more than
+// STAB_LSQ supporters in a least-squares split) was exceeded and the candidate was not found unstable elsewhere: its
+// verdict is unknown (the reference, which has no such limits, evaluates the visits of a walk one after the other and
+// stops at the first failure; here they are evaluated side by side, so a limit hit on a branch of a candidate that
+// fails anyway must not count).
+template <bool CONT, typename Geo>
+__device__ __forceinline__ bool stab_virtual_wave(const Geo& geo, const StabState& st, int n, bool need, const double cand[9],
+                                                  double density, const StabWave& w, int lane, uint32_t& cap_err, bool& lane_err, bool& ill) {
+  // supporter count of every candidate; the first two ids stay in registers (the common class needs no second scan)
+  int k = 0;
+  uint32_t id0 = 0, id1 = 0;
+  if (need) {
+    for (int i = 0; i < n; i++) {
+      double t[9], area[4];
+      geo(i, t);
+      if (!stab_contact<CONT>(cand, t, area)) continue;
+      id0 = k == 0 ? (uint32_t)i : id0;
+      id1 = k == 1 ? (uint32_t)i : id1;
+      k++;
     }
   }
-  if (CONT ? (fabs(b.g[2]) < 1e-6) : (b.g[2] == 0)) return true;  // max_h == 0: check_box returns first (:448-449)
-  int fid[STAB_DEPTH], fnext[STAB_DEPTH];
-  int depth = 1;
-  fid[0] = n; fnext[0] = 0;
-  double shares[STAB_SMAX][4];
-  while (depth > 0) {
-    const int d = depth - 1;
-    const int id = fid[d];
-    stab_load_box<CONT>(geo, st, id, b);
-    if (fnext[d] == 0) {
-      if (b.nsup == 0) { depth--; continue; }
-      const double (*gp)[2] = reinterpret_cast<const double (*)[2]>(st.poly + (size_t)id * STAB_PMAX * 2);
-      const double* stk = st.stack + (size_t)id * 4;
-      if (!stab_pip(stk, gp, st.npoly[id])) return false;
-      // distribute to every supporter first (up_edges[self] = share; calculate_new_com())
-      double own[3] = {stk[0], stk[1], stk[2]};
-      int alias_k;
-      if (!stab_shares<CONT>(geo, b, stk, own, false, -1, nullptr, shares, &alias_k)) { err = true; return false; }
-      st.alias[id] = alias_k;
-      for (int k = 0; k < b.nsup; k++) {
-        double* e = st.share + ((size_t)id * STAB_SMAX + k) * 4;
-        e[0] = shares[k][0]; e[1] = shares[k][1]; e[2] = shares[k][2]; e[3] = shares[k][3];
-        stab_com(geo, st, n + 1, b.sup[k], (const int*)0, 0, (const double*)0, st.stack + (size_t)b.sup[k] * 4);
+  if (!__ballot(need && k > 0)) return true;
+  double cstk[4];
+  stab_cand_stack(cand, density, cstk);
+  lane_err = false;
+  if (lane < 6) w.ctl[lane] = 0;
+  __syncthreads();
+  bool pending = need && k > 0;
+  const int mycls = stab_class(k);
+  while (true) {
+    const uint64_t pm = __ballot(pending);
+    if (!pm) break;
+    const int first = __ffsll((unsigned long long)pm) - 1;
+    const int kc = __builtin_amdgcn_readlane(mycls, first);
+    const int per = kc <= STAB_NSUP_MAX ? stab_ws_need(kc) : 0x7FFFFFFF;
+    const int fit = w.hull_bytes / per;
+    const bool member = pending && mycls == kc;
+    const uint64_t mm = __ballot(member);
+    const int rk = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+    bool act = member && rk < fit;
+    if (fit == 0) {  // this class does not fit the workspace at all (wave-uniform)
+      if (member) atomicOr(&w.ctl[4 + (lane >> 5)], 1u << (lane & 31));
+      pending = pending && !member;
+      continue;
+    }
+    {
+      // ... and only as many candidates as the (empty) queue takes children of: the first ones whose supporter counts
+      // add up to its capacity
+      const int cum = stab_wave_incl_sum(act ? k : 0, lane);
+      act = act && (cum <= w.qcap - stab_queue_reserve(w.qcap) || (lane == first && k <= w.qcap));
+      if (!__ballot(act)) {  // a single candidate's children do not fit
+        if (lane == first) atomicOr(&w.ctl[3], STAB_WHY_QUEUE);
+        pending = pending && !member;
+        continue;
       }
     }
-    if (fnext[d] >= b.nsup) { depth--; continue; }
-    const int i = fnext[d]++;
-    if (depth >= STAB_DEPTH) { err = true; return false; }
-    fid[depth] = b.sup[i];
-    fnext[depth] = 0;
+    pending = pending && !act;
+    // what the lane examines in this pass: a candidate (level 0) or, further down, a popped task
+    bool have = false;
+    double bg[9], stk[4] = {0, 0, 0, 0};
+    int kk = 0, skip = (int)STAB_NOBOX, cl = lane;
+    const uint32_t* supw = w.qmeta;
+    if (act) {
+      StabWsView v = stab_ws_view(w.hull + (size_t)rk * per, kc);
+      if (kc == 2) { v.ids[0] = id0; v.ids[1] = id1; }
+      else stab_find_supporters<CONT>(geo, n, cand, v.ids, kc);
+      const int rc = stab_level0_pip<CONT>(geo, cand, cstk, k, v);
+      if (rc == 0) atomicOr(&w.ctl[1 + (lane >> 5)], 1u << (lane & 31));
+      if (rc < 0) atomicOr(&w.ctl[4 + (lane >> 5)], 1u << (lane & 31));
+      have = rc == 1;
+      kk = k;
+      supw = v.ids;
+#pragma unroll
+      for (int c = 0; c < 9; c++) bg[c] = cand[c];
+      stk[0] = cstk[0]; stk[1] = cstk[1]; stk[2] = cstk[2]; stk[3] = cstk[3];
+    }
+    while (true) {
+      if (have) {
+        auto emit = [&](int Si, const double child[4]) {
+          const uint32_t pos = atomicAdd(&w.ctl[0], 1u);
+          if (pos < (uint32_t)w.qcap) {
+            w.qmeta[pos] = (uint32_t)cl | ((uint32_t)Si << 6);
+            w.qstk[(size_t)pos * 4 + 0] = child[0]; w.qstk[(size_t)pos * 4 + 1] = child[1];
+            w.qstk[(size_t)pos * 4 + 2] = child[2]; w.qstk[(size_t)pos * 4 + 3] = child[3];
+          } else {
+            atomicOr(&w.ctl[3], STAB_WHY_QUEUE);
+          }
+        };
+        StabSup sup{supw};
+        if (!stab_children<CONT>(geo, st, bg, kk, sup, stk, skip, ill, emit)) atomicOr(&w.ctl[4 + (cl >> 5)], 1u << (cl & 31));
+      }
+      __syncthreads();
+      const uint32_t qraw = w.ctl[0];
+      const int qn = (int)(qraw < (uint32_t)w.qcap ? qraw : (uint32_t)w.qcap);
+      if (qn == 0 || w.ctl[3]) break;
+      const uint64_t failed = (((uint64_t)w.ctl[2] << 32) | w.ctl[1]) | (((uint64_t)w.ctl[5] << 32) | w.ctl[4]);
+      // pop from the end: lane j looks at task qn - 1 - j.  As many tasks are taken as the queue can then hold the
+      // children of (every task of box S pushes nsup(S)): the longest prefix of lanes with
+      // (tasks left) + (children so far) <= capacity -- so the queue cannot overflow unless one task alone does
+      const int ti = qn - 1 - lane;
+      uint32_t meta = 0;
+      int kS = 0;
+      if (ti >= 0) {
+        meta = w.qmeta[ti];
+        kS = stab_nsup(st, (int)(meta >> 6));
+        if ((failed >> (meta & 63u)) & 1ull) kS = 0;  // tasks of a candidate that has already failed push nothing
+      }
+      const int cum = stab_wave_incl_sum(kS, lane);
+      // WIDE pops fill the queue only up to (capacity - reserve).  When not even the last task can be popped that way the
+      // wave goes NARROW: one task per pass, the last one -- a plain depth-first descent into that candidate's subtree,
+      // which needs (depth x fan-out) slots at most and finds them in the reserve; the wide passes resume once it is done.
+      const bool fits = ti >= 0 && (qn - (lane + 1)) + cum <= w.qcap - stab_queue_reserve(w.qcap);
+      const uint64_t fm = __ballot(fits);
+      int take = (~fm) ? __ffsll((unsigned long long)~fm) - 1 : 64;
+      if (take == 0 && (qn - 1) + __builtin_amdgcn_readfirstlane(kS) <= w.qcap) take = 1;
+      if (take == 0) {  // the last task alone does not fit
+        __syncthreads();
+        if (lane == 0) atomicOr(&w.ctl[3], STAB_WHY_QUEUE);
+        __syncthreads();
+        break;
+      }
+      const bool has = lane < take;
+      if (has) {
+        stk[0] = w.qstk[(size_t)ti * 4 + 0]; stk[1] = w.qstk[(size_t)ti * 4 + 1];
+        stk[2] = w.qstk[(size_t)ti * 4 + 2]; stk[3] = w.qstk[(size_t)ti * 4 + 3];
+      }
+      __syncthreads();
+      if (lane == 0) w.ctl[0] = (uint32_t)(qn - take);
+      __syncthreads();
+      cl = (int)(meta & 63u);
+      const int S = (int)(meta >> 6);
+      have = false;
+      if (has && !((failed >> cl) & 1ull)) {
+        kk = stab_nsup(st, S);
+        if (kk > 0) {
+          const double (*gp)[2] = reinterpret_cast<const double (*)[2]>(st.poly + (size_t)stab_poff(st, S) * 2);
+          if (!stab_pip(stk, gp, stab_npoly(st, S))) atomicOr(&w.ctl[1 + (cl >> 5)], 1u << (cl & 31));
+          else {
+            have = true;
+            geo(S, bg);
+            supw = st.ent + stab_soff(st, S);
+            skip = S;
+          }
+        }
+      }
+    }
+    if (w.ctl[3]) break;
+  }
+  __syncthreads();
+  const uint64_t failed = ((uint64_t)w.ctl[2] << 32) | w.ctl[1];
+  const uint64_t unknown = (((uint64_t)w.ctl[5] << 32) | w.ctl[4]) & ~failed;
+  cap_err |= w.ctl[3];
+  lane_err = (unknown >> lane) & 1ull;
+  __syncthreads();
+  return !((failed >> lane) & 1ull) && !lane_err;
+}
+// HBM -> LDS: the used part of env e's state (n placed boxes, n_ent pool entries, n_poly vertices).  False: it does not
+// fit this launch's pools (the env belongs to the retry pass).
+__device__ __forceinline__ bool stab_load(const StabHbm& hb, int I, int e, int n, int n_ent, int n_poly, StabState& st, int lane) {
+  st.n_ent = n_ent;
+  st.n_poly = n_poly;
+  if (n_ent > st.SP || n_poly > st.PP) return false;
+  const double* gs = hb.stk + (size_t)e * I * 4;
+  for (int i = lane; i < n * 4; i += 64) st.stk[i] = gs[i];
+  const double* gd = hb.den + (size_t)e * I;
+  for (int i = lane; i < n; i += 64) st.den[i] = gd[i];
+  const uint32_t* gm = hb.meta + (size_t)e * I * 2;
+  for (int i = lane; i < n * 2; i += 64) st.meta[i] = gm[i];
+  const uint32_t* gu = hb.up + (size_t)e * I;
+  for (int i = lane; i < n; i += 64) st.up[i] = gu[i];
+  const uint32_t* ge = hb.ent + (size_t)e * hb.sp_stride;
+  for (int i = lane; i < n_ent; i += 64) st.ent[i] = ge[i];
+  const double* gh = hb.share + (size_t)e * hb.sp_stride * 4;
+  for (int i = lane; i < n_ent * 4; i += 64) st.share[i] = gh[i];
+  const double* gp = hb.poly + (size_t)e * hb.pp_stride * 2;
+  for (int i = lane; i < n_poly * 2; i += 64) st.poly[i] = gp[i];
+  return true;
+}
+// LDS -> HBM.  `from_box`: boxes below it were already in HBM when the launch began -- of those only what a commit
+// walk may have rewritten goes back (stacks, meta words, up-list words, entry words and shares: everything but the
+// polygons, which never change once stored).
+__device__ __forceinline__ void stab_store(const StabHbm& hb, int I, int e, int n, const StabState& st, int poly_from, int lane) {
+  double* gs = hb.stk + (size_t)e * I * 4;
+  for (int i = lane; i < n * 4; i += 64) gs[i] = st.stk[i];
+  double* gd = hb.den + (size_t)e * I;
+  for (int i = lane; i < n; i += 64) gd[i] = st.den[i];
+  uint32_t* gm = hb.meta + (size_t)e * I * 2;
+  for (int i = lane; i < n * 2; i += 64) gm[i] = st.meta[i];
+  uint32_t* gu = hb.up + (size_t)e * I;
+  for (int i = lane; i < n; i += 64) gu[i] = st.up[i];
+  uint32_t* ge = hb.ent + (size_t)e * hb.sp_stride;
+  for (int i = lane; i < st.n_ent; i += 64) ge[i] = st.ent[i];
+  double* gh = hb.share + (size_t)e * hb.sp_stride * 4;
+  for (int i = lane; i < st.n_ent * 4; i += 64) gh[i] = st.share[i];
+  double* gp = hb.poly + (size_t)e * hb.pp_stride * 2;
+  for (int i = poly_from * 2 + lane; i < st.n_poly * 2; i += 64) gp[i] = st.poly[i];
+}
+#endif  // __HIPCC__
+
+// ---- the commit ---------------------------------------------------------------------------------------------------
+// calculated_impact() of the box just placed as id `n` (geometry already visible through geo(n, .)): records its
+// supporters / polygon / stack, propagates the shares downward and re-checks every box on the way (D/space.py:73-164).
+// Sequential (one lane).  `ws` / `ws_bytes`: workspace for the hull, then for the depth-first stack.
+// Returns 1: stable, 0: unstable, -1: a capacity (pools, workspace, supporters) was exceeded.
+template <bool CONT, typename Geo>
+PCT_SD int stab_commit(const Geo& geo, StabState& st, int n, double density, unsigned char* ws, int ws_bytes, bool& ill) {
+  double bg[9];
+  geo(n, bg);
+  // supporters: as many ids as the workspace can take a hull for
+  int kcap = 1;
+  while (kcap < STAB_NSUP_MAX && stab_ws_need(kcap + 1) <= ws_bytes) kcap++;
+  if (stab_ws_need(kcap) > ws_bytes) return -1;
+  StabWsView w = stab_ws_view(ws, kcap);
+  const int k = stab_find_supporters<CONT>(geo, n, bg, w.ids, kcap);
+  if (k > kcap || k > STAB_NSUP_MAX) return -1;
+  if (st.n_ent + k > st.SP || st.n_ent + k >= (int)STAB_END) return -1;
+  st.den[n] = density;
+  {
+    double sx = bg[6], sy = bg[7], sz = bg[8];
+    double* s = st.stk + (size_t)n * 4;
+    s[0] = bg[0] + sx / 2; s[1] = bg[1] + sy / 2; s[2] = bg[2] + sz / 2; s[3] = sx * sy * sz * density;
+  }
+  const int soff = st.n_ent, poff = st.n_poly;
+  st.up[n] = STAB_END | (STAB_END << 16);
+  for (int i = 0; i < k; i++) {  // one pool entry per supporter, chained at the tail of that supporter's up-list
+    const int S = (int)w.ids[i];
+    const uint32_t j = (uint32_t)(soff + i);
+    st.ent[j] = (uint32_t)S | ((uint32_t)n << 10) | (STAB_END << 20);
+    const uint32_t ht = st.up[S];
+    const uint32_t head = ht & 0xFFFFu, tail = ht >> 16;
+    if (head == STAB_END) st.up[S] = j | (j << 16);
+    else {
+      st.ent[tail] = (st.ent[tail] & 0xFFFFFu) | (j << 20);
+      st.up[S] = head | (j << 16);
+    }
+  }
+  st.n_ent += k;
+  int np = 0;
+  if (k > 0) {
+    StabSup sup{w.ids};
+    int nl, nu;
+    stab_hull<CONT>(geo, bg, k, sup, w.pts, w.up, nl, nu);
+    np = nl + nu;
+    if (np > 255 || st.n_poly + np > st.PP || st.n_poly + np > 0xFFFF) return -1;
+    double cx, cy;
+    stab_hull_centroid(w.pts, nl, w.up, nu, cx, cy);
+    for (int i = 0; i < np; i++) {
+      double vx, vy;
+      stab_hull_vertex(w.pts, nl, w.up, i, cx, cy, vx, vy);
+      st.poly[(size_t)(poff + i) * 2 + 0] = vx;
+      st.poly[(size_t)(poff + i) * 2 + 1] = vy;
+    }
+    st.n_poly += np;
+  }
+  st.meta[2 * n] = (uint32_t)k | (0u << 8) | ((uint32_t)np << 16);
+  st.meta[2 * n + 1] = (uint32_t)soff | ((uint32_t)poff << 16);
+  if (CONT ? (fabs(bg[2]) < 1e-6) : (bg[2] == 0)) return 1;  // max_h == 0: check_box returns first (:448-449)
+  // explicit depth-first walk; frame = box id | next supporter << 16
+  uint32_t* frames = reinterpret_cast<uint32_t*>(ws);
+  const int fcap = ws_bytes / 4;
+  int depth = 1;
+  frames[0] = (uint32_t)n;
+  while (depth > 0) {
+    const int d = depth - 1;
+    const int id = (int)(frames[d] & 0xFFFFu);
+    const int next = (int)(frames[d] >> 16);
+    const int kk = stab_nsup(st, id);
+    if (kk == 0) { depth--; continue; }
+    StabSup sup{st.ent + stab_soff(st, id)};
+    if (next == 0) {
+      const double (*gp)[2] = reinterpret_cast<const double (*)[2]>(st.poly + (size_t)stab_poff(st, id) * 2);
+      const double stk[4] = {st.stk[(size_t)id * 4 + 0], st.stk[(size_t)id * 4 + 1], st.stk[(size_t)id * 4 + 2],
+                             st.stk[(size_t)id * 4 + 3]};
+      if (!stab_pip(stk, gp, stab_npoly(st, id))) return 0;
+      // distribute to every supporter first (up_edges[self] = share; calculate_new_com())
+      double g[9];
+      geo(id, g);
+      StabSplit sp;
+      if (!stab_split<CONT>(geo, g, kk, sup, stk, sp)) return -1;
+      ill = ill || sp.ill;
+      const int alias_k = sp.mode == 0 ? 0 : (sp.mode == 1 ? sp.direct : -1);
+      st.meta[2 * id] = (st.meta[2 * id] & 0xFFFF00FFu) | ((uint32_t)(alias_k + 1) << 8);
+      const double own[3] = {stk[0], stk[1], stk[2]};
+      for (int i = 0; i < kk; i++) {
+        double sh[4];
+        stab_share_of<CONT>(geo, g, kk, sup, stk, own, false, sp, i, sh);
+        double* e = st.share + (size_t)(stab_soff(st, id) + i) * 4;
+        e[0] = sh[0]; e[1] = sh[1]; e[2] = sh[2]; e[3] = sh[3];
+        const int Si = sup(i);
+        double com[4];
+        stab_com(geo, st, Si, (int)STAB_NOBOX, (const double*)0, com);
+        double* t = st.stk + (size_t)Si * 4;
+        t[0] = com[0]; t[1] = com[1]; t[2] = com[2]; t[3] = com[3];
+      }
+    }
+    if (next >= kk) { depth--; continue; }
+    frames[d] = (uint32_t)id | ((uint32_t)(next + 1) << 16);
+    if (depth >= fcap) return -1;
+    frames[depth] = (uint32_t)sup(next);
     depth++;
   }
-  return true;
+  return 1;
 }
 
 }  // namespace pct

@@ -225,20 +225,24 @@ class PctVecEnv(VecEnv):
         # outputs live in torch tensors bound into the handle (zero copy)
         dev = self.device
         self._obs = torch.zeros(self.N, self.row_len, dtype=torch.float32, device=dev)
-        self._reward = torch.zeros(self.N, dtype=torch.float32, device=dev)
-        self._done = torch.zeros(self.N, dtype=torch.uint8, device=dev)
-        self._counter = torch.zeros(self.N, dtype=torch.int32, device=dev)
-        self._ratio = torch.zeros(self.N, dtype=torch.float64, device=dev)
-        self._flags = torch.zeros(self.N, dtype=torch.int32, device=dev)
+        # the small per-step outputs live in ONE device block (ratio f64 | reward f32 | counter i32 | flags u32 | done u8),
+        # so that step_wait hands them to the host with a single copy into a pinned mirror of the same layout
+        N = self.N
+        offs, o = {}, 0
+        for nm, dt, w in (("ratio", torch.float64, 8), ("reward", torch.float32, 4), ("counter", torch.int32, 4),
+                          ("flags", torch.int32, 4), ("done", torch.uint8, 1)):
+            offs[nm] = (o, o + N * w, dt)
+            o += N * w
+        self._pack = torch.zeros(o, dtype=torch.uint8, device=dev)
+        self._h_pack = torch.zeros(o, dtype=torch.uint8).pin_memory()
+        view = lambda buf, nm: buf[offs[nm][0]:offs[nm][1]].view(offs[nm][2])
+        self._ratio, self._reward, self._counter = view(self._pack, "ratio"), view(self._pack, "reward"), view(self._pack, "counter")
+        self._flags, self._done = view(self._pack, "flags"), view(self._pack, "done")
+        self._h_ratio, self._h_reward, self._h_counter = view(self._h_pack, "ratio"), view(self._h_pack, "reward"), view(self._h_pack, "counter")
+        self._h_flags, self._h_done = view(self._h_pack, "flags"), view(self._h_pack, "done")
         self._own = (self._obs, self._reward)
         self._slot_keepalive = None
         self._bind_own_views()
-        # pinned host mirrors for the small per-step outputs
-        self._h_reward = torch.zeros(self.N, dtype=torch.float32).pin_memory()
-        self._h_done = torch.zeros(self.N, dtype=torch.uint8).pin_memory()
-        self._h_counter = torch.zeros(self.N, dtype=torch.int32).pin_memory()
-        self._h_ratio = torch.zeros(self.N, dtype=torch.float64).pin_memory()
-        self._h_flags = torch.zeros(self.N, dtype=torch.int32).pin_memory()
         self._actions_keepalive = None
         self.waiting_step = False
 
@@ -301,8 +305,16 @@ class PctVecEnv(VecEnv):
 
     @property
     def error_flags(self):
-        """Sticky per-env PCT_FLAG_* bits (synchronises the stream)."""
-        return self._flags.cpu().numpy().view(np.uint32)
+        """Sticky per-env PCT_FLAG_* ERROR bits (synchronises the stream); the non-fatal notice PCT_FLAG_ILL_CONDITIONED
+        is reported by `ill_conditioned` instead."""
+        return self._flags.cpu().numpy().view(np.uint32) & np.uint32(_lib.FLAG_ERROR_MASK)
+
+    @property
+    def ill_conditioned(self):
+        """bool [N]: the env has taken a >= 3-supporter load split whose rank decision lay within a factor 1000 of the
+        least-squares cut (PCT_FLAG_ILL_CONDITIONED, sticky): from there on the reference's own verdicts depend on its
+        LAPACK build and may differ."""
+        return (self._flags.cpu().numpy().view(np.uint32) & np.uint32(_lib.FLAG_ILL_CONDITIONED)) != 0
 
     # ------------------------------------------------------------------ VecEnv surface
     def reset(self):
@@ -452,12 +464,10 @@ class PctVecEnv(VecEnv):
         return out
 
     def step_wait(self):
-        # one small async D2H per output, then a single stream sync (envs.py:178-182)
-        self._h_reward.copy_(self._reward, non_blocking=True)
-        self._h_done.copy_(self._done, non_blocking=True)
-        self._h_counter.copy_(self._counter, non_blocking=True)
-        self._h_ratio.copy_(self._ratio, non_blocking=True)
-        self._h_flags.copy_(self._flags, non_blocking=True)
+        # ONE async D2H of the packed output block, then a single stream sync (envs.py:178-182)
+        self._h_pack.copy_(self._pack, non_blocking=True)
+        if self._reward.data_ptr() != self._own[1].data_ptr():  # a rollout slot holds the reward (step_into)
+            self._h_reward.copy_(self._reward, non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()
         self.waiting_step = False
         reward = self._h_reward.clone().unsqueeze(1)
@@ -465,7 +475,7 @@ class PctVecEnv(VecEnv):
         counter = self._h_counter.numpy().copy()
         ratio = self._h_ratio.numpy().copy()
         if self.strict:
-            f = self._h_flags.numpy().view(np.uint32)
+            f = self._h_flags.numpy().view(np.uint32) & np.uint32(_lib.FLAG_ERROR_MASK)
             if f.any():
                 bad = int(np.nonzero(f)[0][0])
                 raise PctEnvError("env %d raised error flags 0x%x (include/pct_env.h PCT_FLAG_*)" % (bad, int(f[bad])))

@@ -179,7 +179,9 @@ static int point_in_polygon(const double pt[2], double (*co)[2], int n) {
  * to eps * sigma_max, as dgelsd does -- the normal-equations form loses everything below sqrt(eps) * sigma_max
  * and then disagrees with LAPACK by up to 5e-3 on the nearly rank-deficient systems this check produces. */
 static void lstsq_min_norm(const double* A, const double* b, int M, int N, double* x) {
-  double U[(16 * 15 / 2 + 1) * 16], V[16 * 16];
+  double* U = (double*)malloc(sizeof(double) * (size_t)M * N);
+  double* V = (double*)malloc(sizeof(double) * (size_t)N * N);
+  double* s2 = (double*)malloc(sizeof(double) * (size_t)N);
   for (int i = 0; i < M * N; i++) U[i] = A[i];
   for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) V[i * N + j] = (i == j);
   for (int sweep = 0; sweep < 60; sweep++) {
@@ -210,7 +212,7 @@ static void lstsq_min_norm(const double* A, const double* b, int M, int N, doubl
       }
     if (!rotated) break;
   }
-  double s2[16], smax2 = 0;
+  double smax2 = 0;
   for (int j = 0; j < N; j++) {
     double a2 = 0;
     for (int r = 0; r < M; r++) a2 += U[r * N + j] * U[r * N + j];
@@ -226,6 +228,7 @@ static void lstsq_min_norm(const double* A, const double* b, int M, int N, doubl
     proj /= s2[j];
     for (int i = 0; i < N; i++) x[i] += V[i * N + j] * proj;
   }
+  free(U); free(V); free(s2);
 }
 
 /* ---- Box ------------------------------------------------------------------------------- */
@@ -340,7 +343,7 @@ static int impact(struct stab* s, sbox* b, int key, int virtual_) {
         }
       for (int j = 0; j < k; j++) A[(M - 1) * k + j] = 1;
       rhs[M - 1] = 1;
-      if (k <= 16) lstsq_min_norm(A, rhs, M, k, xr);
+      lstsq_min_norm(A, rhs, M, k, xr);
       for (int i = 0; i < k; i++) {
         sstack sh = {{b->bottom[i].c2[0], b->bottom[i].c2[1], st->c[2]}, st->m * xr[i]};
         GIVE(i, sh, 0);

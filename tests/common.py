@@ -67,7 +67,7 @@ GOLDEN_CASES = ["discrete_s2_10_80_50", "discrete_s2_rect_60_30", "discrete_s2_1
                 "discrete_s3_10_80_50", "discrete_s3_rect_60_30",
                 "discrete_s2_ep_10_80_50", "discrete_s2_ep_rect_60_16", "discrete_s1_ep_10_80_50",
                 "discrete_s2_ev_10_80_50", "discrete_s1_ev_rect_60_24", "discrete_s2_ev_small_bin",
-                "discrete_s1_flat_lstsq", "discrete_s3_flat_lstsq"]
+                "discrete_s1_flat_lstsq", "discrete_s3_flat_lstsq", "discrete_s1_flat20"]
 LNES_CODE = {"EMS": 0, "EV": 1, "EP": 2, "CP": 3, "FC": 4}
 
 CONT_CASES = ["continuous_s2_10_80_50", "continuous_s2_100_200_200", "continuous_s2_rect_60_20",
@@ -79,7 +79,7 @@ CONT_STAB_CASES = ["continuous_s1_10_80_50", "continuous_s1_unit_80_50", "contin
 # CPU-only fixtures (stability, settings 1/3: restated in the oracle, not yet on the GPU)
 ORACLE_ONLY_CASES = []
 STAB_CASES = ["discrete_s1_10_80_50", "discrete_s1_rect_60_30", "discrete_s3_10_80_50", "discrete_s3_rect_60_30",
-              "discrete_s1_flat_lstsq", "discrete_s3_flat_lstsq"]
+              "discrete_s1_flat_lstsq", "discrete_s3_flat_lstsq", "discrete_s1_flat20"]
 
 DATASET_CASES = ["discrete_s2_dataset", "continuous_s2_dataset", "discrete_s3_dataset", "continuous_s3_dataset"]
 

@@ -143,6 +143,11 @@ CASES = {
                                    stream_T=512, seed=67, base=44, flat=True),
     "discrete_s3_flat_lstsq": dict(setting=3, container=(12, 10, 8), lo=1, hi=7, I=150, L=40, N=3, steps=250,
                                    stream_T=512, seed=63, base=45, flat=True),
+    # a 20^3 bin of flat items under setting 1 -- wide boxes on many supporters, hundreds of placed
+    # boxes: outgrows the stability pools / walk queue of the normal pass (round 2: 16 supporters, 24 hull vertices and
+    # depth 24 were hard limits and such an env was flagged and terminated); must run through the large-capacity pass
+    "discrete_s1_flat20": dict(setting=1, container=(20, 20, 20), lo=2, hi=9, I=320, L=60, N=2, steps=300,
+                               stream_T=512, seed=73, base=47, flat=True),
 }
 
 

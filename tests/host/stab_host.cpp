@@ -3,9 +3,13 @@
 // exposes it under the oracle's stab_* interface, so that `make -C tests/host` yields an
 // oracle variant (libpct_oracle_prodstab.so) whose stability decisions come from the product
 // source.  tests/test_stab_host.py runs the setting-1 reference fixtures through it: the
-// restructuring (no recursion, no dictionaries, lazy virtual stacks) is thereby checked on the
-// CPU against the reference before it is trusted on the GPU.  Nothing in the product uses this.
+// restructuring (pooled LDS-shaped state, up-lists instead of dictionaries, the virtual walk as
+// independent tasks) is thereby checked on the CPU against the reference before it is trusted on
+// the GPU.  The tasks a wave pops 64 at a time are popped one at a time here, LAST IN FIRST OUT
+// like the device queue (their order cannot matter: see the header of pct_stab.cuh).
+// Nothing in the product uses this.
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -18,29 +22,18 @@ struct stab {
   int n;
   std::vector<double> geo;  // [cap][9] lx,ly,lz,xe,ye,ze,sx,sy,sz
   bool cont;
-  std::vector<double> stack, share, poly, den;
-  std::vector<int> nsup, sup, npoly, alias;
-  int overflow;
+  pct::StabCaps caps;
+  std::vector<unsigned char> mem, ws;
+  pct::StabState st;
+  int overflow, ill;
+  int max_k0, max_q, max_ent, max_poly, max_split_k;  // statistics (PCT_STAB_HOST_STATS=1 prints them at stab_free)
 };
 
 struct GeoFn {
   const double* g;
   void operator()(int i, double out[9]) const { memcpy(out, g + 9 * (size_t)i, 9 * sizeof(double)); }
 };
-
-static pct::StabState view(stab* s) {
-  pct::StabState st;
-  st.I = s->cap;
-  st.stack = s->stack.data();
-  st.nsup = s->nsup.data();
-  st.sup = s->sup.data();
-  st.share = s->share.data();
-  st.npoly = s->npoly.data();
-  st.poly = s->poly.data();
-  st.den = s->den.data();
-  st.alias = s->alias.data();
-  return st;
-}
+struct Task { int S; double stk[4]; };
 
 extern "C" {
 struct stab* stab_create(int cap, double eps) {
@@ -49,38 +42,70 @@ struct stab* stab_create(int cap, double eps) {
   s->cap = cap + 2;
   s->n = 0;
   s->overflow = 0;
+  s->ill = 0;
   s->geo.assign((size_t)s->cap * 9, 0.0);
-  s->stack.assign((size_t)s->cap * 4, 0.0);
-  s->share.assign((size_t)s->cap * pct::STAB_SMAX * 4, 0.0);
-  s->poly.assign((size_t)s->cap * pct::STAB_PMAX * 2, 0.0);
-  s->nsup.assign((size_t)s->cap, 0);
-  s->sup.assign((size_t)s->cap * pct::STAB_SMAX, 0);
-  s->npoly.assign((size_t)s->cap, 0);
-  s->den.assign((size_t)s->cap, 1.0);
-  s->alias.assign((size_t)s->cap, -1);
+  // deliberately small pools by default (PCT_STAB_HOST_SP / _PP / _WS override): the capacity paths are exercised too
+  const char* e;
+  s->caps.SP = (e = getenv("PCT_STAB_HOST_SP")) ? atoi(e) : 4000;
+  s->caps.PP = (e = getenv("PCT_STAB_HOST_PP")) ? atoi(e) : 60000;
+  s->caps.ws_bytes = (e = getenv("PCT_STAB_HOST_WS")) ? atoi(e) : pct::stab_ws_need(255);
+  s->caps.queue = 0;
+  s->mem.assign(pct::stab_state_bytes(s->cap, s->caps) + 16, 0);
+  s->ws.assign((size_t)s->caps.ws_bytes + 16, 0);
+  s->st = pct::stab_carve(s->mem.data(), s->cap, s->caps);
   return s;
 }
-void stab_reset(struct stab* s) { s->n = 0; }
-void stab_free(struct stab* s) { delete s; }
+void stab_reset(struct stab* s) { s->n = 0; s->st.n_ent = 0; s->st.n_poly = 0; }
+void stab_free(struct stab* s) {
+  if (getenv("PCT_STAB_HOST_STATS"))
+    fprintf(stderr, "stab stats: max supporters of a candidate %d, max queue %d, max pool entries %d, max polygon vertices %d\n",
+            s->max_k0, s->max_q, s->max_ent, s->max_poly);
+  delete s;
+}
 int stab_overflowed(struct stab* s) { return s->overflow; }
+int stab_ill_conditioned(struct stab* s) { return s->ill; }
 
 int stab_check(struct stab* s, double x, double y, double z, double lx, double ly, double max_h, double density,
                int virtual_) {
   GeoFn geo{s->geo.data()};
-  pct::StabState st = view(s);
-  bool err = false;
+  bool ill = false;
   double cand[9] = {lx, ly, max_h, lx + x, ly + y, max_h + z, x, y, z};
   if (virtual_) {
     if (s->cont ? (fabs(max_h) < 1e-6) : (max_h == 0)) return 1;  // space.py:448-449
-    bool ok = s->cont ? pct::stab_virtual<true>(geo, st, s->n, cand, density, err)
-                      : pct::stab_virtual<false>(geo, st, s->n, cand, density, err);
-    if (err) s->overflow = 1;
-    return ok ? 1 : 0;
+    int kcap = 1;
+    while (kcap < pct::STAB_NSUP_MAX && pct::stab_ws_need(kcap + 1) <= s->caps.ws_bytes) kcap++;
+    pct::StabWsView w = pct::stab_ws_view(s->ws.data(), kcap);
+    const int k = s->cont ? pct::stab_find_supporters<true>(geo, s->n, cand, w.ids, kcap)
+                          : pct::stab_find_supporters<false>(geo, s->n, cand, w.ids, kcap);
+    if (k > kcap) { s->overflow = 1; return 0; }
+    if (k > s->max_k0) s->max_k0 = k;
+    std::vector<Task> q;
+    auto emit = [&](int Si, const double child[4]) { Task t; t.S = Si; memcpy(t.stk, child, sizeof t.stk); q.push_back(t); };
+    int rc = s->cont ? pct::stab_level0<true>(geo, s->st, cand, density, k, w, ill, emit)
+                     : pct::stab_level0<false>(geo, s->st, cand, density, k, w, ill, emit);
+    while (rc == 1 && !q.empty()) {
+      if ((int)q.size() > s->max_q) s->max_q = (int)q.size();
+      Task t = q.back();
+      q.pop_back();
+      rc = s->cont ? pct::stab_visit<true>(geo, s->st, t.S, t.stk, ill, emit) : pct::stab_visit<false>(geo, s->st, t.S, t.stk, ill, emit);
+    }
+    if (ill) s->ill = 1;
+    if (rc < 0) { s->overflow = 1; return 0; }
+    return rc;
   }
   memcpy(s->geo.data() + 9 * (size_t)s->n, cand, sizeof cand);
-  bool ok = s->cont ? pct::stab_commit<true>(geo, st, s->n, density, err) : pct::stab_commit<false>(geo, st, s->n, density, err);
-  if (err) s->overflow = 1;
-  if (ok) s->n++;
-  return ok ? 1 : 0;
+  // a failed commit leaves the pools as they were (the device requeues / resets the env; here the caller goes on)
+  const int ne = s->st.n_ent, np = s->st.n_poly;
+  std::vector<unsigned char> snap(s->mem);
+  int rc = s->cont ? pct::stab_commit<true>(geo, s->st, s->n, density, s->ws.data(), s->caps.ws_bytes, ill)
+                   : pct::stab_commit<false>(geo, s->st, s->n, density, s->ws.data(), s->caps.ws_bytes, ill);
+  if (ill) s->ill = 1;
+  if (rc < 0) s->overflow = 1;
+  if (s->st.n_ent > s->max_ent) s->max_ent = s->st.n_ent;
+  if (s->st.n_poly > s->max_poly) s->max_poly = s->st.n_poly;
+  if (rc == 1) { s->n++; return 1; }
+  s->mem = snap;
+  s->st.n_ent = ne; s->st.n_poly = np;
+  return 0;
 }
 }

@@ -192,3 +192,35 @@ def test_discrete_overflow_is_rerun_with_larger_lists(name, ems, cand):
         assert np.array_equal(reward[:, 0].numpy().astype(np.float64), z["reward"][t].astype(np.float32).astype(np.float64))
     assert not env.error_flags.any(), np.unique(env.error_flags)
     env.close()
+
+
+@pytest.mark.parametrize("name", ["discrete_s1_flat20", "discrete_s1_flat_lstsq", "discrete_s3_10_80_50", "continuous_s1_flat_lstsq",
+                                  "continuous_s1_10_80_50"])
+def test_stability_overflow_is_rerun_with_larger_pools(name, monkeypatch):
+    """VERDICT r2 item 6 / ADVICE r2: no env of the stability settings dies of a capacity either.  With stability pools,
+    hull workspace and walk queue far too small for the fixture (normal pass: 24 pool entries, 48 polygon vertices, room
+    for two 2-supporter hulls, 8 queue slots), every env soon outgrows them -- in the commit of a placed box or in a
+    candidate's virtual check -- and is handed, state untouched (the stability state is LDS-resident during a transition:
+    nothing of a half-done commit has been stored), to the large-capacity pass.  The trajectory must still equal the
+    reference fixture (the 20^3 flat-item one among them: hundreds of least-squares splits, boxes on up to 9 supporters)
+    and no flag may be raised."""
+    for k, v in (("PCT_STAB_SP", "24"), ("PCT_STAB_PP", "48"), ("PCT_STAB_WS", "560"), ("PCT_STAB_Q", "8")):
+        monkeypatch.setenv(k, v)
+    c, z = load_case(name)
+    kw = dict(setting=c["setting"], container_size=c["container"], internal_node_holder=c["I"], leaf_node_holder=c["L"],
+              env_id_base=c["base"], item_stream=z["stream"], device="cuda:0")
+    if name.startswith("continuous"):
+        env = _pkg().PctVecEnv(c["N"], continuous=True, sample_left_bound=c["lo"], sample_right_bound=c["hi"], **kw)
+    else:
+        env = _pkg().PctVecEnv(c["N"], item_set=case_items(c), **kw)
+    if "density" in z.files:
+        env.set_density_stream(z["density"])
+    obs = env.reset()
+    for t in range(c["steps"]):
+        o = obs.cpu().numpy()
+        assert np.array_equal(o, z["obs"][t].astype(np.float32)), (name, t)
+        env.step_hash_policy(1)
+        obs, reward, done, infos = env.step_wait()
+        assert np.array_equal(done.astype(np.uint8), z["done"][t]), (name, t)
+    assert not env.error_flags.any(), [hex(int(x)) for x in np.unique(env.error_flags)]
+    env.close()
