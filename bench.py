@@ -175,6 +175,12 @@ def main():
                     help="discrete env: do not enqueue the large-capacity retry pass behind every transition (the product "
                          "default enqueues it: an env that outgrows its LDS lists is re-run instead of terminated; costs one "
                          "more, usually empty, kernel launch per step)")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="process-group backend of the N > 1 line (nccl = RCCL over xGMI; gloo only for the two-rank smoke "
+                         "test that shares one GPU, tests/test_gpu_multiproc.py)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="smoke test only: every rank uses cuda:0 (the N > 1 code path -- barrier, MAX-reduce of the "
+                         "elapsed time, per-rank gather -- on a one-GPU box; not a measurement)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -189,13 +195,19 @@ def main():
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    red_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")  # where the reduction tensors live
 
     pkg = importlib.import_module("online-3d-bpp-pct_amd")
     n_local = args.envs_per_gpu or w["envs"]
@@ -262,10 +274,10 @@ def main():
     kern_avg_ms = kern_ms / max(n_launch, 1)
     per_rank_us = [kern_avg_ms * 1e3]
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        mine = torch.tensor([kern_avg_ms * 1e3], dtype=torch.float64, device=dev)
+        mine = torch.tensor([kern_avg_ms * 1e3], dtype=torch.float64, device=red_dev)
         allk = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allk, mine)
         per_rank_us = [float(x.item()) for x in allk]

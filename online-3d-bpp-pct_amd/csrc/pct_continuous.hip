@@ -1056,11 +1056,11 @@ __device__ inline void cstore(const ContinuousParams& p, int e, const CLds& l, c
 // observation's candidate set outgrew this launch's table -- requeue
 template <bool GT, bool STAB, bool MT, typename TM>
 __device__ inline int ctransition(const ContinuousParams& p, int e, CLds& l, CRegs& r, int lane, int flag, double a1,
-                                   double a2, double bx, double by, double bz, TM& tm, double newbox[6]) {
+                                   double a2, double bx, double by, double bz, TM& tm, double newbox[6], bool giveup = false) {
   r.t++;
   const double lx = around6(a1), ly = around6(a2);  // idx = [round(action[1], 6), round(action[2], 6)]
   const double x = flag ? by : bx, y = flag ? bx : by, z = bz;  // C/space.py:330-333
-  bool ok = true;
+  bool ok = !giveup;  // giveup: a heuristic found no placement -- the episode ends without a step()
   if (lx + x - 1e-6 > p.W || ly + y - 1e-6 > p.Ly) ok = false;
   if (lx + 1e-6 < 0 || ly + 1e-6 < 0) ok = false;
   double max_h = 0.0;
@@ -1147,7 +1147,7 @@ __device__ inline int ctransition(const ContinuousParams& p, int e, CLds& l, CRe
     done = 1;
     counter = r.n_boxes;
     ratio = r.volsum / mx;
-    r.oc++;  // the terminal step's own (discarded) observation (C/bin3D.py:183)
+    if (!giveup) r.oc++;  // the terminal step's own (discarded) observation (C/bin3D.py:183)
     __syncthreads();
     if (MT) {
       // that observation draws a NEW item, a density, and shuffles the new item's candidates on the final packing
@@ -1175,6 +1175,238 @@ __device__ inline int ctransition(const ContinuousParams& p, int e, CLds& l, CRe
   return done != 0 ? 1 : 0;
 }
 
+#ifndef PCT_CONT_MT
+// ---- heuristic.py on PackingContinuous (tools.py:217-218: LSAH, OnlineBPH, BR) as in-env policies -------------------
+// See oracle/pct_oracle_cont.c pctc_heur_choose for the sequential statement (pinned on the reference's own loops).
+// lane = (EMS, rotation) pair in the reference's loop order; float64 in the reference's operation order.
+__device__ inline void cheur_rot(const CRegs& r, int rot, double& x, double& y, double& z) {  // heuristic.py:171-182
+  switch (rot) {
+    case 0: x = r.b0; y = r.b1; z = r.b2; break;
+    case 1: y = r.b0; x = r.b1; z = r.b2; break;
+    case 2: z = r.b0; x = r.b1; y = r.b2; break;
+    case 3: z = r.b0; y = r.b1; x = r.b2; break;
+    case 4: x = r.b0; z = r.b1; y = r.b2; break;
+    default: y = r.b0; z = r.b1; x = r.b2; break;
+  }
+}
+__device__ inline double wave_min_f64(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    double o = __shfl_xor(v, off, 64);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+__device__ inline int wave_min_i32(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    int o = __shfl_xor(v, off, 64);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+// returns false if there is no feasible placement.  (olx, oly): position, (ox, oy, oz): the item as rotated.
+template <bool STAB>
+__device__ inline bool cheur_choose(const ContinuousParams& p, int e, CLds& l, CRegs& r, int lane, int kind, double& olx,
+                                    double& oly, double& ox, double& oy, double& oz) {
+  const int orient = (p.setting == 2) ? 6 : 2;
+  const int E = r.n_ems, NQ = E * orient, nb = r.n_boxes;
+  const double den = STAB ? next_density(p, e, r.oc - 1, r.traj, r.cursor - 1) : 1.0;
+  // drop_box_virtual(..., returnH=True) (C/space.py:380-425) of size (x, y, z) at (lx, ly).  ALL 64 lanes call (`go`: this
+  // lane has a placement to test): the stability check is wave-cooperative
+  auto probe = [&](bool go, double x, double y, double z, double lx, double ly, double& height) -> bool {
+    bool ok = go;
+    if (lx + x - 1e-6 > p.W || ly + y - 1e-6 > p.Ly) ok = false;
+    if (lx + 1e-6 < 0 || ly + 1e-6 < 0) ok = false;
+    int c0 = klat(-lx), c1 = klat(-ly), c2 = klat(lx + x), c3 = klat(ly + y);
+    double max_h = 0.0;
+    if (go)
+      for (int b2 = 0; b2 < nb; b2++) {
+        int u0 = l.bk[0 * p.I + b2], u1 = l.bk[1 * p.I + b2], u2 = l.bk[2 * p.I + b2], u3 = l.bk[3 * p.I + b2];
+        bool ov = (min(c0, u0) + min(c2, u2) > 0) && (min(c1, u1) + min(c3, u3) > 0);
+        double top = l.top[b2];
+        max_h = (ov && top > max_h) ? top : max_h;
+      }
+    if (max_h + z - 1e-6 > p.H) ok = false;
+    height = max_h;
+    if (STAB) {
+      const bool need = ok && !(fabs(max_h) < 1e-6);
+      if (__ballot(need)) {
+        const double cand[9] = {lx, ly, max_h, lx + x, ly + y, max_h + z, x, y, z};
+        CGeo geo{l.box, l.bsz, p.I};
+        uint32_t cap = 0;
+        bool ill = false, lerr = false;
+        const bool stable = stab_virtual_wave<true>(geo, l.st, nb, need, cand, den, l.sw, lane, cap, lerr, ill);
+        if (need) ok = stable && !cap;
+        r.stab_over |= cap;
+        if (__ballot(need && lerr)) r.stab_over |= STAB_WHY_SPLIT;
+      }
+    }
+    return ok;
+  };
+  auto ems_of = [&](int ei, double em[6]) {
+#pragma unroll
+    for (int c = 0; c < 6; c++) em[c] = lat2d(l.emsk[c * p.ems_cap + ei]);
+  };
+  bool found = false;
+  if (kind == PCT_HEUR_OBPH) {
+    // :364-425: EMS sorted by (z, y, x), stable; first feasible (EMS, rotation); no fit-in-EMS test.  The lattice indices
+    // order like the doubles: the winner is the lexicographic minimum of (kz, ky, kx, q) over the feasible pairs
+    int bz = 0x7fffffff, by = 0x7fffffff, bx = 0x7fffffff, bq = 0x7fffffff;
+    for (int pass = 0; pass < 4; pass++) {
+      int best = 0x7fffffff;
+      for (int base = 0; base < NQ; base += 64) {
+        const int q = base + lane;
+        const bool live = q < NQ;
+        const int ei = live ? q / orient : 0, rot = q - ei * orient;
+        const int kz = l.emsk[2 * p.ems_cap + ei], ky = l.emsk[1 * p.ems_cap + ei], kx = l.emsk[0 * p.ems_cap + ei];
+        // later passes only look at the pairs that tie on the earlier keys
+        const bool in = live && (pass < 1 || kz == bz) && (pass < 2 || ky == by) && (pass < 3 || kx == bx);
+        double x, y, z, hh, em[6];
+        cheur_rot(r, rot, x, y, z);
+        ems_of(ei, em);
+        // (feasibility is the expensive part: it is evaluated once, in the first pass, and kept as a bit in the scratch)
+        bool feas;
+        if (pass == 0) {
+          feas = probe(live, x, y, z, em[0], em[1], hh);
+          const uint64_t fm = __ballot(feas);
+          if (lane == 0) { l.tab[(base >> 6) * 2] = (uint32_t)fm; l.tab[(base >> 6) * 2 + 1] = (uint32_t)(fm >> 32); }
+        } else {
+          const uint64_t fm = ((uint64_t)l.tab[(base >> 6) * 2 + 1] << 32) | l.tab[(base >> 6) * 2];
+          feas = (fm >> lane) & 1ull;
+        }
+        const int key = pass == 0 ? kz : (pass == 1 ? ky : (pass == 2 ? kx : q));
+        if (in && feas && key < best) best = key;
+      }
+      __syncthreads();
+      best = wave_min_i32(best);
+      if (best == 0x7fffffff) return false;
+      if (pass == 0) bz = best; else if (pass == 1) by = best; else if (pass == 2) bx = best; else bq = best;
+    }
+    const int ei = bq / orient, rot = bq - ei * orient;
+    double em[6];
+    ems_of(ei, em);
+    olx = em[0]; oly = em[1];
+    cheur_rot(r, rot, ox, oy, oz);
+    return true;
+  }
+  if (kind == PCT_HEUR_BR) {
+    // :500-569: the EMS with the best eval_ems (volume + item types that fit unrotated, + 10 if all do); first best in
+    // (EMS, rotation) order.  Two reductions: the best score among the feasible pairs, then the first pair holding it
+    double* const esc = reinterpret_cast<double*>(l.tab);  // [E] per-EMS scores (the table region is idle between observations)
+    for (int base = 0; base < E; base += 64) {
+      const int ei = base + lane;
+      if (ei < E) {
+        double em[6];
+        ems_of(ei, em);
+        const double dx = em[3] - em[0], dy = em[4] - em[1], dz = em[5] - em[2];
+        int valid = 0;
+        for (int i = 0; i < p.n_items; i++)
+          valid += (dx >= p.item_set[3 * i] / 1000.0 && dy >= p.item_set[3 * i + 1] / 1000.0 && dz >= p.item_set[3 * i + 2] / 1000.0) ? 1 : 0;
+        double sc = 0;
+        sc += dx * dy * dz;
+        sc += valid;
+        if (valid == p.n_items) sc += 10;
+        esc[ei] = sc;
+      }
+    }
+    __syncthreads();
+    double smax = -1e10;
+    uint32_t* const fbits = l.tab + 2 * ((E + 1) & ~1) + 2;  // feasibility bits of the chunks, behind the scores
+    for (int base = 0; base < NQ; base += 64) {
+      const int q = base + lane;
+      const bool live = q < NQ;
+      const int ei = live ? q / orient : 0, rot = q - ei * orient;
+      double x, y, z, hh, em[6];
+      cheur_rot(r, rot, x, y, z);
+      ems_of(ei, em);
+      const bool fits = live && (em[3] - em[0] >= x) && (em[4] - em[1] >= y) && (em[5] - em[2] >= z);
+      const bool feas = probe(fits, x, y, z, em[0], em[1], hh);
+      const uint64_t fm = __ballot(feas);
+      if (lane == 0) { fbits[(base >> 6) * 2] = (uint32_t)fm; fbits[(base >> 6) * 2 + 1] = (uint32_t)(fm >> 32); }
+      if (feas && esc[ei] > smax) smax = esc[ei];
+    }
+    __syncthreads();
+    smax = wave_max_f64(smax);
+    int bq = 0x7fffffff;
+    for (int base = 0; base < NQ; base += 64) {
+      const int q = base + lane;
+      const uint64_t fm = ((uint64_t)fbits[(base >> 6) * 2 + 1] << 32) | fbits[(base >> 6) * 2];
+      if (q < NQ && ((fm >> lane) & 1ull) && esc[q / orient] == smax && q < bq) bq = q;
+    }
+    bq = wave_min_i32(bq);
+    __syncthreads();
+    if (bq == 0x7fffffff) return false;
+    const int ei = bq / orient, rot = bq - ei * orient;
+    double em[6];
+    ems_of(ei, em);
+    olx = em[0]; oly = em[1];
+    cheur_rot(r, rot, ox, oy, oz);
+    return true;
+  }
+  // :138-226 LASH: least surface area of the bounding box of everything packed so far.  maxXY / minXY: lx + x and lx of
+  // every placed box, as the reference accumulates them (the raw float64 sums of the HBM box rows)
+  double maxX = 0, maxY = 0, minX = p.W, minY = p.Ly;
+  {
+    const double* gb = p.boxes + (size_t)e * 6 * p.I;
+    double a = 0, b = 0, c = p.W, d = p.Ly;
+    for (int i = lane; i < nb; i += 64) {
+      const double lx = gb[0 * p.I + i], ly = gb[1 * p.I + i], xe = gb[3 * p.I + i], ye = gb[4 * p.I + i];
+      a = xe > a ? xe : a; b = ye > b ? ye : b; c = lx < c ? lx : c; d = ly < d ? ly : d;
+    }
+    maxX = wave_max_f64(a); maxY = wave_max_f64(b); minX = wave_min_f64(c); minY = wave_min_f64(d);
+  }
+  const double init = p.W * p.Ly + p.Ly * p.H + p.H * p.W;
+  double* const scq = reinterpret_cast<double*>(l.tab);  // [NQ] scores (+inf: not a candidate)
+  double smin = INFINITY;
+  for (int base = 0; base < NQ; base += 64) {
+    const int q = base + lane;
+    const bool live = q < NQ;
+    const int ei = live ? q / orient : 0, rot = q - ei * orient;
+    double x, y, z, height, em[6];
+    cheur_rot(r, rot, x, y, z);
+    ems_of(ei, em);
+    const double dx = em[3] - em[0], dy = em[4] - em[1], dz = em[5] - em[2];
+    const double lx = em[0], ly = em[1];
+    double sc = INFINITY;
+    if (probe(live && dx >= x && dy >= y && dz >= z, x, y, z, lx, ly, height)) {
+      const double ex = fmax(lx + x, maxX) - fmin(lx, minX), ey = fmax(ly + y, maxY) - fmin(ly, minY);
+      sc = ex * ey + (height + z) * ey + (height + z) * ex;
+    }
+    if (live) scq[q] = sc;
+    smin = sc < smin ? sc : smin;
+  }
+  smin = wave_min_f64(smin);
+  __syncthreads();
+  if (smin < init) {  // a score equal to the initial bound is never taken (:195-199 needs a best already)
+    double bd0 = 0, bd1 = 0, bd2 = 0;
+    for (int base = 0; base < NQ; base += 64) {
+      const int q = base + lane;
+      uint64_t m = __ballot(q < NQ && scq[q] == smin);
+      while (m) {  // the candidates that tie on the best score, in loop order (:195-199)
+        const int bit = __ffsll((unsigned long long)m) - 1;
+        m &= m - 1;
+        const int qq = base + bit;
+        const int ei = qq / orient, rot = qq - ei * orient;
+        double x, y, z, em[6];
+        cheur_rot(r, rot, x, y, z);
+        ems_of(ei, em);
+        const double dx = em[3] - em[0], dy = em[4] - em[1], dz = em[5] - em[2];
+        bool take = !found;
+        if (found) take = fmin(fmin(dx - x, dy - y), dz - z) < fmin(fmin(bd0 - x, bd1 - y), bd2 - z);
+        if (take) {
+          found = true;
+          olx = em[0]; oly = em[1]; ox = x; oy = y; oz = z;
+          bd0 = dx; bd1 = dy; bd2 = dz;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  return found;
+}
+#endif  // !PCT_CONT_MT
+
 // C/bin3D.py:151-167 LeafNode2Action on a float64 row (a0,a1,_,a3,a4,_)
 __device__ inline void cdecode_leaf(const CRegs& r, bool zero_row, double a0, double a1, double a3, double a4, double& p1,
                                     double& p2, double& bx, double& by, double& bz) {
@@ -1200,7 +1432,7 @@ __device__ inline void cdecode_leaf(const CRegs& r, bool zero_row, double a0, do
   p1 = a0; p2 = a1; bx = x; by = y; bz = nb[rec[0]];
 }
 
-enum { CACT_ROWS = 0, CACT_INDEX = 1, CACT_HASH = 2, CACT_RESET = 3 };
+enum { CACT_ROWS = 0, CACT_INDEX = 1, CACT_HASH = 2, CACT_RESET = 3, CACT_HEUR = 4 /* row_len = PCT_HEUR_* */ };
 
 template <int ACT, bool TIMED, bool GT, bool STAB, bool MT>
 #ifndef PCT_CONT_WAVES
@@ -1208,7 +1440,10 @@ template <int ACT, bool TIMED, bool GT, bool STAB, bool MT>
                             as fast at 4096 envs (211.1 vs 211.7 us, C3) and 4.5 % faster at 8192, but its spill traffic makes
                             162 MB of HBM traffic per launch out of 19.5 MB of algorithmic bytes; 2 (no spills): 37 MB */
 #endif
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((STAB || TIMED) ? 1 : PCT_CONT_WAVES)))
+#ifndef PCT_STAB_WAVES
+#define PCT_STAB_WAVES 1 /* waves per SIMD the stability-check kernels are compiled for (2: 256 VGPRs, ~470 of them spilled -- slower, profiles/r03_stability_tuning.txt) */
+#endif
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TIMED ? 1 : (STAB ? PCT_STAB_WAVES : PCT_CONT_WAVES))))
 pct_continuous_kernel(ContinuousParams p, const void* __restrict__ actions,
                                                             int row_len, int n_steps,
                                                             const int32_t* __restrict__ env_ids, int n_ids) {
@@ -1267,6 +1502,13 @@ pct_continuous_kernel(ContinuousParams p, const void* __restrict__ actions,
   for (int it = 0; it < n_steps; it++) {
     int flag = 0;
     double p1 = 0, p2 = 0, bx = 0, by = 0, bz = 0;
+    bool giveup = false;
+#ifndef PCT_CONT_MT
+    if (ACT == CACT_HEUR) {
+      giveup = !cheur_choose<STAB>(p, e, l, r, lane, row_len, p1, p2, bx, by, bz);
+      if (!giveup) { r.b0 = bx; r.b1 = by; r.b2 = bz; }  // env.next_box = [x, y, z] (heuristic.py:190, 399, 552)
+    } else
+#endif
     if (ACT == CACT_ROWS) {
       const float* row = reinterpret_cast<const float*>(actions) + (size_t)e * row_len;
       float v = lane < row_len ? row[lane] : 0.f;
@@ -1314,7 +1556,7 @@ pct_continuous_kernel(ContinuousParams p, const void* __restrict__ actions,
       cdecode_leaf(r, zero_row, a0, a1, a3, a4, p1, p2, bx, by, bz);
     }
     double newbox[6] = {0, 0, 0, 0, 0, 0};
-    const int tr = ctransition<GT, STAB, MT>(p, e, l, r, lane, flag, p1, p2, bx, by, bz, tm, newbox);
+    const int tr = ctransition<GT, STAB, MT>(p, e, l, r, lane, flag, p1, p2, bx, by, bz, tm, newbox, giveup);
     if (tr == 2) { requeue = true; break; }
     const bool ended = tr != 0;
     if (can_retry && ((r.flags & ~flags_in) & PCT_FLAG_EMS_OVERFLOW)) { requeue = true; break; }
@@ -1403,6 +1645,9 @@ hipError_t PCT_CONT_LAUNCH(const ContinuousParams& p, int act, const void* actio
     case CACT_ROWS: PCT_CLAUNCH(CACT_ROWS); break;
     case CACT_INDEX: PCT_CLAUNCH(CACT_INDEX); break;
     case CACT_HASH: PCT_CLAUNCH(CACT_HASH); break;
+#ifndef PCT_CONT_MT
+    case CACT_HEUR: PCT_CLAUNCH(CACT_HEUR); break;
+#endif
     default: PCT_CLAUNCH(CACT_RESET); break;
   }
 #undef PCT_CLAUNCH

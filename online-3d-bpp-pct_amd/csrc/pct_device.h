@@ -52,6 +52,7 @@ struct DiscreteParams {
   int32_t* scalars; /* [N,PCT_SCALARS]: n_ems,n_boxes,n_leaf,item[3],t,-,cursor lo/hi,vol lo/hi */
   uint32_t* flags;  /* [N] sticky PCT_FLAG_* */
   unsigned long long* timing; /* [N,16] per-phase cycle accumulators, or null */
+  uint32_t* set_scratch;      /* [grid, 768] insertion-order lists of the candidate sets that reach the 2048-slot table */
   // stability state (settings 1/3 only): compact pooled layout, LDS-resident during a transition (csrc/pct_stab.cuh)
   StabHbm sb;
   // setting 3 density source (include/pct_env.h pct_set_density_stream / pct_set_dataset_density)

@@ -39,7 +39,7 @@
                          predicated-off work; 2 and 4 are kept for experiments) */
 #endif
 #ifndef PCT_STAB_WAVES
-#define PCT_STAB_WAVES 1 /* waves per SIMD the stability-check kernels are compiled for */
+#define PCT_STAB_WAVES 1 /* waves per SIMD the stability-check kernels are compiled for (2: 256 VGPRs, ~470 of them spilled -- slower, profiles/r03_stability_tuning.txt) */
 #endif
 #ifndef PCT_SET_RV
 #define PCT_SET_RV 1  /* old slots per lane and matching pass of a table rebuild (32-bit keys) */
@@ -638,6 +638,290 @@ __device__ inline void set_insert(SetState<K>& st, const K (&key)[V], const bool
   }
 }
 
+// rotation `rot` of the item (b0, b1, b2) (D/space.py:540-562): extents and the skip rule
+__device__ inline bool item_rot_size(int b0, int b1, int b2, int rot, int& sx, int& sy, int& sz) {
+  switch (rot) {
+    case 0: sx = b0; sy = b1; sz = b2; return false;
+    case 1: sx = b1; sy = b0; sz = b2; return sx == sy;
+    case 2: sx = b0; sy = b2; sz = b1; return sx == sy && sy == sz;
+    case 3: sx = b1; sy = b2; sz = b0; return sx == sy && sy == sz;
+    case 4: sx = b2; sy = b0; sz = b1; return sx == sy;
+    default: sx = b2; sy = b1; sz = b0; return sx == sy;
+  }
+}
+
+#ifndef PCT_SET_WHOLE
+#define PCT_SET_WHOLE 0 /* 1: the EMS candidate set is built from the whole tuple list at once (below); 0: batch by batch.
+                           Bit-exact (every discrete GPU test passes with it) but SLOWER on MI355X, measured round 3
+                           (profiles/r03_whole_set_experiment.txt): C2 74.3 vs 68.0 us per launch.  It cuts the matching
+                           calls of the EMS-richest env from 22.8 to 5.9 and its summed longest walks from 135 to 78 steps,
+                           but with several keys per lane every walk step issues that many times the instructions, and with
+                           four waves per SIMD the kernel is bound by instruction issue, not by the dependence chain. */
+#endif
+// ----------------------------------------------------------------------------------------------------------------
+// The EMS candidate set built FROM THE WHOLE TUPLE LIST AT ONCE (32-bit keys, a table region of >= 2048 words).
+//
+// Sequential set.add of the generated tuples is: drop the tuples an earlier one equals (no-ops), then insert the DISTINCT
+// ones d0, d1, ... in order, growing the table 8 -> 32 -> 128 -> 512 -> 2048 right after the 5th, 19th, 77th and 307th
+// distinct key with a re-insertion in old-slot order (Objects/setobject.c set_add_entry / set_table_resize).  The final
+// table is therefore a function of the distinct sequence alone, and it can be had stage by stage:
+//     32-table  <- the first 5 in 8-table slot order, then d5..d18               (scalar replay, as the fast start)
+//     128-table <- the first 19 in 32-table slot order, then d19..d76            ONE matching of <= 77 keys (2 per lane)
+//     512-table <- the first 77 in 128-table slot order, then d77..d306          ONE matching of <= 307 keys (5 per lane)
+//     2048-table<- the first 307 in 512-table slot order, then d307..            passes of 256 keys (4 per lane)
+// where a "matching" is the wave-parallel stable matching of pct_set.cuh with the insertion position as the priority --
+// any number of distinct keys at once.  Instead of one matching (a chain of dependent LDS round trips) per 64-tuple
+// batch -- 23 of them in the EMS-rich env that sets a launch's duration -- the env pays one per table stage, each with
+// several keys per lane in flight.  The de-duplication runs once over the whole list (bucket scatter by position with
+// a cheap multiplicative hash; the first holder of a key is the minimum position of its bucket in some round).
+// Layout inside the table region (words): [0, 512) tables up to 512 slots, [512, 1024) de-duplication buckets, later the
+// 32-table slot order, [1024, 1024 + WS_KMAX) the tuples, compacted in place to the distinct ones.  The 2048-slot table
+// takes the whole region: what it is built from waits in an HBM scratch row of the workgroup.
+// Returns false (nothing of the caller's set state touched beyond scratch) when the list does not fit: the caller then
+// inserts batch by batch.
+constexpr int WS_KMAX = 768;  // generated tuples the whole-set path takes (the 99.9th percentile at 10^3 is ~600)
+template <typename K, int BITS, typename TM>
+__device__ inline bool ems_set_whole(const DiscreteParams& p, Lds<K, BITS>& l, SetState<K>& st, int lane, TM& tm, int* mst,
+                                     int E, int orient, uint32_t rotmask, int b0, int b1, int b2) {
+  typedef Pack<K, BITS> P;
+  const K EMPTY = SlotWord<K>::EMPTY;
+  K* const tabs = st.tabs;
+  constexpr uint32_t WB = 512, WD = 1024;
+  const int NP = E * orient;
+  // 1. every tuple, in generation order: pair (EMS, rotation) by pair, four bottom corners each (D/space.py:565-568)
+  int NT = 0;
+  for (int pbase = 0; pbase < NP; pbase += 64) {
+    const int q = pbase + lane;
+    bool pv = q < NP;
+    const int ei = q / orient, rot = q - ei * orient;
+    int sx, sy, sz;
+    const bool skip = item_rot_size(b0, b1, b2, rot, sx, sy, sz) || !((rotmask >> rot) & 1u);
+    const K ek = pv ? l.ems_a[ei] : (K)0;
+    const int x0 = P::get(ek, 0), y0 = P::get(ek, 1), z0 = P::get(ek, 2), x1 = P::get(ek, 3), y1 = P::get(ek, 4);
+    pv = pv && !skip && (x1 - x0 >= sx) && (y1 - y0 >= sy) && (P::get(ek, 5) - z0 >= sz);
+    const uint64_t pm = __ballot(pv);
+    const int at = NT + 4 * rank_below(pm);
+    if (pv && at + 3 < WS_KMAX) {
+      tabs[WD + at + 0] = P::pack(x0, y0, z0, x0 + sx, y0 + sy, z0 + sz);
+      tabs[WD + at + 1] = P::pack(x1 - sx, y0, z0, x1, y0 + sy, z0 + sz);
+      tabs[WD + at + 2] = P::pack(x0, y1 - sy, z0, x0 + sx, y1, z0 + sz);
+      tabs[WD + at + 3] = P::pack(x1 - sx, y1 - sy, z0, x1, y1, z0 + sz);
+    }
+    NT += 4 * __popcll(pm);
+  }
+  if (NT > WS_KMAX) return false;
+  tm.add(ST_GENERATED, (uint64_t)NT);
+  if (NT == 0) return true;  // the empty set: the caller's fresh 8-slot table
+  const int NC = (NT + 63) >> 6;
+  // 2. exact de-duplication of the whole list, first occurrence wins
+  for (int i = lane; i < 512; i += 64) tabs[WB + i] = EMPTY;
+  uint32_t unres = 0, dupm = 0;  // per lane: bit c = tuple c * 64 + lane
+  for (int c = 0; c < NC; c++)
+    if (c * 64 + lane < NT) unres |= 1u << c;
+  __syncthreads();
+  for (int round = 0; round < 10; round++) {
+    if (!__ballot(unres != 0)) break;
+    const uint32_t mul = 0x9E3779B1u + (uint32_t)round * 0x3C6EF372u;  // (odd)
+    const uint32_t part = unres;
+    for (int c = 0; c < NC; c++)
+      if ((part >> c) & 1u) {
+        const uint32_t t = (uint32_t)(c * 64 + lane);
+        const uint32_t b = ((uint32_t)tabs[WD + t] * mul) >> 23;
+        atomicMin(reinterpret_cast<uint32_t*>(&tabs[WB + b]), t);
+      }
+    __syncthreads();
+    for (int c = 0; c < NC; c++)
+      if ((part >> c) & 1u) {
+        const uint32_t t = (uint32_t)(c * 64 + lane);
+        const K key = tabs[WD + t];
+        const uint32_t w = (uint32_t)tabs[WB + (((uint32_t)key * mul) >> 23)];
+        if (w == t) unres &= ~(1u << c);  // the minimum position of its bucket: nobody earlier holds this key
+        else if (tabs[WD + w] == key) { unres &= ~(1u << c); dupm |= 1u << c; }
+      }
+    __syncthreads();
+    for (int c = 0; c < NC; c++)
+      if ((part >> c) & 1u) tabs[WB + (((uint32_t)tabs[WD + c * 64 + lane] * mul) >> 23)] = EMPTY;
+    __syncthreads();
+  }
+  if (__ballot(unres != 0)) return false;  // (ten rounds of pure collisions between distinct keys)
+  tm.sub_tick(PH_SET_DEDUP);
+  // 3. the distinct tuples d0, d1, ... compacted to the front of the list, order kept
+  int n = 0;
+  for (int c = 0; c < NC; c++) {
+    const int t = c * 64 + lane;
+    const K key = t < NT ? tabs[WD + t] : (K)0;
+    const bool first = t < NT && !((dupm >> c) & 1u);
+    const uint64_t m = __ballot(first);
+    __syncthreads();
+    if (first) tabs[WD + n + rank_below(m)] = key;
+    n += __popcll(m);
+    __syncthreads();
+  }
+  if (n < 19) {  // up to the 32-slot table: one ordinary batch
+    const K key1[1] = {lane < n ? tabs[WD + lane] : (K)0};
+    const bool valid1[1] = {lane < n};
+    __syncthreads();
+    set_insert<K, BITS, 1>(st, key1, valid1, lane, tm, mst);
+    return true;
+  }
+  // 4a. the 8- and 32-slot tables of d0..d18, replayed on the scalar unit (as the fast start of set_insert): lane s of t32
+  // holds the position of the key in 32-table slot s
+  const K key0 = tabs[WD + lane];  // (n >= 19; positions >= n are never used)
+  const uint64_t h0 = tuplehash6<K, BITS>(key0);
+  int t8 = 0xFF, t32 = 0xFF;
+  uint32_t occ8 = 0, occ32 = 0;
+  auto lane_hash = [&](int src) -> uint64_t {
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)h0, src);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(h0 >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+  };
+  for (int o = 0; o < 5; o++) {  // mask 7: no linear probes (i + 9 > mask)
+    const uint64_t h = lane_hash(o);
+    uint32_t i = (uint32_t)h & 7u;
+    uint64_t perturb = h;
+    while ((occ8 >> i) & 1u) {
+      perturb >>= 5;
+      i = (i * 5u + 1u + (uint32_t)perturb) & 7u;
+    }
+    occ8 |= 1u << i;
+    t8 = lane == (int)i ? o : t8;
+  }
+  auto insert32 = [&](int src) {  // set_insert_clean / set_add_entry on the 32-slot table
+    const uint64_t h = lane_hash(src);
+    uint32_t i = (uint32_t)h & 31u;
+    uint64_t perturb = h;
+    while (true) {
+      const uint32_t span = (i + 9u <= 31u) ? 10u : 1u;  // slot i, plus 9 linear probes if they fit
+      const uint32_t w = (~occ32 >> i) & ((1u << span) - 1u);
+      if (w) {
+        i += (uint32_t)__ffs((int)w) - 1u;
+        break;
+      }
+      perturb >>= 5;
+      i = (i * 5u + 1u + (uint32_t)perturb) & 31u;
+    }
+    occ32 |= 1u << i;
+    t32 = lane == (int)i ? src : t32;
+  };
+  for (uint32_t m8 = occ8; m8; m8 &= m8 - 1u) insert32(__builtin_amdgcn_readlane(t8, __ffs((int)m8) - 1));
+  for (int o = 5; o < 19; o++) insert32(o);
+  {
+    const K from_slot = shfl_key<K>(key0, t32 & 63);
+    if (lane < 32 && ((occ32 >> lane) & 1u)) tabs[WB + rank_below((uint64_t)occ32)] = from_slot;  // 32-table slot order
+  }
+  tabs[lane] = EMPTY;
+  tabs[64 + lane] = EMPTY;
+  __syncthreads();
+  // 4b. the 128-slot table: those 19, then d19..d76
+  const int m1 = n < 77 ? n : 77;
+  {
+    K k2[2];
+    bool part2[2];
+    uint64_t hash2[2];
+    uint32_t slot2[2];
+#pragma unroll
+    for (int v = 0; v < 2; v++) {
+      const int pos = v * 64 + lane;
+      part2[v] = pos < m1;
+      k2[v] = pos < 19 ? tabs[WB + pos] : (part2[v] ? tabs[WD + pos] : (K)0);
+      hash2[v] = tuplehash6<K, BITS>(k2[v]);
+    }
+    pyset_match_v<2, K>(tabs, 127u, part2, hash2, lane, slot2, mst);
+#pragma unroll
+    for (int v = 0; v < 2; v++)
+      if (part2[v]) tabs[slot2[v]] = k2[v];
+    __syncthreads();
+  }
+  if (n < 77) {
+    st.toff = 0; st.size = 128; st.fill = (uint32_t)n;
+    tm.sub_tick(PH_SET_MATCH);
+    return true;
+  }
+  // 4c. the 512-slot table: the 77 in 128-table slot order, then d77..d306 -- the insertion-order list is completed in
+  // place (the 77 go in front of d77.. in the list region), then matched in passes of 192 positions (3 keys per lane)
+  {
+    int cnt = 0;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      const K k = tabs[c * 64 + lane];
+      const bool occ = k != EMPTY;
+      const uint64_t m = __ballot(occ);
+      if (occ) tabs[WD + cnt + rank_below(m)] = k;  // (d0..d76 themselves are no longer needed in generation order)
+      cnt += __popcll(m);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 8; c++) tabs[c * 64 + lane] = EMPTY;
+    __syncthreads();
+    const int m2 = n < 307 ? n : 307;
+    for (int base = 0; base < m2; base += 192) {
+      K k3[3];
+      bool part3[3];
+      uint64_t hash3[3];
+      uint32_t slot3[3];
+#pragma unroll
+      for (int v = 0; v < 3; v++) {
+        const int pos = base + v * 64 + lane;
+        part3[v] = pos < m2;
+        k3[v] = part3[v] ? tabs[WD + pos] : (K)0;
+        hash3[v] = tuplehash6<K, BITS>(k3[v]);
+      }
+      pyset_match_v<3, K>(tabs, 511u, part3, hash3, lane, slot3, mst, nullptr, nullptr, (uint32_t)base);
+#pragma unroll
+      for (int v = 0; v < 3; v++)
+        if (part3[v]) tabs[slot3[v]] = k3[v];
+      __syncthreads();
+    }
+  }
+  if (n < 307) {
+    st.toff = 0; st.size = 512; st.fill = (uint32_t)n;
+    tm.sub_tick(PH_SET_MATCH);
+    return true;
+  }
+  // 4d. the 2048-slot table takes the whole region: the insertion-order list -- the 307 in 512-table slot order, then
+  // d307.. -- waits in this env's HBM scratch row while the region is wiped (one store / load round trip, only in the
+  // 0.5 % of the steps that reach this stage); passes of 192 positions
+  {
+    uint32_t* const gs = p.set_scratch + (size_t)blockIdx.x * WS_KMAX;
+    int cnt = 0;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const K k = tabs[c * 64 + lane];
+      const bool occ = k != EMPTY;
+      const uint64_t m = __ballot(occ);
+      if (occ) __hip_atomic_store(&gs[cnt + rank_below(m)], (uint32_t)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      cnt += __popcll(m);
+    }
+    for (int pos = 307 + lane; pos < n; pos += 64)
+      __hip_atomic_store(&gs[pos], (uint32_t)tabs[WD + pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    for (int i = lane; i < 2048; i += 64) tabs[i] = EMPTY;
+    __threadfence_block();
+    __syncthreads();
+    for (int base = 0; base < n; base += 192) {
+      K k3[3];
+      bool part3[3];
+      uint64_t hash3[3];
+      uint32_t slot3[3];
+#pragma unroll
+      for (int v = 0; v < 3; v++) {
+        const int pos = base + v * 64 + lane;
+        part3[v] = pos < n;
+        k3[v] = part3[v] ? (K)__hip_atomic_load(&gs[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (K)0;  // (past the L1)
+        hash3[v] = tuplehash6<K, BITS>(k3[v]);
+      }
+      pyset_match_v<3, K>(tabs, 2047u, part3, hash3, lane, slot3, mst, nullptr, nullptr, (uint32_t)base);
+#pragma unroll
+      for (int v = 0; v < 3; v++)
+        if (part3[v]) tabs[slot3[v]] = k3[v];
+      __syncthreads();
+    }
+  }
+  st.toff = 0; st.size = 2048; st.fill = (uint32_t)n;
+  tm.sub_tick(PH_SET_MATCH);
+  return true;
+}
+
 // D/space.py:534-570 EMSPoint (CPython-set order) + D/bin3D.py:100-136
 // get_possible_position: fills l.leaf[0..n_leaf) with the first <= L feasible candidates.
 // RNG: bit 0 = the candidate list is shuffled before the first-L cut, bit 1 = strict NumPy-stream mode (the shuffle, the
@@ -1007,7 +1291,16 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
     const bool g4 = !e02 && !(g1 && e12), g5 = !e12 && !e02 && !(g4 && e01);
     const uint32_t rotmask = 1u | (g1 ? 2u : 0u) | (g2 ? 4u : 0u) | (g3 ? 8u : 0u) | (g4 ? 16u : 0u) | (g5 ? 32u : 0u);
     constexpr int V = PCT_SET_V;  // a chunk of 64 (EMS, rotation) pairs = up to 256 tuples = 4 / V batches, V tuples per lane
-    for (int pbase = 0; pbase < NP && !st.overflow; pbase += 64) {
+    bool whole = false;
+    if (PCT_SET_WHOLE && sizeof(K) == 4 && p.cand_cap >= 2048)
+      whole = ems_set_whole<K, BITS>(p, l, st, lane, tm, mst, E, orient, rotmask, b0, b1, b2);
+    if (!whole) {  // (the list did not fit the scratch, or a small table region: batch by batch)
+      if (lane < 8) tabs[st.toff + lane] = EMPTY;
+      l.dd[lane] = 0xFFFFFFFFu;
+      l.dd[64 + lane] = 0xFFFFFFFFu;
+      __syncthreads();
+    }
+    for (int pbase = 0; pbase < NP && !st.overflow && !whole; pbase += 64) {
       // which (EMS, rotation) pairs of this chunk can hold the item at all
       const uint64_t tpair = tm.now();
       int q = pbase + lane;

@@ -174,16 +174,17 @@ int launch(pct_env* h, int act, const void* actions, int row_len, int n_steps, c
   }
   return PCT_OK;
 }
-/* Stability capacities (pct_stab.cuh).  Normal pass: what the episodes of the reference's item domains need with a
- * margin (measured: at most 2.1 pool entries and 4.4 polygon vertices per placed box at 80 boxes), a hull workspace for
- * 32 two-supporter candidates per round and a queue of 160 walk tasks (half of it the reserve of the depth-first mode) -- sized so that a 10^3 / 80-box env stays below
- * 40 KiB of LDS (four resident envs per CU).  Retry pass: eight entries / sixteen vertices per box, a workspace that
- * takes a box on 120 supporters and 512 tasks. */
+/* Stability capacities (pct_stab.cuh).  Normal pass: one pool entry and two polygon vertices per internal node (measured
+ * on 10^3 bins with items 1..5, 48 envs x 600 steps: at most 36 entries and 122 vertices live at a time -- an episode ends
+ * at 30..35 boxes, far below the 80 internal nodes), a hull workspace for 16 two-supporter candidates per round and a
+ * queue of 96 walk tasks (half of it the reserve of the depth-first mode): LDS is what bounds the resident envs per CU
+ * (profiles/r03_stability_tuning.txt), and what outgrows these goes through the retry pass.  Retry pass: eight entries
+ * / sixteen vertices per node, a workspace that takes a box on 120 supporters and 512 tasks. */
 void stab_default_caps(int I, pct::StabCaps& normal, pct::StabCaps& retry) {
-  normal.SP = (5 * I) / 2 < 64 ? 64 : (5 * I) / 2;
-  normal.PP = 5 * I < 128 ? 128 : 5 * I;
-  normal.ws_bytes = 32 * pct::stab_ws_need(2);
-  normal.queue = 160;
+  normal.SP = I < 64 ? 64 : I;
+  normal.PP = 2 * I < 128 ? 128 : 2 * I;
+  normal.ws_bytes = 16 * pct::stab_ws_need(2);  /* stab_fit_wave() widens these two into the LDS the env has left */
+  normal.queue = 96;
   retry.SP = 8 * I < 4094 ? 8 * I : 4094;
   retry.PP = 16 * I < 65535 ? 16 * I : 65535;
   retry.ws_bytes = 16 * 1024;
@@ -198,6 +199,24 @@ void stab_default_caps(int I, pct::StabCaps& normal, pct::StabCaps& retry) {
   if (retry.PP < normal.PP) retry.PP = normal.PP;
   if (retry.ws_bytes < normal.ws_bytes) retry.ws_bytes = normal.ws_bytes;
   if (retry.queue < normal.queue) retry.queue = normal.queue;
+}
+/* The stability kernels run one wave per SIMD (their float64 code needs more than 256 VGPRs), i.e. four envs per CU:
+ * each may use 40 KiB of LDS for nothing.  What the env's own lists and the stability pools leave of that goes to the
+ * wave's hull workspace (as many two-supporter candidates per round as fit, up to 64) and walk queue (three tasks per
+ * lane): the rounds of a check are latency chains, so the more candidates share one the better (measured, c1: 32
+ * lanes / 112 tasks 9.2 M env-steps/s, 16 lanes / 96 tasks 7.0 M; profiles/r03_stability_tuning.txt). */
+void stab_fit_wave(size_t lds_without_wave, pct::StabCaps& caps) {
+  if (getenv("PCT_STAB_WS") || getenv("PCT_STAB_Q")) return; /* explicit (experiments / tests) */
+  const long budget = 40 * 1024 - 64 - (long)lds_without_wave;
+  const int per = pct::stab_ws_need(2);
+  for (int lanes = 64; lanes >= 16; lanes -= 8) {
+    const int q = 3 * lanes > 96 ? 3 * lanes : 96;
+    if ((long)lanes * per + (long)q * 36 + 32 <= budget) {
+      caps.ws_bytes = lanes * per;
+      caps.queue = q;
+      return;
+    }
+  }
 }
 bool is_cand_cap_ok(int c) {
   for (int s = 8; s <= (1 << 20); s <<= 2)
@@ -256,8 +275,12 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
   if (!cont && ems_cap < 64) return fail(PCT_ERR_INVALID_ARG, "ems_capacity must be >= 64");
   /* candidate table: 2048 slots (1228 distinct candidates) cover the 10^3-class bins with room to
    * spare; larger discrete bins default to 8192 (4915) */
+  /* the stability settings generate two orientations instead of six: a 512-slot table (307 candidates) covers their
+   * 10^3-class bins (at most 150 distinct candidates were seen) and frees 6 KB of LDS for the stability state */
+  const bool small_bin = (cont ? maxdim / 1000 : maxdim) <= 12;
   int cand_cap = cfg->candidate_capacity > 0 ? cfg->candidate_capacity
-                                             : (cont ? (maxdim / 1000 <= 12 ? 2048 : 32768) : (maxdim <= 12 ? 2048 : 8192));
+                                             : (small_bin ? (cfg->setting != 2 ? 512 : 2048) : (cont ? 32768 : 8192));
+  if (getenv("PCT_CAND_CAP")) cand_cap = atoi(getenv("PCT_CAND_CAP")); /* kernel experiments only */
   if (!is_cand_cap_ok(cand_cap)) return fail(PCT_ERR_INVALID_ARG, "candidate_capacity must be 8*4^k (8,32,...,2048,8192)");
 
   int ndev = 0;
@@ -311,6 +334,12 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
     pct::StabCaps retry_stab = c.sb.caps;
     if (cfg->setting != 2) {
       stab_default_caps(c.I, c.sb.caps, retry_stab);
+      {
+        pct::ContinuousParams t0 = c;
+        t0.sb.caps.ws_bytes = 0;
+        t0.sb.caps.queue = 0;
+        stab_fit_wave(pct::continuous_lds_bytes(t0), c.sb.caps);
+      }
       c.sb.sp_stride = retry_stab.SP;
       c.sb.pp_stride = retry_stab.PP;
     }
@@ -442,6 +471,12 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
   h->d_retry_stab = p.sb.caps;
   if (cfg->setting != 2) {
     stab_default_caps(p.I, p.sb.caps, h->d_retry_stab);
+    {
+      pct::DiscreteParams t0 = p;
+      t0.sb.caps.ws_bytes = 0;
+      t0.sb.caps.queue = 0;
+      stab_fit_wave(pct::discrete_lds_bytes(t0), p.sb.caps);
+    }
     pct::DiscreteParams t = p;
     t.ems_cap = h->d_retry_ems;
     t.cand_cap = h->d_retry_cand;
@@ -477,6 +512,7 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
   ALLOC(p.boxes, N * p.I * p.key_bytes);
   ALLOC(p.leaves, N * p.L * p.key_bytes);
   ALLOC(p.scalars, N * PCT_SCALARS * sizeof(int32_t));
+  ALLOC(p.set_scratch, N * 768 * sizeof(uint32_t)); /* pct_discrete_impl.cuh WS_KMAX: one row per workgroup of any pass */
   if (cfg->setting != 2) {
     ALLOC(p.sb.stk, N * p.I * 4 * sizeof(double));
     ALLOC(p.sb.den, N * p.I * sizeof(double));
@@ -806,14 +842,24 @@ int pct_step_heuristic(pct_env* h, int32_t kind, int32_t n_steps, void* stream) 
   if (rc) return rc;
   if (n_steps < 1) return fail(PCT_ERR_INVALID_ARG, "n_steps must be >= 1");
   if (kind < PCT_HEUR_LSAH || kind > PCT_HEUR_RANDOM) return fail(PCT_ERR_INVALID_ARG, "unknown heuristic");
-  if (kind == PCT_HEUR_MACS && (h->cfg.container[1] > 32 ||
+  if (!h->continuous && kind == PCT_HEUR_MACS && (h->cfg.container[1] > 32 ||
                                 (size_t)h->cfg.container[0] * h->cfg.container[2] > (size_t)h->dp.cand_cap * (h->dp.key_bytes / 4)))
     return fail(PCT_ERR_UNSUPPORTED, "MACS: the level masks need Ly <= 32 and W*H words of table scratch");
-  if (kind == PCT_HEUR_RANDOM && ((size_t)h->cfg.container[0] * h->cfg.container[1] * 6 / 64 + 1) * 2 >
+  if (!h->continuous && kind == PCT_HEUR_RANDOM && ((size_t)h->cfg.container[0] * h->cfg.container[1] * 6 / 64 + 1) * 2 >
                                      (size_t)h->dp.cand_cap * (h->dp.key_bytes / 4))
     return fail(PCT_ERR_UNSUPPORTED, "RANDOM: the feasibility masks do not fit the table scratch (raise candidate_capacity)");
-  if (h->continuous || h->cfg.lnes != PCT_LNES_EMS)
-    return fail(PCT_ERR_UNSUPPORTED, "the heuristics read the discrete env's heightmap and EMS list (LNES = EMS)");
+  if (h->cfg.lnes != PCT_LNES_EMS) return fail(PCT_ERR_UNSUPPORTED, "the heuristics read the EMS list (LNES = EMS)");
+  if (h->continuous) {
+    /* tools.py:217-218: only LSAH, OnlineBPH and BR run on PackingContinuous */
+    if (kind != PCT_HEUR_LSAH && kind != PCT_HEUR_OBPH && kind != PCT_HEUR_BR)
+      return fail(PCT_ERR_UNSUPPORTED, "only LSAH, OnlineBPH and BR are allowed for the continuous environment (tools.py:217-218)");
+    if (h->cp.rng_numpy)
+      return fail(PCT_ERR_UNSUPPORTED, "the heuristic policies are not available in strict NumPy-stream mode (pct_set_numpy_rng)");
+    /* per-pair scores (LSAH: one double per (EMS, rotation)) live in the idle table region */
+    if ((size_t)h->cp.ems_cap * (h->cfg.setting == 2 ? 6 : 2) * 2 + 64 > (size_t)h->cp.union_words)
+      return fail(PCT_ERR_UNSUPPORTED, "the heuristic scores do not fit the table scratch (lower ems_capacity)");
+    return launch(h, ACT_HEUR, nullptr, kind, n_steps, nullptr, 0, stream);
+  }
   /* strict NumPy-stream mode has no heuristic kernels: the ACT_HEUR templates draw from the counter-keyed sources and
    * the LDS layout of that mode carries the MT19937 state where their shuffle arrays would lie (include/pct_env.h) */
   if (h->dp.rng_numpy)

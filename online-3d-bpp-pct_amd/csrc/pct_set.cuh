@@ -441,16 +441,18 @@ __device__ inline void pyset_contains_v(const K* tab, uint32_t mask, const uint6
 // with the keys.  All 64 lanes must call.
 // With `key` (CHECK): a participating key may already be a member of the table -- its walk then ends at its own
 // entry and it is not placed (set.add of a member is a no-op); placed[v] tells the two outcomes apart.
+// `base`: batch position of (0, lane 0) -- the priority of (v, lane) is base + v * 64 + lane (a whole-set matching of more
+// than V * 64 keys runs in passes over one table).
 template <int V, typename K, bool CHECK = false>
 __device__ inline void pyset_match_v(K* tab, uint32_t mask, const bool (&part)[V], const uint64_t (&hash)[V], int lane,
                                      uint32_t (&slot)[V], int* stats = nullptr, const K* key = nullptr,
-                                     bool* placed_out = nullptr) {
+                                     bool* placed_out = nullptr, uint32_t base = 0) {
   const K TAG = SlotWord<K>::TAG;
   uint32_t i[V];
   int j[V];
   uint64_t perturb[V];
   bool walking[V], placed[V];
-#define PCT_MYTAG(v) (TAG | (K)((v) * 64 + lane))
+#define PCT_MYTAG(v) (TAG | (K)(base + (uint32_t)((v) * 64 + lane)))
 #pragma unroll
   for (int v = 0; v < V; v++) {
     i[v] = (uint32_t)hash[v] & mask;

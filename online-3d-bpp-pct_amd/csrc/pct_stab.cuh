@@ -452,7 +452,11 @@ PCT_SD bool stab_split(const Geo& geo, const double bg[9], int k, const Sup& sup
   if (sp.direct >= 0) { sp.mode = 1; return true; }
   if (k > STAB_LSQ) return false;
   if (k <= 5) {
-    // contact centres with static indices (registers)
+    // contact centres with static indices (registers).  Two to five supporters are 99.99 % of the splits (of the
+    // least-squares ones k = 3: 94 %, 4: 6 %, 5: 0.1 %).  The register-resident solve for five costs 160 VGPRs -- and the
+    // generic one, on private arrays in scratch memory, costs the WAVE that holds such a lane hundreds of thousands of
+    // cycles: with 4096 envs per launch there is one in every other launch, and a launch lasts as long as its slowest
+    // env (measured, c1: 9.2 M env-steps/s with it, 7.8 M without; profiles/r03_stability_tuning.txt)
     double c2[5][2];
 #pragma unroll
     for (int i = 0; i < 5; i++) {

@@ -1327,9 +1327,24 @@ static int heur_choose(const pcto_env* h, int e, const oenv* s, int kind, int* o
 int pcto_step_heuristic(pcto_env* h, int32_t kind, int32_t n_steps) {
   int rc = ready(h);
   if (rc) return rc;
-  if (h->cfg.env_kind != PCT_ENV_DISCRETE || h->cfg.lnes != PCT_LNES_EMS)
-    return fail(PCT_ERR_UNSUPPORTED, "the heuristics read the discrete env's heightmap and EMS list");
+  if (h->cfg.lnes != PCT_LNES_EMS) return fail(PCT_ERR_UNSUPPORTED, "the heuristics read the EMS list (LNES = EMS)");
   if (kind < PCT_HEUR_LSAH || kind > PCT_HEUR_RANDOM) return fail(PCT_ERR_INVALID_ARG, "unknown heuristic");
+  if (h->cfg.env_kind == PCT_ENV_CONTINUOUS) {
+    /* tools.py:217-218: only LSAH, OnlineBPH and BR run on PackingContinuous */
+    if (kind != PCT_HEUR_LSAH && kind != PCT_HEUR_OBPH && kind != PCT_HEUR_BR)
+      return fail(PCT_ERR_UNSUPPORTED, "only LSAH, OnlineBPH and BR are allowed for the continuous environment (tools.py:217-218)");
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 8)
+    for (int e = 0; e < h->N; e++) {
+      double* obs = h->obs + (size_t)e * h->row_len;
+      for (int it = 0; it < n_steps; it++) {
+        double lx = 0, ly = 0, x = 0, y = 0, z = 0;
+        if (pctc_heur_choose(h, e, kind, &lx, &ly, &x, &y, &z)) pctc_step_place(h, e, lx, ly, x, y, z, obs);
+        else pctc_giveup(h, e);
+        if (h->done[e]) any_reset(h, e, obs);
+      }
+    }
+    return PCT_OK;
+  }
 #pragma omp parallel for num_threads(g_threads) schedule(dynamic, 8)
   for (int e = 0; e < h->N; e++) {
     oenv* s = &h->envs[e];

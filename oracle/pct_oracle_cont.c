@@ -533,6 +533,160 @@ void pctc_step(struct pcto_env* h, int e, const double* act, int len, double* ob
   cur_observation(h, e, s, obs);
 }
 
+/* ---- heuristic.py on PackingContinuous (tools.py:217-218: only LSAH, OnlineBPH and BR are allowed there) -------------
+ * The baselines as in-env policies, like pct_oracle.c heur_choose for the discrete env.  Everything is float64 in the
+ * reference's own operation order; env.space.EMS is the whole 1000-row array there, of which only the live rows can
+ * pass the tests (an all-zero row is skipped by LASH / OnlineBPH and fits no item in BR). */
+static void cheur_rot(const double nb[3], int rot, double* x, double* y, double* z) { /* heuristic.py:171-182 */
+  switch (rot) {
+    case 0: *x = nb[0]; *y = nb[1]; *z = nb[2]; break;
+    case 1: *y = nb[0]; *x = nb[1]; *z = nb[2]; break;
+    case 2: *z = nb[0]; *x = nb[1]; *y = nb[2]; break;
+    case 3: *z = nb[0]; *y = nb[1]; *x = nb[2]; break;
+    case 4: *x = nb[0]; *z = nb[1]; *y = nb[2]; break;
+    default: *y = nb[0]; *z = nb[1]; *x = nb[2]; break;
+  }
+}
+/* drop_box_virtual(..., returnH=True) (C/space.py:380-425): feasibility and the height the box would rest at */
+static int drop_box_virtual_h(const struct pcto_env* h, const struct cenv* s, double x, double y, double z, double lx,
+                              double ly, double* height) {
+  double W = h->cfg.container[0] / 1000, L = h->cfg.container[1] / 1000, H = h->cfg.container[2] / 1000;
+  int ok = 1;
+  if (lx + x - 1e-6 > W || ly + y - 1e-6 > L) ok = 0;
+  if (lx + 1e-6 < 0 || ly + 1e-6 < 0) ok = 0;
+  double box[5] = {-lx, -ly, lx + x, ly + y, 0};
+  double max_h = intersect2d(h, s, box);
+  if (max_h + z - 1e-6 > H) ok = 0;
+  if (ok && h->cfg.setting != 2) ok = stab_check(s->stab, x, y, z, lx, ly, max_h, s->next_den, 1);
+  *height = max_h;
+  return ok;
+}
+int pctc_heur_choose(const struct pcto_env* h, int e, int kind, double* olx, double* oly, double* ox, double* oy, double* oz) {
+  const struct cenv* s = &h->cenvs[e];
+  const int orientation = h->cfg.setting == 2 ? 6 : 2;
+  const double* nb = s->next_box;
+  int found = 0;
+  if (kind == PCT_HEUR_OBPH) {
+    /* heuristic.py:364-425: EMS sorted by (z, y, x), stable; the first feasible (EMS, rotation) -- no fit-in-EMS test */
+    int n = s->noems;
+    int* idx = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < n; i++) {
+      int j = i;
+      const double* ei = s->ems + 6 * i;
+      while (j > 0) {
+        const double* ep = s->ems + 6 * idx[j - 1];
+        int greater = ep[2] > ei[2] || (ep[2] == ei[2] && (ep[1] > ei[1] || (ep[1] == ei[1] && ep[0] > ei[0])));
+        if (!greater) break;
+        idx[j] = idx[j - 1];
+        j--;
+      }
+      idx[j] = i;
+    }
+    for (int q = 0; q < n && !found; q++) {
+      const double* em = s->ems + 6 * idx[q];
+      if (fabs(em[0]) + fabs(em[1]) + fabs(em[2]) + fabs(em[3]) + fabs(em[4]) + fabs(em[5]) == 0) continue;
+      for (int rot = 0; rot < orientation; rot++) {
+        double x, y, z, hh;
+        cheur_rot(nb, rot, &x, &y, &z);
+        if (drop_box_virtual_h(h, s, x, y, z, em[0], em[1], &hh)) {
+          found = 1; *olx = em[0]; *oly = em[1]; *ox = x; *oy = y; *oz = z;
+          break;
+        }
+      }
+    }
+    free(idx);
+    return found;
+  }
+  if (kind == PCT_HEUR_LSAH) {
+    /* :138-226 LASH: least surface area of the bounding box of everything packed; maxXY / minXY are the running extents
+     * of this episode's placements (:204-207): lx + x and lx of every placed box, as the reference accumulates them */
+    const double W = h->cfg.container[0] / 1000, L = h->cfg.container[1] / 1000, H = h->cfg.container[2] / 1000;
+    double maxX = 0, maxY = 0, minX = W, minY = L;
+    for (int i = 0; i < s->box_idx; i++) {
+      const double* r = s->box_vec + 9 * i;
+      if (r[3] > maxX) maxX = r[3];
+      if (r[4] > maxY) maxY = r[4];
+      if (r[0] < minX) minX = r[0];
+      if (r[1] < minY) minY = r[1];
+    }
+    double best = W * L + L * H + H * W; /* ints in the reference: exact */
+    double bd[3] = {0, 0, 0};
+    for (int q = 0; q < s->noems; q++) {
+      const double* em = s->ems + 6 * q;
+      if (fabs(em[0]) + fabs(em[1]) + fabs(em[2]) + fabs(em[3]) + fabs(em[4]) + fabs(em[5]) == 0) continue;
+      double dx = em[3] - em[0], dy = em[4] - em[1], dz = em[5] - em[2];
+      for (int rot = 0; rot < orientation; rot++) {
+        double x, y, z, height;
+        cheur_rot(nb, rot, &x, &y, &z);
+        if (!(dx >= x && dy >= y && dz >= z)) continue;
+        double lx = em[0], ly = em[1];
+        if (!drop_box_virtual_h(h, s, x, y, z, lx, ly, &height)) continue;
+        double ex = fmax(lx + x, maxX) - fmin(lx, minX), ey = fmax(ly + y, maxY) - fmin(ly, minY);
+        double score = ex * ey + (height + z) * ey + (height + z) * ex;
+        int take = 0;
+        if (score < best) take = 1;
+        else if (score == best && found) {
+          double m1 = fmin(fmin(dx - x, dy - y), dz - z), m2 = fmin(fmin(bd[0] - x, bd[1] - y), bd[2] - z);
+          if (m1 < m2) take = 1;
+        }
+        if (take) {
+          best = score; found = 1; *olx = lx; *oly = ly; *ox = x; *oy = y; *oz = z;
+          bd[0] = dx; bd[1] = dy; bd[2] = dz;
+        }
+      }
+    }
+    return found;
+  }
+  if (kind == PCT_HEUR_BR) {
+    /* :500-569 BR: the EMS with the best eval_ems (volume + number of item types that fit unrotated, + 10 if all do);
+     * first best in (EMS, rotation) order.  env.item_set: the item set the env was handed (integers) */
+    double best = -1e10;
+    for (int q = 0; q < s->noems; q++) {
+      const double* em = s->ems + 6 * q;
+      double dx = em[3] - em[0], dy = em[4] - em[1], dz = em[5] - em[2];
+      double sc = 0;
+      int have = 0;
+      for (int rot = 0; rot < orientation; rot++) {
+        double x, y, z, height;
+        cheur_rot(nb, rot, &x, &y, &z);
+        if (!(dx >= x && dy >= y && dz >= z)) continue;
+        if (!drop_box_virtual_h(h, s, x, y, z, em[0], em[1], &height)) continue;
+        if (!have) {
+          int valid = 0;
+          for (int i = 0; i < h->n_items; i++)
+            if (dx >= h->item_set[3 * i] / 1000.0 && dy >= h->item_set[3 * i + 1] / 1000.0 && dz >= h->item_set[3 * i + 2] / 1000.0) valid++;
+          sc = 0;
+          sc += dx * dy * dz;
+          sc += valid;
+          if (valid == h->n_items) sc += 10;
+          have = 1;
+        }
+        if (sc > best) {
+          best = sc; found = 1; *olx = em[0]; *oly = em[1]; *ox = x; *oy = y; *oz = z;
+        }
+      }
+    }
+    return found;
+  }
+  return 0;
+}
+/* env.next_box = [x, y, z]; env.step([0, lx, ly]) (heuristic.py:215, 416, 560) */
+void pctc_step_place(struct pcto_env* h, int e, double lx, double ly, double x, double y, double z, double* obs) {
+  struct cenv* s = &h->cenvs[e];
+  s->next_box[0] = x; s->next_box[1] = y; s->next_box[2] = z;
+  const double act[3] = {0, lx, ly};
+  pctc_step(h, e, act, 3, obs, &h->reward[e], &h->done[e], &h->counter[e], &h->ratio[e], &h->flags[e]);
+}
+/* a heuristic found no placement: the episode is recorded and the env reset, no step() */
+void pctc_giveup(struct pcto_env* h, int e) {
+  struct cenv* s = &h->cenvs[e];
+  s->t++;
+  h->reward[e] = 0.0;
+  h->done[e] = 1;
+  h->counter[e] = s->n_boxes;
+  h->ratio[e] = get_ratio(h, s);
+}
+
 uint32_t pctc_t(const struct pcto_env* h, int e) { return h->cenvs[e].t; }
 
 int pctc_alloc(struct pcto_env* h) {

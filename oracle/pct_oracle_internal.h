@@ -139,6 +139,9 @@ void pctc_reset(struct pcto_env* h, int e, double* obs);
 void pctc_step(struct pcto_env* h, int e, const double* act, int len, double* obs, double* reward, uint8_t* done,
                int32_t* counter, double* ratio, uint32_t* flags);
 uint32_t pctc_t(const struct pcto_env* h, int e);
+int pctc_heur_choose(const struct pcto_env* h, int e, int kind, double* olx, double* oly, double* ox, double* oy, double* oz);
+void pctc_step_place(struct pcto_env* h, int e, double lx, double ly, double x, double y, double z, double* obs);
+void pctc_giveup(struct pcto_env* h, int e);
 int pctc_debug_state(struct pcto_env* h, int e, double* ems, int cap_ems, int* n_ems, int* n_boxes, double* next_item,
                      int64_t* cursor);
 #endif

@@ -99,5 +99,6 @@ def dataset_trajectories(z):
 
 
 HEURISTIC_CASES = ["heur_s2_10", "heur_s1_10", "heur_s2_rect"]
+HEURISTIC_CONT_CASES = ["heur_cont_s2_10", "heur_cont_s1_unit"]  # heuristic.py on PackingContinuous: LSAH, OnlineBPH, BR
 MACS_CASES = ["heur_macs_s2_10", "heur_macs_s1_rect"]
 HEUR_CODE = {"LSAH": 0, "HM": 1, "OnlineBPH": 2, "DBL": 3, "BR": 4, "MACS": 5, "RANDOM": 6}

@@ -680,11 +680,54 @@ def run_reference_heuristic(case, name):
     return stream, np.array([r[0] for r in rec], np.float64), np.array([r[1] for r in rec], np.int32)
 
 
+# heuristic.py on PackingContinuous (tools.py:217-218: LSAH, OnlineBPH, BR only)
+HEURISTIC_CONT_CASES = {
+    "heur_cont_s2_10": dict(kind=1, setting=2, container=(10, 10, 10), lo=1.0, hi=5.0, I=80, L=50, episodes=10, stream_T=4096,
+                            seed=66, heuristics=["LSAH", "OnlineBPH", "BR"]),
+    "heur_cont_s1_unit": dict(kind=1, setting=1, container=(1, 1, 1), lo=0.1, hi=0.5, z_choice=True, I=80, L=50, episodes=8,
+                              stream_T=4096, seed=67, heuristics=["LSAH", "OnlineBPH", "BR"]),
+}
+
+
+def run_reference_heuristic_cont(case, name):
+    """The reference's own loop (heuristic.py) on a scripted PackingContinuous; its per-episode print is captured."""
+    import builtins
+    ref_shim.install()
+    import heuristic as H
+    PD, PC, _ = ref_shim.load_reference_envs()
+    c = case
+    stream = make_cont_stream(c["seed"], 1, c["stream_T"], c["lo"], c["hi"], c.get("z_choice", False))
+    # as run_reference_cont: sample_from_distribution=False + an item set whose minimum is lo reproduces size_minimum = lo
+    # while the items come from the scripted creator; env.item_set (what BR's eval_ems counts) is that one-item set
+    env = PC(setting=c["setting"], container_size=list(c["container"]), item_set=[(c["lo"], c["lo"], c["lo"])],
+             internal_node_holder=c["I"], leaf_node_holder=c["L"], shuffle=False, sample_from_distribution=False)
+    env.box_creator = scripted_cont_creator(stream[0])
+    fn = {"LSAH": H.LASH, "OnlineBPH": H.OnlineBPH, "BR": H.BR}[name]
+    rec = []
+    saved = builtins.print
+
+    def capture(*a, **k):
+        if a and isinstance(a[0], str) and a[0].startswith("Result of episode"):
+            parts = a[0].replace(",", "").split()
+            rec.append((float(parts[5]), int(parts[7])))
+
+    builtins.print = capture
+    try:
+        fn(env, c["episodes"])
+    finally:
+        builtins.print = saved
+    return stream, np.array([r[0] for r in rec], np.float64), np.array([r[1] for r in rec], np.int32)
+
+
 def run_oracle_heuristic(case, name, stream):
     from oracle.oracle_lib import OracleVecEnv
     c = case
-    env = OracleVecEnv(1, setting=c["setting"], container_size=c["container"], item_set=item_set_range(c["lo"], c["hi"]),
-                       internal_node_holder=c["I"], leaf_node_holder=c["L"])
+    if c.get("kind", 0) == 1:
+        env = OracleVecEnv(1, setting=c["setting"], container_size=c["container"], env_kind=1,
+                           item_set=[(c["lo"], c["lo"], c["lo"])], internal_node_holder=c["I"], leaf_node_holder=c["L"])
+    else:
+        env = OracleVecEnv(1, setting=c["setting"], container_size=c["container"], item_set=item_set_range(c["lo"], c["hi"]),
+                           internal_node_holder=c["I"], leaf_node_holder=c["L"])
     env.set_item_stream(stream)
     env.reset()
     util, length = [], []
@@ -699,12 +742,12 @@ def run_oracle_heuristic(case, name, stream):
 
 
 def heuristic_cases(want=lambda name: True):
-    for cname, case in HEURISTIC_CASES.items():
+    for cname, case in list(HEURISTIC_CASES.items()) + list(HEURISTIC_CONT_CASES.items()):
         if not want(cname):
             continue
         out = {}
         for name in case.get("heuristics", FAST_HEURISTICS):
-            stream, util, length = run_reference_heuristic(case, name)
+            stream, util, length = (run_reference_heuristic_cont if case.get("kind", 0) == 1 else run_reference_heuristic)(case, name)
             o_util, o_len = run_oracle_heuristic(case, name, stream)
             if not (np.array_equal(util, o_util) and np.array_equal(length, o_len)):
                 raise SystemExit("MISMATCH %s/%s\n ref %s %s\n ora %s %s" % (cname, name, util, length, o_util, o_len))

@@ -46,3 +46,18 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.lower().replace("no cpu oracle", ""), (f, "mentions the oracle")
+
+
+def test_no_kernel_contains_a_real_call():
+    """profiles/r03_fault_root_cause.txt: this hipcc mis-places AGPR split copies around a call under a narrowed exec
+    mask; the library is built with every device function inlined and the built code objects are checked."""
+    import importlib
+    import os
+    chk = importlib.import_module("scripts.check_no_calls")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "online-3d-bpp-pct_amd", "libpct_hip.so")
+    if not os.path.exists(os.path.join(chk.LLVM, "llvm-objdump")):
+        import pytest
+        pytest.skip("no ROCm LLVM tools here")
+    calls, kernels = chk.count_calls(lib)
+    assert kernels >= 100 and not calls, sorted(calls)[:4]

@@ -224,3 +224,59 @@ def test_stability_overflow_is_rerun_with_larger_pools(name, monkeypatch):
         assert np.array_equal(done.astype(np.uint8), z["done"][t]), (name, t)
     assert not env.error_flags.any(), [hex(int(x)) for x in np.unique(env.error_flags)]
     env.close()
+
+
+# ---- VERDICT r2 item 8 / What's weak 3: the observation compared at EVERY step at BASELINE scale (short runs), C5 at its
+# 2048-env per-GPU slice, and the soak as a driver-runnable test at HEAD ------------------------------------------------
+def _make_pair(kind, N):
+    from oracle.oracle_lib import OracleVecEnv
+    items = item_set_range(1, 5)
+    if kind == "c2":
+        kw = dict(setting=2, container_size=(10, 10, 10))
+        return (_pkg().PctVecEnv(N, item_set=items, seed=4, device="cuda:0", **kw),
+                OracleVecEnv(N, item_set=items, threads=_threads(), **kw))
+    if kind == "c1":
+        kw = dict(setting=1, container_size=(10, 10, 10))
+        return (_pkg().PctVecEnv(N, item_set=items, seed=4, device="cuda:0", **kw),
+                OracleVecEnv(N, item_set=items, threads=_threads(), **kw))
+    if kind == "c3":
+        kw = dict(setting=2, container_size=(10, 10, 10))
+        return (_pkg().PctVecEnv(N, continuous=True, sample_left_bound=1.0, sample_right_bound=5.0, seed=4, device="cuda:0", **kw),
+                OracleVecEnv(N, env_kind=1, sample_bounds=(1.0, 5.0), threads=_threads(), **kw))
+    if kind == "c3s1":
+        kw = dict(setting=1, container_size=(1, 1, 1))
+        return (_pkg().PctVecEnv(N, continuous=True, sample_left_bound=0.1, sample_right_bound=0.5, seed=4, device="cuda:0", **kw),
+                OracleVecEnv(N, env_kind=1, sample_bounds=(0.1, 0.5), threads=_threads(), **kw))
+    kw = dict(setting=2, container_size=(100, 100, 100), internal_node_holder=200, leaf_node_holder=200)
+    return (_pkg().PctVecEnv(N, continuous=True, sample_left_bound=5.0, sample_right_bound=25.0, seed=4, device="cuda:0", **kw),
+            OracleVecEnv(N, env_kind=1, sample_bounds=(5.0, 25.0), threads=_threads(), **kw))
+
+
+@pytest.mark.parametrize("kind,N,steps", [("c2", 4096, 60), ("c3", 4096, 40), ("c1", 4096, 40), ("c3s1", 4096, 30)])
+def test_full_size_observation_every_step(kind, N, steps):
+    """BASELINE.json's env counts with the handle's defaults; observation, reward, done and counter compared with the
+    oracle after EVERY step (the longer runs above sample the observation every 10-15 steps)."""
+    env, ora = _make_pair(kind, N)
+    ora.set_sampler(4)
+    _run(env, ora, steps, 1)
+    env.close()
+
+
+def test_c5_per_gpu_slice_vs_oracle():
+    """configs[4]'s per-GPU slice: 2048 envs of the 100^3 / 200 / 200 continuous env on default capacities (short: the
+    oracle needs ~1 s per step at this size), observation every 4th step."""
+    env, ora = _make_pair("c5", 2048)
+    ora.set_sampler(4)
+    _run(env, ora, 24, 4)
+    env.close()
+
+
+@pytest.mark.parametrize("kind", ["c2", "c1", "c3", "c3s1"])
+def test_soak_vs_oracle(kind):
+    """The soak of scripts/soak_parity.py as a test the driver runs at HEAD: 2048 envs x 300 steps per mode (0.6 M
+    env-steps each, thousands of episodes and resets), reward / done / counter every step, the observation every 5th
+    and at the end, no flag."""
+    env, ora = _make_pair(kind, 2048)
+    ora.set_sampler(4)
+    assert _run(env, ora, 300, 5) > 1000
+    env.close()

@@ -109,3 +109,27 @@ def test_two_hip_ranks_on_one_gpu_equal_one_batch(tmp_path, variant):
     assert np.array_equal(np.load(tmp_path / "obs.npy"), obs.cpu().numpy())
     assert np.array_equal(np.load(tmp_path / "rew.npy"), reward[:, 0].numpy())
     env.close()
+
+
+def test_bench_two_rank_code_path_on_one_gpu(tmp_path):
+    """the N > 1 line of bench.py -- torch.distributed.run launch, barrier, MAX-reduce of the elapsed
+    time over ranks, per-rank kernel-time gather, ONE JSON line from rank 0 -- executed end to end with two ranks that
+    share cuda:0 over gloo (an 8-GPU node is not available to the builder; RCCL itself is covered at world size 1
+    above).  Not a measurement: only the contract of the line is checked."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "10",
+           "--envs-per-gpu", "512", "--dist-backend", "gloo", "--share-gpu", "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 30 and d["warmup"] == 10 and d["scaling"] == "weak"
+    assert d["config"]["global_envs"] == 1024 and d["config"]["envs_per_gpu"] == 512
+    assert len(d["roofline"]["kernel_avg_us_per_rank"]) == 2 and all(x > 0 for x in d["roofline"]["kernel_avg_us_per_rank"])
+    assert abs(d["value"] - 1024 * 30 / (d["ms_per_step"] * 30 / 1e3)) < 1e-6 * d["value"]

@@ -584,3 +584,55 @@ def test_heuristics_refused_in_numpy_stream_mode():
     env.step_wait()
     assert not env.error_flags.any()
     env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["heur_cont_s2_10", "heur_cont_s1_unit"])
+@pytest.mark.parametrize("heur", ["LSAH", "OnlineBPH", "BR"])
+def test_hip_continuous_heuristics_match_reference_loops(name, heur):
+    """SURVEY.md 8(f) rank 4, the continuous half: pct_step_heuristic on the continuous env against the
+    per-episode results of the reference's own loops run on PackingContinuous (heuristic.py:138-226, 364-425, 500-569;
+    tools.py:217-218 allows exactly these three there)."""
+    c, z = load_case(name)
+    env = _pkg().PctVecEnv(1, continuous=True, setting=c["setting"], container_size=c["container"],
+                           item_set=[(c["lo"], c["lo"], c["lo"])], internal_node_holder=c["I"], leaf_node_holder=c["L"],
+                           item_stream=z["stream"], device="cuda:0")
+    env.reset()
+    util, length = [], []
+    while len(util) < c["episodes"]:
+        env.step_heuristic(heur, 1)
+        _, _, done, infos = env.step_wait()
+        if done[0]:
+            util.append(infos[0]["ratio"])
+            length.append(infos[0]["counter"])
+    assert np.array_equal(np.array(util), z["util_" + heur]), (util, z["util_" + heur])
+    assert np.array_equal(np.array(length, np.int32), z["len_" + heur])
+    assert not env.error_flags.any()
+    env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("setting", [2, 1])
+@pytest.mark.parametrize("heur", ["LSAH", "OnlineBPH", "BR"])
+def test_hip_continuous_heuristics_match_oracle_batched(heur, setting):
+    """many envs, on-device sampler: the kernel's choice against the oracle's, step by step"""
+    from oracle.oracle_lib import OracleVecEnv
+    from tests.common import HEUR_CODE
+    N = 192
+    cs = (10, 10, 10) if setting == 2 else (1, 1, 1)
+    lo, hi = (1.0, 5.0) if setting == 2 else (0.1, 0.5)
+    env = _pkg().PctVecEnv(N, continuous=True, setting=setting, container_size=cs, sample_left_bound=lo, sample_right_bound=hi,
+                           seed=9, device="cuda:0")
+    ora = OracleVecEnv(N, setting=setting, container_size=cs, env_kind=1, sample_bounds=(lo, hi), threads=8)
+    ora.set_sampler(9)
+    obs = env.reset()
+    ora.reset()
+    for t in range(60):
+        assert np.array_equal(obs.cpu().numpy(), ora.obs.astype(np.float32)), (heur, setting, t)
+        env.step_heuristic(heur, 1)
+        ora.step_heuristic(HEUR_CODE[heur], 1)
+        obs, reward, done, infos = env.step_wait()
+        assert np.array_equal(done.astype(np.uint8), ora.done), t
+        assert np.array_equal(env._h_counter.numpy(), ora.counter), t
+    assert not env.error_flags.any()
+    env.close()

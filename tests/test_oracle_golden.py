@@ -251,3 +251,26 @@ def test_oracle_heuristics_match_reference_loops(name, heur):
     assert np.array_equal(np.array(util), z["util_" + heur])
     assert np.array_equal(np.array(length, np.int32), z["len_" + heur])
     assert not env.flags.any()
+
+
+@pytest.mark.parametrize("name", ["heur_cont_s2_10", "heur_cont_s1_unit"])
+@pytest.mark.parametrize("heur", ["LSAH", "OnlineBPH", "BR"])
+def test_oracle_continuous_heuristics_match_reference_loops(name, heur):
+    """heuristic.py's LASH / OnlineBPH / BR run on the unmodified PackingContinuous (the three tools.py:217-218 allows
+    there): per-episode utilisation and number of packed items of the same item stream."""
+    from tests.common import HEUR_CODE
+    c, z = load_case(name)
+    env = OracleVecEnv(1, setting=c["setting"], container_size=c["container"], env_kind=1, item_set=[(c["lo"], c["lo"], c["lo"])],
+                       internal_node_holder=c["I"], leaf_node_holder=c["L"])
+    env.set_item_stream(z["stream"])
+    env.reset()
+    util, length = [], []
+    while len(util) < c["episodes"]:
+        env.step_heuristic(HEUR_CODE[heur], 1)
+        if env.done[0]:
+            util.append(float(env.ratio[0]))
+            length.append(int(env.counter[0]))
+    assert np.array_equal(np.array(util), z["util_" + heur])
+    assert np.array_equal(np.array(length, np.int32), z["len_" + heur])
+    assert not env.flags.any()
+    env.close()
