@@ -29,17 +29,17 @@
 
 namespace pct {
 
-__device__ inline double around6(double x) { return rint(x * 1e6) / 1e6; }  // np.around(x, 6)
-__device__ inline int klat(double x) { return (int)rint(x * 1e6); }
+__device__ __forceinline__ double around6(double x) { return rint(x * 1e6) / 1e6; }  // np.around(x, 6)
+__device__ __forceinline__ int klat(double x) { return (int)rint(x * 1e6); }
 // An EMS coordinate is always the result of np.around(., 6) (or a bin size, or 0): the double nearest to k / 1e6
 // for an integer k.  The lists hold k (int32: half the LDS and HBM of the double); lat2d gives the double back
 // EXACTLY -- one Newton step on k * RN(1e-6) with fused residuals equals the correctly rounded quotient for
 // every |k| <= 2e8 (checked exhaustively on the host), at three instructions instead of a float64 division.
-__device__ inline double lat2d(int k) {
+__device__ __forceinline__ double lat2d(int k) {
   const double a = (double)k, q1 = a * 1e-6;
   return fma(fma(-1e6, q1, a), 1e-6, q1);
 }
-__device__ inline double wave_max_f64(double v) {
+__device__ __forceinline__ double wave_max_f64(double v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
     double o = __shfl_xor(v, off, 64);
@@ -50,7 +50,7 @@ __device__ inline double wave_max_f64(double v) {
 
 // Python/pyhash.c _Py_HashDouble for finite v: (M * 2^k) mod (2^61 - 1) with v = M * 2^k,
 // i.e. the 53-bit mantissa rotated left by k mod 61 inside 61 bits; sign applied after; -1 -> -2.
-__device__ inline uint64_t py_hash_double(double v) {
+__device__ __forceinline__ uint64_t py_hash_double(double v) {
   if (v == 0.0) return 0;
   uint64_t bits = (uint64_t)__double_as_longlong(v);
   int ef = (int)((bits >> 52) & 0x7FF);
@@ -64,7 +64,7 @@ __device__ inline uint64_t py_hash_double(double v) {
   if (sx == -1) sx = -2;
   return (uint64_t)sx;
 }
-__device__ inline uint64_t tuplehash6d(const double t[6]) {
+__device__ __forceinline__ uint64_t tuplehash6d(const double t[6]) {
   uint64_t acc = tuplehash_begin();
 #pragma unroll
   for (int i = 0; i < 6; i++) acc = tuplehash_lane(acc, py_hash_double(t[i]));
@@ -107,10 +107,10 @@ struct CLds {
 };
 
 // words of the region shared by the hash table and the GENEMS children scratch
-__host__ __device__ inline int cunion_words(const ContinuousParams& p) { return p.union_words; }
+__host__ __device__ __forceinline__ int cunion_words(const ContinuousParams& p) { return p.union_words; }
 
 // LDS bytes of everything but the stability state (which follows, 16-byte aligned)
-__host__ __device__ inline size_t continuous_lds_base_bytes(const ContinuousParams& p) {
+__host__ __device__ __forceinline__ size_t continuous_lds_base_bytes(const ContinuousParams& p) {
   const bool stab = p.setting != 2;
   size_t dbl = stab ? 9 * (size_t)p.I : (size_t)p.I;
   size_t i32 = 6 * (size_t)p.ems_cap + (size_t)p.union_words + 4 * (size_t)p.I + 128 + (p.rng_numpy ? 624 : 0);
@@ -119,7 +119,7 @@ __host__ __device__ inline size_t continuous_lds_base_bytes(const ContinuousPara
   return (dbl * 8 + i32 * 4 + u16 * 2 + 16 + 15) & ~(size_t)15;
 }
 
-__device__ inline CLds carve(const ContinuousParams& p, unsigned char* base) {
+__device__ __forceinline__ CLds carve(const ContinuousParams& p, unsigned char* base) {
   CLds l;
   double* d = reinterpret_cast<double*>(base);
   const bool stab = p.setting != 2;
@@ -155,7 +155,7 @@ size_t continuous_lds_bytes(const ContinuousParams& p) {
 }
 #endif
 
-__device__ inline void cdraw_item(const ContinuousParams& p, int e, CRegs& r) {
+__device__ __forceinline__ void cdraw_item(const ContinuousParams& p, int e, CRegs& r) {
   uint64_t c = r.cursor++;
   if (p.source == PCT_ITEMS_DATASET) {  // binCreator.py:64-72; sizes round(.,3) (C/bin3D.py:85)
     int t = r.traj < p.ds_ntraj ? r.traj : p.ds_ntraj - 1;
@@ -193,7 +193,7 @@ __device__ inline void cdraw_item(const ContinuousParams& p, int e, CRegs& r) {
 // Python's round(x, 3) of a positive double as the lattice index k (the result is the double nearest k/1000):
 // correctly rounded on the exact binary value of x, ties to even.  x = m 2^e2 is compared with the midpoints
 // (2k +- 1)/2000 in integers: m 2000 < 2^64.
-__device__ inline int cmp_x_mid(double x, long long twok1) {  // sign of x * 2000 - twok1
+__device__ __forceinline__ int cmp_x_mid(double x, long long twok1) {  // sign of x * 2000 - twok1
   if (twok1 <= 0) return 1;
   const uint64_t bits = (uint64_t)__double_as_longlong(x);
   const int e2 = (int)((bits >> 52) & 0x7FFu) - 1075;
@@ -205,7 +205,7 @@ __device__ inline int cmp_x_mid(double x, long long twok1) {  // sign of x * 200
   if (hi != B) return hi > B ? 1 : -1;
   return (A & ((1ull << sft) - 1ull)) ? 1 : 0;
 }
-__device__ inline int round3_lattice(double x) {
+__device__ __forceinline__ int round3_lattice(double x) {
   long long k = (long long)(x * 1000.0 + 0.5);
   for (int it = 0; it < 3; it++) {
     const int up = cmp_x_mid(x, 2 * k + 1), dn = cmp_x_mid(x, 2 * k - 1);
@@ -218,7 +218,7 @@ __device__ inline int round3_lattice(double x) {
 // C/bin3D.py:103-113 gen_next_box, sampling mode: round(np.random.uniform(a, b), 3) (legacy uniform: a + (b - a) *
 // random_sample(), no contraction), and np.random.choice of five heights (-> randint(0, 5)) under settings 1 / 3;
 // then cur_observation's density draw (:88-90)
-__device__ inline void cdraw_item_mt(const ContinuousParams& p, CLds& l, CRegs& r, int lane) {
+__device__ __forceinline__ void cdraw_item_mt(const ContinuousParams& p, CLds& l, CRegs& r, int lane) {
   r.cursor++;
   const double a = (double)p.sample_left / 1000.0, b = (double)p.sample_right / 1000.0;
   const double span = __dsub_rn(b, a);
@@ -232,12 +232,12 @@ __device__ inline void cdraw_item_mt(const ContinuousParams& p, CLds& l, CRegs& 
 }
 // box_creator.generate_box_size() (C/bin3D.py:73,202; binCreator.py:37-39): a randint over the item set that the
 // sampling mode never reads
-__device__ inline void cskip_creator_mt(const ContinuousParams& p, CLds& l, CRegs& r, int lane) {
+__device__ __forceinline__ void cskip_creator_mt(const ContinuousParams& p, CLds& l, CRegs& r, int lane) {
   (void)mt_interval(l, r, lane, (uint32_t)p.np_items - 1u);
 }
 
 // C/space.py:281-303 reset
-__device__ inline void cspace_reset(const ContinuousParams& p, CLds& l, CRegs& r, int lane) {
+__device__ __forceinline__ void cspace_reset(const ContinuousParams& p, CLds& l, CRegs& r, int lane) {
   if (lane == 0) {
     l.emsk[0 * p.ems_cap] = 0; l.emsk[1 * p.ems_cap] = 0; l.emsk[2 * p.ems_cap] = 0;
     l.emsk[3 * p.ems_cap] = klat(p.W); l.emsk[4 * p.ems_cap] = klat(p.Ly); l.emsk[5 * p.ems_cap] = klat(p.H);
@@ -256,7 +256,7 @@ __device__ inline void cspace_reset(const ContinuousParams& p, CLds& l, CRegs& r
 }
 
 // rotation `rot` of the item (C/space.py:537-557): extents and the skip rule (abs < 1e-6)
-__device__ inline bool crot_size(const CRegs& r, int rot, double& sx, double& sy, double& sz) {
+__device__ __forceinline__ bool crot_size(const CRegs& r, int rot, double& sx, double& sy, double& sz) {
   switch (rot) {
     case 0: sx = r.b0; sy = r.b1; sz = r.b2; return false;
     case 1: sx = r.b1; sy = r.b0; sz = r.b2; return fabs(sx - sy) < 1e-6;
@@ -268,7 +268,7 @@ __device__ inline bool crot_size(const CRegs& r, int rot, double& sx, double& sy
 }
 
 // The 6-tuple a generator id stands for: g = (ems * orient + rot) * 4 + corner (:560-563)
-__device__ inline void cand_tuple(const ContinuousParams& p, const CLds& l, const CRegs& r, int orient, uint32_t g,
+__device__ __forceinline__ void cand_tuple(const ContinuousParams& p, const CLds& l, const CRegs& r, int orient, uint32_t g,
                                   double t[6]) {
   int corner = (int)(g & 3u);
   int q = (int)(g >> 2);
@@ -282,24 +282,24 @@ __device__ inline void cand_tuple(const ContinuousParams& p, const CLds& l, cons
   t[2] = z0;
   t[5] = z0 + sz;
 }
-__device__ inline bool tuple_eq(const double a[6], const double b[6]) {
+__device__ __forceinline__ bool tuple_eq(const double a[6], const double b[6]) {
   return (a[0] == b[0]) & (a[1] == b[1]) & (a[2] == b[2]) & (a[3] == b[3]) & (a[4] == b[4]) & (a[5] == b[5]);
 }
 // table word of a key: 15-bit fingerprint of its hash | 16-bit generator id (tag bit clear)
-__device__ inline uint32_t cword(uint64_t hash, uint32_t g) { return (uint32_t)((hash >> 40) & 0x7FFFu) << 16 | g; }
+__device__ __forceinline__ uint32_t cword(uint64_t hash, uint32_t g) { return (uint32_t)((hash >> 40) & 0x7FFFu) << 16 | g; }
 
 struct CGeo {  // placed-box geometry for the stability code
   const double* box;
   const double* bsz;
   int I;
-  __device__ inline void operator()(int i, double g[9]) const {
+  __device__ __forceinline__ void operator()(int i, double g[9]) const {
 #pragma unroll
     for (int c = 0; c < 6; c++) g[c] = box[c * I + i];
     g[6] = bsz[0 * I + i]; g[7] = bsz[1 * I + i]; g[8] = bsz[2 * I + i];
   }
 };
 // C/space.py:441-487 GENEMS + :510-528 EliminateInscribedEMS.  l.emsk -> l.emsk.
-__device__ inline void cgenems(const ContinuousParams& p, CLds& l, CRegs& r, int lane, const double loc[6]) {
+__device__ __forceinline__ void cgenems(const ContinuousParams& p, CLds& l, CRegs& r, int lane, const double loc[6]) {
   // Survivors (EMS the box does not intersect) stay where they are in l.emsk until the end; only the
   // children go to the scratch list (l.emsb, [6][scap], aliasing the idle hash table).  The pre-GENEMS
   // list is containment-free and a child lies inside its parent, so a survivor can neither be deleted
@@ -437,7 +437,7 @@ __device__ inline void cgenems(const ContinuousParams& p, CLds& l, CRegs& r, int
 // a failed step builds and discards (C/bin3D.py:183) -- only its draws matter: the set is built for its size, the
 // shuffle's draws are consumed, nothing is written.
 template <bool GT, bool STAB, bool MT, bool COUNT_ONLY, typename TM>
-__device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CRegs& r, int lane, TM& tm) {
+__device__ __forceinline__ bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CRegs& r, int lane, TM& tm) {
   const int E = r.n_ems, cap = p.ems_cap;
   const int orient = (p.setting == 2) ? 6 : 2;
   const int NP = E * orient;
@@ -451,7 +451,7 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
   uint16_t* const order = GT ? p.gorder + gslot * (size_t)p.order_cap : reinterpret_cast<uint16_t*>(l.tab);
   // LDS table: every size starts at offset 0 (a rebuild first lifts the old table into registers); HBM table:
   // two regions, ping-pong
-  auto region = [&](uint32_t sz) -> uint32_t { return GT ? table_region(p.cand_cap, sz) : 0u; };
+  auto region = [&](uint32_t sz) __attribute__((always_inline)) -> uint32_t { return GT ? table_region(p.cand_cap, sz) : 0u; };
   uint32_t toff = region(size);
   if (lane < 8) tab_st<GT, uint32_t>(&tabs[toff + lane], EMPTY);
   l.dd[lane] = 0xFFFFFFFFu;
@@ -461,7 +461,7 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
   int npend = 0;
   tm.sub_start();
 
-  auto flush = [&](int cnt) {
+  auto flush = [&](int cnt) __attribute__((always_inline)) {
     bool pending = lane < cnt;
     uint32_t g = pending ? (uint32_t)l.pend[lane] : 0u;
     uint16_t mv = (lane + 64 < npend) ? l.pend[lane + 64] : (uint16_t)0;
@@ -492,7 +492,7 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
         uint64_t rem = pm0;
         int t8 = 0xFF, t32 = 0xFF;
         uint32_t occ8 = 0, occ32 = 0;
-        auto lane_hash = [&](int src) -> uint64_t {
+        auto lane_hash = [&](int src) __attribute__((always_inline)) -> uint64_t {
           uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)hash, src);
           uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(hash >> 32), src);
           return ((uint64_t)hi << 32) | lo;
@@ -510,7 +510,7 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
           occ8 |= 1u << i;
           t8 = lane == (int)i ? src : t8;
         }
-        auto insert32 = [&](int src) {
+        auto insert32 = [&](int src) __attribute__((always_inline)) {
           const uint64_t h = lane_hash(src);
           uint32_t i = (uint32_t)h & 31u;
           uint64_t perturb = h;
@@ -569,7 +569,7 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
       }
     }
     const uint32_t word = cword(hash, g);
-    auto same = [&](uint32_t w) -> bool {
+    auto same = [&](uint32_t w) __attribute__((always_inline)) -> bool {
       if ((w >> 16) != (word >> 16)) return false;  // different hash
       double o[6];
       cand_tuple(p, l, r, orient, w & 0xFFFFu, o);
@@ -601,7 +601,7 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
         // de-duplication words and go into the new table 64 at a time -- 60 % of the matching passes of a
         // chunk-by-chunk re-insertion, each of which recomputes and re-hashes its tuples.
         int nq = 0;
-        auto reinsert = [&](uint32_t ow, uint32_t off) {  // up to 64 old entries into the new table at `off`
+        auto reinsert = [&](uint32_t ow, uint32_t off) __attribute__((always_inline)) {  // up to 64 old entries into the new table at `off`
           bool opart = ow != EMPTY;
           double o[6];
           cand_tuple(p, l, r, orient, opart ? (ow & 0xFFFFu) : 0u, o);
@@ -612,7 +612,7 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
           if (oplaced) tab_st<GT, uint32_t>(&tabs[off + oslot], ow);
           __syncthreads();
         };
-        auto push = [&](uint32_t ow, uint32_t off) {  // one chunk of old slots
+        auto push = [&](uint32_t ow, uint32_t off) __attribute__((always_inline)) {  // one chunk of old slots
           const uint64_t m = __ballot(ow != EMPTY);
           if (ow != EMPTY) l.dd[nq + rank_below(m)] = ow;
           nq += __popcll(m);
@@ -627,7 +627,7 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
             reinsert(w, off);
           }
         };
-        auto drain = [&](uint32_t off) {
+        auto drain = [&](uint32_t off) __attribute__((always_inline)) {
           if (nq > 0) {
             const uint32_t w = lane < nq ? l.dd[lane] : EMPTY;
             __syncthreads();
@@ -768,7 +768,7 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
   // wave-cooperative task walk (pct_stab.cuh stab_virtual_wave)
   bool stab_ill = false;
   bool unknown = false;  // the last call left this lane's candidate undecided (a capacity of its own was exceeded)
-  auto feasible = [&](bool live, const double t[6]) -> bool {
+  auto feasible = [&](bool live, const double t[6]) __attribute__((always_inline)) -> bool {
     unknown = false;
     double lx = t[0], ly = t[1];
     double x = t[3] - t[0], y = t[4] - t[1], z = t[5] - t[2];
@@ -877,7 +877,7 @@ __device__ inline bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CR
 // C/bin3D.py:78-100 observation rows, float32 (envs.py:180)
 // `full` rewrites every row; otherwise only what changed since this env's previous observation:
 // the row of the box just placed (`new_row`, or -1), the leaf rows and the next-item row
-__device__ inline void cwrite_obs(const ContinuousParams& p, int e, const CLds& l, const CRegs& r, int lane,
+__device__ __forceinline__ void cwrite_obs(const ContinuousParams& p, int e, const CLds& l, const CRegs& r, int lane,
                                   float* __restrict__ obs, bool full, int new_row, const double newbox[6]) {
   const float nden = p.rng_numpy ? (float)(p.setting == 3 ? r.den_cur : 1.0)
                                  : (float)next_density(p, e, r.oc - 1, r.traj, r.cursor - 1);  // C/bin3D.py:81-90,98
@@ -954,7 +954,7 @@ __device__ inline void cwrite_obs(const ContinuousParams& p, int e, const CLds& 
         lane == 0 ? nden : (lane == 3 ? (float)a : (lane == 4 ? (float)b : (lane == 5 ? (float)c : (lane == 8 ? 1.0f : 0.f))));
 }
 
-__device__ inline void cload(const ContinuousParams& p, int e, CLds& l, CRegs& r, int lane) {
+__device__ __forceinline__ void cload(const ContinuousParams& p, int e, CLds& l, CRegs& r, int lane) {
   const int32_t* sc = p.scalars + (size_t)e * PCT_SCALARS;
   r.n_ems = sc[0]; r.n_boxes = sc[1]; r.n_leaf = sc[2];
   r.ik0 = sc[3]; r.ik1 = sc[4]; r.ik2 = sc[5];
@@ -1009,7 +1009,7 @@ __device__ inline void cload(const ContinuousParams& p, int e, CLds& l, CRegs& r
 
 // the box just placed goes to its HBM row at once (rows are only ever appended; the row count lives in the
 // scalars, which cstore writes): lane 0, six strided stores
-__device__ inline void cstore_box(const ContinuousParams& p, int e, int bi, const double g[6], const double sz[3], int lane) {
+__device__ __forceinline__ void cstore_box(const ContinuousParams& p, int e, int bi, const double g[6], const double sz[3], int lane) {
   if (lane == 0) {
     double* gb = p.boxes + (size_t)e * 6 * p.I;
 #pragma unroll
@@ -1021,7 +1021,7 @@ __device__ inline void cstore_box(const ContinuousParams& p, int e, int bi, cons
   }
 }
 
-__device__ inline void cstore(const ContinuousParams& p, int e, const CLds& l, const CRegs& r, int lane) {
+__device__ __forceinline__ void cstore(const ContinuousParams& p, int e, const CLds& l, const CRegs& r, int lane) {
   int32_t* sc = p.scalars + (size_t)e * PCT_SCALARS;
   int32_t* ge = p.ems + (size_t)e * 6 * p.ems_stride;
   uint16_t* gl = p.leafg + (size_t)e * p.L;
@@ -1055,7 +1055,7 @@ __device__ inline void cstore(const ContinuousParams& p, int e, const CLds& l, c
 // returns 0: the episode goes on, 1: it ended and the env was reset, 2 (NumPy-stream mode): the discarded
 // observation's candidate set outgrew this launch's table -- requeue
 template <bool GT, bool STAB, bool MT, typename TM>
-__device__ inline int ctransition(const ContinuousParams& p, int e, CLds& l, CRegs& r, int lane, int flag, double a1,
+__device__ __forceinline__ int ctransition(const ContinuousParams& p, int e, CLds& l, CRegs& r, int lane, int flag, double a1,
                                    double a2, double bx, double by, double bz, TM& tm, double newbox[6], bool giveup = false) {
   r.t++;
   const double lx = around6(a1), ly = around6(a2);  // idx = [round(action[1], 6), round(action[2], 6)]
@@ -1179,7 +1179,7 @@ __device__ inline int ctransition(const ContinuousParams& p, int e, CLds& l, CRe
 // ---- heuristic.py on PackingContinuous (tools.py:217-218: LSAH, OnlineBPH, BR) as in-env policies -------------------
 // See oracle/pct_oracle_cont.c pctc_heur_choose for the sequential statement (pinned on the reference's own loops).
 // lane = (EMS, rotation) pair in the reference's loop order; float64 in the reference's operation order.
-__device__ inline void cheur_rot(const CRegs& r, int rot, double& x, double& y, double& z) {  // heuristic.py:171-182
+__device__ __forceinline__ void cheur_rot(const CRegs& r, int rot, double& x, double& y, double& z) {  // heuristic.py:171-182
   switch (rot) {
     case 0: x = r.b0; y = r.b1; z = r.b2; break;
     case 1: y = r.b0; x = r.b1; z = r.b2; break;
@@ -1189,7 +1189,7 @@ __device__ inline void cheur_rot(const CRegs& r, int rot, double& x, double& y, 
     default: y = r.b0; z = r.b1; x = r.b2; break;
   }
 }
-__device__ inline double wave_min_f64(double v) {
+__device__ __forceinline__ double wave_min_f64(double v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
     double o = __shfl_xor(v, off, 64);
@@ -1197,7 +1197,7 @@ __device__ inline double wave_min_f64(double v) {
   }
   return v;
 }
-__device__ inline int wave_min_i32(int v) {
+__device__ __forceinline__ int wave_min_i32(int v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
     int o = __shfl_xor(v, off, 64);
@@ -1207,14 +1207,14 @@ __device__ inline int wave_min_i32(int v) {
 }
 // returns false if there is no feasible placement.  (olx, oly): position, (ox, oy, oz): the item as rotated.
 template <bool STAB>
-__device__ inline bool cheur_choose(const ContinuousParams& p, int e, CLds& l, CRegs& r, int lane, int kind, double& olx,
+__device__ __forceinline__ bool cheur_choose(const ContinuousParams& p, int e, CLds& l, CRegs& r, int lane, int kind, double& olx,
                                     double& oly, double& ox, double& oy, double& oz) {
   const int orient = (p.setting == 2) ? 6 : 2;
   const int E = r.n_ems, NQ = E * orient, nb = r.n_boxes;
   const double den = STAB ? next_density(p, e, r.oc - 1, r.traj, r.cursor - 1) : 1.0;
   // drop_box_virtual(..., returnH=True) (C/space.py:380-425) of size (x, y, z) at (lx, ly).  ALL 64 lanes call (`go`: this
   // lane has a placement to test): the stability check is wave-cooperative
-  auto probe = [&](bool go, double x, double y, double z, double lx, double ly, double& height) -> bool {
+  auto probe = [&](bool go, double x, double y, double z, double lx, double ly, double& height) __attribute__((always_inline)) -> bool {
     bool ok = go;
     if (lx + x - 1e-6 > p.W || ly + y - 1e-6 > p.Ly) ok = false;
     if (lx + 1e-6 < 0 || ly + 1e-6 < 0) ok = false;
@@ -1244,7 +1244,7 @@ __device__ inline bool cheur_choose(const ContinuousParams& p, int e, CLds& l, C
     }
     return ok;
   };
-  auto ems_of = [&](int ei, double em[6]) {
+  auto ems_of = [&](int ei, double em[6]) __attribute__((always_inline)) {
 #pragma unroll
     for (int c = 0; c < 6; c++) em[c] = lat2d(l.emsk[c * p.ems_cap + ei]);
   };
@@ -1408,7 +1408,7 @@ __device__ inline bool cheur_choose(const ContinuousParams& p, int e, CLds& l, C
 #endif  // !PCT_CONT_MT
 
 // C/bin3D.py:151-167 LeafNode2Action on a float64 row (a0,a1,_,a3,a4,_)
-__device__ inline void cdecode_leaf(const CRegs& r, bool zero_row, double a0, double a1, double a3, double a4, double& p1,
+__device__ __forceinline__ void cdecode_leaf(const CRegs& r, bool zero_row, double a0, double a1, double a3, double a4, double& p1,
                                     double& p2, double& bx, double& by, double& bz) {
   if (zero_row) {
     p1 = 0; p2 = 0; bx = r.b0; by = r.b1; bz = r.b2;

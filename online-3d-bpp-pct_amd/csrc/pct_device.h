@@ -127,7 +127,7 @@ struct ContinuousParams {
 // take a higher issue priority (s_setprio) so that they run at a lone wave's pace from the start while the light
 // waves of the same SIMD fill the gaps, instead of crawling at a quarter of it until the light ones are gone
 // (C2: 75.4 -> 71.2 us per launch).  prio_t: ascending EMS-count thresholds of priorities 1..3 (0: off).
-__device__ inline void wave_priority(int n_ems, const int prio_t[3]) {
+__device__ __forceinline__ void wave_priority(int n_ems, const int prio_t[3]) {
   if (prio_t[0] <= 0) return;
   if (n_ems >= prio_t[2]) __builtin_amdgcn_s_setprio(3);
   else if (n_ems >= prio_t[1]) __builtin_amdgcn_s_setprio(2);
@@ -136,7 +136,7 @@ __device__ inline void wave_priority(int n_ems, const int prio_t[3]) {
 }
 
 template <typename Params>
-__device__ inline double next_density(const Params& p, int e, uint32_t oc, int traj, unsigned long long item_index) {
+__device__ __forceinline__ double next_density(const Params& p, int e, uint32_t oc, int traj, unsigned long long item_index) {
   if (p.setting != 3) return 1.0;
   if (p.source == PCT_ITEMS_DATASET) {  // self.next_box[3]
     int t = traj < p.ds_ntraj ? traj : p.ds_ntraj - 1;

@@ -62,7 +62,7 @@ struct Pack {
 };
 
 template <typename K, int BITS>
-__device__ inline uint64_t tuplehash6(K key) {
+__device__ __forceinline__ uint64_t tuplehash6(K key) {
   uint64_t acc = tuplehash_begin();
 #pragma unroll
   for (int i = 0; i < 6; i++) acc = tuplehash_lane(acc, (uint64_t)Pack<K, BITS>::get(key, i));  // hash(int) == int
@@ -109,17 +109,17 @@ struct Lds {
   StabWave sw;    /* ... and the wave's hull workspace + task queue */
 };
 
-__host__ __device__ inline int discrete_scheme_words(const DiscreteParams& p) {
+__host__ __device__ __forceinline__ int discrete_scheme_words(const DiscreteParams& p) {
   if (p.lnes == PCT_LNES_CP || p.lnes == PCT_LNES_EP) return 6 * (p.I + 2);
   if (p.lnes == PCT_LNES_EV) return 288;
   return 0;
 }
-__host__ __device__ inline int discrete_scratch_words(const DiscreteParams& p) {
+__host__ __device__ __forceinline__ int discrete_scratch_words(const DiscreteParams& p) {
   return (int)(128 * sizeof(uint32_t) / p.key_bytes);  // dd[128 x u32], in key words
 }
 
 // LDS bytes of everything but the stability state (which follows, 16-byte aligned)
-__host__ __device__ inline size_t discrete_lds_base_bytes(const DiscreteParams& p) {
+__host__ __device__ __forceinline__ size_t discrete_lds_base_bytes(const DiscreteParams& p) {
   size_t k = p.key_bytes;
   size_t n = (size_t)table_words_compact((uint32_t)p.cand_cap) + p.ems_cap + discrete_scratch_words(p) + p.I + p.L;
   size_t hb = ((size_t)p.AA * (k == 4 ? 1 : 2) + 3) & ~(size_t)3;
@@ -130,7 +130,7 @@ __host__ __device__ inline size_t discrete_lds_base_bytes(const DiscreteParams& 
 }
 
 template <typename K, int BITS>
-__device__ inline Lds<K, BITS> carve_lds(const DiscreteParams& p, unsigned char* base) {
+__device__ __forceinline__ Lds<K, BITS> carve_lds(const DiscreteParams& p, unsigned char* base) {
   Lds<K, BITS> l;
   K* q = reinterpret_cast<K*>(base);
   l.tab0 = q; q += table_words_compact((uint32_t)p.cand_cap);
@@ -162,14 +162,14 @@ __device__ inline Lds<K, BITS> carve_lds(const DiscreteParams& p, unsigned char*
 template <typename K, int BITS>
 struct BoxGeo {
   const K* box;
-  __device__ inline void operator()(int i, double g[9]) const {
+  __device__ __forceinline__ void operator()(int i, double g[9]) const {
     K k = box[i];
 #pragma unroll
     for (int c = 0; c < 6; c++) g[c] = (double)Pack<K, BITS>::get(k, c);
     g[6] = g[3] - g[0]; g[7] = g[4] - g[1]; g[8] = g[5] - g[2];  // exact for integers
   }
 };
-__device__ inline void draw_item(const DiscreteParams& p, int e, EnvRegs& r) {
+__device__ __forceinline__ void draw_item(const DiscreteParams& p, int e, EnvRegs& r) {
   // binCreator.py:37-39 generate_box_size, through the scripted / counter-based sources
   uint64_t c = r.cursor++;
   const int32_t* it;
@@ -196,7 +196,7 @@ __device__ inline void draw_item(const DiscreteParams& p, int e, EnvRegs& r) {
 
 // binCreator.py:37-39 in strict NumPy-stream mode: idx = np.random.randint(0, len(box_set))
 template <typename L>
-__device__ inline void draw_item_mt(const DiscreteParams& p, L& l, EnvRegs& r, int lane) {
+__device__ __forceinline__ void draw_item_mt(const DiscreteParams& p, L& l, EnvRegs& r, int lane) {
   r.cursor++;
   const uint32_t idx = mt_interval(l, r, lane, (uint32_t)p.n_items - 1u);
   const int32_t* it = p.item_set + (size_t)idx * 3;
@@ -207,7 +207,7 @@ __device__ inline void draw_item_mt(const DiscreteParams& p, L& l, EnvRegs& r, i
 
 // D/space.py:290-314 Space.reset on the LDS-resident state
 template <typename K, int BITS>
-__device__ inline void space_reset(const DiscreteParams& p, Lds<K, BITS>& l, EnvRegs& r, int lane) {
+__device__ __forceinline__ void space_reset(const DiscreteParams& p, Lds<K, BITS>& l, EnvRegs& r, int lane) {
   for (int c = lane; c < p.AA; c += 64) l.hmap[c] = 0;
   if (lane == 0) l.ems_a[0] = Pack<K, BITS>::pack(0, 0, 0, p.W, p.Ly, p.H);
   r.n_ems = 1;
@@ -226,7 +226,7 @@ __device__ inline void space_reset(const DiscreteParams& p, Lds<K, BITS>& l, Env
 
 // D/space.py:457-483 GENEMS + :518-531 EliminateInscribedEMS.  ems_a -> ems_a.
 template <typename K, int BITS>
-__device__ inline void genems(const DiscreteParams& p, Lds<K, BITS>& l, EnvRegs& r, int lane, int bx0, int by0,
+__device__ __forceinline__ void genems(const DiscreteParams& p, Lds<K, BITS>& l, EnvRegs& r, int lane, int bx0, int by0,
                               int bz0, int bx1, int by1, int bz1) {
   typedef Pack<K, BITS> P;
   const int E = r.n_ems;
@@ -234,7 +234,7 @@ __device__ inline void genems(const DiscreteParams& p, Lds<K, BITS>& l, EnvRegs&
   const int lb = p.low_bound <= 0 ? 1 : p.low_bound;
   // children of the intersected EMS held by this lane, written at `first` + (this lane's offset
   // among the chunk's children): parent index, then branch order.  Returns the chunk's child count.
-  auto emit_children = [&](bool live, K k, int first) -> int {
+  auto emit_children = [&](bool live, K k, int first) __attribute__((always_inline)) -> int {
     int x1 = P::get(k, 0), y1 = P::get(k, 1), z1 = P::get(k, 2), x2 = P::get(k, 3), y2 = P::get(k, 4),
         z2 = P::get(k, 5);
     int x3 = max(bx0, x1), y3 = max(by0, y1), z3 = max(bz0, z1);
@@ -257,7 +257,7 @@ __device__ inline void genems(const DiscreteParams& p, Lds<K, BITS>& l, EnvRegs&
     if (c4) { if (pos < scap) l.ems_b[pos] = P::pack(x1, y1, z4, x2, y2, z2); pos++; }
     return __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3) + __popcll(m4);
   };
-  auto intersects = [&](K k) -> bool {
+  auto intersects = [&](K k) __attribute__((always_inline)) -> bool {
     int t1 = max(bx0, P::get(k, 0)), u1 = max(by0, P::get(k, 1)), v1 = max(bz0, P::get(k, 2));
     int t2 = min(bx1, P::get(k, 3)), u2 = min(by1, P::get(k, 4)), v2 = min(bz1, P::get(k, 5));
     return (t1 < t2) && (u1 < u2) && (v1 < v2);
@@ -400,7 +400,7 @@ struct SetState {
 // in old-slot order (Objects/setobject.c set_add_entry / set_table_resize / set_insert_clean).
 // A table rebuild re-inserts RV*64 old slots per matching pass.
 template <typename K, int BITS, int V, typename TM>
-__device__ inline void set_insert(SetState<K>& st, const K (&key)[V], const bool (&valid)[V], int lane, TM& tm,
+__device__ __forceinline__ void set_insert(SetState<K>& st, const K (&key)[V], const bool (&valid)[V], int lane, TM& tm,
                                   int* mst) {
   const K EMPTY = SlotWord<K>::EMPTY;
   K* const tabs = st.tabs;
@@ -440,7 +440,7 @@ __device__ inline void set_insert(SetState<K>& st, const K (&key)[V], const bool
       int t8 = 0xFF, t32 = 0xFF;  // per lane: source lane of the key in that slot
       uint32_t occ8 = 0, occ32 = 0;
       const uint64_t h0 = hash0;
-      auto lane_hash = [&](int src) -> uint64_t {
+      auto lane_hash = [&](int src) __attribute__((always_inline)) -> uint64_t {
         uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)h0, src);
         uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(h0 >> 32), src);
         return ((uint64_t)hi << 32) | lo;
@@ -458,7 +458,7 @@ __device__ inline void set_insert(SetState<K>& st, const K (&key)[V], const bool
         occ8 |= 1u << i;
         t8 = lane == (int)i ? src : t8;
       }
-      auto insert32 = [&](int src) {  // set_insert_clean / set_add_entry on the 32-slot table
+      auto insert32 = [&](int src) __attribute__((always_inline)) {  // set_insert_clean / set_add_entry on the 32-slot table
         const uint64_t h = lane_hash(src);
         uint32_t i = (uint32_t)h & 31u;
         uint64_t perturb = h;
@@ -639,7 +639,7 @@ __device__ inline void set_insert(SetState<K>& st, const K (&key)[V], const bool
 }
 
 // rotation `rot` of the item (b0, b1, b2) (D/space.py:540-562): extents and the skip rule
-__device__ inline bool item_rot_size(int b0, int b1, int b2, int rot, int& sx, int& sy, int& sz) {
+__device__ __forceinline__ bool item_rot_size(int b0, int b1, int b2, int rot, int& sx, int& sy, int& sz) {
   switch (rot) {
     case 0: sx = b0; sy = b1; sz = b2; return false;
     case 1: sx = b1; sy = b0; sz = b2; return sx == sy;
@@ -681,7 +681,7 @@ __device__ inline bool item_rot_size(int b0, int b1, int b2, int rot, int& sx, i
 // inserts batch by batch.
 constexpr int WS_KMAX = 768;  // generated tuples the whole-set path takes (the 99.9th percentile at 10^3 is ~600)
 template <typename K, int BITS, typename TM>
-__device__ inline bool ems_set_whole(const DiscreteParams& p, Lds<K, BITS>& l, SetState<K>& st, int lane, TM& tm, int* mst,
+__device__ __forceinline__ bool ems_set_whole(const DiscreteParams& p, Lds<K, BITS>& l, SetState<K>& st, int lane, TM& tm, int* mst,
                                      int E, int orient, uint32_t rotmask, int b0, int b1, int b2) {
   typedef Pack<K, BITS> P;
   const K EMPTY = SlotWord<K>::EMPTY;
@@ -770,7 +770,7 @@ __device__ inline bool ems_set_whole(const DiscreteParams& p, Lds<K, BITS>& l, S
   const uint64_t h0 = tuplehash6<K, BITS>(key0);
   int t8 = 0xFF, t32 = 0xFF;
   uint32_t occ8 = 0, occ32 = 0;
-  auto lane_hash = [&](int src) -> uint64_t {
+  auto lane_hash = [&](int src) __attribute__((always_inline)) -> uint64_t {
     uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)h0, src);
     uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(h0 >> 32), src);
     return ((uint64_t)hi << 32) | lo;
@@ -786,7 +786,7 @@ __device__ inline bool ems_set_whole(const DiscreteParams& p, Lds<K, BITS>& l, S
     occ8 |= 1u << i;
     t8 = lane == (int)i ? o : t8;
   }
-  auto insert32 = [&](int src) {  // set_insert_clean / set_add_entry on the 32-slot table
+  auto insert32 = [&](int src) __attribute__((always_inline)) {  // set_insert_clean / set_add_entry on the 32-slot table
     const uint64_t h = lane_hash(src);
     uint32_t i = (uint32_t)h & 31u;
     uint64_t perturb = h;
@@ -927,7 +927,7 @@ __device__ inline bool ems_set_whole(const DiscreteParams& p, Lds<K, BITS>& l, S
 // RNG: bit 0 = the candidate list is shuffled before the first-L cut, bit 1 = strict NumPy-stream mode (the shuffle, the
 // item picks and the densities consume the env's MT19937 stream; otherwise they are counter-keyed)
 template <typename K, int BITS, bool STAB, int SCHEME, int RNG, typename TM>
-__device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& l, EnvRegs& r, int lane, TM& tm) {
+__device__ __forceinline__ void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& l, EnvRegs& r, int lane, TM& tm) {
   typedef Pack<K, BITS> P;
   constexpr bool SHUFFLE = (RNG & 1) != 0, MT = (RNG & 2) != 0;
   // strict mode: the observation's density is drawn first (D/bin3D.py:80-84), the shuffle draws follow below
@@ -957,7 +957,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
   tm.sub_start();
 
   // rotation r of the item (D/space.py:540-562): extents and the skip rule
-  auto rot_size = [&](int rot, int& sx, int& sy, int& sz) -> bool {
+  auto rot_size = [&](int rot, int& sx, int& sy, int& sz) __attribute__((always_inline)) -> bool {
     switch (rot) {
       case 0: sx = b0; sy = b1; sz = b2; return false;
       case 1: sx = b1; sy = b0; sz = b2; return sx == sy;
@@ -999,13 +999,13 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
     // rotation (<= 24 tuples, possibly with negative coordinates, which is why they do not go
     // through the packed-key table); one lane replays set.add on a 128-slot table of candidate ids.
     uint32_t* tb = l.cp;  // [128] ids (rot * 4 + corner), 0xFF = empty
-    auto ev_tuple = [&](int id, int t[6]) {
+    auto ev_tuple = [&](int id, int t[6]) __attribute__((always_inline)) {
       int sx, sy, sz;
       rot_size(id >> 2, sx, sy, sz);
       int xs = (id & 2) ? p.W - sx : 0, ys = (id & 1) ? p.Ly - sy : 0;  // add order :654-674
       t[0] = xs; t[1] = ys; t[2] = 0; t[3] = xs + sx; t[4] = ys + sy; t[5] = sz;
     };
-    auto ev_hash = [&](const int t[6]) {
+    auto ev_hash = [&](const int t[6]) __attribute__((always_inline)) {
       uint64_t acc = tuplehash_begin();
       for (int c = 0; c < 6; c++) acc = tuplehash_lane(acc, pyhash_int(t[c]));
       return tuplehash_end6(acc);
@@ -1014,7 +1014,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
       uint32_t sz_t = 8, fill = 0;
       for (int i = 0; i < 8; i++) tb[i] = 0xFFu;
       // set_insert_clean / set_add_entry probe sequence (LINEAR_PROBES 9, PERTURB_SHIFT 5)
-      auto probe_insert = [&](uint32_t* tab, uint32_t mask, int id, bool check) -> bool {
+      auto probe_insert = [&](uint32_t* tab, uint32_t mask, int id, bool check) __attribute__((always_inline)) -> bool {
         int t[6];
         ev_tuple(id, t);
         Walk w;
@@ -1360,7 +1360,7 @@ __device__ inline void leaf_nodes(const DiscreteParams& p, int e, Lds<K, BITS>& 
   // that need one is a wave-cooperative task walk (pct_stab.cuh stab_virtual_wave).
   bool stab_ill = false;
   bool unknown = false;  // the last call left this lane's candidate undecided (a capacity of its own was exceeded)
-  auto feasible = [&](K k) -> bool {
+  auto feasible = [&](K k) __attribute__((always_inline)) -> bool {
     unknown = false;
     const bool occ = k != SlotWord<K>::EMPTY;
     int xs = P::get(k, 0), ys = P::get(k, 1), xe = P::get(k, 3), ye = P::get(k, 4);
@@ -1504,7 +1504,7 @@ template <typename K, int BITS>
 // `full` rewrites every row (reset, end of an episode, freshly bound buffer); otherwise the buffer
 // still holds this env's previous observation and only what changed is written: the row of the
 // box just placed (`new_row`, or -1), the L leaf rows and the next-item row.
-__device__ inline void write_obs(const DiscreteParams& p, int e, const Lds<K, BITS>& l, const EnvRegs& r, int lane,
+__device__ __forceinline__ void write_obs(const DiscreteParams& p, int e, const Lds<K, BITS>& l, const EnvRegs& r, int lane,
                                  float* __restrict__ obs, bool full, int new_row) {
   typedef Pack<K, BITS> P;
   int a = r.item0, b = r.item1, c = r.item2, tmp;
@@ -1573,7 +1573,7 @@ __device__ inline void write_obs(const DiscreteParams& p, int e, const Lds<K, BI
 }
 
 template <typename K, int BITS>
-__device__ inline void load_state(const DiscreteParams& p, int e, Lds<K, BITS>& l, EnvRegs& r, int lane,
+__device__ __forceinline__ void load_state(const DiscreteParams& p, int e, Lds<K, BITS>& l, EnvRegs& r, int lane,
                                   bool need_boxes, bool need_leaves) {
   const K* g_ems = reinterpret_cast<const K*>(p.ems) + (size_t)e * p.ems_stride;
   const K* g_box = reinterpret_cast<const K*>(p.boxes) + (size_t)e * p.I;
@@ -1626,7 +1626,7 @@ __device__ inline void load_state(const DiscreteParams& p, int e, Lds<K, BITS>& 
 }
 
 template <typename K, int BITS>
-__device__ inline void store_state(const DiscreteParams& p, int e, const Lds<K, BITS>& l, const EnvRegs& r, int lane) {
+__device__ __forceinline__ void store_state(const DiscreteParams& p, int e, const Lds<K, BITS>& l, const EnvRegs& r, int lane) {
   K* g_ems = reinterpret_cast<K*>(p.ems) + (size_t)e * p.ems_stride;
   K* g_box = reinterpret_cast<K*>(p.boxes) + (size_t)e * p.I;
   K* g_leaf = reinterpret_cast<K*>(p.leaves) + (size_t)e * p.L;
@@ -1659,7 +1659,7 @@ __device__ inline void store_state(const DiscreteParams& p, int e, const Lds<K, 
 
 // ---- heuristic.py: the placement rules of the heuristic baselines as in-env policies ----------
 // rotation convention of heuristic.py:260-271 (shared by all of them; not EMSPoint's)
-__device__ inline void heur_rot(int b0, int b1, int b2, int rot, int& x, int& y, int& z) {
+__device__ __forceinline__ void heur_rot(int b0, int b1, int b2, int rot, int& x, int& y, int& z) {
   switch (rot) {
     case 0: x = b0; y = b1; z = b2; break;
     case 1: y = b0; x = b1; z = b2; break;
@@ -1675,7 +1675,7 @@ __device__ inline void heur_rot(int b0, int b1, int b2, int rot, int& x, int& y,
 // is the lexicographic minimum of (score, position in the reference's loop order), which is what
 // "replace on strictly better" leaves.  Returns false if there is no feasible placement.
 template <typename K, int BITS, bool STAB>
-__device__ inline bool heur_choose(const DiscreteParams& p, int e, Lds<K, BITS>& l, const EnvRegs& r, int lane, int kind,
+__device__ __forceinline__ bool heur_choose(const DiscreteParams& p, int e, Lds<K, BITS>& l, const EnvRegs& r, int lane, int kind,
                                    int& olx, int& oly, int& ox, int& oy, int& oz, uint32_t& stab_err) {
   typedef Pack<K, BITS> P;
   const int orient = STAB ? 2 : 6;
@@ -1685,7 +1685,7 @@ __device__ inline bool heur_choose(const DiscreteParams& p, int e, Lds<K, BITS>&
   // drop_box_virtual (D/space.py:393-433) of size (x,y,z) at (lx,ly): feasibility, height, and the sum of
   // the heightmap under the footprint (NumPy clips the slice to the array)
   // ALL 64 lanes call (`go`: this lane has a placement to test): the stability check is wave-cooperative
-  auto probe = [&](bool go, int x, int y, int z, int lx, int ly, int& mh, long long& under) -> bool {
+  auto probe = [&](bool go, int x, int y, int z, int lx, int ly, int& mh, long long& under) __attribute__((always_inline)) -> bool {
     mh = 0;
     under = 0;
     if (go) {
@@ -1992,7 +1992,7 @@ __device__ inline bool heur_choose(const DiscreteParams& p, int e, Lds<K, BITS>&
 // One transition of one env with the state resident in LDS (D/bin3D.py:151-188 plus the
 // VecEnv worker's auto-reset).  (flag, lx, ly) + (bx, by, bz) is the decoded action.
 template <typename K, int BITS, bool STAB, int SCHEME, int RNG, typename TM>
-__device__ inline bool transition(const DiscreteParams& p, int e, Lds<K, BITS>& l, EnvRegs& r, int lane, bool bad,
+__device__ __forceinline__ bool transition(const DiscreteParams& p, int e, Lds<K, BITS>& l, EnvRegs& r, int lane, bool bad,
                                   int flag, int lx, int ly, int bx, int by, int bz, TM& tm, bool giveup = false) {
   typedef Pack<K, BITS> P;
   constexpr bool SHUFFLE = (RNG & 1) != 0, MT = (RNG & 2) != 0;
@@ -2118,7 +2118,7 @@ __device__ inline bool transition(const DiscreteParams& p, int e, Lds<K, BITS>& 
 
 // D/bin3D.py:139-149 LeafNode2Action for a leaf given as six integers (zero row -> (0,0,0)
 // with the unrotated item)
-__device__ inline void decode_leaf(const EnvRegs& r, bool zero_row, int xs, int ys, int xe, int ye, bool& bad,
+__device__ __forceinline__ void decode_leaf(const EnvRegs& r, bool zero_row, int xs, int ys, int xe, int ye, bool& bad,
                                    int& lx, int& ly, int& bx, int& by, int& bz) {
   bad = false;
   if (zero_row) {
@@ -2146,7 +2146,7 @@ enum { ACT_ROWS = 0, ACT_INDEX = 1, ACT_HASH = 2, ACT_RESET = 3, ACT_HEUR = 4 /*
 
 // one env, one launch's worth of transitions (the body of the kernel below)
 template <typename K, int BITS, int ACT, bool TIMED, bool STAB, int SCHEME, int RNG>
-__device__ inline void discrete_env_steps(const DiscreteParams& p, const void* __restrict__ actions, int row_len, int n_steps,
+__device__ __forceinline__ void discrete_env_steps(const DiscreteParams& p, const void* __restrict__ actions, int row_len, int n_steps,
                                           int e, unsigned char* smem) {
   const int lane = threadIdx.x;
   Lds<K, BITS> l = carve_lds<K, BITS>(p, smem);
@@ -2183,7 +2183,7 @@ __device__ inline void discrete_env_steps(const DiscreteParams& p, const void* _
   // env has left nothing of a half-done commit behind.  A stability capacity -- pools, hull workspace, task queue --
   // that is exceeded requeues the env likewise; only where no larger pass exists does it raise the flag.)
   const bool can_retry = p.retry_count != nullptr && !p.retry_mode;
-  auto overflowed = [&]() -> bool {
+  auto overflowed = [&]() __attribute__((always_inline)) -> bool {
     if (STAB && r.stab_over && !can_retry) {
       r.flags |= PCT_FLAG_STABILITY_OVERFLOW | r.stab_over;
       r.stab_over = 0;

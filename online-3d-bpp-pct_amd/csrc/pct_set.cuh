@@ -7,7 +7,7 @@
 
 namespace pct {
 
-__device__ inline int wave_max_i32(int v) {
+__device__ __forceinline__ int wave_max_i32(int v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
     int o = __shfl_xor(v, off, 64);
@@ -15,7 +15,7 @@ __device__ inline int wave_max_i32(int v) {
   }
   return v;
 }
-__device__ inline uint64_t wave_min_u64(uint64_t v) {
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
   for (int off = 32; off > 0; off >>= 1) {
     uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, off, 64);
     uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), off, 64);
@@ -24,7 +24,7 @@ __device__ inline uint64_t wave_min_u64(uint64_t v) {
   }
   return v;
 }
-__device__ inline long long wave_sum_i64(long long v) {
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
   for (int off = 32; off > 0; off >>= 1) {
     uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)(uint64_t)v, off, 64);
     uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)((uint64_t)v >> 32), off, 64);
@@ -34,33 +34,33 @@ __device__ inline long long wave_sum_i64(long long v) {
 }
 // number of set bits of a wave-uniform mask below this lane (the rank of the lane among the set
 // lanes): v_mbcnt_lo/hi, no per-lane mask register needed
-__device__ inline int rank_below(uint64_t m) {
+__device__ __forceinline__ int rank_below(uint64_t m) {
   return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
-__device__ inline uint64_t lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
-__device__ inline uint64_t bcast_u64(uint64_t v, int src) {
+__device__ __forceinline__ uint64_t lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
+__device__ __forceinline__ uint64_t bcast_u64(uint64_t v, int src) {
   uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, src);
   uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), src);
   return ((uint64_t)hi << 32) | lo;
 }
 template <typename K>
-__device__ inline K bcast_key(K v, int src);
+__device__ __forceinline__ K bcast_key(K v, int src);
 template <>
-__device__ inline uint32_t bcast_key<uint32_t>(uint32_t v, int src) {
+__device__ __forceinline__ uint32_t bcast_key<uint32_t>(uint32_t v, int src) {
   return __builtin_amdgcn_readlane(v, src);
 }
 template <>
-__device__ inline uint64_t bcast_key<uint64_t>(uint64_t v, int src) {
+__device__ __forceinline__ uint64_t bcast_key<uint64_t>(uint64_t v, int src) {
   return bcast_u64(v, src);
 }
 template <typename K>
-__device__ inline K uniform_key(K v);
+__device__ __forceinline__ K uniform_key(K v);
 template <>
-__device__ inline uint32_t uniform_key<uint32_t>(uint32_t v) {
+__device__ __forceinline__ uint32_t uniform_key<uint32_t>(uint32_t v) {
   return __builtin_amdgcn_readfirstlane(v);
 }
 template <>
-__device__ inline uint64_t uniform_key<uint64_t>(uint64_t v) {
+__device__ __forceinline__ uint64_t uniform_key<uint64_t>(uint64_t v) {
   uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
   uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
   return ((uint64_t)hi << 32) | lo;
@@ -72,21 +72,21 @@ __device__ inline uint64_t uniform_key<uint64_t>(uint64_t v) {
 #define PCT_XXPRIME_1 11400714785074694791ULL
 #define PCT_XXPRIME_2 14029467366897019727ULL
 #define PCT_XXPRIME_5 2870177450012600261ULL
-__device__ inline uint64_t tuplehash_begin() { return PCT_XXPRIME_5; }
-__device__ inline uint64_t tuplehash_lane(uint64_t acc, uint64_t lane) {
+__device__ __forceinline__ uint64_t tuplehash_begin() { return PCT_XXPRIME_5; }
+__device__ __forceinline__ uint64_t tuplehash_lane(uint64_t acc, uint64_t lane) {
   acc += lane * PCT_XXPRIME_2;
   acc = (acc << 31) | (acc >> 33);
   acc *= PCT_XXPRIME_1;
   return acc;
 }
-__device__ inline uint64_t tuplehash_end(uint64_t acc, uint64_t len) {
+__device__ __forceinline__ uint64_t tuplehash_end(uint64_t acc, uint64_t len) {
   acc += len ^ (PCT_XXPRIME_5 ^ 3527539ULL);
   if (acc == (uint64_t)-1) return 1546275796ULL;
   return acc;
 }
-__device__ inline uint64_t tuplehash_end6(uint64_t acc) { return tuplehash_end(acc, 6ULL); }
+__device__ __forceinline__ uint64_t tuplehash_end6(uint64_t acc) { return tuplehash_end(acc, 6ULL); }
 // hash(int) as the tuple hash sees it: the value itself (two's complement), except hash(-1) == -2
-__device__ inline uint64_t pyhash_int(int v) { return v == -1 ? (uint64_t)(int64_t)-2 : (uint64_t)(int64_t)v; }
+__device__ __forceinline__ uint64_t pyhash_int(int v) { return v == -1 ? (uint64_t)(int64_t)-2 : (uint64_t)(int64_t)v; }
 
 // ----------------------------------------------------------------------------------------
 // CPython set emulation, wave-parallel and exact.
@@ -110,8 +110,8 @@ template <>
 struct SlotWord<uint64_t> {
   static constexpr uint64_t EMPTY = ~0ull, TAG = 1ull << 63;
 };
-__device__ inline uint32_t lds_atomic_min(uint32_t* p, uint32_t v) { return atomicMin(p, v); }
-__device__ inline uint64_t lds_atomic_min(uint64_t* p, uint64_t v) {
+__device__ __forceinline__ uint32_t lds_atomic_min(uint32_t* p, uint32_t v) { return atomicMin(p, v); }
+__device__ __forceinline__ uint64_t lds_atomic_min(uint64_t* p, uint64_t v) {
   return (uint64_t)atomicMin(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v);
 }
 
@@ -121,12 +121,12 @@ __device__ inline uint64_t lds_atomic_min(uint64_t* p, uint64_t v) {
 // (agent-scope relaxed atomics) because a vector L1 line is not refreshed by this wave's own
 // atomics.
 template <bool GT, typename K>
-__device__ inline K tab_ld(const K* p) {
+__device__ __forceinline__ K tab_ld(const K* p) {
   if (GT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return *p;
 }
 template <bool GT, typename K>
-__device__ inline void tab_st(K* p, K v) {
+__device__ __forceinline__ void tab_st(K* p, K v) {
   if (GT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   else *p = v;
 }
@@ -135,12 +135,12 @@ struct Walk {  // position on a key's probe path: slot = i + j
   uint32_t i;
   int j;
   uint64_t perturb;
-  __device__ inline void start(uint64_t hash, uint32_t mask) {
+  __device__ __forceinline__ void start(uint64_t hash, uint32_t mask) {
     perturb = hash;
     i = (uint32_t)hash & mask;
     j = 0;
   }
-  __device__ inline void next(uint32_t mask) {
+  __device__ __forceinline__ void next(uint32_t mask) {
     int probes = (i + 9u <= mask) ? 9 : 0;
     if (j < probes) {
       j++;
@@ -153,7 +153,7 @@ struct Walk {  // position on a key's probe path: slot = i + j
 };
 
 // One step along a probe path, without branches: the next linear probe, or the next perturbed jump
-__device__ inline void walk_advance(uint32_t& i, int& j, uint64_t& perturb, uint32_t mask) {
+__device__ __forceinline__ void walk_advance(uint32_t& i, int& j, uint64_t& perturb, uint32_t mask) {
   const bool lin = j < ((i + 9u <= mask) ? 9 : 0);
   const uint64_t pn = perturb >> 5;
   const uint32_t in = (i * 5u + 1u + (uint32_t)pn) & mask;
@@ -168,7 +168,7 @@ __device__ inline void walk_advance(uint32_t& i, int& j, uint64_t& perturb, uint
 // runs as many iterations as its longest walk and an iteration is a handful of selects around one
 // LDS read.  All 64 lanes must call; a lane without a key passes active = false.
 template <typename K, bool GT = false, typename Same>
-__device__ inline bool pyset_contains(const K* tab, uint32_t mask, uint64_t hash, bool active, Same same,
+__device__ __forceinline__ bool pyset_contains(const K* tab, uint32_t mask, uint64_t hash, bool active, Same same,
                                       int* probes = nullptr) {
   uint32_t i = (uint32_t)hash & mask;
   int j = 0;
@@ -193,7 +193,7 @@ __device__ inline bool pyset_contains(const K* tab, uint32_t mask, uint64_t hash
 // TAG|lane in tab[slot]; a participating lane that is not placed found its key already in the
 // table (check_found).  All 64 lanes must call.
 template <typename K, bool GT = false, typename Same>
-__device__ inline void pyset_match(K* tab, uint32_t mask, bool part, uint64_t hash, int lane, bool check_found,
+__device__ __forceinline__ void pyset_match(K* tab, uint32_t mask, bool part, uint64_t hash, int lane, bool check_found,
                                    bool& placed, uint32_t& slot, Same same, int* stats = nullptr) {
   const K TAG = SlotWord<K>::TAG;
   const K mytag = TAG | (K)lane;
@@ -279,7 +279,7 @@ __device__ inline void pyset_match(K* tab, uint32_t mask, bool part, uint64_t ha
 // the later lane and all its potential duplicates (same hash, hence same bucket in every round)
 // stay for the next round, which uses other hash bits.  `dd` = NB words of LDS, all ones.
 template <int NB, typename SameAs>
-__device__ inline bool batch_find_duplicates(uint32_t* dd, bool active, uint64_t hash, int lane, int cnt,
+__device__ __forceinline__ bool batch_find_duplicates(uint32_t* dd, bool active, uint64_t hash, int lane, int cnt,
                                              SameAs same_as) {
   bool unresolved = active, dup = false;
   for (int round = 0; round < 8; round++) {
@@ -309,7 +309,7 @@ __device__ inline bool batch_find_duplicates(uint32_t* dd, bool active, uint64_t
 // Same as batch_find_duplicates, but the earlier lane's hash and payload (e.g. a generator id the key can be
 // rebuilt from) come over cross-lane shuffles instead of an LDS copy of the batch: `same(hash_w, payload_w)`.
 template <int NB, typename Same>
-__device__ inline bool batch_find_duplicates_shfl(uint32_t* dd, bool active, uint64_t hash, uint32_t payload, int lane,
+__device__ __forceinline__ bool batch_find_duplicates_shfl(uint32_t* dd, bool active, uint64_t hash, uint32_t payload, int lane,
                                                   Same same) {
   bool unresolved = active, dup = false;
   for (int round = 0; round < 8; round++) {
@@ -345,13 +345,13 @@ __device__ inline bool batch_find_duplicates_shfl(uint32_t* dd, bool active, uin
 }
 
 template <typename K>
-__device__ inline K shfl_key(K v, int src);
+__device__ __forceinline__ K shfl_key(K v, int src);
 template <>
-__device__ inline uint32_t shfl_key<uint32_t>(uint32_t v, int src) {
+__device__ __forceinline__ uint32_t shfl_key<uint32_t>(uint32_t v, int src) {
   return (uint32_t)__shfl((int)v, src, 64);
 }
 template <>
-__device__ inline uint64_t shfl_key<uint64_t>(uint64_t v, int src) {
+__device__ __forceinline__ uint64_t shfl_key<uint64_t>(uint64_t v, int src) {
   uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, 64);
   uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64);
   return ((uint64_t)hi << 32) | lo;
@@ -360,7 +360,7 @@ __device__ inline uint64_t shfl_key<uint64_t>(uint64_t v, int src) {
 // Same, for keys that fit a register: the minimum lane's key is fetched with a cross-lane
 // shuffle instead of an LDS copy of the batch.
 template <int NB, typename K>
-__device__ inline bool batch_find_duplicates_reg(uint32_t* dd, bool active, K key, uint64_t hash, int lane) {
+__device__ __forceinline__ bool batch_find_duplicates_reg(uint32_t* dd, bool active, K key, uint64_t hash, int lane) {
   bool unresolved = active, dup = false;
   for (int round = 0; round < 9; round++) {
     if (!__ballot(unresolved)) return dup;
@@ -394,7 +394,7 @@ __device__ inline bool batch_find_duplicates_reg(uint32_t* dd, bool active, K ke
 // first in insertion order, then slice 1, ...  LDS tables only (integer keys compared by value).
 // ----------------------------------------------------------------------------------------
 template <int V>
-__device__ inline bool any_of(const bool (&b)[V]) {
+__device__ __forceinline__ bool any_of(const bool (&b)[V]) {
   bool a = false;
 #pragma unroll
   for (int v = 0; v < V; v++) a = a || b[v];
@@ -403,7 +403,7 @@ __device__ inline bool any_of(const bool (&b)[V]) {
 
 // Read-only membership test of V keys per lane (no tags may be present): found[v] for active[v] keys.
 template <int V, typename K>
-__device__ inline void pyset_contains_v(const K* tab, uint32_t mask, const uint64_t (&hash)[V], const K (&key)[V],
+__device__ __forceinline__ void pyset_contains_v(const K* tab, uint32_t mask, const uint64_t (&hash)[V], const K (&key)[V],
                                         const bool (&valid)[V], bool (&found)[V], int* probes = nullptr) {
   uint32_t i[V];
   int j[V];
@@ -444,7 +444,7 @@ __device__ inline void pyset_contains_v(const K* tab, uint32_t mask, const uint6
 // `base`: batch position of (0, lane 0) -- the priority of (v, lane) is base + v * 64 + lane (a whole-set matching of more
 // than V * 64 keys runs in passes over one table).
 template <int V, typename K, bool CHECK = false>
-__device__ inline void pyset_match_v(K* tab, uint32_t mask, const bool (&part)[V], const uint64_t (&hash)[V], int lane,
+__device__ __forceinline__ void pyset_match_v(K* tab, uint32_t mask, const bool (&part)[V], const uint64_t (&hash)[V], int lane,
                                      uint32_t (&slot)[V], int* stats = nullptr, const K* key = nullptr,
                                      bool* placed_out = nullptr, uint32_t base = 0) {
   const K TAG = SlotWord<K>::TAG;
@@ -518,7 +518,7 @@ __device__ inline void pyset_match_v(K* tab, uint32_t mask, const bool (&part)[V
 // duplicate, different -> both stay for the next round, which uses other hash bits); the key of a position
 // comes over a cross-lane shuffle of the slice it lives in.  `dd` = NB words of LDS, all ones.
 template <int V, int NB, typename K>
-__device__ inline void batch_find_duplicates_v(uint32_t* dd, const bool (&active)[V], const K (&key)[V],
+__device__ __forceinline__ void batch_find_duplicates_v(uint32_t* dd, const bool (&active)[V], const K (&key)[V],
                                                const uint64_t (&hash)[V], int lane, bool (&dup)[V]) {
   bool unresolved[V];
 #pragma unroll
@@ -571,7 +571,7 @@ __device__ inline void batch_find_duplicates_v(uint32_t* dd, const bool (&active
 // Tables of a set with capacity `cap` in ONE LDS region: every size up to 2048 slots starts at
 // offset 0 (a rebuild first lifts the <= 512 old slots into registers, then reuses the space);
 // only a final table larger than 2048 slots lives behind the quarter-size region it grows from.
-__device__ inline uint32_t table_offset_compact(uint32_t cap, uint32_t size) {
+__device__ __forceinline__ uint32_t table_offset_compact(uint32_t cap, uint32_t size) {
   return (cap > 2048u && size == cap) ? cap / 4u : 0u;
 }
 __device__ __host__ inline uint32_t table_words_compact(uint32_t cap) { return cap > 2048u ? cap + cap / 4u : cap; }
@@ -580,7 +580,7 @@ __device__ __host__ inline uint32_t table_words_compact(uint32_t cap) { return c
 // old -> new without a temporary): cap in region 0, cap/4 in region 1, cap/16 in 0, ...
 // Returned as a slot OFFSET from tab0 (tab1 follows tab0 in LDS) so that every table access
 // stays a plain LDS access off one base pointer.
-__device__ inline uint32_t table_region(uint32_t cap, uint32_t size) {
+__device__ __forceinline__ uint32_t table_region(uint32_t cap, uint32_t size) {
   int lv = 0;
   while (size < cap) {
     size <<= 2;
@@ -594,13 +594,13 @@ __device__ inline uint32_t table_region(uint32_t cap, uint32_t size) {
 // The untimed specialisation is empty, so production kernels carry no extra registers.
 template <bool ON>
 struct PhaseTimer {
-  __device__ inline void start() {}
-  __device__ inline void tick(int) {}
-  __device__ inline void flush(unsigned long long*, int) {}
-  __device__ inline void sub_start() {}
-  __device__ inline void sub_tick(int) {}
-  __device__ inline void add(int, uint64_t) {}
-  __device__ inline uint64_t now() { return 0; }
+  __device__ __forceinline__ void start() {}
+  __device__ __forceinline__ void tick(int) {}
+  __device__ __forceinline__ void flush(unsigned long long*, int) {}
+  __device__ __forceinline__ void sub_start() {}
+  __device__ __forceinline__ void sub_tick(int) {}
+  __device__ __forceinline__ void add(int, uint64_t) {}
+  __device__ __forceinline__ uint64_t now() { return 0; }
   static constexpr bool on = false;
 };
 template <>
@@ -608,25 +608,25 @@ struct PhaseTimer<true> {
   static constexpr bool on = true;
   uint64_t last;
   uint64_t acc[PCT_TIMING_SLOTS];
-  __device__ inline void add(int i, uint64_t v) { acc[i] += v; }  // plain statistics (slots 12..)
-  __device__ inline uint64_t now() { return __builtin_readcyclecounter(); }
-  __device__ inline void start() {
+  __device__ __forceinline__ void add(int i, uint64_t v) { acc[i] += v; }  // plain statistics (slots 12..)
+  __device__ __forceinline__ uint64_t now() { return __builtin_readcyclecounter(); }
+  __device__ __forceinline__ void start() {
     for (int i = 0; i < PCT_TIMING_SLOTS; i++) acc[i] = 0;
     last = __builtin_readcyclecounter();
   }
-  __device__ inline void tick(int i) {
+  __device__ __forceinline__ void tick(int i) {
     uint64_t now = __builtin_readcyclecounter();
     acc[i] += now - last;
     last = now;
   }
   uint64_t sub_last;
-  __device__ inline void sub_start() { sub_last = __builtin_readcyclecounter(); }
-  __device__ inline void sub_tick(int i) {
+  __device__ __forceinline__ void sub_start() { sub_last = __builtin_readcyclecounter(); }
+  __device__ __forceinline__ void sub_tick(int i) {
     uint64_t now = __builtin_readcyclecounter();
     acc[i] += now - sub_last;
     sub_last = now;
   }
-  __device__ inline void flush(unsigned long long* o, int n_steps) {
+  __device__ __forceinline__ void flush(unsigned long long* o, int n_steps) {
     for (int i = 0; i < PCT_TIMING_SLOTS; i++)
       if (i != 7) o[i] += acc[i];
     o[7] += (unsigned long long)n_steps;

@@ -433,11 +433,13 @@ PCT_SD void stab_split_fixed(const double (*c2)[2], const double stk[4], double 
 struct StabSplit {
   int mode, direct;
   double f[5];
-  double fx[STAB_LSQ];  // k > 5 only (a run-time indexed private array: scratch memory, 0.01 % of the splits)
   bool ill;
 };
+// the fractions of a split over more than five supporters (0.01 % of them) live in a run-time indexed private array --
+// scratch memory -- kept OUT of StabSplit so that the struct itself stays in registers
+struct StabSplitX { double fx[STAB_LSQ]; };
 template <bool CONT, typename Geo, typename Sup>
-PCT_SD bool stab_split(const Geo& geo, const double bg[9], int k, const Sup& sup, const double stk[4], StabSplit& sp) {
+PCT_SD bool stab_split(const Geo& geo, const double bg[9], int k, const Sup& sup, const double stk[4], StabSplit& sp, StabSplitX& sx) {
   sp.mode = 0; sp.direct = -1; sp.ill = false;
 #pragma unroll
   for (int i = 0; i < 5; i++) sp.f[i] = 0;
@@ -515,14 +517,14 @@ PCT_SD bool stab_split(const Geo& geo, const double bg[9], int k, const Sup& sup
     }
   for (int j = 0; j < k; j++) A[(M - 1) * k + j] = 1;
   rhs[M - 1] = 1;
-  stab_lstsq(A, rhs, M, k, sp.fx, sp.ill);
+  stab_lstsq(A, rhs, M, k, sx.fx, sp.ill);
   return true;
 }
 // the share supporter i receives.  `own_centre`: the box's own centre, which the VIRTUAL flavour puts into the zero-mass
 // shares of a direct split (the commit uses the stack's centre there)
 template <bool CONT, typename Geo, typename Sup>
 PCT_SD void stab_share_of(const Geo& geo, const double bg[9], int k, const Sup& sup, const double stk[4],
-                          const double own_centre[3], bool virtual_, const StabSplit& sp, int i, double out[4]) {
+                          const double own_centre[3], bool virtual_, const StabSplit& sp, const StabSplitX& sx, int i, double out[4]) {
   if (sp.mode == 0 || (sp.mode == 1 && i == sp.direct)) {
     out[0] = stk[0]; out[1] = stk[1]; out[2] = stk[2]; out[3] = stk[3];
     return;
@@ -539,7 +541,7 @@ PCT_SD void stab_share_of(const Geo& geo, const double bg[9], int k, const Sup& 
   f = i == 2 ? sp.f[2] : f;
   f = i == 3 ? sp.f[3] : f;
   f = i == 4 ? sp.f[4] : f;
-  if (k > 5) f = sp.fx[i];
+  if (k > 5) f = sx.fx[i];
   out[0] = (a[0] + a[2]) / 2;
   out[1] = (a[1] + a[3]) / 2;
   out[2] = stk[2];
@@ -584,12 +586,13 @@ template <bool CONT, typename Geo, typename Emit>
 PCT_SD bool stab_children(const Geo& geo, const StabState& st, const double bg[9], int k, const StabSup& sup, const double stk[4],
                           int skip, bool& ill, Emit emit) {
   StabSplit sp;
-  if (!stab_split<CONT>(geo, bg, k, sup, stk, sp)) return false;
+  StabSplitX sx;
+  if (!stab_split<CONT>(geo, bg, k, sup, stk, sp, sx)) return false;
   ill = ill || sp.ill;
   const double own[3] = {bg[0] + bg[6] / 2, bg[1] + bg[7] / 2, bg[2] + bg[8] / 2};
   for (int i = 0; i < k; i++) {
     double share[4], child[4];
-    stab_share_of<CONT>(geo, bg, k, sup, stk, own, true, sp, i, share);
+    stab_share_of<CONT>(geo, bg, k, sup, stk, own, true, sp, sx, i, share);
     const int Si = sup(i);
     stab_com(geo, st, Si, skip, share, child);
     emit(Si, child);
@@ -800,7 +803,7 @@ __device__ __forceinline__ bool stab_virtual_wave(const Geo& geo, const StabStat
     }
     while (true) {
       if (have) {
-        auto emit = [&](int Si, const double child[4]) {
+        auto emit = [&](int Si, const double child[4]) __attribute__((always_inline)) {
           const uint32_t pos = atomicAdd(&w.ctl[0], 1u);
           if (pos < (uint32_t)w.qcap) {
             w.qmeta[pos] = (uint32_t)cl | ((uint32_t)Si << 6);
@@ -1000,14 +1003,15 @@ PCT_SD int stab_commit(const Geo& geo, StabState& st, int n, double density, uns
       double g[9];
       geo(id, g);
       StabSplit sp;
-      if (!stab_split<CONT>(geo, g, kk, sup, stk, sp)) return -1;
+      StabSplitX sx;
+      if (!stab_split<CONT>(geo, g, kk, sup, stk, sp, sx)) return -1;
       ill = ill || sp.ill;
       const int alias_k = sp.mode == 0 ? 0 : (sp.mode == 1 ? sp.direct : -1);
       st.meta[2 * id] = (st.meta[2 * id] & 0xFFFF00FFu) | ((uint32_t)(alias_k + 1) << 8);
       const double own[3] = {stk[0], stk[1], stk[2]};
       for (int i = 0; i < kk; i++) {
         double sh[4];
-        stab_share_of<CONT>(geo, g, kk, sup, stk, own, false, sp, i, sh);
+        stab_share_of<CONT>(geo, g, kk, sup, stk, own, false, sp, sx, i, sh);
         double* e = st.share + (size_t)(stab_soff(st, id) + i) * 4;
         e[0] = sh[0]; e[1] = sh[1]; e[2] = sh[2]; e[3] = sh[3];
         const int Si = sup(i);

@@ -58,6 +58,7 @@ def lib():
         L.pcto_set_numpy_item_count.argtypes = [vp, ctypes.c_int32]
         L.pcto_set_shuffle_seed.argtypes = [vp, ctypes.c_uint64]
         L.pcto_step_heuristic.argtypes = [vp, ctypes.c_int32, ctypes.c_int32]
+        L.pcto_ill_conditioned.argtypes = [vp, vp]
         L.pcto_set_density_stream.argtypes = [vp, vp, ctypes.c_int64]
         L.pcto_set_dataset_density.argtypes = [vp, vp]
         for name in ("pcto_obs", "pcto_reward", "pcto_done", "pcto_info_counter", "pcto_info_ratio",
@@ -154,6 +155,13 @@ class OracleVecEnv(object):
 
     def step_heuristic(self, kind, n_steps=1):
         self._check(lib().pcto_step_heuristic(self._h, int(kind), int(n_steps)))
+
+    def ill_conditioned(self):
+        """bool [N]: the env has taken a least-squares split whose rank decision lay within a factor 1000 of the cut
+        (sticky; what the product reports as PCT_FLAG_ILL_CONDITIONED)"""
+        out = np.zeros(self.N, np.uint8)
+        self._check(lib().pcto_ill_conditioned(self._h, out.ctypes.data))
+        return out.astype(bool)
 
     def set_sampler(self, seed):
         self._check(lib().pcto_set_sampler(self._h, seed))

@@ -1034,6 +1034,16 @@ uint8_t* pcto_done(pcto_env* h) { return h->done; }
 int32_t* pcto_info_counter(pcto_env* h) { return h->counter; }
 double* pcto_info_ratio(pcto_env* h) { return h->ratio; }
 uint32_t* pcto_error_flags(pcto_env* h) { return h->flags; }
+void pcto_set_ill_near(int on) { stab_set_ill_near(on); } /* analysis mode of the notice, see pct_oracle_stab.c */
+/* out[e] = 1 iff env e has taken an ill-conditioned least-squares split so far (the product's PCT_FLAG_ILL_CONDITIONED) */
+int pcto_ill_conditioned(pcto_env* h, uint8_t* out) {
+  if (!h || !out) return fail(PCT_ERR_INVALID_ARG, "null argument");
+  for (int e = 0; e < h->N; e++) {
+    const struct stab* st = h->cfg.env_kind == PCT_ENV_CONTINUOUS ? pctc_stab(h, e) : h->envs[e].stab;
+    out[e] = (st && stab_ill_conditioned(st)) ? 1 : 0;
+  }
+  return PCT_OK;
+}
 
 static int ready(const pcto_env* h) {
   if (!h) return fail(PCT_ERR_INVALID_ARG, "null handle");

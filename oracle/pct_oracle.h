@@ -51,6 +51,8 @@ uint8_t* pcto_done(pcto_env* env);    /* [N] */
 int32_t* pcto_info_counter(pcto_env* env);
 double* pcto_info_ratio(pcto_env* env);
 uint32_t* pcto_error_flags(pcto_env* env);
+void pcto_set_ill_near(int on); /* analysis only: also note decisions within 1e-9 of a tie on stacks carrying a least-squares share */
+int pcto_ill_conditioned(pcto_env* env, uint8_t* out); /* [N] sticky notice of the stability settings (PCT_FLAG_ILL_CONDITIONED) */
 
 int pcto_reset(pcto_env* env, const int32_t* env_ids, int32_t n);
 /* auto_reset != 0: VecEnv worker semantics (shmem_vec_env.py:139-143) -- a done env is

@@ -688,6 +688,7 @@ void pctc_giveup(struct pcto_env* h, int e) {
 }
 
 uint32_t pctc_t(const struct pcto_env* h, int e) { return h->cenvs[e].t; }
+const struct stab* pctc_stab(const struct pcto_env* h, int e) { return h->cenvs[e].stab; }
 
 int pctc_alloc(struct pcto_env* h) {
   for (int d = 0; d < 3; d++)

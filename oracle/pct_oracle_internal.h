@@ -129,6 +129,8 @@ static inline double pcto_next_density(const struct pcto_env* h, int e, uint64_t
 struct stab* stab_create(int cap, double eps);
 void stab_reset(struct stab* s);
 void stab_free(struct stab* s);
+int stab_ill_conditioned(const struct stab* s); /* sticky notice, see pct_oracle_stab.c */
+void stab_set_ill_near(int on);
 int stab_check(struct stab* s, double x, double y, double z, double lx, double ly, double max_h, double density,
                int virtual_);
 
@@ -139,6 +141,7 @@ void pctc_reset(struct pcto_env* h, int e, double* obs);
 void pctc_step(struct pcto_env* h, int e, const double* act, int len, double* obs, double* reward, uint8_t* done,
                int32_t* counter, double* ratio, uint32_t* flags);
 uint32_t pctc_t(const struct pcto_env* h, int e);
+const struct stab* pctc_stab(const struct pcto_env* h, int e);
 int pctc_heur_choose(const struct pcto_env* h, int e, int kind, double* olx, double* oly, double* ox, double* oy, double* oz);
 void pctc_step_place(struct pcto_env* h, int e, double lx, double ly, double x, double y, double z, double* obs);
 void pctc_giveup(struct pcto_env* h, int e);

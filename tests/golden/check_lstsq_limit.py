@@ -81,35 +81,40 @@ def jacobi_lstsq(A, b):
     return x.reshape(-1, 1)
 
 
-MODE = {"jacobi": False, "maxdiff": 0.0}
-_counting = np.linalg.lstsq  # gen_golden's counting wrapper around LAPACK
+def main():
+    MODE = {"jacobi": False, "maxdiff": 0.0}
+    _counting = np.linalg.lstsq  # gen_golden's counting wrapper around LAPACK
 
 
-def switchable(A, b, rcond=None):
-    r = _counting(A, b, rcond=rcond)
-    x2 = jacobi_lstsq(A, b)
-    MODE["maxdiff"] = max(MODE["maxdiff"], float(np.abs(r[0] - x2).max()))
-    return ((x2,) + tuple(r[1:])) if MODE["jacobi"] else r
+    def switchable(A, b, rcond=None):
+        r = _counting(A, b, rcond=rcond)
+        x2 = jacobi_lstsq(A, b)
+        MODE["maxdiff"] = max(MODE["maxdiff"], float(np.abs(r[0] - x2).max()))
+        return ((x2,) + tuple(r[1:])) if MODE["jacobi"] else r
 
 
-np.linalg.lstsq = switchable
-for label, jac in (("A. unmodified reference (LAPACK gelsd) vs oracle", False),
-                   ("B. reference with the oracle's Jacobi solve patched in vs oracle", True)):
-    MODE["jacobi"] = jac
-    print(label)
-    runs = div = steps = calls = 0
-    for name in ("discrete_s1_flat_lstsq", "discrete_s3_flat_lstsq"):
-        for seed in range(61, 69):
-            case = dict(g.CASES[name], seed=seed)
-            g.LSTSQ["calls"] = 0
-            ref = g.run_reference(case)
-            ora = g.run_oracle(case, ref["stream"], ref["density"])
-            bad = np.argwhere(ref["obs"] != ora["obs"])
-            per_env = [int(bad[bad[:, 1] == e][:, 0].min()) if (bad[:, 1] == e).any() else -1 for e in range(case["N"])]
-            runs += case["N"]
-            div += sum(1 for x in per_env if x >= 0)
-            steps += sum((x if x >= 0 else case["steps"]) for x in per_env)
-            calls += g.LSTSQ["calls"]
-            print("  %-24s seed %d: %5d lstsq calls, first divergence per env %s" % (name, seed, g.LSTSQ["calls"], per_env), flush=True)
-    print("  => %d env-runs, %d parted ways, %d env-steps identical, %d lstsq calls; max |gelsd - Jacobi| over all solves %.2e"
-          % (runs, div, steps, calls, MODE["maxdiff"]), flush=True)
+    np.linalg.lstsq = switchable
+    for label, jac in (("A. unmodified reference (LAPACK gelsd) vs oracle", False),
+                       ("B. reference with the oracle's Jacobi solve patched in vs oracle", True)):
+        MODE["jacobi"] = jac
+        print(label)
+        runs = div = steps = calls = 0
+        for name in ("discrete_s1_flat_lstsq", "discrete_s3_flat_lstsq"):
+            for seed in range(61, 69):
+                case = dict(g.CASES[name], seed=seed)
+                g.LSTSQ["calls"] = 0
+                ref = g.run_reference(case)
+                ora = g.run_oracle(case, ref["stream"], ref["density"])
+                bad = np.argwhere(ref["obs"] != ora["obs"])
+                per_env = [int(bad[bad[:, 1] == e][:, 0].min()) if (bad[:, 1] == e).any() else -1 for e in range(case["N"])]
+                runs += case["N"]
+                div += sum(1 for x in per_env if x >= 0)
+                steps += sum((x if x >= 0 else case["steps"]) for x in per_env)
+                calls += g.LSTSQ["calls"]
+                print("  %-24s seed %d: %5d lstsq calls, first divergence per env %s" % (name, seed, g.LSTSQ["calls"], per_env), flush=True)
+        print("  => %d env-runs, %d parted ways, %d env-steps identical, %d lstsq calls; max |gelsd - Jacobi| over all solves %.2e"
+              % (runs, div, steps, calls, MODE["maxdiff"]), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -64,6 +64,7 @@ void stab_free(struct stab* s) {
 }
 int stab_overflowed(struct stab* s) { return s->overflow; }
 int stab_ill_conditioned(struct stab* s) { return s->ill; }
+void stab_set_ill_near(int) {}  // (the tie notice is an analysis mode of the oracle only)
 
 int stab_check(struct stab* s, double x, double y, double z, double lx, double ly, double max_h, double density,
                int virtual_) {

@@ -636,3 +636,31 @@ def test_hip_continuous_heuristics_match_oracle_batched(heur, setting):
         assert np.array_equal(env._h_counter.numpy(), ora.counter), t
     assert not env.error_flags.any()
     env.close()
+
+
+@pytest.mark.gpu
+def test_hip_notice_precedes_the_lapack_divergence():
+    """on the adversarial stream whose env 0 meets a rank decision at the least-squares cut (the
+    unmodified reference's trajectory is LAPACK dgelsd's from step 79 on; tests/golden/check_ill_notice.py), the kernels
+    equal the reference before that step and on the other envs throughout, part ways exactly there, and have raised the
+    non-fatal PCT_FLAG_ILL_CONDITIONED on that env -- and only on it -- no later than that step; no error flag."""
+    c, z = load_case("discrete_s1_flat_diverging")
+    env = _pkg().PctVecEnv(c["N"], setting=c["setting"], container_size=c["container"], item_set=case_items(c),
+                           internal_node_holder=c["I"], leaf_node_holder=c["L"], env_id_base=c["base"], item_stream=z["stream"],
+                           device="cuda:0")
+    obs = env.reset()
+    div = z["first_divergence"]
+    alive = np.ones(c["N"], bool)
+    for t in range(c["steps"]):
+        bad = (obs.cpu().numpy() != z["obs"][t]).any(1)
+        ill = env.ill_conditioned
+        for e in range(c["N"]):
+            if alive[e] and bad[e]:
+                assert t == div[e] and ill[e], (e, t)
+                alive[e] = False
+        env.step_hash_policy(1)
+        obs, _, _, _ = env.step_wait()
+    assert list(alive) == [False, True, True, True]
+    assert list(env.ill_conditioned) == [True, False, False, False]
+    assert not env.error_flags.any()
+    env.close()

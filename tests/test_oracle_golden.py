@@ -274,3 +274,30 @@ def test_oracle_continuous_heuristics_match_reference_loops(name, heur):
     assert np.array_equal(np.array(length, np.int32), z["len_" + heur])
     assert not env.flags.any()
     env.close()
+
+
+def test_oracle_notice_precedes_the_lapack_divergence():
+    """tests/golden/discrete_s1_flat_diverging.npz is the UNMODIFIED reference on the one adversarial stream (seed 66) whose
+    env 0 meets a least-squares system with a rank decision at the cut (sigma_max 1.1e15, smallest kept singular value
+    1.97 x the rcond cut): from step 79 on the reference's trajectory is LAPACK dgelsd's.  The oracle must equal the
+    reference before that step and on every other env throughout, and its notice (the product's
+    PCT_FLAG_ILL_CONDITIONED) must be up on env 0 no later than that step and on no other env."""
+    c, z = load_case("discrete_s1_flat_diverging")
+    env = OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"], item_set=case_items(c),
+                       internal_node_holder=c["I"], leaf_node_holder=c["L"], env_id_base=c["base"])
+    env.set_item_stream(z["stream"])
+    env.reset()
+    div = z["first_divergence"]
+    assert list(div) == [79, -1, -1, -1]
+    alive = np.ones(c["N"], bool)
+    for t in range(c["steps"]):
+        bad = (env.obs.astype(np.float32) != z["obs"][t]).any(1)
+        ill = env.ill_conditioned()
+        for e in range(c["N"]):
+            if alive[e] and bad[e]:
+                assert t == div[e] and ill[e], (e, t)  # parts ways exactly where recorded, with the notice already up
+                alive[e] = False
+        env.step_hash_policy(1)
+    assert list(alive) == [False, True, True, True]
+    assert list(env.ill_conditioned()) == [True, False, False, False]
+    env.close()
