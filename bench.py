@@ -73,7 +73,7 @@ WORKLOADS = {
                metric="env-steps/sec (whole node), continuous setting 2, 80 internal/50 leaf",
                what="PctContinuous0 setting 2, bin 10x10x10, 80 internal / 50 leaf, %d batched envs per MI355X "
                     "(BASELINE.json configs[2]); item sizes round(U(1,5),3) from the on-device counter sampler; float64 kernel"),
-    "c5": dict(cont=True, setting=2, container=(100, 100, 100), I=200, L=200, envs=2048, bounds=(5.0, 25.0), ref=None,
+    "c5": dict(cont=True, setting=2, container=(100, 100, 100), I=200, L=200, envs=2048, bounds=(5.0, 25.0), ref="continuous_c5_shmem",
                metric="env-steps/sec (whole node), continuous setting 2, 100^3 bin, 200 internal/200 leaf",
                what="PctContinuous0 setting 2, bin 100^3, 200 internal / 200 leaf, %d batched envs per MI355X (the per-GPU "
                     "slice of BASELINE.json configs[4]); item sizes round(U(5,25),3) (SURVEY.md 8(d))"),

@@ -8,7 +8,8 @@ The unmodified reference is imported under tests/golden/ref_shim.py (stub gym, N
 is the same stand-in as everywhere else -- leaf = mix32(env, t) % (number of valid leaves), computed on the
 host from the observation the VecEnv returned (SURVEY.md 8(d) CPU baseline timing (i), (ii)).
 
-    PYTHONDONTWRITEBYTECODE=1 python scripts/time_reference_cpu.py [seconds-per-config] [workers]
+    PYTHONDONTWRITEBYTECODE=1 python scripts/time_reference_cpu.py [seconds-per-config] [workers] [only-config ...]
+(with config names given, only those are timed and merged into the existing JSON)
 """
 import json
 import os
@@ -42,16 +43,17 @@ from wrapper.dummy_vec_env import DummyVecEnv  # noqa: E402
 I, L = 80, 50
 
 
-def args_for(kind, setting, nproc):
+def args_for(kind, setting, nproc, container=None, bounds=(1.0, 5.0), holders=None):
     cont = kind == "continuous"
+    Ih, Lh = holders or (I, L)
     return SimpleNamespace(
         id="PctContinuous-v0" if cont else "PctDiscrete-v0", seed=4, num_processes=nproc, device=torch.device("cpu"),
-        setting=setting, container_size=givenData.container_size, item_size_set=givenData.item_size_set,
-        dataset_path=None, load_dataset=False, internal_node_holder=I, leaf_node_holder=L, lnes="EMS", shuffle=False,
-        sample_from_distribution=cont, sample_left_bound=1.0 if cont else None, sample_right_bound=5.0 if cont else None)
+        setting=setting, container_size=container or givenData.container_size, item_size_set=givenData.item_size_set,
+        dataset_path=None, load_dataset=False, internal_node_holder=Ih, leaf_node_holder=Lh, lnes="EMS", shuffle=False,
+        sample_from_distribution=cont, sample_left_bound=bounds[0] if cont else None, sample_right_bound=bounds[1] if cont else None)
 
 
-def drive(venv, n, seconds, warm):
+def drive(venv, n, seconds, warm, I=I, L=L):
     obs = venv.reset()
     g = np.arange(n, dtype=np.uint64)
     t = 0
@@ -80,26 +82,36 @@ def drive(venv, n, seconds, warm):
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
     workers = int(sys.argv[2]) if len(sys.argv) > 2 else (os.cpu_count() or 1)
+    only = sys.argv[3:]
+    dst = os.path.join(ROOT, "profiles", "cpu_reference_baseline.json")
     out = {"host": {"cores": os.cpu_count(), "python": sys.version.split()[0], "numpy": np.__version__},
            "recipe": "PYTHONDONTWRITEBYTECODE=1 python scripts/time_reference_cpu.py %g %d (build container; the unmodified "
                      "reference under tests/golden/ref_shim.py; torch.set_num_threads(1), OMP_NUM_THREADS=1)" % (seconds, workers),
            "configs": {}}
-    for name, kind, setting in (("discrete_s2_shmem", "discrete", 2), ("continuous_s2_shmem", "continuous", 2)):
-        venv = refenvs.make_vec_envs(args_for(kind, setting, workers), None, True)  # ShmemVecEnv(fork) + VecPyTorch
-        v, it, dt = drive(venv, workers, seconds, warm=100)
+    if only:
+        out = json.load(open(dst))
+    cfgs = (("discrete_s2_shmem", "discrete", 2, {}), ("continuous_s2_shmem", "continuous", 2, {}),
+            # BASELINE configs[4]'s env (C5): 100^3 bin, 200 / 200 nodes, items U(5, 25)
+            ("continuous_c5_shmem", "continuous", 2, dict(container=(100, 100, 100), bounds=(5.0, 25.0), holders=(200, 200))))
+    for name, kind, setting, extra in cfgs:
+        if only and name not in only:
+            continue
+        venv = refenvs.make_vec_envs(args_for(kind, setting, workers, **extra), None, True)  # ShmemVecEnv(fork) + VecPyTorch
+        Ih, Lh = extra.get("holders", (I, L))
+        v, it, dt = drive(venv, workers, seconds, warm=30 if extra else 100, I=Ih, L=Lh)
         venv.close()
         out["configs"][name] = {"value": v, "unit": "env-steps/s", "workers": workers, "iterations": it, "seconds": dt,
                                 "path": "envs.make_vec_envs -> ShmemVecEnv(context='fork') + VecPyTorch(cpu)"}
         print(name, "%.1f env-steps/s (%d workers, %d iterations, %.1f s)" % (v, workers, it, dt), flush=True)
     # BASELINE configs[0]: setting 1, one env under DummyVecEnv
-    a = args_for("discrete", 1, 1)
-    venv = refenvs.VecPyTorch(DummyVecEnv([refenvs.make_env(a.id, a.seed, 0, None, True, a)]), a.device)
-    v, it, dt = drive(venv, 1, seconds, warm=100)
-    venv.close()
-    out["configs"]["discrete_s1_dummy_1env"] = {"value": v, "unit": "env-steps/s", "workers": 1, "iterations": it, "seconds": dt,
-                                                "path": "DummyVecEnv([env]) + VecPyTorch(cpu) (BASELINE configs[0])"}
-    print("discrete_s1_dummy_1env %.1f env-steps/s" % v, flush=True)
-    dst = os.path.join(ROOT, "profiles", "cpu_reference_baseline.json")
+    if not only or "discrete_s1_dummy_1env" in only:
+        a = args_for("discrete", 1, 1)
+        venv = refenvs.VecPyTorch(DummyVecEnv([refenvs.make_env(a.id, a.seed, 0, None, True, a)]), a.device)
+        v, it, dt = drive(venv, 1, seconds, warm=100)
+        venv.close()
+        out["configs"]["discrete_s1_dummy_1env"] = {"value": v, "unit": "env-steps/s", "workers": 1, "iterations": it, "seconds": dt,
+                                                    "path": "DummyVecEnv([env]) + VecPyTorch(cpu) (BASELINE configs[0])"}
+        print("discrete_s1_dummy_1env %.1f env-steps/s" % v, flush=True)
     json.dump(out, open(dst, "w"), indent=1)
     print("wrote", dst)
 
