@@ -197,8 +197,9 @@ int pct_set_dataset_density(pct_env* env, const double* den);
  * item_set[pct_pick(seed, g, c, n)] (discrete) -- see pct_pick below. */
 int pct_set_sampler(pct_env* env, uint64_t seed);
 
-/* Strict NumPy-stream mode (discrete env with LNES = EMS and bins up to 31 per axis, or the continuous env -- see
- * pct_set_numpy_item_count below; before the first reset).  Env e then
+/* Strict NumPy-stream mode (the discrete env with any leaf expansion -- bin3D.py:114-115 shuffles whatever --lnes
+ * produced -- and any bin size, or the continuous env -- see pct_set_numpy_item_count below; before the first reset).
+ * Env e then
  * consumes the MT19937 stream that np.random.seed(seed + env_id_base + e) starts, exactly as the env's worker process
  * does under ShmemVecEnv(fork) (envs.py:49 env.seed(seed + rank); bin3D.py:47-54): the item is
  * item_set[np.random.randint(0, n)] (binCreator.py:37-39), the setting-3 density np.random.random() redrawn while 0

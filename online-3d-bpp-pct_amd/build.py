@@ -11,8 +11,10 @@ import time
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpct_hip.so")
-SOURCES = ["pct_env.hip", "pct_discrete.hip", "pct_discrete_stab.hip", "pct_discrete_u64.hip", "pct_discrete_u64_stab.hip",
-           "pct_continuous.hip", "pct_continuous_mt.hip"]
+# (slowest translation units first: they are handed to the worker pool in this order)
+SOURCES = ["pct_discrete_stab.hip", "pct_discrete_stab_mt.hip", "pct_discrete_u64_stab.hip", "pct_discrete_u64_stab_mt.hip",
+           "pct_continuous.hip", "pct_continuous_mt.hip", "pct_discrete.hip", "pct_discrete_mt.hip", "pct_discrete_u64.hip",
+           "pct_discrete_u64_mt.hip", "pct_env.hip"]
 HEADERS = [os.path.join(CSRC, "pct_device.h"), os.path.join(CSRC, "pct_set.cuh"), os.path.join(CSRC, "pct_stab.cuh"),
            os.path.join(CSRC, "pct_discrete_impl.cuh"), os.path.join(CSRC, "pct_mt.cuh"),
            os.path.join(HERE, "..", "include", "pct_env.h")]
@@ -54,6 +56,10 @@ def build_library(force=False, verbose=False):
             "pct_discrete_stab.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_mt.cuh", "pct_discrete_impl.cuh"],
             "pct_discrete_u64.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_mt.cuh", "pct_discrete_impl.cuh"],
             "pct_discrete_u64_stab.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_mt.cuh", "pct_discrete_impl.cuh"],
+            "pct_discrete_mt.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_mt.cuh", "pct_discrete_impl.cuh"],
+            "pct_discrete_stab_mt.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_mt.cuh", "pct_discrete_impl.cuh"],
+            "pct_discrete_u64_mt.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_mt.cuh", "pct_discrete_impl.cuh"],
+            "pct_discrete_u64_stab_mt.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_mt.cuh", "pct_discrete_impl.cuh"],
             "pct_continuous.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_mt.cuh"],
             "pct_continuous_mt.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_mt.cuh", "pct_continuous.hip"]}
 
@@ -72,7 +78,7 @@ def build_library(force=False, verbose=False):
             print("%s: %.0f s" % (src, time.time() - t0))
         return obj
 
-    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
     if verbose:

@@ -149,7 +149,7 @@ __device__ __forceinline__ CLds carve(const ContinuousParams& p, unsigned char* 
 
 #ifndef PCT_CONT_MT
 size_t continuous_lds_bytes(const ContinuousParams& p) {
-  size_t b = continuous_lds_base_bytes(p);
+  size_t b = PCT_LDS_STASH + continuous_lds_base_bytes(p);
   if (p.setting != 2) b += ((stab_state_bytes(p.I, p.sb.caps) + 15) & ~(size_t)15) + stab_wave_bytes(p.sb.caps);
   return b;
 }
@@ -1177,7 +1177,7 @@ __device__ __forceinline__ int ctransition(const ContinuousParams& p, int e, CLd
 
 #ifndef PCT_CONT_MT
 // ---- heuristic.py on PackingContinuous (tools.py:217-218: LSAH, OnlineBPH, BR) as in-env policies -------------------
-// See oracle/pct_oracle_cont.c pctc_heur_choose for the sequential statement (pinned on the reference's own loops).
+// (The tests hold a sequential CPU restatement of these loops, pinned on the reference's own.)
 // lane = (EMS, rotation) pair in the reference's loop order; float64 in the reference's operation order.
 __device__ __forceinline__ void cheur_rot(const CRegs& r, int rot, double& x, double& y, double& z) {  // heuristic.py:171-182
   switch (rot) {
@@ -1457,9 +1457,13 @@ pct_continuous_kernel(ContinuousParams p, const void* __restrict__ actions,
   // zeroed here, so that no memset sits between the launches (retry_mode = +1 / -1: offset of the other)
   if (p.retry_mode && blockIdx.x == 0 && threadIdx.x == 0) p.retry_count[p.retry_mode] = 0;
   for (int work = blockIdx.x; work < limit; work += gridDim.x) {
-  const int e = p.retry_mode ? p.retry_ids[work] : (listed ? env_ids[work] : work);
+  // (heavy-first dispatch: p.order is a permutation of 0..N-1, see pct_device.h)
+  // (readfirstlane: a loaded id would otherwise live, with every address derived from it, in vector registers)
+  const int e = __builtin_amdgcn_readfirstlane(
+      p.retry_mode ? p.retry_ids[work] : (listed ? env_ids[work] : ((ACT != CACT_RESET && p.order) ? p.order[work] : work)));
   if (e < 0 || e >= p.N) continue;
-  CLds l = carve(p, smem);
+  work_key_begin(smem);
+  CLds l = carve(p, smem + PCT_LDS_STASH);
   CRegs r;
   PhaseTimer<TIMED> tm;
   tm.start();
@@ -1579,6 +1583,7 @@ pct_continuous_kernel(ContinuousParams p, const void* __restrict__ actions,
   }
   }  // step / reset
   if (requeue && lane == 0) p.retry_ids[atomicAdd(p.retry_count, 1)] = e;
+  work_key_end(smem, p.scalars, p.N, e, ACT == CACT_RESET);
   __syncthreads();
   }  // work items
 }

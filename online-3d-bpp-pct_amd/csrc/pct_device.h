@@ -34,6 +34,12 @@ struct DiscreteParams {
   // item source
   int source, n_items, env_id_base;
   int prio_t[3];     /* wave_priority thresholds on the EMS count (0: off) */
+  /* Heavy-first dispatch (pct_env.hip, pct_order_kernel): when a launch holds more envs than the chip keeps resident,
+   * workgroup b steps env order[b] -- the envs sorted by their work key, the shader-clock cycles their previous step
+   * took, longest first -- so that no long step starts last (any bijection is a correct placement).  null: b steps
+   * env b.  The keys live behind the scalars (work_key_slot): no pointer of their own is kept live in the kernels, and
+   * the step's start time waits in the first 16 bytes of the workgroup's LDS (PCT_LDS_STASH). */
+  const int32_t* order; /* [N] this launch's workgroup -> env map, or null */
   int rng_numpy;     /* 1: strict NumPy-stream mode -- item picks, setting-3 densities and the candidate shuffle consume
                         the env's own MT19937 stream exactly as the reference's worker process does */
   uint32_t* mt;      /* [N,624] MT19937 state words of every env (position: scalars[7]) */
@@ -103,6 +109,7 @@ struct ContinuousParams {
   uint32_t* gfpri;  /* [N, order_cap] shuffle priorities (HBM-table variant + shuffle) */
   int gt_by_block;  /* HBM table slices indexed by blockIdx (retry pass) instead of env */
   int prio_t[3];    /* wave_priority thresholds on the EMS count (0: off) */
+  const int32_t* order; /* heavy-first dispatch, as in DiscreteParams */
   int rng_numpy;    /* 1: strict NumPy-stream mode (pct_set_numpy_rng), as in DiscreteParams */
   int np_items;     /* len(item_set) behind RandomBoxCreator's unread randint draws (sampling mode) */
   uint32_t* mt;     /* [N,624] MT19937 state words (position: scalars[7]) */
@@ -127,6 +134,20 @@ struct ContinuousParams {
 // take a higher issue priority (s_setprio) so that they run at a lone wave's pace from the start while the light
 // waves of the same SIMD fill the gaps, instead of crawling at a quarter of it until the light ones are gone
 // (C2: 75.4 -> 71.2 us per launch).  prio_t: ascending EMS-count thresholds of priorities 1..3 (0: off).
+// Heavy-first dispatch: the sort key of env e (shader-clock cycles of its last step, low 32 bits of the counter: a step
+// is far shorter than their 1.8 s wrap) sits behind the [N, PCT_SCALARS] scalars; the step's start time is parked in the
+// first PCT_LDS_STASH bytes of the workgroup's LDS, in front of everything carve_lds / carve lay out.
+#define PCT_LDS_STASH 16
+__device__ __forceinline__ uint32_t* work_key_slot(int32_t* scalars, int N, int e) {
+  return reinterpret_cast<uint32_t*>(scalars) + (size_t)N * PCT_SCALARS + e;
+}
+__device__ __forceinline__ void work_key_begin(unsigned char* smem) {
+  if (threadIdx.x == 0) *reinterpret_cast<uint32_t*>(smem) = (uint32_t)__builtin_readcyclecounter();
+}
+__device__ __forceinline__ void work_key_end(unsigned char* smem, int32_t* scalars, int N, int e, bool reset) {
+  if (threadIdx.x == 0)
+    *work_key_slot(scalars, N, e) = reset ? 0u : (uint32_t)__builtin_readcyclecounter() - *reinterpret_cast<uint32_t*>(smem);
+}
 __device__ __forceinline__ void wave_priority(int n_ems, const int prio_t[3]) {
   if (prio_t[0] <= 0) return;
   if (n_ems >= prio_t[2]) __builtin_amdgcn_s_setprio(3);

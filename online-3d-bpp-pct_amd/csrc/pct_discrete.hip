@@ -1,6 +1,7 @@
 // pct_discrete.hip -- instantiates the setting-2 discrete-env kernels for 32-bit keys (bins <= 31 per
 // axis: six 5-bit coordinates) and hosts the launch dispatcher; the kernels themselves are in
-// pct_discrete_impl.cuh, the other instantiations in pct_discrete_stab.hip, pct_discrete_u64.hip, pct_discrete_u64_stab.hip.
+// pct_discrete_impl.cuh, the other instantiations in pct_discrete_stab.hip, pct_discrete_u64.hip, pct_discrete_u64_stab.hip and
+// (strict NumPy-stream mode) pct_discrete_{,stab_,u64_,u64_stab_}mt.hip.
 #include "pct_discrete_impl.cuh"
 
 namespace pct {
@@ -34,6 +35,16 @@ __global__ void __launch_bounds__(64) pct_policy_hash_rows_kernel(DiscreteParams
 }
 
 
+// ... and their strict NumPy-stream twins (pct_discrete_*_mt.hip)
+#define PCT_DECL_MT(name)                                                                                           \
+  hipError_t name(const DiscreteParams& p, int act, const void* actions, int row_len, int n_steps, const int32_t* env_ids, \
+                  int n_ids, hipStream_t stream)
+PCT_DECL_MT(launch_discrete_u32_mt);
+PCT_DECL_MT(launch_discrete_u32_stab_mt);
+PCT_DECL_MT(launch_discrete_u64_mt);
+PCT_DECL_MT(launch_discrete_u64_stab_mt);
+#undef PCT_DECL_MT
+
 hipError_t launch_policy_hash_rows(const DiscreteParams& p, float* rows_out, hipStream_t stream) {
   hipLaunchKernelGGL(pct_policy_hash_rows_kernel, dim3(p.N), dim3(64), 0, stream, p, rows_out);
   return hipGetLastError();
@@ -42,6 +53,13 @@ hipError_t launch_policy_hash_rows(const DiscreteParams& p, float* rows_out, hip
 hipError_t launch_discrete(const DiscreteParams& p, int act, const void* actions, int row_len, int n_steps,
                            const int32_t* env_ids, int n_ids, hipStream_t stream) {
   const bool stab = p.setting != 2;
+  if (p.rng_numpy) {
+    if (p.key_bytes == 4)
+      return stab ? launch_discrete_u32_stab_mt(p, act, actions, row_len, n_steps, env_ids, n_ids, stream)
+                  : launch_discrete_u32_mt(p, act, actions, row_len, n_steps, env_ids, n_ids, stream);
+    return stab ? launch_discrete_u64_stab_mt(p, act, actions, row_len, n_steps, env_ids, n_ids, stream)
+                : launch_discrete_u64_mt(p, act, actions, row_len, n_steps, env_ids, n_ids, stream);
+  }
   if (p.key_bytes == 4)
     return stab ? launch_discrete_u32_stab(p, act, actions, row_len, n_steps, env_ids, n_ids, stream)
                 : launch_typed<uint32_t, 5, false>(p, act, actions, row_len, n_steps, env_ids, n_ids, stream);

@@ -1670,8 +1670,8 @@ __device__ __forceinline__ void heur_rot(int b0, int b1, int b2, int rot, int& x
   }
 }
 
-// Picks the placement heuristic `kind` would step with (heuristic.py; see oracle/pct_oracle.c
-// heur_choose for the sequential statement).  Every lane evaluates its own candidates; the winner
+// Picks the placement heuristic `kind` would step with (heuristic.py; the tests hold a sequential
+// CPU restatement of the same loops).  Every lane evaluates its own candidates; the winner
 // is the lexicographic minimum of (score, position in the reference's loop order), which is what
 // "replace on strictly better" leaves.  Returns false if there is no feasible placement.
 template <typename K, int BITS, bool STAB>
@@ -2149,7 +2149,7 @@ template <typename K, int BITS, int ACT, bool TIMED, bool STAB, int SCHEME, int 
 __device__ __forceinline__ void discrete_env_steps(const DiscreteParams& p, const void* __restrict__ actions, int row_len, int n_steps,
                                           int e, unsigned char* smem) {
   const int lane = threadIdx.x;
-  Lds<K, BITS> l = carve_lds<K, BITS>(p, smem);
+  Lds<K, BITS> l = carve_lds<K, BITS>(p, smem + PCT_LDS_STASH);
   EnvRegs r;
   PhaseTimer<TIMED> tm;
   tm.start();
@@ -2273,7 +2273,11 @@ pct_discrete_kernel(DiscreteParams p, const void* __restrict__ actions,
     const int limit = *p.retry_count;
     if (blockIdx.x == 0 && threadIdx.x == 0) p.retry_count[p.retry_mode] = 0;  // retry_mode = +1 / -1: offset of the other
     for (int w = blockIdx.x; w < limit; w += gridDim.x) {
-      discrete_env_steps<K, BITS, ACT, TIMED, STAB, SCHEME, RNG>(p, actions, row_len, n_steps, p.retry_ids[w], smem);
+      const int e = __builtin_amdgcn_readfirstlane(p.retry_ids[w]);
+      work_key_begin(smem);
+      discrete_env_steps<K, BITS, ACT, TIMED, STAB, SCHEME, RNG>(p, actions, row_len, n_steps, e, smem);
+      // (the large-capacity run is what this env's next step will look like: its key replaces the normal pass's)
+      work_key_end(smem, p.scalars, p.N, e, false);
       __syncthreads();
     }
     return;
@@ -2281,10 +2285,16 @@ pct_discrete_kernel(DiscreteParams p, const void* __restrict__ actions,
   int e = blockIdx.x;
   if (ACT == ACT_RESET && env_ids) {
     if (e >= n_ids) return;
-    e = env_ids[e];
+    e = __builtin_amdgcn_readfirstlane(env_ids[e]);
     if (e < 0 || e >= p.N) return;
+  } else if (ACT != ACT_RESET && p.order) {
+    // heavy-first dispatch: a permutation of 0..N-1.  (readfirstlane: the compiler would otherwise keep the loaded id,
+    // and every address derived from it, in vector registers -- 34 more spilled VGPRs in the setting-2 kernel)
+    e = __builtin_amdgcn_readfirstlane(p.order[e]);
   }
+  work_key_begin(smem);
   discrete_env_steps<K, BITS, ACT, TIMED, STAB, SCHEME, RNG>(p, actions, row_len, n_steps, e, smem);
+  work_key_end(smem, p.scalars, p.N, e, ACT == ACT_RESET);
 }
 
 }  // namespace pct
@@ -2295,15 +2305,16 @@ pct_discrete_kernel(DiscreteParams p, const void* __restrict__ actions,
 namespace pct {
 
 inline size_t discrete_lds_bytes_impl(const DiscreteParams& p) {
-  size_t b = discrete_lds_base_bytes(p);
+  size_t b = PCT_LDS_STASH + discrete_lds_base_bytes(p);
   if (p.setting != 2) b += ((stab_state_bytes(p.I, p.sb.caps) + 15) & ~(size_t)15) + stab_wave_bytes(p.sb.caps);
   return b;
 }
 
 // STAB selects the half of the instantiations a translation unit carries: the setting-2 kernels (false) or the
-// stability-check kernels of settings 1 / 3 (true) -- four translation units (u32 / u64 keys x plain / stability)
-// compile in parallel
-template <typename K, int BITS, bool STAB>
+// stability-check kernels of settings 1 / 3 (true); MTSEL the random source: the counter-keyed kernels (false) or the
+// strict NumPy-stream kernels (true, per-env MT19937: pct_set_numpy_rng) -- eight translation units (u32 / u64 keys x
+// plain / stability x counter / NumPy stream) compile in parallel
+template <typename K, int BITS, bool STAB, bool MTSEL = false>
 inline hipError_t launch_typed(const DiscreteParams& p, int act, const void* actions, int row_len, int n_steps,
                                const int32_t* env_ids, int n_ids, hipStream_t stream) {
   size_t lds = discrete_lds_bytes_impl(p);
@@ -2311,9 +2322,10 @@ inline hipError_t launch_typed(const DiscreteParams& p, int act, const void* act
   const int scheme = p.lnes == PCT_LNES_EMS ? 0 : 1;  // 1: every other expansion, dispatched inside the kernel
   int grid = p.retry_mode ? n_ids : ((act == ACT_RESET && env_ids) ? n_ids : p.N);
   if (grid <= 0) return hipSuccess;
-  // RNG mode: bit 0 shuffle, bit 1 strict NumPy stream (EMS expansion with 32-bit keys only; checked by the host)
-#define PCT_KERN_MT(A, S, C) ((sizeof(K) == 4 && (C) == 0 && p.rng_numpy) ? (p.shuffle ? pct_discrete_kernel<K, BITS, A, false, S, 0, (sizeof(K) == 4 ? 3 : 1)> : pct_discrete_kernel<K, BITS, A, false, S, 0, (sizeof(K) == 4 ? 2 : 0)>) : nullptr)
-#define PCT_KERN(A, T, S, C) (PCT_KERN_MT(A, S, C) ? PCT_KERN_MT(A, S, C) : (p.shuffle ? pct_discrete_kernel<K, BITS, A, false, S, C, 1> : pct_discrete_kernel<K, BITS, A, T, S, C, 0>))
+  if (MTSEL != (p.rng_numpy != 0)) return hipErrorInvalidValue;  // (launch_discrete picks the translation unit)
+  // RNG mode: bit 0 shuffle, bit 1 strict NumPy stream (no timed build, no heuristic kernels: checked by the host)
+  constexpr int R_SHUF = MTSEL ? 3 : 1, R_PLAIN = MTSEL ? 2 : 0;
+#define PCT_KERN(A, T, S, C) (p.shuffle ? pct_discrete_kernel<K, BITS, A, false, S, C, R_SHUF> : pct_discrete_kernel<K, BITS, A, (MTSEL ? false : T), S, C, R_PLAIN>)
 #define PCT_LAUNCH(A)                                                                                        \
   do {                                                                                                       \
     void (*kern)(DiscreteParams, const void*, int, int, const int32_t*, int);                                \
@@ -2327,6 +2339,9 @@ inline hipError_t launch_typed(const DiscreteParams& p, int act, const void* act
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, stream, p, actions, row_len, n_steps, env_ids, n_ids); \
   } while (0)
   if (act == ACT_HEUR) {  // heuristic policies read the EMS list: LNES == EMS only (checked by the caller)
+    if constexpr (MTSEL) {
+      return hipErrorInvalidValue;
+    } else {
     void (*kern)(DiscreteParams, const void*, int, int, const int32_t*, int);
     kern = p.shuffle ? pct_discrete_kernel<K, BITS, ACT_HEUR, false, STAB, 0, 1>
                      : pct_discrete_kernel<K, BITS, ACT_HEUR, false, STAB, 0, 0>;
@@ -2336,6 +2351,7 @@ inline hipError_t launch_typed(const DiscreteParams& p, int act, const void* act
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, stream, p, actions, row_len, n_steps, env_ids, n_ids);
     return hipGetLastError();
+    }
   }
   switch (act) {
     case ACT_ROWS: PCT_LAUNCH(ACT_ROWS); break;

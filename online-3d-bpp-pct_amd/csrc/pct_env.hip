@@ -68,6 +68,10 @@ struct pct_env {
   int64_t prof_launches;
   double prof_ms;
   unsigned long long* timing_buf;
+  // heavy-first dispatch (pct_device.h: work_key / order)
+  int order_state;      /* 0: not decided yet (first full launch), 1: on, -1: off */
+  int32_t* d_order;     /* [N] */
+
 };
 
 namespace {
@@ -121,10 +125,88 @@ int prof_begin(pct_env* h, hipStream_t s, size_t* slot) {
   HIP_TRY(hipEventRecord(h->ev_pool[*slot].first, s));
   return PCT_OK;
 }
+/* Heavy-first dispatch.  A launch that holds more envs than the chip keeps resident is worked off in the order the
+ * dispatcher hands out workgroups; an env whose step is five times the mean (a crowded bin, a deep stability walk) that
+ * happens to start last sets the launch's length all by itself (c1: 4 envs per SIMD slot in turn, launch = 1.7 x the
+ * mean slot).  Every env's wave therefore leaves the cycles its step took (work_key_slot), this kernel turns them into a
+ * workgroup -> env map, longest first (one 1024-thread workgroup, a 256-bin counting sort -- a few microseconds), and
+ * the step kernel looks its env up in it: longest-processing-time-first list scheduling.  Any bijection is a correct
+ * placement, so the results do not depend on it. */
+__global__ void __launch_bounds__(1024) pct_order_kernel(const uint32_t* __restrict__ key, int32_t* __restrict__ order, int N) {
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t start[256];
+  __shared__ uint32_t smax;
+  const int t = threadIdx.x;
+  if (t < 256) hist[t] = 0;
+  if (t == 0) smax = 0;
+  __syncthreads();
+  // (a running mean of the cycles instead of the last step's sorts no better: measured, profiles/r03_heavy_first.txt)
+  uint32_t m = 0;
+  for (int i = t; i < N; i += 1024) m = max(m, key[i]);
+  for (int o = 32; o; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+  if ((t & 63) == 0) atomicMax(&smax, m);
+  __syncthreads();
+  const uint64_t div = (uint64_t)smax + 1u;
+  auto bin = [&](uint32_t k) -> uint32_t { return 255u - (uint32_t)(((uint64_t)k << 8) / div); };  // bin 0 = the longest
+  for (int i = t; i < N; i += 1024) atomicAdd(&hist[bin(key[i])], 1u);
+  __syncthreads();
+  if (t < 64) {  // exclusive prefix sum over the 256 bins: four per lane of one wave
+    const uint32_t a = hist[4 * t], b = hist[4 * t + 1], c = hist[4 * t + 2], d = hist[4 * t + 3];
+    uint32_t incl = a + b + c + d;
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t v = (uint32_t)__shfl_up((int)incl, o, 64);
+      if (t >= o) incl += v;
+    }
+    const uint32_t excl = incl - (a + b + c + d);
+    start[4 * t] = excl;
+    start[4 * t + 1] = excl + a;
+    start[4 * t + 2] = excl + a + b;
+    start[4 * t + 3] = excl + a + b + c;
+  }
+  __syncthreads();
+  for (int i = t; i < N; i += 1024) order[atomicAdd(&start[bin(key[i])], 1u)] = i;
+}
+
+int order_setup(pct_env* h) {
+  h->order_state = -1;
+  const char* ev = getenv("PCT_ORDER"); /* kernel experiments: 0 = never, 1 = always */
+  if (ev && atoi(ev) <= 0) return PCT_OK;
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, h->device));
+  const bool stab = h->cfg.setting != 2;
+  size_t lds = h->continuous ? pct::continuous_lds_bytes(h->cp) : pct::discrete_lds_bytes(h->dp);
+  lds = (lds + 511) & ~(size_t)511;
+  const size_t lds_cu = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 160 * 1024;
+  long per_cu = lds ? (long)(lds_cu / lds) : 64;
+  const long by_regs = stab ? 4 : 16; /* one-wave workgroups: the stability kernels run 1 wave per SIMD, the plain ones 4 */
+  if (per_cu > by_regs) per_cu = by_regs;
+  const long resident = per_cu * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+  const long N = h->continuous ? h->cp.N : h->dp.N;
+  if (!(ev && atoi(ev) > 0) && N <= resident) return PCT_OK;
+  int rc = dev_alloc(h, (void**)&h->d_order, (size_t)N * sizeof(int32_t), true);
+  if (rc) return rc;
+
+  h->order_state = 1;
+  return PCT_OK;
+}
+
 int launch(pct_env* h, int act, const void* actions, int row_len, int n_steps, const int32_t* ids, int n_ids,
            void* stream) {
   hipStream_t s = (hipStream_t)stream;
   size_t slot = 0;
+  if (h->order_state == 0) {
+    int rc = order_setup(h);
+    if (rc) return rc;
+  }
+  h->dp.order = h->cp.order = nullptr;
+  if (h->order_state == 1 && act != ACT_RESET && !ids) {
+    const int N = h->continuous ? h->cp.N : h->dp.N;
+    const int32_t* scalars = h->continuous ? h->cp.scalars : h->dp.scalars;
+    hipLaunchKernelGGL(pct_order_kernel, dim3(1), dim3(1024), 0, s,
+                       reinterpret_cast<const uint32_t*>(scalars) + (size_t)N * PCT_SCALARS, h->d_order, N);
+    HIP_TRY(hipGetLastError());
+    h->dp.order = h->cp.order = h->d_order;
+  }
   if (h->profiling) {
     int rc = prof_begin(h, s, &slot);
     if (rc) return rc;
@@ -147,6 +229,7 @@ int launch(pct_env* h, int act, const void* actions, int row_len, int n_steps, c
       q.low_bound = c.low_bound; q.obs = c.obs; q.reward = c.reward; q.done = c.done; q.counter = c.counter;
       q.ratio = c.ratio; q.flags = c.flags; q.timing = nullptr; q.full_obs = c.full_obs; q.mask = c.mask;
       q.retry_count = c.retry_count;
+      q.order = nullptr;
       q.retry_mode = h->c_retry_parity ? -1 : 1;
       h->c_retry_parity ^= 1;
       HIP_TRY(pct::launch_continuous(q, act, actions, row_len, n_steps, ids, h->cp_retry_blocks, s));
@@ -279,7 +362,11 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
    * 10^3-class bins (at most 150 distinct candidates were seen) and frees 6 KB of LDS for the stability state */
   const bool small_bin = (cont ? maxdim / 1000 : maxdim) <= 12;
   int cand_cap = cfg->candidate_capacity > 0 ? cfg->candidate_capacity
-                                             : (small_bin ? (cfg->setting != 2 ? 512 : 2048) : (cont ? 32768 : 8192));
+                                             : (small_bin ? (cfg->setting != 2 ? 512 : 2048)
+                                                          /* larger discrete bins under the stability settings: two orientations x
+                                                           * 256 EMS = at most 512 candidates, a 2048-slot table; 8192 slots of
+                                                           * 64-bit keys would not leave room for the stability state */
+                                                          : (cont ? 32768 : (cfg->setting != 2 ? 2048 : 8192)));
   if (getenv("PCT_CAND_CAP")) cand_cap = atoi(getenv("PCT_CAND_CAP")); /* kernel experiments only */
   if (!is_cand_cap_ok(cand_cap)) return fail(PCT_ERR_INVALID_ARG, "candidate_capacity must be 8*4^k (8,32,...,2048,8192)");
 
@@ -300,6 +387,8 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
   h->prof_launches = 0;
   h->prof_ms = 0.0;
   h->timing_buf = nullptr;
+  h->order_state = 0;
+  h->d_order = nullptr;
   h->continuous = cont;
   h->has_dretry = false;
   memset(&h->cp, 0, sizeof h->cp);
@@ -387,7 +476,7 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
       CALLOC_(c.gorder, Nn * (size_t)c.order_cap * sizeof(uint16_t));
       if (c.shuffle) CALLOC_(c.gfpri, Nn * (size_t)c.order_cap * sizeof(uint32_t));
     }
-    CALLOC_(c.scalars, Nn * PCT_SCALARS * sizeof(int32_t));
+    CALLOC_(c.scalars, Nn * (PCT_SCALARS + 1) * sizeof(int32_t)); /* (+ the [N] work keys of the heavy-first dispatch) */
     CALLOC_(h->own_flags, Nn * sizeof(uint32_t));
     CALLOC_(h->own_obs, Nn * c.row_len * sizeof(float));
     CALLOC_(h->own_reward, Nn * sizeof(float));
@@ -417,12 +506,14 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
       q.union_words = 12 * q.ems_cap > 192 ? 12 * q.ems_cap : 192; /* children scratch only: 2 * ems_cap of them */
       if (cfg->setting != 2) { /* larger stability pools / workspace / queue, as far as the LDS of that pass goes */
         q.sb.caps = retry_stab;
-        while (pct::continuous_lds_bytes(q) > 160 * 1024 && q.sb.caps.SP > c.sb.caps.SP) {
+        /* (strict NumPy-stream mode, chosen after pct_create, adds the env's 624 MT19937 words: room is kept for them) */
+        const size_t lds_room = 160 * 1024 - 624 * sizeof(uint32_t);
+        while (pct::continuous_lds_bytes(q) > lds_room && q.sb.caps.SP > c.sb.caps.SP) {
           q.sb.caps.SP = (q.sb.caps.SP * 3) / 4 > c.sb.caps.SP ? (q.sb.caps.SP * 3) / 4 : c.sb.caps.SP;
           q.sb.caps.PP = (q.sb.caps.PP * 3) / 4 > c.sb.caps.PP ? (q.sb.caps.PP * 3) / 4 : c.sb.caps.PP;
           q.sb.caps.queue = (q.sb.caps.queue * 3) / 4 > c.sb.caps.queue ? (q.sb.caps.queue * 3) / 4 : c.sb.caps.queue;
         }
-        if (pct::continuous_lds_bytes(q) > 160 * 1024) { pct_destroy(h); return fail(PCT_ERR_INVALID_ARG, "the retry pass does not fit the LDS"); }
+        if (pct::continuous_lds_bytes(q) > lds_room) { pct_destroy(h); return fail(PCT_ERR_INVALID_ARG, "the retry pass does not fit the LDS"); }
       }
       CALLOC_(q.gtab, (size_t)RB * (size_t)(big + big / 4) * sizeof(uint32_t));
       CALLOC_(q.gorder, (size_t)RB * (size_t)q.order_cap * sizeof(uint16_t));
@@ -457,15 +548,17 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
   /* retry pass: four times the EMS list (up to 1024) and, while it still fits the 160 KB of LDS, four times
    * the candidate table; the HBM EMS rows are as long as the longest list any pass may leave behind.  The
    * stability settings keep per-box state beyond the lists and run without it (overflow -> flag). */
+  /* (strict NumPy-stream mode, chosen after pct_create, adds the env's 624 MT19937 words: room is kept for them) */
+  const size_t lds_room = 160 * 1024 - 624 * sizeof(uint32_t);
   h->d_retry_ems = ems_cap * 4 < 1024 ? ems_cap * 4 : (ems_cap > 1024 ? ems_cap : 1024);
   h->d_retry_cand = cand_cap;
   {
     pct::DiscreteParams t = p;
     t.ems_cap = h->d_retry_ems;
     t.cand_cap = cand_cap * 4;
-    if (pct::discrete_lds_bytes(t) <= 160 * 1024) h->d_retry_cand = cand_cap * 4;
+    if (pct::discrete_lds_bytes(t) <= lds_room) h->d_retry_cand = cand_cap * 4;
     t.cand_cap = h->d_retry_cand;
-    if (pct::discrete_lds_bytes(t) > 160 * 1024) h->d_retry_ems = ems_cap;
+    if (pct::discrete_lds_bytes(t) > lds_room) h->d_retry_ems = ems_cap;
   }
   /* stability settings: pool / workspace / queue capacities of the normal pass and of the retry pass (pct_stab.cuh) */
   h->d_retry_stab = p.sb.caps;
@@ -481,12 +574,12 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
     t.ems_cap = h->d_retry_ems;
     t.cand_cap = h->d_retry_cand;
     t.sb.caps = h->d_retry_stab;
-    while (pct::discrete_lds_bytes(t) > 160 * 1024 && t.sb.caps.SP > p.sb.caps.SP) {  /* shrink until the pass fits */
+    while (pct::discrete_lds_bytes(t) > lds_room && t.sb.caps.SP > p.sb.caps.SP) {  /* shrink until the pass fits */
       t.sb.caps.SP = (t.sb.caps.SP * 3) / 4 > p.sb.caps.SP ? (t.sb.caps.SP * 3) / 4 : p.sb.caps.SP;
       t.sb.caps.PP = (t.sb.caps.PP * 3) / 4 > p.sb.caps.PP ? (t.sb.caps.PP * 3) / 4 : p.sb.caps.PP;
       t.sb.caps.queue = (t.sb.caps.queue * 3) / 4 > p.sb.caps.queue ? (t.sb.caps.queue * 3) / 4 : p.sb.caps.queue;
     }
-    if (pct::discrete_lds_bytes(t) > 160 * 1024) { h->d_retry_ems = ems_cap; h->d_retry_cand = cand_cap; t.sb.caps = p.sb.caps; }
+    if (pct::discrete_lds_bytes(t) > lds_room) { h->d_retry_ems = ems_cap; h->d_retry_cand = cand_cap; t.sb.caps = p.sb.caps; }
     h->d_retry_stab = t.sb.caps;
     p.sb.sp_stride = h->d_retry_stab.SP;
     p.sb.pp_stride = h->d_retry_stab.PP;
@@ -511,7 +604,7 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
   ALLOC(p.ems, N * p.ems_stride * p.key_bytes);
   ALLOC(p.boxes, N * p.I * p.key_bytes);
   ALLOC(p.leaves, N * p.L * p.key_bytes);
-  ALLOC(p.scalars, N * PCT_SCALARS * sizeof(int32_t));
+  ALLOC(p.scalars, N * (PCT_SCALARS + 1) * sizeof(int32_t)); /* (+ the [N] work keys of the heavy-first dispatch) */
   ALLOC(p.set_scratch, N * 768 * sizeof(uint32_t)); /* pct_discrete_impl.cuh WS_KMAX: one row per workgroup of any pass */
   if (cfg->setting != 2) {
     ALLOC(p.sb.stk, N * p.I * 4 * sizeof(double));
@@ -694,8 +787,6 @@ int pct_set_shuffle_seed(pct_env* h, uint64_t seed) {
 
 int pct_set_numpy_rng(pct_env* h, uint32_t seed) {
   if (!h) return fail(PCT_ERR_INVALID_ARG, "null handle");
-  if (!h->continuous && (h->dp.key_bytes != 4 || h->cfg.lnes != PCT_LNES_EMS))
-    return fail(PCT_ERR_UNSUPPORTED, "NumPy-stream mode: discrete env with bins up to 31 per axis and LNES = EMS, or the continuous env");
   if (h->continuous && h->cp.sample_right <= 0)
     return fail(PCT_ERR_UNSUPPORTED, "NumPy-stream mode, continuous env: items sampled from U(a, b) (pct_set_sample_bounds)");
   if (!h->have_items) return fail(PCT_ERR_STATE, "pct_set_item_set / pct_set_sample_bounds must come first");
@@ -739,6 +830,14 @@ int pct_set_numpy_rng(pct_env* h, uint32_t seed) {
   h->dp.rng_numpy = 1;
   h->dp.source = PCT_ITEMS_SAMPLER;
   if (pct::discrete_lds_bytes(h->dp) > 160 * 1024) return fail(PCT_ERR_INVALID_ARG, "capacities + MT19937 state exceed the LDS");
+  if (h->has_dretry) {
+    pct::DiscreteParams q = h->dp;
+    q.ems_cap = h->d_retry_ems;
+    q.cand_cap = h->d_retry_cand;
+    q.sb.caps = h->d_retry_stab;
+    if (pct::discrete_lds_bytes(q) > 160 * 1024)
+      return fail(PCT_ERR_INVALID_ARG, "the retry pass's capacities + MT19937 state exceed the LDS");
+  }
   return PCT_OK;
 }
 

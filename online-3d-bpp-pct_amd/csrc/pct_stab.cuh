@@ -32,7 +32,7 @@
 // for the large-capacity retry pass.
 //
 // The same source compiles for the host (tests/host/stab_host.cpp) so that the restructured algorithm is checked
-// against the oracle and the reference fixtures on the CPU as well.
+// against the tests' CPU restatement and the reference fixtures on the CPU as well.
 #ifndef PCT_STAB_CUH
 #define PCT_STAB_CUH
 #include <math.h>
@@ -263,7 +263,7 @@ PCT_SD bool stab_pip_hull(const double* pt, const double (*lo)[2], int nl, const
 
 // minimum-norm least squares for the >= 3 supporter case (stands in for np.linalg.lstsq / LAPACK dgelsd):
 // one-sided Jacobi (Hestenes) SVD of A itself, x = sum_j V_j (U_j . b) / sigma_j^2 over sigma_j > eps * max(M,N) *
-// sigma_max -- the same method, operation for operation, as the oracle's lstsq_min_norm (see there for why not A^T A).
+// sigma_max -- the same method, operation for operation, as the CPU restatement the tests check against (lstsq_min_norm; A^T A would square the condition number).
 // `ill` reports a rank decision taken within a factor STAB_ILL_BAND of the cut: there the reference's own verdict
 // depends on the rounding noise of its LAPACK build (profiles/r02_lstsq_limit.txt, r03_lstsq_limit.txt).
 constexpr double STAB_ILL_BAND = 1e3;
@@ -321,7 +321,7 @@ PCT_SD void stab_lstsq(const double* A, const double* b, int M, int N, double* x
 }
 
 // np.dot of two 2-vectors as NumPy's BLAS computes it (OpenBLAS ddot on x86 cores with FMA): acc = x0*y0;
-// acc = fma(x1, y1, acc) -- see oracle/pct_oracle_stab.c dot2 (v_fma_f64 on the GPU: the same IEEE operation)
+// acc = fma(x1, y1, acc) (NumPy's 2-vector dot on an FMA host; v_fma_f64 on the GPU is the same IEEE operation)
 PCT_SD double stab_dot2(double x0, double x1, double y0, double y1) { return fma(x1, y1, x0 * y0); }
 
 // The same solve with every extent a compile-time constant (N supporters, M = N(N-1)/2 + 1 rows) and every loop over

@@ -765,6 +765,18 @@ NUMPY_STREAM_CASES = {
     "discrete_s2_numpy_stream": dict(setting=2, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, N=6, steps=250, seed=4, base=0),
     "discrete_s1_numpy_stream": dict(setting=1, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, N=4, steps=200, seed=11, base=5),
     "discrete_s3_numpy_stream": dict(setting=3, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, N=4, steps=200, seed=12, base=2),
+    # every other configuration the reference shuffles (bin3D.py:114-115 runs after whatever --lnes produced and for any
+    # bin): the EV / EP / CP / FC expansions, and bins beyond 31 cells per axis (64-bit candidate keys in the kernels)
+    "discrete_s2_numpy_stream_cp": dict(setting=2, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, N=4, steps=200, seed=41, base=1, lnes="CP"),
+    "discrete_s1_numpy_stream_cp": dict(setting=1, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, N=3, steps=160, seed=42, base=0, lnes="CP"),
+    "discrete_s2_numpy_stream_ep": dict(setting=2, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, N=4, steps=200, seed=43, base=2, lnes="EP"),
+    "discrete_s3_numpy_stream_ep": dict(setting=3, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, N=3, steps=160, seed=44, base=0, lnes="EP"),
+    "discrete_s2_numpy_stream_ev": dict(setting=2, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, N=4, steps=120, seed=45, base=3, lnes="EV"),
+    "discrete_s2_numpy_stream_fc": dict(setting=2, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, N=3, steps=160, seed=46, base=0, lnes="FC"),
+    "discrete_s1_numpy_stream_fc": dict(setting=1, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, N=3, steps=120, seed=47, base=4, lnes="FC"),
+    "discrete_s2_numpy_stream_u64": dict(setting=2, container=(40, 40, 40), lo=4, hi=20, I=80, L=50, N=4, steps=200, seed=48, base=0),
+    "discrete_s1_numpy_stream_u64": dict(setting=1, container=(40, 40, 40), lo=4, hi=20, I=80, L=50, N=3, steps=160, seed=49, base=2),
+    "discrete_s2_numpy_stream_u64_cp": dict(setting=2, container=(40, 40, 40), lo=4, hi=20, I=80, L=50, N=3, steps=160, seed=50, base=1, lnes="CP"),
     # continuous env, sample_from_distribution=True (the CLI's --continuous default, main.py / arguments.py):
     # items round(np.random.uniform(a, b), 3), z from np.random.choice under settings 1 / 3, the RandomBoxCreator's
     # unread randint over givenData.item_size_set (125 entries), np.random.shuffle of the float positions
@@ -793,7 +805,7 @@ def run_reference_numpy_stream(c):
                      sample_left_bound=c["lo"], sample_right_bound=c["hi"])
         else:
             env = PD(setting=c["setting"], container_size=list(c["container"]), item_set=items, internal_node_holder=I,
-                     leaf_node_holder=L, LNES="EMS", shuffle=True)
+                     leaf_node_holder=L, LNES=c.get("lnes", "EMS"), shuffle=True)
         obs = env.reset()
         g = c["base"] + e
         for t in range(T):
@@ -821,7 +833,8 @@ def run_oracle_numpy_stream(c):
         env.set_numpy_rng(c["seed"], n_item_set=len(GIVEN_ITEM_SET))
     else:
         env = OracleVecEnv(N, setting=c["setting"], container_size=c["container"], item_set=item_set_range(c["lo"], c["hi"]),
-                           internal_node_holder=I, leaf_node_holder=L, env_id_base=c["base"], shuffle=True)
+                           internal_node_holder=I, leaf_node_holder=L, env_id_base=c["base"], shuffle=True,
+                           lnes={"EV": 1, "EP": 2, "CP": 3, "FC": 4}.get(c.get("lnes"), 0))
         env.set_numpy_rng(c["seed"])
     out = dict(obs=np.zeros((T + 1, N, (I + L + 1) * 9), dt), reward=np.zeros((T, N)), done=np.zeros((T, N), np.uint8),
                counter=np.zeros((T, N), np.int32), ratio=np.zeros((T, N)))

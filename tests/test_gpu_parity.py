@@ -664,3 +664,70 @@ def test_hip_notice_precedes_the_lapack_divergence():
     assert list(env.ill_conditioned) == [True, False, False, False]
     assert not env.error_flags.any()
     env.close()
+
+
+@pytest.mark.parametrize("kind,setting", [("discrete", 2), ("discrete", 1), ("continuous", 2), ("continuous", 1)])
+def test_heavy_first_dispatch_changes_nothing(kind, setting, monkeypatch):
+    """pct_order_kernel (pct_env.hip): with more envs than the chip keeps resident, workgroup b steps the env with the b-th
+    longest previous step.  Any workgroup -> env bijection is a correct placement: forced on (PCT_ORDER=1) and forced off
+    (PCT_ORDER=0; read at the handle's first launch) the trajectories are identical, and the oracle agrees."""
+    from oracle.oracle_lib import OracleVecEnv
+    N, steps = 768, 60
+    if kind == "discrete":
+        kw = dict(setting=setting, container_size=(10, 10, 10), item_set=item_set_range(1, 5), internal_node_holder=80,
+                  leaf_node_holder=50, env_id_base=40)
+        okw = dict(kw)
+    else:
+        kw = dict(setting=setting, container_size=(10, 10, 10), continuous=True, sample_left_bound=1.0, sample_right_bound=5.0,
+                  internal_node_holder=80, leaf_node_holder=50, env_id_base=40)
+        okw = dict(setting=setting, container_size=(10, 10, 10), env_kind=1, sample_bounds=(1.0, 5.0), internal_node_holder=80,
+                   leaf_node_holder=50, env_id_base=40)
+    envs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("PCT_ORDER", flag)
+        env = _pkg().PctVecEnv(N, seed=9, device="cuda:0", **kw)
+        env.reset()  # (the first launch decides)
+        envs.append(env)
+    ora = OracleVecEnv(N, threads=16, **okw)
+    ora.set_sampler(9)
+    ora.reset()
+    for t in range(steps):
+        outs = []
+        for env in envs:
+            env.step_hash_policy(1)
+            outs.append(env.step_wait())
+        ora.step_hash_policy(1)
+        (o1, r1, d1, _), (o0, r0, d0, _) = outs
+        assert torch.equal(o1, o0) and torch.equal(r1, r0) and np.array_equal(d1, d0), (kind, setting, t)
+        assert np.array_equal(d1.astype(np.uint8), ora.done), (kind, setting, t)
+        if t % 10 == 0:
+            assert np.array_equal(o1.cpu().numpy(), ora.obs.astype(np.float32)), (kind, setting, t)
+    for env in envs:
+        assert not env.error_flags.any()
+        env.close()
+    ora.close()
+
+
+@pytest.mark.parametrize("setting", [1, 3])
+def test_hip_stability_64bit_keys_matches_oracle(setting):
+    """settings 1 / 3 in a bin beyond 31 cells per axis (64-bit candidate keys + the stability state in one workgroup's
+    LDS; default capacities): HIP vs oracle step by step on the counter sampler"""
+    from oracle.oracle_lib import OracleVecEnv
+    N, items = 48, item_set_range(4, 16)
+    kw = dict(setting=setting, container_size=(40, 36, 33), item_set=items, internal_node_holder=100, leaf_node_holder=60,
+              env_id_base=17)
+    ora = OracleVecEnv(N, threads=16, **kw)
+    ora.set_sampler(5)
+    env = _pkg().PctVecEnv(N, seed=5, device="cuda:0", **kw)
+    ora.reset()
+    obs = env.reset()
+    for t in range(120):
+        assert np.array_equal(obs.cpu().numpy(), ora.obs.astype(np.float32)), (setting, t)
+        env.step_hash_policy(1)
+        ora.step_hash_policy(1)
+        obs, reward, done, infos = env.step_wait()
+        assert np.array_equal(done.astype(np.uint8), ora.done), (setting, t)
+        assert np.array_equal(reward[:, 0].numpy(), ora.reward.astype(np.float32)), (setting, t)
+    assert not env.error_flags.any()
+    env.close()
+    ora.close()

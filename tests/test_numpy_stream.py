@@ -12,7 +12,14 @@ import pytest
 
 from tests.common import hash_policy_index, item_set_range, load_case
 
-CASES = ["discrete_s2_numpy_stream", "discrete_s1_numpy_stream", "discrete_s3_numpy_stream"]
+CASES = ["discrete_s2_numpy_stream", "discrete_s1_numpy_stream", "discrete_s3_numpy_stream",
+         # bin3D.py:114-115 shuffles whatever --lnes produced, in any bin: the other leaf expansions and bins beyond 31
+         # cells per axis (64-bit candidate keys in the kernels), again against unscripted reference runs
+         "discrete_s2_numpy_stream_cp", "discrete_s1_numpy_stream_cp", "discrete_s2_numpy_stream_ep",
+         "discrete_s3_numpy_stream_ep", "discrete_s2_numpy_stream_ev", "discrete_s2_numpy_stream_fc",
+         "discrete_s1_numpy_stream_fc", "discrete_s2_numpy_stream_u64", "discrete_s1_numpy_stream_u64",
+         "discrete_s2_numpy_stream_u64_cp"]
+LNES_ID = {"EV": 1, "EP": 2, "CP": 3, "FC": 4}
 # continuous env in its sampling mode (C/bin3D.py:14-16,103-113): items are round(np.random.uniform(a, b), 3), plus
 # the RandomBoxCreator's unread randint, the density and the shuffle; a failed step's discarded observation draws a
 # whole new item
@@ -49,7 +56,8 @@ def test_oracle_numpy_stream_matches_reference(name):
     from oracle.oracle_lib import OracleVecEnv
     c, z = load_case(name)
     env = OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"], item_set=item_set_range(c["lo"], c["hi"]),
-                       internal_node_holder=c["I"], leaf_node_holder=c["L"], env_id_base=c["base"], shuffle=True)
+                       internal_node_holder=c["I"], leaf_node_holder=c["L"], env_id_base=c["base"], shuffle=True,
+                       lnes=LNES_ID.get(c.get("lnes"), 0))
     env.set_numpy_rng(c["seed"])
     env.reset()
     for t in range(c["steps"]):
@@ -173,7 +181,7 @@ def test_hip_numpy_stream_matches_reference(name, mode):
     c, z = load_case(name)
     env = pkg.PctVecEnv(c["N"], setting=c["setting"], container_size=c["container"], item_set=item_set_range(c["lo"], c["hi"]),
                         internal_node_holder=c["I"], leaf_node_holder=c["L"], env_id_base=c["base"], shuffle=True,
-                        rng="numpy", seed=c["seed"], device="cuda:0")
+                        rng="numpy", seed=c["seed"], device="cuda:0", LNES=c.get("lnes", "EMS"))
     obs = env.reset()
     for t in range(c["steps"]):
         o = obs.cpu().numpy()
