@@ -368,18 +368,35 @@ __device__ __forceinline__ void cgenems(const ContinuousParams& p, CLds& l, CReg
       a0 = l.emsb[0 * scap + i]; a1 = l.emsb[1 * scap + i]; a2 = l.emsb[2 * scap + i];
       a3 = l.emsb[3 * scap + i]; a4 = l.emsb[4 * scap + i]; a5 = l.emsb[5 * scap + i];
     }
+    // Each test is `a inside b` for a wave-uniform b: the 64 b of a chunk sit one per lane in registers and reach
+    // the comparison through readlane (scalar operands) -- no LDS round trip inside the pair loop.
     bool del = false;
-    for (int j = 0; j < E; j++) {
-      if (!((smask[(j >> 6) * 2 + ((j >> 5) & 1)] >> (j & 31)) & 1u)) continue;  // not a survivor (wave-uniform)
-      int b0 = l.emsk[0 * cap + j], b1 = l.emsk[1 * cap + j], b2 = l.emsk[2 * cap + j];
-      int b3 = l.emsk[3 * cap + j], b4 = l.emsk[4 * cap + j], b5 = l.emsk[5 * cap + j];
-      del |= (a0 >= b0) & (a1 >= b1) & (a2 >= b2) & (a3 <= b3) & (a4 <= b4) & (a5 <= b5);
+    for (int jb = 0; jb < E; jb += 64) {
+      const int jj = jb + lane;
+      const bool jl = jj < E;
+      const int b0 = jl ? l.emsk[0 * cap + jj] : 0, b1 = jl ? l.emsk[1 * cap + jj] : 0, b2 = jl ? l.emsk[2 * cap + jj] : 0;
+      const int b3 = jl ? l.emsk[3 * cap + jj] : 0, b4 = jl ? l.emsk[4 * cap + jj] : 0, b5 = jl ? l.emsk[5 * cap + jj] : 0;
+      uint64_t sm = ((uint64_t)smask[(jb >> 6) * 2 + 1] << 32) | smask[(jb >> 6) * 2];  // survivors only (wave-uniform)
+      while (sm) {
+        const int j = __ffsll((unsigned long long)sm) - 1;
+        sm &= sm - 1;
+        const int c0 = __builtin_amdgcn_readlane(b0, j), c1 = __builtin_amdgcn_readlane(b1, j), c2 = __builtin_amdgcn_readlane(b2, j);
+        const int c3 = __builtin_amdgcn_readlane(b3, j), c4 = __builtin_amdgcn_readlane(b4, j), c5 = __builtin_amdgcn_readlane(b5, j);
+        del |= (a0 >= c0) & (a1 >= c1) & (a2 >= c2) & (a3 <= c3) & (a4 <= c4) & (a5 <= c5);
+      }
     }
-    for (int j = 0; j < C; j++) {
-      int b0 = l.emsb[0 * scap + j], b1 = l.emsb[1 * scap + j], b2 = l.emsb[2 * scap + j];
-      int b3 = l.emsb[3 * scap + j], b4 = l.emsb[4 * scap + j], b5 = l.emsb[5 * scap + j];
-      bool inside = (a0 >= b0) & (a1 >= b1) & (a2 >= b2) & (a3 <= b3) & (a4 <= b4) & (a5 <= b5);
-      del |= inside & (j != i);
+    for (int jb = 0; jb < C; jb += 64) {
+      const int jj = jb + lane;
+      const bool jl = jj < C;
+      const int b0 = jl ? l.emsb[0 * scap + jj] : 0, b1 = jl ? l.emsb[1 * scap + jj] : 0, b2 = jl ? l.emsb[2 * scap + jj] : 0;
+      const int b3 = jl ? l.emsb[3 * scap + jj] : 0, b4 = jl ? l.emsb[4 * scap + jj] : 0, b5 = jl ? l.emsb[5 * scap + jj] : 0;
+      const int n = C - jb < 64 ? C - jb : 64;
+      for (int j = 0; j < n; j++) {
+        const int c0 = __builtin_amdgcn_readlane(b0, j), c1 = __builtin_amdgcn_readlane(b1, j), c2 = __builtin_amdgcn_readlane(b2, j);
+        const int c3 = __builtin_amdgcn_readlane(b3, j), c4 = __builtin_amdgcn_readlane(b4, j), c5 = __builtin_amdgcn_readlane(b5, j);
+        const bool inside = (a0 >= c0) & (a1 >= c1) & (a2 >= c2) & (a3 <= c3) & (a4 <= c4) & (a5 <= c5);
+        del |= inside & (jb + j != i);
+      }
     }
     uint64_t mk = __ballot(live && !del);
     if (lane == 0) { kmask[(base >> 6) * 2] = (uint32_t)mk; kmask[(base >> 6) * 2 + 1] = (uint32_t)(mk >> 32); }
@@ -1583,7 +1600,7 @@ pct_continuous_kernel(ContinuousParams p, const void* __restrict__ actions,
   }
   }  // step / reset
   if (requeue && lane == 0) p.retry_ids[atomicAdd(p.retry_count, 1)] = e;
-  work_key_end(smem, p.scalars, p.N, e, ACT == CACT_RESET);
+  work_key_end(smem, p.scalars, p.N, e, ACT == CACT_RESET, r.n_ems);
   __syncthreads();
   }  // work items
 }

@@ -134,8 +134,8 @@ struct ContinuousParams {
 // take a higher issue priority (s_setprio) so that they run at a lone wave's pace from the start while the light
 // waves of the same SIMD fill the gaps, instead of crawling at a quarter of it until the light ones are gone
 // (C2: 75.4 -> 71.2 us per launch).  prio_t: ascending EMS-count thresholds of priorities 1..3 (0: off).
-// Heavy-first dispatch: the sort key of env e (shader-clock cycles of its last step, low 32 bits of the counter: a step
-// is far shorter than their 1.8 s wrap) sits behind the [N, PCT_SCALARS] scalars; the step's start time is parked in the
+// Heavy-first dispatch: the sort key of env e (shader-clock cycles of its last step -- low 32 bits of the counter: a step
+// is far shorter than their 1.8 s wrap -- and its live EMS count) sits behind the [N, PCT_SCALARS] scalars; the step's start time is parked in the
 // first PCT_LDS_STASH bytes of the workgroup's LDS, in front of everything carve_lds / carve lay out.
 #define PCT_LDS_STASH 16
 __device__ __forceinline__ uint32_t* work_key_slot(int32_t* scalars, int N, int e) {
@@ -144,9 +144,13 @@ __device__ __forceinline__ uint32_t* work_key_slot(int32_t* scalars, int N, int 
 __device__ __forceinline__ void work_key_begin(unsigned char* smem) {
   if (threadIdx.x == 0) *reinterpret_cast<uint32_t*>(smem) = (uint32_t)__builtin_readcyclecounter();
 }
-__device__ __forceinline__ void work_key_end(unsigned char* smem, int32_t* scalars, int N, int e, bool reset) {
-  if (threadIdx.x == 0)
-    *work_key_slot(scalars, N, e) = reset ? 0u : (uint32_t)__builtin_readcyclecounter() - *reinterpret_cast<uint32_t*>(smem);
+// key word: cycles / 256 (20 bits, saturating) << 12 | live EMS count (12 bits, saturating); 0 after a reset
+__device__ __forceinline__ void work_key_end(unsigned char* smem, int32_t* scalars, int N, int e, bool reset, int n_ems) {
+  if (threadIdx.x == 0) {
+    const uint32_t cyc = ((uint32_t)__builtin_readcyclecounter() - *reinterpret_cast<uint32_t*>(smem)) >> 8;
+    const uint32_t ne = n_ems < 0 ? 0u : (uint32_t)n_ems;
+    *work_key_slot(scalars, N, e) = reset ? 0u : ((cyc > 0xFFFFFu ? 0xFFFFFu : cyc) << 12) | (ne > 0xFFFu ? 0xFFFu : ne);
+  }
 }
 __device__ __forceinline__ void wave_priority(int n_ems, const int prio_t[3]) {
   if (prio_t[0] <= 0) return;

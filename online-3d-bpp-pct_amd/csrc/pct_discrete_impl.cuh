@@ -2147,7 +2147,8 @@ enum { ACT_ROWS = 0, ACT_INDEX = 1, ACT_HASH = 2, ACT_RESET = 3, ACT_HEUR = 4 /*
 // one env, one launch's worth of transitions (the body of the kernel below)
 template <typename K, int BITS, int ACT, bool TIMED, bool STAB, int SCHEME, int RNG>
 __device__ __forceinline__ void discrete_env_steps(const DiscreteParams& p, const void* __restrict__ actions, int row_len, int n_steps,
-                                          int e, unsigned char* smem) {
+                                          int e, unsigned char* smem, int& ems_out) {
+  ems_out = 0;  // the live EMS count the env is left with (half of the heavy-first dispatch's sort key)
   const int lane = threadIdx.x;
   Lds<K, BITS> l = carve_lds<K, BITS>(p, smem + PCT_LDS_STASH);
   EnvRegs r;
@@ -2207,6 +2208,7 @@ __device__ __forceinline__ void discrete_env_steps(const DiscreteParams& p, cons
     }
     write_obs<K, BITS>(p, e, l, r, lane, obs, true, -1);
     store_state<K, BITS>(p, e, l, r, lane);
+    ems_out = r.n_ems;
     return;
   }
 
@@ -2254,6 +2256,7 @@ __device__ __forceinline__ void discrete_env_steps(const DiscreteParams& p, cons
     tm.tick(PH_OBS);
   }
   store_state<K, BITS>(p, e, l, r, lane);
+  ems_out = r.n_ems;
   tm.tick(PH_STORE);
   if (TIMED && lane == 0) tm.flush(p.timing + (size_t)e * PCT_TIMING_SLOTS, n_steps);
 }
@@ -2275,9 +2278,10 @@ pct_discrete_kernel(DiscreteParams p, const void* __restrict__ actions,
     for (int w = blockIdx.x; w < limit; w += gridDim.x) {
       const int e = __builtin_amdgcn_readfirstlane(p.retry_ids[w]);
       work_key_begin(smem);
-      discrete_env_steps<K, BITS, ACT, TIMED, STAB, SCHEME, RNG>(p, actions, row_len, n_steps, e, smem);
+      int n_ems = 0;
+      discrete_env_steps<K, BITS, ACT, TIMED, STAB, SCHEME, RNG>(p, actions, row_len, n_steps, e, smem, n_ems);
       // (the large-capacity run is what this env's next step will look like: its key replaces the normal pass's)
-      work_key_end(smem, p.scalars, p.N, e, false);
+      work_key_end(smem, p.scalars, p.N, e, false, n_ems);
       __syncthreads();
     }
     return;
@@ -2293,8 +2297,9 @@ pct_discrete_kernel(DiscreteParams p, const void* __restrict__ actions,
     e = __builtin_amdgcn_readfirstlane(p.order[e]);
   }
   work_key_begin(smem);
-  discrete_env_steps<K, BITS, ACT, TIMED, STAB, SCHEME, RNG>(p, actions, row_len, n_steps, e, smem);
-  work_key_end(smem, p.scalars, p.N, e, ACT == ACT_RESET);
+  int n_ems = 0;
+  discrete_env_steps<K, BITS, ACT, TIMED, STAB, SCHEME, RNG>(p, actions, row_len, n_steps, e, smem, n_ems);
+  work_key_end(smem, p.scalars, p.N, e, ACT == ACT_RESET, n_ems);
 }
 
 }  // namespace pct

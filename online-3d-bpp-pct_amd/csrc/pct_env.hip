@@ -71,6 +71,7 @@ struct pct_env {
   // heavy-first dispatch (pct_device.h: work_key / order)
   int order_state;      /* 0: not decided yet (first full launch), 1: on, -1: off */
   int32_t* d_order;     /* [N] */
+  int order_mode;       /* what the sort key is made of (pct_order_kernel) */
 
 };
 
@@ -132,22 +133,35 @@ int prof_begin(pct_env* h, hipStream_t s, size_t* slot) {
  * workgroup -> env map, longest first (one 1024-thread workgroup, a 256-bin counting sort -- a few microseconds), and
  * the step kernel looks its env up in it: longest-processing-time-first list scheduling.  Any bijection is a correct
  * placement, so the results do not depend on it. */
-__global__ void __launch_bounds__(1024) pct_order_kernel(const uint32_t* __restrict__ key, int32_t* __restrict__ order, int N) {
+__global__ void __launch_bounds__(1024) pct_order_kernel(const uint32_t* __restrict__ key, int32_t* __restrict__ order, int N, int mode) {
   __shared__ uint32_t hist[256];
   __shared__ uint32_t start[256];
-  __shared__ uint32_t smax;
+  __shared__ uint32_t cmax, emax;
   const int t = threadIdx.x;
   if (t < 256) hist[t] = 0;
-  if (t == 0) smax = 0;
+  if (t == 0) cmax = emax = 0;
   __syncthreads();
-  // (a running mean of the cycles instead of the last step's sorts no better: measured, profiles/r03_heavy_first.txt)
-  uint32_t m = 0;
-  for (int i = t; i < N; i += 1024) m = max(m, key[i]);
-  for (int o = 32; o; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
-  if ((t & 63) == 0) atomicMax(&smax, m);
+  // key word (pct_device.h work_key_end): cycles / 256 << 12 | live EMS count; the sort value is the sum of the two, each
+  // scaled to its maximum over the envs (mode 2, the default; 0: the cycles alone, 1: the EMS count alone -- measured:
+  // profiles/r03_heavy_first.txt), cut into 256 bins, bin 0 = the longest
+  uint32_t mc = 0, me = 0;
+  for (int i = t; i < N; i += 1024) {
+    const uint32_t k = key[i];
+    mc = max(mc, k >> 12);
+    me = max(me, k & 0xFFFu);
+  }
+  for (int o = 32; o; o >>= 1) {
+    mc = max(mc, (uint32_t)__shfl_xor((int)mc, o, 64));
+    me = max(me, (uint32_t)__shfl_xor((int)me, o, 64));
+  }
+  if ((t & 63) == 0) { atomicMax(&cmax, mc); atomicMax(&emax, me); }
   __syncthreads();
-  const uint64_t div = (uint64_t)smax + 1u;
-  auto bin = [&](uint32_t k) -> uint32_t { return 255u - (uint32_t)(((uint64_t)k << 8) / div); };  // bin 0 = the longest
+  const float wc = mode == 1 ? 0.f : (mode == 0 ? 255.9f : 127.95f) / (float)(cmax + 1u);
+  const float we = mode == 0 ? 0.f : (mode == 1 ? 255.9f : 127.95f) / (float)(emax + 1u);
+  auto bin = [&](uint32_t k) -> uint32_t {
+    const uint32_t v = k ? (uint32_t)((float)(k >> 12) * wc + (float)(k & 0xFFFu) * we) : 0u;  // (0: just reset)
+    return 255u - (v > 255u ? 255u : v);
+  };
   for (int i = t; i < N; i += 1024) atomicAdd(&hist[bin(key[i])], 1u);
   __syncthreads();
   if (t < 64) {  // exclusive prefix sum over the 256 bins: four per lane of one wave
@@ -185,6 +199,7 @@ int order_setup(pct_env* h) {
   if (!(ev && atoi(ev) > 0) && N <= resident) return PCT_OK;
   int rc = dev_alloc(h, (void**)&h->d_order, (size_t)N * sizeof(int32_t), true);
   if (rc) return rc;
+  h->order_mode = getenv("PCT_ORDER_MODE") ? atoi(getenv("PCT_ORDER_MODE")) : 2; /* kernel experiments only */
 
   h->order_state = 1;
   return PCT_OK;
@@ -203,7 +218,7 @@ int launch(pct_env* h, int act, const void* actions, int row_len, int n_steps, c
     const int N = h->continuous ? h->cp.N : h->dp.N;
     const int32_t* scalars = h->continuous ? h->cp.scalars : h->dp.scalars;
     hipLaunchKernelGGL(pct_order_kernel, dim3(1), dim3(1024), 0, s,
-                       reinterpret_cast<const uint32_t*>(scalars) + (size_t)N * PCT_SCALARS, h->d_order, N);
+                       reinterpret_cast<const uint32_t*>(scalars) + (size_t)N * PCT_SCALARS, h->d_order, N, h->order_mode);
     HIP_TRY(hipGetLastError());
     h->dp.order = h->cp.order = h->d_order;
   }

@@ -1,0 +1,10 @@
+run() {
+  timeout 250 python bench.py --workload $1 --envs-per-gpu $2 --steps $3 --warmup $4 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('MODE=$PCT_ORDER_MODE $1@$2 %.3f M/s ms/step %.4f kernel %.1f us' % (d['value']/1e6, d['ms_per_step'], d['roofline']['kernel_avg_us']))"
+}
+for m in 0 1 2; do export PCT_ORDER_MODE=$m
+  run c1 4096 300 100
+  run c3s1 4096 200 80
+  run c3 4096 500 100
+  run c5 2048 100 60
+  run c2 16384 500 100
+done 2>&1 | tee gpurun_out/order_mode.txt

@@ -64,3 +64,39 @@ for lo, hi in [(0, 5), (5, 19), (19, 77), (77, 150), (150, 307), (307, 2000)]:
     if m.any():
         print("  distinct in [%d,%d): %5.1f%% of steps, mean total %.0f, set %.0f" % (
             lo, hi, 100 * m.mean(), t[m].mean(), rec[:, :, 3].ravel()[m].mean()))
+
+# Heavy-first dispatch (pct_order_kernel): how long a launch is when S envs are resident at a time and the rest are handed
+# out, in a given order, as slots free up (greedy list scheduling on the measured cycles) -- in workgroup-id order, sorted
+# by the previous step's cycles (what the kernel does), by the previous step's EMS count, and by the step's own cycles
+# (the best any predictor could do); lower bound max(sum / S, max).
+import heapq
+SLOTS = int(os.environ.get("PCT_PROFILE_SLOTS", "0")) or {"c1": 1024, "c3": 2816, "c5": 1280}.get(MODE, N)
+
+
+def makespan(cost, order, S):
+    heap = [0.0] * S
+    for e in order:
+        heapq.heappush(heap, heapq.heappop(heap) + cost[e])
+    return max(heap)
+
+
+if SLOTS < N:
+    res = {"id order": [], "prev cycles": [], "prev EMS": [], "prev cycles x EMS": [], "rank sum of both": [],
+           "2-step mean cycles": [], "own cycles (ideal)": [], "lower bound": []}
+    cc = []
+    for s in range(1, K):
+        cost, prev = tot[s], tot[s - 1]
+        cc.append(np.corrcoef(cost, prev)[0, 1])
+        res["id order"].append(makespan(cost, np.arange(N), SLOTS))
+        res["prev cycles"].append(makespan(cost, np.argsort(-prev, kind="stable"), SLOTS))
+        res["prev EMS"].append(makespan(cost, np.argsort(-rec[s - 1, :, 12], kind="stable"), SLOTS))
+        res["prev cycles x EMS"].append(makespan(cost, np.argsort(-prev * (1 + rec[s - 1, :, 12]), kind="stable"), SLOTS))
+        rk = np.argsort(np.argsort(prev)) + np.argsort(np.argsort(rec[s - 1, :, 12]))
+        res["rank sum of both"].append(makespan(cost, np.argsort(-rk, kind="stable"), SLOTS))
+        res["2-step mean cycles"].append(makespan(cost, np.argsort(-(prev + tot[max(s - 2, 0)]), kind="stable"), SLOTS))
+        res["own cycles (ideal)"].append(makespan(cost, np.argsort(-cost, kind="stable"), SLOTS))
+        res["lower bound"].append(max(cost.sum() / SLOTS, cost.max()))
+    print("  list scheduling on %d slots (one wave each; timed build), launch length in k cycles, mean over %d launches:" % (SLOTS, K - 1))
+    for k, v in res.items():
+        print("    %-20s %8.1f" % (k, np.mean(v) / 1e3))
+    print("    correlation of an env's cycles with its previous step's: %.2f" % np.mean(cc))
