@@ -27,12 +27,38 @@ def _hipcc():
     raise RuntimeError("hipcc not found: cannot build the gfx950 library")
 
 
+_IMPL = ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_mt.cuh", "pct_discrete_impl.cuh"]
+# which headers a translation unit includes (a change elsewhere does not recompile it)
+DEPS = {"pct_env.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh"],
+        "pct_discrete.hip": _IMPL, "pct_discrete_stab.hip": _IMPL, "pct_discrete_u64.hip": _IMPL, "pct_discrete_u64_stab.hip": _IMPL,
+        "pct_discrete_mt.hip": _IMPL, "pct_discrete_stab_mt.hip": _IMPL, "pct_discrete_u64_mt.hip": _IMPL,
+        "pct_discrete_u64_stab_mt.hip": _IMPL,
+        "pct_continuous.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_mt.cuh"],
+        "pct_continuous_mt.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_mt.cuh", "pct_continuous.hip"]}
+
+
+def _tu_inputs(src):
+    return [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in DEPS[src]] + [
+        os.path.join(HERE, "..", "include", "pct_env.h"), os.path.abspath(__file__)]  # (this file holds the flags)
+
+
+def _obj(src):
+    return os.path.join(HERE, "build", os.path.splitext(src)[0] + ".o")
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    if any(os.path.getmtime(d) > t for d in deps):
+        return True
+    # a source edited while a build was running is older than the library that build linked, but newer than the object
+    # it was compiled into (objects stay in the build container; where there are none the library's own time decides)
+    for src in SOURCES:
+        if os.path.exists(_obj(src)) and any(os.path.getmtime(d) > os.path.getmtime(_obj(src)) for d in _tu_inputs(src)):
+            return True
+    return False
 
 
 def build_library(force=False, verbose=False):
@@ -50,23 +76,9 @@ def build_library(force=False, verbose=False):
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
 
-    # which headers a translation unit includes (a change elsewhere does not recompile it)
-    deps = {"pct_env.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh"],
-            "pct_discrete.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_mt.cuh", "pct_discrete_impl.cuh"],
-            "pct_discrete_stab.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_mt.cuh", "pct_discrete_impl.cuh"],
-            "pct_discrete_u64.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_mt.cuh", "pct_discrete_impl.cuh"],
-            "pct_discrete_u64_stab.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_mt.cuh", "pct_discrete_impl.cuh"],
-            "pct_discrete_mt.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_mt.cuh", "pct_discrete_impl.cuh"],
-            "pct_discrete_stab_mt.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_mt.cuh", "pct_discrete_impl.cuh"],
-            "pct_discrete_u64_mt.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_mt.cuh", "pct_discrete_impl.cuh"],
-            "pct_discrete_u64_stab_mt.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_mt.cuh", "pct_discrete_impl.cuh"],
-            "pct_continuous.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_mt.cuh"],
-            "pct_continuous_mt.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_mt.cuh", "pct_continuous.hip"]}
-
     def compile_one(src):
-        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
-        srcs = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in deps[src]] + [
-            os.path.join(HERE, "..", "include", "pct_env.h"), os.path.abspath(__file__)]  # (this file holds the flags)
+        obj = _obj(src)
+        srcs = _tu_inputs(src)
         if not force and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in srcs):
             return obj
         cmd = [_hipcc(), *flags, "-Wno-pass-failed", "-c", os.path.join(CSRC, src), "-o", obj]

@@ -1868,19 +1868,22 @@ __device__ __forceinline__ bool heur_choose(const DiscreteParams& p, int e, Lds<
     // below the heightmap, so (i, j) is empty at level h iff hmap[i][j] <= h -- one row mask per
     // (level, row), built once per step in the idle table region; the candidate's footprint is cleared
     // from the rows it covers.  Largest rectangle of a level: for every band of rows i1..i2 the AND of
-    // their masks, times the longest run of ones (Ly <= 32, checked by the host).
-    uint32_t* rows = scratch;  // [H][W]
-    for (int c = lane; c < p.H * p.W; c += 64) {
-      const int lv = c / p.W, i = c - lv * p.W;
-      uint32_t m = 0;
-      for (int j = 0; j < p.Ly; j++) m |= ((int)l.hmap[i * p.A + j] <= lv) ? (1u << j) : 0u;
-      rows[c] = m;
-    }
-    __syncthreads();
-    const int NC = NQ * 4;
-    for (int base = 0; base < NC; base += 64) {
-      int qc = base + lane;
-      {
+    // their masks, times the longest run of ones.
+    // Row masks are 32 bits wide for Ly <= 32 and 64 bits wide up to Ly = 64 (checked by the host).
+    auto macs = [&](auto mask_tag) __attribute__((always_inline)) {
+      typedef decltype(mask_tag) M;
+      constexpr int MB = (int)sizeof(M) * 8;
+      M* rows = reinterpret_cast<M*>(scratch);  // [H][W]
+      for (int c = lane; c < p.H * p.W; c += 64) {
+        const int lv = c / p.W, i = c - lv * p.W;
+        M m = 0;
+        for (int j = 0; j < p.Ly; j++) m |= ((int)l.hmap[i * p.A + j] <= lv) ? ((M)1 << j) : (M)0;
+        rows[c] = m;
+      }
+      __syncthreads();
+      const int NC = NQ * 4;
+      for (int base = 0; base < NC; base += 64) {
+        int qc = base + lane;
         const bool live = qc < NC;
         int q = qc >> 2, corner = qc & 3;
         int ei = q / orient, rot = q - ei * orient;
@@ -1892,19 +1895,20 @@ __device__ __forceinline__ bool heur_choose(const DiscreteParams& p, int e, Lds<
         int lx = (corner & 1) ? P::get(ek, 3) - x : P::get(ek, 0);
         int ly = (corner & 2) ? P::get(ek, 4) - y : P::get(ek, 1);
         if (probe(live && dx >= x && dy >= y && dz >= z, x, y, z, lx, ly, mh, under)) {
-          const uint32_t foot = ((y >= 32 ? 0u : (1u << y)) - 1u) << ly;
+          const M foot = (M)((y >= MB ? (M)0 : ((M)1 << y)) - (M)1) << ly;
           uint32_t score = 0;
           for (int lv = 0; lv < mh; lv++) {
-            const uint32_t* rw = rows + lv * p.W;
+            const M* rw = rows + lv * p.W;
             uint32_t level_max = 0;
             for (int i1 = 0; i1 < p.W; i1++) {
-              uint32_t band = 0xFFFFFFFFu;
+              M band = ~(M)0;
               for (int i2 = i1; i2 < p.W; i2++) {
-                uint32_t rm = rw[i2];
+                M rm = rw[i2];
                 if (i2 >= lx && i2 < lx + x) rm &= ~foot;
                 band &= rm;
                 if (!band) break;
-                uint32_t t = band, run = 0;
+                M t = band;
+                uint32_t run = 0;
                 while (t) { t &= t << 1; run++; }
                 const uint32_t area = run * (uint32_t)(i2 - i1 + 1);
                 level_max = area > level_max ? area : level_max;
@@ -1916,7 +1920,9 @@ __device__ __forceinline__ bool heur_choose(const DiscreteParams& p, int e, Lds<
           best = key < best ? key : best;
         }
       }
-    }
+    };
+    if (p.Ly <= 32) macs((uint32_t)0);
+    else macs((uint64_t)0);
     best = wave_min_u64(best);
     __syncthreads();
     if (best == NONE) return false;

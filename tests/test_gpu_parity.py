@@ -531,6 +531,33 @@ def test_hip_heuristics_match_oracle_batched(heur, setting):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("setting,container", [(2, (9, 40, 8)), (1, (8, 36, 9)), (2, (7, 64, 6))])
+def test_hip_macs_wide_bins_match_oracle(setting, container):
+    """MACS (heuristic.py:11-136) in bins wider than 32 cells along y: the level row masks are 64 bits wide there (and the
+    candidate keys 64 bits: the other half of the heuristic kernels)"""
+    from oracle.oracle_lib import OracleVecEnv
+    from tests.common import HEUR_CODE
+    N, items = 16, item_set_range(2, 6)
+    kw = dict(setting=setting, container_size=container, item_set=items, internal_node_holder=120, leaf_node_holder=30,
+              env_id_base=3)
+    ora = OracleVecEnv(N, threads=16, **kw)
+    ora.set_sampler(8)
+    env = _pkg().PctVecEnv(N, seed=8, device="cuda:0", **kw)
+    ora.reset()
+    obs = env.reset()
+    for t in range(40):
+        assert np.array_equal(obs.cpu().numpy(), ora.obs.astype(np.float32)), (container, t)
+        env.step_heuristic("MACS", 1)
+        ora.step_heuristic(HEUR_CODE["MACS"], 1)
+        obs, reward, done, infos = env.step_wait()
+        assert np.array_equal(done.astype(np.uint8), ora.done), (container, t)
+        assert np.array_equal(reward[:, 0].numpy(), ora.reward.astype(np.float32))
+    assert not env.error_flags.any() and not ora.flags.any()
+    env.close()
+    ora.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["discrete", "continuous"])
 def test_hip_observation_is_rewritten_in_full_after_rebinding_the_buffer(kind):
     """Between steps the kernel only rewrites the rows that changed (new box row, leaf rows, next
