@@ -72,12 +72,8 @@ struct pct_env {
   int order_state;      /* 0: not decided yet (first full launch), 1: on, -1: off */
   int32_t* d_order;     /* [N] */
   int order_mode;       /* what the sort key is made of (pct_order_kernel) */
-  /* the sort runs AHEAD, on a stream of its own, as soon as a step's kernels have left their keys: it overlaps whatever
-   * the caller does between two steps (the policy) instead of sitting in front of the next step kernel */
-  hipStream_t order_stream;
-  hipEvent_t ev_keys, ev_order;
-  bool order_ahead;     /* side stream in use (PCT_ORDER_AHEAD=0: sort inline, in front of the step kernel) */
-  bool order_pending;   /* d_order is being / has been computed on order_stream from the latest keys */
+  /* (Sorting AHEAD on a stream of its own, overlapping the caller's policy, was tried: the two cross-stream event waits per
+   * step cost ~20 us, five times what the in-line sort kernel takes -- profiles/r03_heavy_first.txt.) */
 
 };
 
@@ -206,13 +202,6 @@ int order_setup(pct_env* h) {
   int rc = dev_alloc(h, (void**)&h->d_order, (size_t)N * sizeof(int32_t), true);
   if (rc) return rc;
   h->order_mode = getenv("PCT_ORDER_MODE") ? atoi(getenv("PCT_ORDER_MODE")) : 2; /* kernel experiments only */
-  h->order_ahead = !(getenv("PCT_ORDER_AHEAD") && atoi(getenv("PCT_ORDER_AHEAD")) == 0);
-  h->order_pending = false;
-  if (h->order_ahead) {
-    HIP_TRY(hipStreamCreateWithFlags(&h->order_stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&h->ev_keys, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&h->ev_order, hipEventDisableTiming));
-  }
 
   h->order_state = 1;
   return PCT_OK;
@@ -225,17 +214,6 @@ hipError_t order_launch(pct_env* h, hipStream_t s) {
                      reinterpret_cast<const uint32_t*>(scalars) + (size_t)N * PCT_SCALARS, h->d_order, N, h->order_mode);
   return hipGetLastError();
 }
-/* after a step's kernels (which wrote the keys) are in the stream: sort for the next step on the side stream */
-int order_ahead(pct_env* h, hipStream_t s, bool capturing) {
-  if (!h->order_ahead || capturing) return PCT_OK;
-  HIP_TRY(hipEventRecord(h->ev_keys, s));
-  HIP_TRY(hipStreamWaitEvent(h->order_stream, h->ev_keys, 0));
-  HIP_TRY(order_launch(h, h->order_stream));
-  HIP_TRY(hipEventRecord(h->ev_order, h->order_stream));
-  h->order_pending = true;
-  return PCT_OK;
-}
-
 int launch(pct_env* h, int act, const void* actions, int row_len, int n_steps, const int32_t* ids, int n_ids,
            void* stream) {
   hipStream_t s = (hipStream_t)stream;
@@ -245,17 +223,8 @@ int launch(pct_env* h, int act, const void* actions, int row_len, int n_steps, c
     if (rc) return rc;
   }
   h->dp.order = h->cp.order = nullptr;
-  const bool ordered = h->order_state == 1 && act != ACT_RESET && !ids;
-  bool capturing = false;
-  if (ordered) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (h->order_ahead && hipStreamIsCapturing(s, &cs) == hipSuccess) capturing = cs != hipStreamCaptureStatusNone;
-    if (h->order_ahead && h->order_pending && !capturing) {
-      HIP_TRY(hipStreamWaitEvent(s, h->ev_order, 0)); /* sorted while the caller was busy */
-    } else {
-      HIP_TRY(order_launch(h, s));
-    }
-    h->order_pending = false;
+  if (h->order_state == 1 && act != ACT_RESET && !ids) {
+    HIP_TRY(order_launch(h, s));
     h->dp.order = h->cp.order = h->d_order;
   }
   if (h->profiling) {
@@ -306,7 +275,6 @@ int launch(pct_env* h, int act, const void* actions, int row_len, int n_steps, c
     }
     if (act != ACT_RESET || !ids) h->dp.full_obs = 0; /* every env has rewritten its rows */
   }
-  if (ordered) return order_ahead(h, s, capturing);
   return PCT_OK;
 }
 /* Stability capacities (pct_stab.cuh).  Normal pass: one pool entry and two polygon vertices per internal node (measured
@@ -440,8 +408,6 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
   h->prof_ms = 0.0;
   h->timing_buf = nullptr;
   h->order_state = 0;
-  h->order_ahead = false;
-  h->order_pending = false;
   h->d_order = nullptr;
   h->continuous = cont;
   h->has_dretry = false;
@@ -699,11 +665,6 @@ int pct_destroy(pct_env* h) {
   (void)hipDeviceSynchronize();
   for (void* q : h->owned) (void)hipFree(q);
   for (auto& ev : h->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-  if (h->order_state == 1 && h->order_ahead) {
-    (void)hipStreamDestroy(h->order_stream);
-    (void)hipEventDestroy(h->ev_keys);
-    (void)hipEventDestroy(h->ev_order);
-  }
   delete h;
   return PCT_OK;
 }
