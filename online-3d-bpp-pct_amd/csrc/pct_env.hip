@@ -142,12 +142,24 @@ __global__ void __launch_bounds__(1024) pct_order_kernel(const uint32_t* __restr
   const int t = threadIdx.x;
   if (t < 256) hist[t] = 0;
   if (t == 0) cmax = emax = 0;
-  __syncthreads();
   // key word (pct_device.h work_key_end): cycles / 256 << 12 | live EMS count; the sort value is the sum of the two, each
   // scaled to its maximum over the envs (mode 2, the default; 0: the cycles alone, 1: the EMS count alone -- measured:
-  // profiles/r03_heavy_first.txt), cut into 256 bins, bin 0 = the longest
+  // profiles/r03_heavy_first.txt), cut into 256 bins, bin 0 = the longest.  Up to 16 keys per thread (N <= 16 384) stay
+  // in registers over the three passes -- maxima, histogram, scatter; a larger N re-reads the rest from memory.
+  constexpr int R = 16;
+  uint32_t kr[R];
+#pragma unroll
+  for (int j = 0; j < R; j++) {
+    const int i = t + j * 1024;
+    kr[j] = i < N ? key[i] : 0u;
+  }
   uint32_t mc = 0, me = 0;
-  for (int i = t; i < N; i += 1024) {
+#pragma unroll
+  for (int j = 0; j < R; j++) {
+    mc = max(mc, kr[j] >> 12);
+    me = max(me, kr[j] & 0xFFFu);
+  }
+  for (int i = t + R * 1024; i < N; i += 1024) {
     const uint32_t k = key[i];
     mc = max(mc, k >> 12);
     me = max(me, k & 0xFFFu);
@@ -156,6 +168,7 @@ __global__ void __launch_bounds__(1024) pct_order_kernel(const uint32_t* __restr
     mc = max(mc, (uint32_t)__shfl_xor((int)mc, o, 64));
     me = max(me, (uint32_t)__shfl_xor((int)me, o, 64));
   }
+  __syncthreads();
   if ((t & 63) == 0) { atomicMax(&cmax, mc); atomicMax(&emax, me); }
   __syncthreads();
   const float wc = mode == 1 ? 0.f : (mode == 0 ? 255.9f : 127.95f) / (float)(cmax + 1u);
@@ -164,7 +177,10 @@ __global__ void __launch_bounds__(1024) pct_order_kernel(const uint32_t* __restr
     const uint32_t v = k ? (uint32_t)((float)(k >> 12) * wc + (float)(k & 0xFFFu) * we) : 0u;  // (0: just reset)
     return 255u - (v > 255u ? 255u : v);
   };
-  for (int i = t; i < N; i += 1024) atomicAdd(&hist[bin(key[i])], 1u);
+#pragma unroll
+  for (int j = 0; j < R; j++)
+    if (t + j * 1024 < N) atomicAdd(&hist[bin(kr[j])], 1u);
+  for (int i = t + R * 1024; i < N; i += 1024) atomicAdd(&hist[bin(key[i])], 1u);
   __syncthreads();
   if (t < 64) {  // exclusive prefix sum over the 256 bins: four per lane of one wave
     const uint32_t a = hist[4 * t], b = hist[4 * t + 1], c = hist[4 * t + 2], d = hist[4 * t + 3];
@@ -180,7 +196,10 @@ __global__ void __launch_bounds__(1024) pct_order_kernel(const uint32_t* __restr
     start[4 * t + 3] = excl + a + b + c;
   }
   __syncthreads();
-  for (int i = t; i < N; i += 1024) order[atomicAdd(&start[bin(key[i])], 1u)] = i;
+#pragma unroll
+  for (int j = 0; j < R; j++)
+    if (t + j * 1024 < N) order[atomicAdd(&start[bin(kr[j])], 1u)] = t + j * 1024;
+  for (int i = t + R * 1024; i < N; i += 1024) order[atomicAdd(&start[bin(key[i])], 1u)] = i;
 }
 
 int order_setup(pct_env* h) {
