@@ -225,3 +225,38 @@ def test_hip_numpy_stream_batched_vs_oracle():
             assert np.array_equal(reward[:, 0].numpy(), ora.reward.astype(np.float32))
         assert not env.error_flags.any()
         env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["discrete", "continuous"])
+def test_hip_numpy_stream_with_heavy_first_dispatch(kind, monkeypatch):
+    """strict mode under the heavy-first dispatch (forced on: PCT_ORDER=1): the env's MT19937 state travels with the env id,
+    not with the workgroup that happens to step it; multi-step launches included"""
+    from oracle.oracle_lib import OracleVecEnv
+    pkg = importlib.import_module("online-3d-bpp-pct_amd")
+    monkeypatch.setenv("PCT_ORDER", "1")
+    N = 384
+    if kind == "discrete":
+        kw = dict(setting=3, container_size=(10, 10, 10), item_set=item_set_range(1, 5), internal_node_holder=80,
+                  leaf_node_holder=50, env_id_base=9, shuffle=True)
+        env = pkg.PctVecEnv(N, rng="numpy", seed=21, device="cuda:0", **kw)
+        ora = OracleVecEnv(N, threads=16, **kw)
+        ora.set_numpy_rng(21)
+    else:
+        kw = dict(setting=2, container_size=(10, 10, 10), internal_node_holder=80, leaf_node_holder=50, env_id_base=9, shuffle=True)
+        env = pkg.PctVecEnv(N, rng="numpy", seed=21, device="cuda:0", continuous=True, sample_left_bound=1.0,
+                            sample_right_bound=5.0, **kw)
+        ora = OracleVecEnv(N, threads=16, env_kind=1, sample_bounds=(1.0, 5.0), **kw)
+        ora.set_numpy_rng(21, n_item_set=GIVEN_ITEM_COUNT)
+    obs = env.reset()
+    ora.reset()
+    for t in range(40):
+        n = 3 if t % 7 == 6 else 1
+        env.step_hash_policy(n)
+        ora.step_hash_policy(n)
+        obs, reward, done, infos = env.step_wait()
+        assert np.array_equal(done.astype(np.uint8), ora.done), (kind, t)
+        assert np.array_equal(obs.cpu().numpy(), ora.obs.astype(np.float32)), (kind, t)
+    assert not env.error_flags.any()
+    env.close()
+    ora.close()
