@@ -368,37 +368,73 @@ __device__ __forceinline__ void cgenems(const ContinuousParams& p, CLds& l, CReg
       a0 = l.emsb[0 * scap + i]; a1 = l.emsb[1 * scap + i]; a2 = l.emsb[2 * scap + i];
       a3 = l.emsb[3 * scap + i]; a4 = l.emsb[4 * scap + i]; a5 = l.emsb[5 * scap + i];
     }
-    // Each test is `a inside b` for a wave-uniform b: the 64 b of a chunk sit one per lane in registers and reach
-    // the comparison through readlane (scalar operands) -- no LDS round trip inside the pair loop.
-    bool del = false;
-    for (int jb = 0; jb < E; jb += 64) {
-      const int jj = jb + lane;
-      const bool jl = jj < E;
-      const int b0 = jl ? l.emsk[0 * cap + jj] : 0, b1 = jl ? l.emsk[1 * cap + jj] : 0, b2 = jl ? l.emsk[2 * cap + jj] : 0;
-      const int b3 = jl ? l.emsk[3 * cap + jj] : 0, b4 = jl ? l.emsk[4 * cap + jj] : 0, b5 = jl ? l.emsk[5 * cap + jj] : 0;
-      uint64_t sm = ((uint64_t)smask[(jb >> 6) * 2 + 1] << 32) | smask[(jb >> 6) * 2];  // survivors only (wave-uniform)
-      while (sm) {
-        const int j = __ffsll((unsigned long long)sm) - 1;
-        sm &= sm - 1;
-        const int c0 = __builtin_amdgcn_readlane(b0, j), c1 = __builtin_amdgcn_readlane(b1, j), c2 = __builtin_amdgcn_readlane(b2, j);
-        const int c3 = __builtin_amdgcn_readlane(b3, j), c4 = __builtin_amdgcn_readlane(b4, j), c5 = __builtin_amdgcn_readlane(b5, j);
-        del |= (a0 >= c0) & (a1 >= c1) & (a2 >= c2) & (a3 <= c3) & (a4 <= c4) & (a5 <= c5);
+    uint64_t mk;
+    if (C + E <= 128) {
+      // Short lists: each test is `a inside b` for a wave-uniform b: the 64 b of a chunk sit one per lane in registers and reach
+      // the comparison through readlane (scalar operands) -- no LDS round trip inside the pair loop.
+      bool del = false;
+      for (int jb = 0; jb < E; jb += 64) {
+        const int jj = jb + lane;
+        const bool jl = jj < E;
+        const int b0 = jl ? l.emsk[0 * cap + jj] : 0, b1 = jl ? l.emsk[1 * cap + jj] : 0, b2 = jl ? l.emsk[2 * cap + jj] : 0;
+        const int b3 = jl ? l.emsk[3 * cap + jj] : 0, b4 = jl ? l.emsk[4 * cap + jj] : 0, b5 = jl ? l.emsk[5 * cap + jj] : 0;
+        uint64_t sm = ((uint64_t)smask[(jb >> 6) * 2 + 1] << 32) | smask[(jb >> 6) * 2];  // survivors only (wave-uniform)
+        while (sm) {
+          const int j = __ffsll((unsigned long long)sm) - 1;
+          sm &= sm - 1;
+          const int c0 = __builtin_amdgcn_readlane(b0, j), c1 = __builtin_amdgcn_readlane(b1, j), c2 = __builtin_amdgcn_readlane(b2, j);
+          const int c3 = __builtin_amdgcn_readlane(b3, j), c4 = __builtin_amdgcn_readlane(b4, j), c5 = __builtin_amdgcn_readlane(b5, j);
+          del |= (a0 >= c0) & (a1 >= c1) & (a2 >= c2) & (a3 <= c3) & (a4 <= c4) & (a5 <= c5);
+        }
       }
-    }
-    for (int jb = 0; jb < C; jb += 64) {
-      const int jj = jb + lane;
-      const bool jl = jj < C;
-      const int b0 = jl ? l.emsb[0 * scap + jj] : 0, b1 = jl ? l.emsb[1 * scap + jj] : 0, b2 = jl ? l.emsb[2 * scap + jj] : 0;
-      const int b3 = jl ? l.emsb[3 * scap + jj] : 0, b4 = jl ? l.emsb[4 * scap + jj] : 0, b5 = jl ? l.emsb[5 * scap + jj] : 0;
-      const int n = C - jb < 64 ? C - jb : 64;
-      for (int j = 0; j < n; j++) {
-        const int c0 = __builtin_amdgcn_readlane(b0, j), c1 = __builtin_amdgcn_readlane(b1, j), c2 = __builtin_amdgcn_readlane(b2, j);
-        const int c3 = __builtin_amdgcn_readlane(b3, j), c4 = __builtin_amdgcn_readlane(b4, j), c5 = __builtin_amdgcn_readlane(b5, j);
-        const bool inside = (a0 >= c0) & (a1 >= c1) & (a2 >= c2) & (a3 <= c3) & (a4 <= c4) & (a5 <= c5);
-        del |= inside & (jb + j != i);
+      for (int jb = 0; jb < C; jb += 64) {
+        const int jj = jb + lane;
+        const bool jl = jj < C;
+        const int b0 = jl ? l.emsb[0 * scap + jj] : 0, b1 = jl ? l.emsb[1 * scap + jj] : 0, b2 = jl ? l.emsb[2 * scap + jj] : 0;
+        const int b3 = jl ? l.emsb[3 * scap + jj] : 0, b4 = jl ? l.emsb[4 * scap + jj] : 0, b5 = jl ? l.emsb[5 * scap + jj] : 0;
+        const int n = C - jb < 64 ? C - jb : 64;
+        for (int j = 0; j < n; j++) {
+          const int c0 = __builtin_amdgcn_readlane(b0, j), c1 = __builtin_amdgcn_readlane(b1, j), c2 = __builtin_amdgcn_readlane(b2, j);
+          const int c3 = __builtin_amdgcn_readlane(b3, j), c4 = __builtin_amdgcn_readlane(b4, j), c5 = __builtin_amdgcn_readlane(b5, j);
+          const bool inside = (a0 >= c0) & (a1 >= c1) & (a2 >= c2) & (a3 <= c3) & (a4 <= c4) & (a5 <= c5);
+          del |= inside & (jb + j != i);
+        }
       }
+      mk = __ballot(live && !del);
+    } else {
+      // Long lists (C5): `a inside b`, one child a at a time against 64 b held one per lane: a's coordinates come out of the chunk's registers
+      // through readlane (scalar operands, no LDS round trip in the pair loop), and a child STOPS at its first container.
+      // The other children go first: at C5 two of three children are deleted, 93 % of those by another child (the children
+      // of overlapping parents nest) -- half a scan on average instead of the whole list.
+      uint64_t pend = __ballot(live);  // children of this chunk not (yet) found inside another box
+      auto sweep = [&](bool jl, int jidx, int b0, int b1, int b2, int b3, int b4, int b5) __attribute__((always_inline)) {
+        uint64_t todo = pend;
+        while (todo) {
+          const int ai = __ffsll((unsigned long long)todo) - 1;
+          todo &= todo - 1;
+          const int c0 = __builtin_amdgcn_readlane(a0, ai), c1 = __builtin_amdgcn_readlane(a1, ai), c2 = __builtin_amdgcn_readlane(a2, ai);
+          const int c3 = __builtin_amdgcn_readlane(a3, ai), c4 = __builtin_amdgcn_readlane(a4, ai), c5 = __builtin_amdgcn_readlane(a5, ai);
+          const bool cont = jl & (c0 >= b0) & (c1 >= b1) & (c2 >= b2) & (c3 <= b3) & (c4 <= b4) & (c5 <= b5) & (jidx != base + ai);
+          if (__ballot(cont)) pend &= ~(1ull << ai);
+        }
+      };
+      for (int jb = 0; jb < C && pend; jb += 64) {
+        const int jj = jb + lane;
+        const bool jl = jj < C;
+        const int b0 = jl ? l.emsb[0 * scap + jj] : 0, b1 = jl ? l.emsb[1 * scap + jj] : 0, b2 = jl ? l.emsb[2 * scap + jj] : 0;
+        const int b3 = jl ? l.emsb[3 * scap + jj] : 0, b4 = jl ? l.emsb[4 * scap + jj] : 0, b5 = jl ? l.emsb[5 * scap + jj] : 0;
+        sweep(jl, jj, b0, b1, b2, b3, b4, b5);
+      }
+      for (int jb = 0; jb < E && pend; jb += 64) {
+        const int jj = jb + lane;
+        const uint64_t sm = ((uint64_t)smask[(jb >> 6) * 2 + 1] << 32) | smask[(jb >> 6) * 2];  // survivors only
+        const bool jl = (sm >> lane) & 1ull;
+        const int b0 = jl ? l.emsk[0 * cap + jj] : 0, b1 = jl ? l.emsk[1 * cap + jj] : 0, b2 = jl ? l.emsk[2 * cap + jj] : 0;
+        const int b3 = jl ? l.emsk[3 * cap + jj] : 0, b4 = jl ? l.emsk[4 * cap + jj] : 0, b5 = jl ? l.emsk[5 * cap + jj] : 0;
+        sweep(jl, -1, b0, b1, b2, b3, b4, b5);
+      }
+      mk = pend;
     }
-    uint64_t mk = __ballot(live && !del);
     if (lane == 0) { kmask[(base >> 6) * 2] = (uint32_t)mk; kmask[(base >> 6) * 2 + 1] = (uint32_t)(mk >> 32); }
   }
   __syncthreads();

@@ -17,6 +17,9 @@ if MODE == "c5":
                         ems_capacity=384, candidate_capacity=8192)
 elif MODE == "c1":
     env = pkg.PctVecEnv(N, setting=1, item_set=items, seed=4, device="cuda:0", monitor=False)
+elif MODE == "c3s1":
+    env = pkg.PctVecEnv(N, continuous=True, setting=1, container_size=(1, 1, 1), sample_left_bound=0.1, sample_right_bound=0.5,
+                        seed=4, device="cuda:0", monitor=False)
 elif MODE == "c3":
     env = pkg.PctVecEnv(N, continuous=True, sample_left_bound=1.0, sample_right_bound=5.0, seed=4, device="cuda:0", monitor=False)
 else:
@@ -65,12 +68,19 @@ for lo, hi in [(0, 5), (5, 19), (19, 77), (77, 150), (150, 307), (307, 2000)]:
         print("  distinct in [%d,%d): %5.1f%% of steps, mean total %.0f, set %.0f" % (
             lo, hi, 100 * m.mean(), t[m].mean(), rec[:, :, 3].ravel()[m].mean()))
 
+# the single slowest env-steps of the whole run (what a rare long launch is made of)
+flat = tot.ravel()
+for idx in np.argsort(-flat)[:5]:
+    si, ei = divmod(int(idx), N)
+    print("  slowest env-step: step %d env %d: %.0f cycles = %.0f us;" % (si, ei, flat[idx], flat[idx] / 2390),
+          " ".join("%s %.0f" % (n, rec[si, ei, i]) for i, n in enumerate(names)), "EMS %d boxes? distinct %d" % (rec[si, ei, 12], rec[si, ei, 13]))
+
 # Heavy-first dispatch (pct_order_kernel): how long a launch is when S envs are resident at a time and the rest are handed
 # out, in a given order, as slots free up (greedy list scheduling on the measured cycles) -- in workgroup-id order, sorted
 # by the previous step's cycles (what the kernel does), by the previous step's EMS count, and by the step's own cycles
 # (the best any predictor could do); lower bound max(sum / S, max).
 import heapq
-SLOTS = int(os.environ.get("PCT_PROFILE_SLOTS", "0")) or {"c1": 1024, "c3": 2816, "c5": 1280}.get(MODE, N)
+SLOTS = int(os.environ.get("PCT_PROFILE_SLOTS", "0")) or {"c1": 1024, "c3s1": 1024, "c3": 2816, "c5": 1280}.get(MODE, N)
 
 
 def makespan(cost, order, S):
