@@ -777,6 +777,12 @@ NUMPY_STREAM_CASES = {
     "discrete_s2_numpy_stream_u64": dict(setting=2, container=(40, 40, 40), lo=4, hi=20, I=80, L=50, N=4, steps=200, seed=48, base=0),
     "discrete_s1_numpy_stream_u64": dict(setting=1, container=(40, 40, 40), lo=4, hi=20, I=80, L=50, N=3, steps=160, seed=49, base=2),
     "discrete_s2_numpy_stream_u64_cp": dict(setting=2, container=(40, 40, 40), lo=4, hi=20, I=80, L=50, N=3, steps=160, seed=50, base=1, lnes="CP"),
+    "discrete_s3_numpy_stream_fc": dict(setting=3, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, N=3, steps=120, seed=71, base=2, lnes="FC"),
+    "discrete_s1_numpy_stream_ep": dict(setting=1, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, N=3, steps=160, seed=72, base=0, lnes="EP"),
+    "discrete_s1_numpy_stream_ev": dict(setting=1, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, N=3, steps=100, seed=73, base=5, lnes="EV"),
+    "discrete_s3_numpy_stream_cp": dict(setting=3, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, N=3, steps=160, seed=74, base=1, lnes="CP"),
+    "discrete_s3_numpy_stream_u64": dict(setting=3, container=(40, 40, 40), lo=4, hi=20, I=80, L=50, N=3, steps=160, seed=75, base=3),
+    "discrete_s1_numpy_stream_u64_ep": dict(setting=1, container=(36, 40, 33), lo=4, hi=18, I=80, L=50, N=3, steps=140, seed=76, base=0, lnes="EP"),
     # continuous env, sample_from_distribution=True (the CLI's --continuous default, main.py / arguments.py):
     # items round(np.random.uniform(a, b), 3), z from np.random.choice under settings 1 / 3, the RandomBoxCreator's
     # unread randint over givenData.item_size_set (125 entries), np.random.shuffle of the float positions

@@ -18,7 +18,10 @@ CASES = ["discrete_s2_numpy_stream", "discrete_s1_numpy_stream", "discrete_s3_nu
          "discrete_s2_numpy_stream_cp", "discrete_s1_numpy_stream_cp", "discrete_s2_numpy_stream_ep",
          "discrete_s3_numpy_stream_ep", "discrete_s2_numpy_stream_ev", "discrete_s2_numpy_stream_fc",
          "discrete_s1_numpy_stream_fc", "discrete_s2_numpy_stream_u64", "discrete_s1_numpy_stream_u64",
-         "discrete_s2_numpy_stream_u64_cp"]
+         "discrete_s2_numpy_stream_u64_cp",
+         # ... and the stability settings under each of them
+         "discrete_s3_numpy_stream_fc", "discrete_s1_numpy_stream_ep", "discrete_s1_numpy_stream_ev",
+         "discrete_s3_numpy_stream_cp", "discrete_s3_numpy_stream_u64", "discrete_s1_numpy_stream_u64_ep"]
 LNES_ID = {"EV": 1, "EP": 2, "CP": 3, "FC": 4}
 # continuous env in its sampling mode (C/bin3D.py:14-16,103-113): items are round(np.random.uniform(a, b), 3), plus
 # the RandomBoxCreator's unread randint, the density and the shuffle; a failed step's discarded observation draws a
