@@ -92,7 +92,8 @@ def makespan(cost, order, S):
 
 if SLOTS < N:
     res = {"id order": [], "prev cycles": [], "prev EMS": [], "prev cycles x EMS": [], "rank sum of both": [],
-           "2-step mean cycles": [], "own cycles (ideal)": [], "lower bound": []}
+           "2-step mean cycles": [], "scaled sum (the kernel's key)": [], "scaled cycles + EMS^2": [], "scaled cycles + 2 EMS": [],
+           "own cycles (ideal)": [], "lower bound": []}
     cc = []
     for s in range(1, K):
         cost, prev = tot[s], tot[s - 1]
@@ -104,9 +105,14 @@ if SLOTS < N:
         rk = np.argsort(np.argsort(prev)) + np.argsort(np.argsort(rec[s - 1, :, 12]))
         res["rank sum of both"].append(makespan(cost, np.argsort(-rk, kind="stable"), SLOTS))
         res["2-step mean cycles"].append(makespan(cost, np.argsort(-(prev + tot[max(s - 2, 0)]), kind="stable"), SLOTS))
+        pe = rec[s - 1, :, 12]
+        kc, ke = prev / (prev.max() + 1), pe / (pe.max() + 1)
+        res["scaled sum (the kernel's key)"].append(makespan(cost, np.argsort(-(kc + ke), kind="stable"), SLOTS))
+        res["scaled cycles + EMS^2"].append(makespan(cost, np.argsort(-(kc + ke * ke), kind="stable"), SLOTS))
+        res["scaled cycles + 2 EMS"].append(makespan(cost, np.argsort(-(kc + 2 * ke), kind="stable"), SLOTS))
         res["own cycles (ideal)"].append(makespan(cost, np.argsort(-cost, kind="stable"), SLOTS))
         res["lower bound"].append(max(cost.sum() / SLOTS, cost.max()))
     print("  list scheduling on %d slots (one wave each; timed build), launch length in k cycles, mean over %d launches:" % (SLOTS, K - 1))
     for k, v in res.items():
-        print("    %-20s %8.1f" % (k, np.mean(v) / 1e3))
+        print("    %-30s %8.1f" % (k, np.mean(v) / 1e3))
     print("    correlation of an env's cycles with its previous step's: %.2f" % np.mean(cc))
