@@ -141,7 +141,7 @@ def reference_baseline(w):
 
 def pmc_profile(name, envs):
     """Counter values per launch from the committed rocprofv3 PMC passes of this workload, or None."""
-    for tag in ("r03", "r02"):  # the newest committed profile of this workload
+    for tag in ("r04", "r03", "r02"):  # the newest committed profile of this workload
         rel = "profiles/%s_pmc_%s.json" % (tag, name)
         path = os.path.join(ROOT, rel)
         if not os.path.exists(path):
@@ -162,11 +162,18 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--envs-per-gpu", type=int, default=0, help="default: the workload's own size (4096 for c2)")
-    ap.add_argument("--mode", choices=["rows", "fused", "host"], default="rows",
-                    help="rows: policy kernel + pct_step_rows per step (default); fused: pct_step_hash_policy(1); "
+    ap.add_argument("--mode", choices=["epilogue", "rows", "fused", "host"], default="epilogue",
+                    help="epilogue (default): pct_step_rows per step, the float32 [N,9] leaf rows it reads having been "
+                         "written to HBM by the previous launch's stand-in policy epilogue (pct_bind_policy_rows) -- one "
+                         "transition dispatch per step; rows: the stand-in policy as its own kernel + pct_step_rows (the "
+                         "rounds 1-3 default); fused: pct_step_hash_policy(1), no rows at all; "
                          "host: the reference trainer's hand-over -- leaf rows to the host as numpy "
                          "(train_tools.py:66-67), VecEnv.step(numpy), reward / done back on the host every step "
                          "(PCIe and a stream sync inside the timed region; never the headline value)")
+    ap.add_argument("--desync", type=int, default=200,
+                    help="untimed transitions right after the synchronous reset, before --warmup, so that a short run "
+                         "(the driver's --warmup 5 --steps 20) measures the steady state -- episodes of every length in "
+                         "flight -- and not the first 25 steps of 4096 envs that all start empty")
     ap.add_argument("--pipelines", type=int, default=1,
                     help="split each GPU's envs into this many independently stepped groups, one HIP stream each "
                          "(1 = one batch per step, the headline configuration)")
@@ -227,14 +234,20 @@ def main():
     envs = [make_env(g) for g in range(P)]
     streams = [torch.cuda.current_stream(dev)] if P == 1 else [torch.cuda.Stream(dev) for _ in range(P)]
     rows = [torch.empty(n_grp, 9, dtype=torch.float32, device=dev) for _ in range(P)]
-    for ev in envs:
-        ev.reset()
+    if args.mode == "epilogue":
+        for g in range(P):
+            envs[g].bind_policy_rows(rows[g])  # reset() and every transition write the next step's rows
+    for g, ev in enumerate(envs):
+        with torch.cuda.stream(streams[g]):
+            ev.reset()
     torch.cuda.synchronize(dev)
 
     def one_step():
         for g in range(P):
             with torch.cuda.stream(streams[g]):
-                if args.mode == "rows":
+                if args.mode == "epilogue":
+                    envs[g].step_rows_device(rows[g])
+                elif args.mode == "rows":
                     envs[g].policy_hash_rows(rows[g])
                     envs[g].step_rows_device(rows[g])
                 elif args.mode == "host":
@@ -243,7 +256,7 @@ def main():
                 else:
                     envs[g].step_hash_policy(1)
 
-    for _ in range(args.warmup):
+    for _ in range(max(0, args.desync) + args.warmup):
         one_step()
     torch.cuda.synchronize(dev)
     for ev in envs:
@@ -288,8 +301,16 @@ def main():
     achieved_gbs = B * n_grp / (kern_avg_ms * 1e-3) / 1e9  # per launch (n_grp envs)
     pmc, pmc_src = pmc_profile(args.workload, n_grp)
     traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
-    kernel_name = ("pct_continuous_kernel<" if w["cont"] else "pct_discrete_kernel<u32,5,") + \
-                  ("ACT_HASH" if args.mode == "fused" else "ACT_ROWS") + (",stability>" if w["setting"] != 2 else ">")
+    # the transition kernel as rocprofv3 names it (profiles/r0x_trace_<workload>.txt); ACT: 0 = rows, 2 = stand-in policy
+    act = 2 if args.mode == "fused" else 0
+    stab = "true" if w["setting"] != 2 else "false"
+    if w["cont"]:
+        gt = "true" if max(w["container"]) > 12 else "false"  # candidate table in HBM (pct_create: bins beyond 12 units)
+        kernel_name = ("void pct::pct_continuous_kernel<%d, false, %s, %s, false>(pct::ContinuousParams, void const*, int, int, "
+                       "int const*, int)" % (act, gt, stab))
+    else:
+        kernel_name = ("void pct::pct_discrete_kernel<unsigned int, 5, %d, false, %s, 0, 0>(pct::DiscreteParams, void const*, "
+                       "int, int, int const*, int)" % (act, stab))
 
     out = {
         "metric": w["metric"],
@@ -305,12 +326,17 @@ def main():
         "dtype": "f64" if w["cont"] else ("i32+f64" if w["setting"] != 2 else "i32"),
         "data": "synthetic",
         "config": {
-            "workload": (w["what"] % n_local) + "; per step: policy kernel -> float32 [N,9] leaf rows -> transition kernel "
-                        "(observation rows rewritten, auto-reset)",
+            "workload": (w["what"] % n_local) + "; per step: " + {
+                "epilogue": "float32 [N,9] leaf rows (HBM, written by the previous launch's stand-in policy epilogue) -> "
+                            "transition kernel (observation rows rewritten, auto-reset, next rows)",
+                "rows": "policy kernel -> float32 [N,9] leaf rows -> transition kernel (observation rows rewritten, auto-reset)",
+                "fused": "transition kernel with the stand-in policy inside (no rows)",
+                "host": "policy kernel -> rows to the host -> VecEnv.step(numpy) -> reward / done / infos on the host"}[args.mode],
             "name": args.workload,
             "envs_per_gpu": n_local,
             "global_envs": world * n_local,
             "mode": args.mode,
+            "desync_steps": max(0, args.desync),
             "pipelines": P,
             "overflow_retry_pass": not args.no_overflow_retry,
             "parallelism": "envs sharded by global id x%d, no collective on the step path" % world,
@@ -340,7 +366,8 @@ def main():
                                  "peak_model": "256 CUs x 2.4 GHz x (4 SIMD-32 x 1 wave64 VALU / 2 cycles + 1 SALU / cycle)"}
     else:
         out["roofline_issue"] = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:
+        # (N > 1: timed on rank 0 after the final barrier, while the other ranks wait in destroy_process_group)
         out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)
     elif rank == 0:
         out["cpu_baseline"] = None

@@ -115,6 +115,7 @@ extern "C" {
                                             bin3D.py:144-145 (list.remove) or in np.max of an
                                             empty slice (space.py:354-355) */
 
+
 /* Lattice: all geometry is integral in "lattice units".  Discrete env: 1 unit = 1.
  * Continuous env: 1 unit = 1e-3 (item sizes are round(U(a,b),3), bin3D.py:106-108). */
 typedef struct pct_config {
@@ -143,7 +144,7 @@ typedef struct pct_config {
   int32_t reserved[3];          /* [0]: PCT_OVERFLOW_RETRY_* (discrete env); others 0 */
 } pct_config;
 #define PCT_OVERFLOW_RETRY_ON 0  /* default: the retry pass is enqueued with every transition (a 16-block kernel that
-                                    exits at once when no env overflowed: about 3 us per step on MI355X) */
+                                    exits at once when no env overflowed: about 5 us per step on MI355X, profiles/r04_experiments.txt) */
 #define PCT_OVERFLOW_RETRY_OFF 1 /* no retry pass: an overflow raises its flag and terminates the env */
 
 typedef struct pct_env pct_env;
@@ -257,8 +258,9 @@ int pct_step_index(pct_env* env, const int64_t* leaf_index, void* stream);
  * valid leaves (leaf 0 if k == 0), t = the env's lifetime step counter. */
 int pct_step_hash_policy(pct_env* env, int32_t n_steps, void* stream);
 /* n_steps batched steps with a heuristic baseline of heuristic.py as the in-env policy (kind =
- * PCT_HEUR_*; discrete env, LNES = EMS): the placement rule reads the env's heightmap / EMS list /
- * stability state, the chosen placement is stepped exactly as `env.next_box = [x,y,z];
+ * PCT_HEUR_*; LNES = EMS; the discrete env takes all seven, the continuous env LSAH / OnlineBPH / BR -- the three
+ * tools.py:217-218 allows on PackingContinuous; not in strict NumPy-stream mode): the placement rule reads the env's
+ * heightmap / EMS list / stability state, the chosen placement is stepped exactly as `env.next_box = [x,y,z];
  * env.step([0,lx,ly])`; an env whose heuristic finds no placement ends its episode WITHOUT a
  * step (done = 1, reward = 0, counter / ratio as at a failed step) and is reset, as the reference
  * loops do (e.g. heuristic.py:241-249,291-296). */
@@ -269,13 +271,18 @@ int pct_step_heuristic(pct_env* env, int32_t kind, int32_t n_steps, void* stream
  * leaf = pct_mix32(g, t) % k and writes that leaf row to rows_out (device float32 [N,9]),
  * ready for pct_step_rows. */
 int pct_policy_hash_rows(pct_env* env, float* rows_out, void* stream);
+/* The same stand-in policy as an EPILOGUE of every following launch (reset / step_*): the transition kernel, having
+ * written an env's new observation, also writes the row pct_policy_hash_rows would gather from it to rows_out (device
+ * float32 [N,9]; the same bytes) -- a benchmark loop `pct_step_rows(rows)` then needs no policy dispatch between two
+ * transitions (the rows still travel through HBM, one launch per step).  NULL switches it off. */
+int pct_bind_policy_rows(pct_env* env, float* rows_out);
 
 /* ---- kernel timing ------------------------------------------------------------------- */
-/* When enabled, the transition kernel of every launch (reset / step_*) is bracketed by a pair of
- * hipEvents recorded on the launch stream -- the step kernel itself, not the small large-capacity retry
- * pass that may follow it.  pct_profile_read synchronises on the recorded
- * events, returns the number of launches and their summed duration since the last read,
- * and clears the accumulator. */
+/* When enabled, the transition kernel of every launch (reset / step_*) carries a pair of hipEvents that bracket
+ * exactly that dispatch (hipExtLaunchKernel start / stop events: the kernel's own begin and end timestamps, no marker
+ * packets on the stream) -- the step kernel itself, not the small large-capacity retry pass that follows it.
+ * pct_profile_read synchronises on the recorded events, returns the number of launches and their summed duration
+ * since the last read, and clears the accumulator. */
 int pct_profile_enable(pct_env* env, int32_t on);
 int pct_profile_read(pct_env* env, int64_t* n_launches, double* total_ms);
 
@@ -290,6 +297,13 @@ int pct_debug_state(pct_env* env, int32_t local_id, int32_t* heightmap, int32_t*
 /* Continuous env: EMS float64 [*n_ems,6] (row-major copy), next item in bin units. */
 int pct_debug_state_f64(pct_env* env, int32_t local_id, double* ems, int32_t cap_ems, int32_t* n_ems,
                         int32_t* n_boxes, double* next_item, int64_t* draw_cursor);
+
+/* The heavy-first dispatch's work keys, host uint32 [N]: shader-clock cycles of every env's last step / 256 << 12 | its live
+ * EMS count (0 right after a reset).  Synchronises the device. */
+int pct_debug_work_keys(pct_env* env, uint32_t* host_out);
+/* The large-capacity retry pass: how many envs the LAST launch queued for it, how many envs it has re-run since
+ * pct_create and in how many launches it found work (any pointer may be NULL).  Synchronises the device. */
+int pct_debug_retry_count(pct_env* env, int32_t* last, int64_t* envs_total, int64_t* launches_total);
 
 /* Per-phase cycle accounting of the transition kernel (profiling aid).  on != 0: (re)start
  * accumulation; host_out, if non-NULL, first receives the accumulators gathered so far:

@@ -19,6 +19,7 @@
 //   EMSPoint                    C/space.py:531-568
 //   get_possible_position       C/bin3D.py:118-148, cur_observation :78-100
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/pct_env.h"
@@ -943,7 +944,7 @@ __device__ __forceinline__ void cwrite_obs(const ContinuousParams& p, int e, con
     double v = 0;
 #pragma unroll
     for (int k = 0; k < 6; k++) v = lane == k ? newbox[k] : v;
-    obs[new_row * 9 + lane] = lane < 6 ? (float)v : (lane == 8 ? 1.0f : 0.f);
+    obs_st(&obs[new_row * 9 + lane], lane < 6 ? (float)v : (lane == 8 ? 1.0f : 0.f));
   }
   if (!full) {
     // incremental: lane = leaf row (nine strided stores), then the item row -- as in the discrete kernel; a
@@ -956,15 +957,16 @@ __device__ __forceinline__ void cwrite_obs(const ContinuousParams& p, int e, con
         double t[6] = {0, 0, 0, 0, 0, 0};
         if (on) cand_tuple(p, l, r, orient, (uint32_t)l.leafg[j], t);
         float* o = obs + (size_t)(p.I + j) * 9;
-        o[0] = (float)t[0]; o[1] = (float)t[1]; o[2] = (float)t[2]; o[3] = (float)t[3]; o[4] = (float)t[4];
-        o[5] = on ? (float)p.H : 0.f;
-        o[6] = 0.f; o[7] = 0.f;
-        o[8] = on ? 1.0f : 0.f;
+        obs_st(o + 0, (float)t[0]); obs_st(o + 1, (float)t[1]); obs_st(o + 2, (float)t[2]); obs_st(o + 3, (float)t[3]);
+        obs_st(o + 4, (float)t[4]);
+        obs_st(o + 5, on ? (float)p.H : 0.f);
+        obs_st(o + 6, 0.f); obs_st(o + 7, 0.f);
+        obs_st(o + 8, on ? 1.0f : 0.f);
       }
     }
     if (lane < 9)
-      obs[(size_t)(p.I + p.L) * 9 + lane] =
-          lane == 0 ? nden : (lane == 3 ? (float)a : (lane == 4 ? (float)b : (lane == 5 ? (float)c : (lane == 8 ? 1.0f : 0.f))));
+      obs_st(&obs[(size_t)(p.I + p.L) * 9 + lane],
+             lane == 0 ? nden : (lane == 3 ? (float)a : (lane == 4 ? (float)b : (lane == 5 ? (float)c : (lane == 8 ? 1.0f : 0.f)))));
     return;
   }
   // full rewrite: the placed boxes come from their HBM rows (written when they were placed; the one placed by
@@ -984,9 +986,9 @@ __device__ __forceinline__ void cwrite_obs(const ContinuousParams& p, int e, con
         for (int k = 0; k < 6; k++) g[k] = newbox[k];
       }
 #pragma unroll
-      for (int k = 0; k < 6; k++) o[k] = (float)g[k];
-      o[6] = 0.f; o[7] = 0.f;  // density column is 0 (:372-373)
-      o[8] = (on || row == 0) ? 1.0f : 0.f;  // row 0: the dummy valid node after reset (C/space.py:285-286)
+      for (int k = 0; k < 6; k++) obs_st(o + k, (float)g[k]);
+      obs_st(o + 6, 0.f); obs_st(o + 7, 0.f);  // density column is 0 (:372-373)
+      obs_st(o + 8, (on || row == 0) ? 1.0f : 0.f);  // row 0: the dummy valid node after reset (C/space.py:285-286)
     }
   }
   for (int jb = 0; jb < p.L; jb += 64) {
@@ -996,15 +998,33 @@ __device__ __forceinline__ void cwrite_obs(const ContinuousParams& p, int e, con
       double t[6] = {0, 0, 0, 0, 0, 0};
       if (on) cand_tuple(p, l, r, orient, (uint32_t)l.leafg[j], t);
       float* o = obs + (size_t)(p.I + j) * 9;
-      o[0] = (float)t[0]; o[1] = (float)t[1]; o[2] = (float)t[2]; o[3] = (float)t[3]; o[4] = (float)t[4];
-      o[5] = on ? (float)p.H : 0.f;
-      o[6] = 0.f; o[7] = 0.f;
-      o[8] = on ? 1.0f : 0.f;
+      obs_st(o + 0, (float)t[0]); obs_st(o + 1, (float)t[1]); obs_st(o + 2, (float)t[2]); obs_st(o + 3, (float)t[3]);
+      obs_st(o + 4, (float)t[4]);
+      obs_st(o + 5, on ? (float)p.H : 0.f);
+      obs_st(o + 6, 0.f); obs_st(o + 7, 0.f);
+      obs_st(o + 8, on ? 1.0f : 0.f);
     }
   }
   if (lane < 9)
-    obs[(size_t)(p.I + p.L) * 9 + lane] =
-        lane == 0 ? nden : (lane == 3 ? (float)a : (lane == 4 ? (float)b : (lane == 5 ? (float)c : (lane == 8 ? 1.0f : 0.f))));
+    obs_st(&obs[(size_t)(p.I + p.L) * 9 + lane],
+           lane == 0 ? nden : (lane == 3 ? (float)a : (lane == 4 ? (float)b : (lane == 5 ? (float)c : (lane == 8 ? 1.0f : 0.f)))));
+}
+
+// Stand-in policy epilogue (pct_bind_policy_rows), as in the discrete kernel: the float32 leaf row the separate policy
+// kernel would gather from the observation just written (leaf pct_mix32(g, t) % k of the k valid ones, else the zero row)
+__device__ __forceinline__ void cpolicy_epilogue(const ContinuousParams& p, int e, const CLds& l, const CRegs& r, int lane) {
+  const int k = r.n_leaf;
+  const int li = k > 0 ? (int)(pct_mix32((uint32_t)(p.env_id_base + e), r.t) % (uint32_t)k) : 0;
+  const int orient = (p.setting == 2) ? 6 : 2;
+  double t[6] = {0, 0, 0, 0, 0, 0};
+  if (k > 0) cand_tuple(p, l, r, orient, (uint32_t)l.leafg[li], t);
+  if (lane < 9) {
+    double v = 0;
+#pragma unroll
+    for (int c = 0; c < 5; c++) v = lane == c ? t[c] : v;
+    const bool on = k > 0;
+    p.policy_rows[(size_t)e * 9 + lane] = lane < 5 ? (float)v : (lane == 5 ? (on ? (float)p.H : 0.f) : (lane == 8 ? (on ? 1.0f : 0.f) : 0.f));
+  }
 }
 
 __device__ __forceinline__ void cload(const ContinuousParams& p, int e, CLds& l, CRegs& r, int lane) {
@@ -1293,6 +1313,7 @@ __device__ __forceinline__ bool cheur_choose(const ContinuousParams& p, int e, C
         if (need) ok = stable && !cap;
         r.stab_over |= cap;
         if (__ballot(need && lerr)) r.stab_over |= STAB_WHY_SPLIT;
+        if (__ballot(ill)) r.flags |= PCT_FLAG_ILL_CONDITIONED;  // a near-cut rank decision inside a heuristic's probe
       }
     }
     return ok;
@@ -1497,18 +1518,30 @@ template <int ACT, bool TIMED, bool GT, bool STAB, bool MT>
 #define PCT_STAB_WAVES 1 /* waves per SIMD the stability-check kernels are compiled for (2: 256 VGPRs, ~470 of them spilled -- slower, profiles/r03_stability_tuning.txt) */
 #endif
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TIMED ? 1 : (STAB ? PCT_STAB_WAVES : PCT_CONT_WAVES))))
-pct_continuous_kernel(ContinuousParams p, const void* __restrict__ actions,
+pct_continuous_kernel(ContinuousParams p_arg, const void* __restrict__ actions,
                                                             int row_len, int n_steps,
                                                             const int32_t* __restrict__ env_ids, int n_ids) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x;
+#if PCT_KERNARG_PTR
+  // the parameter block is read where it is used, from the kernarg segment (pct_device.h pct_param_fence)
+  const ContinuousParams& p = *(const ContinuousParams*)pct_param_fence((PctConstParams<ContinuousParams>)__builtin_amdgcn_kernarg_segment_ptr());
+#else
+  const ContinuousParams& p = p_arg;
+#endif
   // work items: every env (normal pass), the listed envs (reset_specific), or -- in the
   // large-capacity retry pass -- the envs the normal pass queued, grid-strided
   const bool listed = (ACT == CACT_RESET && env_ids != nullptr);
-  const int limit = p.retry_mode ? *p.retry_count : (listed ? n_ids : p.N);
+  int limit = listed ? n_ids : p.N;
   // retry pass: p.retry_count is this step's counter of a ping-pong pair; the other one (the next step's) is
   // zeroed here, so that no memset sits between the launches (retry_mode = +1 / -1: offset of the other)
-  if (p.retry_mode && blockIdx.x == 0 && threadIdx.x == 0) p.retry_count[p.retry_mode] = 0;
+  if (p.retry_mode) {
+    limit = *p.retry_count;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      p.retry_count[p.retry_mode] = 0;
+      if (limit > 0 && p.retry_total) { p.retry_total[0] += limit; p.retry_total[1] += 1; }
+    }
+  }
   for (int work = blockIdx.x; work < limit; work += gridDim.x) {
   // (heavy-first dispatch: p.order is a permutation of 0..N-1, see pct_device.h)
   // (readfirstlane: a loaded id would otherwise live, with every address derived from it, in vector registers)
@@ -1530,7 +1563,7 @@ pct_continuous_kernel(ContinuousParams p, const void* __restrict__ actions,
   const uint32_t flags_in = r.flags;
   bool requeue = can_retry && ACT != CACT_RESET && (r.n_ems > p.ems_cap || r.stab_over);
   if (requeue) {
-    if (lane == 0) p.retry_ids[atomicAdd(p.retry_count, 1)] = e;
+    retry_enqueue(p.retry_count, p.retry_ids, e);
     __syncthreads();
     continue;
   }
@@ -1552,6 +1585,7 @@ pct_continuous_kernel(ContinuousParams p, const void* __restrict__ actions,
     if (!requeue) {
       const double nobox[6] = {0, 0, 0, 0, 0, 0};
       cwrite_obs(p, e, l, r, lane, obs, true, -1, nobox);
+      if (p.policy_rows) cpolicy_epilogue(p, e, l, r, lane);
       cstore(p, e, l, r, lane);
     }
   } else {
@@ -1630,12 +1664,13 @@ pct_continuous_kernel(ContinuousParams p, const void* __restrict__ actions,
     tm.tick(PH_OBS);
   }
   if (!requeue) {
+    if (p.policy_rows) cpolicy_epilogue(p, e, l, r, lane);
     cstore(p, e, l, r, lane);
     tm.tick(PH_STORE);
     if (TIMED && lane == 0) tm.flush(p.timing + (size_t)e * PCT_TIMING_SLOTS, n_steps);
   }
   }  // step / reset
-  if (requeue && lane == 0) p.retry_ids[atomicAdd(p.retry_count, 1)] = e;
+  if (requeue) retry_enqueue(p.retry_count, p.retry_ids, e);
   work_key_end(smem, p.scalars, p.N, e, ACT == CACT_RESET, r.n_ems);
   __syncthreads();
   }  // work items
@@ -1697,7 +1732,8 @@ hipError_t PCT_CONT_LAUNCH(const ContinuousParams& p, int act, const void* actio
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
       if (er != hipSuccess) return er;                                                                         \
     }                                                                                                          \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, stream, p, actions, row_len, n_steps, env_ids, n_ids); \
+    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, stream, (hipEvent_t)p.launch_ev_start,             \
+                          (hipEvent_t)p.launch_ev_stop, 0, p, actions, row_len, n_steps, env_ids, n_ids); \
   } while (0)
   switch (act) {
     case CACT_ROWS: PCT_CLAUNCH(CACT_ROWS); break;

@@ -10,7 +10,33 @@
 
 #define PCT_SCALARS 16 /* int32 words of per-env scalar state (word 15: stability pools in use, entries | vertices << 16) */
 
+#ifndef PCT_KERNARG_PTR
+#define PCT_KERNARG_PTR 1 /* 1: the kernels read their parameter block from the kernarg segment at the point of use */
+#endif
+
 namespace pct {
+
+#if defined(__HIPCC__)
+// A kernel's parameter block as it lies in the kernarg segment (constant address space: uniform scalar loads).
+template <typename P>
+using PctConstParams = const __attribute__((address_space(4))) P*;
+// An opaque copy of the pointer: loads through the result cannot be merged with, or hoisted above, the ones before the
+// fence -- a cold phase re-reads the handful of words it needs instead of keeping them live (or spilled) across the hot
+// loops.  The pointer stays in scalar registers and in the constant address space.
+template <typename P>
+__device__ __forceinline__ PctConstParams<P> pct_param_fence(PctConstParams<P> q) {
+  asm volatile("" : "+s"(q));
+  return q;
+}
+template <typename P>
+__device__ __forceinline__ const P& pct_param_refresh(const P& p) {
+#if PCT_KERNARG_PTR
+  return *(const P*)pct_param_fence((PctConstParams<P>)(&p));
+#else
+  return p;
+#endif
+}
+#endif
 
 // HBM layout of the discrete env state: struct-of-arrays over envs, every array holds one
 // contiguous slice per env (a wave reads its env's slice with consecutive lanes on
@@ -72,6 +98,12 @@ struct DiscreteParams {
   int32_t* counter; /* [N] */
   double* ratio;    /* [N] */
   float* mask;      /* [N] 1 - done as float32 (storage.py masks), or null */
+  float* policy_rows; /* [N,9] stand-in policy epilogue (pct_bind_policy_rows): the leaf row pct_policy_hash_rows would gather
+                         from the observation this launch writes, or null */
+  int* retry_total; /* [2] envs the retry pass has ever re-run, launches in which it found work (pct_debug_retry_count) */
+  /* host-side launch options, never read by a kernel: events that bracket exactly this dispatch (hipExtLaunchKernel) */
+  void* launch_ev_start;
+  void* launch_ev_stop;
 };
 
 // HBM layout of the continuous env state (float64, SoA over envs; within an env every
@@ -126,6 +158,10 @@ struct ContinuousParams {
   int32_t* counter;
   double* ratio;
   float* mask; /* as in DiscreteParams */
+  float* policy_rows; /* as in DiscreteParams */
+  int* retry_total;   /* as in DiscreteParams */
+  void* launch_ev_start; /* host-side launch options, as in DiscreteParams */
+  void* launch_ev_stop;
 };
 
 // D/bin3D.py:75-84 next_den of the observation number `oc` (the env's life-long observation
@@ -158,6 +194,26 @@ __device__ __forceinline__ void wave_priority(int n_ems, const int prio_t[3]) {
   else if (n_ems >= prio_t[1]) __builtin_amdgcn_s_setprio(2);
   else if (n_ems >= prio_t[0]) __builtin_amdgcn_s_setprio(1);
   else __builtin_amdgcn_s_setprio(0);
+}
+
+// Observation rows are written once and read by the NEXT kernel (the policy), never again by this one: PCT_OBS_NT = 1 marks
+// the stores non-temporal (streaming) so that they do not sit in the L2 as dirty lines the end-of-kernel release has to write back.
+#ifndef PCT_OBS_NT
+#define PCT_OBS_NT 0
+#endif
+__device__ __forceinline__ void obs_st(float* q, float v) {
+#if PCT_OBS_NT
+  __builtin_nontemporal_store(v, q);
+#else
+  *q = v;
+#endif
+}
+
+// Retry queue of a launch: written by the normal pass, read by the retry pass enqueued behind it.  (Round 4 tried to overlap
+// the two -- the retry pass dispatched with hipExtAnyOrderLaunch and waiting in-kernel on a counter of finished workgroups:
+// the flag does not lift the barrier on gfx950 and the counter cost the normal pass 1 us, profiles/r04_experiments.txt.)
+__device__ __forceinline__ void retry_enqueue(int* count, int* ids, int e) {
+  if (threadIdx.x == 0) ids[atomicAdd(count, 1)] = e;
 }
 
 template <typename Params>

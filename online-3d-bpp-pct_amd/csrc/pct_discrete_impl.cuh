@@ -22,6 +22,7 @@
 #ifndef PCT_DISCRETE_IMPL_CUH
 #define PCT_DISCRETE_IMPL_CUH
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/pct_env.h"
@@ -658,6 +659,10 @@ __device__ __forceinline__ bool item_rot_size(int b0, int b1, int b2, int rot, i
                            but with several keys per lane every walk step issues that many times the instructions, and with
                            four waves per SIMD the kernel is bound by instruction issue, not by the dependence chain. */
 #endif
+#ifndef PCT_SET_WHOLE_MIN
+#define PCT_SET_WHOLE_MIN 0 /* (EMS, rotation) pairs from which on an env takes the whole-list path (experiments: only the EMS-rich
+                               envs that set a launch's length, the others batch by batch) */
+#endif
 // ----------------------------------------------------------------------------------------------------------------
 // The EMS candidate set built FROM THE WHOLE TUPLE LIST AT ONCE (32-bit keys, a table region of >= 2048 words).
 //
@@ -952,7 +957,7 @@ __device__ __forceinline__ void leaf_nodes(const DiscreteParams& p, int e, Lds<K
   l.dd[lane] = 0xFFFFFFFFu;
   l.dd[64 + lane] = 0xFFFFFFFFu;
   __syncthreads();
-  int mstat[3] = {0, 0, 0};  // timed build only: match calls, outer rounds, sum over calls of the longest walk
+  int mstat[4] = {0, 0, 0, 0};  // timed build only: match calls, outer rounds, sum over calls of the longest walk, cycles inside the walk loops
   int* const mst = TM::on ? mstat : nullptr;
   tm.sub_start();
 
@@ -1292,7 +1297,7 @@ __device__ __forceinline__ void leaf_nodes(const DiscreteParams& p, int e, Lds<K
     const uint32_t rotmask = 1u | (g1 ? 2u : 0u) | (g2 ? 4u : 0u) | (g3 ? 8u : 0u) | (g4 ? 16u : 0u) | (g5 ? 32u : 0u);
     constexpr int V = PCT_SET_V;  // a chunk of 64 (EMS, rotation) pairs = up to 256 tuples = 4 / V batches, V tuples per lane
     bool whole = false;
-    if (PCT_SET_WHOLE && sizeof(K) == 4 && p.cand_cap >= 2048)
+    if (PCT_SET_WHOLE && sizeof(K) == 4 && p.cand_cap >= 2048 && NP >= PCT_SET_WHOLE_MIN)
       whole = ems_set_whole<K, BITS>(p, l, st, lane, tm, mst, E, orient, rotmask, b0, b1, b2);
     if (!whole) {  // (the list did not fit the scratch, or a small table region: batch by batch)
       if (lane < 8) tabs[st.toff + lane] = EMPTY;
@@ -1347,7 +1352,7 @@ __device__ __forceinline__ void leaf_nodes(const DiscreteParams& p, int e, Lds<K
   __syncthreads();
   tm.add(ST_EMS, (uint64_t)E);
   tm.add(ST_DISTINCT, (uint64_t)fill);
-  if (TM::on) { tm.add(ST_MATCH_CALLS, (uint64_t)mstat[0]); tm.add(ST_MATCH_ROUNDS, (uint64_t)mstat[1]); tm.add(ST_MATCH_PROBES, (uint64_t)mstat[2]); }
+  if (TM::on) { tm.add(ST_MATCH_CALLS, (uint64_t)mstat[0]); tm.add(ST_MATCH_ROUNDS, (uint64_t)mstat[1]); tm.add(ST_MATCH_PROBES, (uint64_t)mstat[2]); tm.add(ST_CONTAINS_CALLS, (uint64_t)mstat[3]); }
   tm.sub_tick(PH_SET_GEN);
   tm.tick(PH_SET);
 
@@ -1359,6 +1364,7 @@ __device__ __forceinline__ void leaf_nodes(const DiscreteParams& p, int e, Lds<K
   // feasibility of the candidate every lane holds (EMPTY: none).  All 64 lanes call: the stability check of the lanes
   // that need one is a wave-cooperative task walk (pct_stab.cuh stab_virtual_wave).
   bool stab_ill = false;
+  StabStats sstats = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // (timed build only)
   bool unknown = false;  // the last call left this lane's candidate undecided (a capacity of its own was exceeded)
   auto feasible = [&](K k) __attribute__((always_inline)) -> bool {
     unknown = false;
@@ -1382,7 +1388,8 @@ __device__ __forceinline__ void leaf_nodes(const DiscreteParams& p, int e, Lds<K
         BoxGeo<K, BITS> geo{l.box};
         uint32_t cap = 0;
         bool ill = false, lerr = false;
-        const bool stable = stab_virtual_wave<false>(geo, l.st, r.n_boxes, need, cand, next_den, l.sw, lane, cap, lerr, ill);
+        const bool stable = stab_virtual_wave<false>(geo, l.st, r.n_boxes, need, cand, next_den, l.sw, lane, cap, lerr, ill,
+                                                     TM::on ? &sstats : nullptr);
         if (need) feas = stable && !cap;
         stab_err |= cap;
         unknown = need && lerr;
@@ -1495,6 +1502,17 @@ __device__ __forceinline__ void leaf_nodes(const DiscreteParams& p, int e, Lds<K
   if (STAB) r.stab_over |= stab_err;  // (wave-uniform)
   if (STAB && stab_ill) r.flags |= PCT_FLAG_ILL_CONDITIONED;
   r.n_leaf = nleaf < p.L ? nleaf : p.L;
+  if (TM::on && STAB) {
+    // pass / task counters are kept by lane 0, the per-lane ones (level-0 tasks, solves) are summed over the wave
+    tm.add(ST_STAB_VPASSES, (uint64_t)__builtin_amdgcn_readfirstlane(sstats.v_passes));
+    tm.add(ST_STAB_VTASKS, (uint64_t)__builtin_amdgcn_readfirstlane(sstats.v_tasks));
+    tm.add(ST_STAB_VNARROW, (uint64_t)__builtin_amdgcn_readfirstlane(sstats.v_narrow));
+    tm.add(ST_STAB_LEVEL0, (uint64_t)wave_sum_i64(sstats.v_level0));
+    tm.add(ST_STAB_LSQ3, (uint64_t)wave_sum_i64(sstats.lsq3));
+    tm.add(ST_STAB_LSQ4, (uint64_t)wave_sum_i64(sstats.lsq4));
+    tm.add(ST_STAB_LSQ5, (uint64_t)wave_sum_i64(sstats.lsq5));
+    tm.add(ST_STAB_LSQX, (uint64_t)wave_sum_i64(sstats.lsqx));
+  }
   __syncthreads();
   tm.tick(PH_FEAS);
 }
@@ -1522,7 +1540,7 @@ __device__ __forceinline__ void write_obs(const DiscreteParams& p, int e, const 
     K k = l.box[new_row];
     float v = lane < 6 ? (float)P::get(k, lane) : (lane == 7 ? 0.f : 1.0f);
     if (dens && lane == 6) v = (float)bden[new_row];
-    obs[new_row * 9 + lane] = v;
+    obs_st(&obs[new_row * 9 + lane], v);
   }
   if (!full) {
     // incremental: lane = leaf row, nine strided stores per lane (far fewer instructions than the
@@ -1533,17 +1551,17 @@ __device__ __forceinline__ void write_obs(const DiscreteParams& p, int e, const 
         const bool on = j < r.n_leaf;
         const K k = on ? l.leaf[j] : (K)0;
         float* o = obs + (size_t)(p.I + j) * 9;
-        o[0] = (float)P::get(k, 0); o[1] = (float)P::get(k, 1); o[2] = (float)P::get(k, 2);
-        o[3] = (float)P::get(k, 3); o[4] = (float)P::get(k, 4);
-        o[5] = on ? (float)p.H : 0.f;
-        o[6] = 0.f; o[7] = 0.f;
-        o[8] = on ? 1.0f : 0.f;
+        obs_st(o + 0, (float)P::get(k, 0)); obs_st(o + 1, (float)P::get(k, 1)); obs_st(o + 2, (float)P::get(k, 2));
+        obs_st(o + 3, (float)P::get(k, 3)); obs_st(o + 4, (float)P::get(k, 4));
+        obs_st(o + 5, on ? (float)p.H : 0.f);
+        obs_st(o + 6, 0.f); obs_st(o + 7, 0.f);
+        obs_st(o + 8, on ? 1.0f : 0.f);
       }
     }
     if (lane < 9) {
       const int col2 = lane;
-      obs[(size_t)(p.I + p.L) * 9 + col2] =
-          col2 == 0 ? nden : (col2 == 3 ? (float)a : (col2 == 4 ? (float)b : (col2 == 5 ? (float)c : (col2 == 8 ? 1.0f : 0.f))));
+      obs_st(&obs[(size_t)(p.I + p.L) * 9 + col2],
+             col2 == 0 ? nden : (col2 == 3 ? (float)a : (col2 == 4 ? (float)b : (col2 == 5 ? (float)c : (col2 == 8 ? 1.0f : 0.f)))));
     }
     return;
   }
@@ -1568,7 +1586,7 @@ __device__ __forceinline__ void write_obs(const DiscreteParams& p, int e, const 
     } else {
       v = col == 0 ? nden : (col == 3 ? (float)a : (col == 4 ? (float)b : (col == 5 ? (float)c : (col == 8 ? 1.0f : 0.f))));
     }
-    obs[row * 9 + col] = v;
+    obs_st(&obs[row * 9 + col], v);
   }
 }
 
@@ -1641,19 +1659,22 @@ __device__ __forceinline__ void store_state(const DiscreteParams& p, int e, cons
     for (int i = lane; i < 624; i += 64) gm[i] = l.mt[i];
   }
   if (p.setting != 2) stab_store(p.sb, p.I, e, r.n_boxes, l.st, r.poly_from, lane);
+  // the 16 scalar words go out as ONE 64-byte store (lane = word; the values are wave-uniform, a select chain puts each into
+  // its lane) instead of 16 single-lane stores
+  {
+    const int32_t w[PCT_SCALARS] = {
+        r.n_ems, r.n_boxes, r.n_leaf, r.item0, r.item1, r.item2, (int32_t)r.t, r.mt_pos,
+        (int32_t)(uint32_t)r.cursor, (int32_t)(uint32_t)(r.cursor >> 32), (int32_t)(uint32_t)(uint64_t)r.vol,
+        (int32_t)(uint32_t)((uint64_t)r.vol >> 32), r.traj, (int32_t)r.oc, r.n_cand,
+        p.setting != 2 ? (int32_t)((uint32_t)l.st.n_ent | ((uint32_t)l.st.n_poly << 16)) : 0};
+    int32_t v = 0;
+#pragma unroll
+    for (int i = 0; i < PCT_SCALARS; i++) v = lane == i ? w[i] : v;
+    if (lane < PCT_SCALARS) sc[lane] = v;
+  }
   if (lane == 0) {
-    if (p.setting != 2) sc[15] = (int32_t)((uint32_t)l.st.n_ent | ((uint32_t)l.st.n_poly << 16));
-    sc[0] = r.n_ems; sc[1] = r.n_boxes; sc[2] = r.n_leaf;
-    sc[3] = r.item0; sc[4] = r.item1; sc[5] = r.item2;
-    sc[6] = (int32_t)r.t;
-    sc[7] = r.mt_pos;
-    sc[14] = r.n_cand;
     if (p.rng_numpy && p.setting == 3) p.mt_den[e] = r.den_cur;
     p.flags[e] = r.flags;
-    sc[8] = (int32_t)(uint32_t)r.cursor; sc[9] = (int32_t)(uint32_t)(r.cursor >> 32);
-    sc[10] = (int32_t)(uint32_t)(uint64_t)r.vol; sc[11] = (int32_t)(uint32_t)((uint64_t)r.vol >> 32);
-    sc[12] = r.traj;
-    sc[13] = (int32_t)r.oc;
   }
 }
 
@@ -1710,6 +1731,7 @@ __device__ __forceinline__ bool heur_choose(const DiscreteParams& p, int e, Lds<
         if (need) feas = stable && !cap;
         stab_err |= cap;
         if (__ballot(need && lerr)) stab_err |= STAB_WHY_SPLIT;
+        if (__ballot(ill)) stab_err |= STAB_NOTE_ILL;  // a near-cut rank decision inside a heuristic's probe
       }
     }
     return feas;
@@ -2043,10 +2065,11 @@ __device__ __forceinline__ bool transition(const DiscreteParams& p, int e, Lds<K
     if (lane == 0) l.box[r.n_boxes] = P::pack(lx, ly, max_h, lx + x, ly + y, max_h + z);
     __syncthreads();
     int rc = 1, ne = 0, npv = 0, ill_i = 0;
+    StabStats cstats = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // (timed build only)
     if (lane == 0) {
       BoxGeo<K, BITS> geo{l.box};
       bool ill = false;
-      rc = stab_commit<false>(geo, l.st, r.n_boxes, item_den, l.sw.hull, l.sw.hull_bytes, ill);
+      rc = stab_commit<false>(geo, l.st, r.n_boxes, item_den, l.sw.hull, l.sw.hull_bytes, ill, TM::on ? &cstats : nullptr);
       ne = l.st.n_ent;
       npv = l.st.n_poly;
       ill_i = ill ? 1 : 0;
@@ -2057,6 +2080,13 @@ __device__ __forceinline__ bool transition(const DiscreteParams& p, int e, Lds<K
     if (__shfl(ill_i, 0, 64)) r.flags |= PCT_FLAG_ILL_CONDITIONED;
     if (rc < 0) r.stab_over |= STAB_WHY_COMMIT;
     ok = rc == 1;
+    if (TM::on) {
+      tm.add(ST_STAB_COMMIT_VISITS, (uint64_t)__builtin_amdgcn_readfirstlane(cstats.commit_visits));
+      tm.add(ST_STAB_LSQ3, (uint64_t)__builtin_amdgcn_readfirstlane(cstats.lsq3));
+      tm.add(ST_STAB_LSQ4, (uint64_t)__builtin_amdgcn_readfirstlane(cstats.lsq4));
+      tm.add(ST_STAB_LSQ5, (uint64_t)__builtin_amdgcn_readfirstlane(cstats.lsq5));
+      tm.add(ST_STAB_LSQX, (uint64_t)__builtin_amdgcn_readfirstlane(cstats.lsqx));
+    }
     __syncthreads();
   }
   if (ok && r.n_boxes >= p.I) {  // IndexError at D/space.py:385
@@ -2150,6 +2180,23 @@ __device__ __forceinline__ void decode_leaf(const EnvRegs& r, bool zero_row, int
 
 enum { ACT_ROWS = 0, ACT_INDEX = 1, ACT_HASH = 2, ACT_RESET = 3, ACT_HEUR = 4 /* row_len = PCT_HEUR_* */ };
 
+// Stand-in policy epilogue (pct_bind_policy_rows): the float32 [9] leaf row pct_policy_hash_rows_kernel would gather from
+// the observation just written -- k = number of valid leaves (the mask column, tools.py:103), leaf pct_mix32(g, t) % k,
+// the all-zero row when there is none (train_tools.py:66) -- written by the transition itself, so that a benchmark
+// loop needs no policy dispatch between two transitions.  Same bytes as the separate kernel's.
+template <typename K, int BITS>
+__device__ __forceinline__ void policy_epilogue(const DiscreteParams& p, int e, const Lds<K, BITS>& l, const EnvRegs& r, int lane) {
+  typedef Pack<K, BITS> P;
+  const int k = r.n_leaf;
+  const int li = k > 0 ? (int)(pct_mix32((uint32_t)(p.env_id_base + e), r.t) % (uint32_t)k) : 0;
+  if (lane < 9) {
+    const bool on = k > 0;
+    const K kk = on ? l.leaf[li] : (K)0;
+    const float v = lane < 5 ? (float)P::get(kk, lane) : (lane == 5 ? (on ? (float)p.H : 0.f) : (lane == 8 ? (on ? 1.0f : 0.f) : 0.f));
+    p.policy_rows[(size_t)e * 9 + lane] = v;
+  }
+}
+
 // one env, one launch's worth of transitions (the body of the kernel below)
 template <typename K, int BITS, int ACT, bool TIMED, bool STAB, int SCHEME, int RNG>
 __device__ __forceinline__ void discrete_env_steps(const DiscreteParams& p, const void* __restrict__ actions, int row_len, int n_steps,
@@ -2198,7 +2245,7 @@ __device__ __forceinline__ void discrete_env_steps(const DiscreteParams& p, cons
     return can_retry && ((((r.flags & ~flags_in) & (PCT_FLAG_EMS_OVERFLOW | PCT_FLAG_CANDIDATE_OVERFLOW)) != 0) || (STAB && r.stab_over));
   };
   if (can_retry && ((r.n_ems > p.ems_cap && ACT != ACT_RESET) || (STAB && r.stab_over && ACT != ACT_RESET))) {
-    if (lane == 0) p.retry_ids[atomicAdd(p.retry_count, 1)] = e;
+    retry_enqueue(p.retry_count, p.retry_ids, e);
     return;
   }
 
@@ -2209,10 +2256,11 @@ __device__ __forceinline__ void discrete_env_steps(const DiscreteParams& p, cons
     else draw_item(p, e, r);
     leaf_nodes<K, BITS, STAB, SCHEME, RNG>(p, e, l, r, lane, tm);
     if (overflowed()) {
-      if (lane == 0) p.retry_ids[atomicAdd(p.retry_count, 1)] = e;
+      retry_enqueue(p.retry_count, p.retry_ids, e);
       return;
     }
     write_obs<K, BITS>(p, e, l, r, lane, obs, true, -1);
+    if (p.policy_rows) policy_epilogue<K, BITS>(p, e, l, r, lane);
     store_state<K, BITS>(p, e, l, r, lane);
     ems_out = r.n_ems;
     return;
@@ -2224,7 +2272,8 @@ __device__ __forceinline__ void discrete_env_steps(const DiscreteParams& p, cons
     if (ACT == ACT_HEUR) {
       uint32_t serr = 0;
       giveup = !heur_choose<K, BITS, STAB>(p, e, l, r, lane, row_len, lx, ly, bx, by, bz, serr);
-      if (STAB) r.stab_over |= serr;
+      if (STAB && (serr & STAB_NOTE_ILL)) r.flags |= PCT_FLAG_ILL_CONDITIONED;
+      if (STAB) r.stab_over |= serr & ~STAB_NOTE_ILL;
     } else if (ACT == ACT_ROWS) {
       float v = act_v;
       float a0 = __shfl(v, 0, 64), a1 = __shfl(v, 1, 64), a2 = __shfl(v, 2, 64), a3 = __shfl(v, 3, 64),
@@ -2254,13 +2303,14 @@ __device__ __forceinline__ void discrete_env_steps(const DiscreteParams& p, cons
     const bool ended = transition<K, BITS, STAB, SCHEME, RNG>(p, e, l, r, lane, bad, flag, lx, ly, bx, by, bz, tm, giveup);
     leaf_nodes<K, BITS, STAB, SCHEME, RNG>(p, e, l, r, lane, tm);
     if (overflowed()) {
-      if (lane == 0) p.retry_ids[atomicAdd(p.retry_count, 1)] = e;
+      retry_enqueue(p.retry_count, p.retry_ids, e);
       return;
     }
     write_obs<K, BITS>(p, e, l, r, lane, obs, ended || (p.full_obs != 0 && it == 0), ended ? -1 : r.n_boxes - 1);
     __syncthreads();
     tm.tick(PH_OBS);
   }
+  if (p.policy_rows) policy_epilogue<K, BITS>(p, e, l, r, lane);
   store_state<K, BITS>(p, e, l, r, lane);
   ems_out = r.n_ems;
   tm.tick(PH_STORE);
@@ -2271,41 +2321,56 @@ template <typename K, int BITS, int ACT, bool TIMED, bool STAB, int SCHEME, int 
 // the plain setting-2 kernels are held to 128 VGPRs (4 waves per SIMD = 16 resident envs per CU, the
 // occupancy the LDS layout is sized for); the float64 stability code and the timed build are not
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STAB ? PCT_STAB_WAVES : 4)))
-pct_discrete_kernel(DiscreteParams p, const void* __restrict__ actions,
+pct_discrete_kernel(DiscreteParams p_arg, const void* __restrict__ actions,
                                                           int row_len, int n_steps,
                                                           const int32_t* __restrict__ env_ids, int n_ids) {
   extern __shared__ __align__(16) unsigned char smem[];
-  if (p.retry_mode) {
-    // large-capacity pass: a small grid strides over the envs the normal pass queued (usually none)
-    // p.retry_count points at this step's counter of a ping-pong pair; the other one (used by the next step's
-    // normal pass, which cannot start before this kernel ends) is zeroed here -- no memset between launches
-    const int limit = *p.retry_count;
-    if (blockIdx.x == 0 && threadIdx.x == 0) p.retry_count[p.retry_mode] = 0;  // retry_mode = +1 / -1: offset of the other
-    for (int w = blockIdx.x; w < limit; w += gridDim.x) {
-      const int e = __builtin_amdgcn_readfirstlane(p.retry_ids[w]);
-      work_key_begin(smem);
-      int n_ems = 0;
-      discrete_env_steps<K, BITS, ACT, TIMED, STAB, SCHEME, RNG>(p, actions, row_len, n_steps, e, smem, n_ems);
-      // (the large-capacity run is what this env's next step will look like: its key replaces the normal pass's)
-      work_key_end(smem, p.scalars, p.N, e, false, n_ems);
-      __syncthreads();
+#if PCT_KERNARG_PTR
+  // The parameter block is read where it is used, straight from the kernarg segment (scalar loads that hit the scalar
+  // cache), instead of through the by-value argument, which the backend loads whole in the entry block and then has to
+  // keep alive -- or spill to VGPR lanes -- for the length of the kernel.
+  const DiscreteParams& p = *(const DiscreteParams*)pct_param_fence((PctConstParams<DiscreteParams>)__builtin_amdgcn_kernarg_segment_ptr());
+#else
+  const DiscreteParams& p = p_arg;
+#endif
+  // One body for both passes (two inlined copies of the transition doubled the kernel's code).  Normal pass: workgroup b
+  // steps env b (or order[b], or env_ids[b] for a partial reset), once.  Large-capacity retry pass: a small grid strides
+  // over the envs the normal pass queued (usually none).  p.retry_count points at this step's counter of a ping-pong
+  // pair; the other one (used by the next step's normal pass, which cannot start before this kernel ends) is zeroed
+  // here -- no memset between launches.
+  const int rm = p.retry_mode;  // +1 / -1: offset of the other counter
+  int limit = 0;
+  if (rm) {
+    limit = *p.retry_count;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      p.retry_count[rm] = 0;
+      if (limit > 0 && p.retry_total) { p.retry_total[0] += limit; p.retry_total[1] += 1; }
     }
-    return;
   }
-  int e = blockIdx.x;
-  if (ACT == ACT_RESET && env_ids) {
-    if (e >= n_ids) return;
-    e = __builtin_amdgcn_readfirstlane(env_ids[e]);
-    if (e < 0 || e >= p.N) return;
-  } else if (ACT != ACT_RESET && p.order) {
-    // heavy-first dispatch: a permutation of 0..N-1.  (readfirstlane: the compiler would otherwise keep the loaded id,
-    // and every address derived from it, in vector registers -- 34 more spilled VGPRs in the setting-2 kernel)
-    e = __builtin_amdgcn_readfirstlane(p.order[e]);
+  int w = blockIdx.x;
+  while (true) {
+    int e = w;
+    if (rm) {
+      if (w >= limit) break;
+      e = __builtin_amdgcn_readfirstlane(p.retry_ids[w]);
+    } else if (ACT == ACT_RESET && env_ids) {
+      if (e >= n_ids) break;
+      e = __builtin_amdgcn_readfirstlane(env_ids[e]);
+      if (e < 0 || e >= p.N) break;
+    } else if (ACT != ACT_RESET && p.order) {
+      // heavy-first dispatch: a permutation of 0..N-1.  (readfirstlane: the compiler would otherwise keep the loaded id,
+      // and every address derived from it, in vector registers -- 34 more spilled VGPRs in the setting-2 kernel)
+      e = __builtin_amdgcn_readfirstlane(p.order[e]);
+    }
+    work_key_begin(smem);
+    int n_ems = 0;
+    discrete_env_steps<K, BITS, ACT, TIMED, STAB, SCHEME, RNG>(p, actions, row_len, n_steps, e, smem, n_ems);
+    // (a large-capacity run is what this env's next step will look like: its key replaces the normal pass's)
+    work_key_end(smem, p.scalars, p.N, e, !rm && ACT == ACT_RESET, n_ems);
+    if (!rm) break;
+    __syncthreads();
+    w += gridDim.x;
   }
-  work_key_begin(smem);
-  int n_ems = 0;
-  discrete_env_steps<K, BITS, ACT, TIMED, STAB, SCHEME, RNG>(p, actions, row_len, n_steps, e, smem, n_ems);
-  work_key_end(smem, p.scalars, p.N, e, ACT == ACT_RESET, n_ems);
 }
 
 }  // namespace pct
@@ -2347,7 +2412,8 @@ inline hipError_t launch_typed(const DiscreteParams& p, int act, const void* act
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
       if (er != hipSuccess) return er;                                                                       \
     }                                                                                                        \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, stream, p, actions, row_len, n_steps, env_ids, n_ids); \
+    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, stream, (hipEvent_t)p.launch_ev_start,           \
+                          (hipEvent_t)p.launch_ev_stop, 0, p, actions, row_len, n_steps, env_ids, n_ids); \
   } while (0)
   if (act == ACT_HEUR) {  // heuristic policies read the EMS list: LNES == EMS only (checked by the caller)
     if constexpr (MTSEL) {
@@ -2360,7 +2426,8 @@ inline hipError_t launch_typed(const DiscreteParams& p, int act, const void* act
       hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (er != hipSuccess) return er;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, stream, p, actions, row_len, n_steps, env_ids, n_ids);
+    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, stream, (hipEvent_t)p.launch_ev_start, (hipEvent_t)p.launch_ev_stop,
+                          0, p, actions, row_len, n_steps, env_ids, n_ids);
     return hipGetLastError();
     }
   }

@@ -2,6 +2,7 @@
 // No torch types, no CPU fallback: every transition is a HIP kernel launch; if there is no
 // usable device pct_create fails with PCT_ERR_NO_DEVICE / PCT_ERR_HIP.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -31,6 +32,21 @@ int fail(int code, const char* fmt, ...) {
   } while (0)
 
 enum { ACT_ROWS = 0, ACT_INDEX = 1, ACT_HASH = 2, ACT_RESET = 3, ACT_HEUR = 4 };
+
+/* Experiment knobs are read only under PCT_EXPERIMENT=1, and range-checked: a stray variable in a
+ * production environment must not resize an LDS pool. */
+bool experiments_on() {
+  const char* e = getenv("PCT_EXPERIMENT");
+  return e && atoi(e) == 1;
+}
+const char* knob(const char* name) { return experiments_on() ? getenv(name) : nullptr; }
+int knob_int(const char* name, int dflt, int lo, int hi) {
+  const char* e = knob(name);
+  if (!e) return dflt;
+  const int v = atoi(e);
+  return (v < lo || v > hi) ? dflt : v;
+}
+
 }  // namespace
 
 struct pct_env {
@@ -48,6 +64,7 @@ struct pct_env {
   int d_retry_parity;
   int* c_retry_base;    /* continuous env: the same */
   int c_retry_parity;
+  int d_retry_blocks;   /* grid of the discrete retry pass */
   bool continuous;
   // owned device memory
   std::vector<void*> owned;
@@ -124,8 +141,8 @@ int prof_begin(pct_env* h, hipStream_t s, size_t* slot) {
       h->ev_pool.push_back(std::make_pair(a, b));
     }
   }
-  *slot = h->ev_used++;
-  HIP_TRY(hipEventRecord(h->ev_pool[*slot].first, s));
+  *slot = h->ev_used++;  /* the pair is handed to hipExtLaunchKernel: it brackets exactly the step kernel's dispatch */
+  (void)s;
   return PCT_OK;
 }
 /* Heavy-first dispatch.  A launch that holds more envs than the chip keeps resident is worked off in the order the
@@ -204,7 +221,7 @@ __global__ void __launch_bounds__(1024) pct_order_kernel(const uint32_t* __restr
 
 int order_setup(pct_env* h) {
   h->order_state = -1;
-  const char* ev = getenv("PCT_ORDER"); /* kernel experiments: 0 = never, 1 = always */
+  const char* ev = knob("PCT_ORDER"); /* kernel experiments: 0 = never, 1 = always */
   if (ev && atoi(ev) <= 0) return PCT_OK;
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, h->device));
@@ -220,7 +237,7 @@ int order_setup(pct_env* h) {
   if (!(ev && atoi(ev) > 0) && N <= resident) return PCT_OK;
   int rc = dev_alloc(h, (void**)&h->d_order, (size_t)N * sizeof(int32_t), true);
   if (rc) return rc;
-  h->order_mode = getenv("PCT_ORDER_MODE") ? atoi(getenv("PCT_ORDER_MODE")) : 2; /* kernel experiments only */
+  h->order_mode = knob_int("PCT_ORDER_MODE", 2, 0, 2); /* kernel experiments only */
 
   h->order_state = 1;
   return PCT_OK;
@@ -246,16 +263,24 @@ int launch(pct_env* h, int act, const void* actions, int row_len, int n_steps, c
     HIP_TRY(order_launch(h, s));
     h->dp.order = h->cp.order = h->d_order;
   }
+  /* the profiling pair brackets the step kernel itself (the kernel the roofline is about), not the retry pass */
+  h->dp.launch_ev_start = h->dp.launch_ev_stop = h->cp.launch_ev_start = h->cp.launch_ev_stop = nullptr;
   if (h->profiling) {
     int rc = prof_begin(h, s, &slot);
     if (rc) return rc;
+    h->dp.launch_ev_start = h->cp.launch_ev_start = (void*)h->ev_pool[slot].first;
+    h->dp.launch_ev_stop = h->cp.launch_ev_stop = (void*)h->ev_pool[slot].second;
+  }
+  const int normal_grid = (act == ACT_RESET && ids) ? n_ids : (h->continuous ? h->cp.N : h->dp.N);
+  if (h->profiling && normal_grid <= 0) { /* nothing is dispatched: the pair would never be signalled */
+    h->ev_used--;
+    h->dp.launch_ev_start = h->dp.launch_ev_stop = h->cp.launch_ev_start = h->cp.launch_ev_stop = nullptr;
   }
   if (h->continuous) {
     h->cp.full_obs = h->dp.full_obs;
+    h->cp.policy_rows = h->dp.policy_rows;
     if (h->has_retry) h->cp.retry_count = h->c_retry_base + h->c_retry_parity; /* ping-pong pair of queue counters */
     HIP_TRY(pct::launch_continuous(h->cp, act, actions, row_len, n_steps, ids, n_ids, s));
-    /* the profiling pair brackets the step kernel itself (the kernel the roofline is about), not the retry pass */
-    if (h->profiling) HIP_TRY(hipEventRecord(h->ev_pool[slot].second, s));
     if (h->has_retry) {
       /* keep the retry pass in step with everything that may have changed on the handle */
       pct::ContinuousParams& q = h->cp_retry;
@@ -268,6 +293,9 @@ int launch(pct_env* h, int act, const void* actions, int row_len, int n_steps, c
       q.low_bound = c.low_bound; q.obs = c.obs; q.reward = c.reward; q.done = c.done; q.counter = c.counter;
       q.ratio = c.ratio; q.flags = c.flags; q.timing = nullptr; q.full_obs = c.full_obs; q.mask = c.mask;
       q.retry_count = c.retry_count;
+      q.policy_rows = c.policy_rows;
+      q.retry_total = c.retry_total;
+      q.launch_ev_start = q.launch_ev_stop = nullptr;
       q.order = nullptr;
       q.retry_mode = h->c_retry_parity ? -1 : 1;
       h->c_retry_parity ^= 1;
@@ -279,7 +307,6 @@ int launch(pct_env* h, int act, const void* actions, int row_len, int n_steps, c
       h->dp.retry_count = h->d_retry_base + h->d_retry_parity;
     }
     HIP_TRY(pct::launch_discrete(h->dp, act, actions, row_len, n_steps, ids, n_ids, s));
-    if (h->profiling) HIP_TRY(hipEventRecord(h->ev_pool[slot].second, s));
     if (h->has_dretry) {
       /* the same step again, with larger LDS lists, for the envs the normal pass queued (usually none: the
        * small grid then exits at once) */
@@ -289,7 +316,8 @@ int launch(pct_env* h, int act, const void* actions, int row_len, int n_steps, c
       q.sb.caps = h->d_retry_stab;
       q.retry_mode = h->d_retry_parity ? -1 : 1;
       q.timing = nullptr;
-      HIP_TRY(pct::launch_discrete(q, act, actions, row_len, n_steps, nullptr, 16, s));
+      q.launch_ev_start = q.launch_ev_stop = nullptr;
+      HIP_TRY(pct::launch_discrete(q, act, actions, row_len, n_steps, nullptr, h->d_retry_blocks, s));
       h->d_retry_parity ^= 1;
     }
     if (act != ACT_RESET || !ids) h->dp.full_obs = 0; /* every env has rewritten its rows */
@@ -304,6 +332,7 @@ int launch(pct_env* h, int act, const void* actions, int row_len, int n_steps, c
  * / sixteen vertices per node, a workspace that takes a box on 120 supporters and 512 tasks. */
 void stab_default_caps(int I, pct::StabCaps& normal, pct::StabCaps& retry) {
   normal.SP = I < 64 ? 64 : I;
+  if (normal.SP > 4094) normal.SP = 4094; /* STAB_END: 12-bit pool offsets */
   normal.PP = 2 * I < 128 ? 128 : 2 * I;
   normal.ws_bytes = 16 * pct::stab_ws_need(2);  /* stab_fit_wave() widens these two into the LDS the env has left */
   normal.queue = 96;
@@ -312,11 +341,10 @@ void stab_default_caps(int I, pct::StabCaps& normal, pct::StabCaps& retry) {
   retry.ws_bytes = 16 * 1024;
   retry.queue = 512;
   /* kernel experiments only: PCT_STAB_SP / _PP / _WS / _Q override the normal pass */
-  const char* e;
-  if ((e = getenv("PCT_STAB_SP"))) normal.SP = atoi(e);
-  if ((e = getenv("PCT_STAB_PP"))) normal.PP = atoi(e);
-  if ((e = getenv("PCT_STAB_WS"))) normal.ws_bytes = atoi(e);
-  if ((e = getenv("PCT_STAB_Q"))) normal.queue = atoi(e);
+  normal.SP = knob_int("PCT_STAB_SP", normal.SP, 1, 4094);
+  normal.PP = knob_int("PCT_STAB_PP", normal.PP, 4, 65535);
+  normal.ws_bytes = knob_int("PCT_STAB_WS", normal.ws_bytes, pct::stab_ws_need(2), 64 * 1024);
+  normal.queue = knob_int("PCT_STAB_Q", normal.queue, 8, 4096);
   if (retry.SP < normal.SP) retry.SP = normal.SP;
   if (retry.PP < normal.PP) retry.PP = normal.PP;
   if (retry.ws_bytes < normal.ws_bytes) retry.ws_bytes = normal.ws_bytes;
@@ -328,7 +356,7 @@ void stab_default_caps(int I, pct::StabCaps& normal, pct::StabCaps& retry) {
  * lane): the rounds of a check are latency chains, so the more candidates share one the better (measured, c1: 32
  * lanes / 112 tasks 9.2 M env-steps/s, 16 lanes / 96 tasks 7.0 M; profiles/r03_stability_tuning.txt). */
 void stab_fit_wave(size_t lds_without_wave, pct::StabCaps& caps) {
-  if (getenv("PCT_STAB_WS") || getenv("PCT_STAB_Q")) return; /* explicit (experiments / tests) */
+  if (knob("PCT_STAB_WS") || knob("PCT_STAB_Q")) return; /* explicit (experiments / tests) */
   const long budget = 40 * 1024 - 64 - (long)lds_without_wave;
   const int per = pct::stab_ws_need(2);
   for (int lanes = 64; lanes >= 16; lanes -= 8) {
@@ -356,7 +384,7 @@ const char* pct_last_error(void) { return g_err; }
  * (profiles/r02_prio_sweep.txt); PCT_WAVE_PRIO="t1,t2,t3" overrides ("0": off) -- a tuning knob, not ABI */
 static void prio_thresholds(int out[3], int d1, int d2, int d3) {
   out[0] = d1; out[1] = d2; out[2] = d3;
-  const char* s = getenv("PCT_WAVE_PRIO");
+  const char* s = knob("PCT_WAVE_PRIO");
   if (!s) return;
   int a = 0, b = 0, c = 0;
   int n = sscanf(s, "%d,%d,%d", &a, &b, &c);
@@ -377,6 +405,9 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
     return fail(PCT_ERR_UNSUPPORTED, "EV / EP / CP / FC are reachable only in the discrete env (C/bin3D.py:53)");
   if (cfg->num_envs < 1 || cfg->internal_node_holder < 1 || cfg->leaf_node_holder < 1)
     return fail(PCT_ERR_INVALID_ARG, "num_envs / holders must be positive");
+  /* the pooled stability state packs box ids into 10 bits (0x3FF = "no box") and pool offsets into 12 / 16 bits (pct_stab.cuh) */
+  if (cfg->setting != 2 && cfg->internal_node_holder > 1022)
+    return fail(PCT_ERR_UNSUPPORTED, "settings 1 / 3 support at most 1022 internal nodes (10-bit box ids of the stability state)");
   int W = cfg->container[0], Ly = cfg->container[1], H = cfg->container[2];
   if (W < 1 || Ly < 1 || H < 1) return fail(PCT_ERR_INVALID_ARG, "bad container");
   int maxdim = W > Ly ? W : Ly;
@@ -406,7 +437,7 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
                                                            * 256 EMS = at most 512 candidates, a 2048-slot table; 8192 slots of
                                                            * 64-bit keys would not leave room for the stability state */
                                                           : (cont ? 32768 : (cfg->setting != 2 ? 2048 : 8192)));
-  if (getenv("PCT_CAND_CAP")) cand_cap = atoi(getenv("PCT_CAND_CAP")); /* kernel experiments only */
+  if (knob("PCT_CAND_CAP") && cfg->candidate_capacity <= 0) cand_cap = atoi(knob("PCT_CAND_CAP")); /* kernel experiments only; never over an explicit capacity */
   if (!is_cand_cap_ok(cand_cap)) return fail(PCT_ERR_INVALID_ARG, "candidate_capacity must be 8*4^k (8,32,...,2048,8192)");
 
   int ndev = 0;
@@ -430,6 +461,7 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
   h->d_order = nullptr;
   h->continuous = cont;
   h->has_dretry = false;
+  h->d_retry_blocks = knob_int("PCT_RETRY_BLOCKS", 16, 1, 1024);
   memset(&h->cp, 0, sizeof h->cp);
   int rc = use_device(h);
   if (rc) { delete h; return rc; }
@@ -528,7 +560,8 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
        * candidate table or a longer EMS list -- are re-run by a small grid-strided pass with 32768-slot tables in
        * HBM (covers ems_capacity * 24 candidates up to 19660) and ems_stride EMS */
       const int RB = 128, big = 32768;
-      CALLOC_(h->c_retry_base, 2 * sizeof(int));
+      CALLOC_(h->c_retry_base, 4 * sizeof(int)); /* queue counters [0,1], totals [2,3] */
+      c.retry_total = h->c_retry_base + 2;
       c.retry_count = h->c_retry_base;
       h->c_retry_parity = 0;
       CALLOC_(c.retry_ids, Nn * sizeof(int));
@@ -655,7 +688,8 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
     ALLOC(p.sb.ent, N * p.sb.sp_stride * sizeof(uint32_t));
   }
   if (h->has_dretry) {
-    ALLOC(h->d_retry_base, 2 * sizeof(int));
+    ALLOC(h->d_retry_base, 4 * sizeof(int)); /* queue counters [0,1], totals [2,3] */
+    p.retry_total = h->d_retry_base + 2;
     p.retry_count = h->d_retry_base;
     h->d_retry_parity = 0;
     ALLOC(p.retry_ids, N * sizeof(int));
@@ -1015,6 +1049,12 @@ int pct_policy_hash_rows(pct_env* h, float* rows_out, void* stream) {
   return PCT_OK;
 }
 
+int pct_bind_policy_rows(pct_env* h, float* rows_out) {
+  if (!h) return fail(PCT_ERR_INVALID_ARG, "null handle");
+  h->dp.policy_rows = rows_out; /* (launch() hands it to the continuous block and to the retry passes) */
+  return PCT_OK;
+}
+
 int pct_profile_enable(pct_env* h, int32_t on) {
   if (!h) return fail(PCT_ERR_INVALID_ARG, "null handle");
   int rc = use_device(h);
@@ -1037,6 +1077,32 @@ int pct_profile_read(pct_env* h, int64_t* n_launches, double* total_ms) {
   if (total_ms) *total_ms = h->prof_ms;
   h->prof_launches = 0;
   h->prof_ms = 0.0;
+  return PCT_OK;
+}
+
+int pct_debug_work_keys(pct_env* h, uint32_t* host_out) {
+  if (!h || !host_out) return fail(PCT_ERR_INVALID_ARG, "null argument");
+  int rc = use_device(h);
+  if (rc) return rc;
+  const size_t N = (size_t)(h->continuous ? h->cp.N : h->dp.N);
+  const int32_t* scalars = h->continuous ? h->cp.scalars : h->dp.scalars;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(host_out, reinterpret_cast<const uint32_t*>(scalars) + N * PCT_SCALARS, N * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return PCT_OK;
+}
+
+int pct_debug_retry_count(pct_env* h, int32_t* last, int64_t* envs_total, int64_t* launches_total) {
+  if (!h) return fail(PCT_ERR_INVALID_ARG, "null handle");
+  int rc = use_device(h);
+  if (rc) return rc;
+  int w[4] = {0, 0, 0, 0};
+  const int* base = h->continuous ? (h->has_retry ? h->c_retry_base : nullptr) : (h->has_dretry ? h->d_retry_base : nullptr);
+  const int parity = h->continuous ? h->c_retry_parity : h->d_retry_parity;
+  HIP_TRY(hipDeviceSynchronize());
+  if (base) HIP_TRY(hipMemcpy(w, base, sizeof w, hipMemcpyDeviceToHost));
+  if (last) *last = w[parity ^ 1]; /* the last launch's counter: the parity was flipped after it was enqueued */
+  if (envs_total) *envs_total = w[2];
+  if (launches_total) *launches_total = w[3];
   return PCT_OK;
 }
 

@@ -115,6 +115,9 @@ __device__ __forceinline__ uint64_t lds_atomic_min(uint64_t* p, uint64_t v) {
   return (uint64_t)atomicMin(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v);
 }
 
+#ifndef PCT_MATCH_MASKS
+#define PCT_MATCH_MASKS 1 /* 1: the one-key-per-lane matching walk keeps its lane sets as scalar masks (pyset_match_v) */
+#endif
 #define PCT_PEND_SLOTS 128
 // Table accessors.  GT == false: the table is in LDS (plain accesses).  GT == true: the table
 // is a per-env slice of HBM (capacities that do not fit in LDS): every access goes to L2
@@ -236,6 +239,66 @@ __device__ __forceinline__ void pyset_match(K* tab, uint32_t mask, bool part, ui
     // smaller than mytag and stays, so the atomic doubles as the read.  Wave-uniform loops with a
     // predicated body (an iteration = one LDS atomic and a handful of selects); a lane's position always
     // moves past the slot it has just tried, so an evicted lane simply resumes.
+#if PCT_MATCH_MASKS
+    {
+      // the lane sets as scalar masks, the next position computed in the atomic's shadow: see pyset_match_v
+      const K EMPTYW = SlotWord<K>::EMPTY;
+      uint32_t ci = (uint32_t)hash & mask;
+      int cj = 0;
+      uint64_t cp = hash;
+      uint32_t pos = ci;
+      uint64_t wm = __ballot(part), pm = 0;
+      while (true) {
+        if (stats) stats[1]++;
+        while (wm) {
+          const bool w = __builtin_amdgcn_inverse_ballot_w64(wm);
+          const uint32_t tried = pos;
+          K old = lds_atomic_min(&tab[pos], w ? mytag : EMPTYW);
+          {
+            uint32_t ni = ci;
+            int nj = cj;
+            uint64_t np = cp;
+            walk_advance(ni, nj, np, mask);
+            const uint32_t npos = ni + (uint32_t)nj;
+            ci = w ? ni : ci;
+            cj = w ? nj : cj;
+            cp = w ? np : cp;
+            pos = w ? npos : pos;
+            uint32_t plo = (uint32_t)cp, phi = (uint32_t)(cp >> 32);
+            if (sizeof(K) == 4) {
+              uint32_t o32 = (uint32_t)old;
+              asm volatile("" : "+v"(o32), "+v"(ci), "+v"(cj), "+v"(plo), "+v"(phi), "+v"(pos));
+              old = (K)o32;
+            } else {
+              uint32_t olo = (uint32_t)old, ohi = (uint32_t)((uint64_t)old >> 32);
+              asm volatile("" : "+v"(olo), "+v"(ohi), "+v"(ci), "+v"(cj), "+v"(plo), "+v"(phi), "+v"(pos));
+              old = (K)(((uint64_t)ohi << 32) | olo);
+            }
+            cp = ((uint64_t)phi << 32) | plo;
+          }
+          my_probes++;
+          const uint64_t won = __ballot(old > mytag) & wm;  // was empty, or tentatively held by a later lane
+          uint64_t stop = won;
+          if (check_found) {
+            const bool cand = w && !(old & TAG);  // a real key: is it this lane's own?
+            if (__ballot(cand)) stop |= __ballot(cand && same(old));
+          }
+          slot = __builtin_amdgcn_inverse_ballot_w64(won) ? tried : slot;
+          pm |= won;
+          wm &= ~stop;
+        }
+        __syncthreads();
+        const bool held = __builtin_amdgcn_inverse_ballot_w64(pm);
+        const K now = tab[slot];
+        wm = __ballot(held && now != mytag);  // evicted by an earlier lane: walk on from the next slot
+        pm &= ~wm;
+        if (!wm) break;
+      }
+      placed = __builtin_amdgcn_inverse_ballot_w64(pm);
+      if (stats) { stats[0]++; stats[2] += wave_max_i32(my_probes); }
+      return;
+    }
+#endif
     uint32_t i = (uint32_t)hash & mask;
     int j = 0;
     uint64_t perturb = hash;
@@ -448,6 +511,81 @@ __device__ __forceinline__ void pyset_match_v(K* tab, uint32_t mask, const bool 
                                      uint32_t (&slot)[V], int* stats = nullptr, const K* key = nullptr,
                                      bool* placed_out = nullptr, uint32_t base = 0) {
   const K TAG = SlotWord<K>::TAG;
+#if PCT_MATCH_MASKS
+  if constexpr (V == 1) {
+    // One key per lane (the shipped configuration): the walk with its lane sets -- walking, won, placed -- kept as 64-bit
+    // masks in SCALAR registers (round 4).  A walk step is a chain: LDS atomic -> compare -> who is still walking -> the next
+    // atomic; scripts/microbench_walk.hip measures 85 cycles for the returning LDS atomic alone and 270 for a step of the
+    // per-lane-predicate formulation below, most of it the compiler's select / re-test sequences around the wave-uniform
+    // loop condition.  Here the chain behind the atomic is v_cmp (into an SGPR pair), two s_and / s_andn2, the loop branch
+    // and one v_cndmask that takes the mask straight from the SGPRs (inverse ballot); the probe-sequence arithmetic of the
+    // NEXT position does not depend on the value returned and runs in the atomic's shadow.  Same proposals, same order,
+    // same fixed point as the formulation below.
+    const K mytag = TAG | (K)(base + (uint32_t)lane);
+    const K EMPTYW = SlotWord<K>::EMPTY;
+    uint32_t ci = (uint32_t)hash[0] & mask;
+    int cj = 0;
+    uint64_t cp = hash[0];
+    uint32_t pos = ci;
+    uint32_t myslot = 0;
+    uint64_t wm = __ballot(part[0]);  // lanes that are walking
+    uint64_t pm = 0;                  // lanes that hold a slot (tentatively, until the fixed point)
+    int my_probes = 0;
+    while (true) {
+      if (stats) stats[1]++;
+      const uint64_t t_loop = stats ? __builtin_readcyclecounter() : 0;  // (timed build only)
+      while (wm) {
+        const bool w = __builtin_amdgcn_inverse_ballot_w64(wm);
+        // every lane issues the atomic: one that is not walking proposes the all-ones word, which changes no slot
+        const uint32_t tried = pos;
+        K old = lds_atomic_min(&tab[pos], w ? mytag : EMPTYW);
+        // past the slot just tried (an evicted key resumes there; a lane that is not walking stays where it is): none of
+        // this depends on the value returned -- it is pinned in front of its first use, in the atomic's shadow
+        {
+          uint32_t ni = ci;
+          int nj = cj;
+          uint64_t np = cp;
+          walk_advance(ni, nj, np, mask);
+          const uint32_t npos = ni + (uint32_t)nj;
+          ci = w ? ni : ci;
+          cj = w ? nj : cj;
+          cp = w ? np : cp;
+          pos = w ? npos : pos;
+          uint32_t plo = (uint32_t)cp, phi = (uint32_t)(cp >> 32);
+          if (sizeof(K) == 4) {
+            uint32_t o32 = (uint32_t)old;
+            asm volatile("" : "+v"(o32), "+v"(ci), "+v"(cj), "+v"(plo), "+v"(phi), "+v"(pos));
+            old = (K)o32;
+          } else {
+            uint32_t olo = (uint32_t)old, ohi = (uint32_t)((uint64_t)old >> 32);
+            asm volatile("" : "+v"(olo), "+v"(ohi), "+v"(ci), "+v"(cj), "+v"(plo), "+v"(phi), "+v"(pos));
+            old = (K)(((uint64_t)ohi << 32) | olo);
+          }
+          cp = ((uint64_t)phi << 32) | plo;
+        }
+        const uint64_t won = __ballot(old > mytag) & wm;  // was empty, or tentatively held by a later position
+        uint64_t stop = won;
+        if (CHECK) stop |= __ballot(!(old & TAG) && old == key[0]) & wm;  // its own entry: set.add of a member is a no-op
+        myslot = __builtin_amdgcn_inverse_ballot_w64(won) ? tried : myslot;
+        pm |= won;
+        if (stats) my_probes++;
+        wm &= ~stop;
+      }
+      if (stats) stats[3] += (int)(__builtin_readcyclecounter() - t_loop);
+      __syncthreads();
+      // evicted by an earlier position: walk on
+      const bool held = __builtin_amdgcn_inverse_ballot_w64(pm);
+      const K now = tab[myslot];
+      wm = __ballot(held && now != mytag);
+      pm &= ~wm;
+      if (!wm) break;
+    }
+    if (stats) { stats[0]++; stats[2] += wave_max_i32(my_probes); }
+    slot[0] = myslot;
+    if (CHECK) placed_out[0] = __builtin_amdgcn_inverse_ballot_w64(pm);
+    return;
+  }
+#endif
   uint32_t i[V];
   int j[V];
   uint64_t perturb[V];
@@ -465,6 +603,7 @@ __device__ __forceinline__ void pyset_match_v(K* tab, uint32_t mask, const bool 
   int my_probes = 0;
   while (true) {
     if (stats) stats[1]++;
+    const uint64_t t_loop = stats ? __builtin_readcyclecounter() : 0;  // (timed build only)
     while (__ballot(any_of<V>(walking))) {
       K old[V];
       uint32_t cur[V];
@@ -494,6 +633,7 @@ __device__ __forceinline__ void pyset_match_v(K* tab, uint32_t mask, const bool 
         walking[v] = walking[v] & !won & !member;
       }
     }
+    if (stats) stats[3] += (int)(__builtin_readcyclecounter() - t_loop);
     __syncthreads();
 #pragma unroll
     for (int v = 0; v < V; v++) {
@@ -639,7 +779,11 @@ enum { PH_LOAD = 0, PH_DROP = 1, PH_GENEMS = 2, PH_SET = 3, PH_FEAS = 4, PH_OBS 
        // plain per-step statistics (not cycles)
        ST_EMS = 12, ST_DISTINCT = 13, ST_GENERATED = 14, ST_MATCH_CALLS = 16, ST_MATCH_ROUNDS = 17, ST_MATCH_PROBES = 18,
        ST_CONTAINS_CALLS = 19, ST_CONTAINS_PROBES = 20, ST_FLUSHES = 21, PH_FAST_START = 22, ST_REBUILDS = 23,
-       PH_SET_HASH = 24, PH_GEN_TUPLE = 25, PH_GEN_HASH = 26, PH_GEN_CONTAINS = 27, PH_GEN_PEND = 28, PH_GEN_PAIRS = 29 };
+       PH_SET_HASH = 24, PH_GEN_TUPLE = 25, PH_GEN_HASH = 26, PH_GEN_CONTAINS = 27, PH_GEN_PEND = 28, PH_GEN_PAIRS = 29,
+       // stability settings (slots the set statistics above leave at zero): commit walk visits, virtual-check passes / tasks /
+       // single-task passes / level-0 candidates, least-squares splits by supporter count
+       ST_STAB_COMMIT_VISITS = 30, ST_STAB_VPASSES = 31, ST_STAB_VTASKS = 15, ST_STAB_VNARROW = 19, ST_STAB_LSQ3 = 20,
+       ST_STAB_LSQ4 = 24, ST_STAB_LSQ5 = 25, ST_STAB_LSQX = 26, ST_STAB_LEVEL0 = 27 };
 
 
 }  // namespace pct

@@ -61,6 +61,7 @@ constexpr uint32_t STAB_WHY_HULL = 0x400u;      // a hull of more than 255 verti
 constexpr uint32_t STAB_WHY_SPLIT = 0x800u;     // more than STAB_LSQ supporters and none of them direct
 constexpr uint32_t STAB_WHY_COMMIT = 0x1000u;   // the commit: pools, workspace or depth-first stack
 constexpr uint32_t STAB_WHY_LOAD = 0x2000u;     // the stored state does not fit this launch's pools
+constexpr uint32_t STAB_NOTE_ILL = 0x4000u;     // (not a capacity: carries the ill-conditioning notice out of a heuristic's probes)
 
 // capacities of one launch (LDS sizes follow from them: stab_state_bytes / stab_ws_bytes)
 struct StabCaps {
@@ -423,6 +424,14 @@ PCT_SD void stab_split_fixed(const double (*c2)[2], const double stk[4], double 
   stab_lstsq_fixed<N>(A, xr, ill);
 }
 
+// optional counters of one env-step (timed build only; a null pointer compiles to nothing): where a long step spends its time
+struct StabStats {
+  int commit_visits;                  // boxes the commit's depth-first walk expanded (re-visits through other paths included)
+  int v_passes, v_tasks, v_narrow;    // virtual checks: queue passes, tasks popped, passes that popped a single task
+  int v_level0;                       // candidates that went through a level-0 task
+  int lsq3, lsq4, lsq5, lsqx;         // least-squares splits by supporter count (x: the generic 6..STAB_LSQ solve)
+};
+
 // How a box with stack `stk` splits over its k supporters (D/space.py:88-160 / :182-256).
 //   mode 0: one supporter (everything; the entry IS the box's stack object)
 //   mode 1: a supporter whose contact rectangle holds the centre of mass ("direct": everything, the others a zero-mass
@@ -439,7 +448,8 @@ struct StabSplit {
 // scratch memory -- kept OUT of StabSplit so that the struct itself stays in registers
 struct StabSplitX { double fx[STAB_LSQ]; };
 template <bool CONT, typename Geo, typename Sup>
-PCT_SD bool stab_split(const Geo& geo, const double bg[9], int k, const Sup& sup, const double stk[4], StabSplit& sp, StabSplitX& sx) {
+PCT_SD bool stab_split(const Geo& geo, const double bg[9], int k, const Sup& sup, const double stk[4], StabSplit& sp, StabSplitX& sx,
+                       StabStats* ss = nullptr) {
   sp.mode = 0; sp.direct = -1; sp.ill = false;
 #pragma unroll
   for (int i = 0; i < 5; i++) sp.f[i] = 0;
@@ -484,12 +494,14 @@ PCT_SD bool stab_split(const Geo& geo, const double bg[9], int k, const Sup& sup
       return true;
     }
     sp.mode = 3;
+    if (ss) { ss->lsq3 += k == 3; ss->lsq4 += k == 4; ss->lsq5 += k == 5; }
     if (k == 3) { double x3[3]; stab_split_fixed<3>(c2, stk, x3, sp.ill); sp.f[0] = x3[0]; sp.f[1] = x3[1]; sp.f[2] = x3[2]; }
     else if (k == 4) { double x4[4]; stab_split_fixed<4>(c2, stk, x4, sp.ill); sp.f[0] = x4[0]; sp.f[1] = x4[1]; sp.f[2] = x4[2]; sp.f[3] = x4[3]; }
     else stab_split_fixed<5>(c2, stk, sp.f, sp.ill);
     return true;
   }
   sp.mode = 3;
+  if (ss) ss->lsqx++;
   double c2[STAB_LSQ][2];
   for (int i = 0; i < k; i++) {
     double a[4];
@@ -584,10 +596,10 @@ PCT_SD void stab_com(const Geo& geo, const StabState& st, int S, int skip, const
 // `emit(Si, child_stack)` is called once per supporter, in order.  False: a capacity was exceeded.
 template <bool CONT, typename Geo, typename Emit>
 PCT_SD bool stab_children(const Geo& geo, const StabState& st, const double bg[9], int k, const StabSup& sup, const double stk[4],
-                          int skip, bool& ill, Emit emit) {
+                          int skip, bool& ill, Emit emit, StabStats* ss = nullptr) {
   StabSplit sp;
   StabSplitX sx;
-  if (!stab_split<CONT>(geo, bg, k, sup, stk, sp, sx)) return false;
+  if (!stab_split<CONT>(geo, bg, k, sup, stk, sp, sx, ss)) return false;
   ill = ill || sp.ill;
   const double own[3] = {bg[0] + bg[6] / 2, bg[1] + bg[7] / 2, bg[2] + bg[8] / 2};
   for (int i = 0; i < k; i++) {
@@ -732,7 +744,8 @@ PCT_SD int stab_class(int k) { return k <= 2 ? 2 : (k <= 8 ? 8 : (k <= 32 ? 32 :
 // fails anyway must not count).
 template <bool CONT, typename Geo>
 __device__ __forceinline__ bool stab_virtual_wave(const Geo& geo, const StabState& st, int n, bool need, const double cand[9],
-                                                  double density, const StabWave& w, int lane, uint32_t& cap_err, bool& lane_err, bool& ill) {
+                                                  double density, const StabWave& w, int lane, uint32_t& cap_err, bool& lane_err, bool& ill,
+                                                  StabStats* ss = nullptr) {
   // supporter count of every candidate; the first two ids stay in registers (the common class needs no second scan)
   int k = 0;
   uint32_t id0 = 0, id1 = 0;
@@ -795,6 +808,7 @@ __device__ __forceinline__ bool stab_virtual_wave(const Geo& geo, const StabStat
       if (rc == 0) atomicOr(&w.ctl[1 + (lane >> 5)], 1u << (lane & 31));
       if (rc < 0) atomicOr(&w.ctl[4 + (lane >> 5)], 1u << (lane & 31));
       have = rc == 1;
+      if (ss) ss->v_level0++;
       kk = k;
       supw = v.ids;
 #pragma unroll
@@ -814,8 +828,9 @@ __device__ __forceinline__ bool stab_virtual_wave(const Geo& geo, const StabStat
           }
         };
         StabSup sup{supw};
-        if (!stab_children<CONT>(geo, st, bg, kk, sup, stk, skip, ill, emit)) atomicOr(&w.ctl[4 + (cl >> 5)], 1u << (cl & 31));
+        if (!stab_children<CONT>(geo, st, bg, kk, sup, stk, skip, ill, emit, ss)) atomicOr(&w.ctl[4 + (cl >> 5)], 1u << (cl & 31));
       }
+      if (ss && lane == 0) ss->v_passes++;
       __syncthreads();
       const uint32_t qraw = w.ctl[0];
       const int qn = (int)(qraw < (uint32_t)w.qcap ? qraw : (uint32_t)w.qcap);
@@ -847,6 +862,7 @@ __device__ __forceinline__ bool stab_virtual_wave(const Geo& geo, const StabStat
         break;
       }
       const bool has = lane < take;
+      if (ss && lane == 0) { ss->v_tasks += take; ss->v_narrow += take == 1; }
       if (has) {
         stk[0] = w.qstk[(size_t)ti * 4 + 0]; stk[1] = w.qstk[(size_t)ti * 4 + 1];
         stk[2] = w.qstk[(size_t)ti * 4 + 2]; stk[3] = w.qstk[(size_t)ti * 4 + 3];
@@ -930,7 +946,8 @@ __device__ __forceinline__ void stab_store(const StabHbm& hb, int I, int e, int 
 // Sequential (one lane).  `ws` / `ws_bytes`: workspace for the hull, then for the depth-first stack.
 // Returns 1: stable, 0: unstable, -1: a capacity (pools, workspace, supporters) was exceeded.
 template <bool CONT, typename Geo>
-PCT_SD int stab_commit(const Geo& geo, StabState& st, int n, double density, unsigned char* ws, int ws_bytes, bool& ill) {
+PCT_SD int stab_commit(const Geo& geo, StabState& st, int n, double density, unsigned char* ws, int ws_bytes, bool& ill,
+                       StabStats* ss = nullptr) {
   double bg[9];
   geo(n, bg);
   // supporters: as many ids as the workspace can take a hull for
@@ -999,12 +1016,13 @@ PCT_SD int stab_commit(const Geo& geo, StabState& st, int n, double density, uns
       const double stk[4] = {st.stk[(size_t)id * 4 + 0], st.stk[(size_t)id * 4 + 1], st.stk[(size_t)id * 4 + 2],
                              st.stk[(size_t)id * 4 + 3]};
       if (!stab_pip(stk, gp, stab_npoly(st, id))) return 0;
+      if (ss) ss->commit_visits++;
       // distribute to every supporter first (up_edges[self] = share; calculate_new_com())
       double g[9];
       geo(id, g);
       StabSplit sp;
       StabSplitX sx;
-      if (!stab_split<CONT>(geo, g, kk, sup, stk, sp, sx)) return -1;
+      if (!stab_split<CONT>(geo, g, kk, sup, stk, sp, sx, ss)) return -1;
       ill = ill || sp.ill;
       const int alias_k = sp.mode == 0 ? 0 : (sp.mode == 1 ? sp.direct : -1);
       st.meta[2 * id] = (st.meta[2 * id] & 0xFFFF00FFu) | ((uint32_t)(alias_k + 1) << 8);

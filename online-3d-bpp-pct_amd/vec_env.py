@@ -424,6 +424,12 @@ class PctVecEnv(VecEnv):
         """Back to the handle's own observation / reward buffers (and no mask output) after a run of step_into()
         calls: the next transition rewrites every observation row there.  RolloutSlots may be dropped afterwards."""
         with torch.cuda.device(self._dev_index):
+            # the live observation / reward are in the slot: carry them over, so that current_obs() and a policy that
+            # reads it after the unbind see the env's CURRENT leaf list (ADVICE r3)
+            if self._obs.data_ptr() != self._own[0].data_ptr():
+                self._own[0].copy_(self._obs.view_as(self._own[0]))
+            if self._reward.data_ptr() != self._own[1].data_ptr():
+                self._own[1].copy_(self._reward.view_as(self._own[1]))
             torch.cuda.current_stream(self.device).synchronize()
         self._bind_own_views()
         self._slot_keepalive = None
@@ -439,6 +445,17 @@ class PctVecEnv(VecEnv):
         with torch.cuda.device(self._dev_index):
             _lib.check(self._L.pct_policy_hash_rows(self._h, out.data_ptr(), self._stream()))
         return out
+
+    def bind_policy_rows(self, rows):
+        """Stand-in policy as an EPILOGUE of every following launch (pct_bind_policy_rows): the transition kernel also
+        writes, for the observation it has just produced, the float32 [N,9] leaf row `policy_hash_rows` would gather
+        from it into `rows` -- `step_rows_device(rows)` can then follow `step_rows_device(rows)` with no policy
+        dispatch in between.  None switches it off."""
+        if rows is not None and not (rows.is_contiguous() and rows.dtype == torch.float32 and rows.device == self.device
+                                     and rows.numel() == self.N * 9):
+            raise ValueError("rows must be a contiguous float32 [N,9] tensor on the env's device")
+        self._policy_rows_keepalive = rows
+        _lib.check(self._L.pct_bind_policy_rows(self._h, rows.data_ptr() if rows is not None else None))
 
     def step_rows_device(self, rows):
         """Enqueue one step from device-resident float32 [N,9|6|3] rows; no host work."""
@@ -488,6 +505,19 @@ class PctVecEnv(VecEnv):
             self._ep_l[done] = 0
         infos = LazyInfos(counter, ratio, done, ep_r, ep_l, time.time() - self._tstart)
         return self._obs, reward, done, infos
+
+    def debug_work_keys(self):
+        """uint32 [N]: cycles of every env's last step / 256 << 12 | live EMS count (the heavy-first dispatch's keys)."""
+        out = np.zeros(self.N, np.uint32)
+        _lib.check(self._L.pct_debug_work_keys(self._h, out.ctypes.data))
+        return out
+
+    def debug_retry_count(self, totals=False):
+        """envs the last launch handed to the large-capacity retry pass; with `totals` also (envs re-run since creation,
+        launches in which the retry pass found work)."""
+        last, envs, launches = ctypes.c_int32(), ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(self._L.pct_debug_retry_count(self._h, ctypes.byref(last), ctypes.byref(envs), ctypes.byref(launches)))
+        return (last.value, envs.value, launches.value) if totals else last.value
 
     def debug_state(self, e, cap_ems=1024):
         if self.continuous:

@@ -14,7 +14,23 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def _llvm_bin():
+    """llvm-objdump & friends next to the hipcc the build uses ($HIPCC, PATH, $ROCM_PATH, /opt/rocm)"""
+    import shutil
+    cands = []
+    for hipcc in (os.environ.get("HIPCC"), shutil.which("hipcc")):
+        if hipcc:
+            cands.append(os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc))), "lib", "llvm", "bin"))
+    cands += [os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin"), "/opt/rocm/lib/llvm/bin"]
+    for c in cands:
+        if os.path.exists(os.path.join(c, "llvm-objdump")):
+            return c
+    return cands[-1]
+
+
+LLVM = _llvm_bin()
 
 
 def device_code_objects(lib, tmp):

@@ -7,7 +7,7 @@ for w in c2 c3; do
   if [ $w = c2 ]; then sets="0 20,26,32 24,30,36 16,22,28 28,32,36 22,30,38"; steps=1500; else sets="0 30,45,60 40,60,80 24,36,48 50,70,90"; steps=600; fi
   for s in $sets; do
     echo "== $w PCT_WAVE_PRIO=$s" >> $out
-    PCT_WAVE_PRIO=$s python bench.py --no-cpu-baseline --workload $w --steps $steps --warmup 100 2>&1 | python -c "
+    PCT_EXPERIMENT=1 PCT_WAVE_PRIO=$s python bench.py --no-cpu-baseline --workload $w --steps $steps --warmup 100 2>&1 | python -c "
 import sys, json
 for line in sys.stdin:
     line=line.strip()

@@ -52,7 +52,7 @@ for i, n in {8: "set.gen", 9: "set.dedup", 10: "set.match", 11: "set.rebuild"}.i
     print("      %-11s %8.0f   (all-env mean %8.0f)" % (n, worst[:, i].mean(), rec[:, :, i].mean()))
 print("    EMS %.1f (mean %.1f)  distinct %.1f (mean %.1f)  generated %.1f (mean %.1f)" % (
     worst[:, 12].mean(), rec[:, :, 12].mean(), worst[:, 13].mean(), rec[:, :, 13].mean(), worst[:, 14].mean(), rec[:, :, 14].mean()))
-extra = {16: "match calls", 17: "match outer rounds", 18: "match longest-walk sum", 19: "contains calls (tuple chunks)",
+extra = {16: "match calls", 17: "match outer rounds", 18: "match longest-walk sum", 19: "cycles inside the matching walk loops",
          20: "contains longest-walk sum", 21: "flushes", 22: "fast-start scalar replay cycles", 23: "rebuilds", 24: "flush hash cycles", 25: "gen: tuple build cycles", 26: "gen: hash cycles", 27: "gen: contains cycles", 28: "gen: pend/ballot cycles", 29: "gen: pair filter cycles"}
 for i, n in extra.items():
     print("    %-34s %9.1f   (all-env mean %9.1f)" % (n, worst[:, i].mean(), rec[:, :, i].mean()))

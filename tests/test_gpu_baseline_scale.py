@@ -204,7 +204,7 @@ def test_stability_overflow_is_rerun_with_larger_pools(name, monkeypatch):
     nothing of a half-done commit has been stored), to the large-capacity pass.  The trajectory must still equal the
     reference fixture (the 20^3 flat-item one among them: hundreds of least-squares splits, boxes on up to 9 supporters)
     and no flag may be raised."""
-    for k, v in (("PCT_STAB_SP", "24"), ("PCT_STAB_PP", "48"), ("PCT_STAB_WS", "560"), ("PCT_STAB_Q", "8")):
+    for k, v in (("PCT_EXPERIMENT", "1"), ("PCT_STAB_SP", "24"), ("PCT_STAB_PP", "48"), ("PCT_STAB_WS", "560"), ("PCT_STAB_Q", "8")):
         monkeypatch.setenv(k, v)
     c, z = load_case(name)
     kw = dict(setting=c["setting"], container_size=c["container"], internal_node_holder=c["I"], leaf_node_holder=c["L"],

@@ -93,6 +93,9 @@ def test_fused_collect_matches_reference_fixture(name):
     # ... and after unbind_rollout_slot() the handle writes its own buffers again: the slots may be dropped
     keep = ro.obs[T].clone()
     env.unbind_rollout_slot()
+    # the live observation came along: a policy that reads current_obs() after the unbind sees the env's
+    # current leaf list, not the stale pre-rollout buffer
+    assert torch.equal(env.current_obs().reshape(-1), keep.reshape(-1))
     del ro
     o3, r3, d3, _ = env.step(torch.zeros(N, dtype=torch.int64))
     assert o3.data_ptr() == env.current_obs().data_ptr() and o3.data_ptr() != keep.data_ptr()
