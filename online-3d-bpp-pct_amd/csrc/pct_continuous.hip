@@ -821,6 +821,7 @@ __device__ __forceinline__ bool cleaf_nodes(const ContinuousParams& p, int e, CL
   // ALL 64 lanes call (`live`: this lane holds a candidate): the stability check of the lanes that need one is a
   // wave-cooperative task walk (pct_stab.cuh stab_virtual_wave)
   bool stab_ill = false;
+  StabStats sstats = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // (timed build only)
   bool unknown = false;  // the last call left this lane's candidate undecided (a capacity of its own was exceeded)
   auto feasible = [&](bool live, const double t[6]) __attribute__((always_inline)) -> bool {
     unknown = false;
@@ -847,7 +848,8 @@ __device__ __forceinline__ bool cleaf_nodes(const ContinuousParams& p, int e, CL
         CGeo geo{l.box, l.bsz, p.I};
         uint32_t cap = 0;
         bool ill = false, lerr = false;
-        const bool stable = stab_virtual_wave<true>(geo, l.st, nb, need, cand, next_den, l.sw, lane, cap, lerr, ill);
+        const bool stable = stab_virtual_wave<true>(geo, l.st, nb, need, cand, next_den, l.sw, lane, cap, lerr, ill,
+                                                    TM::on ? &sstats : nullptr);
         if (need) ok = stable && !cap;
         stab_err |= cap;
         unknown = need && lerr;
@@ -923,6 +925,16 @@ __device__ __forceinline__ bool cleaf_nodes(const ContinuousParams& p, int e, CL
   if (STAB) r.stab_over |= stab_err;  // (wave-uniform)
   if (STAB && stab_ill) r.flags |= PCT_FLAG_ILL_CONDITIONED;
   r.n_leaf = nleaf < p.L ? nleaf : p.L;
+  if (TM::on && STAB) {
+    tm.add(ST_STAB_VPASSES, (uint64_t)__builtin_amdgcn_readfirstlane(sstats.v_passes));
+    tm.add(ST_STAB_VTASKS, (uint64_t)__builtin_amdgcn_readfirstlane(sstats.v_tasks));
+    tm.add(ST_STAB_VNARROW, (uint64_t)__builtin_amdgcn_readfirstlane(sstats.v_narrow));
+    tm.add(ST_STAB_LEVEL0, (uint64_t)wave_sum_i64(sstats.v_level0));
+    tm.add(ST_STAB_LSQ3, (uint64_t)wave_sum_i64(sstats.lsq3));
+    tm.add(ST_STAB_LSQ4, (uint64_t)wave_sum_i64(sstats.lsq4));
+    tm.add(ST_STAB_LSQ5, (uint64_t)wave_sum_i64(sstats.lsq5));
+    tm.add(ST_STAB_LSQX, (uint64_t)wave_sum_i64(sstats.lsqx));
+  }
   __syncthreads();
   tm.tick(PH_FEAS);
   return false;
@@ -1159,20 +1171,22 @@ __device__ __forceinline__ int ctransition(const ContinuousParams& p, int e, CLd
       l.bsz[0 * p.I + bi] = x; l.bsz[1 * p.I + bi] = y; l.bsz[2 * p.I + bi] = z;
     }
     __syncthreads();
-    int rc = 1, ne = 0, npv = 0, ill_i = 0;
-    if (lane == 0) {
-      CGeo geo{l.box, l.bsz, p.I};
-      bool ill = false;
-      const double den = MT ? (p.setting == 3 ? r.den_cur : 1.0) : next_density(p, e, r.oc - 1, r.traj, r.cursor - 1);
-      rc = stab_commit<true>(geo, l.st, bi, den, l.sw.hull, l.sw.hull_bytes, ill);
-      ne = l.st.n_ent;
-      npv = l.st.n_poly;
-      ill_i = ill ? 1 : 0;
+    CGeo geo{l.box, l.bsz, p.I};
+    bool ill = false;
+    const double den = MT ? (p.setting == 3 ? r.den_cur : 1.0) : next_density(p, e, r.oc - 1, r.traj, r.cursor - 1);
+    // lane 0 walks; a split over six and more supporters is solved by the whole wave (pct_stab.cuh stab_commit_wave)
+    StabStats cstats = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // (timed build only)
+    const int rc = stab_commit_wave<true>(geo, l.st, bi, den, l.sw, lane, ill, TM::on ? &cstats : nullptr);
+    if (TM::on) {
+      tm.add(ST_STAB_COMMIT_VISITS, (uint64_t)__builtin_amdgcn_readfirstlane(cstats.commit_visits));
+      tm.add(ST_STAB_LSQ3, (uint64_t)__builtin_amdgcn_readfirstlane(cstats.lsq3));
+      tm.add(ST_STAB_LSQ4, (uint64_t)__builtin_amdgcn_readfirstlane(cstats.lsq4));
+      tm.add(ST_STAB_LSQ5, (uint64_t)__builtin_amdgcn_readfirstlane(cstats.lsq5));
+      tm.add(ST_STAB_LSQX, (uint64_t)__builtin_amdgcn_readfirstlane(cstats.lsqx));
     }
-    rc = __shfl(rc, 0, 64);
-    l.st.n_ent = __shfl(ne, 0, 64);
-    l.st.n_poly = __shfl(npv, 0, 64);
-    if (__shfl(ill_i, 0, 64)) r.flags |= PCT_FLAG_ILL_CONDITIONED;
+    l.st.n_ent = __builtin_amdgcn_readfirstlane(l.st.n_ent);
+    l.st.n_poly = __builtin_amdgcn_readfirstlane(l.st.n_poly);
+    if (__builtin_amdgcn_readfirstlane(ill ? 1 : 0)) r.flags |= PCT_FLAG_ILL_CONDITIONED;
     if (rc < 0) r.stab_over |= STAB_WHY_COMMIT;
     ok = rc == 1;
     __syncthreads();
@@ -1722,7 +1736,9 @@ hipError_t PCT_CONT_LAUNCH(const ContinuousParams& p, int act, const void* actio
 #define PCT_CLAUNCH(A)                                                                                         \
   do {                                                                                                         \
     void (*kern)(ContinuousParams, const void*, int, int, const int32_t*, int);                                \
-    if (stab) kern = p.table_global ? pct_continuous_kernel<A, false, true, true, PCT_CONT_MTV>                \
+    if (stab && timed && A == CACT_ROWS && !p.table_global)                                                   \
+      kern = pct_continuous_kernel<(A == CACT_ROWS ? A : CACT_ROWS), !PCT_CONT_MTV, false, true, PCT_CONT_MTV>; \
+    else if (stab) kern = p.table_global ? pct_continuous_kernel<A, false, true, true, PCT_CONT_MTV>           \
                                     : pct_continuous_kernel<A, false, false, true, PCT_CONT_MTV>;              \
     else if (p.table_global) kern = pct_continuous_kernel<A, false, true, false, PCT_CONT_MTV>;                \
     else kern = timed ? pct_continuous_kernel<A, !PCT_CONT_MTV, false, false, PCT_CONT_MTV>                    \

@@ -2064,20 +2064,14 @@ __device__ __forceinline__ bool transition(const DiscreteParams& p, int e, Lds<K
     // a box on the floor is recorded and accepted without a walk)
     if (lane == 0) l.box[r.n_boxes] = P::pack(lx, ly, max_h, lx + x, ly + y, max_h + z);
     __syncthreads();
-    int rc = 1, ne = 0, npv = 0, ill_i = 0;
     StabStats cstats = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // (timed build only)
-    if (lane == 0) {
-      BoxGeo<K, BITS> geo{l.box};
-      bool ill = false;
-      rc = stab_commit<false>(geo, l.st, r.n_boxes, item_den, l.sw.hull, l.sw.hull_bytes, ill, TM::on ? &cstats : nullptr);
-      ne = l.st.n_ent;
-      npv = l.st.n_poly;
-      ill_i = ill ? 1 : 0;
-    }
-    rc = __shfl(rc, 0, 64);
-    l.st.n_ent = __shfl(ne, 0, 64);
-    l.st.n_poly = __shfl(npv, 0, 64);
-    if (__shfl(ill_i, 0, 64)) r.flags |= PCT_FLAG_ILL_CONDITIONED;
+    BoxGeo<K, BITS> geo{l.box};
+    bool ill = false;
+    // lane 0 walks; a split over six and more supporters is solved by the whole wave (pct_stab.cuh stab_commit_wave)
+    const int rc = stab_commit_wave<false>(geo, l.st, r.n_boxes, item_den, l.sw, lane, ill, TM::on ? &cstats : nullptr);
+    l.st.n_ent = __builtin_amdgcn_readfirstlane(l.st.n_ent);
+    l.st.n_poly = __builtin_amdgcn_readfirstlane(l.st.n_poly);
+    if (__builtin_amdgcn_readfirstlane(ill ? 1 : 0)) r.flags |= PCT_FLAG_ILL_CONDITIONED;
     if (rc < 0) r.stab_over |= STAB_WHY_COMMIT;
     ok = rc == 1;
     if (TM::on) {

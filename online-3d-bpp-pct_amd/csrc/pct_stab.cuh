@@ -50,7 +50,8 @@
 
 namespace pct {
 
-constexpr int STAB_LSQ = 8;          // supporters the least-squares split handles (more: capacity error)
+constexpr int STAB_LSQ = 16;         // most supporters a least-squares split can be given (a launch's caps.lsq_n may be lower:
+                                     // 8 in the normal pass, 16 in the retry pass; more is a capacity error)
 constexpr int STAB_NSUP_MAX = 255;   // supporters per box (8-bit count)
 constexpr uint32_t STAB_END = 0xFFFu;  // end of an up-list / "no parent"
 constexpr uint32_t STAB_NOBOX = 0x3FFu;
@@ -58,7 +59,7 @@ constexpr uint32_t STAB_NOBOX = 0x3FFu;
 constexpr uint32_t STAB_WHY_QUEUE = 0x100u;     // one task's children do not fit the walk queue
 constexpr uint32_t STAB_WHY_WS = 0x200u;        // a candidate's hull does not fit the workspace / > 255 supporters
 constexpr uint32_t STAB_WHY_HULL = 0x400u;      // a hull of more than 255 vertices
-constexpr uint32_t STAB_WHY_SPLIT = 0x800u;     // more than STAB_LSQ supporters and none of them direct
+constexpr uint32_t STAB_WHY_SPLIT = 0x800u;     // more supporters than this launch's least-squares workspace takes (caps.lsq_n), none of them direct
 constexpr uint32_t STAB_WHY_COMMIT = 0x1000u;   // the commit: pools, workspace or depth-first stack
 constexpr uint32_t STAB_WHY_LOAD = 0x2000u;     // the stored state does not fit this launch's pools
 constexpr uint32_t STAB_NOTE_ILL = 0x4000u;     // (not a capacity: carries the ill-conditioning notice out of a heuristic's probes)
@@ -69,6 +70,7 @@ struct StabCaps {
   int PP;       // polygon pool vertices
   int ws_bytes;  // hull workspace (level-0 candidates of a round / the commit's hull and depth-first stack)
   int queue;     // walk tasks the LDS queue holds
+  int lsq_n;     // supporters the wave-cooperative least-squares split takes (its LDS workspace: stab_lsq_bytes), 6..STAB_LSQ
 };
 
 // per-env stability state: pointers into LDS (device) or host memory
@@ -268,6 +270,7 @@ PCT_SD bool stab_pip_hull(const double* pt, const double (*lo)[2], int nl, const
 // `ill` reports a rank decision taken within a factor STAB_ILL_BAND of the cut: there the reference's own verdict
 // depends on the rounding noise of its LAPACK build (profiles/r02_lstsq_limit.txt, r03_lstsq_limit.txt).
 constexpr double STAB_ILL_BAND = 1e3;
+#if !defined(__HIPCC__)
 PCT_SD void stab_lstsq(const double* A, const double* b, int M, int N, double* x, bool& ill) {
   double U[(STAB_LSQ * (STAB_LSQ - 1) / 2 + 1) * STAB_LSQ], V[STAB_LSQ * STAB_LSQ];
   for (int i = 0; i < M * N; i++) U[i] = A[i];
@@ -320,6 +323,7 @@ PCT_SD void stab_lstsq(const double* A, const double* b, int M, int N, double* x
     for (int i = 0; i < N; i++) x[i] += V[i * N + j] * proj;
   }
 }
+#endif
 
 // np.dot of two 2-vectors as NumPy's BLAS computes it (OpenBLAS ddot on x86 cores with FMA): acc = x0*y0;
 // acc = fma(x1, y1, acc) (NumPy's 2-vector dot on an FMA host; v_fma_f64 on the GPU is the same IEEE operation)
@@ -439,6 +443,8 @@ struct StabStats {
 //   mode 2: two supporters (lever rule on the line through the contact centres)
 //   mode 3: three and more (least squares over all pairs)
 // f[i]: the fraction of the mass supporter i receives (modes 2, 3; i < 5 -- more than five supporters keep theirs in fx)
+//   mode 4 (device only): three and more, beyond five -- the system is left to the wave-cooperative solve (stab_lsq_wave), which
+//           turns it into mode 3 with the fractions in StabSplitX
 struct StabSplit {
   int mode, direct;
   double f[5];
@@ -449,7 +455,7 @@ struct StabSplit {
 struct StabSplitX { double fx[STAB_LSQ]; };
 template <bool CONT, typename Geo, typename Sup>
 PCT_SD bool stab_split(const Geo& geo, const double bg[9], int k, const Sup& sup, const double stk[4], StabSplit& sp, StabSplitX& sx,
-                       StabStats* ss = nullptr) {
+                       StabStats* ss = nullptr, int lsq_n = STAB_LSQ) {
   sp.mode = 0; sp.direct = -1; sp.ill = false;
 #pragma unroll
   for (int i = 0; i < 5; i++) sp.f[i] = 0;
@@ -462,7 +468,7 @@ PCT_SD bool stab_split(const Geo& geo, const double bg[9], int k, const Sup& sup
     if (inside) { sp.direct = i; break; }
   }
   if (sp.direct >= 0) { sp.mode = 1; return true; }
-  if (k > STAB_LSQ) return false;
+  if (k > lsq_n || k > STAB_LSQ) return false;
   if (k <= 5) {
     // contact centres with static indices (registers).  Two to five supporters are 99.99 % of the splits (of the
     // least-squares ones k = 3: 94 %, 4: 6 %, 5: 0.1 %).  The register-resident solve for five costs 160 VGPRs -- and the
@@ -500,8 +506,16 @@ PCT_SD bool stab_split(const Geo& geo, const double bg[9], int k, const Sup& sup
     else stab_split_fixed<5>(c2, stk, sp.f, sp.ill);
     return true;
   }
-  sp.mode = 3;
   if (ss) ss->lsqx++;
+#if defined(__HIPCC__)
+  // six and more supporters (0.01 % of the splits): a per-lane solve on private arrays lived in scratch memory and cost the wave
+  // that held such a lane 1.7 M cycles -- THE long launches of the stability settings (profiles/r04_stability_cliff.txt).  The
+  // system goes to the wave instead: stab_lsq_wave, rows across the lanes, the matrix in LDS.
+  sp.mode = 4;
+  (void)sx;
+  return true;
+#else
+  sp.mode = 3;
   double c2[STAB_LSQ][2];
   for (int i = 0; i < k; i++) {
     double a[4];
@@ -531,6 +545,7 @@ PCT_SD bool stab_split(const Geo& geo, const double bg[9], int k, const Sup& sup
   rhs[M - 1] = 1;
   stab_lstsq(A, rhs, M, k, sx.fx, sp.ill);
   return true;
+#endif
 }
 // the share supporter i receives.  `own_centre`: the box's own centre, which the VIRTUAL flavour puts into the zero-mass
 // shares of a direct split (the commit uses the stack's centre there)
@@ -595,6 +610,19 @@ PCT_SD void stab_com(const Geo& geo, const StabState& st, int S, int skip, const
 // parent's committed entry (`skip`: the parent's id, STAB_NOBOX for a candidate) replaced by the virtual share.
 // `emit(Si, child_stack)` is called once per supporter, in order.  False: a capacity was exceeded.
 template <bool CONT, typename Geo, typename Emit>
+PCT_SD void stab_children_emit(const Geo& geo, const StabState& st, const double bg[9], int k, const StabSup& sup, const double stk[4],
+                               int skip, const StabSplit& sp, const StabSplitX& sx, Emit emit) {
+  const double own[3] = {bg[0] + bg[6] / 2, bg[1] + bg[7] / 2, bg[2] + bg[8] / 2};
+  for (int i = 0; i < k; i++) {
+    double share[4], child[4];
+    stab_share_of<CONT>(geo, bg, k, sup, stk, own, true, sp, sx, i, share);
+    const int Si = sup(i);
+    stab_com(geo, st, Si, skip, share, child);
+    emit(Si, child);
+  }
+}
+#if !defined(__HIPCC__)
+template <bool CONT, typename Geo, typename Emit>
 PCT_SD bool stab_children(const Geo& geo, const StabState& st, const double bg[9], int k, const StabSup& sup, const double stk[4],
                           int skip, bool& ill, Emit emit, StabStats* ss = nullptr) {
   StabSplit sp;
@@ -624,6 +652,7 @@ PCT_SD int stab_visit(const Geo& geo, const StabState& st, int S, const double v
   StabSup sup{st.ent + stab_soff(st, S)};
   return stab_children<CONT>(geo, st, bg, k, sup, vstk, S, ill, emit) ? 1 : -1;
 }
+#endif  // host flavour: split and emit in one go
 // workspace bytes the hull of a box with up to k supporters needs (points, upper chain, supporter ids)
 PCT_HD int stab_ws_need(int k) { return (4 * k) * 16 + (4 * k + 1) * 16 + ((4 * k + 7) & ~7); }
 struct StabWsView {
@@ -668,6 +697,7 @@ PCT_SD int stab_level0_pip(const Geo& geo, const double cand[9], const double cs
   if (nl + nu > 255) return -1;
   return stab_pip_hull(cstk, w.pts, nl, w.up, nu) ? 1 : 0;
 }
+#if !defined(__HIPCC__)
 // the whole level-0 task.  Same return values and `emit` as stab_visit.
 template <bool CONT, typename Geo, typename Emit>
 PCT_SD int stab_level0(const Geo& geo, const StabState& st, const double cand[9], double density, int k, const StabWsView& w,
@@ -680,6 +710,7 @@ PCT_SD int stab_level0(const Geo& geo, const StabState& st, const double cand[9]
   StabSup sup{w.ids};
   return stab_children<CONT>(geo, st, cand, k, sup, cstk, (int)STAB_NOBOX, ill, emit) ? 1 : -1;
 }
+#endif
 
 // HBM mirror of the per-env stability state (struct-of-arrays over envs; the pool rows are as long as the largest
 // capacities of any pass, the LDS copies as long as THIS launch's)
@@ -695,10 +726,143 @@ struct StabHbm {
   uint32_t* ent;   // [N][sp_stride]
 };
 
+// LDS doubles of the wave-cooperative least-squares split for up to n supporters: inputs (stack x / y, n contact centres),
+// the n fractions, three product columns, U (M x n, column-major), V (n x n, column-major); M = n (n - 1) / 2 + 1 rows
+PCT_HD int stab_lsq_rows(int n) { return n * (n - 1) / 2 + 1; }
+PCT_HD int stab_lsq_rows8(int n) { return (stab_lsq_rows(n) + 7) & ~7; }  // the product columns are padded to a multiple of 8 rows
+PCT_HD size_t stab_lsq_bytes(int n) {
+  if (n <= 0) return 0;
+  const size_t M = (size_t)stab_lsq_rows(n), M8 = (size_t)stab_lsq_rows8(n);
+  return sizeof(double) * (2 + 2 * (size_t)n + (size_t)n + 3 * M8 + M * (size_t)n + (size_t)n * (size_t)n);
+}
+
 #if defined(__HIPCC__)
+// ---- the wave-cooperative least-squares split -------------------------------------------------------------------------
+// np.linalg.lstsq of the >= 3-supporter system (D/space.py:134-152) for k supporters, by the WHOLE wave: the one-sided Jacobi
+// SVD of stab_lstsq / lstsq_min_norm, operation for operation -- the column sums run over the rows in order (every lane adds
+// the same M products, read back from LDS), rotations and the final back-substitution use the same expressions -- with the
+// rows of U spread over the lanes and the matrix in LDS instead of one lane's private arrays in scratch memory.
+// In: ws[0], ws[1] = the stack's x, y; ws[2 + 2 i], ws[3 + 2 i] = contact centre of supporter i.  Out: ws[2 + 2 nmax + i] = the
+// fraction of supporter i.  All 64 lanes call (wave-uniform arguments).  Returns the ill-conditioning notice.
+__device__ __forceinline__ bool stab_lsq_wave(double* ws, int nmax, int k, int lane) {
+  const int M = stab_lsq_rows(k), M8 = stab_lsq_rows8(k), Mmax = stab_lsq_rows(nmax);
+  const double* in = ws;
+  double* x = ws + 2 + 2 * nmax;
+  double* S = x + nmax;              // [3][M8] products of a column pair (zero beyond row M), later proj / keep flags
+  double* U = S + 3 * (size_t)stab_lsq_rows8(nmax);  // [k][M]
+  double* V = U + (size_t)Mmax * nmax;  // [k][k]
+  const double s0 = in[0], s1 = in[1];
+  // the system: one row per supporter pair (i < j, in that order), a closing row of ones
+  for (int r = lane; r < M; r += 64) {
+    int i = 0, base = 0;
+    while (r < M - 1 && r >= base + (k - 1 - i)) { base += k - 1 - i; i++; }
+    const int j = i + 1 + (r - base);
+    double rr = 0;
+    bool row_on = false;
+    if (r < M - 1) {
+      const double ei0 = in[2 + 2 * i], ei1 = in[3 + 2 * i], ej0 = in[2 + 2 * j], ej1 = in[3 + 2 * j];
+      const double t0 = ei0 - ej0, t1 = ei1 - ej1;
+      const double mol = stab_dot2(s0 - ei0, s1 - ei1, t0, t1);
+      if (mol != 0) { rr = fabs(stab_dot2(s0 - ej0, s1 - ej1, t0, t1)) / mol; row_on = true; }
+    }
+    for (int c = 0; c < k; c++) {
+      double v = 0;
+      if (r == M - 1) v = 1;
+      else if (row_on) v = c == i ? 1.0 : (c == j ? -rr : 0.0);
+      U[(size_t)c * M + r] = v;
+    }
+  }
+  for (int q = lane; q < k * k; q += 64) V[q] = (q / k == q % k) ? 1.0 : 0.0;
+  __syncthreads();
+  for (int sweep = 0; sweep < 60; sweep++) {
+    bool rotated = false;
+    for (int p = 0; p < k; p++)
+      for (int q = p + 1; q < k; q++) {
+        for (int r = lane; r < M8; r += 64) {
+          const double up = r < M ? U[(size_t)p * M + r] : 0.0, uq = r < M ? U[(size_t)q * M + r] : 0.0;
+          S[r] = up * up; S[M8 + r] = uq * uq; S[2 * M8 + r] = up * uq;
+        }
+        __syncthreads();
+        // the three column sums, over the rows IN ORDER (every lane the same additions); eight rows' products are fetched
+        // at a time -- the rows beyond M hold +0.0, which leaves a sum that started at +0.0 unchanged
+        double alpha = 0, beta = 0, gamma = 0;
+        for (int r = 0; r < M8; r += 8) {
+          double a[8], b[8], g[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) { a[u] = S[r + u]; b[u] = S[M8 + r + u]; g[u] = S[2 * M8 + r + u]; }
+#pragma unroll
+          for (int u = 0; u < 8; u++) { alpha += a[u]; beta += b[u]; gamma += g[u]; }
+        }
+        __syncthreads();
+        if (gamma == 0 || fabs(gamma) <= 2.220446049250313e-16 * sqrt(alpha * beta)) continue;
+        rotated = true;
+        const double zeta = (beta - alpha) / (2 * gamma);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1 + zeta * zeta));
+        const double c = 1 / sqrt(1 + t * t), sn = c * t;
+        for (int r = lane; r < M; r += 64) {
+          const double up = U[(size_t)p * M + r], uq = U[(size_t)q * M + r];
+          U[(size_t)p * M + r] = c * up - sn * uq;
+          U[(size_t)q * M + r] = sn * up + c * uq;
+        }
+        if (lane < k) {
+          const double vp = V[p * k + lane], vq = V[q * k + lane];
+          V[p * k + lane] = c * vp - sn * vq;
+          V[q * k + lane] = sn * vp + c * vq;
+        }
+        __syncthreads();
+      }
+    if (!rotated) break;
+  }
+  // singular values: lane j sums column j over the rows, in order
+  double s2 = 0;
+  if (lane < k)
+    for (int r = 0; r < M; r++) { const double u = U[(size_t)lane * M + r]; s2 += u * u; }
+  double smax2 = lane < k ? s2 : 0.0;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const double o = __shfl_xor(smax2, off, 64);
+    smax2 = o > smax2 ? o : smax2;
+  }
+  const double rc = 2.220446049250313e-16 * (double)(M > k ? M : k);
+  const double sj = sqrt(s2), cut = rc * sqrt(smax2);
+  const bool ill = lane < k && s2 > 0 && sj > cut / STAB_ILL_BAND && sj < cut * STAB_ILL_BAND;
+  const bool keep = lane < k && !(s2 <= 0 || sj <= cut);
+  if (lane < k) {
+    // proj = sum_r U[r][j] b[r] with b = e_{M-1}: zeros, then the last row's entry
+    double proj = 0.0;
+    proj += U[(size_t)lane * M + (M - 1)] * 1.0;
+    proj /= s2;
+    S[lane] = keep ? proj : 0.0;
+    S[M8 + lane] = keep ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  if (lane < k) {
+    double xi = 0;
+    for (int j = 0; j < k; j++)
+      if (S[M8 + j] != 0.0) xi += V[j * k + lane] * S[j];
+    x[lane] = xi;
+  }
+  __syncthreads();
+  return __ballot(ill) != 0;
+}
+// the contact centres of a box's supporters and its stack, laid out as stab_lsq_wave reads them (one lane writes)
+template <bool CONT, typename Geo, typename Sup>
+__device__ __forceinline__ void stab_lsq_inputs(const Geo& geo, const double bg[9], int k, const Sup& sup, const double stk[4], double* ws) {
+  ws[0] = stk[0];
+  ws[1] = stk[1];
+  for (int i = 0; i < k; i++) {
+    double a[4];
+    stab_area<CONT>(geo, bg, sup(i), a);
+    ws[2 + 2 * i] = (a[0] + a[2]) / 2;
+    ws[3 + 2 * i] = (a[1] + a[3]) / 2;
+  }
+}
+
 // ---- the wave-cooperative driver ----------------------------------------------------------------------------------
 // LDS workspace of a wave: the hull workspace (shared by the level-0 tasks of a round) and the task queue.
 struct StabWave {
+  double* lsq;   // workspace of the cooperative least-squares split (stab_lsq_bytes(lsq_n))
+  int lsq_n;
   unsigned char* hull;
   int hull_bytes;
   uint32_t* ctl;    // [6] queue count, failed candidates (lanes 0..31, 32..63), global capacity error (STAB_WHY_*),
@@ -707,10 +871,15 @@ struct StabWave {
   double* qstk;     // [qcap][4]
   int qcap;
 };
-PCT_HD size_t stab_wave_bytes(const StabCaps& c) { return (size_t)c.ws_bytes + (size_t)c.queue * (4 * sizeof(double) + sizeof(uint32_t)) + 32; }
-// carve: the queue's doubles first (8-byte aligned base), then the hull workspace, then the words
+PCT_HD size_t stab_wave_bytes(const StabCaps& c) {
+  return stab_lsq_bytes(c.lsq_n) + (size_t)c.ws_bytes + (size_t)c.queue * (4 * sizeof(double) + sizeof(uint32_t)) + 32;
+}
+// carve: the least-squares workspace and the queue's doubles first (8-byte aligned base), then the hull workspace, then the words
 PCT_SD StabWave stab_wave_carve(unsigned char* base, const StabCaps& c) {
   StabWave w;
+  w.lsq = reinterpret_cast<double*>(base);
+  w.lsq_n = c.lsq_n;
+  base += stab_lsq_bytes(c.lsq_n);
   w.qstk = reinterpret_cast<double*>(base);
   w.hull = base + (size_t)c.queue * 4 * sizeof(double);
   w.hull_bytes = c.ws_bytes;
@@ -816,19 +985,43 @@ __device__ __forceinline__ bool stab_virtual_wave(const Geo& geo, const StabStat
       stk[0] = cstk[0]; stk[1] = cstk[1]; stk[2] = cstk[2]; stk[3] = cstk[3];
     }
     while (true) {
-      if (have) {
-        auto emit = [&](int Si, const double child[4]) __attribute__((always_inline)) {
-          const uint32_t pos = atomicAdd(&w.ctl[0], 1u);
-          if (pos < (uint32_t)w.qcap) {
-            w.qmeta[pos] = (uint32_t)cl | ((uint32_t)Si << 6);
-            w.qstk[(size_t)pos * 4 + 0] = child[0]; w.qstk[(size_t)pos * 4 + 1] = child[1];
-            w.qstk[(size_t)pos * 4 + 2] = child[2]; w.qstk[(size_t)pos * 4 + 3] = child[3];
-          } else {
-            atomicOr(&w.ctl[3], STAB_WHY_QUEUE);
-          }
-        };
+      {
+        // how the box under examination splits its stack over its supporters; a split over six and more goes to the wave
+        StabSplit sp;
+        StabSplitX sx;
+        sp.mode = 0;
         StabSup sup{supw};
-        if (!stab_children<CONT>(geo, st, bg, kk, sup, stk, skip, ill, emit, ss)) atomicOr(&w.ctl[4 + (cl >> 5)], 1u << (cl & 31));
+        if (have && !stab_split<CONT>(geo, bg, kk, sup, stk, sp, sx, ss, w.lsq_n)) {
+          atomicOr(&w.ctl[4 + (cl >> 5)], 1u << (cl & 31));
+          have = false;
+        }
+        for (uint64_t cm = __ballot(have && sp.mode == 4); cm; cm &= cm - 1) {
+          const int src = __ffsll((unsigned long long)cm) - 1;
+          const int ks = __builtin_amdgcn_readlane(kk, src);
+          if (lane == src) stab_lsq_inputs<CONT>(geo, bg, kk, sup, stk, w.lsq);
+          __syncthreads();
+          const bool sill = stab_lsq_wave(w.lsq, w.lsq_n, ks, lane);
+          if (lane == src) {
+            for (int i = 0; i < kk; i++) sx.fx[i] = w.lsq[2 + 2 * w.lsq_n + i];
+            sp.mode = 3;
+            sp.ill = sill;
+          }
+          __syncthreads();
+        }
+        if (have) {
+          ill = ill || sp.ill;
+          auto emit = [&](int Si, const double child[4]) __attribute__((always_inline)) {
+            const uint32_t pos = atomicAdd(&w.ctl[0], 1u);
+            if (pos < (uint32_t)w.qcap) {
+              w.qmeta[pos] = (uint32_t)cl | ((uint32_t)Si << 6);
+              w.qstk[(size_t)pos * 4 + 0] = child[0]; w.qstk[(size_t)pos * 4 + 1] = child[1];
+              w.qstk[(size_t)pos * 4 + 2] = child[2]; w.qstk[(size_t)pos * 4 + 3] = child[3];
+            } else {
+              atomicOr(&w.ctl[3], STAB_WHY_QUEUE);
+            }
+          };
+          stab_children_emit<CONT>(geo, st, bg, kk, sup, stk, skip, sp, sx, emit);
+        }
       }
       if (ss && lane == 0) ss->v_passes++;
       __syncthreads();
@@ -943,11 +1136,12 @@ __device__ __forceinline__ void stab_store(const StabHbm& hb, int I, int e, int 
 // ---- the commit ---------------------------------------------------------------------------------------------------
 // calculated_impact() of the box just placed as id `n` (geometry already visible through geo(n, .)): records its
 // supporters / polygon / stack, propagates the shares downward and re-checks every box on the way (D/space.py:73-164).
-// Sequential (one lane).  `ws` / `ws_bytes`: workspace for the hull, then for the depth-first stack.
+// The walk is order dependent and sequential.  `ws` / `ws_bytes`: workspace for the hull, then for the depth-first stack.
 // Returns 1: stable, 0: unstable, -1: a capacity (pools, workspace, supporters) was exceeded.
+//
+// First half: the box's own record.  1: it stands on the floor (accepted without a walk), 2: the walk follows, -1: capacity.
 template <bool CONT, typename Geo>
-PCT_SD int stab_commit(const Geo& geo, StabState& st, int n, double density, unsigned char* ws, int ws_bytes, bool& ill,
-                       StabStats* ss = nullptr) {
+PCT_SD int stab_commit_record(const Geo& geo, StabState& st, int n, double density, unsigned char* ws, int ws_bytes) {
   double bg[9];
   geo(n, bg);
   // supporters: as many ids as the workspace can take a hull for
@@ -999,6 +1193,34 @@ PCT_SD int stab_commit(const Geo& geo, StabState& st, int n, double density, uns
   st.meta[2 * n] = (uint32_t)k | (0u << 8) | ((uint32_t)np << 16);
   st.meta[2 * n + 1] = (uint32_t)soff | ((uint32_t)poff << 16);
   if (CONT ? (fabs(bg[2]) < 1e-6) : (bg[2] == 0)) return 1;  // max_h == 0: check_box returns first (:448-449)
+  return 2;
+}
+// A box of the walk hands its stack down, once its split is known: up_edges[self] = share; calculate_new_com() for every supporter
+template <bool CONT, typename Geo>
+PCT_SD void stab_commit_expand(const Geo& geo, StabState& st, int id, int kk, const StabSup& sup, const double g[9], const double stk[4],
+                               const StabSplit& sp, const StabSplitX& sx) {
+  const int alias_k = sp.mode == 0 ? 0 : (sp.mode == 1 ? sp.direct : -1);
+  st.meta[2 * id] = (st.meta[2 * id] & 0xFFFF00FFu) | ((uint32_t)(alias_k + 1) << 8);
+  const double own[3] = {stk[0], stk[1], stk[2]};
+  for (int i = 0; i < kk; i++) {
+    double sh[4];
+    stab_share_of<CONT>(geo, g, kk, sup, stk, own, false, sp, sx, i, sh);
+    double* e = st.share + (size_t)(stab_soff(st, id) + i) * 4;
+    e[0] = sh[0]; e[1] = sh[1]; e[2] = sh[2]; e[3] = sh[3];
+    const int Si = sup(i);
+    double com[4];
+    stab_com(geo, st, Si, (int)STAB_NOBOX, (const double*)0, com);
+    double* t = st.stk + (size_t)Si * 4;
+    t[0] = com[0]; t[1] = com[1]; t[2] = com[2]; t[3] = com[3];
+  }
+}
+#if !defined(__HIPCC__)
+// host flavour (tests/host/stab_host.cpp): one thread, every split solved in line
+template <bool CONT, typename Geo>
+PCT_SD int stab_commit(const Geo& geo, StabState& st, int n, double density, unsigned char* ws, int ws_bytes, bool& ill,
+                       StabStats* ss = nullptr) {
+  const int rec = stab_commit_record<CONT>(geo, st, n, density, ws, ws_bytes);
+  if (rec != 2) return rec;
   // explicit depth-first walk; frame = box id | next supporter << 16
   uint32_t* frames = reinterpret_cast<uint32_t*>(ws);
   const int fcap = ws_bytes / 4;
@@ -1017,27 +1239,13 @@ PCT_SD int stab_commit(const Geo& geo, StabState& st, int n, double density, uns
                              st.stk[(size_t)id * 4 + 3]};
       if (!stab_pip(stk, gp, stab_npoly(st, id))) return 0;
       if (ss) ss->commit_visits++;
-      // distribute to every supporter first (up_edges[self] = share; calculate_new_com())
       double g[9];
       geo(id, g);
       StabSplit sp;
       StabSplitX sx;
       if (!stab_split<CONT>(geo, g, kk, sup, stk, sp, sx, ss)) return -1;
       ill = ill || sp.ill;
-      const int alias_k = sp.mode == 0 ? 0 : (sp.mode == 1 ? sp.direct : -1);
-      st.meta[2 * id] = (st.meta[2 * id] & 0xFFFF00FFu) | ((uint32_t)(alias_k + 1) << 8);
-      const double own[3] = {stk[0], stk[1], stk[2]};
-      for (int i = 0; i < kk; i++) {
-        double sh[4];
-        stab_share_of<CONT>(geo, g, kk, sup, stk, own, false, sp, sx, i, sh);
-        double* e = st.share + (size_t)(stab_soff(st, id) + i) * 4;
-        e[0] = sh[0]; e[1] = sh[1]; e[2] = sh[2]; e[3] = sh[3];
-        const int Si = sup(i);
-        double com[4];
-        stab_com(geo, st, Si, (int)STAB_NOBOX, (const double*)0, com);
-        double* t = st.stk + (size_t)Si * 4;
-        t[0] = com[0]; t[1] = com[1]; t[2] = com[2]; t[3] = com[3];
-      }
+      stab_commit_expand<CONT>(geo, st, id, kk, sup, g, stk, sp, sx);
     }
     if (next >= kk) { depth--; continue; }
     frames[d] = (uint32_t)id | ((uint32_t)(next + 1) << 16);
@@ -1047,6 +1255,86 @@ PCT_SD int stab_commit(const Geo& geo, StabState& st, int n, double density, uns
   }
   return 1;
 }
+#else
+// device flavour: lane 0 walks; when a box splits over six and more supporters the whole wave solves that system
+// (stab_lsq_wave) and lane 0 takes the walk up again where it left.  All 64 lanes call; the return value is wave-uniform;
+// only lane 0's copy of `st` (n_ent, n_poly) and of `ill` / `ss` is updated -- the caller broadcasts what it needs.
+template <bool CONT, typename Geo>
+__device__ __forceinline__ int stab_commit_wave(const Geo& geo, StabState& st, int n, double density, const StabWave& w, int lane, bool& ill,
+                                                StabStats* ss = nullptr) {
+  unsigned char* ws = w.hull;
+  const int ws_bytes = w.hull_bytes;
+  int rec = 0;
+  if (lane == 0) rec = stab_commit_record<CONT>(geo, st, n, density, ws, ws_bytes);
+  rec = __builtin_amdgcn_readfirstlane(rec);
+  if (rec != 2) return rec;
+  uint32_t* frames = reinterpret_cast<uint32_t*>(ws);
+  const int fcap = ws_bytes / 4;
+  int depth = 1;
+  if (lane == 0) frames[0] = (uint32_t)n;
+  StabSplit sp;
+  StabSplitX sx;
+  sp.mode = 0; sp.direct = -1; sp.ill = false;
+  bool resume = false;
+  int pend_k = 0;
+  int rc = 1;
+  while (true) {
+    int code = 0;  // 0: the walk is through, 1: unstable, 2: capacity, 3: a split for the wave
+    if (lane == 0) {
+      while (depth > 0) {
+        const int d = depth - 1;
+        const int id = (int)(frames[d] & 0xFFFFu);
+        const int next = (int)(frames[d] >> 16);
+        const int kk = stab_nsup(st, id);
+        if (kk == 0) { depth--; continue; }
+        StabSup sup{st.ent + stab_soff(st, id)};
+        if (next == 0) {
+          const double stk[4] = {st.stk[(size_t)id * 4 + 0], st.stk[(size_t)id * 4 + 1], st.stk[(size_t)id * 4 + 2],
+                                 st.stk[(size_t)id * 4 + 3]};
+          double g[9];
+          geo(id, g);
+          if (!resume) {
+            const double (*gp)[2] = reinterpret_cast<const double (*)[2]>(st.poly + (size_t)stab_poff(st, id) * 2);
+            if (!stab_pip(stk, gp, stab_npoly(st, id))) { code = 1; break; }
+            if (ss) ss->commit_visits++;
+            if (!stab_split<CONT>(geo, g, kk, sup, stk, sp, sx, ss, w.lsq_n)) { code = 2; break; }
+            if (sp.mode == 4) {
+              stab_lsq_inputs<CONT>(geo, g, kk, sup, stk, w.lsq);
+              pend_k = kk;
+              code = 3;
+              break;
+            }
+          }
+          resume = false;
+          ill = ill || sp.ill;
+          stab_commit_expand<CONT>(geo, st, id, kk, sup, g, stk, sp, sx);
+        }
+        if (next >= kk) { depth--; continue; }
+        frames[d] = (uint32_t)id | ((uint32_t)(next + 1) << 16);
+        if (depth >= fcap) { code = 2; break; }
+        frames[depth] = (uint32_t)sup(next);
+        depth++;
+      }
+    }
+    code = __builtin_amdgcn_readfirstlane(code);
+    if (code != 3) {
+      rc = code == 0 ? 1 : (code == 1 ? 0 : -1);
+      break;
+    }
+    const int ks = __builtin_amdgcn_readfirstlane(pend_k);
+    __syncthreads();
+    const bool sill = stab_lsq_wave(w.lsq, w.lsq_n, ks, lane);
+    if (lane == 0) {
+      for (int i = 0; i < ks; i++) sx.fx[i] = w.lsq[2 + 2 * w.lsq_n + i];
+      sp.mode = 3;
+      sp.ill = sill;
+      resume = true;
+    }
+    __syncthreads();
+  }
+  return rc;
+}
+#endif
 
 }  // namespace pct
 #endif

@@ -38,7 +38,7 @@ for _ in range(300):
 torch.cuda.synchronize()
 env.profile_enable(True)
 env.profile_read()
-if TIMED and not W["cont"]:
+if TIMED:
     env.phase_timing(True)
 dur = np.zeros(K)
 keymax = np.zeros(K, np.int64)
@@ -59,7 +59,7 @@ for s in range(K):
     st = env.debug_state(int(keyarg[s]))
     boxes[s] = st["n_boxes"]
     retry[s] = env.debug_retry_count()
-    if TIMED and not W["cont"]:
+    if TIMED:
         rec = env.phase_timing(True)
         phase[s] = rec[keyarg[s]]
 env.profile_enable(False)
@@ -77,7 +77,7 @@ for s in order[:max(12, int((dur > 2 * med).sum()))][:40]:
     line = "    launch %4d: %8.1f us  slowest env %5d: %9d cycles (%.1f us), %3d boxes, %3d EMS, retry queue %d" % (
         s, dur[s], keyarg[s], keymax[s], keymax[s] / 2400, boxes[s], emsat[s], retry[s])
     print(line)
-    if TIMED and not W["cont"]:
+    if TIMED:
         print("        phases: " + "  ".join("%s %d" % (n, phase[s, i]) for i, n in enumerate(names)))
         print("        stats : " + "  ".join("%s %d" % (n, phase[s, i]) for i, n in stat_names.items()))
 # consecutive long launches = the lifetime of one episode?
