@@ -188,6 +188,8 @@ def main():
     ap.add_argument("--share-gpu", action="store_true",
                     help="smoke test only: every rank uses cuda:0 (the N > 1 code path -- barrier, MAX-reduce of the "
                          "elapsed time, per-rank gather -- on a one-GPU box; not a measurement)")
+    ap.add_argument("--ems-capacity", type=int, default=0, help="experiments: pct_config.ems_capacity (0 = the library's default)")
+    ap.add_argument("--candidate-capacity", type=int, default=0, help="experiments: pct_config.candidate_capacity (0 = default)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -226,7 +228,8 @@ def main():
     def make_env(g):
         base = rank * n_local + g * n_grp
         kw = dict(setting=w["setting"], container_size=w["container"], internal_node_holder=w["I"], leaf_node_holder=w["L"],
-                  seed=4, env_id_base=base, device=dev, monitor=False, overflow_retry=not args.no_overflow_retry)
+                  seed=4, env_id_base=base, device=dev, monitor=False, overflow_retry=not args.no_overflow_retry,
+                  ems_capacity=args.ems_capacity, candidate_capacity=args.candidate_capacity)
         if w["cont"]:
             return pkg.PctVecEnv(n_grp, continuous=True, sample_left_bound=w["bounds"][0], sample_right_bound=w["bounds"][1], **kw)
         return pkg.PctVecEnv(n_grp, item_set=item_set(), **kw)
@@ -339,6 +342,7 @@ def main():
             "desync_steps": max(0, args.desync),
             "pipelines": P,
             "overflow_retry_pass": not args.no_overflow_retry,
+            "ems_capacity": args.ems_capacity or "default", "candidate_capacity": args.candidate_capacity or "default",
             "parallelism": "envs sharded by global id x%d, no collective on the step path" % world,
         },
         "roofline": {

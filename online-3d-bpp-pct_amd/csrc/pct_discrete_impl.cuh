@@ -42,6 +42,9 @@
 #ifndef PCT_STAB_WAVES
 #define PCT_STAB_WAVES 1 /* waves per SIMD the stability-check kernels are compiled for (2: 256 VGPRs, ~470 of them spilled -- slower, profiles/r03_stability_tuning.txt) */
 #endif
+#ifndef PCT_SET_CARRY
+#define PCT_SET_CARRY 1 /* 1: insertion batches of exactly 64 tuples across the 64-pair chunks of the EMS expansion (one key per lane) */
+#endif
 #ifndef PCT_SET_RV
 #define PCT_SET_RV 1  /* old slots per lane and matching pass of a table rebuild (32-bit keys) */
 #endif
@@ -1305,7 +1308,65 @@ __device__ __forceinline__ void leaf_nodes(const DiscreteParams& p, int e, Lds<K
       l.dd[64 + lane] = 0xFFFFFFFFu;
       __syncthreads();
     }
+#if PCT_SET_CARRY
+    // Batches of exactly 64 tuples across chunk boundaries (round 4): a chunk of 64 (EMS, rotation) pairs yields 4 x (pairs that
+    // fit) tuples, and its last batch used to go out part full -- 2.8 batches per step for 117 tuples, 10.4 for the 545 of the
+    // EMS-richest env whose candidate set sets a launch's length.  The tuples a chunk leaves over (< 64) wait in a register,
+    // one per lane, in front of the next chunk's; batch position = generation order, as before.
+    K carry = (K)0;
+    int nc = 0;  // lanes [0, nc) hold a carried tuple
+    auto tuple_of = [&](int tt) __attribute__((always_inline)) -> K {  // tuple number tt of the current chunk (l.vp)
+      const int qq = (int)l.vp[(tt >> 2) & 63];
+      const int corner = tt & 3;
+      const int e2 = qq / orient;
+      int tx, ty, tz;
+      rot_size(qq - e2 * orient, tx, ty, tz);
+      const K k2 = l.ems_a[e2];
+      const int x0 = P::get(k2, 0), y0 = P::get(k2, 1), z0 = P::get(k2, 2), x1 = P::get(k2, 3), y1 = P::get(k2, 4);
+      const int xs = (corner & 1) ? x1 - tx : x0;
+      const int ys = (corner & 2) ? y1 - ty : y0;
+      return P::pack(xs, ys, z0, xs + tx, ys + ty, z0 + tz);
+    };
+    for (int pbase = 0; pbase < NP && !st.overflow && !whole && V == 1; pbase += 64) {
+      const uint64_t tpair = tm.now();
+      int q = pbase + lane;
+      bool pv = q < NP;
+      int ei = q / orient, rot = q - ei * orient;
+      int sx, sy, sz;
+      bool skip = rot_size(rot, sx, sy, sz) || !((rotmask >> rot) & 1u);
+      K ek = pv ? l.ems_a[ei] : (K)0;
+      pv = pv && !skip && (P::get(ek, 3) - P::get(ek, 0) >= sx) && (P::get(ek, 4) - P::get(ek, 1) >= sy) &&
+           (P::get(ek, 5) - P::get(ek, 2) >= sz);
+      uint64_t pm = __ballot(pv);
+      const int nt = 4 * __popcll(pm);  // four bottom-corner placements per pair (:565-568)
+      if (!nt) continue;
+      if (pv) l.vp[rank_below(pm)] = (uint16_t)q;
+      tm.add(ST_GENERATED, (uint64_t)nt);
+      __syncthreads();
+      if (TM::on) tm.add(PH_GEN_PAIRS, tm.now() - tpair);
+      int off = 0;
+      while (nc + (nt - off) >= 64 && !st.overflow) {
+        const K key1[1] = {lane < nc ? carry : tuple_of(off + lane - nc)};
+        const bool valid1[1] = {true};
+        set_insert<K, BITS, 1>(st, key1, valid1, lane, tm, mst);
+        off += 64 - nc;
+        nc = 0;
+      }
+      const int rem = nt - off;  // (< 64 - nc) joins the carry
+      if (lane >= nc && lane < nc + rem) carry = tuple_of(off + lane - nc);
+      nc += rem;
+      __syncthreads();
+    }
+    if (V == 1 && nc > 0 && !st.overflow && !whole) {
+      const K key1[1] = {carry};
+      const bool valid1[1] = {lane < nc};
+      set_insert<K, BITS, 1>(st, key1, valid1, lane, tm, mst);
+      __syncthreads();
+    }
+    for (int pbase = 0; pbase < NP && !st.overflow && !whole && V != 1; pbase += 64) {
+#else
     for (int pbase = 0; pbase < NP && !st.overflow && !whole; pbase += 64) {
+#endif
       // which (EMS, rotation) pairs of this chunk can hold the item at all
       const uint64_t tpair = tm.now();
       int q = pbase + lane;
