@@ -21,7 +21,7 @@ KERNEL = "pct_continuous_kernel" if wl in ("c3", "c5", "c3s1") else "pct_discret
 
 out = {"tag": tag, "workload": wl, "envs_per_launch": envs,
        "command": "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --workload %s --steps %d --warmup 200; "
-                  "--steps %d --warmup 100 for each --pmc pass (scripts/profile_gpu.sh)" % (wl, tsteps, psteps)}
+                  "--desync 0 --steps %d --warmup 100 for each --pmc pass (scripts/profile_gpu.sh)" % (wl, tsteps, psteps)}
 db = os.path.join(src, "trace", "trace_results.db")
 lines = []
 if os.path.exists(db):
@@ -32,11 +32,11 @@ if os.path.exists(db):
                             "max(grid_x), max(workgroup_x) from kernels group by name, grid_x order by sum(duration) desc"))
     tot = sum(r[2] for r in rows)
     lines = ["# rocprofv3 --kernel-trace --stats summary (%s, workload %s): python bench.py --workload %s --steps %d --warmup 200" % (tag, wl, wl, tsteps),
-             "%-100s %8s %12s %10s %10s %10s %6s %7s %5s %5s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "pct", "lds_B", "vgpr", "sgpr")]
+             "%-100s %8s %12s %10s %10s %10s %6s %7s %5s %5s %9s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "pct", "lds_B", "vgpr", "sgpr", "scratch_B")]
     for r in rows[:8]:
         nm = r[0] if len(r[0]) <= 100 else r[0][:84] + ".." + r[0][-14:]
-        lines.append("%-100s %8d %12.1f %10.2f %10.2f %10.2f %6.2f %7d %5d %5d" % (
-            nm, r[1], r[2] / 1e3, r[3] / 1e3, r[4] / 1e3, r[5] / 1e3, 100 * r[2] / tot, r[6], r[8], r[9]))
+        lines.append("%-100s %8d %12.1f %10.2f %10.2f %10.2f %6.2f %7d %5d %5d %9d" % (
+            nm, r[1], r[2] / 1e3, r[3] / 1e3, r[4] / 1e3, r[5] / 1e3, 100 * r[2] / tot, r[6], r[8], r[9], r[7]))
     # steady-state average of the step kernel: the timed 2000 launches are the last 2000 of the main (non-retry) grid
     d = [x[0] for x in cur.execute("select duration from kernels where name like ? and grid_x >= ? order by start",
                                    ("%" + KERNEL + "%", envs * 64))]

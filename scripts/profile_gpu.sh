@@ -15,10 +15,10 @@ cd /tmp
 # 1. kernel trace + stats over the same command as the bench line
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH --steps $TSTEPS --warmup 200 > $OUT/trace_bench.json 2> $OUT/trace.err
 # 2. PMC passes (own runs, kernel-trace only)
-timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU -d $OUT/pmc_sq -o pmc -- $BENCH --steps $PSTEPS --warmup 100 > $OUT/pmc_sq.json 2> $OUT/pmc_sq.err
-timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_BRANCH SQ_THREAD_CYCLES_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR -d $OUT/pmc_sq2 -o pmc -- $BENCH --steps $PSTEPS --warmup 100 > $OUT/pmc_sq2.json 2> $OUT/pmc_sq2.err
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $BENCH --steps $PSTEPS --warmup 100 > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
-timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $BENCH --steps $PSTEPS --warmup 100 > $OUT/pmc_write.json 2> $OUT/pmc_write.err
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU -d $OUT/pmc_sq -o pmc -- $BENCH --desync 0 --steps $PSTEPS --warmup 100 > $OUT/pmc_sq.json 2> $OUT/pmc_sq.err
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_BRANCH SQ_THREAD_CYCLES_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR -d $OUT/pmc_sq2 -o pmc -- $BENCH --desync 0 --steps $PSTEPS --warmup 100 > $OUT/pmc_sq2.json 2> $OUT/pmc_sq2.err
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $BENCH --desync 0 --steps $PSTEPS --warmup 100 > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $BENCH --desync 0 --steps $PSTEPS --warmup 100 > $OUT/pmc_write.json 2> $OUT/pmc_write.err
 # summaries are made here, on the GPU box (the databases are too large to travel back whole)
 cd $REPO
 ENVS=$(python -c "import bench; print(bench.WORKLOADS['$WL']['envs'])")
