@@ -336,8 +336,12 @@ void stab_default_caps(int I, pct::StabCaps& normal, pct::StabCaps& retry) {
   normal.PP = 2 * I < 128 ? 128 : 2 * I;
   normal.ws_bytes = 16 * pct::stab_ws_need(2);  /* stab_fit_wave() widens these two into the LDS the env has left */
   normal.queue = 96;
-  normal.lsq_n = 8;  /* least-squares splits over up to 8 supporters in the normal pass (3.3 KB of LDS), 16 in the retry pass */
+  /* least-squares splits over up to 8 supporters in the normal pass (3.3 KB of LDS: one system of 7 / 8 supporters or two of 6 at
+   * a time), up to 16 in the retry pass (four / two systems of the small classes side by side) */
+  normal.lsq_n = 8;
+  normal.lsq_bytes = (int)pct::stab_lsq_bytes(normal.lsq_n, false);
   retry.lsq_n = pct::STAB_LSQ;
+  retry.lsq_bytes = (int)pct::stab_lsq_bytes(retry.lsq_n, true);
   retry.SP = 8 * I < 4094 ? 8 * I : 4094;
   retry.PP = 16 * I < 65535 ? 16 * I : 65535;
   retry.ws_bytes = 16 * 1024;
@@ -359,7 +363,7 @@ void stab_default_caps(int I, pct::StabCaps& normal, pct::StabCaps& retry) {
  * lanes / 112 tasks 9.2 M env-steps/s, 16 lanes / 96 tasks 7.0 M; profiles/r03_stability_tuning.txt). */
 void stab_fit_wave(size_t lds_without_wave, pct::StabCaps& caps) {
   if (knob("PCT_STAB_WS") || knob("PCT_STAB_Q")) return; /* explicit (experiments / tests) */
-  const long budget = 40 * 1024 - 64 - (long)lds_without_wave - (long)pct::stab_lsq_bytes(caps.lsq_n);
+  const long budget = 40 * 1024 - 64 - (long)lds_without_wave - (long)caps.lsq_bytes;
   const int per = pct::stab_ws_need(2);
   for (int lanes = 64; lanes >= 16; lanes -= 8) {
     const int q = 3 * lanes > 96 ? 3 * lanes : 96;
@@ -501,6 +505,7 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
         t0.sb.caps.ws_bytes = 0;
         t0.sb.caps.queue = 0;
         t0.sb.caps.lsq_n = 0;
+        t0.sb.caps.lsq_bytes = 0;
         stab_fit_wave(pct::continuous_lds_bytes(t0), c.sb.caps);
       }
       c.sb.sp_stride = retry_stab.SP;
@@ -644,6 +649,7 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
       t0.sb.caps.ws_bytes = 0;
       t0.sb.caps.queue = 0;
       t0.sb.caps.lsq_n = 0;
+      t0.sb.caps.lsq_bytes = 0;
       stab_fit_wave(pct::discrete_lds_bytes(t0), p.sb.caps);
     }
     pct::DiscreteParams t = p;

@@ -70,7 +70,9 @@ struct StabCaps {
   int PP;       // polygon pool vertices
   int ws_bytes;  // hull workspace (level-0 candidates of a round / the commit's hull and depth-first stack)
   int queue;     // walk tasks the LDS queue holds
-  int lsq_n;     // supporters the wave-cooperative least-squares split takes (its LDS workspace: stab_lsq_bytes), 6..STAB_LSQ
+  int lsq_n;     // supporters the wave-cooperative least-squares split takes, 6..STAB_LSQ
+  int lsq_bytes; // its LDS workspace: at least one system of lsq_n supporters (stab_lsq_bytes); what is beyond that holds
+                 // further systems of the smaller size classes side by side
 };
 
 // per-env stability state: pointers into LDS (device) or host memory
@@ -726,143 +728,182 @@ struct StabHbm {
   uint32_t* ent;   // [N][sp_stride]
 };
 
-// LDS doubles of the wave-cooperative least-squares split for up to n supporters: inputs (stack x / y, n contact centres),
-// the n fractions, three product columns, U (M x n, column-major), V (n x n, column-major); M = n (n - 1) / 2 + 1 rows
+// LDS doubles of ONE system of the wave-cooperative least-squares split for up to n supporters: a header (k, the stack's x / y, n
+// contact centres), the n fractions, three product columns, U (M x n, column-major), V (n x n, column-major); M = n (n - 1) / 2 + 1
 PCT_HD int stab_lsq_rows(int n) { return n * (n - 1) / 2 + 1; }
 PCT_HD int stab_lsq_rows8(int n) { return (stab_lsq_rows(n) + 7) & ~7; }  // the product columns are padded to a multiple of 8 rows
-PCT_HD size_t stab_lsq_bytes(int n) {
-  if (n <= 0) return 0;
+PCT_HD size_t stab_lsq_slot_doubles(int n) {
   const size_t M = (size_t)stab_lsq_rows(n), M8 = (size_t)stab_lsq_rows8(n);
-  return sizeof(double) * (2 + 2 * (size_t)n + (size_t)n + 3 * M8 + M * (size_t)n + (size_t)n * (size_t)n);
+  return 4 + 2 * (size_t)n + (size_t)n + 3 * M8 + M * (size_t)n + (size_t)n * (size_t)n;
+}
+// lanes that share one system: 16 up to 6 supporters (16 rows), 32 up to 8 (29 rows), else the whole wave
+PCT_HD int stab_lsq_group(int k) { return k <= 6 ? 16 : (k <= 8 ? 32 : 64); }
+PCT_HD int stab_lsq_class_n(int k, int lsq_n) { return k <= 6 ? 6 : (k <= 8 ? 8 : lsq_n); }
+// workspace bytes: one system of up to n supporters (narrow: the normal pass, where LDS is what bounds the resident envs --
+// that still takes two systems of the 6-supporter class), or (wide: the retry pass) as many systems as a class's lane groups
+// allow -- four of the 6-supporter class, two of the 8-supporter class
+PCT_HD size_t stab_lsq_bytes(int n, bool wide) {
+  if (n <= 0) return 0;
+  size_t d = stab_lsq_slot_doubles(n);
+  if (wide) {
+    if (4 * stab_lsq_slot_doubles(6) > d) d = 4 * stab_lsq_slot_doubles(6);
+    if (2 * stab_lsq_slot_doubles(8) > d) d = 2 * stab_lsq_slot_doubles(8);
+  }
+  return sizeof(double) * d;
 }
 
 #if defined(__HIPCC__)
 // ---- the wave-cooperative least-squares split -------------------------------------------------------------------------
-// np.linalg.lstsq of the >= 3-supporter system (D/space.py:134-152) for k supporters, by the WHOLE wave: the one-sided Jacobi
-// SVD of stab_lstsq / lstsq_min_norm, operation for operation -- the column sums run over the rows in order (every lane adds
-// the same M products, read back from LDS), rotations and the final back-substitution use the same expressions -- with the
-// rows of U spread over the lanes and the matrix in LDS instead of one lane's private arrays in scratch memory.
-// In: ws[0], ws[1] = the stack's x, y; ws[2 + 2 i], ws[3 + 2 i] = contact centre of supporter i.  Out: ws[2 + 2 nmax + i] = the
-// fraction of supporter i.  All 64 lanes call (wave-uniform arguments).  Returns the ill-conditioning notice.
-__device__ __forceinline__ bool stab_lsq_wave(double* ws, int nmax, int k, int lane) {
-  const int M = stab_lsq_rows(k), M8 = stab_lsq_rows8(k), Mmax = stab_lsq_rows(nmax);
-  const double* in = ws;
-  double* x = ws + 2 + 2 * nmax;
-  double* S = x + nmax;              // [3][M8] products of a column pair (zero beyond row M), later proj / keep flags
-  double* U = S + 3 * (size_t)stab_lsq_rows8(nmax);  // [k][M]
-  double* V = U + (size_t)Mmax * nmax;  // [k][k]
-  const double s0 = in[0], s1 = in[1];
-  // the system: one row per supporter pair (i < j, in that order), a closing row of ones
-  for (int r = lane; r < M; r += 64) {
-    int i = 0, base = 0;
-    while (r < M - 1 && r >= base + (k - 1 - i)) { base += k - 1 - i; i++; }
-    const int j = i + 1 + (r - base);
-    double rr = 0;
-    bool row_on = false;
-    if (r < M - 1) {
-      const double ei0 = in[2 + 2 * i], ei1 = in[3 + 2 * i], ej0 = in[2 + 2 * j], ej1 = in[3 + 2 * j];
-      const double t0 = ei0 - ej0, t1 = ei1 - ej1;
-      const double mol = stab_dot2(s0 - ei0, s1 - ei1, t0, t1);
-      if (mol != 0) { rr = fabs(stab_dot2(s0 - ej0, s1 - ej1, t0, t1)) / mol; row_on = true; }
-    }
-    for (int c = 0; c < k; c++) {
-      double v = 0;
-      if (r == M - 1) v = 1;
-      else if (row_on) v = c == i ? 1.0 : (c == j ? -rr : 0.0);
-      U[(size_t)c * M + r] = v;
-    }
-  }
-  for (int q = lane; q < k * k; q += 64) V[q] = (q / k == q % k) ? 1.0 : 0.0;
-  __syncthreads();
-  for (int sweep = 0; sweep < 60; sweep++) {
-    bool rotated = false;
-    for (int p = 0; p < k; p++)
-      for (int q = p + 1; q < k; q++) {
-        for (int r = lane; r < M8; r += 64) {
-          const double up = r < M ? U[(size_t)p * M + r] : 0.0, uq = r < M ? U[(size_t)q * M + r] : 0.0;
-          S[r] = up * up; S[M8 + r] = uq * uq; S[2 * M8 + r] = up * uq;
-        }
-        __syncthreads();
-        // the three column sums, over the rows IN ORDER (every lane the same additions); eight rows' products are fetched
-        // at a time -- the rows beyond M hold +0.0, which leaves a sum that started at +0.0 unchanged
-        double alpha = 0, beta = 0, gamma = 0;
-        for (int r = 0; r < M8; r += 8) {
-          double a[8], b[8], g[8];
-#pragma unroll
-          for (int u = 0; u < 8; u++) { a[u] = S[r + u]; b[u] = S[M8 + r + u]; g[u] = S[2 * M8 + r + u]; }
-#pragma unroll
-          for (int u = 0; u < 8; u++) { alpha += a[u]; beta += b[u]; gamma += g[u]; }
-        }
-        __syncthreads();
-        if (gamma == 0 || fabs(gamma) <= 2.220446049250313e-16 * sqrt(alpha * beta)) continue;
-        rotated = true;
-        const double zeta = (beta - alpha) / (2 * gamma);
-        const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1 + zeta * zeta));
-        const double c = 1 / sqrt(1 + t * t), sn = c * t;
-        for (int r = lane; r < M; r += 64) {
-          const double up = U[(size_t)p * M + r], uq = U[(size_t)q * M + r];
-          U[(size_t)p * M + r] = c * up - sn * uq;
-          U[(size_t)q * M + r] = sn * up + c * uq;
-        }
-        if (lane < k) {
-          const double vp = V[p * k + lane], vq = V[q * k + lane];
-          V[p * k + lane] = c * vp - sn * vq;
-          V[q * k + lane] = sn * vp + c * vq;
-        }
-        __syncthreads();
-      }
-    if (!rotated) break;
-  }
-  // singular values: lane j sums column j over the rows, in order
-  double s2 = 0;
-  if (lane < k)
-    for (int r = 0; r < M; r++) { const double u = U[(size_t)lane * M + r]; s2 += u * u; }
-  double smax2 = lane < k ? s2 : 0.0;
+// np.linalg.lstsq of the >= 3-supporter system (D/space.py:134-152) for k supporters, by the wave: the one-sided Jacobi SVD of
+// stab_lstsq / lstsq_min_norm, operation for operation -- the column sums run over the rows in order (every lane of a system
+// adds the same M products, read back from LDS), rotations and the final back-substitution use the same expressions -- with
+// the rows of U spread over the lanes and the matrix in LDS instead of one lane's private arrays in scratch memory.  Several
+// INDEPENDENT systems of one size class are solved side by side, one per group of G lanes (64 / G of them): the same
+// instruction stream, every group on its own slot of the workspace, a group whose system has converged sitting out.
+// Slot s (at ws + s * slot doubles, laid out for `n` supporters): [0] = k (0: idle slot), [1], [2] = the stack's x, y,
+// [4 + 2 i], [5 + 2 i] = contact centre of supporter i.  Out: [4 + 2 n + i] = the fraction of supporter i.  All 64 lanes call
+// (wave-uniform G, n, nslot = systems the workspace holds, <= 64 / G).  Returns, per lane, the notice of its group's system.
+__device__ __forceinline__ bool stab_lsq_wave(double* ws, int G, int n, int nslot, int lane) {
+  const int gl = lane & (G - 1);
+  const int grp = lane / G < nslot ? lane / G : 0;  // (a lane group beyond the workspace's slots sits out)
+  double* w = ws + (size_t)grp * stab_lsq_slot_doubles(n);
+  const int k = lane / G < nslot ? (int)w[0] : 0;
+  const int M = stab_lsq_rows(k), M8 = stab_lsq_rows8(k);
+  const double* in = w + 4;
+  double* x = w + 4 + 2 * n;
+  double* S = x + n;                                 // [3][M8] products of a column pair (zero beyond row M), later proj / keep
+  double* U = S + 3 * (size_t)stab_lsq_rows8(n);     // [k][M]
+  double* V = U + (size_t)stab_lsq_rows(n) * n;      // [k][k]
+  const double s0 = w[1], s1 = w[2];
+  int kmax = k;
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
+    const int o = __shfl_xor(kmax, off, 64);
+    kmax = o > kmax ? o : kmax;
+  }
+  // the system: one row per supporter pair (i < j, in that order), a closing row of ones
+  if (k > 0)
+    for (int r = gl; r < M; r += G) {
+      int i = 0, base = 0;
+      while (r < M - 1 && r >= base + (k - 1 - i)) { base += k - 1 - i; i++; }
+      const int j = i + 1 + (r - base);
+      double rr = 0;
+      bool row_on = false;
+      if (r < M - 1) {
+        const double ei0 = in[2 * i], ei1 = in[2 * i + 1], ej0 = in[2 * j], ej1 = in[2 * j + 1];
+        const double t0 = ei0 - ej0, t1 = ei1 - ej1;
+        const double mol = stab_dot2(s0 - ei0, s1 - ei1, t0, t1);
+        if (mol != 0) { rr = fabs(stab_dot2(s0 - ej0, s1 - ej1, t0, t1)) / mol; row_on = true; }
+      }
+      for (int c = 0; c < k; c++) {
+        double v = 0;
+        if (r == M - 1) v = 1;
+        else if (row_on) v = c == i ? 1.0 : (c == j ? -rr : 0.0);
+        U[(size_t)c * M + r] = v;
+      }
+    }
+  for (int q = gl; q < k * k; q += G) V[q] = (q / k == q % k) ? 1.0 : 0.0;
+  __syncthreads();
+  bool done = k == 0;  // this group's system has converged (the same in every lane of a group)
+  for (int sweep = 0; sweep < 60 && __ballot(!done); sweep++) {
+    bool rotated = false;
+    for (int p = 0; p < kmax; p++)
+      for (int q = p + 1; q < kmax; q++) {
+        const bool on = !done && q < k;
+        if (on)
+          for (int r = gl; r < M8; r += G) {
+            const double up = r < M ? U[(size_t)p * M + r] : 0.0, uq = r < M ? U[(size_t)q * M + r] : 0.0;
+            S[r] = up * up; S[M8 + r] = uq * uq; S[2 * M8 + r] = up * uq;
+          }
+        __syncthreads();
+        // the three column sums, over the rows IN ORDER (every lane of the group the same additions); eight rows' products are
+        // fetched at a time -- the rows beyond M hold +0.0, which leaves a sum that started at +0.0 unchanged
+        double alpha = 0, beta = 0, gamma = 0;
+        if (on)
+          for (int r = 0; r < M8; r += 8) {
+            double a[8], b[8], g[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { a[u] = S[r + u]; b[u] = S[M8 + r + u]; g[u] = S[2 * M8 + r + u]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) { alpha += a[u]; beta += b[u]; gamma += g[u]; }
+          }
+        __syncthreads();
+        const bool rot = on && !(gamma == 0 || fabs(gamma) <= 2.220446049250313e-16 * sqrt(alpha * beta));
+        if (__ballot(rot)) {
+          rotated = rotated || rot;
+          const double zeta = (beta - alpha) / (2 * gamma);
+          const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1 + zeta * zeta));
+          const double c = 1 / sqrt(1 + t * t), sn = c * t;
+          if (rot) {
+            for (int r = gl; r < M; r += G) {
+              const double up = U[(size_t)p * M + r], uq = U[(size_t)q * M + r];
+              U[(size_t)p * M + r] = c * up - sn * uq;
+              U[(size_t)q * M + r] = sn * up + c * uq;
+            }
+            if (gl < k) {
+              const double vp = V[p * k + gl], vq = V[q * k + gl];
+              V[p * k + gl] = c * vp - sn * vq;
+              V[q * k + gl] = sn * vp + c * vq;
+            }
+          }
+          __syncthreads();
+        }
+      }
+    if (!rotated) done = true;
+  }
+  // singular values: lane j of a group sums column j over the rows, in order
+  double s2 = 0;
+  if (gl < k)
+    for (int r = 0; r < M; r++) { const double u = U[(size_t)gl * M + r]; s2 += u * u; }
+  double smax2 = gl < k ? s2 : 0.0;
+  for (int off = G >> 1; off >= 1; off >>= 1) {  // (within the group: the partner of lane l is l ^ off)
     const double o = __shfl_xor(smax2, off, 64);
     smax2 = o > smax2 ? o : smax2;
   }
   const double rc = 2.220446049250313e-16 * (double)(M > k ? M : k);
   const double sj = sqrt(s2), cut = rc * sqrt(smax2);
-  const bool ill = lane < k && s2 > 0 && sj > cut / STAB_ILL_BAND && sj < cut * STAB_ILL_BAND;
-  const bool keep = lane < k && !(s2 <= 0 || sj <= cut);
-  if (lane < k) {
+  const bool ill = gl < k && s2 > 0 && sj > cut / STAB_ILL_BAND && sj < cut * STAB_ILL_BAND;
+  const bool keep = gl < k && !(s2 <= 0 || sj <= cut);
+  if (gl < k) {
     // proj = sum_r U[r][j] b[r] with b = e_{M-1}: zeros, then the last row's entry
     double proj = 0.0;
-    proj += U[(size_t)lane * M + (M - 1)] * 1.0;
+    proj += U[(size_t)gl * M + (M - 1)] * 1.0;
     proj /= s2;
-    S[lane] = keep ? proj : 0.0;
-    S[M8 + lane] = keep ? 1.0 : 0.0;
+    S[gl] = keep ? proj : 0.0;
+    S[M8 + gl] = keep ? 1.0 : 0.0;
   }
   __syncthreads();
-  if (lane < k) {
+  if (gl < k) {
     double xi = 0;
     for (int j = 0; j < k; j++)
-      if (S[M8 + j] != 0.0) xi += V[j * k + lane] * S[j];
-    x[lane] = xi;
+      if (S[M8 + j] != 0.0) xi += V[j * k + gl] * S[j];
+    x[gl] = xi;
   }
   __syncthreads();
-  return __ballot(ill) != 0;
+  // the notice of a group: any of its lanes
+  const uint64_t im = __ballot(ill);
+  const uint64_t gm = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << (lane & ~(G - 1));
+  return (im & gm) != 0;
 }
-// the contact centres of a box's supporters and its stack, laid out as stab_lsq_wave reads them (one lane writes)
+// one system's slot as stab_lsq_wave reads it: k, the stack's x / y, the contact centres of the box's supporters (one lane writes)
 template <bool CONT, typename Geo, typename Sup>
-__device__ __forceinline__ void stab_lsq_inputs(const Geo& geo, const double bg[9], int k, const Sup& sup, const double stk[4], double* ws) {
-  ws[0] = stk[0];
-  ws[1] = stk[1];
+__device__ __forceinline__ void stab_lsq_inputs(const Geo& geo, const double bg[9], int k, const Sup& sup, const double stk[4], double* slot) {
+  slot[0] = (double)k;
+  slot[1] = stk[0];
+  slot[2] = stk[1];
   for (int i = 0; i < k; i++) {
     double a[4];
     stab_area<CONT>(geo, bg, sup(i), a);
-    ws[2 + 2 * i] = (a[0] + a[2]) / 2;
-    ws[3 + 2 * i] = (a[1] + a[3]) / 2;
+    slot[4 + 2 * i] = (a[0] + a[2]) / 2;
+    slot[5 + 2 * i] = (a[1] + a[3]) / 2;
   }
 }
 
 // ---- the wave-cooperative driver ----------------------------------------------------------------------------------
 // LDS workspace of a wave: the hull workspace (shared by the level-0 tasks of a round) and the task queue.
 struct StabWave {
-  double* lsq;   // workspace of the cooperative least-squares split (stab_lsq_bytes(lsq_n))
-  int lsq_n;
+  double* lsq;   // workspace of the cooperative least-squares split (caps.lsq_bytes)
+  int lsq_n, lsq_doubles;
   unsigned char* hull;
   int hull_bytes;
   uint32_t* ctl;    // [6] queue count, failed candidates (lanes 0..31, 32..63), global capacity error (STAB_WHY_*),
@@ -872,18 +913,22 @@ struct StabWave {
   int qcap;
 };
 PCT_HD size_t stab_wave_bytes(const StabCaps& c) {
-  return stab_lsq_bytes(c.lsq_n) + (size_t)c.ws_bytes + (size_t)c.queue * (4 * sizeof(double) + sizeof(uint32_t)) + 32;
+  return (size_t)c.lsq_bytes + (size_t)((c.ws_bytes + 7) & ~7) + (size_t)c.queue * (4 * sizeof(double) + sizeof(uint32_t)) + 32;
 }
 // carve: the least-squares workspace and the queue's doubles first (8-byte aligned base), then the hull workspace, then the words
 PCT_SD StabWave stab_wave_carve(unsigned char* base, const StabCaps& c) {
   StabWave w;
   w.lsq = reinterpret_cast<double*>(base);
   w.lsq_n = c.lsq_n;
-  base += stab_lsq_bytes(c.lsq_n);
-  w.qstk = reinterpret_cast<double*>(base);
-  w.hull = base + (size_t)c.queue * 4 * sizeof(double);
+  w.lsq_doubles = c.lsq_bytes / (int)sizeof(double);
+  base += (size_t)c.lsq_bytes;
+  // the hull workspace follows the least-squares workspace directly: in the passes of a round that work on popped tasks (whose
+  // supporter lists are pool entries) it is idle, and further systems of the small size classes are solved in it
+  w.hull = base;
   w.hull_bytes = c.ws_bytes;
-  w.qmeta = reinterpret_cast<uint32_t*>(w.hull + c.ws_bytes);
+  base += (size_t)((c.ws_bytes + 7) & ~7);
+  w.qstk = reinterpret_cast<double*>(base);
+  w.qmeta = reinterpret_cast<uint32_t*>(base + (size_t)c.queue * 4 * sizeof(double));
   w.ctl = w.qmeta + c.queue;
   w.qcap = c.queue;
   return w;
@@ -984,6 +1029,7 @@ __device__ __forceinline__ bool stab_virtual_wave(const Geo& geo, const StabStat
       for (int c = 0; c < 9; c++) bg[c] = cand[c];
       stk[0] = cstk[0]; stk[1] = cstk[1]; stk[2] = cstk[2]; stk[3] = cstk[3];
     }
+    bool hull_idle = false;  // (the first pass of a round examines the candidates themselves: their supporter ids are in the hull workspace)
     while (true) {
       {
         // how the box under examination splits its stack over its supporters; a split over six and more goes to the wave
@@ -995,18 +1041,34 @@ __device__ __forceinline__ bool stab_virtual_wave(const Geo& geo, const StabStat
           atomicOr(&w.ctl[4 + (cl >> 5)], 1u << (cl & 31));
           have = false;
         }
-        for (uint64_t cm = __ballot(have && sp.mode == 4); cm; cm &= cm - 1) {
-          const int src = __ffsll((unsigned long long)cm) - 1;
-          const int ks = __builtin_amdgcn_readlane(kk, src);
-          if (lane == src) stab_lsq_inputs<CONT>(geo, bg, kk, sup, stk, w.lsq);
+        // the splits for the wave, one size class at a time, as many systems side by side as the class's lane groups allow
+        for (uint64_t cm = __ballot(have && sp.mode == 4); cm;) {
+          const int first = __ffsll((unsigned long long)cm) - 1;
+          const int kf = __builtin_amdgcn_readlane(kk, first);
+          const int G = stab_lsq_group(kf), cn = stab_lsq_class_n(kf, w.lsq_n);
+          const size_t sd = stab_lsq_slot_doubles(cn);
+          const bool mine = ((cm >> lane) & 1ull) && stab_lsq_group(kk) == G;
+          const uint64_t mm = __ballot(mine);
+          const int rk = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+          // systems of this class the workspace holds (with the hull workspace behind it when that is idle), at most one per lane group
+          int nslot = (w.lsq_doubles + (hull_idle ? w.hull_bytes / (int)sizeof(double) : 0)) / (int)sd;
+          nslot = nslot < 64 / G ? nslot : 64 / G;
+          const bool sel = mine && rk < nslot;
+          if (lane < nslot) w.lsq[(size_t)lane * sd] = 0.0;  // idle slots
           __syncthreads();
-          const bool sill = stab_lsq_wave(w.lsq, w.lsq_n, ks, lane);
-          if (lane == src) {
-            for (int i = 0; i < kk; i++) sx.fx[i] = w.lsq[2 + 2 * w.lsq_n + i];
+          if (sel) stab_lsq_inputs<CONT>(geo, bg, kk, sup, stk, w.lsq + (size_t)rk * sd);
+          __syncthreads();
+          const bool gill = stab_lsq_wave(w.lsq, G, cn, nslot, lane);
+          // a system's notice comes back in its group's lanes: fetch the one of this lane's slot
+          const uint64_t illm = __ballot(gill);
+          if (sel) {
+            const double* slot = w.lsq + (size_t)rk * sd;
+            for (int i = 0; i < kk; i++) sx.fx[i] = slot[4 + 2 * cn + i];
             sp.mode = 3;
-            sp.ill = sill;
+            sp.ill = (illm >> (rk * G)) & 1ull;
           }
           __syncthreads();
+          cm &= ~__ballot(sel);
         }
         if (have) {
           ill = ill || sp.ill;
@@ -1023,6 +1085,7 @@ __device__ __forceinline__ bool stab_virtual_wave(const Geo& geo, const StabStat
           stab_children_emit<CONT>(geo, st, bg, kk, sup, stk, skip, sp, sx, emit);
         }
       }
+      hull_idle = true;
       if (ss && lane == 0) ss->v_passes++;
       __syncthreads();
       const uint32_t qraw = w.ctl[0];
@@ -1299,7 +1362,7 @@ __device__ __forceinline__ int stab_commit_wave(const Geo& geo, StabState& st, i
             if (ss) ss->commit_visits++;
             if (!stab_split<CONT>(geo, g, kk, sup, stk, sp, sx, ss, w.lsq_n)) { code = 2; break; }
             if (sp.mode == 4) {
-              stab_lsq_inputs<CONT>(geo, g, kk, sup, stk, w.lsq);
+              stab_lsq_inputs<CONT>(geo, g, kk, sup, stk, w.lsq);  // (slot 0)
               pend_k = kk;
               code = 3;
               break;
@@ -1322,10 +1385,12 @@ __device__ __forceinline__ int stab_commit_wave(const Geo& geo, StabState& st, i
       break;
     }
     const int ks = __builtin_amdgcn_readfirstlane(pend_k);
+    const int G = stab_lsq_group(ks), cn = stab_lsq_class_n(ks, w.lsq_n);
+    const size_t sd = stab_lsq_slot_doubles(cn);
     __syncthreads();
-    const bool sill = stab_lsq_wave(w.lsq, w.lsq_n, ks, lane);
+    const bool sill = stab_lsq_wave(w.lsq, G, cn, 1, lane);  // one system, in slot 0
     if (lane == 0) {
-      for (int i = 0; i < ks; i++) sx.fx[i] = w.lsq[2 + 2 * w.lsq_n + i];
+      for (int i = 0; i < ks; i++) sx.fx[i] = w.lsq[4 + 2 * cn + i];
       sp.mode = 3;
       sp.ill = sill;
       resume = true;

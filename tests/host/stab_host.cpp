@@ -51,6 +51,7 @@ struct stab* stab_create(int cap, double eps) {
   s->caps.ws_bytes = (e = getenv("PCT_STAB_HOST_WS")) ? atoi(e) : pct::stab_ws_need(255);
   s->caps.queue = 0;
   s->caps.lsq_n = pct::STAB_LSQ;
+  s->caps.lsq_bytes = 0;
   s->mem.assign(pct::stab_state_bytes(s->cap, s->caps) + 16, 0);
   s->ws.assign((size_t)s->caps.ws_bytes + 16, 0);
   s->st = pct::stab_carve(s->mem.data(), s->cap, s->caps);
