@@ -296,7 +296,7 @@ def test_stability_launches_have_no_latency_cliff():
     env.profile_enable(True)
     env.profile_read()
     dur = []
-    for _ in range(140):
+    for _ in range(240):  # steps 380..620 from the reset: both clusters (395-407 and 586-608)
         env.step_rows_device(rows)
         n, ms = env.profile_read()
         dur.append(ms * 1e3 / max(n, 1))
