@@ -85,7 +85,7 @@ extern "C" {
 #define PCT_HEUR_OBPH 2 /* :364-425 OnlineBPH */
 #define PCT_HEUR_DBL 3  /* :431-498 DBL */
 #define PCT_HEUR_BR 4   /* :500-569 BR */
-#define PCT_HEUR_MACS 5 /* :11-136 MACS (bins up to 64 along y) */
+#define PCT_HEUR_MACS 5 /* :11-136 MACS */
 #define PCT_HEUR_RANDOM 6 /* :300-362 random; np.random.randint(0, n) -> pct_mix32(global env id, t) % n */
 
 /* item source */

@@ -1952,7 +1952,7 @@ __device__ __forceinline__ bool heur_choose(const DiscreteParams& p, int e, Lds<
     // (level, row), built once per step in the idle table region; the candidate's footprint is cleared
     // from the rows it covers.  Largest rectangle of a level: for every band of rows i1..i2 the AND of
     // their masks, times the longest run of ones.
-    // Row masks are 32 bits wide for Ly <= 32 and 64 bits wide up to Ly = 64 (checked by the host).
+    // Row masks are 32 bits wide for Ly <= 32, 64 bits wide up to Ly = 64 and multi-word beyond (macs_wide).
     auto macs = [&](auto mask_tag) __attribute__((always_inline)) {
       typedef decltype(mask_tag) M;
       constexpr int MB = (int)sizeof(M) * 8;
@@ -2004,8 +2004,80 @@ __device__ __forceinline__ bool heur_choose(const DiscreteParams& p, int e, Lds<
         }
       }
     };
+    // Beyond 64 cells along y (round 4): the same sweep on multi-word masks, NW = ceil(Ly / 64) words of 64 bits per (level,
+    // row); the band, its run-length copy and the footprint are small per-lane arrays (a coverage path, not a tuned one).
+    auto macs_wide = [&]() __attribute__((always_inline)) {
+      constexpr int MAXW = 16;  // Ly <= 1023
+      const int NW = (p.Ly + 63) >> 6;
+      uint64_t* rows = reinterpret_cast<uint64_t*>(scratch);  // [H][W][NW]
+      for (int c = lane; c < p.H * p.W * NW; c += 64) {
+        const int lv = c / (p.W * NW), rem = c - lv * p.W * NW, i = rem / NW, wd = rem - i * NW;
+        uint64_t m = 0;
+        for (int j = wd * 64; j < p.Ly && j < wd * 64 + 64; j++) m |= ((int)l.hmap[i * p.A + j] <= lv) ? (1ull << (j - wd * 64)) : 0ull;
+        rows[c] = m;
+      }
+      __syncthreads();
+      const int NC = NQ * 4;
+      for (int base = 0; base < NC; base += 64) {
+        int qc = base + lane;
+        const bool live = qc < NC;
+        int q = qc >> 2, corner = qc & 3;
+        int ei = q / orient, rot = q - ei * orient;
+        K ek = live ? l.ems_a[ei] : (K)0;
+        int dx = P::get(ek, 3) - P::get(ek, 0), dy = P::get(ek, 4) - P::get(ek, 1), dz = P::get(ek, 5) - P::get(ek, 2);
+        int x, y, z, mh;
+        long long under;
+        heur_rot(b0, b1, b2, rot, x, y, z);
+        int lx = (corner & 1) ? P::get(ek, 3) - x : P::get(ek, 0);
+        int ly = (corner & 2) ? P::get(ek, 4) - y : P::get(ek, 1);
+        if (probe(live && dx >= x && dy >= y && dz >= z, x, y, z, lx, ly, mh, under)) {
+          uint64_t foot[MAXW], band[MAXW], tt[MAXW];
+          for (int wd = 0; wd < NW; wd++) {  // bits [ly, ly + y) of the row
+            const int lo = ly - wd * 64, hi = ly + y - wd * 64;
+            const uint64_t a = lo <= 0 ? ~0ull : (lo >= 64 ? 0ull : (~0ull << lo));
+            const uint64_t b = hi >= 64 ? ~0ull : (hi <= 0 ? 0ull : ((1ull << hi) - 1ull));
+            foot[wd] = a & b;
+          }
+          uint32_t score = 0;
+          for (int lv = 0; lv < mh; lv++) {
+            const uint64_t* rw = rows + (size_t)lv * p.W * NW;
+            uint32_t level_max = 0;
+            for (int i1 = 0; i1 < p.W; i1++) {
+              for (int wd = 0; wd < NW; wd++) band[wd] = ~0ull;
+              for (int i2 = i1; i2 < p.W; i2++) {
+                uint64_t any = 0;
+                for (int wd = 0; wd < NW; wd++) {
+                  uint64_t rm = rw[i2 * NW + wd];
+                  if (i2 >= lx && i2 < lx + x) rm &= ~foot[wd];
+                  band[wd] &= rm;
+                  any |= band[wd];
+                  tt[wd] = band[wd];
+                }
+                if (!any) break;
+                uint32_t run = 0;
+                while (any) {  // longest run of ones: t &= t << 1 across the words until nothing is left
+                  any = 0;
+                  for (int wd = NW - 1; wd >= 0; wd--) {
+                    const uint64_t sh = (tt[wd] << 1) | (wd > 0 ? (tt[wd - 1] >> 63) : 0ull);
+                    tt[wd] &= sh;
+                    any |= tt[wd];
+                  }
+                  run++;
+                }
+                const uint32_t area = run * (uint32_t)(i2 - i1 + 1);
+                level_max = area > level_max ? area : level_max;
+              }
+            }
+            score += level_max;
+          }
+          uint64_t key = ((uint64_t)(0xFFFFFFFFu - score) << 24) | (uint64_t)qc;
+          best = key < best ? key : best;
+        }
+      }
+    };
     if (p.Ly <= 32) macs((uint32_t)0);
-    else macs((uint64_t)0);
+    else if (p.Ly <= 64) macs((uint64_t)0);
+    else macs_wide();
     best = wave_min_u64(best);
     __syncthreads();
     if (best == NONE) return false;

@@ -1024,10 +1024,11 @@ int pct_step_heuristic(pct_env* h, int32_t kind, int32_t n_steps, void* stream) 
   if (rc) return rc;
   if (n_steps < 1) return fail(PCT_ERR_INVALID_ARG, "n_steps must be >= 1");
   if (kind < PCT_HEUR_LSAH || kind > PCT_HEUR_RANDOM) return fail(PCT_ERR_INVALID_ARG, "unknown heuristic");
+  /* MACS keeps one empty-cell mask per (level, row) in the idle table region: 32-bit words, two per 64 cells along y */
   if (!h->continuous && kind == PCT_HEUR_MACS &&
-      (h->cfg.container[1] > 64 || (size_t)h->cfg.container[0] * h->cfg.container[2] * (h->cfg.container[1] > 32 ? 2 : 1) >
-                                        (size_t)h->dp.cand_cap * (h->dp.key_bytes / 4)))
-    return fail(PCT_ERR_UNSUPPORTED, "MACS: the level masks need Ly <= 64 and W*H (Ly > 32: 2*W*H) words of table scratch");
+      (size_t)h->cfg.container[0] * h->cfg.container[2] * (h->cfg.container[1] > 32 ? 2 * (size_t)((h->cfg.container[1] + 63) / 64) : 1) >
+          (size_t)h->dp.cand_cap * (h->dp.key_bytes / 4))
+    return fail(PCT_ERR_UNSUPPORTED, "MACS: the level masks (W * H * ceil(Ly / 64) 64-bit words) do not fit the table scratch (raise candidate_capacity)");
   if (!h->continuous && kind == PCT_HEUR_RANDOM && ((size_t)h->cfg.container[0] * h->cfg.container[1] * 6 / 64 + 1) * 2 >
                                      (size_t)h->dp.cand_cap * (h->dp.key_bytes / 4))
     return fail(PCT_ERR_UNSUPPORTED, "RANDOM: the feasibility masks do not fit the table scratch (raise candidate_capacity)");

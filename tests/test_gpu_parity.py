@@ -535,10 +535,10 @@ def test_hip_heuristics_match_oracle_batched(heur, setting):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("setting,container", [(2, (9, 40, 8)), (1, (8, 36, 9)), (2, (7, 64, 6))])
+@pytest.mark.parametrize("setting,container", [(2, (9, 40, 8)), (1, (8, 36, 9)), (2, (7, 64, 6)), (2, (5, 80, 5)), (1, (4, 130, 7))])
 def test_hip_macs_wide_bins_match_oracle(setting, container):
     """MACS (heuristic.py:11-136) in bins wider than 32 cells along y: the level row masks are 64 bits wide there (and the
-    candidate keys 64 bits: the other half of the heuristic kernels)"""
+    candidate keys 64 bits: the other half of the heuristic kernels); beyond 64 cells they are multi-word (round 4)"""
     from oracle.oracle_lib import OracleVecEnv
     from tests.common import HEUR_CODE
     N, items = 16, item_set_range(2, 6)
