@@ -7,12 +7,16 @@
 A "step" is ONE batched transition of the workload on every GPU.  The default workload (c2) is
 BASELINE.json configs[1], the configuration the headline metric is quoted on: PctDiscrete0 setting 2
 (EMS leaves), bin 10x10x10, 80 internal / 50 leaf nodes, 4096 envs per GPU, items drawn uniformly from
-(1..5)^3 by the on-device counter-based sampler.  Per step the stand-in policy kernel reads the leaf mask
-from the observation and writes one float32 leaf row per env ([N,9], what train_tools.py:66-67 hands the
-env), then pct_step_rows runs the transition kernel, which regenerates the [I+L+1,9] float32
-observation, reward, done and info for every env (auto-reset included).  Everything stays in HBM; the
-host only enqueues.  Envs shard across GPUs by global env id with no collective on the step path
-("scaling": "weak", per-GPU work fixed).
+(1..5)^3 by the on-device counter-based sampler.  Per step pct_step_rows runs the transition kernel on one
+float32 leaf row per env ([N,9] in HBM, what train_tools.py:66-67 hands the env): it regenerates the
+[I+L+1,9] float32 observation, reward, done and info for every env (auto-reset included).  The rows come
+from the stand-in policy (leaf = pct_mix32(env, t) % k over the k valid leaves of the observation): by
+default written by the PREVIOUS launch's policy epilogue (pct_bind_policy_rows: `--mode epilogue`, one
+transition dispatch per step), or by the stand-in policy as its own kernel between two steps (`--mode rows`,
+the rounds 1-3 default).  Before --warmup come 200 untimed de-synchronisation steps (`--desync`), so that a
+short run measures episodes of every length in flight, not 4096 envs that all start empty.  Everything
+stays in HBM; the host only enqueues.  Envs shard across GPUs by global env id with no collective on the
+step path ("scaling": "weak", per-GPU work fixed).
 
 Other workloads (parity-test configurations of BASELINE.json, measurable with the same contract):
   c4    the per-GPU slice of configs[3] (65 536 envs over 8 GPUs): c2 with 8192 envs per GPU --
@@ -26,9 +30,11 @@ Other workloads (parity-test configurations of BASELINE.json, measurable with th
 Printed JSON (one line, rank 0): the driver contract plus
   roofline        the transition kernel against the HBM roof: algorithmic bytes per launch
                   (B(I,L) = 36 (I+L+1) + 41 per env-step x envs per launch) / its average
-                  duration measured with HIP events recorded by the library on the launch stream during
-                  the timed region; `traffic` = HBM bytes per launch from rocprofv3 PMC passes of the same
-                  command (a separate profiled run; `traffic_source` names the committed file);
+                  duration measured with HIP events over the timed region (the library hands an event pair
+                  to hipExtLaunchKernel as the step kernel's start / stop events: exactly that dispatch, on
+                  the launch stream); `kernel` = the name rocprofv3 prints for it; `traffic` = HBM bytes
+                  per launch from rocprofv3 PMC passes of the same command (a separate profiled run;
+                  `traffic_source` names the committed file);
   roofline_issue  the same kernel against the instruction-issue rate of the chip (VALU + SALU wave
                   instructions per launch from the committed PMC pass / the measured duration);
   cpu_baseline    the CPU oracle (C restatement of the reference env, oracle/) timed on this box's host
