@@ -193,6 +193,46 @@ def test_hip_policy_kernel_rows_path_equals_fused():
     b.close()
 
 
+@pytest.mark.parametrize("kind", ["discrete_s2", "discrete_s1", "continuous_s2", "continuous_big"])
+def test_hip_policy_epilogue_writes_the_policy_kernels_rows(kind):
+    """pct_bind_policy_rows (round 4): the transition kernel's stand-in policy epilogue writes, after reset and after every
+    step (auto-resets, heavy-first dispatch and the large-capacity retry pass included), byte for byte the rows the separate
+    policy kernel gathers from the observation -- and stepping on them is stepping with the fused stand-in policy."""
+    items = item_set_range(1, 5)
+    N = 2048
+    if kind == "discrete_s2":
+        mk = lambda: _pkg().PctVecEnv(N, item_set=items, seed=13, device="cuda:0")
+    elif kind == "discrete_s1":
+        mk = lambda: _pkg().PctVecEnv(N, setting=1, item_set=items, seed=13, device="cuda:0")
+    elif kind == "continuous_s2":
+        mk = lambda: _pkg().PctVecEnv(N, continuous=True, sample_left_bound=1.0, sample_right_bound=5.0, seed=13, device="cuda:0")
+    else:  # small capacities: the retry pass has work (candidate sets beyond 512 slots, EMS lists beyond 64)
+        N = 512
+        mk = lambda: _pkg().PctVecEnv(N, continuous=True, container_size=(20, 20, 20), sample_left_bound=2.0, sample_right_bound=6.0,
+                                      internal_node_holder=120, leaf_node_holder=60, seed=13, device="cuda:0",
+                                      ems_capacity=64, candidate_capacity=512)
+    a, b = mk(), mk()
+    rows = torch.empty(N, 9, dtype=torch.float32, device="cuda:0")
+    check = torch.empty(N, 9, dtype=torch.float32, device="cuda:0")
+    a.bind_policy_rows(rows)
+    a.reset()
+    b.reset()
+    for t in range(60):
+        a.policy_hash_rows(check)
+        assert torch.equal(rows, check), (kind, t, (rows != check).any(1).nonzero()[:4].ravel().tolist())
+        a.step_rows_device(rows.clone())  # (a copy: the launch rewrites `rows` while it reads its actions)
+        b.step_hash_policy(1)
+    oa, ra, da, _ = a.step_wait()
+    ob, rb, db, _ = b.step_wait()
+    assert torch.equal(oa, ob) and torch.equal(ra, rb) and np.array_equal(da, db)
+    assert not a.error_flags.any()
+    if kind == "continuous_big":
+        assert a.debug_retry_count(totals=True)[1] > 0  # the retry pass wrote some of those rows
+    a.bind_policy_rows(None)
+    a.close()
+    b.close()
+
+
 def test_hip_full_size_properties():
     """BASELINE config C2 (4096 envs, 10^3, 80/50) with the on-device sampler: invariants that
     hold at any size -- volume conservation (heightmap consistent with the packed boxes),
