@@ -527,14 +527,8 @@ __device__ __forceinline__ bool cleaf_nodes(const ContinuousParams& p, int e, CL
     cand_tuple(p, l, r, orient, g, t);
     uint64_t hash = tuplehash6d(t);
     __syncthreads();
-    // exact in-batch de-duplication (first occurrence stays): equal hashes first, then the tuples; the other
-    // lane's hash and generator id come over a shuffle
-    pending = pending && !batch_find_duplicates_shfl<128>(l.dd, pending, hash, g, lane, [&](uint64_t hw, uint32_t gw) -> bool {
-      if (hw != hash) return false;
-      double o[6];
-      cand_tuple(p, l, r, orient, gw, o);
-      return tuple_eq(o, t);
-    });
+    // exact in-batch de-duplication (first occurrence stays): the first holder's tuple comes over cross-lane reads
+    pending = pending && !batch_find_duplicates_t6<128>(l.dd, pending, hash, t, lane);
     tm.sub_tick(PH_SET_DEDUP);
     if (fill == 0 && size == 8 && p.cand_cap >= 512) {
       const uint64_t pm0 = __ballot(pending);

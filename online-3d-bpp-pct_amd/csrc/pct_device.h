@@ -196,13 +196,17 @@ __device__ __forceinline__ void wave_priority(int n_ems, const int prio_t[3]) {
   else __builtin_amdgcn_s_setprio(0);
 }
 
-// Observation rows are written once and read by the NEXT kernel (the policy), never again by this one: PCT_OBS_NT = 1 marks
-// the stores non-temporal (streaming) so that they do not sit in the L2 as dirty lines the end-of-kernel release has to write back.
+// Observation rows are written once and read by the NEXT kernel (the policy), never again by this one.  PCT_OBS_NT = 2 (default):
+// write-through stores (system scope: sc0 sc1), so that the 20 MB of fresh rows a launch leaves do not wait in the L2 as dirty
+// lines for the end-of-kernel release -- C2 64.4 -> 65.3 M env-steps/s (kernel 55.5 -> 54.6 us); 1: non-temporal stores
+// (measured: no gain); 0: plain stores.  profiles/r04_experiments.txt items 2 and 7.
 #ifndef PCT_OBS_NT
-#define PCT_OBS_NT 0
+#define PCT_OBS_NT 2
 #endif
 __device__ __forceinline__ void obs_st(float* q, float v) {
-#if PCT_OBS_NT
+#if PCT_OBS_NT == 2
+  __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (write-through: sc0 sc1)
+#elif PCT_OBS_NT
   __builtin_nontemporal_store(v, q);
 #else
   *q = v;

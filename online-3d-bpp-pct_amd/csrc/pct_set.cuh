@@ -407,6 +407,41 @@ __device__ __forceinline__ bool batch_find_duplicates_shfl(uint32_t* dd, bool ac
   return dup;
 }
 
+// Same again for keys that are six doubles held in registers (the continuous env's candidate tuples): the first holder's
+// tuple itself comes over twelve cross-lane reads and is compared value for value -- no hash comparison, and no recomputation
+// of the other lane's tuple from its generator id (float64 lattice conversions and the rotation switch: ~120 instructions that
+// every lane of the wave paid in every round that held a duplicate).
+template <int NB>
+__device__ __forceinline__ bool batch_find_duplicates_t6(uint32_t* dd, bool active, uint64_t hash, const double (&t)[6], int lane) {
+  bool unresolved = active, dup = false;
+  for (int round = 0; round < 8; round++) {
+    if (!__ballot(unresolved)) return dup;
+    const uint32_t b = (uint32_t)(hash >> (3 + 7 * round)) & (uint32_t)(NB - 1);
+    if (unresolved) atomicMin(&dd[b], (uint32_t)lane);
+    __syncthreads();
+    const uint32_t w = unresolved ? dd[b] : (uint32_t)lane;
+    __syncthreads();
+    bool eq = true;
+#pragma unroll
+    for (int c = 0; c < 6; c++) eq = eq && (__shfl(t[c], (int)(w & 63u), 64) == t[c]);
+    if (unresolved) {
+      dd[b] = 0xFFFFFFFFu;
+      if (w == (uint32_t)lane) unresolved = false;
+      else if (eq) { dup = true; unresolved = false; }
+    }
+    __syncthreads();
+  }
+  // eight rounds of pure collisions between distinct keys: exhaustive scan over the earlier lanes
+  const uint64_t am = __ballot(active);
+  for (int i = 0; i < 64; i++) {
+    bool eq = true;
+#pragma unroll
+    for (int c = 0; c < 6; c++) eq = eq && (__shfl(t[c], i, 64) == t[c]);
+    if (unresolved && ((am >> i) & 1ull) && i < lane && eq) dup = true;
+  }
+  return dup;
+}
+
 template <typename K>
 __device__ __forceinline__ K shfl_key(K v, int src);
 template <>
