@@ -1518,9 +1518,10 @@ enum { CACT_ROWS = 0, CACT_INDEX = 1, CACT_HASH = 2, CACT_RESET = 3, CACT_HEUR =
 
 template <int ACT, bool TIMED, bool GT, bool STAB, bool MT>
 #ifndef PCT_CONT_WAVES
-#define PCT_CONT_WAVES 2 /* waves per SIMD the plain kernel is compiled for.  3 (168 VGPRs, 68 of them spilled to scratch) is
-                            as fast at 4096 envs (211.1 vs 211.7 us, C3) and 4.5 % faster at 8192, but its spill traffic makes
-                            162 MB of HBM traffic per launch out of 19.5 MB of algorithmic bytes; 2 (no spills): 37 MB */
+#define PCT_CONT_WAVES 3 /* waves per SIMD the plain kernel is compiled for.  C3's 14.2 KB of LDS admit 11 envs per CU, two waves
+                            per SIMD only 8.  Round 2: 3 (168 VGPRs, 68 of them spilled) was as fast as 2 at 4096 envs and its spills
+                            made 162 MB of HBM traffic per launch.  Round 4 (the kernel needs 217 VGPRs since the kernarg entry): 3
+                            spills 32 -- C3 26.8 -> 27.3 M env-steps/s, 34.2 -> 37.4 M at 8192 envs, C5 unchanged */
 #endif
 #ifndef PCT_STAB_WAVES
 #define PCT_STAB_WAVES 1 /* waves per SIMD the stability-check kernels are compiled for (2: 256 VGPRs, ~470 of them spilled -- slower, profiles/r03_stability_tuning.txt) */

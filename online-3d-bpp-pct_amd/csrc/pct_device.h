@@ -196,12 +196,13 @@ __device__ __forceinline__ void wave_priority(int n_ems, const int prio_t[3]) {
   else __builtin_amdgcn_s_setprio(0);
 }
 
-// Observation rows are written once and read by the NEXT kernel (the policy), never again by this one.  PCT_OBS_NT = 2 (default):
-// write-through stores (system scope: sc0 sc1), so that the 20 MB of fresh rows a launch leaves do not wait in the L2 as dirty
-// lines for the end-of-kernel release -- C2 64.4 -> 65.3 M env-steps/s (kernel 55.5 -> 54.6 us); 1: non-temporal stores
-// (measured: no gain); 0: plain stores.  profiles/r04_experiments.txt items 2 and 7.
+// Observation rows are written once and read by the NEXT kernel (the policy), never again by this one.  Two ways of keeping them
+// from waiting in the L2 as dirty lines for the end-of-kernel release were measured (profiles/r04_experiments.txt items 2, 7):
+// PCT_OBS_NT = 1, non-temporal stores: no gain; = 2, write-through stores (system scope: sc0 sc1): C2 +1.4 % env-steps/s, but
+// every 4-byte store becomes a partial-line write to memory -- HBM traffic 21.6 -> 71.2 MB per launch (1.11 x -> 3.65 x the
+// algorithmic bytes).  Default 0: plain stores.
 #ifndef PCT_OBS_NT
-#define PCT_OBS_NT 2
+#define PCT_OBS_NT 0
 #endif
 __device__ __forceinline__ void obs_st(float* q, float v) {
 #if PCT_OBS_NT == 2

@@ -230,7 +230,8 @@ int order_setup(pct_env* h) {
   lds = (lds + 511) & ~(size_t)511;
   const size_t lds_cu = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 160 * 1024;
   long per_cu = lds ? (long)(lds_cu / lds) : 64;
-  const long by_regs = stab ? 4 : 16; /* one-wave workgroups: the stability kernels run 1 wave per SIMD, the plain ones 4 */
+  /* one-wave workgroups: the stability kernels run 1 wave per SIMD, the plain discrete ones 4, the plain continuous ones 3 */
+  const long by_regs = stab ? 4 : (h->continuous ? 12 : 16);
   if (per_cu > by_regs) per_cu = by_regs;
   const long resident = per_cu * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
   const long N = h->continuous ? h->cp.N : h->dp.N;
