@@ -50,10 +50,11 @@ def main():
     ap.add_argument("--discrete-steps", type=int, default=1000000)
     ap.add_argument("--continuous-steps", type=int, default=200000)
     ap.add_argument("--seed0", type=int, default=100000)
+    ap.add_argument("--setting", type=int, default=1, choices=[1, 3], help="1: unit densities; 3: per-item densities (scripted)")
     a = ap.parse_args()
     # the C1 domain (configs[0]: setting 1, 10^3, items 1..5, 80 / 50) and the continuous setting-1 unit bin of c3s1
-    dcase = dict(setting=1, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, N=4, steps=2000, stream_T=4096, base=0)
-    ccase = dict(setting=1, container=(1, 1, 1), lo=0.1, hi=0.5, I=80, L=50, N=2, steps=1000, stream_T=4096, base=0,
+    dcase = dict(setting=a.setting, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, N=4, steps=2000, stream_T=4096, base=0)
+    ccase = dict(setting=a.setting, container=(1, 1, 1), lo=0.1, hi=0.5, I=80, L=50, N=2, steps=1000, stream_T=4096, base=0,
                  z_choice=True)
     jobs = []
     nd = -(-a.discrete_steps // (dcase["N"] * dcase["steps"]))
