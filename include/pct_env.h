@@ -113,9 +113,9 @@ extern "C" {
                                             the LAST BIT of a well-conditioned solve that decides an exactly degenerate
                                             point-in-polygon test (convex_hull.py:104-105) -- 15 of the 17 adversarial
                                             divergences and all 11 found in 1.2 M on-domain env-steps of discrete setting 1
-                                            (one step in 10^5; none in 0.24 M continuous steps) carry NO notice.  At those
-                                            steps the unmodified reference parts ways with itself when its NumPy runs on
-                                            other BLAS kernels (profiles/r04_lstsq_ondomain.txt) */
+                                            (one step in 10^5; none in 0.24 M continuous steps) carry NO notice.  In four of
+                                            ten such cases the unmodified reference parts ways with ITSELF at that step when
+                                            its NumPy runs on other BLAS kernels (profiles/r04_lstsq_ondomain.txt) */
 #define PCT_FLAG_DATASET_EXHAUSTED 0x20u /* LoadBoxCreator ran past its last trajectory: the
                                             reference raises IndexError at binCreator.py:58 */
 #define PCT_FLAG_BAD_ACTION 0x8u         /* malformed action: reference raises ValueError at

@@ -96,8 +96,8 @@ def main():
             n_self += any(x >= 0 for x in fd)
             print("    %-12s (OpenBLAS reports %s): leaves the native run at %s; oracle vs this run: %s" % (
                 core, ",".join(map(str, r["arch"])), fd, r["vs_oracle"]))
-    print("=> %d of %d (chunk, core type) re-runs of the UNMODIFIED reference leave its own native-kernel trajectory" % (
-        n_self, len(div) * (len(CORES) - 1)))
+    print("=> %d of %d (chunk, core type) re-runs of the UNMODIFIED reference leave its own native-kernel trajectory (SKYLAKEX is the "
+          "native choice of the build container: those re-runs are controls)" % (n_self, len(div) * (len(CORES) - 1)))
 
 
 if __name__ == "__main__":
