@@ -288,8 +288,10 @@ int pct_bind_policy_rows(pct_env* env, float* rows_out);
 /* When enabled, the transition kernel of every launch (reset / step_*) carries a pair of hipEvents that bracket
  * exactly that dispatch (hipExtLaunchKernel start / stop events: the kernel's own begin and end timestamps, no marker
  * packets on the stream) -- the step kernel itself, not the small large-capacity retry pass that follows it.
- * pct_profile_read synchronises on the recorded events, returns the number of launches and their summed duration
- * since the last read, and clears the accumulator. */
+ * pct_profile_read synchronises on the recorded events, returns the number of TIMED launches and their summed duration
+ * since the last read, and clears the accumulator.  `on` = K > 1: only every K-th launch carries a pair (a dispatch with
+ * events costs ~7 us of its own on ROCm 7.2 / MI355X: time every launch when single launches matter, sample when the
+ * average does). */
 int pct_profile_enable(pct_env* env, int32_t on);
 int pct_profile_read(pct_env* env, int64_t* n_launches, double* total_ms);
 

@@ -464,7 +464,8 @@ class PctVecEnv(VecEnv):
         self.waiting_step = True
 
     def profile_enable(self, on=True):
-        _lib.check(self._L.pct_profile_enable(self._h, int(bool(on))))
+        """True / 1: every transition launch carries the HIP event pair; K > 1: every K-th one; False: none."""
+        _lib.check(self._L.pct_profile_enable(self._h, int(on)))
 
     def profile_read(self):
         """(launches, total_ms) of the transition kernels since the last read (HIP events
