@@ -34,7 +34,8 @@ class PctConfig(ctypes.Structure):
 
 def build(force=False):
     so = os.path.join(_HERE, "libpct_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("pct_oracle.c", "pct_oracle_cont.c", "pct_oracle_stab.c", "pct_oracle.h", "pct_oracle_internal.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("pct_oracle.c", "pct_oracle_cont.c", "pct_oracle_stab.c", "pct_oracle_gelsd.c", "pct_oracle.h",
+                                               "pct_oracle_internal.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "pct_env.h"))
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libpct_oracle.so"])
@@ -72,8 +73,42 @@ def lib():
         L.pcto_debug_state.argtypes = [vp, ctypes.c_int32, vp, vp, ctypes.c_int32, vp, vp, vp, vp]
         L.pcto_pyset_order.argtypes = [vp, ctypes.c_int32, vp]
         L.pcto_set_num_threads.argtypes = [ctypes.c_int]
+        L.pcto_set_lstsq_mode.argtypes = [ctypes.c_int]
+        L.pcto_get_lstsq_mode.restype = ctypes.c_int
+        L.gelsd_lstsq.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]
+        L.gelsd_lstsq.restype = ctypes.c_int
+        if os.environ.get("PCT_ORACLE_LSTSQ", "") == "gelsd":
+            L.pcto_set_lstsq_mode(1)
         _LIB = L
     return _LIB
+
+
+LSTSQ_JACOBI, LSTSQ_GELSD = 0, 1
+
+
+def set_lstsq_mode(mode):
+    """Process-wide solver behind np.linalg.lstsq in the oracle's stability check: LSTSQ_JACOBI (default, what the kernels run by
+    default) or LSTSQ_GELSD (LAPACK dgelsd as the reference's NumPy executes it, oracle/pct_oracle_gelsd.c).  Returns the old mode."""
+    old = lib().pcto_get_lstsq_mode()
+    lib().pcto_set_lstsq_mode(int(mode))
+    return old
+
+
+def gelsd_lstsq(a, b):
+    """np.linalg.lstsq(a, b, rcond=None) through oracle/pct_oracle_gelsd.c -> (x, rank, singular values, near_cut)"""
+    import numpy as np
+    a = np.ascontiguousarray(a, np.float64)
+    b = np.ascontiguousarray(np.asarray(b, np.float64).ravel())
+    m, n = a.shape
+    x = np.zeros(n)
+    sv = np.zeros(n)
+    rank = ctypes.c_int(0)
+    near = ctypes.c_int(0)
+    info = lib().gelsd_lstsq(a.ctypes.data, b.ctypes.data, m, n, x.ctypes.data, ctypes.addressof(rank), sv.ctypes.data,
+                             ctypes.addressof(near))
+    if info:
+        raise RuntimeError("dbdsqr did not converge")
+    return x, rank.value, sv, bool(near.value)
 
 
 def _np_view(ptr, shape, dtype):

@@ -1035,6 +1035,9 @@ int32_t* pcto_info_counter(pcto_env* h) { return h->counter; }
 double* pcto_info_ratio(pcto_env* h) { return h->ratio; }
 uint32_t* pcto_error_flags(pcto_env* h) { return h->flags; }
 void pcto_set_ill_near(int on) { stab_set_ill_near(on); } /* analysis mode of the notice, see pct_oracle_stab.c */
+/* process-wide: which solver stands behind np.linalg.lstsq in the stability check (pct_oracle_stab.c / pct_oracle_gelsd.c) */
+void pcto_set_lstsq_mode(int mode) { stab_set_lstsq_mode(mode); }
+int pcto_get_lstsq_mode(void) { return stab_get_lstsq_mode(); }
 /* out[e] = 1 iff env e has taken an ill-conditioned least-squares split so far (the product's PCT_FLAG_ILL_CONDITIONED) */
 int pcto_ill_conditioned(pcto_env* h, uint8_t* out) {
   if (!h || !out) return fail(PCT_ERR_INVALID_ARG, "null argument");

@@ -51,6 +51,13 @@ uint8_t* pcto_done(pcto_env* env);    /* [N] */
 int32_t* pcto_info_counter(pcto_env* env);
 double* pcto_info_ratio(pcto_env* env);
 uint32_t* pcto_error_flags(pcto_env* env);
+/* np.linalg.lstsq of the stability check (settings 1 / 3), process-wide.  0 (default): the one-sided Jacobi SVD that the kernels
+ * run by default (pct_set_lstsq_mode(env, PCT_LSTSQ_JACOBI)); 1: LAPACK dgelsd operation for operation as the reference's NumPy
+ * (2.2.6, OpenBLAS 0.3.29, AVX-512 kernel set) executes it -- pct_oracle_gelsd.c; the kernels' PCT_LSTSQ_GELSD */
+void pcto_set_lstsq_mode(int mode);
+int pcto_get_lstsq_mode(void);
+/* the solve itself, for tests: row-major M x N system -> x[N], singular values sv[N], rank; returns dbdsqr's info */
+int gelsd_lstsq(const double* A, const double* b, int M, int N, double* x, int* rank, double* sv, int* near_cut);
 void pcto_set_ill_near(int on); /* analysis only: also note decisions within 1e-9 of a tie on stacks carrying a least-squares share */
 int pcto_ill_conditioned(pcto_env* env, uint8_t* out); /* [N] sticky notice of the stability settings (PCT_FLAG_ILL_CONDITIONED) */
 

@@ -131,6 +131,10 @@ void stab_reset(struct stab* s);
 void stab_free(struct stab* s);
 int stab_ill_conditioned(const struct stab* s); /* sticky notice, see pct_oracle_stab.c */
 void stab_set_ill_near(int on);
+void stab_set_lstsq_mode(int mode); /* 0: Jacobi stand-in (default), 1: dgelsd as NumPy's OpenBLAS executes it */
+int stab_get_lstsq_mode(void);
+/* pct_oracle_gelsd.c */
+int gelsd_lstsq(const double* Arow, const double* brow, int M, int N, double* x, int* rank_out, double* sv_out, int* near_cut);
 int stab_check(struct stab* s, double x, double y, double z, double lx, double ly, double max_h, double density,
                int virtual_);
 

@@ -205,7 +205,20 @@ static int point_in_polygon(const double pt[2], double (*co)[2], int n) {
  * NumPy's default rcond = eps * max(M, N).  Working on A (not on A^T A) keeps the small singular values accurate
  * to eps * sigma_max, as dgelsd does -- the normal-equations form loses everything below sqrt(eps) * sigma_max
  * and then disagrees with LAPACK by up to 5e-3 on the nearly rank-deficient systems this check produces. */
+static int g_lstsq_mode = 0; /* 0: the Jacobi stand-in below (what the kernels run by default), 1: LAPACK dgelsd as the
+                                reference's NumPy executes it (pct_oracle_gelsd.c) */
+void stab_set_lstsq_mode(int mode) { g_lstsq_mode = mode; }
+int stab_get_lstsq_mode(void) { return g_lstsq_mode; }
 static void lstsq_min_norm(const double* A, const double* b, int M, int N, double* x) {
+  if (g_lstsq_mode == 1) {
+    double sv[64];
+    int near_cut = 0;
+    if (N <= 64 && gelsd_lstsq(A, b, M, N, x, NULL, sv, &near_cut) == 0) {
+      if (near_cut) g_ill = 1;
+      return;
+    }
+    g_ill = 1; /* (more than 64 supporters, or no convergence: NumPy would raise) -- the stand-in takes over */
+  }
   double* U = (double*)malloc(sizeof(double) * (size_t)M * N);
   double* V = (double*)malloc(sizeof(double) * (size_t)N * N);
   double* s2 = (double*)malloc(sizeof(double) * (size_t)N);

@@ -25,6 +25,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 def chunk(job):
     import gen_golden as g
     kind, case = job
+    from oracle import oracle_lib
+    oracle_lib.set_lstsq_mode(oracle_lib.LSTSQ_GELSD if case.pop("lstsq", "jacobi") == "gelsd" else oracle_lib.LSTSQ_JACOBI)
     g.LSTSQ["calls"] = 0
     if kind == "discrete":
         ref = g.run_reference(case)
@@ -51,6 +53,9 @@ def main():
     ap.add_argument("--continuous-steps", type=int, default=200000)
     ap.add_argument("--seed0", type=int, default=100000)
     ap.add_argument("--setting", type=int, default=1, choices=[1, 3], help="1: unit densities; 3: per-item densities (scripted)")
+    ap.add_argument("--lstsq", default="jacobi", choices=["jacobi", "gelsd"],
+                    help="the oracle's solver: the Jacobi stand-in (the kernels' default) or the dgelsd restatement (pct_oracle_gelsd.c)")
+    ap.add_argument("--only-discrete-seeds", default="", help="comma-separated chunk seeds: run just these discrete chunks")
     a = ap.parse_args()
     # the C1 domain (configs[0]: setting 1, 10^3, items 1..5, 80 / 50) and the continuous setting-1 unit bin of c3s1
     dcase = dict(setting=a.setting, container=(10, 10, 10), lo=1, hi=5, I=80, L=50, N=4, steps=2000, stream_T=4096, base=0)
@@ -61,11 +66,16 @@ def main():
     nc = -(-a.continuous_steps // (ccase["N"] * ccase["steps"]))
     for i in range(max(nd, nc)):  # interleaved, so that a partial log covers both domains
         if i < nd:
-            jobs.append(("discrete", dict(dcase, seed=a.seed0 + i, base=7 * i)))
+            jobs.append(("discrete", dict(dcase, seed=a.seed0 + i, base=7 * i, lstsq=a.lstsq)))
         if i < nc:
-            jobs.append(("continuous", dict(ccase, seed=a.seed0 + 50000 + i, base=11 * i)))
+            jobs.append(("continuous", dict(ccase, seed=a.seed0 + 50000 + i, base=11 * i, lstsq=a.lstsq)))
+    if a.only_discrete_seeds:
+        only = [int(x) for x in a.only_discrete_seeds.split(",")]
+        jobs = [("discrete", dict(dcase, seed=sd, base=7 * (sd - a.seed0), lstsq=a.lstsq)) for sd in only]
+        nd, nc = len(jobs), 0
     print("On-domain sample of the least-squares stand-in: unmodified reference (np.linalg.lstsq = LAPACK dgelsd) vs the C oracle")
-    print("(one-sided Jacobi SVD), same scripted item streams, stand-in policy, every observation / reward / done / counter / ratio compared.")
+    print("(%s), same scripted item streams, stand-in policy, every observation / reward / done / counter / ratio compared."
+          % ("one-sided Jacobi SVD" if a.lstsq == "jacobi" else "--lstsq gelsd: oracle/pct_oracle_gelsd.c, dgelsd operation for operation"))
     print("discrete: %s\ncontinuous: %s" % (dcase, ccase))
     print("%d + %d chunks on %d processes" % (nd, nc, a.procs), flush=True)
     tot = {k: dict(steps=0, calls=0, runs=0, div=0, episodes=0, same=0) for k in ("discrete", "continuous")}
