@@ -1,0 +1,98 @@
+"""oracle/pct_oracle_gelsd.c -- np.linalg.lstsq as the reference's NumPy executes it (LAPACK dgelsd, operation for operation).
+
+The reference solves the >= 3-supporter split of the stability check with np.linalg.lstsq (D/space.py:152,249; C/space.py:148,245).
+tests/golden/check_gelsd_port.py pins the restatement to the live library routine by routine in the build container; here, on any
+machine: the committed vectors (tests/golden/lstsq_systems.npz: systems recorded from reference runs and constructed ones, with
+NumPy's solution / rank / singular values), and the reference fixtures through the oracle in gelsd mode -- including the adversarial
+stream on which the Jacobi stand-in parts ways with the reference (discrete_s1_flat_diverging)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle_lib
+from oracle.oracle_lib import OracleVecEnv
+from tests.common import case_items, load_case
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture
+def gelsd_mode():
+    old = oracle_lib.set_lstsq_mode(oracle_lib.LSTSQ_GELSD)
+    yield
+    oracle_lib.set_lstsq_mode(old)
+
+
+def _systems():
+    z = np.load(os.path.join(HERE, "golden", "lstsq_systems.npz"))
+    off = 0
+    for i in range(len(z["M"])):
+        m, n = int(z["M"][i]), int(z["N"][i])
+        a = z["A"][off:off + m * n].reshape(m, n)
+        off += m * n
+        b = np.zeros(m)
+        b[-1] = 1.0
+        yield a, b, z["x"][i, :n], int(z["rank"][i]), z["sv"][i, :n]
+
+
+def test_gelsd_port_reproduces_numpy_bit_for_bit():
+    """x, the effective rank and the singular values of every committed system: identical to what NumPy 2.2.6 (OpenBLAS 0.3.29,
+    AVX-512 kernel set) returned in the build container -- 3 .. 16 supporters, rank-deficient systems included"""
+    n = deficient = 0
+    sizes = set()
+    for a, b, x, rank, sv in _systems():
+        x2, rank2, sv2, _ = oracle_lib.gelsd_lstsq(a, b)
+        assert np.array_equal(x, x2), (n, a.shape)
+        assert rank == rank2 and np.array_equal(sv, sv2), (n, a.shape)
+        n += 1
+        deficient += rank < a.shape[1]
+        sizes.add(a.shape[1])
+    assert n > 1000 and deficient > 0 and {3, 4, 5, 6, 8, 16} <= sizes
+
+
+def test_gelsd_port_is_a_least_squares_solution():
+    """independent of the recorded vectors: the normal equations hold and the solution is the minimum-norm one (checked
+    against NumPy's solver of whatever machine this runs on, to 1e-9 -- the last bits are the machine's)"""
+    for i, (a, b, _, rank, _) in enumerate(_systems()):
+        if i % 7:
+            continue
+        x2, rank2, sv2, _ = oracle_lib.gelsd_lstsq(a, b)
+        want = np.linalg.lstsq(a, b, rcond=None)
+        if int(want[2]) == rank:  # (a rank decision at the cut may fall differently on another machine)
+            assert np.allclose(x2, want[0], rtol=1e-7, atol=1e-9 * max(1.0, np.abs(want[0]).max())), i
+
+
+@pytest.mark.parametrize("name", ["discrete_s1_flat_lstsq", "discrete_s3_flat_lstsq", "discrete_s1_flat20"])
+def test_oracle_gelsd_mode_matches_reference_fixtures(name, gelsd_mode):
+    """the adversarial flat-item fixtures (thousands of least-squares splits, up to eight supporters): unmodified reference ==
+    oracle in gelsd mode, every observation / reward / done"""
+    c, z = load_case(name)
+    env = OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"], item_set=case_items(c),
+                       internal_node_holder=c["I"], leaf_node_holder=c["L"], env_id_base=c["base"])
+    env.set_item_stream(z["stream"])
+    if "density" in z:
+        env.set_density_stream(z["density"])
+    env.reset()
+    for t in range(c["steps"]):
+        assert np.array_equal(env.obs.astype(np.float32), z["obs"][t]), t
+        env.step_hash_policy(1)
+        assert np.array_equal(env.reward, z["reward"][t]) and np.array_equal(env.done, z["done"][t]), t
+    env.close()
+
+
+def test_oracle_gelsd_mode_follows_the_reference_through_the_rank_cut(gelsd_mode):
+    """discrete_s1_flat_diverging: the unmodified reference on the stream whose env 0 meets a rank decision 1.97 x above the rcond
+    cut at step 79 -- the Jacobi stand-in parts ways there (test_oracle_notice_precedes_the_lapack_divergence); with dgelsd
+    restated the oracle IS the reference on all four envs over the whole recording"""
+    c, z = load_case("discrete_s1_flat_diverging")
+    env = OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"], item_set=case_items(c),
+                       internal_node_holder=c["I"], leaf_node_holder=c["L"], env_id_base=c["base"])
+    env.set_item_stream(z["stream"])
+    env.reset()
+    for t in range(c["steps"]):
+        assert np.array_equal(env.obs.astype(np.float32), z["obs"][t]), t
+        env.step_hash_policy(1)
+    assert np.array_equal(env.obs.astype(np.float32), z["obs"][c["steps"]])
+    assert env.ill_conditioned()[0]  # the notice is still raised: a singular value within 1e3 of the cut
+    env.close()
