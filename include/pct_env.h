@@ -115,7 +115,9 @@ extern "C" {
                                             divergences and all 11 found in 1.2 M on-domain env-steps of discrete setting 1
                                             (one step in 10^5; none in 0.24 M continuous steps) carry NO notice.  In four of
                                             ten such cases the unmodified reference parts ways with ITSELF at that step when
-                                            its NumPy runs on other BLAS kernels (profiles/r04_lstsq_ondomain.txt) */
+                                            its NumPy runs on other BLAS kernels (profiles/r04_lstsq_ondomain.txt).
+                                            pct_set_lstsq_mode(env, PCT_LSTSQ_GELSD) removes both kinds: the split is then
+                                            solved exactly as the reference's NumPy solves it (the notice is still raised) */
 #define PCT_FLAG_DATASET_EXHAUSTED 0x20u /* LoadBoxCreator ran past its last trajectory: the
                                             reference raises IndexError at binCreator.py:58 */
 #define PCT_FLAG_BAD_ACTION 0x8u         /* malformed action: reference raises ValueError at
@@ -228,6 +230,27 @@ int pct_set_numpy_item_count(pct_env* env, int32_t n);
 
 /* Seed of the shuffle permutation (default 0). */
 int pct_set_shuffle_seed(pct_env* env, uint64_t seed);
+
+/* Which solver stands behind np.linalg.lstsq in the stability check (settings 1 / 3: a stack split over three and more
+ * supporters none of which holds its centre of mass, D/space.py:134-163, :236-259; C/space.py:130-159, :232-255).
+ *   PCT_LSTSQ_JACOBI (default): a one-sided Jacobi SVD -- the same minimum-norm solution as the reference's, equal to it up to
+ *     the last bits; on the reference's own item domain one env-run in 55 (2000 steps each) parts ways with the reference
+ *     through such a bit (see PCT_FLAG_ILL_CONDITIONED).
+ *   PCT_LSTSQ_GELSD: LAPACK dgelsd operation for operation AS THE REFERENCE'S NUMPY EXECUTES IT (NumPy 2.2.6 = OpenBLAS 0.3.29 /
+ *     LAPACK 3.11 with the kernel set OpenBLAS selects on AVX-512 hosts: dgeqr2, dgebd2, dbdsqr ..., the fused / split sums of
+ *     its dgemv / dger / drot kernels and the 80-bit x87 dnrm2; csrc/pct_gelsd.cuh).  Bit-identical solutions: the 13 on-domain
+ *     and 17 adversarial env-runs that part ways under PCT_LSTSQ_JACOBI follow the reference to the end
+ *     (profiles/r04_gelsd_port.txt).  One lane solves a system, so a step that holds such a split is slower.
+ *   PCT_LSTSQ_GELSD_AVX2: the same with the kernel set OpenBLAS selects on AVX2 hosts ("Haswell": Intel Haswell .. , AMD Zen) -- its
+ *     dgemv 'N', daxpy and dgemm kernels sum differently, np.linalg.lstsq then returns other last bits on 98 % of these systems,
+ *     and a reference run on such a host follows another trajectory at a tie (about one step in 10^5 on the discrete env).  Choose the
+ *     flavour of the machine the reference ran on.
+ * Callable at any time between steps; applies to the normal and the retry pass.  Replaces nothing in the reference's
+ * interface: it names the LAPACK the reference inherits from its NumPy wheel. */
+#define PCT_LSTSQ_JACOBI 0
+#define PCT_LSTSQ_GELSD 1
+#define PCT_LSTSQ_GELSD_AVX2 2
+int pct_set_lstsq_mode(pct_env* env, int32_t mode);
 
 /* ---- outputs ------------------------------------------------------------------------ */
 /* Bind caller-owned device buffers (e.g. torch tensors).  Any pointer may be NULL to keep

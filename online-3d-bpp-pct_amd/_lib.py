@@ -20,13 +20,14 @@ LNES_EMS, LNES_EV, LNES_EP, LNES_CP, LNES_FC = 0, 1, 2, 3, 4
 FLAG_INTERNAL_OVERFLOW, FLAG_EMS_OVERFLOW, FLAG_CANDIDATE_OVERFLOW, FLAG_BAD_ACTION = 1, 2, 4, 8
 FLAG_STABILITY_OVERFLOW, FLAG_DATASET_EXHAUSTED = 16, 32
 FLAG_ILL_CONDITIONED = 64  # non-fatal notice (include/pct_env.h)
+LSTSQ_JACOBI, LSTSQ_GELSD, LSTSQ_GELSD_AVX2 = 0, 1, 2  # pct_set_lstsq_mode
 FLAG_ERROR_MASK = 0xFFFFFFFF & ~FLAG_ILL_CONDITIONED
 
 # every symbol include/pct_env.h declares
 ABI_SYMBOLS = [
     "pct_abi_version", "pct_last_error", "pct_create", "pct_destroy", "pct_set_item_set",
     "pct_set_sample_bounds", "pct_set_item_stream", "pct_set_item_dataset", "pct_set_sampler", "pct_set_numpy_rng", "pct_set_numpy_item_count",
-    "pct_set_shuffle_seed",
+    "pct_set_shuffle_seed", "pct_set_lstsq_mode",
     "pct_set_density_stream", "pct_set_dataset_density", "pct_bind_outputs", "pct_bind_rollout_slot", "pct_obs",
     "pct_reward", "pct_done", "pct_info_counter", "pct_info_ratio", "pct_error_flags", "pct_obs_row_len",
     "pct_reset", "pct_step_rows", "pct_step_index", "pct_step_hash_policy", "pct_step_heuristic", "pct_debug_state",
@@ -80,6 +81,7 @@ def load():
     L.pct_set_numpy_rng.argtypes = [vp, ctypes.c_uint32]
     L.pct_set_numpy_item_count.argtypes = [vp, ctypes.c_int32]
     L.pct_set_shuffle_seed.argtypes = [vp, u64]
+    L.pct_set_lstsq_mode.argtypes = [vp, i32]
     L.pct_step_heuristic.argtypes = [vp, i32, i32, vp]
     L.pct_set_density_stream.argtypes = [vp, vp, i64]
     L.pct_set_dataset_density.argtypes = [vp, vp]

@@ -15,7 +15,7 @@ LIB = os.path.join(HERE, "libpct_hip.so")
 SOURCES = ["pct_discrete_stab.hip", "pct_discrete_stab_mt.hip", "pct_discrete_u64_stab.hip", "pct_discrete_u64_stab_mt.hip",
            "pct_continuous.hip", "pct_continuous_mt.hip", "pct_discrete.hip", "pct_discrete_mt.hip", "pct_discrete_u64.hip",
            "pct_discrete_u64_mt.hip", "pct_env.hip"]
-HEADERS = [os.path.join(CSRC, "pct_device.h"), os.path.join(CSRC, "pct_set.cuh"), os.path.join(CSRC, "pct_stab.cuh"),
+HEADERS = [os.path.join(CSRC, "pct_device.h"), os.path.join(CSRC, "pct_set.cuh"), os.path.join(CSRC, "pct_stab.cuh"), os.path.join(CSRC, "pct_gelsd.cuh"),
            os.path.join(CSRC, "pct_discrete_impl.cuh"), os.path.join(CSRC, "pct_mt.cuh"),
            os.path.join(HERE, "..", "include", "pct_env.h")]
 
@@ -27,14 +27,14 @@ def _hipcc():
     raise RuntimeError("hipcc not found: cannot build the gfx950 library")
 
 
-_IMPL = ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_mt.cuh", "pct_discrete_impl.cuh"]
+_IMPL = ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_gelsd.cuh", "pct_mt.cuh", "pct_discrete_impl.cuh"]
 # which headers a translation unit includes (a change elsewhere does not recompile it)
-DEPS = {"pct_env.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh"],
+DEPS = {"pct_env.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_gelsd.cuh"],
         "pct_discrete.hip": _IMPL, "pct_discrete_stab.hip": _IMPL, "pct_discrete_u64.hip": _IMPL, "pct_discrete_u64_stab.hip": _IMPL,
         "pct_discrete_mt.hip": _IMPL, "pct_discrete_stab_mt.hip": _IMPL, "pct_discrete_u64_mt.hip": _IMPL,
         "pct_discrete_u64_stab_mt.hip": _IMPL,
-        "pct_continuous.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_mt.cuh"],
-        "pct_continuous_mt.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_mt.cuh", "pct_continuous.hip"]}
+        "pct_continuous.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_gelsd.cuh", "pct_mt.cuh"],
+        "pct_continuous_mt.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_gelsd.cuh", "pct_mt.cuh", "pct_continuous.hip"]}
 
 
 def _tu_inputs(src):

@@ -344,6 +344,8 @@ void stab_default_caps(int I, pct::StabCaps& normal, pct::StabCaps& retry) {
   normal.queue = 96;
   /* least-squares splits over up to 8 supporters in the normal pass (3.3 KB of LDS: one system of 7 / 8 supporters or two of 6 at
    * a time), up to 16 in the retry pass (four / two systems of the small classes side by side) */
+  normal.gelsd = 0; /* pct_set_lstsq_mode */
+  retry.gelsd = 0;
   normal.lsq_n = 8;
   normal.lsq_bytes = (int)pct::stab_lsq_bytes(normal.lsq_n, false);
   retry.lsq_n = pct::STAB_LSQ;
@@ -873,6 +875,24 @@ int pct_set_shuffle_seed(pct_env* h, uint64_t seed) {
   h->dp.shuffle_seed = seed;
   h->cp.shuffle_seed = seed;
   h->cp_retry.shuffle_seed = seed;
+  return PCT_OK;
+}
+
+int pct_set_lstsq_mode(pct_env* h, int32_t mode) {
+  if (!h) return fail(PCT_ERR_INVALID_ARG, "null handle");
+  if (mode != PCT_LSTSQ_JACOBI && mode != PCT_LSTSQ_GELSD && mode != PCT_LSTSQ_GELSD_AVX2)
+    return fail(PCT_ERR_INVALID_ARG, "lstsq mode: PCT_LSTSQ_JACOBI, PCT_LSTSQ_GELSD or PCT_LSTSQ_GELSD_AVX2");
+  if (h->cfg.setting == 2) return PCT_OK; /* no stability check: nothing to select */
+  /* a launch's workspace is sized for one Jacobi system of its largest class; the dgelsd workspace of that class must fit it */
+  const pct::StabCaps* all[] = {&h->dp.sb.caps, &h->cp.sb.caps, &h->cp_retry.sb.caps, &h->d_retry_stab};
+  if (mode != PCT_LSTSQ_JACOBI)
+    for (const pct::StabCaps* c : all)
+      if (c->lsq_n > 0 && sizeof(double) * pct::stab_lsq_slot_doubles(c->lsq_n, true) > (size_t)c->lsq_bytes)
+        return fail(PCT_ERR_UNSUPPORTED, "the least-squares workspace of this handle does not hold a dgelsd system");
+  h->dp.sb.caps.gelsd = mode;
+  h->cp.sb.caps.gelsd = mode;
+  h->cp_retry.sb.caps.gelsd = mode;
+  h->d_retry_stab.gelsd = mode;
   return PCT_OK;
 }
 

@@ -1,0 +1,851 @@
+// pct_gelsd.cuh -- np.linalg.lstsq of the stability check, as the reference's NumPy executes it (PCT_LSTSQ_GELSD).
+//
+// The reference splits a stack over >= 3 supporters (none of them "direct") with np.linalg.lstsq(coefficient, value, rcond=None):
+// D/space.py:134-163, :236-259; C/space.py:130-159, :232-255.  That is LAPACK dgelsd inside the OpenBLAS of the NumPy wheel; the
+// default solver of the kernels (a one-sided Jacobi SVD, pct_stab.cuh) returns the same minimum-norm solution up to the last
+// bits, and a last bit decides an exactly degenerate test downstream in about one on-domain env-run out of 55
+// (profiles/r04_lstsq_ondomain.txt).  This file is the strict alternative: the path dgelsd takes for these systems
+// (M = k (k - 1) / 2 + 1 rows, k <= 16 columns, one right-hand side), operation for operation --
+//   dgeqr2, dorm2r (Q^T b), dgebd2, dorm2r, dlalsd (scale, dlasdq = dbdsqr with vectors + sort, rank cut, V (.)), dorml2 --
+// with the arithmetic of the BLAS kernels OpenBLAS 0.3.29 dispatches to on AVX-512 hosts (NumPy 2.2.6's bundled library in
+// the build container; PCT_LSTSQ_GELSD) or on AVX2 hosts, AMD Zen included (its "Haswell" kernel set; PCT_LSTSQ_GELSD_AVX2 --
+// dgemv 'N', daxpy and the dgemm kernel differ): which products are fused, how many lanes a sum is split over, and dnrm2's
+// 80-bit x87 accumulation, emulated here with 64-bit integer mantissas.  Plain IEEE double operations otherwise (the library is built with
+// -ffp-contract=off; fma() is v_fma_f64 / the C fma, division and sqrt are correctly rounded on both sides).
+// The routines are written for one lane working on a workspace in LDS (no private arrays, no calls); tests/host compiles them
+// for the CPU, where tests/test_stab_host.py checks them against the recorded NumPy vectors and the reference fixtures.
+#ifndef PCT_GELSD_CUH
+#define PCT_GELSD_CUH
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define PCT_GD __device__ __forceinline__
+#define PCT_GNOUNROLL _Pragma("nounroll")
+#else
+#define PCT_GD static inline
+#define PCT_GNOUNROLL
+#endif
+// Every routine is inlined into the kernels (no calls inside a kernel, build.py), so each CALL SITE costs the routine's whole body:
+// the drivers below are written as loops over "which vector / which target" with ONE site per routine where that is possible
+// (PCT_GNOUNROLL keeps the compiler from undoing it).
+
+namespace pct {
+namespace gelsd {
+
+// ---- 80-bit extended precision (x87, round to nearest even, 64-bit mantissa), non-negative values only -----------------------
+// value = m * 2^e with 2^63 <= m < 2^64, or m == 0
+struct Ext { uint64_t m; int e; };
+
+PCT_GD uint64_t mulhi64(uint64_t a, uint64_t b) {
+#if defined(__HIPCC__)
+  return __umul64hi(a, b);
+#else
+  return (uint64_t)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+PCT_GD int clz64(uint64_t v) {
+#if defined(__HIPCC__)
+  return __clzll((long long)v);
+#else
+  return __builtin_clzll(v);
+#endif
+}
+// (hi, lo) with hi's top bit set, `sticky`: non-zero bits below lo -> m rounded to nearest even (carry into the exponent)
+PCT_GD Ext ext_round(uint64_t hi, uint64_t lo, bool sticky, int e) {
+  const bool rnd = (lo >> 63) != 0;
+  const bool rest = (lo << 1) != 0 || sticky;
+  Ext r;
+  r.m = hi;
+  r.e = e;
+  if (rnd && (rest || (hi & 1ull))) {
+    r.m = hi + 1;
+    if (r.m == 0) { r.m = 1ull << 63; r.e = e + 1; }
+  }
+  return r;
+}
+// fld + fmul st(0): the square of a double, rounded to 64 bits
+PCT_GD Ext ext_square(double v) {
+  Ext z;
+  z.m = 0; z.e = 0;
+  uint64_t bits;
+  {
+    union { double d; uint64_t u; } cv;
+    cv.d = v;
+    bits = cv.u;
+  }
+  const int ex = (int)((bits >> 52) & 0x7FF);
+  uint64_t f = bits & 0xFFFFFFFFFFFFFull;
+  int q;
+  if (ex == 0) {
+    if (f == 0) return z;
+    q = -1074;
+  } else {
+    f |= 1ull << 52;
+    q = ex - 1075;
+  }
+  const int s = clz64(f);
+  const uint64_t g = f << s;  // v = g * 2^(q - s), 2^63 <= g
+  uint64_t hi = mulhi64(g, g), lo = g * g;
+  int e = 2 * (q - s) + 64;
+  if (!(hi >> 63)) {  // the product lies in [2^126, 2^127)
+    hi = (hi << 1) | (lo >> 63);
+    lo <<= 1;
+    e -= 1;
+  }
+  return ext_round(hi, lo, false, e);
+}
+// faddp of two non-negative values
+PCT_GD Ext ext_add(Ext x, Ext y) {
+  if (y.m == 0) return x;
+  if (x.m == 0) return y;
+  if (x.e < y.e || (x.e == y.e && x.m < y.m)) { const Ext t = x; x = y; y = t; }
+  const int d = x.e - y.e;
+  if (d > 65) return x;  // y is below a quarter of x's last place
+  // X = x.m : 0, Y = (y.m : 0) >> d
+  uint64_t yh, yl;
+  bool sticky = false;
+  if (d == 0) { yh = y.m; yl = 0; }
+  else if (d < 64) { yh = y.m >> d; yl = y.m << (64 - d); }
+  else if (d == 64) { yh = 0; yl = y.m; }
+  else { yh = 0; yl = y.m >> 1; sticky = (y.m & 1ull) != 0; }
+  uint64_t hi = x.m + yh, lo = yl;
+  int e = x.e;
+  if (hi < x.m) {  // carry out of bit 127: one place down
+    sticky = sticky || (lo & 1ull);
+    lo = (lo >> 1) | (hi << 63);
+    hi = (hi >> 1) | (1ull << 63);
+    e += 1;
+  }
+  return ext_round(hi, lo, sticky, e);
+}
+// fsqrt, then fstp qword: the square root rounded to 64 bits, then to a double
+PCT_GD double ext_sqrt_to_double(Ext x) {
+  if (x.m == 0) return 0.0;
+  // N = x.m << 64 (exponent e - 64) or x.m << 63 (exponent e - 63), whichever exponent is even; root = isqrt(N), 2^63 <= root
+  uint64_t nh, nl;
+  int e2;
+  if (((x.e - 64) & 1) == 0) { nh = x.m; nl = 0; e2 = x.e - 64; }
+  else { nh = x.m >> 1; nl = x.m << 63; e2 = x.e - 63; }
+  uint64_t root = 0, rh = 0, rl = 0;  // remainder (rh : rl), at most 65 bits
+  for (int i = 0; i < 64; i++) {
+    // rem = (rem << 2) | top two bits of N;  N <<= 2
+    rh = (rh << 2) | (rl >> 62);
+    rl = (rl << 2) | (nh >> 62);
+    nh = (nh << 2) | (nl >> 62);
+    nl <<= 2;
+    // trial = (root << 2) | 1  (root holds the bits found so far)
+    const uint64_t th = root >> 62, tl = (root << 2) | 1ull;
+    root <<= 1;
+    if (rh > th || (rh == th && rl >= tl)) {
+      const uint64_t b = rl < tl ? 1ull : 0ull;
+      rl -= tl;
+      rh = rh - th - b;
+      root |= 1ull;
+    }
+  }
+  // round to nearest: up iff N - root^2 > root (a tie cannot occur)
+  int e = e2 / 2;
+  uint64_t m = root;
+  if (rh != 0 || rl > root) {
+    m = root + 1;
+    if (m == 0) { m = 1ull << 63; e += 1; }
+  }
+  // to double: 64 -> 53 bits, nearest even
+  uint64_t f = m >> 11;
+  const uint64_t low = m & 0x7FFull;
+  if (low > 0x400ull || (low == 0x400ull && (f & 1ull))) f += 1;
+  int ex = e + 63 + 1023;
+  if (f >> 53) { f >>= 1; ex += 1; }
+  if (ex <= 0) return 0.0;  // (far below anything a stability system holds)
+  if (ex >= 2047) return INFINITY;
+  union { double d; uint64_t u; } cv;
+  cv.u = ((uint64_t)ex << 52) | (f & 0xFFFFFFFFFFFFFull);
+  return cv.d;
+}
+
+// ---- BLAS, as OpenBLAS' SkylakeX kernel set computes it (kernel/x86_64: nrm2.S, dgemv_t_4.c + Haswell microkernels,
+// dgemv_n_4.c + SkylakeX microkernel, ger.c -> daxpy, drot + SkylakeX microkernel) ------------------------------------------
+// dnrm2: accumulators A..D over the leading blocks of eight (element i into accumulator i mod 4), the tail into A,
+// ((C + A) + B) + D, fsqrt, one rounding to double
+PCT_GD double dnrm2(int n, const double* x, int incx) {
+  if (n <= 0) return 0.0;
+  Ext a, b, c, d;
+  a.m = b.m = c.m = d.m = 0;
+  a.e = b.e = c.e = d.e = 0;
+  const int n8 = n & ~7;
+  PCT_GNOUNROLL
+  for (int i = 0; i < n; i++) {
+    const Ext sq = ext_square(x[i * incx]);
+    const int w = i < n8 ? (i & 3) : 0;
+    Ext cur = w == 0 ? a : (w == 1 ? b : (w == 2 ? c : d));
+    cur = ext_add(cur, sq);
+    if (w == 0) a = cur;
+    else if (w == 1) b = cur;
+    else if (w == 2) c = cur;
+    else d = cur;
+  }
+  Ext t = c;
+  PCT_GNOUNROLL
+  for (int k = 0; k < 3; k++) t = ext_add(t, k == 0 ? a : (k == 1 ? b : d));
+  return ext_sqrt_to_double(t);
+}
+PCT_GD void dscal(int n, double alpha, double* x, int incx) {
+  for (int i = 0; i < n; i++) x[i * incx] = alpha * x[i * incx];
+}
+// y[0..n) = A^T x (alpha = 1, beta = 0): rows in groups of four -- columns by the 4x4 kernel (AVX2 FMA, four lanes,
+// (l0 + l2) + (l1 + l3)), then two by the 4x2 kernel (SSE2, two lanes, products and sums rounded separately, l0 + l1), then
+// one by the 4x1 kernel (SSE2, (r0 + r2) + (r1 + r3)) -- and the m mod 4 tail rows: t = a1 x1; fma(a0, x0, t); fma(a2, x2, t); y + t
+PCT_GD void dgemv_t(int m, int n, const double* a, int lda, const double* x, int incx, double* y) {
+  const int m2 = m & ~3, m3 = m & 3, n4 = n & ~3;
+  for (int j = 0; j < n; j++) {
+    const double* c = a + j * lda;
+    double yj = 0.0;
+    if (m2 > 0) {
+      if (j < n4) {
+        double l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+        for (int i = 0; i < m2; i += 4) {
+          l0 = fma(c[i], x[i * incx], l0);
+          l1 = fma(c[i + 1], x[(i + 1) * incx], l1);
+          l2 = fma(c[i + 2], x[(i + 2) * incx], l2);
+          l3 = fma(c[i + 3], x[(i + 3) * incx], l3);
+        }
+        const double t = (l0 + l2) + (l1 + l3);
+        yj = yj + t * 1.0;
+      } else if ((n & 2) && j < n4 + 2) {
+        double l0 = 0, l1 = 0;
+        for (int i = 0; i < m2; i += 2) {
+          l0 = l0 + c[i] * x[i * incx];
+          l1 = l1 + c[i + 1] * x[(i + 1) * incx];
+        }
+        yj = fma(1.0, l0 + l1, yj);
+      } else {
+        double l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+        for (int i = 0; i < m2; i += 4) {
+          l0 = l0 + c[i] * x[i * incx];
+          l1 = l1 + c[i + 1] * x[(i + 1) * incx];
+          l2 = l2 + c[i + 2] * x[(i + 2) * incx];
+          l3 = l3 + c[i + 3] * x[(i + 3) * incx];
+        }
+        yj = fma(1.0, (l0 + l2) + (l1 + l3), yj);
+      }
+    }
+    if (m3 == 1) yj = fma(c[m2], x[m2 * incx], yj);
+    else if (m3 >= 2) {
+      double t = c[m2 + 1] * x[(m2 + 1) * incx];
+      t = fma(c[m2], x[m2 * incx], t);
+      if (m3 == 3) t = fma(c[m2 + 2], x[(m2 + 2) * incx], t);
+      yj = yj + t;
+    }
+    y[j] = yj;
+  }
+}
+// y[0..m) = A x (alpha = 1, beta = 0) with a STRIDED x (dlarf from the right in dgebd2: x is a row of A): rows in groups of
+// four -- columns in groups of four (t = a1 x1; fma a0 x0; fma a2 x2; fma a3 x3; y = fma(1, t, y)), the rest one by one,
+// y + a x rounded separately -- and the tail rows: t = fma(a, x, t) over all columns.  avx2: the Haswell kernel set instead
+PCT_GD void dgemv_n_strided(int m, int n, const double* a, int lda, const double* x, int incx, double* y, bool avx2) {
+  const int m2 = m & ~3, n4 = n & ~3;
+  for (int i = 0; i < m2; i++) {
+    double yi = 0.0;
+    for (int j = 0; j < n4; j += 4) {
+      double t;
+      if (avx2) {  // Haswell microkernel: two FMA chains, (a0 x0 + a2 x2) + (a1 x1 + a3 x3)
+        double t4 = a[i + j * lda] * x[j * incx], t5 = a[i + (j + 1) * lda] * x[(j + 1) * incx];
+        t4 = fma(a[i + (j + 2) * lda], x[(j + 2) * incx], t4);
+        t5 = fma(a[i + (j + 3) * lda], x[(j + 3) * incx], t5);
+        t = t4 + t5;
+      } else {     // SkylakeX microkernel: one chain starting from a1 x1
+        t = a[i + (j + 1) * lda] * x[(j + 1) * incx];
+        t = fma(a[i + j * lda], x[j * incx], t);
+        t = fma(a[i + (j + 2) * lda], x[(j + 2) * incx], t);
+        t = fma(a[i + (j + 3) * lda], x[(j + 3) * incx], t);
+      }
+      yi = fma(1.0, t, yi);
+    }
+    for (int j = n4; j < n; j++) yi = yi + a[i + j * lda] * (x[j * incx] * 1.0);
+    y[i] = yi;
+  }
+  for (int i = m2; i < m; i++) {  // the C tail: one FMA chain (SkylakeX build) / products and sums rounded separately (Haswell build)
+    double t = 0.0;
+    for (int j = 0; j < n; j++) t = avx2 ? t + a[i + j * lda] * x[j * incx] : fma(a[i + j * lda], x[j * incx], t);
+    y[i] = avx2 ? 0.0 + 1.0 * t : fma(1.0, t, 0.0);
+  }
+}
+// A += alpha x y^T: per column t = alpha y_j, a_ij = fma(t, x_i, a_ij)
+PCT_GD void dger(int m, int n, double alpha, const double* x, int incx, const double* y, int incy, double* a, int lda, bool avx2) {
+  if (alpha == 0.0) return;
+  // (Haswell daxpy: blocks of sixteen through the FMA microkernel, the rest multiply and add rounded separately)
+  const int mf = avx2 ? (m & ~15) : m;
+  for (int j = 0; j < n; j++) {
+    const double t = alpha * y[j * incy];
+    for (int i = 0; i < m; i++) {
+      const double v = a[i + j * lda];
+      a[i + j * lda] = i < mf ? fma(t, x[i * incx], v) : v + t * x[i * incx];
+    }
+  }
+}
+PCT_GD void drot(int n, double* x, int incx, double* y, int incy, double c, double s) {
+  for (int i = 0; i < n; i++) {
+    const double xv = x[i * incx], yv = y[i * incy];
+    x[i * incx] = fma(c, xv, s * yv);
+    y[i * incy] = fma(c, yv, -(s * xv));
+  }
+}
+
+// ---- LAPACK 3.11 (compiled Fortran: plain double arithmetic in program order) ----------------------------------------------
+constexpr double EPS = 1.1102230246251565e-16;      // dlamch('E')
+constexpr double SAFMIN = 2.2250738585072014e-308;  // dlamch('S')
+PCT_GD double sgn(double a, double b) { return copysign(fabs(a), b); }
+
+PCT_GD double dlapy2(double x, double y) {
+  const double xa = fabs(x), ya = fabs(y);
+  const double w = xa > ya ? xa : ya, z = xa < ya ? xa : ya;
+  if (z == 0.0 || w > 1.7976931348623157e308) return w;
+  const double q = z / w;
+  return w * sqrt(1.0 + q * q);
+}
+PCT_GD void dlarfg(int n, double* alpha, double* x, int incx, double* tau) {
+  if (n <= 1) { *tau = 0.0; return; }
+  const double safmin = SAFMIN / EPS, rsafmn = 1.0 / safmin;
+  int knt = 0;
+  double beta = 0.0;
+  PCT_GNOUNROLL
+  for (int pass = 0; pass < 2; pass++) {  // (the second pass: after a rescaling of a tiny vector, which these systems never need)
+    const double xnorm = dnrm2(n - 1, x, incx);
+    if (pass == 0 && xnorm == 0.0) { *tau = 0.0; return; }
+    beta = -sgn(dlapy2(*alpha, xnorm), *alpha);
+    if (pass == 1 || !(fabs(beta) < safmin)) break;
+    do {
+      knt++;
+      dscal(n - 1, rsafmn, x, incx);
+      beta *= rsafmn;
+      *alpha *= rsafmn;
+    } while (fabs(beta) < safmin && knt < 20);
+  }
+  *tau = (beta - *alpha) / beta;
+  dscal(n - 1, 1.0 / (*alpha - beta), x, incx);
+  for (int j = 0; j < knt; j++) beta *= safmin;
+  *alpha = beta;
+}
+// dlarf from the left: C (m x n) := (I - tau v v^T) C; trailing zeros of v and trailing zero columns of C are skipped
+PCT_GD void dlarf_left(int m, int n, const double* v, int incv, double tau, double* c, int ldc, double* work, bool avx2) {
+  if (tau == 0.0) return;
+  int lastv = m;
+  while (lastv > 0 && v[(lastv - 1) * incv] == 0.0) lastv--;
+  int lastc = n;
+  for (; lastc > 0; lastc--) {
+    bool nz = false;
+    for (int i = 0; i < lastv; i++)
+      if (c[i + (lastc - 1) * ldc] != 0.0) { nz = true; break; }
+    if (nz) break;
+  }
+  if (lastv <= 0) return;
+  dgemv_t(lastv, lastc, c, ldc, v, incv, work);
+  dger(lastv, lastc, -tau, v, incv, work, 1, c, ldc, avx2);
+}
+// dlarf from the right: C (m x n) := C (I - tau v v^T), v a strided row
+PCT_GD void dlarf_right(int m, int n, const double* v, int incv, double tau, double* c, int ldc, double* work, bool avx2) {
+  if (tau == 0.0) return;
+  int lastv = n;
+  while (lastv > 0 && v[(lastv - 1) * incv] == 0.0) lastv--;
+  int lastc = m;
+  for (; lastc > 0; lastc--) {
+    bool nz = false;
+    for (int j = 0; j < lastv; j++)
+      if (c[(lastc - 1) + j * ldc] != 0.0) { nz = true; break; }
+    if (nz) break;
+  }
+  if (lastv <= 0) return;
+  dgemv_n_strided(lastc, lastv, c, ldc, v, incv, work, avx2);
+  dger(lastc, lastv, -tau, work, 1, v, incv, c, ldc, avx2);
+}
+PCT_GD void dlartg(double f, double g, double& c, double& s, double& r) {
+  const double safmax = 1.0 / SAFMIN;
+  const double rtmin = 1.4916681462400413e-154;  // sqrt(safmin)
+  const double rtmax = 4.7403759540545887e+153;  // sqrt(safmax / 2)
+  const double f1 = fabs(f), g1 = fabs(g);
+  if (g == 0.0) { c = 1.0; s = 0.0; r = f; }
+  else if (f == 0.0) { c = 0.0; s = sgn(1.0, g); r = g1; }
+  else if (f1 > rtmin && f1 < rtmax && g1 > rtmin && g1 < rtmax) {
+    const double d = sqrt(f * f + g * g);
+    c = f1 / d;
+    r = sgn(d, f);
+    s = g / r;
+  } else {
+    double u = f1 > g1 ? f1 : g1;
+    if (u < SAFMIN) u = SAFMIN;
+    if (u > safmax) u = safmax;
+    const double fs = f / u, gs = g / u;
+    const double d = sqrt(fs * fs + gs * gs);
+    c = fabs(fs) / d;
+    r = sgn(d, f);
+    s = gs / r;
+    r = r * u;
+  }
+}
+PCT_GD void dlas2(double f, double g, double h, double& ssmin, double& ssmax) {
+  const double fa = fabs(f), ga = fabs(g), ha = fabs(h);
+  const double fhmn = fa < ha ? fa : ha, fhmx = fa > ha ? fa : ha;
+  if (fhmn == 0.0) {
+    ssmin = 0.0;
+    if (fhmx == 0.0) ssmax = ga;
+    else {
+      const double mx = fhmx > ga ? fhmx : ga, mn = fhmx < ga ? fhmx : ga;
+      const double q = mn / mx;
+      ssmax = mx * sqrt(1.0 + q * q);
+    }
+  } else if (ga < fhmx) {
+    const double as = 1.0 + fhmn / fhmx, at = (fhmx - fhmn) / fhmx;
+    const double q = ga / fhmx, au = q * q;
+    const double c = 2.0 / (sqrt(as * as + au) + sqrt(at * at + au));
+    ssmin = fhmn * c;
+    ssmax = fhmx / c;
+  } else {
+    const double au = fhmx / ga;
+    if (au == 0.0) { ssmin = (fhmn * fhmx) / ga; ssmax = ga; }
+    else {
+      const double as = 1.0 + fhmn / fhmx, at = (fhmx - fhmn) / fhmx;
+      const double p = as * au, q = at * au;
+      const double c = 1.0 / (sqrt(1.0 + p * p) + sqrt(1.0 + q * q));
+      ssmin = (fhmn * c) * au;
+      ssmin = ssmin + ssmin;
+      ssmax = ga / (c + c);
+    }
+  }
+}
+PCT_GD void dlasv2(double f, double g, double h, double& ssmin, double& ssmax, double& snr, double& csr, double& snl, double& csl) {
+  double ft = f, fa = fabs(ft), ht = h, ha = fabs(h);
+  int pmax = 1;
+  const bool swap = ha > fa;
+  if (swap) { pmax = 3; double t = ft; ft = ht; ht = t; t = fa; fa = ha; ha = t; }
+  const double gt = g, ga = fabs(gt);
+  double clt = 1.0, crt = 1.0, slt = 0.0, srt = 0.0;
+  if (ga == 0.0) { ssmin = ha; ssmax = fa; }
+  else {
+    bool gasmal = true;
+    if (ga > fa) {
+      pmax = 2;
+      if (fa / ga < EPS) {
+        gasmal = false;
+        ssmax = ga;
+        if (ha > 1.0) ssmin = fa / (ga / ha); else ssmin = (fa / ga) * ha;
+        clt = 1.0; slt = ht / gt; srt = 1.0; crt = ft / gt;
+      }
+    }
+    if (gasmal) {
+      const double d = fa - ha;
+      double l = d == fa ? 1.0 : d / fa;
+      const double m = gt / ft;
+      double t = 2.0 - l;
+      const double mm = m * m, tt = t * t;
+      const double s = sqrt(tt + mm);
+      const double r = l == 0.0 ? fabs(m) : sqrt(l * l + mm);
+      const double a = 0.5 * (s + r);
+      ssmin = ha / a;
+      ssmax = fa * a;
+      if (mm == 0.0) {
+        if (l == 0.0) t = sgn(2.0, ft) * sgn(1.0, gt);
+        else t = gt / sgn(d, ft) + m / t;
+      } else t = (m / (s + t) + m / (r + l)) * (1.0 + a);
+      l = sqrt(t * t + 4.0);
+      crt = 2.0 / l;
+      srt = t / l;
+      clt = (crt + srt * m) / a;
+      slt = (ht / ft) * srt / a;
+    }
+  }
+  if (swap) { csl = srt; snl = crt; csr = slt; snr = clt; }
+  else { csl = clt; snl = slt; csr = crt; snr = srt; }
+  double tsign;
+  if (pmax == 1) tsign = sgn(1.0, csr) * sgn(1.0, csl) * sgn(1.0, f);
+  else if (pmax == 2) tsign = sgn(1.0, snr) * sgn(1.0, csl) * sgn(1.0, g);
+  else tsign = sgn(1.0, snr) * sgn(1.0, snl) * sgn(1.0, h);
+  ssmax = sgn(ssmax, tsign);
+  ssmin = sgn(ssmin, tsign * sgn(1.0, f) * sgn(1.0, h));
+}
+// dlascl('G', 0, 0, cfrom, cto, ...) on a vector
+PCT_GD void dlascl_vec(double cfrom, double cto, int n, double* x) {
+  const double smlnum = SAFMIN, bignum = 1.0 / smlnum;
+  double cfromc = cfrom, ctoc = cto, mul;
+  bool done;
+  do {
+    const double cfrom1 = cfromc * smlnum;
+    if (cfrom1 == cfromc) { mul = ctoc / cfromc; done = true; }
+    else {
+      const double cto1 = ctoc / bignum;
+      if (cto1 == ctoc) { mul = ctoc; done = true; cfromc = 1.0; }
+      else if (fabs(cfrom1) > fabs(ctoc) && ctoc != 0.0) { mul = smlnum; done = false; cfromc = cfrom1; }
+      else if (fabs(cto1) > fabs(cfromc)) { mul = bignum; done = false; ctoc = cto1; }
+      else { mul = ctoc / cfromc; done = true; if (mul == 1.0) return; }
+    }
+    for (int i = 0; i < n; i++) x[i] = x[i] * mul;
+  } while (!done);
+}
+
+// dbdsqr('U', n, ncvt = n, 0, ncc = 1): SVD of the upper bidiagonal (d, e); right rotations into VT (n x n, ldvt = n), left
+// ones into the column cc.  work: 4 (n - 1) doubles.  Returns false when the iteration limit is reached.
+PCT_GD bool dbdsqr(int n, double* d, double* e, double* vt, double* cc, double* work) {
+  const double hndrth = 0.01;
+  const int maxitr = 6;
+  const int ldvt = n;
+  const int nm1 = n - 1, nm12 = nm1 + nm1, nm13 = nm12 + nm1;
+  int idir = 0;
+  if (n > 1) {
+    const double tol = 0x1.8ace5422aa0dbp+6 * EPS;  // max(10, min(100, eps^(-1/8))) * eps
+    double smax = 0.0;
+    for (int i = 0; i < n; i++) smax = fabs(d[i]) > smax ? fabs(d[i]) : smax;
+    for (int i = 0; i < n - 1; i++) smax = fabs(e[i]) > smax ? fabs(e[i]) : smax;
+    double smin = 0.0;
+    double sminoa = fabs(d[0]);
+    if (sminoa != 0.0) {
+      double mu = sminoa;
+      for (int i = 1; i < n; i++) {
+        mu = fabs(d[i]) * (mu / (mu + fabs(e[i - 1])));
+        sminoa = mu < sminoa ? mu : sminoa;
+        if (sminoa == 0.0) break;
+      }
+    }
+    sminoa = sminoa / sqrt((double)n);
+    double thresh = tol * sminoa;
+    {
+      const double t2 = maxitr * (n * (n * SAFMIN));
+      thresh = t2 > thresh ? t2 : thresh;
+    }
+    const int maxitdivn = maxitr * n;
+    int iterdivn = 0, iter = -1, oldll = -1, oldm = -1;
+    int m = n;
+    while (m > 1) {
+      if (iter >= n) {
+        iter -= n;
+        iterdivn++;
+        if (iterdivn >= maxitdivn) return false;
+      }
+      smax = fabs(d[m - 1]);
+      int ll = 0;
+      bool split = false;
+      for (int lll = 1; lll <= m - 1; lll++) {
+        ll = m - lll;
+        const double abss = fabs(d[ll - 1]), abse = fabs(e[ll - 1]);
+        if (abse <= thresh) { split = true; break; }
+        smax = abss > smax ? abss : smax;
+        smax = abse > smax ? abse : smax;
+      }
+      if (split) {
+        e[ll - 1] = 0.0;
+        if (ll == m - 1) { m = m - 1; continue; }
+      } else ll = 0;
+      ll = ll + 1;
+      if (ll == m - 1) {
+        double sigmn, sigmx, sinr, cosr, sinl, cosl;
+        dlasv2(d[m - 2], e[m - 2], d[m - 1], sigmn, sigmx, sinr, cosr, sinl, cosl);
+        d[m - 2] = sigmx; e[m - 2] = 0.0; d[m - 1] = sigmn;
+        drot(n, &vt[m - 2], ldvt, &vt[m - 1], ldvt, cosr, sinr);
+        drot(1, &cc[m - 2], 1, &cc[m - 1], 1, cosl, sinl);
+        m = m - 2;
+        continue;
+      }
+      if (ll > oldm || m < oldll) idir = fabs(d[ll - 1]) >= fabs(d[m - 1]) ? 1 : 2;
+      bool conv = false;
+      if (idir == 1) {
+        if (fabs(e[m - 2]) <= fabs(tol) * fabs(d[m - 1])) { e[m - 2] = 0.0; continue; }
+        double mu = fabs(d[ll - 1]);
+        smin = mu;
+        for (int lll = ll; lll <= m - 1; lll++) {
+          if (fabs(e[lll - 1]) <= tol * mu) { e[lll - 1] = 0.0; conv = true; break; }
+          mu = fabs(d[lll]) * (mu / (mu + fabs(e[lll - 1])));
+          smin = mu < smin ? mu : smin;
+        }
+      } else {
+        if (fabs(e[ll - 1]) <= fabs(tol) * fabs(d[ll - 1])) { e[ll - 1] = 0.0; continue; }
+        double mu = fabs(d[m - 1]);
+        smin = mu;
+        for (int lll = m - 1; lll >= ll; lll--) {
+          if (fabs(e[lll - 1]) <= tol * mu) { e[lll - 1] = 0.0; conv = true; break; }
+          mu = fabs(d[lll - 1]) * (mu / (mu + fabs(e[lll - 1])));
+          smin = mu < smin ? mu : smin;
+        }
+      }
+      if (conv) continue;
+      oldll = ll; oldm = m;
+      double shift = 0.0, r = 0.0;
+      {
+        const double bound = EPS > hndrth * tol ? EPS : hndrth * tol;
+        if (!(n * tol * (smin / smax) <= bound)) {
+          double sll;
+          if (idir == 1) { sll = fabs(d[ll - 1]); dlas2(d[m - 2], e[m - 2], d[m - 1], shift, r); }
+          else { sll = fabs(d[m - 1]); dlas2(d[ll - 1], e[ll - 1], d[ll], shift, r); }
+          if (sll > 0.0) {
+            const double q = shift / sll;
+            if (q * q < EPS) shift = 0.0;
+          }
+        }
+      }
+      iter = iter + m - ll;
+      // One sweep, written once for both chase directions: position p = 0 .. cnt - 1 runs from the larger end of the block to the
+      // smaller (idir 1: rows ll .. m downwards, idir 2: rows m .. ll upwards); di(p) / ei(p): the 0-based indices of the p-th
+      // diagonal entry and of the off-diagonal entry between positions p and p + 1.
+      double* w0 = work;
+      double* w1 = work + nm1;
+      double* w2 = work + nm12;
+      double* w3 = work + nm13;
+      const int cnt = m - ll + 1;
+      const int dbase = idir == 1 ? ll - 1 : m - 1, ebase = idir == 1 ? ll - 1 : m - 2, step = idir == 1 ? 1 : -1;
+      const double sg = idir == 1 ? 1.0 : -1.0;  // (the upward chase stores its sines negated: dbdsqr's WORK(.) = -SN)
+      if (shift == 0.0) {
+        double cs = 1.0, oldcs = 1.0, sn = 0.0, oldsn = 0.0;
+        PCT_GNOUNROLL
+        for (int p = 0; p < cnt - 1; p++) {
+          const int dp = dbase + step * p, dq = dp + step, ep = ebase + step * p;
+          dlartg(d[dp] * cs, e[ep], cs, sn, r);
+          if (p > 0) e[ep - step] = oldsn * r;
+          double dn;
+          dlartg(oldcs * r, d[dq] * sn, oldcs, oldsn, dn);
+          d[dp] = dn;
+          w0[p] = cs; w1[p] = sg * sn; w2[p] = oldcs; w3[p] = sg * oldsn;
+        }
+        const int dl = dbase + step * (cnt - 1);
+        const double h = d[dl] * cs;
+        d[dl] = h * oldcs;
+        e[ebase + step * (cnt - 2)] = h * oldsn;
+      } else {
+        double f = (fabs(d[dbase]) - shift) * (sgn(1.0, d[dbase]) + shift / d[dbase]);
+        double g = e[ebase];
+        double cosr, sinr, cosl, sinl;
+        PCT_GNOUNROLL
+        for (int p = 0; p < cnt - 1; p++) {
+          const int dp = dbase + step * p, dq = dp + step, ep = ebase + step * p;
+          dlartg(f, g, cosr, sinr, r);
+          if (p > 0) e[ep - step] = r;
+          f = cosr * d[dp] + sinr * e[ep];
+          e[ep] = cosr * e[ep] - sinr * d[dp];
+          g = sinr * d[dq];
+          d[dq] = cosr * d[dq];
+          dlartg(f, g, cosl, sinl, r);
+          d[dp] = r;
+          f = cosl * e[ep] + sinl * d[dq];
+          d[dq] = cosl * d[dq] - sinl * e[ep];
+          if (p < cnt - 2) {
+            g = sinl * e[ep + step];
+            e[ep + step] = cosl * e[ep + step];
+          }
+          w0[p] = cosr; w1[p] = sg * sinr; w2[p] = cosl; w3[p] = sg * sinl;
+        }
+        e[ebase + step * (cnt - 2)] = f;
+      }
+      // dlasr('L', 'V', 'F' / 'B'): the right rotations (the first pair of a step) go into VT when chasing downwards, into the
+      // column cc when chasing upwards, the left rotations into the other one -- in the order of the sweep
+      PCT_GNOUNROLL
+      for (int tgt = 0; tgt < 2; tgt++) {
+        const bool first = (tgt == 0) == (idir == 1);
+        const double* cw = first ? w0 : w2;
+        const double* sw = first ? w1 : w3;
+        double* mat = tgt == 0 ? vt : cc;
+        const int ncol = tgt == 0 ? n : 1;
+        for (int p = 0; p < cnt - 1; p++) {
+          const double ct = cw[p], st = sw[p];
+          if (ct != 1.0 || st != 0.0) {
+            const int dp = dbase + step * p, dq = dp + step;
+            const int rhi = idir == 1 ? dq : dp, rlo = idir == 1 ? dp : dq;
+            for (int c = 0; c < ncol; c++) {
+              const double temp = mat[rhi + c * ldvt];
+              mat[rhi + c * ldvt] = ct * temp - st * mat[rlo + c * ldvt];
+              mat[rlo + c * ldvt] = st * temp + ct * mat[rlo + c * ldvt];
+            }
+          }
+        }
+      }
+      {
+        const int el = ebase + step * (cnt - 2);
+        if (fabs(e[el]) <= thresh) e[el] = 0.0;
+      }
+    }
+  }
+  for (int i = 0; i < n; i++) {
+    if (d[i] == 0.0) d[i] = 0.0;
+    if (d[i] < 0.0) {
+      d[i] = -d[i];
+      dscal(n, -1.0, &vt[i], ldvt);
+    }
+  }
+  // decreasing order: one transposition per singular value
+  for (int i = 1; i <= n - 1; i++) {
+    int isub = 1;
+    double smn = d[0];
+    for (int j = 2; j <= n + 1 - i; j++)
+      if (d[j - 1] <= smn) { isub = j; smn = d[j - 1]; }
+    if (isub != n + 1 - i) {
+      d[isub - 1] = d[n - i];
+      d[n - i] = smn;
+      for (int c = 0; c < n; c++) {
+        const double t = vt[(isub - 1) + c * ldvt];
+        vt[(isub - 1) + c * ldvt] = vt[(n - i) + c * ldvt];
+        vt[(n - i) + c * ldvt] = t;
+      }
+      const double t = cc[isub - 1];
+      cc[isub - 1] = cc[n - i];
+      cc[n - i] = t;
+    }
+  }
+  return true;
+}
+
+// doubles of workspace the solve of an M x n system takes: A (M n), b (M), VT (n n), tau / tauq, taup, d, e (4 n), work (4 n)
+PCT_GD int solve_doubles(int n) {
+  const int M = n * (n - 1) / 2 + 1;
+  return M * n + M + n * n + 8 * n;
+}
+constexpr double ILL_BAND = 1e3;  // the notice: a singular value within this factor of the rank cut (as STAB_ILL_BAND)
+
+// The split of a stack at (s0, s1) over k >= 3 supporters with contact centres in[2 i], in[2 i + 1] (D/space.py:134-163): the
+// system (one row per supporter pair i < j, a closing row of ones, right-hand side e_M) is built in ws and solved as dgelsd
+// solves it.  x[0..k): the fractions.  `ill`: a singular value within 1e3 of the rank cut.  Returns false when dbdsqr does not
+// converge (NumPy raises LinAlgError there; x is zero then).
+// (dot2: pct_stab.cuh's stab_dot2, np.dot of two 2-vectors on an FMA host, passed in to keep it the single definition)
+template <typename Dot2>
+PCT_GD bool split_t(double* ws, int k, const double* in, double s0, double s1, Dot2 dot2, double* x, bool& ill, bool avx2 = false) {
+  const int n = k, M = k * (k - 1) / 2 + 1, lda = M;
+  double* a = ws;
+  double* b = a + M * n;
+  double* vt = b + M;
+  double* tau = vt + n * n;   // (spare: the column reflectors are applied where they are made)
+  double* taup = tau + n;
+  double* d = taup + n;
+  double* e = d + n;
+  double* work = e + n;       // 4 n
+  for (int i = 0; i < M * n; i++) a[i] = 0.0;
+  for (int i = 0; i < M; i++) b[i] = 0.0;
+  {
+    int row = 0;
+    for (int i = 0; i < k - 1; i++)
+      for (int j = i + 1; j < k; j++) {
+        const double ei0 = in[2 * i], ei1 = in[2 * i + 1], ej0 = in[2 * j], ej1 = in[2 * j + 1];
+        const double t0 = ei0 - ej0, t1 = ei1 - ej1;
+        const double mol = dot2(s0 - ei0, s1 - ei1, t0, t1);
+        if (mol != 0) {
+          const double rr = fabs(dot2(s0 - ej0, s1 - ej1, t0, t1)) / mol;
+          a[row + i * lda] = 1.0;
+          a[row + j * lda] = -rr;
+        }
+        row++;
+      }
+    for (int j = 0; j < k; j++) a[(M - 1) + j * lda] = 1.0;
+    b[M - 1] = 1.0;
+  }
+  for (int j = 0; j < n; j++) x[j] = 0.0;
+  ill = false;
+  // (dgelsd scales A and b only when an entry leaves [1e-292, 1e292]; the closing row of ones keeps max|A| >= 1)
+  // Stage 0, dgeqr2 + dorm2r: A = Q R by column reflectors, each applied to the trailing columns and -- dorm2r('L', 'T') applies
+  // the same reflectors to b in the same order, and b meets nothing else in between -- to b at once.  Stage 1, dgebd2 + dormbr('Q'):
+  // R (the top n x n) to bidiagonal form by a column reflector (again applied to b at once) and a row reflector per step; the row
+  // reflectors (taup) meet b only after the bidiagonal solve.
+  PCT_GNOUNROLL
+  for (int stage = 0; stage < 2; stage++) {
+    const int rows = stage == 0 ? M : n;
+    PCT_GNOUNROLL
+    for (int i = 0; i < n; i++) {
+      const int nparts = (stage == 1 && i < n - 1) ? 2 : 1;
+      PCT_GNOUNROLL
+      for (int part = 0; part < nparts; part++) {
+        const int len = part == 0 ? rows - i : n - i - 1;
+        const int inc = part == 0 ? 1 : lda;
+        double* alpha = part == 0 ? &a[i + i * lda] : &a[i + (i + 1) * lda];
+        double* xv = part == 0 ? &a[(i + 1 < rows ? i + 1 : rows - 1) + i * lda] : &a[i + (i + 2 < n ? i + 2 : n - 1) * lda];
+        double tauv;
+        dlarfg(len, alpha, xv, inc, &tauv);
+        const double saved = *alpha;
+        if (stage == 1) {
+          if (part == 0) d[i] = saved;
+          else { e[i] = saved; taup[i] = tauv; }
+        }
+        *alpha = 1.0;
+        if (part == 0) {
+          PCT_GNOUNROLL
+          for (int tgt = 0; tgt < 2; tgt++) {  // the trailing columns of A, then b
+            const int nc = tgt == 0 ? n - i - 1 : 1;
+            double* c = tgt == 0 ? &a[i + (i + 1) * lda] : &b[i];
+            if (nc > 0) dlarf_left(len, nc, alpha, 1, tauv, c, lda, work, avx2);
+          }
+        } else {
+          dlarf_right(n - i - 1, n - i - 1, alpha, lda, tauv, &a[(i + 1) + (i + 1) * lda], lda, work, avx2);
+        }
+        *alpha = saved;
+      }
+    }
+    if (stage == 0)
+      for (int j = 0; j < n - 1; j++)
+        for (int i = j + 1; i < n; i++) a[i + j * lda] = 0.0;
+  }
+  taup[n - 1] = 0.0;
+  // dlalsd('U', 25, n, 1, d, e, b, ...)
+  double orgnrm = 0.0;
+  for (int i = 0; i < n; i++) orgnrm = fabs(d[i]) > orgnrm ? fabs(d[i]) : orgnrm;
+  for (int i = 0; i < n - 1; i++) orgnrm = fabs(e[i]) > orgnrm ? fabs(e[i]) : orgnrm;
+  if (orgnrm == 0.0) return true;
+  dlascl_vec(orgnrm, 1.0, n, d);
+  dlascl_vec(orgnrm, 1.0, n - 1, e);
+  for (int i = 0; i < n * n; i++) vt[i] = 0.0;
+  for (int i = 0; i < n; i++) vt[i + i * n] = 1.0;
+  if (!dbdsqr(n, d, e, vt, b, work)) { ill = true; return false; }
+  // dlasdq: into increasing order
+  for (int i = 1; i <= n; i++) {
+    int isub = i;
+    double smn = d[i - 1];
+    for (int j = i + 1; j <= n; j++)
+      if (d[j - 1] < smn) { isub = j; smn = d[j - 1]; }
+    if (isub != i) {
+      d[isub - 1] = d[i - 1];
+      d[i - 1] = smn;
+      for (int c = 0; c < n; c++) {
+        const double t = vt[(isub - 1) + c * n];
+        vt[(isub - 1) + c * n] = vt[(i - 1) + c * n];
+        vt[(i - 1) + c * n] = t;
+      }
+      const double t = b[isub - 1];
+      b[isub - 1] = b[i - 1];
+      b[i - 1] = t;
+    }
+  }
+  int imax = 0;
+  for (int i = 1; i < n; i++)
+    if (fabs(d[i]) > fabs(d[imax])) imax = i;
+  const double rcond = 2.220446049250313e-16 * (double)(M > n ? M : n);
+  const double tol = rcond * fabs(d[imax]);
+  for (int i = 0; i < n; i++)
+    if (d[i] > 0.0 && d[i] > tol / ILL_BAND && d[i] < tol * ILL_BAND) ill = true;
+  for (int i = 0; i < n; i++) {
+    if (d[i] <= tol) b[i] = 0.0;
+    else dlascl_vec(d[i], 1.0, 1, &b[i]);
+  }
+  // dgemm('T', 'N', n, 1, n): the packed kernel, acc = fma(vt(k, i), b(k), acc) in k order
+  // (Haswell kernel: rows in groups of four with four accumulators over the leading blocks of eight k, the tail into the first,
+  // (q0 + q1) + (q2 + q3); its n mod 4 last rows, like every row of the SkylakeX kernel, one chain)
+  for (int i = 0; i < n; i++) {
+    double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+    const bool four = avx2 && i < (n & ~3);
+    const int kb = four ? (n & ~7) : 0;
+    for (int kk = 0; kk < kb; kk += 4) {
+      q0 = fma(vt[kk + i * n], b[kk], q0);
+      q1 = fma(vt[kk + 1 + i * n], b[kk + 1], q1);
+      q2 = fma(vt[kk + 2 + i * n], b[kk + 2], q2);
+      q3 = fma(vt[kk + 3 + i * n], b[kk + 3], q3);
+    }
+    for (int kk = kb; kk < n; kk++) q0 = fma(vt[kk + i * n], b[kk], q0);
+    work[i] = four ? (q0 + q1) + (q2 + q3) : q0;
+  }
+  for (int i = 0; i < n; i++) b[i] = work[i];
+  dlascl_vec(orgnrm, 1.0, n, b);
+  // dormbr('P', 'L', 'N') = dorml2('L', 'T'): the row reflectors, last first
+  for (int i = n - 2; i >= 0; i--) {
+    const double aii = a[i + (i + 1) * lda];
+    a[i + (i + 1) * lda] = 1.0;
+    dlarf_left(n - 1 - i, 1, &a[i + (i + 1) * lda], lda, taup[i], &b[i + 1], M, work, avx2);
+    a[i + (i + 1) * lda] = aii;
+  }
+  for (int j = 0; j < n; j++) x[j] = b[j];
+  return true;
+}
+
+}  // namespace gelsd
+}  // namespace pct
+#endif

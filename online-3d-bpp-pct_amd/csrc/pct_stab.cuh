@@ -48,6 +48,8 @@
 #define PCT_SM inline
 #endif
 
+#include "pct_gelsd.cuh"
+
 namespace pct {
 
 constexpr int STAB_LSQ = 16;         // most supporters a least-squares split can be given (a launch's caps.lsq_n may be lower:
@@ -73,7 +75,13 @@ struct StabCaps {
   int lsq_n;     // supporters the wave-cooperative least-squares split takes, 6..STAB_LSQ
   int lsq_bytes; // its LDS workspace: at least one system of lsq_n supporters (stab_lsq_bytes); what is beyond that holds
                  // further systems of the smaller size classes side by side
+  int gelsd;     // PCT_LSTSQ_GELSD (1) / PCT_LSTSQ_GELSD_AVX2 (2): every least-squares split (three supporters and more) is solved as
+                 // LAPACK dgelsd solves it (pct_gelsd.cuh; with the arithmetic of OpenBLAS' AVX-512 / AVX2 kernel set), one lane per
+                 // system on a slot of the same workspace, instead of the Jacobi solves
 };
+#if !defined(__HIPCC__)
+static int g_stab_host_gelsd = 0;  // host test build (tests/host): the mode the handle carries in StabCaps on the device
+#endif
 
 // per-env stability state: pointers into LDS (device) or host memory
 struct StabState {
@@ -330,6 +338,12 @@ PCT_SD void stab_lstsq(const double* A, const double* b, int M, int N, double* x
 // np.dot of two 2-vectors as NumPy's BLAS computes it (OpenBLAS ddot on x86 cores with FMA): acc = x0*y0;
 // acc = fma(x1, y1, acc) (NumPy's 2-vector dot on an FMA host; v_fma_f64 on the GPU is the same IEEE operation)
 PCT_SD double stab_dot2(double x0, double x1, double y0, double y1) { return fma(x1, y1, x0 * y0); }
+// ... and on a host whose OpenBLAS runs the "Haswell" kernel set (AVX2 hosts, AMD Zen included): that ddot's tail loop is compiled
+// without FMA, both products and the sum are rounded (PCT_LSTSQ_GELSD_AVX2; measured against np.dot under OPENBLAS_CORETYPE=HASWELL)
+struct StabDot2 {
+  bool plain;
+  PCT_SM double operator()(double x0, double x1, double y0, double y1) const { return plain ? x0 * y0 + x1 * y1 : fma(x1, y1, x0 * y0); }
+};
 
 // The same solve with every extent a compile-time constant (N supporters, M = N(N-1)/2 + 1 rows) and every loop over
 // rows, columns and column pairs unrolled: U and V are then registers, not dynamically indexed private arrays in
@@ -457,7 +471,12 @@ struct StabSplit {
 struct StabSplitX { double fx[STAB_LSQ]; };
 template <bool CONT, typename Geo, typename Sup>
 PCT_SD bool stab_split(const Geo& geo, const double bg[9], int k, const Sup& sup, const double stk[4], StabSplit& sp, StabSplitX& sx,
-                       StabStats* ss = nullptr, int lsq_n = STAB_LSQ) {
+                       StabStats* ss = nullptr, int lsq_n = STAB_LSQ, int lsq_mode = 0) {
+#if !defined(__HIPCC__)
+  if (g_stab_host_gelsd) lsq_mode = g_stab_host_gelsd;
+#endif
+  const bool gelsd = lsq_mode != 0, gelsd_avx2 = lsq_mode == 2;
+  (void)gelsd_avx2;
   sp.mode = 0; sp.direct = -1; sp.ill = false;
 #pragma unroll
   for (int i = 0; i < 5; i++) sp.f[i] = 0;
@@ -471,6 +490,31 @@ PCT_SD bool stab_split(const Geo& geo, const double bg[9], int k, const Sup& sup
   }
   if (sp.direct >= 0) { sp.mode = 1; return true; }
   if (k > lsq_n || k > STAB_LSQ) return false;
+  if (gelsd && k >= 3) {
+    // strict mode: the split is np.linalg.lstsq as the reference's NumPy executes it (pct_gelsd.cuh)
+    if (ss) { ss->lsq3 += k == 3; ss->lsq4 += k == 4; ss->lsq5 += k == 5; ss->lsqx += k > 5; }
+#if defined(__HIPCC__)
+    sp.mode = 4;  // solved by one lane on a slot of the wave's least-squares workspace (stab_gelsd_slots)
+    (void)sx;
+    return true;
+#else
+    sp.mode = 3;
+    double cen[2 * STAB_LSQ], wsg[(STAB_LSQ * (STAB_LSQ - 1) / 2 + 1) * (STAB_LSQ + 1) + STAB_LSQ * STAB_LSQ + 8 * STAB_LSQ];
+    for (int i = 0; i < k; i++) {
+      double a[4];
+      stab_area<CONT>(geo, bg, sup(i), a);
+      cen[2 * i] = (a[0] + a[2]) / 2;
+      cen[2 * i + 1] = (a[1] + a[3]) / 2;
+    }
+    double xg[STAB_LSQ];
+    gelsd::split_t(wsg, k, cen, stk[0], stk[1], StabDot2{gelsd_avx2}, xg, sp.ill, gelsd_avx2);
+    for (int i = 0; i < k; i++) {
+      if (k <= 5) sp.f[i] = xg[i];
+      else sx.fx[i] = xg[i];
+    }
+    return true;
+#endif
+  }
   if (k <= 5) {
     // contact centres with static indices (registers).  Two to five supporters are 99.99 % of the splits (of the
     // least-squares ones k = 3: 94 %, 4: 6 %, 5: 0.1 %).  The register-resident solve for five costs 160 VGPRs -- and the
@@ -491,13 +535,14 @@ PCT_SD bool stab_split(const Geo& geo, const double bg[9], int k, const Sup& sup
     if (k == 2) {
       const double e00 = c2[0][0], e01 = c2[0][1], e10 = c2[1][0], e11 = c2[1][1];
       double t0 = e00 - e10, t1 = e01 - e11;
-      double len = sqrt(stab_dot2(t0, t1, t0, t1));
+      const StabDot2 dot2{gelsd_avx2};  // (the lever rule's np.dot / np.linalg.norm follow the host flavour too)
+      double len = sqrt(dot2(t0, t1, t0, t1));
       // tri_base_len ** 2: NumPy calls libm pow(len, 2.0); a correctly rounded square is len*len
       // (glibc's pow agrees except for rare near-midpoint roundings; the device pow does not)
       double l2 = len * len;
       t0 /= l2; t1 /= l2;
-      sp.f[0] = fabs(stab_dot2(stk[0] - e10, stk[1] - e11, t0, t1));
-      sp.f[1] = fabs(stab_dot2(stk[0] - e00, stk[1] - e01, t0, t1));
+      sp.f[0] = fabs(dot2(stk[0] - e10, stk[1] - e11, t0, t1));
+      sp.f[1] = fabs(dot2(stk[0] - e00, stk[1] - e01, t0, t1));
       sp.mode = 2;
       return true;
     }
@@ -732,13 +777,24 @@ struct StabHbm {
 // contact centres), the n fractions, three product columns, U (M x n, column-major), V (n x n, column-major); M = n (n - 1) / 2 + 1
 PCT_HD int stab_lsq_rows(int n) { return n * (n - 1) / 2 + 1; }
 PCT_HD int stab_lsq_rows8(int n) { return (stab_lsq_rows(n) + 7) & ~7; }  // the product columns are padded to a multiple of 8 rows
-PCT_HD size_t stab_lsq_slot_doubles(int n) {
+PCT_HD size_t stab_lsq_slot_doubles(int n, bool gelsd = false) {
   const size_t M = (size_t)stab_lsq_rows(n), M8 = (size_t)stab_lsq_rows8(n);
+  // gelsd mode: the same header and fractions, then the dgelsd workspace (A, b, VT, four n-vectors, 4 n of work); never more than
+  // the Jacobi slot from 8 supporters on, i.e. for the classes a launch's workspace is sized by (lsq_n = 8 / 16)
+  if (gelsd) return 4 + 2 * (size_t)n + (size_t)n + M * (size_t)n + M + (size_t)n * (size_t)n + 8 * (size_t)n;
   return 4 + 2 * (size_t)n + (size_t)n + 3 * M8 + M * (size_t)n + (size_t)n * (size_t)n;
 }
-// lanes that share one system: 16 up to 6 supporters (16 rows), 32 up to 8 (29 rows), else the whole wave
-PCT_HD int stab_lsq_group(int k) { return k <= 6 ? 16 : (k <= 8 ? 32 : 64); }
-PCT_HD int stab_lsq_class_n(int k, int lsq_n) { return k <= 6 ? 6 : (k <= 8 ? 8 : lsq_n); }
+// lanes that share one system: 16 up to 6 supporters (16 rows), 32 up to 8 (29 rows), else the whole wave.  gelsd mode: ONE lane
+// solves a system; the classes are up to 4 / up to 8 / up to lsq_n supporters and the "group" widths 1 / 2 / 4 tell them apart
+// (lane rk * G solves slot rk)
+PCT_HD int stab_lsq_group(int k, bool gelsd = false) {
+  if (gelsd) return k <= 4 ? 1 : (k <= 8 ? 2 : 4);
+  return k <= 6 ? 16 : (k <= 8 ? 32 : 64);
+}
+PCT_HD int stab_lsq_class_n(int k, int lsq_n, bool gelsd = false) {
+  if (gelsd) return k <= 4 ? 4 : (k <= 8 ? 8 : lsq_n);
+  return k <= 6 ? 6 : (k <= 8 ? 8 : lsq_n);
+}
 // workspace bytes: one system of up to n supporters (narrow: the normal pass, where LDS is what bounds the resident envs --
 // that still takes two systems of the 6-supporter class), or (wide: the retry pass) as many systems as a class's lane groups
 // allow -- four of the 6-supporter class, two of the 8-supporter class
@@ -899,11 +955,29 @@ __device__ __forceinline__ void stab_lsq_inputs(const Geo& geo, const double bg[
   }
 }
 
+// gelsd mode: the systems of slots 0 .. nslot - 1 (laid out for class n: stab_lsq_slot_doubles(n, true) doubles each, the header
+// as stab_lsq_wave reads it), each solved by ONE lane -- lane s * G takes slot s -- with pct_gelsd.cuh on the slot's own
+// workspace.  All 64 lanes call; returns the system's notice in its solving lane.
+__device__ __forceinline__ bool stab_gelsd_slots(double* ws, int G, int n, int nslot, int lane, bool avx2) {
+  const size_t sd = stab_lsq_slot_doubles(n, true);
+  const int slot = lane / G;
+  bool ill = false;
+  if ((lane & (G - 1)) == 0 && slot < nslot) {
+    double* w = ws + (size_t)slot * sd;
+    const int k = (int)w[0];
+    if (k >= 3) gelsd::split_t(w + 4 + 3 * n, k, w + 4, w[1], w[2], StabDot2{avx2}, w + 4 + 2 * n, ill, avx2);
+  }
+  __syncthreads();
+  return ill;
+}
+
 // ---- the wave-cooperative driver ----------------------------------------------------------------------------------
 // LDS workspace of a wave: the hull workspace (shared by the level-0 tasks of a round) and the task queue.
 struct StabWave {
   double* lsq;   // workspace of the cooperative least-squares split (caps.lsq_bytes)
   int lsq_n, lsq_doubles;
+  bool gelsd, gelsd_avx2;  // caps.gelsd != 0 / == 2
+  int lsq_mode;            // caps.gelsd
   unsigned char* hull;
   int hull_bytes;
   uint32_t* ctl;    // [6] queue count, failed candidates (lanes 0..31, 32..63), global capacity error (STAB_WHY_*),
@@ -921,6 +995,9 @@ PCT_SD StabWave stab_wave_carve(unsigned char* base, const StabCaps& c) {
   w.lsq = reinterpret_cast<double*>(base);
   w.lsq_n = c.lsq_n;
   w.lsq_doubles = c.lsq_bytes / (int)sizeof(double);
+  w.gelsd = c.gelsd != 0;
+  w.gelsd_avx2 = c.gelsd == 2;
+  w.lsq_mode = c.gelsd;
   base += (size_t)c.lsq_bytes;
   // the hull workspace follows the least-squares workspace directly: in the passes of a round that work on popped tasks (whose
   // supporter lists are pool entries) it is idle, and further systems of the small size classes are solved in it
@@ -1037,7 +1114,7 @@ __device__ __forceinline__ bool stab_virtual_wave(const Geo& geo, const StabStat
         StabSplitX sx;
         sp.mode = 0;
         StabSup sup{supw};
-        if (have && !stab_split<CONT>(geo, bg, kk, sup, stk, sp, sx, ss, w.lsq_n)) {
+        if (have && !stab_split<CONT>(geo, bg, kk, sup, stk, sp, sx, ss, w.lsq_n, w.lsq_mode)) {
           atomicOr(&w.ctl[4 + (cl >> 5)], 1u << (cl & 31));
           have = false;
         }
@@ -1045,9 +1122,9 @@ __device__ __forceinline__ bool stab_virtual_wave(const Geo& geo, const StabStat
         for (uint64_t cm = __ballot(have && sp.mode == 4); cm;) {
           const int first = __ffsll((unsigned long long)cm) - 1;
           const int kf = __builtin_amdgcn_readlane(kk, first);
-          const int G = stab_lsq_group(kf), cn = stab_lsq_class_n(kf, w.lsq_n);
-          const size_t sd = stab_lsq_slot_doubles(cn);
-          const bool mine = ((cm >> lane) & 1ull) && stab_lsq_group(kk) == G;
+          const int G = stab_lsq_group(kf, w.gelsd), cn = stab_lsq_class_n(kf, w.lsq_n, w.gelsd);
+          const size_t sd = stab_lsq_slot_doubles(cn, w.gelsd);
+          const bool mine = ((cm >> lane) & 1ull) && stab_lsq_group(kk, w.gelsd) == G;
           const uint64_t mm = __ballot(mine);
           const int rk = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
           // systems of this class the workspace holds (with the hull workspace behind it when that is idle), at most one per lane group
@@ -1058,12 +1135,18 @@ __device__ __forceinline__ bool stab_virtual_wave(const Geo& geo, const StabStat
           __syncthreads();
           if (sel) stab_lsq_inputs<CONT>(geo, bg, kk, sup, stk, w.lsq + (size_t)rk * sd);
           __syncthreads();
-          const bool gill = stab_lsq_wave(w.lsq, G, cn, nslot, lane);
+          const bool gill = w.gelsd ? stab_gelsd_slots(w.lsq, G, cn, nslot, lane, w.gelsd_avx2) : stab_lsq_wave(w.lsq, G, cn, nslot, lane);
           // a system's notice comes back in its group's lanes: fetch the one of this lane's slot
           const uint64_t illm = __ballot(gill);
           if (sel) {
             const double* slot = w.lsq + (size_t)rk * sd;
-            for (int i = 0; i < kk; i++) sx.fx[i] = slot[4 + 2 * cn + i];
+            if (kk <= 5) {  // (gelsd mode only: up to five fractions live in registers, as after the per-lane solves)
+              sp.f[0] = slot[4 + 2 * cn]; sp.f[1] = slot[5 + 2 * cn]; sp.f[2] = slot[6 + 2 * cn];
+              sp.f[3] = kk > 3 ? slot[7 + 2 * cn] : 0.0;
+              sp.f[4] = kk > 4 ? slot[8 + 2 * cn] : 0.0;
+            } else {
+              for (int i = 0; i < kk; i++) sx.fx[i] = slot[4 + 2 * cn + i];
+            }
             sp.mode = 3;
             sp.ill = (illm >> (rk * G)) & 1ull;
           }
@@ -1360,7 +1443,7 @@ __device__ __forceinline__ int stab_commit_wave(const Geo& geo, StabState& st, i
             const double (*gp)[2] = reinterpret_cast<const double (*)[2]>(st.poly + (size_t)stab_poff(st, id) * 2);
             if (!stab_pip(stk, gp, stab_npoly(st, id))) { code = 1; break; }
             if (ss) ss->commit_visits++;
-            if (!stab_split<CONT>(geo, g, kk, sup, stk, sp, sx, ss, w.lsq_n)) { code = 2; break; }
+            if (!stab_split<CONT>(geo, g, kk, sup, stk, sp, sx, ss, w.lsq_n, w.lsq_mode)) { code = 2; break; }
             if (sp.mode == 4) {
               stab_lsq_inputs<CONT>(geo, g, kk, sup, stk, w.lsq);  // (slot 0)
               pend_k = kk;
@@ -1385,12 +1468,17 @@ __device__ __forceinline__ int stab_commit_wave(const Geo& geo, StabState& st, i
       break;
     }
     const int ks = __builtin_amdgcn_readfirstlane(pend_k);
-    const int G = stab_lsq_group(ks), cn = stab_lsq_class_n(ks, w.lsq_n);
-    const size_t sd = stab_lsq_slot_doubles(cn);
+    const int G = stab_lsq_group(ks, w.gelsd), cn = stab_lsq_class_n(ks, w.lsq_n, w.gelsd);
     __syncthreads();
-    const bool sill = stab_lsq_wave(w.lsq, G, cn, 1, lane);  // one system, in slot 0
+    const bool sill = w.gelsd ? stab_gelsd_slots(w.lsq, G, cn, 1, lane, w.gelsd_avx2) : stab_lsq_wave(w.lsq, G, cn, 1, lane);  // one system, in slot 0
     if (lane == 0) {
-      for (int i = 0; i < ks; i++) sx.fx[i] = w.lsq[4 + 2 * cn + i];
+      if (ks <= 5) {  // (gelsd mode only)
+        sp.f[0] = w.lsq[4 + 2 * cn]; sp.f[1] = w.lsq[5 + 2 * cn]; sp.f[2] = w.lsq[6 + 2 * cn];
+        sp.f[3] = ks > 3 ? w.lsq[7 + 2 * cn] : 0.0;
+        sp.f[4] = ks > 4 ? w.lsq[8 + 2 * cn] : 0.0;
+      } else {
+        for (int i = 0; i < ks; i++) sx.fx[i] = w.lsq[4 + 2 * cn + i];
+      }
       sp.mode = 3;
       sp.ill = sill;
       resume = true;

@@ -130,7 +130,7 @@ class PctVecEnv(VecEnv):
                  load_test_data=False, internal_node_holder=80, leaf_node_holder=50, LNES="EMS", shuffle=False,
                  sample_from_distribution=False, sample_left_bound=None, sample_right_bound=None,
                  device="cuda:0", seed=0, env_id_base=0, item_stream=None, continuous=False, monitor=True,
-                 strict=True, ems_capacity=0, candidate_capacity=0, overflow_retry=True, rng="counter"):
+                 strict=True, ems_capacity=0, candidate_capacity=0, overflow_retry=True, rng="counter", lstsq="jacobi"):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise PctEnvError("PctVecEnv runs on an AMD GPU only (device=%r); there is no CPU path" % (device,))
@@ -222,6 +222,15 @@ class PctVecEnv(VecEnv):
 
         if shuffle:
             _lib.check(self._L.pct_set_shuffle_seed(self._h, int(seed)))
+        # the solver behind np.linalg.lstsq in the stability check (settings 1 / 3): "jacobi" (default; the reference's solution up
+        # to the last bits) or "gelsd" (LAPACK dgelsd as the reference's NumPy executes it: bit-identical, slower) -- pct_env.h
+        # ("gelsd_avx2": as NumPy executes it on AVX2 hosts, AMD Zen included -- OpenBLAS' other kernel set)
+        modes = {"jacobi": _lib.LSTSQ_JACOBI, "gelsd": _lib.LSTSQ_GELSD, "gelsd_avx2": _lib.LSTSQ_GELSD_AVX2}
+        if lstsq not in modes:
+            raise ValueError("lstsq must be 'jacobi', 'gelsd' or 'gelsd_avx2'")
+        self.lstsq = lstsq
+        if lstsq != "jacobi":
+            _lib.check(self._L.pct_set_lstsq_mode(self._h, modes[lstsq]))
         # outputs live in torch tensors bound into the handle (zero copy)
         dev = self.device
         self._obs = torch.zeros(self.N, self.row_len, dtype=torch.float32, device=dev)

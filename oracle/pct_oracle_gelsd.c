@@ -44,6 +44,14 @@
 
 #define A_(i, j) a[(size_t)(i) + (size_t)(j) * (size_t)lda]
 
+/* Which of OpenBLAS' kernel sets is restated: 0 = "SkylakeX" (AVX-512 hosts; the build container, every fixture), 1 = "Haswell" (what
+ * OpenBLAS runs on AVX2 hosts, AMD Zen included: OPENBLAS_CORETYPE=HASWELL / ZEN).  The two differ in dgemv 'N' and in daxpy (dger);
+ * with them np.linalg.lstsq returns other last bits on 98 % of the stability systems (tests/golden/check_gelsd_port.py), and a run of
+ * the reference takes another path at a tie about once in 10^5 steps (profiles/r04_lstsq_ondomain.txt). */
+static int g_kernel_set = 0;
+void gelsd_set_kernel_set(int s) { g_kernel_set = s; }
+int gelsd_get_kernel_set(void) { return g_kernel_set; }
+
 /* ---- BLAS, as the SkylakeX kernel set computes it --------------------------------------------------------- */
 double gelsd_dnrm2(int n, const double* x, int incx) {
   if (n <= 0) return 0.0;
@@ -112,6 +120,33 @@ void gelsd_dgemv_n(int m, int n, double alpha, const double* a, int lda, const d
   for (int i = 0; i < m; i++) y[i] = 0.0;
   if (m <= 0 || n <= 0 || alpha == 0.0) return;
   const int m2 = m & ~3, n4 = n & ~3;
+  if (g_kernel_set == 1) {
+    /* Haswell: the 4x4 microkernel sums two FMA chains, (a0 x0 + a2 x2) + (a1 x1 + a3 x3); the pair kernel (unit stride) a0 x0 + a1 x1;
+     * y = fma(t, alpha, y); single columns as below; the C tails are compiled WITHOUT FMA */
+    for (int i = 0; i < m2; i++) {
+      double yi = 0.0;
+      for (int j = 0; j < n4; j += 4) {
+        double t4 = A_(i, j) * x[(size_t)j * incx], t5 = A_(i, j + 1) * x[(size_t)(j + 1) * incx];
+        t4 = fma(A_(i, j + 2), x[(size_t)(j + 2) * incx], t4);
+        t5 = fma(A_(i, j + 3), x[(size_t)(j + 3) * incx], t5);
+        yi = fma(t4 + t5, alpha, yi);
+      }
+      int j = n4;
+      if (incx == 1 && (n & 2)) {
+        const double t4 = A_(i, j) * x[j], t5 = A_(i, j + 1) * x[j + 1];
+        yi = fma(t4 + t5, alpha, yi);
+        j += 2;
+      }
+      for (; j < n; j++) yi = yi + A_(i, j) * (x[(size_t)j * incx] * alpha);
+      y[i] = yi;
+    }
+    for (int i = m2; i < m; i++) {
+      double t = 0.0;
+      for (int j = 0; j < n; j++) t = t + A_(i, j) * x[(size_t)j * incx];
+      y[i] = 0.0 + alpha * t;
+    }
+    return;
+  }
   for (int i = 0; i < m2; i++) {
     double yi = 0.0;
     for (int j = 0; j < n4; j += 4) {
@@ -142,7 +177,10 @@ void gelsd_dger(int m, int n, double alpha, const double* x, int incx, const dou
   if (m <= 0 || n <= 0 || alpha == 0.0) return;
   for (int j = 0; j < n; j++) {
     const double t = alpha * y[(size_t)j * incy];
-    for (int i = 0; i < m; i++) A_(i, j) = fma(t, x[(size_t)i * incx], A_(i, j));
+    /* Haswell daxpy: blocks of sixteen through the FMA microkernel, the rest multiply and add rounded separately */
+    const int mf = g_kernel_set == 1 ? (m & ~15) : m;
+    for (int i = 0; i < mf; i++) A_(i, j) = fma(t, x[(size_t)i * incx], A_(i, j));
+    for (int i = mf; i < m; i++) A_(i, j) = A_(i, j) + t * x[(size_t)i * incx];
   }
 }
 void gelsd_drot(int n, double* x, int incx, double* y, int incy, double c, double s) {
@@ -681,7 +719,17 @@ int gelsd_lstsq(const double* Arow, const double* brow, int M, int N, double* x,
     /* dgemm('T', 'N', N, 1, N, 1, VT, N, b, ., 0, wk, N) */
     for (int i = 0; i < N; i++) {
       double acc = 0.0;
-      for (int k = 0; k < N; k++) acc = fma(vt[k + (size_t)i * N], b[k], acc);
+      if (gelsd_get_kernel_set() == 1 && i < (N & ~3)) {
+        /* Haswell dgemm kernel, rows in groups of four: four accumulators over the leading blocks of eight k (k mod 4), the tail
+         * into the first, (a0 + a1) + (a2 + a3); the n mod 4 last rows one FMA chain */
+        double q[4] = {0, 0, 0, 0};
+        const int kb = N & ~7;
+        for (int k = 0; k < kb; k++) q[k & 3] = fma(vt[k + (size_t)i * N], b[k], q[k & 3]);
+        for (int k = kb; k < N; k++) q[0] = fma(vt[k + (size_t)i * N], b[k], q[0]);
+        acc = (q[0] + q[1]) + (q[2] + q[3]);
+      } else {
+        for (int k = 0; k < N; k++) acc = fma(vt[k + (size_t)i * N], b[k], acc);
+      }
       wk[i] = acc;
     }
     for (int i = 0; i < N; i++) b[i] = wk[i];

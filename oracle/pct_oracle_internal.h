@@ -134,6 +134,8 @@ void stab_set_ill_near(int on);
 void stab_set_lstsq_mode(int mode); /* 0: Jacobi stand-in (default), 1: dgelsd as NumPy's OpenBLAS executes it */
 int stab_get_lstsq_mode(void);
 /* pct_oracle_gelsd.c */
+void gelsd_set_kernel_set(int s); /* 0: OpenBLAS "SkylakeX" kernels (AVX-512 hosts), 1: "Haswell" (AVX2 hosts, AMD Zen) */
+int gelsd_get_kernel_set(void);
 int gelsd_lstsq(const double* Arow, const double* brow, int M, int N, double* x, int* rank_out, double* sv_out, int* near_cut);
 int stab_check(struct stab* s, double x, double y, double z, double lx, double ly, double max_h, double density,
                int virtual_);

@@ -43,7 +43,11 @@
  * acc = x0*y0; acc = fma(x1, y1, acc) -- ONE rounding for the second product and the sum, not two.  Measured
  * against np.dot on 200 000 random pairs (0 disagreements; the two-rounding form disagrees on 40 %).  It
  * decides the exactly-degenerate tests downstream (a stack centre on the line through a polygon edge). */
-static double dot2(double x0, double x1, double y0, double y1) { return fma(x1, y1, x0 * y0); }
+/* (...on hosts where OpenBLAS runs its SkylakeX kernel set -- AVX-512, the build container.  Its "Haswell" kernel set -- AVX2 hosts, AMD
+ * Zen included -- compiles that ddot's tail loop WITHOUT FMA: x0*y0 + x1*y1, three roundings; measured under OPENBLAS_CORETYPE=HASWELL,
+ * 20 000 of 20 000.  stab_set_lstsq_mode(2) selects that flavour together with the Haswell BLAS arithmetic of pct_oracle_gelsd.c.) */
+static int g_dot_plain = 0;
+static double dot2(double x0, double x1, double y0, double y1) { return g_dot_plain ? x0 * y0 + x1 * y1 : fma(x1, y1, x0 * y0); }
 
 typedef struct { double c[3]; double m; } sstack;
 typedef struct { int box; double area[4]; double c2[2]; } sdown; /* DownEdge */
@@ -207,17 +211,25 @@ static int point_in_polygon(const double pt[2], double (*co)[2], int n) {
  * and then disagrees with LAPACK by up to 5e-3 on the nearly rank-deficient systems this check produces. */
 static int g_lstsq_mode = 0; /* 0: the Jacobi stand-in below (what the kernels run by default), 1: LAPACK dgelsd as the
                                 reference's NumPy executes it (pct_oracle_gelsd.c) */
-void stab_set_lstsq_mode(int mode) { g_lstsq_mode = mode; }
-int stab_get_lstsq_mode(void) { return g_lstsq_mode; }
+void stab_set_lstsq_mode(int mode) { /* 0: Jacobi; 1: dgelsd, AVX-512 kernel set; 2: dgelsd, AVX2 (Haswell / Zen) kernel set */
+  g_lstsq_mode = mode != 0;
+  gelsd_set_kernel_set(mode == 2);
+  g_dot_plain = mode == 2;
+}
+int stab_get_lstsq_mode(void) { return g_lstsq_mode ? 1 + gelsd_get_kernel_set() : 0; }
 static void lstsq_min_norm(const double* A, const double* b, int M, int N, double* x) {
   if (g_lstsq_mode == 1) {
     double sv[64];
     int near_cut = 0;
-    if (N <= 64 && gelsd_lstsq(A, b, M, N, x, NULL, sv, &near_cut) == 0) {
+    if (N <= 64) {
+      if (gelsd_lstsq(A, b, M, N, x, NULL, sv, &near_cut) != 0) { /* dbdsqr did not converge: NumPy raises LinAlgError there */
+        for (int i = 0; i < N; i++) x[i] = 0;
+        near_cut = 1;
+      }
       if (near_cut) g_ill = 1;
       return;
     }
-    g_ill = 1; /* (more than 64 supporters, or no convergence: NumPy would raise) -- the stand-in takes over */
+    g_ill = 1; /* (more than 64 supporters: the stand-in takes over) */
   }
   double* U = (double*)malloc(sizeof(double) * (size_t)M * N);
   double* V = (double*)malloc(sizeof(double) * (size_t)N * N);

@@ -9,7 +9,8 @@ scipy_<name>_64_) and every routine of the restatement is compared BIT FOR BIT w
   3. the whole solve against np.linalg.lstsq: systems built the way the reference builds them (k = 3 .. 25 supporters, integer,
      3-decimal and highly degenerate geometry -> rank-deficient systems) and the systems recorded from reference runs
   4. --write-fixture: tests/golden/lstsq_systems.npz (recorded + constructed systems with NumPy's x / rank / singular values), the
-     vectors tests/test_gelsd_port.py checks on any machine
+     vectors tests/test_gelsd_port.py checks on any machine (lstsq_systems_avx2.npz when run with OPENBLAS_CORETYPE=HASWELL: the
+     kernel set of AVX2 hosts, checked against the restatement's AVX2 flavour)
   5. --streams: the unmodified reference against the oracle in gelsd mode on the adversarial flat-item streams of
      check_lstsq_limit.py (17 of 56 env-runs part ways under the Jacobi stand-in) -- every observation compared
 
@@ -214,9 +215,14 @@ def main():
     L, core, cfg = openblas()
     G = C.CDLL(oracle_lib.build())
     print("NumPy %s; bundled OpenBLAS: %s; kernel set in use: %s" % (np.__version__, cfg.strip(), core))
-    if core != "SkylakeX":
-        print("NOTE: oracle/pct_oracle_gelsd.c restates the SkylakeX kernel set; on this host OpenBLAS runs %s kernels -- mismatches "
-              "below are then the reference differing from ITSELF across machines (profiles/r04_lstsq_ondomain.txt)" % core)
+    if core == "Haswell":  # (OPENBLAS_CORETYPE=HASWELL / ZEN, or an AVX2 host)
+        oracle_lib.set_lstsq_mode(oracle_lib.LSTSQ_GELSD_AVX2)
+        oracle_lib.set_lstsq_mode(oracle_lib.LSTSQ_JACOBI)  # (the kernel set stays selected for the direct calls below)
+        G.gelsd_set_kernel_set(1)
+        print("OpenBLAS runs its Haswell kernel set here: checking the restatement's AVX2 flavour (LSTSQ_GELSD_AVX2)")
+    elif core != "SkylakeX":
+        print("NOTE: oracle/pct_oracle_gelsd.c restates the SkylakeX and Haswell kernel sets; on this host OpenBLAS runs %s kernels -- "
+              "mismatches below are then the reference differing from ITSELF across machines (profiles/r04_lstsq_ondomain.txt)" % core)
     rng = np.random.default_rng(20260925)
     bad = check_blas(L, G, rng, a.trials)
     print("1. BLAS kernels, %d random calls each: mismatches %s" % (a.trials, bad))
@@ -267,10 +273,11 @@ def main():
             X[i, :Ns[i]] = np.asarray(w[0]).ravel()
             S[i, :Ns[i]] = w[3]
             R[i] = int(w[2])
-        np.savez_compressed(os.path.join(HERE, "lstsq_systems.npz"), M=Ms, N=Ns, A=Aflat, x=X, sv=S, rank=R,
+        fname = "lstsq_systems_avx2.npz" if core == "Haswell" else "lstsq_systems.npz"
+        np.savez_compressed(os.path.join(HERE, fname), M=Ms, N=Ns, A=Aflat, x=X, sv=S, rank=R,
                             meta=np.array("np.linalg.lstsq(A, e_M, rcond=None) of NumPy %s (%s, %s kernels); A row-major, b = last unit "
                                           "vector" % (np.__version__, cfg.strip(), core)))
-        print("4. wrote tests/golden/lstsq_systems.npz: %d systems" % n)
+        print("4. wrote tests/golden/%s: %d systems" % (fname, n))
     if a.streams:
         import gen_golden as g
         for label, mode in (("Jacobi stand-in", oracle_lib.LSTSQ_JACOBI), ("gelsd restatement", oracle_lib.LSTSQ_GELSD)):

@@ -26,7 +26,8 @@ def chunk(job):
     import gen_golden as g
     kind, case = job
     from oracle import oracle_lib
-    oracle_lib.set_lstsq_mode(oracle_lib.LSTSQ_GELSD if case.pop("lstsq", "jacobi") == "gelsd" else oracle_lib.LSTSQ_JACOBI)
+    oracle_lib.set_lstsq_mode({"jacobi": oracle_lib.LSTSQ_JACOBI, "gelsd": oracle_lib.LSTSQ_GELSD,
+                               "gelsd_avx2": oracle_lib.LSTSQ_GELSD_AVX2}[case.pop("lstsq", "jacobi")])
     g.LSTSQ["calls"] = 0
     if kind == "discrete":
         ref = g.run_reference(case)
@@ -53,8 +54,10 @@ def main():
     ap.add_argument("--continuous-steps", type=int, default=200000)
     ap.add_argument("--seed0", type=int, default=100000)
     ap.add_argument("--setting", type=int, default=1, choices=[1, 3], help="1: unit densities; 3: per-item densities (scripted)")
-    ap.add_argument("--lstsq", default="jacobi", choices=["jacobi", "gelsd"],
-                    help="the oracle's solver: the Jacobi stand-in (the kernels' default) or the dgelsd restatement (pct_oracle_gelsd.c)")
+    ap.add_argument("--lstsq", default="jacobi", choices=["jacobi", "gelsd", "gelsd_avx2"],
+                    help="the oracle's solver: the Jacobi stand-in (the kernels' default) or the dgelsd restatement (pct_oracle_gelsd.c) with "
+                         "OpenBLAS' SkylakeX kernel arithmetic (gelsd) / its Haswell one (gelsd_avx2: run the reference with "
+                         "OPENBLAS_CORETYPE=HASWELL, or on an AVX2 host)")
     ap.add_argument("--only-discrete-seeds", default="", help="comma-separated chunk seeds: run just these discrete chunks")
     a = ap.parse_args()
     # the C1 domain (configs[0]: setting 1, 10^3, items 1..5, 80 / 50) and the continuous setting-1 unit bin of c3s1
@@ -75,7 +78,8 @@ def main():
         nd, nc = len(jobs), 0
     print("On-domain sample of the least-squares stand-in: unmodified reference (np.linalg.lstsq = LAPACK dgelsd) vs the C oracle")
     print("(%s), same scripted item streams, stand-in policy, every observation / reward / done / counter / ratio compared."
-          % ("one-sided Jacobi SVD" if a.lstsq == "jacobi" else "--lstsq gelsd: oracle/pct_oracle_gelsd.c, dgelsd operation for operation"))
+          % ("one-sided Jacobi SVD" if a.lstsq == "jacobi" else "--lstsq %s: oracle/pct_oracle_gelsd.c, dgelsd operation for operation" % a.lstsq))
+    print("OPENBLAS_CORETYPE=%s" % os.environ.get("OPENBLAS_CORETYPE", "(native)"))
     print("discrete: %s\ncontinuous: %s" % (dcase, ccase))
     print("%d + %d chunks on %d processes" % (nd, nc, a.procs), flush=True)
     tot = {k: dict(steps=0, calls=0, runs=0, div=0, episodes=0, same=0) for k in ("discrete", "continuous")}

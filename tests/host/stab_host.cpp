@@ -67,6 +67,22 @@ void stab_free(struct stab* s) {
 int stab_overflowed(struct stab* s) { return s->overflow; }
 int stab_ill_conditioned(struct stab* s) { return s->ill; }
 void stab_set_ill_near(int) {}  // (the tie notice is an analysis mode of the oracle only)
+// the product's PCT_LSTSQ_GELSD (csrc/pct_gelsd.cuh compiled for the host) under the oracle's switch
+void stab_set_lstsq_mode(int mode) { pct::g_stab_host_gelsd = mode; }
+int stab_get_lstsq_mode(void) { return pct::g_stab_host_gelsd; }
+// pct_oracle.h exports the oracle's own restatement under this name; here it is the PRODUCT's solve (geometry-free entry for tests):
+// row-major M x N system with the right-hand side e_M is not what the product takes, so tests/test_stab_host.py uses gelsd_host_split
+int gelsd_lstsq(const double*, const double*, int, int, double*, int*, double*, int*) { return -1; }
+int gelsd_host_split(int k, const double* centres, double s0, double s1, double* x, int* ill) {
+  std::vector<double> ws((size_t)pct::gelsd::solve_doubles(k) + 2, 0.0);
+  bool i2 = false;
+  const bool ok = pct::gelsd::split_t(ws.data(), k, centres, s0, s1, pct::StabDot2{pct::g_stab_host_gelsd == 2}, x, i2, pct::g_stab_host_gelsd == 2);
+  *ill = i2;
+  return ok;
+}
+double gelsd_host_dnrm2(int n, const double* x, int incx) { return pct::gelsd::dnrm2(n, x, incx); }
+// dbdsqr('U', n, ncvt = n, 0, 1): d[n], e[n - 1], vt[n * n] (column-major), c[n], work[4 n]
+int gelsd_host_dbdsqr(int n, double* d, double* e, double* vt, double* c, double* work) { return pct::gelsd::dbdsqr(n, d, e, vt, c, work) ? 0 : 1; }
 
 int stab_check(struct stab* s, double x, double y, double z, double lx, double ly, double max_h, double density,
                int virtual_) {

@@ -24,8 +24,11 @@ def gelsd_mode():
     oracle_lib.set_lstsq_mode(old)
 
 
-def _systems():
-    z = np.load(os.path.join(HERE, "golden", "lstsq_systems.npz"))
+FLAVOURS = [("lstsq_systems.npz", oracle_lib.LSTSQ_GELSD), ("lstsq_systems_avx2.npz", oracle_lib.LSTSQ_GELSD_AVX2)]
+
+
+def _systems(fname="lstsq_systems.npz"):
+    z = np.load(os.path.join(HERE, "golden", fname))
     off = 0
     for i in range(len(z["M"])):
         m, n = int(z["M"][i]), int(z["N"][i])
@@ -36,19 +39,38 @@ def _systems():
         yield a, b, z["x"][i, :n], int(z["rank"][i]), z["sv"][i, :n]
 
 
-def test_gelsd_port_reproduces_numpy_bit_for_bit():
-    """x, the effective rank and the singular values of every committed system: identical to what NumPy 2.2.6 (OpenBLAS 0.3.29,
-    AVX-512 kernel set) returned in the build container -- 3 .. 16 supporters, rank-deficient systems included"""
+@pytest.mark.parametrize("fname,mode", FLAVOURS)
+def test_gelsd_port_reproduces_numpy_bit_for_bit(fname, mode):
+    """x, the effective rank and the singular values of every committed system: identical to what NumPy 2.2.6 (OpenBLAS 0.3.29)
+    returned in the build container -- 3 .. 16 supporters, rank-deficient systems included -- with its AVX-512 kernel set
+    (lstsq_systems.npz, LSTSQ_GELSD) and with the kernel set of AVX2 hosts (OPENBLAS_CORETYPE=HASWELL: lstsq_systems_avx2.npz,
+    LSTSQ_GELSD_AVX2).  The two recordings are the same systems; their solutions differ in the last bits on most of them."""
+    old = oracle_lib.set_lstsq_mode(mode)  # (selects the kernel set the direct call below uses)
+    oracle_lib.set_lstsq_mode(old)
+    import ctypes
+    ctypes.CDLL(oracle_lib.build()).gelsd_set_kernel_set(1 if mode == oracle_lib.LSTSQ_GELSD_AVX2 else 0)
     n = deficient = 0
     sizes = set()
-    for a, b, x, rank, sv in _systems():
+    for a, b, x, rank, sv in _systems(fname):
         x2, rank2, sv2, _ = oracle_lib.gelsd_lstsq(a, b)
         assert np.array_equal(x, x2), (n, a.shape)
         assert rank == rank2 and np.array_equal(sv, sv2), (n, a.shape)
         n += 1
         deficient += rank < a.shape[1]
         sizes.add(a.shape[1])
+    ctypes.CDLL(oracle_lib.build()).gelsd_set_kernel_set(0)
     assert n > 1000 and deficient > 0 and {3, 4, 5, 6, 8, 16} <= sizes
+
+
+def test_the_two_kernel_sets_give_numpy_other_last_bits():
+    """the reference's np.linalg.lstsq is a property of the machine: of the same 1066 systems the AVX-512 and the AVX2 recording
+    agree bit for bit on a minority"""
+    same = total = 0
+    for (a, _, x, _, _), (a2, _, x2, _, _) in zip(_systems("lstsq_systems.npz"), _systems("lstsq_systems_avx2.npz")):
+        if np.array_equal(a, a2):
+            total += 1
+            same += np.array_equal(x, x2)
+    assert total > 500 and same < 0.5 * total, (same, total)
 
 
 def test_gelsd_port_is_a_least_squares_solution():
@@ -96,3 +118,31 @@ def test_oracle_gelsd_mode_follows_the_reference_through_the_rank_cut(gelsd_mode
     assert np.array_equal(env.obs.astype(np.float32), z["obs"][c["steps"]])
     assert env.ill_conditioned()[0]  # the notice is still raised: a singular value within 1e3 of the cut
     env.close()
+
+
+@pytest.mark.parametrize("name", ["discrete_s1_ondomain_avx2", "discrete_s1_flat_lstsq_avx2"])
+def test_oracle_avx2_flavour_matches_reference_on_avx2_kernels(name):
+    """tests/golden/gen_golden_avx2.py: the unmodified reference with NumPy's OpenBLAS forced onto the kernel set of AVX2 hosts (AMD Zen
+    included).  LSTSQ_GELSD_AVX2 follows it; on discrete_s1_ondomain_avx2 the AVX-512 flavour leaves that recording at step 115 of env
+    1 -- exactly where the reference on an AVX-512 host and the reference on an AVX2 host part ways (profiles/r04_lstsq_ondomain.txt)"""
+    c, z = load_case(name)
+    for mode in (oracle_lib.LSTSQ_GELSD_AVX2, oracle_lib.LSTSQ_GELSD):
+        old = oracle_lib.set_lstsq_mode(mode)
+        try:
+            env = OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"], item_set=case_items(c),
+                               internal_node_holder=c["I"], leaf_node_holder=c["L"], env_id_base=c["base"])
+            env.set_item_stream(z["stream"])
+            env.reset()
+            first = np.full(c["N"], -1)
+            for t in range(c["steps"] + 1):
+                bad = (env.obs.astype(np.float32) != z["obs"][t]).any(1)
+                first = np.where((first < 0) & bad, t, first)
+                if t < c["steps"]:
+                    env.step_hash_policy(1)
+            env.close()
+        finally:
+            oracle_lib.set_lstsq_mode(old)
+        if mode == oracle_lib.LSTSQ_GELSD_AVX2:
+            assert (first < 0).all(), first
+        else:
+            assert np.array_equal(first, z["first_difference_from_avx512"]), first

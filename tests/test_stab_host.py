@@ -102,3 +102,227 @@ def test_product_stability_continuous_matches_reference_fixture(name):
             env.step_hash_policy(1)
             assert np.array_equal(env.done, z["done"][t]) and np.array_equal(env.reward, z["reward"][t])
         env.close()
+
+
+# ---- PCT_LSTSQ_GELSD: the product's dgelsd (csrc/pct_gelsd.cuh), compiled for the host ---------------------------------------
+class _Gelsd(object):
+    """the loaded oracle library (plain or variant) in gelsd mode"""
+
+    def __init__(self, mode=None):
+        self.mode = ol.LSTSQ_GELSD if mode is None else mode
+
+    def __enter__(self):
+        self.old = ol.set_lstsq_mode(self.mode)
+
+    def __exit__(self, *a):
+        ol.set_lstsq_mode(self.old)
+
+
+@pytest.mark.parametrize("name", ["discrete_s1_flat_lstsq", "discrete_s3_flat_lstsq", "discrete_s1_flat20", "discrete_s1_10_80_50",
+                                  "discrete_s1_flat_diverging"])
+def test_product_gelsd_matches_reference_fixture(name):
+    """the kernels' strict solver against the unmodified reference: thousands of least-squares splits over up to eight
+    supporters, and -- discrete_s1_flat_diverging -- the stream on which the default Jacobi solver parts ways at step 79"""
+    c, z = load_case(name)
+    with _Variant(), _Gelsd():
+        env = ol.OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"], item_set=case_items(c),
+                              internal_node_holder=c["I"], leaf_node_holder=c["L"], env_id_base=c["base"])
+        env.set_item_stream(z["stream"])
+        if case_density(z) is not None:
+            env.set_density_stream(case_density(z))
+        env.reset()
+        for t in range(c["steps"]):
+            assert np.array_equal(env.obs.astype(np.float32), z["obs"][t]), (name, t)
+            env.step_hash_policy(1)
+        assert np.array_equal(env.obs.astype(np.float32), z["obs"][c["steps"]])
+        env.close()
+
+
+@pytest.mark.parametrize("name", ["continuous_s1_flat_lstsq", "continuous_s1_unit_80_50"])
+def test_product_gelsd_continuous_matches_reference_fixture(name):
+    c, z = load_case(name)
+    with _Variant(), _Gelsd():
+        env = ol.OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"], env_kind=1,
+                              sample_bounds=(c["lo"], c["hi"]), internal_node_holder=c["I"], leaf_node_holder=c["L"],
+                              env_id_base=c["base"])
+        env.set_item_stream(z["stream"])
+        env.reset()
+        for t in range(c["steps"]):
+            assert np.array_equal(env.obs, z["obs"][t]), (name, t)
+            env.step_hash_policy(1)
+        env.close()
+
+
+def test_product_gelsd_equals_oracle_gelsd_on_flat_streams():
+    """product source vs the oracle's own restatement (two independently written dgelsd, one with long double, one with integer
+    x87 arithmetic), both in gelsd mode: observations, dones and the ill-conditioning notice over wide flat items on a 20^3 bin"""
+    items = [(x, y, 1) for x in range(2, 9) for y in range(2, 9)]
+    stream = make_stream(4242, 16, 2048, items)
+    kw = dict(setting=1, container_size=(20, 20, 20), item_set=items, internal_node_holder=400, leaf_node_holder=50)
+    with _Gelsd():
+        a = ol.OracleVecEnv(16, **kw)
+        a.set_item_stream(stream)
+        a.reset()
+        ref_obs, ref_done, ref_ill = [], [], []
+        for t in range(400):
+            ref_obs.append(a.obs.copy())
+            a.step_hash_policy(1)
+            ref_done.append(a.done.copy())
+            ref_ill.append(a.ill_conditioned().copy())
+        a.close()
+    with _Variant(), _Gelsd():
+        b = ol.OracleVecEnv(16, **kw)
+        b.set_item_stream(stream)
+        b.reset()
+        for t in range(400):
+            assert np.array_equal(b.obs, ref_obs[t]), t
+            b.step_hash_policy(1)
+            assert np.array_equal(b.done, ref_done[t]), t
+            assert np.array_equal(b.ill_conditioned(), ref_ill[t]), t
+        b.close()
+
+
+def test_product_x87_dnrm2_equals_long_double():
+    """pct_gelsd.cuh emulates OpenBLAS' x87 dnrm2 (80-bit squares and sums, fsqrt, one rounding to double) with 64-bit integer
+    mantissas; the oracle computes the same with the FPU's long double"""
+    plain = ctypes.CDLL(ol.build())
+    plain.gelsd_dnrm2.restype = ctypes.c_double
+    with _Variant():
+        var = ctypes.CDLL(VARIANT)
+    var.gelsd_host_dnrm2.restype = ctypes.c_double
+    rng = np.random.default_rng(8)
+    for t in range(20000):
+        n = int(rng.integers(1, 130))
+        inc = int(rng.integers(1, 4))
+        x = rng.standard_normal(n * inc) * 10.0 ** (rng.integers(-140, 140) if t % 4 == 0 else rng.integers(-3, 4))
+        if t % 7 == 0:
+            x[rng.integers(0, len(x))] = 0.0
+        if t % 5 == 0:
+            x = np.round(x * 8) / 8  # many exactly representable squares / ties
+        p = x.ctypes.data_as(ctypes.c_void_p)
+        assert plain.gelsd_dnrm2(ctypes.c_int(n), p, ctypes.c_int(inc)) == var.gelsd_host_dnrm2(ctypes.c_int(n), p, ctypes.c_int(inc)), t
+
+
+def test_product_gelsd_split_equals_recorded_numpy_solutions():
+    """the product's split (geometry -> system -> dgelsd) on geometry whose dot products are exact in double on any machine
+    (half-integer coordinates), against the oracle's restatement fed the same system -- which tests/test_gelsd_port.py pins to NumPy"""
+    with _Variant():
+        var = ctypes.CDLL(VARIANT)
+    rng = np.random.default_rng(12)
+    deficient = 0
+    for t in range(3000):
+        k = int(rng.choice([3, 3, 4, 5, 6, 8, 11, 16]))
+        pts = rng.integers(0, 40 if t % 2 else 6, (k, 2)) / 2.0  # (the narrow grid: collinear / repeated centres, dropped rows)
+        com = rng.integers(0, 80 if t % 2 else 12, 2) / 4.0
+        M = k * (k - 1) // 2 + 1
+        A = np.zeros((M, k))
+        b = np.zeros(M)
+        r = 0
+        for i in range(k - 1):
+            for j in range(i + 1, k):
+                tv = pts[i] - pts[j]
+                mol = float((com - pts[i]) @ tv)
+                if mol != 0:
+                    A[r, i] = 1
+                    A[r, j] = -abs(float((com - pts[j]) @ tv)) / mol
+                r += 1
+        A[-1, :] = 1
+        b[-1] = 1
+        x, rank, sv, near = ol.gelsd_lstsq(A, b)
+        deficient += rank < k
+        x2 = np.zeros(k)
+        ill = ctypes.c_int(0)
+        cen = np.ascontiguousarray(pts)
+        ok = var.gelsd_host_split(ctypes.c_int(k), cen.ctypes.data_as(ctypes.c_void_p), ctypes.c_double(com[0]), ctypes.c_double(com[1]),
+                                  x2.ctypes.data_as(ctypes.c_void_p), ctypes.byref(ill))
+        assert ok and np.array_equal(x, x2) and bool(ill.value) == near, (t, k)
+    assert deficient > 5
+
+
+def test_product_dbdsqr_equals_oracle_dbdsqr():
+    """the bidiagonal SVD sweeps (zero-shift and shifted, chasing downwards and upwards -- written once for both directions in the
+    product, four times as in LAPACK in the oracle): singular values, V^T and the rotated right-hand side, bit for bit, on graded,
+    split and random bidiagonals"""
+    plain = ctypes.CDLL(ol.build())
+    plain.gelsd_dbdsqr.restype = ctypes.c_int
+    with _Variant():
+        var = ctypes.CDLL(VARIANT)
+    rng = np.random.default_rng(31)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    for t in range(6000):
+        n = int(rng.integers(1, 17))
+        d, e = rng.standard_normal(n), rng.standard_normal(max(n - 1, 1))
+        if t % 3 == 0:
+            d = d * 10.0 ** rng.integers(-9, 1, n)  # graded: zero-shift sweeps
+        if t % 4 == 0:
+            d = d[::-1].copy()                       # larger end at the bottom: the upward chase
+        if t % 5 == 0:
+            e[rng.integers(0, len(e))] = 0.0         # a split
+        if t % 7 == 0:
+            d[rng.integers(0, n)] = 0.0
+        vt, c = np.asfortranarray(np.eye(n)), rng.standard_normal(n)
+        d2, e2, vt2, c2 = d.copy(), e.copy(), vt.copy(order="F"), c.copy()
+        i1 = plain.gelsd_dbdsqr(ctypes.c_int(n), ctypes.c_int(n), P(d), P(e), P(vt), ctypes.c_int(n), P(c), P(np.zeros(4 * n + 8)))
+        i2 = var.gelsd_host_dbdsqr(ctypes.c_int(n), P(d2), P(e2), P(vt2), P(c2), P(np.zeros(4 * n + 8)))
+        assert i1 == i2 and np.array_equal(d, d2) and np.array_equal(vt, vt2) and np.array_equal(c, c2), (t, n)
+
+
+@pytest.mark.parametrize("name", ["discrete_s1_ondomain_avx2", "discrete_s1_flat_lstsq_avx2"])
+def test_product_gelsd_avx2_matches_reference_on_avx2_kernels(name):
+    """PCT_LSTSQ_GELSD_AVX2 in the product's source: the reference as it runs on AVX2 hosts (tests/golden/gen_golden_avx2.py)"""
+    c, z = load_case(name)
+    with _Variant(), _Gelsd(ol.LSTSQ_GELSD_AVX2):
+        env = ol.OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"], item_set=case_items(c),
+                              internal_node_holder=c["I"], leaf_node_holder=c["L"], env_id_base=c["base"])
+        env.set_item_stream(z["stream"])
+        env.reset()
+        for t in range(c["steps"]):
+            assert np.array_equal(env.obs.astype(np.float32), z["obs"][t]), (name, t)
+            env.step_hash_policy(1)
+        assert np.array_equal(env.obs.astype(np.float32), z["obs"][c["steps"]])
+        env.close()
+
+
+def test_product_gelsd_avx2_split_equals_oracle_avx2():
+    """both flavours of the product's split against the oracle's restatement with the same kernel set, on geometry with exact dot
+    products; and the two flavours differ from each other on most systems"""
+    with _Variant():
+        var = ctypes.CDLL(VARIANT)
+    plain = ctypes.CDLL(ol.build())
+    rng = np.random.default_rng(13)
+    differ = total = 0
+    for t in range(1500):
+        k = int(rng.choice([3, 4, 5, 6, 8, 9, 12, 16]))
+        pts = rng.integers(0, 40, (k, 2)) / 2.0
+        com = rng.integers(0, 80, 2) / 4.0
+        M = k * (k - 1) // 2 + 1
+        A = np.zeros((M, k))
+        b = np.zeros(M)
+        r = 0
+        for i in range(k - 1):
+            for j in range(i + 1, k):
+                tv = pts[i] - pts[j]
+                mol = float((com - pts[i]) @ tv)
+                if mol != 0:
+                    A[r, i] = 1
+                    A[r, j] = -abs(float((com - pts[j]) @ tv)) / mol
+                r += 1
+        A[-1, :] = 1
+        b[-1] = 1
+        xs = []
+        for mode in (1, 2):
+            plain.gelsd_set_kernel_set(mode - 1)
+            x, rank, sv, near = ol.gelsd_lstsq(A, b)
+            var.stab_set_lstsq_mode(mode)
+            x2 = np.zeros(k)
+            ill = ctypes.c_int(0)
+            cen = np.ascontiguousarray(pts)
+            ok = var.gelsd_host_split(ctypes.c_int(k), cen.ctypes.data_as(ctypes.c_void_p), ctypes.c_double(com[0]), ctypes.c_double(com[1]),
+                                      x2.ctypes.data_as(ctypes.c_void_p), ctypes.byref(ill))
+            assert ok and np.array_equal(x, x2), (t, k, mode)
+            xs.append(x2)
+        total += 1
+        differ += not np.array_equal(xs[0], xs[1])
+    plain.gelsd_set_kernel_set(0)
+    var.stab_set_lstsq_mode(0)
+    assert differ > 0.5 * total

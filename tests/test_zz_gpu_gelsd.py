@@ -1,0 +1,135 @@
+"""GPU: pct_set_lstsq_mode(PCT_LSTSQ_GELSD) -- the kernels' strict least-squares solver (csrc/pct_gelsd.cuh: LAPACK dgelsd as the
+reference's NumPy executes it) against the unmodified reference's fixtures and against the oracle's independent restatement
+(oracle/pct_oracle_gelsd.c) on the same seeded inputs.  Bit-exact, through the C ABI via PctVecEnv(lstsq="gelsd").
+
+(The file sorts last on purpose: these are the round-4 additions; the suites of the default solver run before them.)"""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle_lib
+from oracle.oracle_lib import OracleVecEnv
+from tests.common import case_density, case_items, load_case, make_stream
+
+pytestmark = pytest.mark.gpu
+
+
+def _pkg():
+    return importlib.import_module("online-3d-bpp-pct_amd")
+
+
+@pytest.fixture
+def oracle_gelsd():
+    old = oracle_lib.set_lstsq_mode(oracle_lib.LSTSQ_GELSD)
+    yield
+    oracle_lib.set_lstsq_mode(old)
+
+
+@pytest.mark.parametrize("name", ["discrete_s1_flat_diverging", "discrete_s1_flat_lstsq", "discrete_s3_flat_lstsq", "discrete_s1_flat20",
+                                  "discrete_s1_10_80_50"])
+def test_hip_gelsd_matches_reference_fixture(name):
+    """the unmodified reference's recordings: every observation of every env.  discrete_s1_flat_diverging is the stream on
+    which the default solver leaves the reference at step 79 (tests/test_gpu_parity.py::test_hip_notice_precedes_...): in
+    gelsd mode the kernels follow the reference through that rank decision to the end of the recording."""
+    c, z = load_case(name)
+    env = _pkg().PctVecEnv(c["N"], setting=c["setting"], container_size=c["container"], item_set=case_items(c),
+                           internal_node_holder=c["I"], leaf_node_holder=c["L"], env_id_base=c["base"], item_stream=z["stream"],
+                           device="cuda:0", lstsq="gelsd")
+    if case_density(z) is not None:
+        env.set_density_stream(case_density(z))
+    obs = env.reset()
+    for t in range(c["steps"]):
+        assert np.array_equal(obs.cpu().numpy(), z["obs"][t]), (name, t)
+        env.step_hash_policy(1)
+        obs, reward, done, _ = env.step_wait()
+        assert np.array_equal(done.astype(np.uint8), z["done"][t]), (name, t)
+    assert np.array_equal(obs.cpu().numpy(), z["obs"][c["steps"]])
+    assert not env.error_flags.any()
+    if name == "discrete_s1_flat_diverging":
+        assert env.ill_conditioned[0]  # the notice is still raised at the rank cut
+    env.close()
+
+
+@pytest.mark.parametrize("name", ["continuous_s1_flat_lstsq", "continuous_s1_unit_80_50"])
+def test_hip_gelsd_continuous_matches_reference_fixture(name):
+    c, z = load_case(name)
+    env = _pkg().PctVecEnv(c["N"], setting=c["setting"], container_size=c["container"], continuous=True, sample_left_bound=c["lo"],
+                           sample_right_bound=c["hi"], internal_node_holder=c["I"], leaf_node_holder=c["L"], env_id_base=c["base"],
+                           item_stream=z["stream"], device="cuda:0", lstsq="gelsd")
+    obs = env.reset()
+    for t in range(c["steps"]):
+        assert np.array_equal(obs.cpu().numpy(), z["obs"][t].astype(np.float32)), (name, t)
+        env.step_hash_policy(1)
+        obs, _, _, _ = env.step_wait()
+    assert not env.error_flags.any()
+    env.close()
+
+
+@pytest.mark.parametrize("kind", ["c1", "wide_flat", "continuous"])
+def test_hip_gelsd_matches_oracle_gelsd(kind, oracle_gelsd):
+    """kernels and oracle both in gelsd mode on seeded streams: observations after every step, dones, counters and the
+    ill-conditioning notice.  c1: the C1 domain at 1024 envs; wide_flat: flat items on a 20^3 bin (splits over up to 16
+    supporters: the retry pass's workspace class); continuous: the unit-bin setting-1 domain."""
+    if kind == "c1":
+        N, steps = 1024, 150
+        items = [(a, b, c) for a in range(1, 6) for b in range(1, 6) for c in range(1, 6)]
+        kw = dict(setting=1, container_size=(10, 10, 10), item_set=items, internal_node_holder=80, leaf_node_holder=50, env_id_base=3)
+        stream = make_stream(77, N, 1024, items)
+        env = _pkg().PctVecEnv(N, item_stream=stream, device="cuda:0", lstsq="gelsd", **kw)
+        ora = OracleVecEnv(N, **kw)
+        ora.set_item_stream(stream)
+    elif kind == "wide_flat":
+        N, steps = 48, 300
+        items = [(x, y, 1) for x in range(2, 9) for y in range(2, 9)]
+        kw = dict(setting=1, container_size=(20, 20, 20), item_set=items, internal_node_holder=400, leaf_node_holder=50, env_id_base=5)
+        stream = make_stream(4242, N, 2048, items)
+        env = _pkg().PctVecEnv(N, item_stream=stream, device="cuda:0", lstsq="gelsd", **kw)
+        ora = OracleVecEnv(N, **kw)
+        ora.set_item_stream(stream)
+    else:
+        N, steps = 256, 120
+        env = _pkg().PctVecEnv(N, setting=1, container_size=(1, 1, 1), continuous=True, sample_left_bound=0.1, sample_right_bound=0.5,
+                               internal_node_holder=80, leaf_node_holder=50, seed=21, env_id_base=9, device="cuda:0", lstsq="gelsd")
+        ora = OracleVecEnv(N, setting=1, container_size=(1, 1, 1), env_kind=1, sample_bounds=(0.1, 0.5), internal_node_holder=80,
+                           leaf_node_holder=50, env_id_base=9)
+        ora.set_sampler(21)
+    obs = env.reset()
+    ora.reset()
+    for t in range(steps):
+        assert np.array_equal(obs.cpu().numpy(), ora.obs.astype(np.float32)), (kind, t)
+        env.step_hash_policy(1)
+        ora.step_hash_policy(1)
+        obs, _, done, _ = env.step_wait()
+        assert np.array_equal(done.astype(np.uint8), ora.done), (kind, t)
+        assert np.array_equal(env._h_counter.numpy(), ora.counter), (kind, t)
+    assert np.array_equal(np.asarray(env.ill_conditioned, bool), ora.ill_conditioned().astype(bool)), kind
+    assert not env.error_flags.any()
+    env.close()
+    ora.close()
+
+
+def test_hip_lstsq_mode_switches_between_steps(oracle_gelsd):
+    """pct_set_lstsq_mode is callable between steps: a handle created in the default mode and switched to gelsd before the
+    first reset behaves like one created with lstsq='gelsd'; setting 2 accepts the call and ignores it"""
+    items = [(x, y, 1) for x in range(2, 9) for y in range(2, 9)]
+    kw = dict(setting=1, container_size=(20, 20, 20), item_set=items, internal_node_holder=400, leaf_node_holder=50)
+    stream = make_stream(11, 8, 1024, items)
+    pkg = _pkg()
+    env = pkg.PctVecEnv(8, item_stream=stream, device="cuda:0", **kw)
+    pkg._lib.check(env._L.pct_set_lstsq_mode(env._h, pkg._lib.LSTSQ_GELSD))
+    ora = OracleVecEnv(8, **kw)
+    ora.set_item_stream(stream)
+    obs = env.reset()
+    ora.reset()
+    for t in range(200):
+        assert np.array_equal(obs.cpu().numpy(), ora.obs.astype(np.float32)), t
+        env.step_hash_policy(1)
+        ora.step_hash_policy(1)
+        obs, _, _, _ = env.step_wait()
+    env.close()
+    ora.close()
+    e2 = pkg.PctVecEnv(4, setting=2, container_size=(10, 10, 10), item_set=[(1, 1, 1), (2, 2, 2)], device="cuda:0", lstsq="gelsd")
+    e2.reset()
+    e2.close()
