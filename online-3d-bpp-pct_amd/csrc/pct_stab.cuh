@@ -335,7 +335,7 @@ PCT_SD void stab_lstsq(const double* A, const double* b, int M, int N, double* x
 }
 #endif
 
-// np.dot of two 2-vectors as NumPy's BLAS computes it (OpenBLAS ddot on x86 cores with FMA): acc = x0*y0;
+// np.dot of two 2-vectors as NumPy's BLAS computes it (OpenBLAS' ddot kernel for AVX-512 hosts): acc = x0*y0;
 // acc = fma(x1, y1, acc) (NumPy's 2-vector dot on an FMA host; v_fma_f64 on the GPU is the same IEEE operation)
 PCT_SD double stab_dot2(double x0, double x1, double y0, double y1) { return fma(x1, y1, x0 * y0); }
 // ... and on a host whose OpenBLAS runs the "Haswell" kernel set (AVX2 hosts, AMD Zen included): that ddot's tail loop is compiled

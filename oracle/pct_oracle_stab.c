@@ -9,8 +9,9 @@
  * can pin down: np.dot / np.linalg.norm go through the BLAS ddot of whatever OpenBLAS kernel
  * the host selects (FMA or not), and np.linalg.lstsq is LAPACK gelsd (>= 3 supporters without
  * a "direct" one; 0.13 % of visits).  Here dot products take the FMA form of
- * OpenBLAS' ddot on every x86 core since Haswell (dot2 below) and the least-squares problem is solved
- * by a Jacobi eigen-decomposition of A^T A (minimum-norm).  Parity status: pinned on the setting-1 fixtures of
+ * OpenBLAS' ddot as built for AVX-512 hosts (dot2 below; its build for AVX2 hosts does NOT fuse: lstsq mode 2) and the
+ * least-squares problem is solved by a one-sided Jacobi SVD (minimum-norm) or, in lstsq modes 1 / 2, as LAPACK dgelsd solves it
+ * (pct_oracle_gelsd.c).  Parity status: pinned on the setting-1 fixtures of
  * tests/golden/gen_golden.py (observations, rewards, dones identical over the recorded
  * episodes); not a proof of bit-identity on every input.
  *
@@ -38,8 +39,8 @@
 
 #include "pct_oracle_internal.h"
 
-/* np.dot of two 2-vectors as NumPy's BLAS computes it: OpenBLAS' ddot kernels for every x86 core with FMA
- * (Haswell and later; the build this oracle was pinned against dispatches to them) accumulate
+/* np.dot of two 2-vectors as NumPy's BLAS computes it: OpenBLAS' ddot kernel for AVX-512 hosts ("SkylakeX": the build this
+ * oracle was pinned against dispatches to it) accumulates
  * acc = x0*y0; acc = fma(x1, y1, acc) -- ONE rounding for the second product and the sum, not two.  Measured
  * against np.dot on 200 000 random pairs (0 disagreements; the two-rounding form disagrees on 40 %).  It
  * decides the exactly-degenerate tests downstream (a stack centre on the line through a polygon edge). */

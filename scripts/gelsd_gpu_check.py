@@ -2,7 +2,8 @@
 """Torch-free GPU check of PCT_LSTSQ_GELSD (seconds to start: no `import torch`, the C ABI through ctypes and libamdhip64 for the
 copies).  The same comparisons as tests/test_zz_gpu_gelsd.py, for a GPU call with little time to spare:
 
-  1. discrete_s1_flat_diverging (the unmodified reference's recording): the kernels in gelsd mode follow it to the end;
+  1. discrete_s1_flat_diverging (the unmodified reference's recording): the kernels in gelsd mode follow it to the end
+     (and discrete_s1_ondomain_avx2, the reference on AVX2-host kernels, in PCT_LSTSQ_GELSD_AVX2 mode);
   2. kernels vs the oracle, both in gelsd mode: the C1 domain, wide flat items on a 20^3 bin (splits over up to 16 supporters),
      the continuous unit bin -- observation after every step, done, the notice.
 
@@ -52,7 +53,7 @@ def ck(rc):
 
 
 class Env(object):
-    def __init__(self, N, setting, container, I, Lh, base, continuous=False):
+    def __init__(self, N, setting, container, I, Lh, base, continuous=False, mode=1):
         c = Cfg()
         c.struct_size = ctypes.sizeof(Cfg)
         c.env_kind = 1 if continuous else 0
@@ -63,7 +64,7 @@ class Env(object):
         self.h = vp()
         ck(L.pct_create(ctypes.byref(c), 0, ctypes.byref(self.h)))
         self.N, self.row = N, (I + Lh + 1) * 9
-        ck(L.pct_set_lstsq_mode(self.h, 1))
+        ck(L.pct_set_lstsq_mode(self.h, mode))
 
     def fetch(self):
         HIP.hipDeviceSynchronize()
@@ -87,9 +88,9 @@ def report(label, ok, detail=""):
     return ok
 
 
-def fixture(name):
+def fixture(name, mode=1):
     c, z = load_case(name)
-    env = Env(c["N"], c["setting"], c["container"], c["I"], c["L"], c["base"])
+    env = Env(c["N"], c["setting"], c["container"], c["I"], c["L"], c["base"], mode=mode)
     items = np.ascontiguousarray(np.asarray(case_items(c), np.int32).reshape(-1, 3))
     ck(L.pct_set_item_set(env.h, items.ctypes.data, len(items)))
     st = np.ascontiguousarray(z["stream"].astype(np.int32))
@@ -156,6 +157,7 @@ def main():
                              leaf_node_holder=50, env_id_base=9),
                         lambda: Env(256, 1, (1, 1, 1), 80, 50, 9, continuous=True), prime_cont)
     ok &= fixture("discrete_s1_flat_lstsq")
+    ok &= fixture("discrete_s1_ondomain_avx2", mode=2)  # PCT_LSTSQ_GELSD_AVX2: the reference as it runs on AVX2 hosts
     print("%s in %.0f s" % ("ALL PASS" if ok else "FAILURES", time.time() - t0), flush=True)
     return 0 if ok else 1
 

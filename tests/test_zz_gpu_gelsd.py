@@ -52,6 +52,33 @@ def test_hip_gelsd_matches_reference_fixture(name):
     env.close()
 
 
+@pytest.mark.parametrize("name", ["discrete_s1_ondomain_avx2", "discrete_s1_flat_lstsq_avx2"])
+def test_hip_gelsd_avx2_matches_reference_on_avx2_kernels(name):
+    """PCT_LSTSQ_GELSD_AVX2: the reference as it runs on AVX2 hosts, AMD Zen included (tests/golden/gen_golden_avx2.py: NumPy's OpenBLAS
+    forced onto its Haswell kernel set -- np.dot unfused, dgemv 'N' / daxpy / dgemm summed differently).  The kernels in that mode
+    follow the recording; in PCT_LSTSQ_GELSD mode they leave discrete_s1_ondomain_avx2 at step 115 of env 1, where the reference on an
+    AVX-512 host and the reference on an AVX2 host part ways."""
+    c, z = load_case(name)
+    for mode in ("gelsd_avx2", "gelsd"):
+        env = _pkg().PctVecEnv(c["N"], setting=c["setting"], container_size=c["container"], item_set=case_items(c),
+                               internal_node_holder=c["I"], leaf_node_holder=c["L"], env_id_base=c["base"], item_stream=z["stream"],
+                               device="cuda:0", lstsq=mode)
+        obs = env.reset()
+        first = np.full(c["N"], -1)
+        for t in range(c["steps"] + 1):
+            bad = (obs.cpu().numpy() != z["obs"][t]).any(1)
+            first = np.where((first < 0) & bad, t, first)
+            if t < c["steps"]:
+                env.step_hash_policy(1)
+                obs, _, _, _ = env.step_wait()
+        assert not env.error_flags.any()
+        env.close()
+        if mode == "gelsd_avx2":
+            assert (first < 0).all(), first
+        else:
+            assert np.array_equal(first, z["first_difference_from_avx512"]), first
+
+
 @pytest.mark.parametrize("name", ["continuous_s1_flat_lstsq", "continuous_s1_unit_80_50"])
 def test_hip_gelsd_continuous_matches_reference_fixture(name):
     c, z = load_case(name)
