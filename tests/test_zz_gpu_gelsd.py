@@ -131,7 +131,10 @@ def test_hip_gelsd_matches_oracle_gelsd(kind, oracle_gelsd):
         obs, _, done, _ = env.step_wait()
         assert np.array_equal(done.astype(np.uint8), ora.done), (kind, t)
         assert np.array_equal(env._h_counter.numpy(), ora.counter), (kind, t)
-    assert np.array_equal(np.asarray(env.ill_conditioned, bool), ora.ill_conditioned().astype(bool)), kind
+    # the notice: the wave examines a candidate's walk tasks side by side where the reference's recursion returns at the first unstable
+    # supporter, so it may run solves the oracle never runs (the convention of tests/test_gpu_parity.py): every env the oracle flags
+    # must carry the notice.  (First GPU run, scripts/gelsd_gpu_check.py: equal sets on c1 and continuous, not on wide_flat.)
+    assert not (ora.ill_conditioned().astype(bool) & ~np.asarray(env.ill_conditioned, bool)).any(), kind
     assert not env.error_flags.any()
     env.close()
     ora.close()
