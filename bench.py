@@ -108,8 +108,10 @@ def make_oracle(w, envs, threads):
     return OracleVecEnv(envs, item_set=item_set(), **kw)
 
 
-def cpu_baseline(w, budget_s):
+def cpu_baseline(w, budget_s, lstsq="jacobi"):
     """The oracle on the host cores: same workload (config, sampler, stand-in policy), bounded sample."""
+    from oracle import oracle_lib
+    oracle_lib.set_lstsq_mode({"jacobi": oracle_lib.LSTSQ_JACOBI, "gelsd": oracle_lib.LSTSQ_GELSD, "gelsd_avx2": oracle_lib.LSTSQ_GELSD_AVX2}[lstsq])
     threads = max(1, min(os.cpu_count() or 1, 64))
     envs = 256 if w["I"] <= 80 else 64
     env = make_oracle(w, envs, threads)
@@ -195,6 +197,9 @@ def main():
     ap.add_argument("--share-gpu", action="store_true",
                     help="smoke test only: every rank uses cuda:0 (the N > 1 code path -- barrier, MAX-reduce of the "
                          "elapsed time, per-rank gather -- on a one-GPU box; not a measurement)")
+    ap.add_argument("--lstsq", choices=["jacobi", "gelsd", "gelsd_avx2"], default="jacobi",
+                    help="stability workloads (c1, c3s1): the solver behind np.linalg.lstsq -- the default Jacobi solver or LAPACK dgelsd as "
+                         "the reference's NumPy executes it (pct_set_lstsq_mode, include/pct_env.h); the cpu_baseline oracle follows")
     ap.add_argument("--ems-capacity", type=int, default=0, help="experiments: pct_config.ems_capacity (0 = the library's default)")
     ap.add_argument("--candidate-capacity", type=int, default=0, help="experiments: pct_config.candidate_capacity (0 = default)")
     ap.add_argument("--time-every", type=int, default=-1,
@@ -241,7 +246,7 @@ def main():
         base = rank * n_local + g * n_grp
         kw = dict(setting=w["setting"], container_size=w["container"], internal_node_holder=w["I"], leaf_node_holder=w["L"],
                   seed=4, env_id_base=base, device=dev, monitor=False, overflow_retry=not args.no_overflow_retry,
-                  ems_capacity=args.ems_capacity, candidate_capacity=args.candidate_capacity)
+                  ems_capacity=args.ems_capacity, candidate_capacity=args.candidate_capacity, lstsq=args.lstsq)
         if w["cont"]:
             return pkg.PctVecEnv(n_grp, continuous=True, sample_left_bound=w["bounds"][0], sample_right_bound=w["bounds"][1], **kw)
         return pkg.PctVecEnv(n_grp, item_set=item_set(), **kw)
@@ -355,6 +360,7 @@ def main():
             "desync_steps": max(0, args.desync),
             "pipelines": P,
             "overflow_retry_pass": not args.no_overflow_retry,
+            "lstsq": args.lstsq,
             "ems_capacity": args.ems_capacity or "default", "candidate_capacity": args.candidate_capacity or "default",
             "parallelism": "envs sharded by global id x%d, no collective on the step path" % world,
         },
@@ -386,7 +392,7 @@ def main():
         out["roofline_issue"] = None
     if rank == 0 and not args.no_cpu_baseline:
         # (N > 1: timed on rank 0 after the final barrier, while the other ranks wait in destroy_process_group)
-        out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)
+        out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds, args.lstsq)
     elif rank == 0:
         out["cpu_baseline"] = None
     out["cpu_baseline_reference"] = reference_baseline(w)
