@@ -102,7 +102,7 @@ extern "C" {
 #define PCT_FLAG_STABILITY_OVERFLOW 0x10u /* stability check (settings 1 / 3): the share / polygon pools, the hull
                                              workspace or the walk queue were exceeded in the retry pass too (the
                                              normal pass requeues such an env, state untouched), or a box rests on
-                                             more than 8 supporters none of which holds its centre of mass */
+                                             more than 16 supporters none of which holds its centre of mass (the normal pass takes 8) */
 #define PCT_FLAG_ILL_CONDITIONED 0x40u   /* NON-FATAL notice (the env is not terminated, PctVecEnv(strict=True) does not
                                             raise): a >= 3-supporter load split (np.linalg.lstsq, space.py:134-163)
                                             took its rank decision within a factor 1000 of the rcond cut -- the
@@ -242,7 +242,8 @@ int pct_set_shuffle_seed(pct_env* env, uint64_t seed);
  *     and 17 adversarial env-runs that part ways under PCT_LSTSQ_JACOBI follow the reference to the end
  *     (profiles/r04_gelsd_port.txt).  One lane solves a system, so a step that holds such a split is slower.
  *   PCT_LSTSQ_GELSD_AVX2: the same with the kernel set OpenBLAS selects on AVX2 hosts ("Haswell": Intel Haswell .. , AMD Zen) -- its
- *     dgemv 'N', daxpy and dgemm kernels sum differently, np.linalg.lstsq then returns other last bits on 98 % of these systems,
+ *     dgemv 'N', daxpy and dgemm kernels sum differently and its ddot does not fuse (np.dot of the 2-vectors at D/space.py:114-115,
+ *     143-145 is x0 y0 + x1 y1 there, also in the two-supporter lever rule); np.linalg.lstsq then returns other last bits on 98 % of these systems,
  *     and a reference run on such a host follows another trajectory at a tie (about one step in 10^5 on the discrete env).  Choose the
  *     flavour of the machine the reference ran on.
  * Callable at any time between steps; applies to the normal and the retry pass.  Replaces nothing in the reference's

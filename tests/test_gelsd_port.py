@@ -146,3 +146,25 @@ def test_oracle_avx2_flavour_matches_reference_on_avx2_kernels(name):
             assert (first < 0).all(), first
         else:
             assert np.array_equal(first, z["first_difference_from_avx512"]), first
+
+
+@pytest.mark.parametrize("name,heur", [("heur_s1_10", "LSAH"), ("heur_s1_10", "OnlineBPH"), ("heur_s1_10", "DBL"), ("heur_s1_10", "BR"),
+                                       ("heur_macs_s1_rect", "MACS")])
+def test_oracle_gelsd_mode_heuristics_match_reference_loops(name, heur, gelsd_mode):
+    """heuristic.py's baselines under the stability setting (their feasibility probes run the same check): per-episode utilisation and
+    length of the unmodified reference's loops, with the splits solved as dgelsd solves them"""
+    from tests.common import HEUR_CODE
+    c, z = load_case(name)
+    env = OracleVecEnv(1, setting=c["setting"], container_size=c["container"], item_set=case_items(c),
+                       internal_node_holder=c["I"], leaf_node_holder=c["L"])
+    env.set_item_stream(z["stream"])
+    env.reset()
+    util, length = [], []
+    while len(util) < c["episodes"]:
+        env.step_heuristic(HEUR_CODE[heur], 1)
+        if env.done[0]:
+            util.append(float(env.ratio[0]))
+            length.append(int(env.counter[0]))
+    assert np.array_equal(np.array(util), z["util_" + heur])
+    assert np.array_equal(np.array(length, np.int32), z["len_" + heur])
+    env.close()
