@@ -8,6 +8,9 @@ timeout 200 python bench.py --workload c2 --no-overflow-retry --no-cpu-baseline 
 timeout 200 python bench.py --workload c2 --mode fused --no-cpu-baseline > gpurun_out/bench_r02/c2_fused.json 2>/dev/null
 timeout 200 python bench.py --workload c2 --envs-per-gpu 16384 --no-cpu-baseline > gpurun_out/bench_r02/c2_16384.json 2>/dev/null
 timeout 200 python bench.py --workload c3 --envs-per-gpu 8192 --no-cpu-baseline > gpurun_out/bench_r02/c3_8192.json 2>/dev/null
+# the stability workloads with the strict least-squares solver (pct_set_lstsq_mode: dgelsd as the reference's NumPy executes it)
+timeout 300 python bench.py --workload c1 --lstsq gelsd --no-cpu-baseline > gpurun_out/bench_r02/c1_gelsd.json 2>/dev/null
+timeout 300 python bench.py --workload c3s1 --lstsq gelsd --no-cpu-baseline > gpurun_out/bench_r02/c3s1_gelsd.json 2>/dev/null
 timeout 120 python scripts/step_profile.py 4096 100 c2 > gpurun_out/bench_r02/step_profile_c2.txt 2>&1
 timeout 120 python scripts/step_profile.py 4096 60 c3 > gpurun_out/bench_r02/step_profile_c3.txt 2>&1
 timeout 120 python scripts/step_profile.py 1024 12 c5 > gpurun_out/bench_r02/step_profile_c5.txt 2>&1

@@ -51,14 +51,16 @@ def test_gelsd_port_reproduces_numpy_bit_for_bit(fname, mode):
     ctypes.CDLL(oracle_lib.build()).gelsd_set_kernel_set(1 if mode == oracle_lib.LSTSQ_GELSD_AVX2 else 0)
     n = deficient = 0
     sizes = set()
-    for a, b, x, rank, sv in _systems(fname):
-        x2, rank2, sv2, _ = oracle_lib.gelsd_lstsq(a, b)
-        assert np.array_equal(x, x2), (n, a.shape)
-        assert rank == rank2 and np.array_equal(sv, sv2), (n, a.shape)
-        n += 1
-        deficient += rank < a.shape[1]
-        sizes.add(a.shape[1])
-    ctypes.CDLL(oracle_lib.build()).gelsd_set_kernel_set(0)
+    try:
+        for a, b, x, rank, sv in _systems(fname):
+            x2, rank2, sv2, _ = oracle_lib.gelsd_lstsq(a, b)
+            assert np.array_equal(x, x2), (n, a.shape)
+            assert rank == rank2 and np.array_equal(sv, sv2), (n, a.shape)
+            n += 1
+            deficient += rank < a.shape[1]
+            sizes.add(a.shape[1])
+    finally:
+        ctypes.CDLL(oracle_lib.build()).gelsd_set_kernel_set(0)
     assert n > 1000 and deficient > 0 and {3, 4, 5, 6, 8, 16} <= sizes
 
 
