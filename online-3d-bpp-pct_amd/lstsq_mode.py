@@ -1,0 +1,47 @@
+"""Which least-squares flavour reproduces a reference run on THIS host (pct_set_lstsq_mode, include/pct_env.h).
+
+The reference's stability check calls np.linalg.lstsq and np.dot (D/space.py:110-115,143-152); both end in the OpenBLAS that the NumPy wheel
+bundles, which picks its kernels by CPU family at load time.  PCT_LSTSQ_GELSD restates the kernel set of AVX-512 hosts ("SkylakeX"),
+PCT_LSTSQ_GELSD_AVX2 the one of AVX2 hosts ("Haswell", which AMD Zen 1-3 also get).  `numpy_lstsq_mode()` asks the NumPy of the running
+process which set it uses -- the answer for a reference that runs (or ran) in this Python on this machine."""
+import ctypes
+import glob
+import os
+
+RESTATED = {"SkylakeX": "gelsd", "Haswell": "gelsd_avx2"}
+# what the restatement was pinned against (tests/golden/check_gelsd_port.py); other releases may order their sums differently
+PINNED_OPENBLAS = "0.3.29"
+
+
+def numpy_blas():
+    """(kernel set, OpenBLAS version) of the BLAS behind this process's NumPy, or (None, None) when it cannot be told"""
+    try:
+        import threadpoolctl
+        for lib in threadpoolctl.threadpool_info():
+            if lib.get("internal_api") == "openblas" and "numpy" in lib.get("filepath", ""):
+                return lib.get("architecture"), lib.get("version")
+    except Exception:
+        pass
+    try:
+        import numpy as np
+        cand = glob.glob(os.path.join(os.path.dirname(np.__file__), "..", "numpy.libs", "libscipy_openblas*.so*"))
+        if cand:
+            L = ctypes.CDLL(cand[0])
+            for sym in ("scipy_openblas_get_corename64_", "scipy_openblas_get_corename"):
+                if hasattr(L, sym):
+                    f = getattr(L, sym)
+                    f.restype = ctypes.c_char_p
+                    return f().decode(), None
+    except Exception:
+        pass
+    return None, None
+
+
+def numpy_lstsq_mode(strict=False):
+    """'gelsd' / 'gelsd_avx2' for the kernel set this process's NumPy runs, else None (strict: raise).  A version of OpenBLAS other
+    than the pinned one is reported through the second value of numpy_blas(); the mode is still returned."""
+    arch, _ = numpy_blas()
+    mode = RESTATED.get(arch)
+    if mode is None and strict:
+        raise RuntimeError("NumPy's BLAS on this host runs the %r kernel set; restated are %s" % (arch, sorted(RESTATED)))
+    return mode

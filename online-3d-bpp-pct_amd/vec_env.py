@@ -225,9 +225,14 @@ class PctVecEnv(VecEnv):
         # the solver behind np.linalg.lstsq in the stability check (settings 1 / 3): "jacobi" (default; the reference's solution up
         # to the last bits) or "gelsd" (LAPACK dgelsd as the reference's NumPy executes it: bit-identical, slower) -- pct_env.h
         # ("gelsd_avx2": as NumPy executes it on AVX2 hosts, AMD Zen included -- OpenBLAS' other kernel set)
+        # ("numpy": whichever of the two this process's NumPy runs on this host -- lstsq_mode.py; for comparing against a reference
+        # that runs in the same Python)
         modes = {"jacobi": _lib.LSTSQ_JACOBI, "gelsd": _lib.LSTSQ_GELSD, "gelsd_avx2": _lib.LSTSQ_GELSD_AVX2}
+        if lstsq == "numpy":
+            from .lstsq_mode import numpy_lstsq_mode
+            lstsq = numpy_lstsq_mode(strict=True)
         if lstsq not in modes:
-            raise ValueError("lstsq must be 'jacobi', 'gelsd' or 'gelsd_avx2'")
+            raise ValueError("lstsq must be 'jacobi', 'gelsd', 'gelsd_avx2' or 'numpy'")
         self.lstsq = lstsq
         if lstsq != "jacobi":
             _lib.check(self._L.pct_set_lstsq_mode(self._h, modes[lstsq]))

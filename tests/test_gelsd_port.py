@@ -170,3 +170,24 @@ def test_oracle_gelsd_mode_heuristics_match_reference_loops(name, heur, gelsd_mo
     assert np.array_equal(np.array(util), z["util_" + heur])
     assert np.array_equal(np.array(length, np.int32), z["len_" + heur])
     env.close()
+
+
+def test_host_flavour_helper_names_this_numpys_kernel_set():
+    """online-3d-bpp-pct_amd/lstsq_mode.py: PctVecEnv(lstsq="numpy") = the flavour of the NumPy this process runs (for comparing
+    against a reference in the same Python).  The two fixture files say which kernel set recorded them; the helper must map those
+    names, and on this machine must return a mode whose recorded solutions np.linalg.lstsq reproduces right now."""
+    import importlib
+    lm = importlib.import_module("online-3d-bpp-pct_amd.lstsq_mode")
+    assert lm.RESTATED == {"SkylakeX": "gelsd", "Haswell": "gelsd_avx2"}
+    arch, version = lm.numpy_blas()
+    mode = lm.numpy_lstsq_mode()
+    assert mode == lm.RESTATED.get(arch)
+    if mode is None or version != lm.PINNED_OPENBLAS:
+        pytest.skip("this host's NumPy runs %r kernels of OpenBLAS %r: nothing recorded to compare with" % (arch, version))
+    fname = "lstsq_systems.npz" if mode == "gelsd" else "lstsq_systems_avx2.npz"
+    n = 0
+    for a, b, x, rank, sv in _systems(fname):
+        if n % 5 == 0:
+            want = np.linalg.lstsq(a, b, rcond=None)
+            assert np.array_equal(np.asarray(want[0]).ravel(), x) and int(want[2]) == rank, n
+        n += 1
