@@ -11,7 +11,8 @@ What it does:
   * restores the NumPy aliases `np.float` / `np.bool` removed in NumPy >= 1.24
     (convex_hull.py:42, wrapper/shmem_vec_env.py:17, wrapper/dummy_vec_env.py:25);
   * puts /root/reference on sys.path with bytecode writing disabled so the import does
-    not drop __pycache__/ into the read-only reference tree.
+    not drop __pycache__/ into the read-only reference tree;
+  * in an interpreter without PyTorch, injects a stub `torch` (the env modules import it for torch.load of datasets only).
 """
 import os
 import sys
@@ -32,6 +33,19 @@ def install():
         np.float = float
     if not hasattr(np, "bool"):
         np.bool = bool
+
+    # An interpreter without PyTorch (the image's second Python: /opt/conda, NumPy 1.26.4 / OpenBLAS 0.3.23, used by
+    # tests/golden/check_other_numpy.py to run the reference on ANOTHER NumPy release): the env modules import torch at
+    # bin3D.py:5 / binCreator.py:3 and touch it only in LoadBoxCreator (torch.load of a dataset), which scripted streams never reach
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        stub = types.ModuleType("torch")
+
+        def _no_torch(*a, **k):
+            raise RuntimeError("torch is stubbed in this interpreter (tests/golden/ref_shim.py)")
+        stub.load = _no_torch
+        sys.modules["torch"] = stub
 
     if "gym" not in sys.modules:
         gym = types.ModuleType("gym")
