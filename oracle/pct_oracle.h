@@ -6,7 +6,7 @@
  * (online-3d-bpp-pct_amd/) never links, imports or falls back to it.
  *
  * Parity status: PINNED -- every part is checked bit for bit against the unmodified Python reference (imported from /root/reference
- * under tests/golden/ref_shim.py) by tests/golden/gen_golden.py, which writes the committed fixtures (tests/golden/*.npz) only
+ * under tests/golden/ref_shim.py) by tests/golden/gen_golden.py, which writes the committed fixtures (the .npz files of tests/golden/) only
  * when the oracle equals the reference, and it reproduces the survey's known-answer hashes: both envs, settings
  * 1 / 2 / 3, all five leaf-node schemes, the dataset and NumPy-stream item sources, the heuristics.  The one place that needs a
  * qualifier is np.linalg.lstsq in the stability check (settings 1 / 3), which is not reference code but the LAPACK of the NumPy wheel:
