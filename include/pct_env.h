@@ -241,7 +241,8 @@ int pct_set_shuffle_seed(pct_env* env, uint64_t seed);
  *     its dgemv / dger / drot kernels and the 80-bit x87 dnrm2; csrc/pct_gelsd.cuh).  Bit-identical solutions: the 13 on-domain
  *     and 17 adversarial env-runs that part ways under PCT_LSTSQ_JACOBI follow the reference to the end
  *     (profiles/r04_gelsd_port.txt).  One lane solves a system, so a step that holds such a split is slower.
- *   PCT_LSTSQ_GELSD_AVX2: the same with the kernel set OpenBLAS selects on AVX2 hosts ("Haswell": Intel Haswell .. , AMD Zen) -- its
+ *   PCT_LSTSQ_GELSD_AVX2: the same with the kernel set OpenBLAS selects on AVX2 hosts without AVX-512 ("Haswell"; also what
+ *     OPENBLAS_CORETYPE=ZEN runs) -- its
  *     dgemv 'N', daxpy and dgemm kernels sum differently and its ddot does not fuse (np.dot of the 2-vectors at D/space.py:114-115,
  *     143-145 is x0 y0 + x1 y1 there, also in the two-supporter lever rule); np.linalg.lstsq then returns other last bits on 98 % of these systems,
  *     and a reference run on such a host follows another trajectory at a tie (about one step in 10^5 on the discrete env).  Choose the
