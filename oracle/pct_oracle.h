@@ -14,8 +14,8 @@
  *     bits of that solve (one on-domain env-run in 55 parts ways on such a bit, profiles/r04_lstsq_ondomain.txt);
  *   - pcto_set_lstsq_mode(1 / 2): dgelsd restated operation for operation with the arithmetic of OpenBLAS' AVX-512 / AVX2 kernel set
  *     (pct_oracle_gelsd.c), pinned routine by routine to the bundled library (tests/golden/check_gelsd_port.py) and against the
- *     reference on 1.94 M on-domain env-steps and the adversarial streams without a single difference
- *     (profiles/r04_lstsq_ondomain_gelsd.txt, r04_lstsq_ondomain_avx2.txt, r04_gelsd_port.txt, r04_gelsd_other_numpy.txt).
+ *     reference on 11.5 M on-domain env-steps and the adversarial streams without a single difference
+ *     (profiles/r04_lstsq_ondomain_gelsd.txt, r04_lstsq_ondomain_gelsd_large.txt, r04_lstsq_ondomain_avx2.txt, r04_gelsd_port.txt, r04_gelsd_other_numpy.txt).
  *
  * The batched API mirrors include/pct_env.h one to one (pcto_* instead of pct_*, host
  * pointers instead of device pointers, float64 observations like the gym env returns
