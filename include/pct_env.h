@@ -118,6 +118,13 @@ extern "C" {
                                             its NumPy runs on other BLAS kernels (profiles/r04_lstsq_ondomain.txt).
                                             pct_set_lstsq_mode(env, PCT_LSTSQ_GELSD) removes both kinds: the split is then
                                             solved exactly as the reference's NumPy solves it (the notice is still raised) */
+#define PCT_FLAG_ILL_COMMIT 0x80u        /* NON-FATAL, provenance of the notice above: it was raised (also) by a solve of a COMMIT walk
+                                            (calculated_impact, space.py:73-164 -- the placement's own, state-changing walk, whose
+                                            solves every evaluation order makes).  A notice WITHOUT this bit came from a candidate's
+                                            virtual check (space.py:166-267) only: the reference walks a candidate's supporters one
+                                            after the other and stops at the first unstable one, the kernels examine them side by
+                                            side, so which solves of a candidate that fails anyway are made at all differs between
+                                            the two -- the commit part of the notice is the part that is comparable */
 #define PCT_FLAG_DATASET_EXHAUSTED 0x20u /* LoadBoxCreator ran past its last trajectory: the
                                             reference raises IndexError at binCreator.py:58 */
 #define PCT_FLAG_BAD_ACTION 0x8u         /* malformed action: reference raises ValueError at
@@ -341,10 +348,11 @@ int pct_debug_retry_count(pct_env* env, int32_t* last, int64_t* envs_total, int6
 
 /* Per-phase cycle accounting of the transition kernel (profiling aid).  on != 0: (re)start
  * accumulation; host_out, if non-NULL, first receives the accumulators gathered so far:
- * uint64 [N,16] = s_memtime cycles in {load, drop_box, GENEMS, candidate set, feasibility,
+ * uint64 [N,40] = s_memtime cycles in {load, drop_box, GENEMS, candidate set, feasibility,
  * observation write, state store}, the number of steps, then the candidate-set detail
- * {generation + membership probes, batch de-duplication, matching, rebuilds}.  Synchronises
- * the device. */
+ * {generation + membership probes, batch de-duplication, matching, rebuilds}, the set's statistics
+ * (slots 12..29) and the stability settings' counters (slots 30..38, csrc/pct_set.cuh).
+ * Synchronises the device. */
 int pct_debug_phase_timing(pct_env* env, int32_t on, uint64_t* host_out);
 
 #if defined(__HIPCC__)

@@ -21,7 +21,8 @@ FLAG_INTERNAL_OVERFLOW, FLAG_EMS_OVERFLOW, FLAG_CANDIDATE_OVERFLOW, FLAG_BAD_ACT
 FLAG_STABILITY_OVERFLOW, FLAG_DATASET_EXHAUSTED = 16, 32
 FLAG_ILL_CONDITIONED = 64  # non-fatal notice (include/pct_env.h)
 LSTSQ_JACOBI, LSTSQ_GELSD, LSTSQ_GELSD_AVX2 = 0, 1, 2  # pct_set_lstsq_mode
-FLAG_ERROR_MASK = 0xFFFFFFFF & ~FLAG_ILL_CONDITIONED
+FLAG_ILL_COMMIT = 128  # non-fatal: ... raised by a solve of a commit walk
+FLAG_ERROR_MASK = 0xFFFFFFFF & ~(FLAG_ILL_CONDITIONED | FLAG_ILL_COMMIT)
 
 # every symbol include/pct_env.h declares
 ABI_SYMBOLS = [

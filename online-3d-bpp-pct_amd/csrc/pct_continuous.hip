@@ -1180,7 +1180,7 @@ __device__ __forceinline__ int ctransition(const ContinuousParams& p, int e, CLd
     }
     l.st.n_ent = __builtin_amdgcn_readfirstlane(l.st.n_ent);
     l.st.n_poly = __builtin_amdgcn_readfirstlane(l.st.n_poly);
-    if (__builtin_amdgcn_readfirstlane(ill ? 1 : 0)) r.flags |= PCT_FLAG_ILL_CONDITIONED;
+    if (__builtin_amdgcn_readfirstlane(ill ? 1 : 0)) r.flags |= PCT_FLAG_ILL_CONDITIONED | PCT_FLAG_ILL_COMMIT;
     if (rc < 0) r.stab_over |= STAB_WHY_COMMIT;
     ok = rc == 1;
     __syncthreads();
@@ -1527,7 +1527,7 @@ template <int ACT, bool TIMED, bool GT, bool STAB, bool MT>
 #define PCT_STAB_WAVES 1 /* waves per SIMD the stability-check kernels are compiled for (2: 256 VGPRs, ~470 of them spilled -- slower, profiles/r03_stability_tuning.txt) */
 #endif
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TIMED ? 1 : (STAB ? PCT_STAB_WAVES : PCT_CONT_WAVES))))
-pct_continuous_kernel(ContinuousParams p_arg, const void* __restrict__ actions,
+pct_continuous_kernel(ContinuousParams p_arg, const void* actions,
                                                             int row_len, int n_steps,
                                                             const int32_t* __restrict__ env_ids, int n_ids) {
   extern __shared__ __align__(16) unsigned char smem[];

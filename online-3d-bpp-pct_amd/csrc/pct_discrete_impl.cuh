@@ -2204,7 +2204,7 @@ __device__ __forceinline__ bool transition(const DiscreteParams& p, int e, Lds<K
     const int rc = stab_commit_wave<false>(geo, l.st, r.n_boxes, item_den, l.sw, lane, ill, TM::on ? &cstats : nullptr);
     l.st.n_ent = __builtin_amdgcn_readfirstlane(l.st.n_ent);
     l.st.n_poly = __builtin_amdgcn_readfirstlane(l.st.n_poly);
-    if (__builtin_amdgcn_readfirstlane(ill ? 1 : 0)) r.flags |= PCT_FLAG_ILL_CONDITIONED;
+    if (__builtin_amdgcn_readfirstlane(ill ? 1 : 0)) r.flags |= PCT_FLAG_ILL_CONDITIONED | PCT_FLAG_ILL_COMMIT;
     if (rc < 0) r.stab_over |= STAB_WHY_COMMIT;
     ok = rc == 1;
     if (TM::on) {
@@ -2326,7 +2326,7 @@ __device__ __forceinline__ void policy_epilogue(const DiscreteParams& p, int e, 
 
 // one env, one launch's worth of transitions (the body of the kernel below)
 template <typename K, int BITS, int ACT, bool TIMED, bool STAB, int SCHEME, int RNG>
-__device__ __forceinline__ void discrete_env_steps(const DiscreteParams& p, const void* __restrict__ actions, int row_len, int n_steps,
+__device__ __forceinline__ void discrete_env_steps(const DiscreteParams& p, const void* actions, int row_len, int n_steps,
                                           int e, unsigned char* smem, int& ems_out) {
   ems_out = 0;  // the live EMS count the env is left with (half of the heavy-first dispatch's sort key)
   const int lane = threadIdx.x;
@@ -2448,7 +2448,7 @@ template <typename K, int BITS, int ACT, bool TIMED, bool STAB, int SCHEME, int 
 // the plain setting-2 kernels are held to 128 VGPRs (4 waves per SIMD = 16 resident envs per CU, the
 // occupancy the LDS layout is sized for); the float64 stability code and the timed build are not
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STAB ? PCT_STAB_WAVES : 4)))
-pct_discrete_kernel(DiscreteParams p_arg, const void* __restrict__ actions,
+pct_discrete_kernel(DiscreteParams p_arg, const void* actions,
                                                           int row_len, int n_steps,
                                                           const int32_t* __restrict__ env_ids, int n_ids) {
   extern __shared__ __align__(16) unsigned char smem[];

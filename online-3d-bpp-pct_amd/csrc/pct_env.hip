@@ -253,6 +253,13 @@ hipError_t order_launch(pct_env* h, hipStream_t s) {
                      reinterpret_cast<const uint32_t*>(scalars) + (size_t)N * PCT_SCALARS, h->d_order, N, h->order_mode);
   return hipGetLastError();
 }
+/* the step kernel was not dispatched: the event pair taken for it will never be signalled -- hand it back, or every later
+ * pct_profile_read would fail in hipEventElapsedTime on it */
+int launch_failed(pct_env* h, bool took_pair, hipError_t e, const char* what) {
+  if (took_pair && h->ev_used > 0) h->ev_used--;
+  h->dp.launch_ev_start = h->dp.launch_ev_stop = h->cp.launch_ev_start = h->cp.launch_ev_stop = nullptr;
+  return fail(PCT_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
 int launch(pct_env* h, int act, const void* actions, int row_len, int n_steps, const int32_t* ids, int n_ids,
            void* stream) {
   hipStream_t s = (hipStream_t)stream;
@@ -286,7 +293,10 @@ int launch(pct_env* h, int act, const void* actions, int row_len, int n_steps, c
     h->cp.full_obs = h->dp.full_obs;
     h->cp.policy_rows = h->dp.policy_rows;
     if (h->has_retry) h->cp.retry_count = h->c_retry_base + h->c_retry_parity; /* ping-pong pair of queue counters */
-    HIP_TRY(pct::launch_continuous(h->cp, act, actions, row_len, n_steps, ids, n_ids, s));
+    {
+      const hipError_t le = pct::launch_continuous(h->cp, act, actions, row_len, n_steps, ids, n_ids, s);
+      if (le != hipSuccess) return launch_failed(h, timed && normal_grid > 0, le, "launch_continuous");
+    }
     if (h->has_retry) {
       /* keep the retry pass in step with everything that may have changed on the handle */
       pct::ContinuousParams& q = h->cp_retry;
@@ -312,7 +322,10 @@ int launch(pct_env* h, int act, const void* actions, int row_len, int n_steps, c
     if (h->has_dretry) { /* ping-pong pair of queue counters: this step's is h->d_retry_base[parity] */
       h->dp.retry_count = h->d_retry_base + h->d_retry_parity;
     }
-    HIP_TRY(pct::launch_discrete(h->dp, act, actions, row_len, n_steps, ids, n_ids, s));
+    {
+      const hipError_t le = pct::launch_discrete(h->dp, act, actions, row_len, n_steps, ids, n_ids, s);
+      if (le != hipSuccess) return launch_failed(h, timed && normal_grid > 0, le, "launch_discrete");
+    }
     if (h->has_dretry) {
       /* the same step again, with larger LDS lists, for the envs the normal pass queued (usually none: the
        * small grid then exits at once) */

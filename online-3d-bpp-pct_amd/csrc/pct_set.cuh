@@ -764,7 +764,7 @@ __device__ __forceinline__ uint32_t table_region(uint32_t cap, uint32_t size) {
   return (lv & 1) ? cap : 0u;
 }
 
-#define PCT_TIMING_SLOTS 32
+#define PCT_TIMING_SLOTS 40
 // optional per-phase cycle accounting (pct_debug_phase_timing): s_memtime deltas per env.
 // The untimed specialisation is empty, so production kernels carry no extra registers.
 template <bool ON>
@@ -815,10 +815,11 @@ enum { PH_LOAD = 0, PH_DROP = 1, PH_GENEMS = 2, PH_SET = 3, PH_FEAS = 4, PH_OBS 
        ST_EMS = 12, ST_DISTINCT = 13, ST_GENERATED = 14, ST_MATCH_CALLS = 16, ST_MATCH_ROUNDS = 17, ST_MATCH_PROBES = 18,
        ST_CONTAINS_CALLS = 19, ST_CONTAINS_PROBES = 20, ST_FLUSHES = 21, PH_FAST_START = 22, ST_REBUILDS = 23,
        PH_SET_HASH = 24, PH_GEN_TUPLE = 25, PH_GEN_HASH = 26, PH_GEN_CONTAINS = 27, PH_GEN_PEND = 28, PH_GEN_PAIRS = 29,
-       // stability settings (slots the set statistics above leave at zero): commit walk visits, virtual-check passes / tasks /
-       // single-task passes / level-0 candidates, least-squares splits by supporter count
-       ST_STAB_COMMIT_VISITS = 30, ST_STAB_VPASSES = 31, ST_STAB_VTASKS = 15, ST_STAB_VNARROW = 19, ST_STAB_LSQ3 = 20,
-       ST_STAB_LSQ4 = 24, ST_STAB_LSQ5 = 25, ST_STAB_LSQX = 26, ST_STAB_LEVEL0 = 27 };
+       // stability settings, slots of their own (round 4 shared slots 15 / 19 / 20 / 24..27 with the set statistics, which a timed
+       // stability build also fills -- ADVICE r4): commit walk visits, virtual-check passes / tasks / single-task passes / level-0
+       // candidates, least-squares splits by supporter count
+       ST_STAB_COMMIT_VISITS = 30, ST_STAB_VPASSES = 31, ST_STAB_VTASKS = 32, ST_STAB_VNARROW = 33, ST_STAB_LSQ3 = 34,
+       ST_STAB_LSQ4 = 35, ST_STAB_LSQ5 = 36, ST_STAB_LSQX = 37, ST_STAB_LEVEL0 = 38 };
 
 
 }  // namespace pct

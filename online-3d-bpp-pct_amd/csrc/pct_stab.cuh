@@ -548,10 +548,16 @@ PCT_SD bool stab_split(const Geo& geo, const double bg[9], int k, const Sup& sup
     }
     sp.mode = 3;
     if (ss) { ss->lsq3 += k == 3; ss->lsq4 += k == 4; ss->lsq5 += k == 5; }
+#if defined(PCT_STAB_COOP_ALL) && defined(__HIPCC__)
+    // every least-squares split goes to the wave (stab_lsq_wave): the register-resident solves below are not compiled
+    sp.mode = 4;
+    return true;
+#else
     if (k == 3) { double x3[3]; stab_split_fixed<3>(c2, stk, x3, sp.ill); sp.f[0] = x3[0]; sp.f[1] = x3[1]; sp.f[2] = x3[2]; }
     else if (k == 4) { double x4[4]; stab_split_fixed<4>(c2, stk, x4, sp.ill); sp.f[0] = x4[0]; sp.f[1] = x4[1]; sp.f[2] = x4[2]; sp.f[3] = x4[3]; }
     else stab_split_fixed<5>(c2, stk, sp.f, sp.ill);
     return true;
+#endif
   }
   if (ss) ss->lsqx++;
 #if defined(__HIPCC__)
@@ -784,11 +790,11 @@ PCT_HD size_t stab_lsq_slot_doubles(int n, bool gelsd = false) {
   if (gelsd) return 4 + 2 * (size_t)n + (size_t)n + M * (size_t)n + M + (size_t)n * (size_t)n + 8 * (size_t)n;
   return 4 + 2 * (size_t)n + (size_t)n + 3 * M8 + M * (size_t)n + (size_t)n * (size_t)n;
 }
-// lanes that share one system: 16 up to 6 supporters (16 rows), 32 up to 8 (29 rows), else the whole wave.  gelsd mode: ONE lane
-// solves a system; the classes are up to 4 / up to 8 / up to lsq_n supporters and the "group" widths 1 / 2 / 4 tell them apart
-// (lane rk * G solves slot rk)
+// lanes that share one system: 16 up to 6 supporters (16 rows), 32 up to 8 (29 rows), else the whole wave.  gelsd mode: the classes
+// are up to 4 / up to 8 / up to lsq_n supporters, solved by groups of 4 / 8 / 16 lanes (a trailing column, the right-hand side, a
+// row of V^T per lane: pct_gelsd.cuh); the widths also tell the classes apart (lanes rk * G ... solve slot rk)
 PCT_HD int stab_lsq_group(int k, bool gelsd = false) {
-  if (gelsd) return k <= 4 ? 1 : (k <= 8 ? 2 : 4);
+  if (gelsd) return k <= 4 ? 4 : (k <= 8 ? 8 : 16);
   return k <= 6 ? 16 : (k <= 8 ? 32 : 64);
 }
 PCT_HD int stab_lsq_class_n(int k, int lsq_n, bool gelsd = false) {
@@ -956,16 +962,17 @@ __device__ __forceinline__ void stab_lsq_inputs(const Geo& geo, const double bg[
 }
 
 // gelsd mode: the systems of slots 0 .. nslot - 1 (laid out for class n: stab_lsq_slot_doubles(n, true) doubles each, the header
-// as stab_lsq_wave reads it), each solved by ONE lane -- lane s * G takes slot s -- with pct_gelsd.cuh on the slot's own
-// workspace.  All 64 lanes call; returns the system's notice in its solving lane.
+// as stab_lsq_wave reads it), each solved by a GROUP of G lanes -- lanes s * G .. s * G + G - 1 take slot s -- with pct_gelsd.cuh on
+// the slot's own workspace (round 4: one lane per system).  All 64 lanes call; returns the system's notice in its group's lanes.
 __device__ __forceinline__ bool stab_gelsd_slots(double* ws, int G, int n, int nslot, int lane, bool avx2) {
   const size_t sd = stab_lsq_slot_doubles(n, true);
   const int slot = lane / G;
   bool ill = false;
-  if ((lane & (G - 1)) == 0 && slot < nslot) {
+  if (slot < nslot) {
     double* w = ws + (size_t)slot * sd;
     const int k = (int)w[0];
-    if (k >= 3) gelsd::split_t(w + 4 + 3 * n, k, w + 4, w[1], w[2], StabDot2{avx2}, w + 4 + 2 * n, ill, avx2);
+    const gelsd::Grp g = {lane & (G - 1), G};
+    if (k >= 3) gelsd::split_t(g, w + 4 + 3 * n, k, w + 4, w[1], w[2], StabDot2{avx2}, w + 4 + 2 * n, ill, avx2);
   }
   __syncthreads();
   return ill;

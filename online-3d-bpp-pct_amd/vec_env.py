@@ -330,6 +330,12 @@ class PctVecEnv(VecEnv):
         LAPACK build and may differ."""
         return (self._flags.cpu().numpy().view(np.uint32) & np.uint32(_lib.FLAG_ILL_CONDITIONED)) != 0
 
+    @property
+    def ill_commit(self):
+        """bool [N]: ... and a solve of the env's own COMMIT walks raised it (PCT_FLAG_ILL_COMMIT): the part of the notice that does
+        not depend on the order in which a candidate's virtual check examines its supporters."""
+        return (self._flags.cpu().numpy().view(np.uint32) & np.uint32(_lib.FLAG_ILL_COMMIT)) != 0
+
     # ------------------------------------------------------------------ VecEnv surface
     def reset(self):
         with torch.cuda.device(self._dev_index):
@@ -489,9 +495,10 @@ class PctVecEnv(VecEnv):
         return n.value, ms.value
 
     def phase_timing(self, on=True):
-        """Start/stop per-phase cycle accounting; returns the uint64 [N,16] gathered so far
-        (columns: load, drop, genems, set, feas, obs, store, steps, set-gen, set-dedup, set-match, set-rebuild)."""
-        out = np.zeros((self.N, 32), np.uint64)  # PCT_TIMING_SLOTS
+        """Start/stop per-phase cycle accounting; returns the uint64 [N,40] gathered so far
+        (columns: load, drop, genems, set, feas, obs, store, steps, set-gen, set-dedup, set-match, set-rebuild, set statistics
+        12..29, stability counters 30..38: csrc/pct_set.cuh)."""
+        out = np.zeros((self.N, 40), np.uint64)  # PCT_TIMING_SLOTS
         _lib.check(self._L.pct_debug_phase_timing(self._h, int(bool(on)), out.ctypes.data))
         return out
 

@@ -60,6 +60,7 @@ def lib():
         L.pcto_set_shuffle_seed.argtypes = [vp, ctypes.c_uint64]
         L.pcto_step_heuristic.argtypes = [vp, ctypes.c_int32, ctypes.c_int32]
         L.pcto_ill_conditioned.argtypes = [vp, vp]
+        L.pcto_ill_commit.argtypes = [vp, vp]
         L.pcto_set_density_stream.argtypes = [vp, vp, ctypes.c_int64]
         L.pcto_set_dataset_density.argtypes = [vp, vp]
         for name in ("pcto_obs", "pcto_reward", "pcto_done", "pcto_info_counter", "pcto_info_ratio",
@@ -197,6 +198,13 @@ class OracleVecEnv(object):
         (sticky; what the product reports as PCT_FLAG_ILL_CONDITIONED)"""
         out = np.zeros(self.N, np.uint8)
         self._check(lib().pcto_ill_conditioned(self._h, out.ctypes.data))
+        return out.astype(bool)
+
+    def ill_commit(self):
+        """bool [N]: ... and a solve of a COMMIT walk raised it (PCT_FLAG_ILL_COMMIT): the part of the notice that does not depend on
+        the order in which a candidate's virtual check examines its supporters"""
+        out = np.zeros(self.N, np.uint8)
+        self._check(lib().pcto_ill_commit(self._h, out.ctypes.data))
         return out.astype(bool)
 
     def set_sampler(self, seed):

@@ -1048,6 +1048,16 @@ int pcto_ill_conditioned(pcto_env* h, uint8_t* out) {
   return PCT_OK;
 }
 
+/* out[e] = 1 iff a solve of env e's COMMIT walks raised the notice (the product's PCT_FLAG_ILL_COMMIT) */
+int pcto_ill_commit(pcto_env* h, uint8_t* out) {
+  if (!h || !out) return fail(PCT_ERR_INVALID_ARG, "null argument");
+  for (int e = 0; e < h->N; e++) {
+    const struct stab* st = h->cfg.env_kind == PCT_ENV_CONTINUOUS ? pctc_stab(h, e) : h->envs[e].stab;
+    out[e] = (st && stab_ill_commit(st)) ? 1 : 0;
+  }
+  return PCT_OK;
+}
+
 static int ready(const pcto_env* h) {
   if (!h) return fail(PCT_ERR_INVALID_ARG, "null handle");
   if (!h->item_set) return fail(PCT_ERR_STATE, "item set not configured");

@@ -64,6 +64,7 @@ int pcto_get_lstsq_mode(void);
 /* the solve itself, for tests: row-major M x N system -> x[N], singular values sv[N], rank; returns dbdsqr's info */
 int gelsd_lstsq(const double* A, const double* b, int M, int N, double* x, int* rank, double* sv, int* near_cut);
 void pcto_set_ill_near(int on); /* analysis only: also note decisions within 1e-9 of a tie on stacks carrying a least-squares share */
+int pcto_ill_commit(pcto_env* env, uint8_t* out);      /* [N] ... raised by a solve of a commit walk (PCT_FLAG_ILL_COMMIT) */
 int pcto_ill_conditioned(pcto_env* env, uint8_t* out); /* [N] sticky notice of the stability settings (PCT_FLAG_ILL_CONDITIONED) */
 
 int pcto_reset(pcto_env* env, const int32_t* env_ids, int32_t n);

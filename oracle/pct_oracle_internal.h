@@ -130,6 +130,7 @@ struct stab* stab_create(int cap, double eps);
 void stab_reset(struct stab* s);
 void stab_free(struct stab* s);
 int stab_ill_conditioned(const struct stab* s); /* sticky notice, see pct_oracle_stab.c */
+int stab_ill_commit(const struct stab* s);      /* ... raised by a solve of a commit walk */
 void stab_set_ill_near(int on);
 void stab_set_lstsq_mode(int mode); /* 0: Jacobi stand-in (default), 1: dgelsd as NumPy's OpenBLAS executes it */
 int stab_get_lstsq_mode(void);

@@ -88,7 +88,11 @@ static _Thread_local int g_tainted;
 static int g_ill_near = 0;
 void stab_set_ill_near(int on) { g_ill_near = on; }
 static int near_rel(double a, double b) { return fabs(a - b) <= ILL_NEAR * fmax(fmax(fabs(a), fabs(b)), 1e-300); }
-int stab_ill_conditioned(const struct stab* s) { return s->ill; }
+int stab_ill_conditioned(const struct stab* s) { return s->ill & 1; }
+/* ... and whether a solve of a COMMIT raised it (calculated_impact, D/space.py:73-164: the state-changing walk, whose solves every
+ * evaluation order makes) rather than only a virtual check's (a candidate's walk stops at its first unstable supporter: which of a
+ * doomed candidate's solves are made at all depends on the order its supporters are examined in) */
+int stab_ill_commit(const struct stab* s) { return (s->ill >> 1) & 1; }
 static int stab_check_(struct stab* s, double x, double y, double z, double lx, double ly, double max_h, double density,
                        int virtual_);
 
@@ -431,7 +435,7 @@ int stab_check(struct stab* s, double x, double y, double z, double lx, double l
   g_ill = 0;
   g_tainted = g_ill_near && s->lsq_seen;
   const int rc_ = stab_check_(s, x, y, z, lx, ly, max_h, density, virtual_);
-  if (g_ill) s->ill = 1;
+  if (g_ill) s->ill |= virtual_ ? 1 : 3;
   return rc_;
 }
 static int stab_check_(struct stab* s, double x, double y, double z, double lx, double ly, double max_h, double density,

@@ -47,7 +47,7 @@ keymean = np.zeros(K)
 emsat = np.zeros(K, np.int64)
 boxes = np.zeros(K, np.int64)
 retry = np.zeros(K, np.int64)
-phase = np.zeros((K, 32))
+phase = np.zeros((K, 40))
 for s in range(K):
     env.step_rows_device(rows)
     n, ms = env.profile_read()
@@ -69,8 +69,8 @@ print("%s: %d launches of %d envs; step kernel us: mean %.1f  p50 %.1f  p90 %.1f
 print("  slowest env of a launch: mean %.0f cycles (= %.1f us at 2.4 GHz); mean env %.0f cycles; launches with a queued retry: %d" % (
     keymax.mean(), keymax.mean() / 2400, keymean.mean(), int((retry > 0).sum())))
 names = ["load", "drop+commit", "genems", "set", "feas", "obs", "store"]
-stat_names = {12: "EMS", 13: "distinct", 30: "commit visits", 31: "virtual passes", 15: "virtual tasks", 19: "narrow passes",
-              20: "lsq k=3", 24: "lsq k=4", 25: "lsq k=5", 26: "lsq k>5", 27: "level-0 candidates"}
+stat_names = {12: "EMS", 13: "distinct", 30: "commit visits", 31: "virtual passes", 32: "virtual tasks", 33: "narrow passes",
+              34: "lsq k=3", 35: "lsq k=4", 36: "lsq k=5", 37: "lsq k>5", 38: "level-0 candidates"}
 order = np.argsort(-dur)
 print("  launches beyond 2x the median (%d of %d), longest first:" % (int((dur > 2 * med).sum()), K))
 for s in order[:max(12, int((dur > 2 * med).sum()))][:40]:

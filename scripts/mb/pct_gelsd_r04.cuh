@@ -12,23 +12,10 @@
 // dgemv 'N', daxpy and the dgemm kernel differ): which products are fused, how many lanes a sum is split over, and dnrm2's
 // 80-bit x87 accumulation, emulated here with 64-bit integer mantissas.  Plain IEEE double operations otherwise (the library is built with
 // -ffp-contract=off; fma() is v_fma_f64 / the C fma, division and sqrt are correctly rounded on both sides).
-// The routines work on a workspace in LDS (no private arrays, no calls) and are written for a GROUP of G lanes of one wavefront
-// per system (round 5; G = 1: one lane, which is also how tests/host compiles them for the CPU, where tests/test_stab_host.py
-// checks them against the recorded NumPy vectors and the reference fixtures).  What a bit of the result depends on is the
-// arithmetic of every ELEMENT -- which products are fused, in which order a sum runs -- not on who computes it:
-//   * the scalar chain of the algorithm (dnrm2, dlapy2, tau, the rotations of dbdsqr, every convergence test) is computed by
-//     EVERY lane of the group, redundantly: the same loads (LDS broadcasts), the same operations, the same stores of the same
-//     values -- so no lane ever waits for another one's scalar, and control flow is uniform within a group;
-//   * the loops over independent elements are split over the lanes, owner computes: a column of the trailing matrix (its
-//     dgemv 'T' sum -- by the kernel variant its POSITION selects -- and its dger update, fused), a row of it for a reflector
-//     from the right (dgemv 'N' row + dger row), a column of V^T / the right-hand side for a sweep's rotations, an element of
-//     dscal / dlascl / the sort's row swaps, a row of the closing dgemm.
-// Between a region of the second kind and its neighbours stands PCT_GSYNC: the lanes of a group run in lockstep (one
-// wavefront, group-uniform branches) and the LDS executes a wavefront's instructions in order, so what is needed is that the
-// COMPILER keeps the accesses on their side of the line -- a workgroup-scope fence (no s_barrier: groups of one wavefront that
-// solve different systems diverge from each other, a barrier inside such a branch would be wrong).
-#ifndef PCT_GELSD_CUH
-#define PCT_GELSD_CUH
+// The routines are written for one lane working on a workspace in LDS (no private arrays, no calls); tests/host compiles them
+// for the CPU, where tests/test_stab_host.py checks them against the recorded NumPy vectors and the reference fixtures.
+#ifndef PCT_GELSD_R04_CUH
+#define PCT_GELSD_R04_CUH
 
 #include <math.h>
 #include <stdint.h>
@@ -36,26 +23,16 @@
 #if defined(__HIPCC__)
 #define PCT_GD __device__ __forceinline__
 #define PCT_GNOUNROLL _Pragma("nounroll")
-#define PCT_GSYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup")
 #else
 #define PCT_GD static inline
 #define PCT_GNOUNROLL
-#define PCT_GSYNC() ((void)0)
-#endif
-// scripts/mb/mb_gelsd.hip defines these to book shader-clock cycles per phase; nothing anywhere else
-#if !defined(PCT_GPROF_T0)
-#define PCT_GPROF_T0(var)
-#define PCT_GPROF_ADD(slot, var)
 #endif
 // Every routine is inlined into the kernels (no calls inside a kernel, build.py), so each CALL SITE costs the routine's whole body:
 // the drivers below are written as loops over "which vector / which target" with ONE site per routine where that is possible
 // (PCT_GNOUNROLL keeps the compiler from undoing it).
 
 namespace pct {
-namespace gelsd {
-
-// the lanes that share one system: lane gl of G (G = 1: one lane does everything)
-struct Grp { int gl, G; };
+namespace gelsd_r04 {
 
 // ---- 80-bit extended precision (x87, round to nearest even, 64-bit mantissa), non-negative values only -----------------------
 // value = m * 2^e with 2^63 <= m < 2^64, or m == 0
@@ -151,9 +128,7 @@ PCT_GD double ext_sqrt_to_double(Ext x) {
   int e2;
   if (((x.e - 64) & 1) == 0) { nh = x.m; nl = 0; e2 = x.e - 64; }
   else { nh = x.m >> 1; nl = x.m << 63; e2 = x.e - 63; }
-  uint64_t root, rh, rl;  // root = floor(sqrt(N)); remainder N - root^2 = (rh : rl), at most 65 bits
-#if defined(PCT_GELSD_BITWISE_SQRT)
-  root = 0; rh = 0; rl = 0;  // (the round-4 digit-by-digit root, 64 dependent iterations: kept as the checker of the fast one, tests/host)
+  uint64_t root = 0, rh = 0, rl = 0;  // remainder (rh : rl), at most 65 bits
   for (int i = 0; i < 64; i++) {
     // rem = (rem << 2) | top two bits of N;  N <<= 2
     rh = (rh << 2) | (rl >> 62);
@@ -170,52 +145,6 @@ PCT_GD double ext_sqrt_to_double(Ext x) {
       root |= 1ull;
     }
   }
-#else
-  {
-    // A double-precision seed (within ~2^12 of the root), one Newton step with the exact 128-bit residual, then the exact
-    // correction by at most a few units: the result is floor(sqrt(N)) whatever the seed's last bits are (the device's sqrt
-    // and the host's may differ there), and the remainder comes out of the same integer arithmetic.
-    const double s = sqrt((double)nh) * 4294967296.0;
-    uint64_t r = s >= 18446744073709551616.0 ? ~0ull : (uint64_t)s;
-    if (r < (1ull << 63)) r = 1ull << 63;
-    {
-      const uint64_t ph = mulhi64(r, r), pl = r * r;
-      const uint64_t dl = nl - pl;
-      const int64_t dh = (int64_t)(nh - ph - (nl < pl ? 1ull : 0ull));
-      const double dd = (double)dh * 18446744073709551616.0 + (double)dl;
-      const double q = floor(dd / (2.0 * (double)r));
-      if (q >= 0.0) {
-        const uint64_t step = (uint64_t)q;
-        r = r + step < r ? ~0ull : r + step;
-      } else {
-        r -= (uint64_t)(-q);
-      }
-    }
-    // rem = N - r^2 as a two's-complement 128-bit number; while rem < 0: r--, rem += 2 r + 1; while rem > 2 r: rem -= 2 r + 1, r++
-    const uint64_t ph = mulhi64(r, r), pl = r * r;
-    rl = nl - pl;
-    rh = nh - ph - (nl < pl ? 1ull : 0ull);
-    PCT_GNOUNROLL
-    while ((int64_t)rh < 0) {
-      r -= 1;
-      const uint64_t th = r >> 63, tl = (r << 1) | 1ull;
-      const uint64_t nl2 = rl + tl;
-      rh = rh + th + (nl2 < rl ? 1ull : 0ull);
-      rl = nl2;
-    }
-    PCT_GNOUNROLL
-    while (true) {
-      const uint64_t th = r >> 63, tl2 = r << 1;  // 2 r = (th : tl2)
-      if (!(rh > th || (rh == th && rl > tl2))) break;
-      const uint64_t tl = tl2 | 1ull;
-      const uint64_t b = rl < tl ? 1ull : 0ull;
-      rl -= tl;
-      rh = rh - th - b;
-      r += 1;
-    }
-    root = r;
-  }
-#endif
   // round to nearest: up iff N - root^2 > root (a tie cannot occur)
   int e = e2 / 2;
   uint64_t m = root;
@@ -239,108 +168,85 @@ PCT_GD double ext_sqrt_to_double(Ext x) {
 // ---- BLAS, as OpenBLAS' SkylakeX kernel set computes it (kernel/x86_64: nrm2.S, dgemv_t_4.c + Haswell microkernels,
 // dgemv_n_4.c + SkylakeX microkernel, ger.c -> daxpy, drot + SkylakeX microkernel) ------------------------------------------
 // dnrm2: accumulators A..D over the leading blocks of eight (element i into accumulator i mod 4), the tail into A,
-// ((C + A) + B) + D, fsqrt, one rounding to double.  (Every lane of a group runs it: the loads are LDS broadcasts, eight in
-// flight at a time; the accumulation is the serial chain it is on the FPU.)
+// ((C + A) + B) + D, fsqrt, one rounding to double
 PCT_GD double dnrm2(int n, const double* x, int incx) {
   if (n <= 0) return 0.0;
-#if !defined(PCT_GELSD_NO_NRM2_SHORTCUT)
-  // One element: fsqrt(round64(x^2)) = |x| (1 + d) with |d| < 2^-64, |x| a 53-bit number: the 64-bit rounding of the root and the
-  // store to double both return |x| (checked against the long chain: tests/test_stab_host.py).  Three of the six non-trivial
-  // reflectors of a three-supporter system have such a one-element tail.
-  if (n == 1) return fabs(x[0]);
-#endif
   Ext a, b, c, d;
   a.m = b.m = c.m = d.m = 0;
   a.e = b.e = c.e = d.e = 0;
   const int n8 = n & ~7;
   PCT_GNOUNROLL
-  for (int i0 = 0; i0 < n; i0 += 8) {
-    double v0, v1, v2, v3, v4, v5, v6, v7;
-    v0 = x[i0 * incx];
-    v1 = i0 + 1 < n ? x[(i0 + 1) * incx] : 0.0;
-    v2 = i0 + 2 < n ? x[(i0 + 2) * incx] : 0.0;
-    v3 = i0 + 3 < n ? x[(i0 + 3) * incx] : 0.0;
-    v4 = i0 + 4 < n ? x[(i0 + 4) * incx] : 0.0;
-    v5 = i0 + 5 < n ? x[(i0 + 5) * incx] : 0.0;
-    v6 = i0 + 6 < n ? x[(i0 + 6) * incx] : 0.0;
-    v7 = i0 + 7 < n ? x[(i0 + 7) * incx] : 0.0;
-    const int cnt = n - i0 < 8 ? n - i0 : 8;
-    PCT_GNOUNROLL
-    for (int u = 0; u < cnt; u++) {
-      const double lo4 = (u & 2) ? ((u & 1) ? v3 : v2) : ((u & 1) ? v1 : v0);
-      const double hi4 = (u & 2) ? ((u & 1) ? v7 : v6) : ((u & 1) ? v5 : v4);
-      const Ext sq = ext_square((u & 4) ? hi4 : lo4);
-      const int w = i0 < n8 ? (u & 3) : 0;
-      Ext cur = w == 0 ? a : (w == 1 ? b : (w == 2 ? c : d));
-      cur = ext_add(cur, sq);
-      if (w == 0) a = cur;
-      else if (w == 1) b = cur;
-      else if (w == 2) c = cur;
-      else d = cur;
-    }
+  for (int i = 0; i < n; i++) {
+    const Ext sq = ext_square(x[i * incx]);
+    const int w = i < n8 ? (i & 3) : 0;
+    Ext cur = w == 0 ? a : (w == 1 ? b : (w == 2 ? c : d));
+    cur = ext_add(cur, sq);
+    if (w == 0) a = cur;
+    else if (w == 1) b = cur;
+    else if (w == 2) c = cur;
+    else d = cur;
   }
   Ext t = c;
   PCT_GNOUNROLL
   for (int k = 0; k < 3; k++) t = ext_add(t, k == 0 ? a : (k == 1 ? b : d));
   return ext_sqrt_to_double(t);
 }
-// x := alpha x, an element per lane
-PCT_GD void dscal(Grp g, int n, double alpha, double* x, int incx) {
-  for (int i = g.gl; i < n; i += g.G) x[i * incx] = alpha * x[i * incx];
+PCT_GD void dscal(int n, double alpha, double* x, int incx) {
+  for (int i = 0; i < n; i++) x[i * incx] = alpha * x[i * incx];
 }
-// One column of y = A^T x (alpha = 1, beta = 0), column j of n (c points at it): rows in groups of four -- by the 4x4 kernel
-// (AVX2 FMA, four lanes, (l0 + l2) + (l1 + l3)) for the columns of the leading groups of four, then two columns by the 4x2
-// kernel (SSE2, two lanes, products and sums rounded separately, l0 + l1), then one by the 4x1 kernel (SSE2, (r0 + r2) +
-// (r1 + r3)) -- and the m mod 4 tail rows: t = a1 x1; fma(a0, x0, t); fma(a2, x2, t); y + t.  Which kernel a column meets
-// depends on its POSITION j among the n columns of the call.
-PCT_GD double dgemv_t_col(int m, int n, int j, const double* c, const double* x, int incx) {
+// y[0..n) = A^T x (alpha = 1, beta = 0): rows in groups of four -- columns by the 4x4 kernel (AVX2 FMA, four lanes,
+// (l0 + l2) + (l1 + l3)), then two by the 4x2 kernel (SSE2, two lanes, products and sums rounded separately, l0 + l1), then
+// one by the 4x1 kernel (SSE2, (r0 + r2) + (r1 + r3)) -- and the m mod 4 tail rows: t = a1 x1; fma(a0, x0, t); fma(a2, x2, t); y + t
+PCT_GD void dgemv_t(int m, int n, const double* a, int lda, const double* x, int incx, double* y) {
   const int m2 = m & ~3, m3 = m & 3, n4 = n & ~3;
-  double yj = 0.0;
-  if (m2 > 0) {
-    if (j < n4) {
-      double l0 = 0, l1 = 0, l2 = 0, l3 = 0;
-      for (int i = 0; i < m2; i += 4) {
-        l0 = fma(c[i], x[i * incx], l0);
-        l1 = fma(c[i + 1], x[(i + 1) * incx], l1);
-        l2 = fma(c[i + 2], x[(i + 2) * incx], l2);
-        l3 = fma(c[i + 3], x[(i + 3) * incx], l3);
+  for (int j = 0; j < n; j++) {
+    const double* c = a + j * lda;
+    double yj = 0.0;
+    if (m2 > 0) {
+      if (j < n4) {
+        double l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+        for (int i = 0; i < m2; i += 4) {
+          l0 = fma(c[i], x[i * incx], l0);
+          l1 = fma(c[i + 1], x[(i + 1) * incx], l1);
+          l2 = fma(c[i + 2], x[(i + 2) * incx], l2);
+          l3 = fma(c[i + 3], x[(i + 3) * incx], l3);
+        }
+        const double t = (l0 + l2) + (l1 + l3);
+        yj = yj + t * 1.0;
+      } else if ((n & 2) && j < n4 + 2) {
+        double l0 = 0, l1 = 0;
+        for (int i = 0; i < m2; i += 2) {
+          l0 = l0 + c[i] * x[i * incx];
+          l1 = l1 + c[i + 1] * x[(i + 1) * incx];
+        }
+        yj = fma(1.0, l0 + l1, yj);
+      } else {
+        double l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+        for (int i = 0; i < m2; i += 4) {
+          l0 = l0 + c[i] * x[i * incx];
+          l1 = l1 + c[i + 1] * x[(i + 1) * incx];
+          l2 = l2 + c[i + 2] * x[(i + 2) * incx];
+          l3 = l3 + c[i + 3] * x[(i + 3) * incx];
+        }
+        yj = fma(1.0, (l0 + l2) + (l1 + l3), yj);
       }
-      const double t = (l0 + l2) + (l1 + l3);
-      yj = yj + t * 1.0;
-    } else if ((n & 2) && j < n4 + 2) {
-      double l0 = 0, l1 = 0;
-      for (int i = 0; i < m2; i += 2) {
-        l0 = l0 + c[i] * x[i * incx];
-        l1 = l1 + c[i + 1] * x[(i + 1) * incx];
-      }
-      yj = fma(1.0, l0 + l1, yj);
-    } else {
-      double l0 = 0, l1 = 0, l2 = 0, l3 = 0;
-      for (int i = 0; i < m2; i += 4) {
-        l0 = l0 + c[i] * x[i * incx];
-        l1 = l1 + c[i + 1] * x[(i + 1) * incx];
-        l2 = l2 + c[i + 2] * x[(i + 2) * incx];
-        l3 = l3 + c[i + 3] * x[(i + 3) * incx];
-      }
-      yj = fma(1.0, (l0 + l2) + (l1 + l3), yj);
     }
+    if (m3 == 1) yj = fma(c[m2], x[m2 * incx], yj);
+    else if (m3 >= 2) {
+      double t = c[m2 + 1] * x[(m2 + 1) * incx];
+      t = fma(c[m2], x[m2 * incx], t);
+      if (m3 == 3) t = fma(c[m2 + 2], x[(m2 + 2) * incx], t);
+      yj = yj + t;
+    }
+    y[j] = yj;
   }
-  if (m3 == 1) yj = fma(c[m2], x[m2 * incx], yj);
-  else if (m3 >= 2) {
-    double t = c[m2 + 1] * x[(m2 + 1) * incx];
-    t = fma(c[m2], x[m2 * incx], t);
-    if (m3 == 3) t = fma(c[m2 + 2], x[(m2 + 2) * incx], t);
-    yj = yj + t;
-  }
-  return yj;
 }
-// One row of y = A x (alpha = 1, beta = 0), row i of m, with a STRIDED x (dlarf from the right in dgebd2: x is a row of A):
-// rows in groups of four -- columns in groups of four (t = a1 x1; fma a0 x0; fma a2 x2; fma a3 x3; y = fma(1, t, y)), the
-// rest one by one, y + a x rounded separately -- and the tail rows: t = fma(a, x, t) over all columns.  avx2: the Haswell
-// kernel set instead
-PCT_GD double dgemv_n_row(int m, int n, int i, const double* a, int lda, const double* x, int incx, bool avx2) {
+// y[0..m) = A x (alpha = 1, beta = 0) with a STRIDED x (dlarf from the right in dgebd2: x is a row of A): rows in groups of
+// four -- columns in groups of four (t = a1 x1; fma a0 x0; fma a2 x2; fma a3 x3; y = fma(1, t, y)), the rest one by one,
+// y + a x rounded separately -- and the tail rows: t = fma(a, x, t) over all columns.  avx2: the Haswell kernel set instead
+PCT_GD void dgemv_n_strided(int m, int n, const double* a, int lda, const double* x, int incx, double* y, bool avx2) {
   const int m2 = m & ~3, n4 = n & ~3;
-  if (i < m2) {
+  for (int i = 0; i < m2; i++) {
     double yi = 0.0;
     for (int j = 0; j < n4; j += 4) {
       double t;
@@ -358,16 +264,34 @@ PCT_GD double dgemv_n_row(int m, int n, int i, const double* a, int lda, const d
       yi = fma(1.0, t, yi);
     }
     for (int j = n4; j < n; j++) yi = yi + a[i + j * lda] * (x[j * incx] * 1.0);
-    return yi;
+    y[i] = yi;
   }
-  // the C tail: one FMA chain (SkylakeX build) / products and sums rounded separately (Haswell build)
-  double t = 0.0;
-  for (int j = 0; j < n; j++) t = avx2 ? t + a[i + j * lda] * x[j * incx] : fma(a[i + j * lda], x[j * incx], t);
-  return avx2 ? 0.0 + 1.0 * t : fma(1.0, t, 0.0);
+  for (int i = m2; i < m; i++) {  // the C tail: one FMA chain (SkylakeX build) / products and sums rounded separately (Haswell build)
+    double t = 0.0;
+    for (int j = 0; j < n; j++) t = avx2 ? t + a[i + j * lda] * x[j * incx] : fma(a[i + j * lda], x[j * incx], t);
+    y[i] = avx2 ? 0.0 + 1.0 * t : fma(1.0, t, 0.0);
+  }
 }
-// dger's element: A += alpha x y^T is, per column, t = alpha y_j and a_ij = fma(t, x_i, a_ij) (daxpy; Haswell daxpy: blocks of
-// sixteen through the FMA microkernel, the rest multiply and add rounded separately -- `fused` says which)
-PCT_GD double dger_elem(double t, double xi, double aij, bool fused) { return fused ? fma(t, xi, aij) : aij + t * xi; }
+// A += alpha x y^T: per column t = alpha y_j, a_ij = fma(t, x_i, a_ij)
+PCT_GD void dger(int m, int n, double alpha, const double* x, int incx, const double* y, int incy, double* a, int lda, bool avx2) {
+  if (alpha == 0.0) return;
+  // (Haswell daxpy: blocks of sixteen through the FMA microkernel, the rest multiply and add rounded separately)
+  const int mf = avx2 ? (m & ~15) : m;
+  for (int j = 0; j < n; j++) {
+    const double t = alpha * y[j * incy];
+    for (int i = 0; i < m; i++) {
+      const double v = a[i + j * lda];
+      a[i + j * lda] = i < mf ? fma(t, x[i * incx], v) : v + t * x[i * incx];
+    }
+  }
+}
+PCT_GD void drot(int n, double* x, int incx, double* y, int incy, double c, double s) {
+  for (int i = 0; i < n; i++) {
+    const double xv = x[i * incx], yv = y[i * incy];
+    x[i * incx] = fma(c, xv, s * yv);
+    y[i * incy] = fma(c, yv, -(s * xv));
+  }
+}
 
 // ---- LAPACK 3.11 (compiled Fortran: plain double arithmetic in program order) ----------------------------------------------
 constexpr double EPS = 1.1102230246251565e-16;      // dlamch('E')
@@ -381,77 +305,50 @@ PCT_GD double dlapy2(double x, double y) {
   const double q = z / w;
   return w * sqrt(1.0 + q * q);
 }
-// dlarfg(n, alpha, x, incx): returns tau; x is scaled in place (an element per lane); `beta` is what dlarfg leaves in alpha
-// (alpha itself when tau = 0) -- the caller stores it when it has applied the reflector, whose leading 1 it writes there first
-PCT_GD double dlarfg(Grp g, int n, const double* alpha, double* x, int incx, double& beta) {
-  double a0 = *alpha;
-  beta = a0;
-  if (n <= 1) return 0.0;
+PCT_GD void dlarfg(int n, double* alpha, double* x, int incx, double* tau) {
+  if (n <= 1) { *tau = 0.0; return; }
   const double safmin = SAFMIN / EPS, rsafmn = 1.0 / safmin;
   int knt = 0;
+  double beta = 0.0;
   PCT_GNOUNROLL
   for (int pass = 0; pass < 2; pass++) {  // (the second pass: after a rescaling of a tiny vector, which these systems never need)
-    PCT_GPROF_T0(tn)
     const double xnorm = dnrm2(n - 1, x, incx);
-    PCT_GPROF_ADD(5, tn)
-    if (pass == 0 && xnorm == 0.0) return 0.0;
-    beta = -sgn(dlapy2(a0, xnorm), a0);
+    if (pass == 0 && xnorm == 0.0) { *tau = 0.0; return; }
+    beta = -sgn(dlapy2(*alpha, xnorm), *alpha);
     if (pass == 1 || !(fabs(beta) < safmin)) break;
     do {
       knt++;
-      PCT_GSYNC();
-      dscal(g, n - 1, rsafmn, x, incx);
-      PCT_GSYNC();
+      dscal(n - 1, rsafmn, x, incx);
       beta *= rsafmn;
-      a0 *= rsafmn;
+      *alpha *= rsafmn;
     } while (fabs(beta) < safmin && knt < 20);
   }
-  const double tau = (beta - a0) / beta;
-  PCT_GSYNC();
-  dscal(g, n - 1, 1.0 / (a0 - beta), x, incx);
-  PCT_GSYNC();
+  *tau = (beta - *alpha) / beta;
+  dscal(n - 1, 1.0 / (*alpha - beta), x, incx);
   for (int j = 0; j < knt; j++) beta *= safmin;
-  return tau;
+  *alpha = beta;
 }
-// dlarf from the left, H = I - tau v v^T (v[0] = 1 stored): onto the nc columns at c (the call on A's trailing columns) and --
-// a call of its own in LAPACK (dorm2r / dorml2: one column) -- onto the column bcol (or null).  A column per lane: its dgemv 'T'
-// sum and its dger update (work(j) never leaves the lane).  Trailing zeros of v and trailing zero columns of C are skipped (iladlr / iladlc).
-PCT_GD void dlarf_left(Grp g, int m, int nc, const double* v, int incv, double tau, double* c, int ldc, double* bcol, bool avx2) {
+// dlarf from the left: C (m x n) := (I - tau v v^T) C; trailing zeros of v and trailing zero columns of C are skipped
+PCT_GD void dlarf_left(int m, int n, const double* v, int incv, double tau, double* c, int ldc, double* work, bool avx2) {
   if (tau == 0.0) return;
   int lastv = m;
   while (lastv > 0 && v[(lastv - 1) * incv] == 0.0) lastv--;
-  if (lastv <= 0) return;
-  int lastc = nc;
+  int lastc = n;
   for (; lastc > 0; lastc--) {
     bool nz = false;
     for (int i = 0; i < lastv; i++)
       if (c[i + (lastc - 1) * ldc] != 0.0) { nz = true; break; }
     if (nz) break;
   }
-  const int mf = avx2 ? (lastv & ~15) : lastv;
-  PCT_GSYNC();
-  PCT_GNOUNROLL
-  for (int t = g.gl; t < lastc + (bcol ? 1 : 0); t += g.G) {
-    const bool isb = t >= lastc;
-    double* col = isb ? bcol : c + t * ldc;
-    if (isb) {  // (the call on one column: it is skipped when that column is zero)
-      bool nz = false;
-      for (int i = 0; i < lastv; i++)
-        if (col[i] != 0.0) { nz = true; break; }
-      if (!nz) continue;
-    }
-    const double w = dgemv_t_col(lastv, isb ? 1 : lastc, isb ? 0 : t, col, v, incv);
-    const double tt = -tau * w;
-    for (int i = 0; i < lastv; i++) col[i] = dger_elem(tt, v[i * incv], col[i], i < mf);
-  }
-  PCT_GSYNC();
+  if (lastv <= 0) return;
+  dgemv_t(lastv, lastc, c, ldc, v, incv, work);
+  dger(lastv, lastc, -tau, v, incv, work, 1, c, ldc, avx2);
 }
-// dlarf from the right: C (m x n) := C (I - tau v v^T), v a strided row.  A row per lane: its dgemv 'N' sum, its dger update
-PCT_GD void dlarf_right(Grp g, int m, int n, const double* v, int incv, double tau, double* c, int ldc, bool avx2) {
+// dlarf from the right: C (m x n) := C (I - tau v v^T), v a strided row
+PCT_GD void dlarf_right(int m, int n, const double* v, int incv, double tau, double* c, int ldc, double* work, bool avx2) {
   if (tau == 0.0) return;
   int lastv = n;
   while (lastv > 0 && v[(lastv - 1) * incv] == 0.0) lastv--;
-  if (lastv <= 0) return;
   int lastc = m;
   for (; lastc > 0; lastc--) {
     bool nz = false;
@@ -459,17 +356,9 @@ PCT_GD void dlarf_right(Grp g, int m, int n, const double* v, int incv, double t
       if (c[(lastc - 1) + j * ldc] != 0.0) { nz = true; break; }
     if (nz) break;
   }
-  const int mf = avx2 ? (lastc & ~15) : lastc;
-  PCT_GSYNC();
-  PCT_GNOUNROLL
-  for (int i = g.gl; i < lastc; i += g.G) {
-    const double w = dgemv_n_row(lastc, lastv, i, c, ldc, v, incv, avx2);
-    for (int j = 0; j < lastv; j++) {
-      const double tt = -tau * v[j * incv];
-      c[i + j * ldc] = dger_elem(tt, w, c[i + j * ldc], i < mf);
-    }
-  }
-  PCT_GSYNC();
+  if (lastv <= 0) return;
+  dgemv_n_strided(lastc, lastv, c, ldc, v, incv, work, avx2);
+  dger(lastc, lastv, -tau, work, 1, v, incv, c, ldc, avx2);
 }
 PCT_GD void dlartg(double f, double g, double& c, double& s, double& r) {
   const double safmax = 1.0 / SAFMIN;
@@ -575,12 +464,11 @@ PCT_GD void dlasv2(double f, double g, double h, double& ssmin, double& ssmax, d
   ssmax = sgn(ssmax, tsign);
   ssmin = sgn(ssmin, tsign * sgn(1.0, f) * sgn(1.0, h));
 }
-// dlascl('G', 0, 0, cfrom, cto, ...) on a vector (the multipliers: every lane; the elements: a lane each)
-PCT_GD void dlascl_vec(Grp g, double cfrom, double cto, int n, double* x) {
+// dlascl('G', 0, 0, cfrom, cto, ...) on a vector
+PCT_GD void dlascl_vec(double cfrom, double cto, int n, double* x) {
   const double smlnum = SAFMIN, bignum = 1.0 / smlnum;
   double cfromc = cfrom, ctoc = cto, mul;
   bool done;
-  PCT_GSYNC();
   do {
     const double cfrom1 = cfromc * smlnum;
     if (cfrom1 == cfromc) { mul = ctoc / cfromc; done = true; }
@@ -589,18 +477,15 @@ PCT_GD void dlascl_vec(Grp g, double cfrom, double cto, int n, double* x) {
       if (cto1 == ctoc) { mul = ctoc; done = true; cfromc = 1.0; }
       else if (fabs(cfrom1) > fabs(ctoc) && ctoc != 0.0) { mul = smlnum; done = false; cfromc = cfrom1; }
       else if (fabs(cto1) > fabs(cfromc)) { mul = bignum; done = false; ctoc = cto1; }
-      else { mul = ctoc / cfromc; done = true; if (mul == 1.0) break; }
+      else { mul = ctoc / cfromc; done = true; if (mul == 1.0) return; }
     }
-    for (int i = g.gl; i < n; i += g.G) x[i] = x[i] * mul;
+    for (int i = 0; i < n; i++) x[i] = x[i] * mul;
   } while (!done);
-  PCT_GSYNC();
 }
 
 // dbdsqr('U', n, ncvt = n, 0, ncc = 1): SVD of the upper bidiagonal (d, e); right rotations into VT (n x n, ldvt = n), left
 // ones into the column cc.  work: 4 (n - 1) doubles.  Returns false when the iteration limit is reached.
-// The chase itself (d, e, the rotations' cosines and sines into work) is the scalar chain every lane runs; a sweep's rotations
-// are then applied a COLUMN of VT (and the column cc) per lane.
-PCT_GD bool dbdsqr(Grp g, int n, double* d, double* e, double* vt, double* cc, double* work) {
+PCT_GD bool dbdsqr(int n, double* d, double* e, double* vt, double* cc, double* work) {
   const double hndrth = 0.01;
   const int maxitr = 6;
   const int ldvt = n;
@@ -655,16 +540,8 @@ PCT_GD bool dbdsqr(Grp g, int n, double* d, double* e, double* vt, double* cc, d
         double sigmn, sigmx, sinr, cosr, sinl, cosl;
         dlasv2(d[m - 2], e[m - 2], d[m - 1], sigmn, sigmx, sinr, cosr, sinl, cosl);
         d[m - 2] = sigmx; e[m - 2] = 0.0; d[m - 1] = sigmn;
-        // drot on rows m - 2, m - 1 of VT (an element pair per lane) and on the pair of cc (x' = fma(c, x, s y), y' = fma(c, y, -(s x)))
-        PCT_GSYNC();
-        for (int i = g.gl; i < n + 1; i += g.G) {
-          double* px = i < n ? &vt[(m - 2) + i * ldvt] : &cc[m - 2];
-          const double cr = i < n ? cosr : cosl, sr = i < n ? sinr : sinl;
-          const double xv = px[0], yv = px[1];
-          px[0] = fma(cr, xv, sr * yv);
-          px[1] = fma(cr, yv, -(sr * xv));
-        }
-        PCT_GSYNC();
+        drot(n, &vt[m - 2], ldvt, &vt[m - 1], ldvt, cosr, sinr);
+        drot(1, &cc[m - 2], 1, &cc[m - 1], 1, cosl, sinl);
         m = m - 2;
         continue;
       }
@@ -733,23 +610,23 @@ PCT_GD bool dbdsqr(Grp g, int n, double* d, double* e, double* vt, double* cc, d
         e[ebase + step * (cnt - 2)] = h * oldsn;
       } else {
         double f = (fabs(d[dbase]) - shift) * (sgn(1.0, d[dbase]) + shift / d[dbase]);
-        double gg = e[ebase];
+        double g = e[ebase];
         double cosr, sinr, cosl, sinl;
         PCT_GNOUNROLL
         for (int p = 0; p < cnt - 1; p++) {
           const int dp = dbase + step * p, dq = dp + step, ep = ebase + step * p;
-          dlartg(f, gg, cosr, sinr, r);
+          dlartg(f, g, cosr, sinr, r);
           if (p > 0) e[ep - step] = r;
           f = cosr * d[dp] + sinr * e[ep];
           e[ep] = cosr * e[ep] - sinr * d[dp];
-          gg = sinr * d[dq];
+          g = sinr * d[dq];
           d[dq] = cosr * d[dq];
-          dlartg(f, gg, cosl, sinl, r);
+          dlartg(f, g, cosl, sinl, r);
           d[dp] = r;
           f = cosl * e[ep] + sinl * d[dq];
           d[dq] = cosl * d[dq] - sinl * e[ep];
           if (p < cnt - 2) {
-            gg = sinl * e[ep + step];
+            g = sinl * e[ep + step];
             e[ep + step] = cosl * e[ep + step];
           }
           w0[p] = cosr; w1[p] = sg * sinr; w2[p] = cosl; w3[p] = sg * sinl;
@@ -757,26 +634,27 @@ PCT_GD bool dbdsqr(Grp g, int n, double* d, double* e, double* vt, double* cc, d
         e[ebase + step * (cnt - 2)] = f;
       }
       // dlasr('L', 'V', 'F' / 'B'): the right rotations (the first pair of a step) go into VT when chasing downwards, into the
-      // column cc when chasing upwards, the left rotations into the other one -- in the order of the sweep; a column per lane
-      PCT_GSYNC();
+      // column cc when chasing upwards, the left rotations into the other one -- in the order of the sweep
       PCT_GNOUNROLL
-      for (int c = g.gl; c < n + 1; c += g.G) {
-        const bool first = (c < n) == (idir == 1);
+      for (int tgt = 0; tgt < 2; tgt++) {
+        const bool first = (tgt == 0) == (idir == 1);
         const double* cw = first ? w0 : w2;
         const double* sw = first ? w1 : w3;
-        double* col = c < n ? vt + c * ldvt : cc;
+        double* mat = tgt == 0 ? vt : cc;
+        const int ncol = tgt == 0 ? n : 1;
         for (int p = 0; p < cnt - 1; p++) {
           const double ct = cw[p], st = sw[p];
           if (ct != 1.0 || st != 0.0) {
             const int dp = dbase + step * p, dq = dp + step;
             const int rhi = idir == 1 ? dq : dp, rlo = idir == 1 ? dp : dq;
-            const double temp = col[rhi];
-            col[rhi] = ct * temp - st * col[rlo];
-            col[rlo] = st * temp + ct * col[rlo];
+            for (int c = 0; c < ncol; c++) {
+              const double temp = mat[rhi + c * ldvt];
+              mat[rhi + c * ldvt] = ct * temp - st * mat[rlo + c * ldvt];
+              mat[rlo + c * ldvt] = st * temp + ct * mat[rlo + c * ldvt];
+            }
           }
         }
       }
-      PCT_GSYNC();
       {
         const int el = ebase + step * (cnt - 2);
         if (fabs(e[el]) <= thresh) e[el] = 0.0;
@@ -787,12 +665,10 @@ PCT_GD bool dbdsqr(Grp g, int n, double* d, double* e, double* vt, double* cc, d
     if (d[i] == 0.0) d[i] = 0.0;
     if (d[i] < 0.0) {
       d[i] = -d[i];
-      PCT_GSYNC();
-      dscal(g, n, -1.0, &vt[i], ldvt);
-      PCT_GSYNC();
+      dscal(n, -1.0, &vt[i], ldvt);
     }
   }
-  // decreasing order: one transposition per singular value (the rows of VT: a column per lane)
+  // decreasing order: one transposition per singular value
   for (int i = 1; i <= n - 1; i++) {
     int isub = 1;
     double smn = d[0];
@@ -801,14 +677,14 @@ PCT_GD bool dbdsqr(Grp g, int n, double* d, double* e, double* vt, double* cc, d
     if (isub != n + 1 - i) {
       d[isub - 1] = d[n - i];
       d[n - i] = smn;
-      PCT_GSYNC();
-      for (int c = g.gl; c < n + 1; c += g.G) {
-        double* col = c < n ? vt + c * ldvt : cc;
-        const double t = col[isub - 1];
-        col[isub - 1] = col[n - i];
-        col[n - i] = t;
+      for (int c = 0; c < n; c++) {
+        const double t = vt[(isub - 1) + c * ldvt];
+        vt[(isub - 1) + c * ldvt] = vt[(n - i) + c * ldvt];
+        vt[(n - i) + c * ldvt] = t;
       }
-      PCT_GSYNC();
+      const double t = cc[isub - 1];
+      cc[isub - 1] = cc[n - i];
+      cc[n - i] = t;
     }
   }
   return true;
@@ -823,11 +699,11 @@ constexpr double ILL_BAND = 1e3;  // the notice: a singular value within this fa
 
 // The split of a stack at (s0, s1) over k >= 3 supporters with contact centres in[2 i], in[2 i + 1] (D/space.py:134-163): the
 // system (one row per supporter pair i < j, a closing row of ones, right-hand side e_M) is built in ws and solved as dgelsd
-// solves it, by the lanes of g (all of them call, with the same arguments).  x[0..k): the fractions.  `ill`: a singular value
-// within 1e3 of the rank cut.  Returns false when dbdsqr does not converge (NumPy raises LinAlgError there; x is zero then).
+// solves it.  x[0..k): the fractions.  `ill`: a singular value within 1e3 of the rank cut.  Returns false when dbdsqr does not
+// converge (NumPy raises LinAlgError there; x is zero then).
 // (dot2: pct_stab.cuh's stab_dot2, np.dot of two 2-vectors on an FMA host, passed in to keep it the single definition)
 template <typename Dot2>
-PCT_GD bool split_t(Grp g, double* ws, int k, const double* in, double s0, double s1, Dot2 dot2, double* x, bool& ill, bool avx2 = false) {
+PCT_GD bool split_t(double* ws, int k, const double* in, double s0, double s1, Dot2 dot2, double* x, bool& ill, bool avx2 = false) {
   const int n = k, M = k * (k - 1) / 2 + 1, lda = M;
   double* a = ws;
   double* b = a + M * n;
@@ -837,31 +713,27 @@ PCT_GD bool split_t(Grp g, double* ws, int k, const double* in, double s0, doubl
   double* d = taup + n;
   double* e = d + n;
   double* work = e + n;       // 4 n
-  PCT_GPROF_T0(tp0)
-  PCT_GSYNC();
-  for (int i = g.gl; i < M * n + M; i += g.G) a[i] = 0.0;  // (A and b are adjacent)
-  PCT_GSYNC();
+  for (int i = 0; i < M * n; i++) a[i] = 0.0;
+  for (int i = 0; i < M; i++) b[i] = 0.0;
   {
-    // a pair row per lane: row (i, j), i < j, in the order of the double loop
-    for (int row = g.gl; row < M - 1; row += g.G) {
-      int i = 0, base = 0;
-      while (row >= base + (k - 1 - i)) { base += k - 1 - i; i++; }
-      const int j = i + 1 + (row - base);
-      const double ei0 = in[2 * i], ei1 = in[2 * i + 1], ej0 = in[2 * j], ej1 = in[2 * j + 1];
-      const double t0 = ei0 - ej0, t1 = ei1 - ej1;
-      const double mol = dot2(s0 - ei0, s1 - ei1, t0, t1);
-      if (mol != 0) {
-        const double rr = fabs(dot2(s0 - ej0, s1 - ej1, t0, t1)) / mol;
-        a[row + i * lda] = 1.0;
-        a[row + j * lda] = -rr;
+    int row = 0;
+    for (int i = 0; i < k - 1; i++)
+      for (int j = i + 1; j < k; j++) {
+        const double ei0 = in[2 * i], ei1 = in[2 * i + 1], ej0 = in[2 * j], ej1 = in[2 * j + 1];
+        const double t0 = ei0 - ej0, t1 = ei1 - ej1;
+        const double mol = dot2(s0 - ei0, s1 - ei1, t0, t1);
+        if (mol != 0) {
+          const double rr = fabs(dot2(s0 - ej0, s1 - ej1, t0, t1)) / mol;
+          a[row + i * lda] = 1.0;
+          a[row + j * lda] = -rr;
+        }
+        row++;
       }
-    }
-    for (int j = g.gl; j < k; j += g.G) { a[(M - 1) + j * lda] = 1.0; x[j] = 0.0; }
-    if (g.gl == 0) b[M - 1] = 1.0;
+    for (int j = 0; j < k; j++) a[(M - 1) + j * lda] = 1.0;
+    b[M - 1] = 1.0;
   }
-  PCT_GSYNC();
+  for (int j = 0; j < n; j++) x[j] = 0.0;
   ill = false;
-  PCT_GPROF_ADD(0, tp0)
   // (dgelsd scales A and b only when an entry leaves [1e-292, 1e292]; the closing row of ones keeps max|A| >= 1)
   // Stage 0, dgeqr2 + dorm2r: A = Q R by column reflectors, each applied to the trailing columns and -- dorm2r('L', 'T') applies
   // the same reflectors to b in the same order, and b meets nothing else in between -- to b at once.  Stage 1, dgebd2 + dormbr('Q'):
@@ -869,7 +741,6 @@ PCT_GD bool split_t(Grp g, double* ws, int k, const double* in, double s0, doubl
   // reflectors (taup) meet b only after the bidiagonal solve.
   PCT_GNOUNROLL
   for (int stage = 0; stage < 2; stage++) {
-    PCT_GPROF_T0(tst)
     const int rows = stage == 0 ? M : n;
     PCT_GNOUNROLL
     for (int i = 0; i < n; i++) {
@@ -880,44 +751,42 @@ PCT_GD bool split_t(Grp g, double* ws, int k, const double* in, double s0, doubl
         const int inc = part == 0 ? 1 : lda;
         double* alpha = part == 0 ? &a[i + i * lda] : &a[i + (i + 1) * lda];
         double* xv = part == 0 ? &a[(i + 1 < rows ? i + 1 : rows - 1) + i * lda] : &a[i + (i + 2 < n ? i + 2 : n - 1) * lda];
-        double saved;
-        const double tauv = dlarfg(g, len, alpha, xv, inc, saved);
+        double tauv;
+        dlarfg(len, alpha, xv, inc, &tauv);
+        const double saved = *alpha;
         if (stage == 1) {
           if (part == 0) d[i] = saved;
           else { e[i] = saved; taup[i] = tauv; }
         }
-        if (tauv != 0.0) {
-          *alpha = 1.0;
-          if (part == 0) dlarf_left(g, len, n - i - 1, alpha, 1, tauv, &a[i + (i + 1) * lda], lda, &b[i], avx2);
-          else dlarf_right(g, n - i - 1, n - i - 1, alpha, lda, tauv, &a[(i + 1) + (i + 1) * lda], lda, avx2);
+        *alpha = 1.0;
+        if (part == 0) {
+          PCT_GNOUNROLL
+          for (int tgt = 0; tgt < 2; tgt++) {  // the trailing columns of A, then b
+            const int nc = tgt == 0 ? n - i - 1 : 1;
+            double* c = tgt == 0 ? &a[i + (i + 1) * lda] : &b[i];
+            if (nc > 0) dlarf_left(len, nc, alpha, 1, tauv, c, lda, work, avx2);
+          }
+        } else {
+          dlarf_right(n - i - 1, n - i - 1, alpha, lda, tauv, &a[(i + 1) + (i + 1) * lda], lda, work, avx2);
         }
         *alpha = saved;
       }
     }
-    if (stage == 0) {
-      PCT_GSYNC();
-      for (int q = g.gl; q < n * n; q += g.G) {
-        const int j = q / n, i = q - j * n;
-        if (i > j) a[i + j * lda] = 0.0;
-      }
-      PCT_GSYNC();
-    }
-    PCT_GPROF_ADD(1 + stage, tst)
+    if (stage == 0)
+      for (int j = 0; j < n - 1; j++)
+        for (int i = j + 1; i < n; i++) a[i + j * lda] = 0.0;
   }
   taup[n - 1] = 0.0;
-  PCT_GPROF_T0(tbd)
   // dlalsd('U', 25, n, 1, d, e, b, ...)
   double orgnrm = 0.0;
   for (int i = 0; i < n; i++) orgnrm = fabs(d[i]) > orgnrm ? fabs(d[i]) : orgnrm;
   for (int i = 0; i < n - 1; i++) orgnrm = fabs(e[i]) > orgnrm ? fabs(e[i]) : orgnrm;
   if (orgnrm == 0.0) return true;
-  dlascl_vec(g, orgnrm, 1.0, n, d);
-  dlascl_vec(g, orgnrm, 1.0, n - 1, e);
-  for (int q = g.gl; q < n * n; q += g.G) vt[q] = (q / n == q % n) ? 1.0 : 0.0;
-  PCT_GSYNC();
-  if (!dbdsqr(g, n, d, e, vt, b, work)) { ill = true; return false; }
-  PCT_GPROF_ADD(3, tbd)
-  PCT_GPROF_T0(tfin)
+  dlascl_vec(orgnrm, 1.0, n, d);
+  dlascl_vec(orgnrm, 1.0, n - 1, e);
+  for (int i = 0; i < n * n; i++) vt[i] = 0.0;
+  for (int i = 0; i < n; i++) vt[i + i * n] = 1.0;
+  if (!dbdsqr(n, d, e, vt, b, work)) { ill = true; return false; }
   // dlasdq: into increasing order
   for (int i = 1; i <= n; i++) {
     int isub = i;
@@ -927,14 +796,14 @@ PCT_GD bool split_t(Grp g, double* ws, int k, const double* in, double s0, doubl
     if (isub != i) {
       d[isub - 1] = d[i - 1];
       d[i - 1] = smn;
-      PCT_GSYNC();
-      for (int c = g.gl; c < n + 1; c += g.G) {
-        double* col = c < n ? vt + c * n : b;
-        const double t = col[isub - 1];
-        col[isub - 1] = col[i - 1];
-        col[i - 1] = t;
+      for (int c = 0; c < n; c++) {
+        const double t = vt[(isub - 1) + c * n];
+        vt[(isub - 1) + c * n] = vt[(i - 1) + c * n];
+        vt[(i - 1) + c * n] = t;
       }
-      PCT_GSYNC();
+      const double t = b[isub - 1];
+      b[isub - 1] = b[i - 1];
+      b[i - 1] = t;
     }
   }
   int imax = 0;
@@ -944,19 +813,14 @@ PCT_GD bool split_t(Grp g, double* ws, int k, const double* in, double s0, doubl
   const double tol = rcond * fabs(d[imax]);
   for (int i = 0; i < n; i++)
     if (d[i] > 0.0 && d[i] > tol / ILL_BAND && d[i] < tol * ILL_BAND) ill = true;
-  // b(i) = 0 below the cut, else dlascl(d(i) -> 1) of the one element; then dgemm('T', 'N', n, 1, n): the packed kernel, acc =
-  // fma(vt(k, i), b(k), acc) in k order (Haswell kernel: rows in groups of four with four accumulators over the leading blocks
-  // of eight k, the tail into the first, (q0 + q1) + (q2 + q3); its n mod 4 last rows, like every row of the SkylakeX kernel, one
-  // chain); a row per lane
-  {
-    const Grp one = {0, 1};
-    for (int i = g.gl; i < n; i += g.G) {
-      if (d[i] <= tol) b[i] = 0.0;
-      else dlascl_vec(one, d[i], 1.0, 1, &b[i]);
-    }
+  for (int i = 0; i < n; i++) {
+    if (d[i] <= tol) b[i] = 0.0;
+    else dlascl_vec(d[i], 1.0, 1, &b[i]);
   }
-  PCT_GSYNC();
-  for (int i = g.gl; i < n; i += g.G) {
+  // dgemm('T', 'N', n, 1, n): the packed kernel, acc = fma(vt(k, i), b(k), acc) in k order
+  // (Haswell kernel: rows in groups of four with four accumulators over the leading blocks of eight k, the tail into the first,
+  // (q0 + q1) + (q2 + q3); its n mod 4 last rows, like every row of the SkylakeX kernel, one chain)
+  for (int i = 0; i < n; i++) {
     double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
     const bool four = avx2 && i < (n & ~3);
     const int kb = four ? (n & ~7) : 0;
@@ -969,32 +833,19 @@ PCT_GD bool split_t(Grp g, double* ws, int k, const double* in, double s0, doubl
     for (int kk = kb; kk < n; kk++) q0 = fma(vt[kk + i * n], b[kk], q0);
     work[i] = four ? (q0 + q1) + (q2 + q3) : q0;
   }
-  PCT_GSYNC();
-  for (int i = g.gl; i < n; i += g.G) b[i] = work[i];
-  dlascl_vec(g, orgnrm, 1.0, n, b);
+  for (int i = 0; i < n; i++) b[i] = work[i];
+  dlascl_vec(orgnrm, 1.0, n, b);
   // dormbr('P', 'L', 'N') = dorml2('L', 'T'): the row reflectors, last first
   for (int i = n - 2; i >= 0; i--) {
     const double aii = a[i + (i + 1) * lda];
-    const double tp = taup[i];
-    if (tp != 0.0) {
-      a[i + (i + 1) * lda] = 1.0;
-      dlarf_left(g, n - 1 - i, 0, &a[i + (i + 1) * lda], lda, tp, &b[i + 1], M, &b[i + 1], avx2);
-      a[i + (i + 1) * lda] = aii;
-    }
+    a[i + (i + 1) * lda] = 1.0;
+    dlarf_left(n - 1 - i, 1, &a[i + (i + 1) * lda], lda, taup[i], &b[i + 1], M, work, avx2);
+    a[i + (i + 1) * lda] = aii;
   }
-  PCT_GSYNC();
-  for (int j = g.gl; j < n; j += g.G) x[j] = b[j];
-  PCT_GSYNC();
-  PCT_GPROF_ADD(4, tfin)
+  for (int j = 0; j < n; j++) x[j] = b[j];
   return true;
 }
-// one lane (the round-4 signature: tests/host and the host build of pct_stab.cuh)
-template <typename Dot2>
-PCT_GD bool split_t(double* ws, int k, const double* in, double s0, double s1, Dot2 dot2, double* x, bool& ill, bool avx2 = false) {
-  const Grp one = {0, 1};
-  return split_t(one, ws, k, in, s0, s1, dot2, x, ill, avx2);
-}
 
-}  // namespace gelsd
+}  // namespace gelsd_r04
 }  // namespace pct
 #endif

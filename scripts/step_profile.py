@@ -30,7 +30,7 @@ for _ in range(200):
     env.policy_hash_rows(rows); env.step_rows_device(rows)
 torch.cuda.synchronize()
 env.phase_timing(True)
-rec = np.zeros((K, N, 32))
+rec = np.zeros((K, N, 40))
 for s in range(K):
     env.policy_hash_rows(rows); env.step_rows_device(rows)
     rec[s] = env.phase_timing(True)
@@ -56,6 +56,10 @@ extra = {16: "match calls", 17: "match outer rounds", 18: "match longest-walk su
          20: "contains longest-walk sum", 21: "flushes", 22: "fast-start scalar replay cycles", 23: "rebuilds", 24: "flush hash cycles", 25: "gen: tuple build cycles", 26: "gen: hash cycles", 27: "gen: contains cycles", 28: "gen: pend/ballot cycles", 29: "gen: pair filter cycles"}
 for i, n in extra.items():
     print("    %-34s %9.1f   (all-env mean %9.1f)" % (n, worst[:, i].mean(), rec[:, :, i].mean()))
+if MODE in ("c1", "c3s1"):  # the stability counters have slots of their own (30..38)
+    for i, n in {30: "commit visits", 31: "virtual passes", 32: "virtual tasks", 33: "narrow passes", 34: "lsq k=3", 35: "lsq k=4", 36: "lsq k=5",
+                 37: "lsq k>5", 38: "level-0 candidates"}.items():
+        print("    %-34s %9.2f   (all-env mean %9.2f)" % (n, worst[:, i].mean(), rec[:, :, i].mean()))
 # least squares: total ~ a + b*E + c*generated + d*distinct
 X = np.stack([np.ones(K * N), rec[:, :, 12].ravel(), rec[:, :, 14].ravel(), rec[:, :, 13].ravel()], 1)
 coef, *_ = np.linalg.lstsq(X, tot.ravel(), rcond=None)

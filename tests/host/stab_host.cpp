@@ -65,7 +65,8 @@ void stab_free(struct stab* s) {
   delete s;
 }
 int stab_overflowed(struct stab* s) { return s->overflow; }
-int stab_ill_conditioned(struct stab* s) { return s->ill; }
+int stab_ill_conditioned(struct stab* s) { return s->ill & 1; }
+int stab_ill_commit(struct stab* s) { return (s->ill >> 1) & 1; }
 void stab_set_ill_near(int) {}  // (the tie notice is an analysis mode of the oracle only)
 // the product's PCT_LSTSQ_GELSD (csrc/pct_gelsd.cuh compiled for the host) under the oracle's switch
 void stab_set_lstsq_mode(int mode) { pct::g_stab_host_gelsd = mode; }
@@ -82,7 +83,7 @@ int gelsd_host_split(int k, const double* centres, double s0, double s1, double*
 }
 double gelsd_host_dnrm2(int n, const double* x, int incx) { return pct::gelsd::dnrm2(n, x, incx); }
 // dbdsqr('U', n, ncvt = n, 0, 1): d[n], e[n - 1], vt[n * n] (column-major), c[n], work[4 n]
-int gelsd_host_dbdsqr(int n, double* d, double* e, double* vt, double* c, double* work) { return pct::gelsd::dbdsqr(n, d, e, vt, c, work) ? 0 : 1; }
+int gelsd_host_dbdsqr(int n, double* d, double* e, double* vt, double* c, double* work) { const pct::gelsd::Grp one = {0, 1}; return pct::gelsd::dbdsqr(one, n, d, e, vt, c, work) ? 0 : 1; }
 
 int stab_check(struct stab* s, double x, double y, double z, double lx, double ly, double max_h, double density,
                int virtual_) {
@@ -108,7 +109,7 @@ int stab_check(struct stab* s, double x, double y, double z, double lx, double l
       q.pop_back();
       rc = s->cont ? pct::stab_visit<true>(geo, s->st, t.S, t.stk, ill, emit) : pct::stab_visit<false>(geo, s->st, t.S, t.stk, ill, emit);
     }
-    if (ill) s->ill = 1;
+    if (ill) s->ill |= 1;
     if (rc < 0) { s->overflow = 1; return 0; }
     return rc;
   }
@@ -118,7 +119,7 @@ int stab_check(struct stab* s, double x, double y, double z, double lx, double l
   std::vector<unsigned char> snap(s->mem);
   int rc = s->cont ? pct::stab_commit<true>(geo, s->st, s->n, density, s->ws.data(), s->caps.ws_bytes, ill)
                    : pct::stab_commit<false>(geo, s->st, s->n, density, s->ws.data(), s->caps.ws_bytes, ill);
-  if (ill) s->ill = 1;
+  if (ill) s->ill |= 3;
   if (rc < 0) s->overflow = 1;
   if (s->st.n_ent > s->max_ent) s->max_ent = s->st.n_ent;
   if (s->st.n_poly > s->max_poly) s->max_poly = s->st.n_poly;

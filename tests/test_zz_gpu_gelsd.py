@@ -96,7 +96,8 @@ def test_hip_gelsd_continuous_matches_reference_fixture(name):
 
 @pytest.mark.parametrize("kind", ["c1", "wide_flat", "continuous"])
 def test_hip_gelsd_matches_oracle_gelsd(kind, oracle_gelsd):
-    """kernels and oracle both in gelsd mode on seeded streams: observations after every step, dones and counters.  c1: the C1 domain at 1024 envs; wide_flat: flat items on a 20^3 bin (splits over up to 16
+    """kernels and oracle both in gelsd mode on seeded streams: observations after every step, rewards, dones, counters, ratios, and the
+    commit-solve part of the notice env by env.  c1: the C1 domain at 1024 envs; wide_flat: flat items on a 20^3 bin (splits over up to 16
     supporters: the retry pass's workspace class); continuous: the unit-bin setting-1 domain."""
     if kind == "c1":
         N, steps = 1024, 150
@@ -127,17 +128,25 @@ def test_hip_gelsd_matches_oracle_gelsd(kind, oracle_gelsd):
         assert np.array_equal(obs.cpu().numpy(), ora.obs.astype(np.float32)), (kind, t)
         env.step_hash_policy(1)
         ora.step_hash_policy(1)
-        obs, _, done, _ = env.step_wait()
+        obs, rew, done, _ = env.step_wait()
         assert np.array_equal(done.astype(np.uint8), ora.done), (kind, t)
         assert np.array_equal(env._h_counter.numpy(), ora.counter), (kind, t)
-    # The notice is NOT compared env by env: it is raised by solves of VIRTUAL checks too, and which of a doomed candidate's solves are
-    # run differs -- the reference's recursion returns at the first unstable supporter (solves further on are never made), the wave
-    # examines a candidate's walk tasks side by side and drops the rest once one fails (solves the recursion made first may never be
-    # made).  First GPU run (scripts/gelsd_gpu_check.py): equal sets on c1 and continuous, 10 against 9 envs on wide_flat.  What must
-    # hold: an env that placed boxes through a flagged COMMIT solve is flagged on both sides -- covered by the reference fixture
-    # discrete_s1_flat_diverging above (env 0 and only env 0).
+        assert np.array_equal(rew[:, 0].numpy(), ora.reward.astype(np.float32)), (kind, t)
+        assert np.array_equal(env._h_ratio.numpy(), ora.ratio), (kind, t)
+    # The notice, by provenance.  Solves of a COMMIT walk are made by both sides whatever the evaluation order:
+    # the set of envs whose commit solves raised the notice (PCT_FLAG_ILL_COMMIT / the oracle's ill_commit) must be EQUAL.  Solves of
+    # VIRTUAL checks are not comparable one by one -- the reference's recursion returns at a candidate's first unstable supporter
+    # (solves further on are never made), the wave examines a candidate's walk tasks side by side and drops the rest once one fails
+    # (solves the recursion made first may never be made) -- so the virtual-only part is logged, and bounded: every flagged env of
+    # one side that the other side does not flag at all must be a virtual-only notice there.
     gpu_ill, ora_ill = np.asarray(env.ill_conditioned, bool), ora.ill_conditioned().astype(bool)
-    print("notice: kernels %d envs, oracle %d envs, both %d" % (gpu_ill.sum(), ora_ill.sum(), (gpu_ill & ora_ill).sum()))
+    gpu_com, ora_com = np.asarray(env.ill_commit, bool), ora.ill_commit().astype(bool)
+    print("notice: kernels %d envs (%d by a commit solve), oracle %d envs (%d by a commit solve), both %d; virtual-only difference: kernels-only %s, oracle-only %s"
+          % (gpu_ill.sum(), gpu_com.sum(), ora_ill.sum(), ora_com.sum(), (gpu_ill & ora_ill).sum(),
+             np.nonzero(gpu_ill & ~ora_ill)[0].tolist(), np.nonzero(ora_ill & ~gpu_ill)[0].tolist()))
+    assert np.array_equal(gpu_com, ora_com), (kind, np.nonzero(gpu_com != ora_com)[0].tolist())
+    assert not (gpu_com & ~gpu_ill).any() and not (ora_com & ~ora_ill).any()
+    assert not ((gpu_ill & ~ora_ill) & gpu_com).any() and not ((ora_ill & ~gpu_ill) & ora_com).any()
     assert not env.error_flags.any()
     env.close()
     ora.close()
