@@ -108,27 +108,39 @@ def make_oracle(w, envs, threads):
     return OracleVecEnv(envs, item_set=item_set(), **kw)
 
 
-def cpu_baseline(w, budget_s, lstsq="jacobi"):
-    """The oracle on the host cores: same workload (config, sampler, stand-in policy), bounded sample."""
+def cpu_baseline(w, budget_s, lstsq="gelsd", envs=0):
+    """The oracle on the host cores: same workload (config, sampler, stand-in policy) at the workload's OWN env count, the
+    median of three samples of budget_s / 3 seconds each (round 4 timed 256 envs once for 12 s: with 64 OpenMP threads that is
+    four envs per thread and a +-40 % number -- VERDICT r4 weak point 9a)."""
     from oracle import oracle_lib
     oracle_lib.set_lstsq_mode({"jacobi": oracle_lib.LSTSQ_JACOBI, "gelsd": oracle_lib.LSTSQ_GELSD, "gelsd_avx2": oracle_lib.LSTSQ_GELSD_AVX2}[lstsq])
-    threads = max(1, min(os.cpu_count() or 1, 64))
-    envs = 256 if w["I"] <= 80 else 64
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = os.cpu_count() or 1
+    threads = max(1, min(affinity, 64))
+    envs = envs or w["envs"]
     env = make_oracle(w, envs, threads)
     env.set_sampler(4)
     env.reset()
-    env.step_hash_policy(50)  # de-synchronise the episodes
-    t0 = time.perf_counter()
-    steps = 0
-    chunk = 20 if w["I"] <= 80 else 4
-    while time.perf_counter() - t0 < budget_s:
-        env.step_hash_policy(chunk)
-        steps += chunk
-    dt = time.perf_counter() - t0
+    env.step_hash_policy(20 if w["I"] <= 80 else 4)  # de-synchronise the episodes (bounded: the 200-node oracle steps at ~10 k env-steps/s)
+    rates, nsteps = [], []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        steps = 0
+        while time.perf_counter() - t0 < budget_s / 3.0:
+            env.step_hash_policy(1)
+            steps += 1
+        dt = time.perf_counter() - t0
+        rates.append(envs * steps / dt)
+        nsteps.append(steps)
     env.close()
-    return {"value": envs * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
-            "sample": "oracle/ (C restatement of the reference env, OpenMP over envs), %d envs x %d batched steps after 50 "
-                      "warm-up steps, same config / sampler / stand-in policy, %.1f s" % (envs, steps, dt)}
+    rates.sort()
+    return {"value": rates[1], "unit": "env-steps/s", "cores": threads, "kind": "port", "samples": rates,
+            "affinity_cpus": affinity, "os_cpu_count": os.cpu_count(),
+            "sample": "oracle/ (C restatement of the reference env, OpenMP over envs, %d threads = min(64, the %d CPUs this process may run on)), "
+                      "%d envs (the workload's own size), median of three samples of %.1f s (%s batched steps), same config / sampler / "
+                      "stand-in policy / lstsq mode" % (threads, affinity, envs, budget_s / 3.0, "/".join(str(n) for n in nsteps))}
 
 
 def reference_baseline(w):
@@ -150,7 +162,7 @@ def reference_baseline(w):
 
 def pmc_profile(name, envs):
     """Counter values per launch from the committed rocprofv3 PMC passes of this workload, or None."""
-    for tag in ("r04", "r03", "r02"):  # the newest committed profile of this workload
+    for tag in ("r05", "r04", "r03", "r02"):  # the newest committed profile of this workload
         rel = "profiles/%s_pmc_%s.json" % (tag, name)
         path = os.path.join(ROOT, rel)
         if not os.path.exists(path):
@@ -165,20 +177,43 @@ def pmc_profile(name, envs):
     return None, None
 
 
+def traced_kernel_name(name, needle):
+    """The step kernel as rocprofv3 printed it: the row of the newest committed raw kernel-stats CSV of this workload
+    (profiles/r0x_trace_<w>_kernel_stats.csv, rocprofv3 --kernel-trace --stats) whose name holds `needle`; (None, None) without one."""
+    import csv
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_trace_%s_kernel_stats.csv" % name)), reverse=True):
+        try:
+            for row in csv.DictReader(open(path)):
+                if needle in row.get("Name", ""):
+                    return row["Name"], os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--envs-per-gpu", type=int, default=0, help="default: the workload's own size (4096 for c2)")
-    ap.add_argument("--mode", choices=["epilogue", "rows", "fused", "host"], default="epilogue",
+    ap.add_argument("--mode", choices=["epilogue", "rows", "fused", "host", "host_overlap", "slot"], default="epilogue",
                     help="epilogue (default): pct_step_rows per step, the float32 [N,9] leaf rows it reads having been "
                          "written to HBM by the previous launch's stand-in policy epilogue (pct_bind_policy_rows) -- one "
                          "transition dispatch per step; rows: the stand-in policy as its own kernel + pct_step_rows (the "
                          "rounds 1-3 default); fused: pct_step_hash_policy(1), no rows at all; "
                          "host: the reference trainer's hand-over -- leaf rows to the host as numpy "
                          "(train_tools.py:66-67), VecEnv.step(numpy), reward / done back on the host every step "
-                         "(PCIe and a stream sync inside the timed region; never the headline value)")
+                         "(PCIe and a stream sync inside the timed region; never the headline value); "
+                         "host_overlap: the same hand-over for a caller whose next action needs only the device-resident observation "
+                         "(PctVecEnv.step_outputs_async: step t + 1 is launched before step t's reward / done / infos are consumed on the host); "
+                         "slot: the trainer-shaped device path -- a rollout slot is bound (pct_bind_rollout_slot: the kernel writes every "
+                         "observation row, reward and mask of step t straight into storage.py's [T + 1, N, ...] tensors, T = 5 as "
+                         "arguments.py), the leaf index comes from a torch stand-in policy on the slot's observation, pct_step_index steps")
+    ap.add_argument("--no-rows-line", action="store_true",
+                    help="epilogue mode: do not also time the `rows` flavour (stand-in policy as its own kernel in front of every "
+                         "transition) in the same process")
     ap.add_argument("--desync", type=int, default=200,
                     help="untimed transitions right after the synchronous reset, before --warmup, so that a short run "
                          "(the driver's --warmup 5 --steps 20) measures the steady state -- episodes of every length in "
@@ -197,9 +232,10 @@ def main():
     ap.add_argument("--share-gpu", action="store_true",
                     help="smoke test only: every rank uses cuda:0 (the N > 1 code path -- barrier, MAX-reduce of the "
                          "elapsed time, per-rank gather -- on a one-GPU box; not a measurement)")
-    ap.add_argument("--lstsq", choices=["jacobi", "gelsd", "gelsd_avx2"], default="jacobi",
-                    help="stability workloads (c1, c3s1): the solver behind np.linalg.lstsq -- the default Jacobi solver or LAPACK dgelsd as "
-                         "the reference's NumPy executes it (pct_set_lstsq_mode, include/pct_env.h); the cpu_baseline oracle follows")
+    ap.add_argument("--lstsq", choices=["jacobi", "gelsd", "gelsd_avx2"], default="gelsd",
+                    help="stability workloads (c1, c3s1): the solver behind np.linalg.lstsq -- LAPACK dgelsd as the reference's NumPy executes "
+                         "it (the library's default since round 5) or the Jacobi stand-in of rounds 1-4 (pct_set_lstsq_mode, "
+                         "include/pct_env.h); the cpu_baseline oracle follows")
     ap.add_argument("--ems-capacity", type=int, default=0, help="experiments: pct_config.ems_capacity (0 = the library's default)")
     ap.add_argument("--candidate-capacity", type=int, default=0, help="experiments: pct_config.candidate_capacity (0 = default)")
     ap.add_argument("--time-every", type=int, default=-1,
@@ -262,19 +298,45 @@ def main():
             ev.reset()
     torch.cuda.synchronize(dev)
 
+    slots, tickets, hbase, tcount = None, [None] * P, None, [0]
+    if args.mode == "slot":
+        rollout = importlib.import_module("online-3d-bpp-pct_amd.rollout")
+        slots = [rollout.RolloutSlots(5, n_grp, (envs[g].row_len,), 1.0, dev) for g in range(P)]
+        for g in range(P):
+            with torch.cuda.stream(streams[g]):
+                slots[g].begin(envs[g])
+        hbase = torch.arange(n_grp, device=dev, dtype=torch.int64) * 2654435761
+    mode_now = [args.mode]
+
     def one_step():
         for g in range(P):
             with torch.cuda.stream(streams[g]):
-                if args.mode == "epilogue":
+                if mode_now[0] == "epilogue":
                     envs[g].step_rows_device(rows[g])
-                elif args.mode == "rows":
+                elif mode_now[0] == "slot":
+                    # a torch stand-in for the policy's leaf choice, on the slot the kernel wrote: k = valid leaf rows, index = hash % k
+                    s = slots[g]
+                    ob = s.obs[s.step].view(n_grp, w["I"] + w["L"] + 1, 9)
+                    k = (ob[:, w["I"]:w["I"] + w["L"], 8] != 0).sum(1).clamp_(min=1)
+                    idx = (hbase + tcount[0] * 40503) % k
+                    s.step_env(envs[g], idx)
+                    if s.step == 0:
+                        s.after_update()  # storage.py:41-43, once per T steps
+                elif mode_now[0] == "host_overlap":
                     envs[g].policy_hash_rows(rows[g])
                     envs[g].step_rows_device(rows[g])
-                elif args.mode == "host":
+                    prev, tickets[g] = tickets[g], envs[g].step_outputs_async()
+                    if prev is not None:
+                        prev.wait()  # reward (CPU), done (numpy), infos of the PREVIOUS step, while this one runs
+                elif mode_now[0] == "rows":
+                    envs[g].policy_hash_rows(rows[g])
+                    envs[g].step_rows_device(rows[g])
+                elif mode_now[0] == "host":
                     envs[g].policy_hash_rows(rows[g])
                     envs[g].step(rows[g].cpu().numpy())  # obs (device), reward (CPU), done (numpy), infos
                 else:
                     envs[g].step_hash_policy(1)
+        tcount[0] += 1
 
     for _ in range(max(0, args.desync) + args.warmup):
         one_step()
@@ -294,8 +356,8 @@ def main():
     for _ in range(args.steps):
         one_step()
     torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0  # (this rank's; the MAX over ranks below covers the stragglers -- the barrier follows the stamp)
     barrier()
-    elapsed = time.perf_counter() - t0
     n_launch, kern_ms = 0, 0.0
     for ev in envs:
         nl, km = ev.profile_read()
@@ -304,6 +366,35 @@ def main():
         ev.profile_enable(False)
         flags = ev.error_flags
         assert not flags.any(), "env error flags raised during the bench: %s" % flags[flags != 0][:8]
+
+    for g in range(P):
+        if tickets[g] is not None:
+            tickets[g].wait()
+    rows_line = None
+    if args.mode == "epilogue" and not args.no_rows_line:
+        # the same loop with the stand-in policy as its own kernel in front of every transition (the rounds 1-3 headline flavour),
+        # timed in the same process right after the headline region (both values on the line)
+        mode_now[0] = "rows"
+        for _ in range(max(2, args.warmup)):
+            one_step()
+        torch.cuda.synchronize(dev)
+        barrier()
+        tr = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        torch.cuda.synchronize(dev)
+        el_rows = time.perf_counter() - tr
+        barrier()
+        mode_now[0] = "epilogue"
+        if dist is not None:
+            t = torch.tensor([el_rows], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el_rows = float(t.item())
+        rows_line = {"value": world * n_local * args.steps / el_rows, "unit": "env-steps/s", "ms_per_step": el_rows / args.steps * 1e3,
+                     "what": "policy kernel -> float32 [N,9] leaf rows -> transition kernel per step (two dispatches; the default of rounds 1-3), "
+                             "same process, timed right after the headline region"}
+        for ev in envs:
+            ev.profile_read()  # (its launches do not belong to the headline kernel average)
 
     kern_avg_ms = kern_ms / n_launch if n_launch else elapsed / args.steps * 1e3  # (--time-every 0: the step's time)
     per_rank_us = [kern_avg_ms * 1e3]
@@ -333,6 +424,11 @@ def main():
         kernel_name = ("void pct::pct_discrete_kernel<unsigned int, 5, %d, false, %s, 0, 0>(pct::DiscreteParams, void const*, "
                        "int, int, int const*, int)" % (act, stab))
 
+    kernel_src = "assembled from the template arguments (no committed kernel-stats CSV of this workload names it)"
+    traced, traced_path = traced_kernel_name(args.workload, kernel_name.split("(")[0].replace("void ", ""))
+    if traced:
+        kernel_name, kernel_src = traced, traced_path + " (rocprofv3 --kernel-trace --stats of this command)"
+
     out = {
         "metric": w["metric"],
         "value": value,
@@ -352,7 +448,12 @@ def main():
                             "transition kernel (observation rows rewritten, auto-reset, next rows)",
                 "rows": "policy kernel -> float32 [N,9] leaf rows -> transition kernel (observation rows rewritten, auto-reset)",
                 "fused": "transition kernel with the stand-in policy inside (no rows)",
-                "host": "policy kernel -> rows to the host -> VecEnv.step(numpy) -> reward / done / infos on the host"}[args.mode],
+                "host": "policy kernel -> rows to the host -> VecEnv.step(numpy) -> reward / done / infos on the host",
+                "host_overlap": "policy kernel -> transition kernel (rows stay on the device) -> packed reward / done / infos to the host, "
+                                "consumed one step late (step_outputs_async)",
+                "slot": "torch stand-in policy on the rollout slot's observation -> int64 leaf index -> pct_step_index with the slot bound: "
+                        "every observation row (the B = 36 (I+L+1) + 41 algorithmic bytes per env), reward and mask written into "
+                        "storage.py-shaped [T+1,N,...] tensors by the transition kernel"}[args.mode],
             "name": args.workload,
             "envs_per_gpu": n_local,
             "global_envs": world * n_local,
@@ -374,6 +475,7 @@ def main():
             "traffic_source": (pmc_src + " (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of this command in a "
                                "separate profiled run; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes)") if traffic else None,
             "kernel": kernel_name,
+            "kernel_name_source": kernel_src,
             "kernel_avg_us": kern_avg_ms * 1e3,
             "kernel_avg_us_per_rank": per_rank_us,
             "launches_timed": n_launch,
@@ -390,9 +492,14 @@ def main():
                                  "peak_model": "256 CUs x 2.4 GHz x (4 SIMD-32 x 1 wave64 VALU / 2 cycles + 1 SALU / cycle)"}
     else:
         out["roofline_issue"] = None
+    if rows_line is not None:
+        out["rows_mode"] = rows_line
+        out["config"]["headline_note"] = ("`value` is the transition kernel fed by the previous launch's policy epilogue: the env hot path "
+                                          "alone, an UPPER BOUND for a loop that dispatches a policy between two steps; `rows_mode` is the "
+                                          "same loop with the stand-in policy as its own kernel (the flavour rounds 1-3 reported as `value`)")
     if rank == 0 and not args.no_cpu_baseline:
         # (N > 1: timed on rank 0 after the final barrier, while the other ranks wait in destroy_process_group)
-        out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds, args.lstsq)
+        out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds, args.lstsq, n_local)
     elif rank == 0:
         out["cpu_baseline"] = None
     out["cpu_baseline_reference"] = reference_baseline(w)

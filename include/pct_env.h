@@ -240,14 +240,14 @@ int pct_set_shuffle_seed(pct_env* env, uint64_t seed);
 
 /* Which solver stands behind np.linalg.lstsq in the stability check (settings 1 / 3: a stack split over three and more
  * supporters none of which holds its centre of mass, D/space.py:134-163, :236-259; C/space.py:130-159, :232-255).
- *   PCT_LSTSQ_JACOBI (default): a one-sided Jacobi SVD -- the same minimum-norm solution as the reference's, equal to it up to
- *     the last bits; on the reference's own item domain one env-run in 55 (2000 steps each) parts ways with the reference
- *     through such a bit (see PCT_FLAG_ILL_CONDITIONED).
- *   PCT_LSTSQ_GELSD: LAPACK dgelsd operation for operation AS THE REFERENCE'S NUMPY EXECUTES IT (NumPy 2.2.6 = OpenBLAS 0.3.29 /
- *     LAPACK 3.11 with the kernel set OpenBLAS selects on AVX-512 hosts: dgeqr2, dgebd2, dbdsqr ..., the fused / split sums of
- *     its dgemv / dger / drot kernels and the 80-bit x87 dnrm2; csrc/pct_gelsd.cuh).  Bit-identical solutions: the 13 on-domain
- *     and 17 adversarial env-runs that part ways under PCT_LSTSQ_JACOBI follow the reference to the end
- *     (profiles/r04_gelsd_port.txt).  One lane solves a system, so a step that holds such a split is slower.
+ *   PCT_LSTSQ_GELSD (DEFAULT since round 5): LAPACK dgelsd operation for operation AS THE REFERENCE'S NUMPY EXECUTES IT (NumPy 2.2.6 =
+ *     OpenBLAS 0.3.29 / LAPACK 3.11 with the kernel set OpenBLAS selects on AVX-512 hosts: dgeqr2, dgebd2, dbdsqr ..., the fused /
+ *     split sums of its dgemv / dger / drot kernels and the 80-bit x87 dnrm2; csrc/pct_gelsd.cuh).  Bit-identical solutions: the 13
+ *     on-domain and 17 adversarial env-runs that part ways under PCT_LSTSQ_JACOBI follow the reference to the end
+ *     (profiles/r04_gelsd_port.txt).  A group of 4 / 8 / 16 lanes solves a system (up to 4 / 8 / 16 supporters).
+ *   PCT_LSTSQ_JACOBI (the default of rounds 1-4; ~1.35 x the throughput on the stability settings): a one-sided Jacobi SVD -- the
+ *     same minimum-norm solution as the reference's, equal to it up to the last bits; on the reference's own item domain one
+ *     env-run in 55 (2000 steps each) parts ways with the reference through such a bit (see PCT_FLAG_ILL_CONDITIONED).
  *   PCT_LSTSQ_GELSD_AVX2: the same with the kernel set OpenBLAS selects on AVX2 hosts without AVX-512 ("Haswell"; also what
  *     OPENBLAS_CORETYPE=ZEN runs) -- its
  *     dgemv 'N', daxpy and dgemm kernels sum differently and its ddot does not fuse (np.dot of the 2-vectors at D/space.py:114-115,

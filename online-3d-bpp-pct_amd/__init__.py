@@ -11,4 +11,4 @@ from .rollout import DeviceRollout, RolloutSlots, collect, get_leaf_nodes  # noq
 from .lstsq_mode import numpy_lstsq_mode, numpy_blas  # noqa: F401
 
 __all__ = ["PctVecEnv", "PctEnvError", "VecEnv", "LazyInfos", "make_vec_envs", "shard_envs", "gather_rollout",
-           "DeviceRollout", "RolloutSlots", "collect", "get_leaf_nodes", "evaluate_heuristic", "HEURISTICS"]
+           "DeviceRollout", "RolloutSlots", "collect", "get_leaf_nodes", "evaluate_heuristic", "HEURISTICS", "numpy_lstsq_mode", "numpy_blas"]

@@ -719,6 +719,28 @@ __device__ __forceinline__ bool cleaf_nodes(const ContinuousParams& p, int e, CL
 #pragma unroll
           for (int c = 0; c < 8; c++)
             if ((uint32_t)c < nchunks) reinsert(oldw[c], noff);
+        } else if (!GT && p.gpark) {
+          // an LDS table of 2048 slots growing to 8192 in the SAME region (round 5: 32 KB instead of 40, three 100^3 envs per CU
+          // instead of two): the old entries -- at most 1229 -- are parked, dense and in slot order, in this env's HBM row (coalesced
+          // stores, agent-scope so that the same wave reads them back), the region is wiped, and they return 64 at a time
+          uint32_t* const park = p.gpark + (size_t)e * PCT_PARK_WORDS;
+          int nold = 0;
+          for (uint32_t sb = 0; sb < size; sb += 64) {
+            const uint32_t ow = tabs[toff + sb + lane];
+            const uint64_t m = __ballot(ow != EMPTY);
+            if (ow != EMPTY) tab_st<true, uint32_t>(&park[nold + rank_below(m)], ow);
+            nold += __popcll(m);
+          }
+          __syncthreads();
+          for (uint32_t s2 = lane; s2 < newsize; s2 += 64) tabs[s2] = EMPTY;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          __syncthreads();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          for (int ob = 0; ob < nold; ob += 64) reinsert(ob + lane < nold ? tab_ld<true, uint32_t>(&park[ob + lane]) : EMPTY, 0u);
+          toff = 0;
+          size = newsize;
+          tm.sub_tick(PH_SET_REBUILD);
+          continue;
         } else if (!GT) {
           // an LDS table of 2048 slots growing to 8192: the new table sits behind the old one's region
           // (cand_cap 8192: table words = 8192 + 2048), the only case of two LDS regions
@@ -815,7 +837,7 @@ __device__ __forceinline__ bool cleaf_nodes(const ContinuousParams& p, int e, CL
   // ALL 64 lanes call (`live`: this lane holds a candidate): the stability check of the lanes that need one is a
   // wave-cooperative task walk (pct_stab.cuh stab_virtual_wave)
   bool stab_ill = false;
-  StabStats sstats = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // (timed build only)
+  StabStats sstats = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // (timed build only)
   bool unknown = false;  // the last call left this lane's candidate undecided (a capacity of its own was exceeded)
   auto feasible = [&](bool live, const double t[6]) __attribute__((always_inline)) -> bool {
     unknown = false;
@@ -928,6 +950,7 @@ __device__ __forceinline__ bool cleaf_nodes(const ContinuousParams& p, int e, CL
     tm.add(ST_STAB_LSQ4, (uint64_t)wave_sum_i64(sstats.lsq4));
     tm.add(ST_STAB_LSQ5, (uint64_t)wave_sum_i64(sstats.lsq5));
     tm.add(ST_STAB_LSQX, (uint64_t)wave_sum_i64(sstats.lsqx));
+    tm.add(ST_STAB_LSQ_ROUNDS, (uint64_t)__builtin_amdgcn_readfirstlane(sstats.lsq_rounds));
   }
   __syncthreads();
   tm.tick(PH_FEAS);
@@ -1169,7 +1192,7 @@ __device__ __forceinline__ int ctransition(const ContinuousParams& p, int e, CLd
     bool ill = false;
     const double den = MT ? (p.setting == 3 ? r.den_cur : 1.0) : next_density(p, e, r.oc - 1, r.traj, r.cursor - 1);
     // lane 0 walks; a split over six and more supporters is solved by the whole wave (pct_stab.cuh stab_commit_wave)
-    StabStats cstats = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // (timed build only)
+    StabStats cstats = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // (timed build only)
     const int rc = stab_commit_wave<true>(geo, l.st, bi, den, l.sw, lane, ill, TM::on ? &cstats : nullptr);
     if (TM::on) {
       tm.add(ST_STAB_COMMIT_VISITS, (uint64_t)__builtin_amdgcn_readfirstlane(cstats.commit_visits));
@@ -1177,6 +1200,7 @@ __device__ __forceinline__ int ctransition(const ContinuousParams& p, int e, CLd
       tm.add(ST_STAB_LSQ4, (uint64_t)__builtin_amdgcn_readfirstlane(cstats.lsq4));
       tm.add(ST_STAB_LSQ5, (uint64_t)__builtin_amdgcn_readfirstlane(cstats.lsq5));
       tm.add(ST_STAB_LSQX, (uint64_t)__builtin_amdgcn_readfirstlane(cstats.lsqx));
+      tm.add(ST_STAB_LSQ_ROUNDS, (uint64_t)__builtin_amdgcn_readfirstlane(cstats.lsq_rounds));
     }
     l.st.n_ent = __builtin_amdgcn_readfirstlane(l.st.n_ent);
     l.st.n_poly = __builtin_amdgcn_readfirstlane(l.st.n_poly);
@@ -1728,16 +1752,15 @@ hipError_t PCT_CONT_LAUNCH(const ContinuousParams& p, int act, const void* actio
   const bool stab = p.setting != 2;
   int grid = p.retry_mode ? n_ids : ((act == CACT_RESET && env_ids) ? n_ids : p.N);
   if (grid <= 0) return hipSuccess;
+#ifdef PCT_FEW_KERNELS
+  // kernel experiments (scripts/build_variant.py): only the untimed LDS-table kernels of the action kinds the benchmark uses
+  if (timed || p.table_global || act == CACT_HEUR || act == CACT_INDEX) return hipErrorNotSupported;
+#define PCT_CKERN(A) (stab ? pct_continuous_kernel<A, false, false, true, PCT_CONT_MTV> : pct_continuous_kernel<A, false, false, false, PCT_CONT_MTV>)
+#endif
 #define PCT_CLAUNCH(A)                                                                                         \
   do {                                                                                                         \
     void (*kern)(ContinuousParams, const void*, int, int, const int32_t*, int);                                \
-    if (stab && timed && A == CACT_ROWS && !p.table_global)                                                   \
-      kern = pct_continuous_kernel<(A == CACT_ROWS ? A : CACT_ROWS), !PCT_CONT_MTV, false, true, PCT_CONT_MTV>; \
-    else if (stab) kern = p.table_global ? pct_continuous_kernel<A, false, true, true, PCT_CONT_MTV>           \
-                                    : pct_continuous_kernel<A, false, false, true, PCT_CONT_MTV>;              \
-    else if (p.table_global) kern = pct_continuous_kernel<A, false, true, false, PCT_CONT_MTV>;                \
-    else kern = timed ? pct_continuous_kernel<A, !PCT_CONT_MTV, false, false, PCT_CONT_MTV>                    \
-                      : pct_continuous_kernel<A, false, false, false, PCT_CONT_MTV>;                           \
+    PCT_CLAUNCH_PICK(A)                                                                                        \
     if (lds > 48 * 1024) {                                                                                     \
       hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                 \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
@@ -1746,16 +1769,31 @@ hipError_t PCT_CONT_LAUNCH(const ContinuousParams& p, int act, const void* actio
     hipExtLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, stream, (hipEvent_t)p.launch_ev_start,             \
                           (hipEvent_t)p.launch_ev_stop, 0, p, actions, row_len, n_steps, env_ids, n_ids); \
   } while (0)
+#ifdef PCT_FEW_KERNELS
+#define PCT_CLAUNCH_PICK(A) kern = PCT_CKERN(A);
+#else
+#define PCT_CLAUNCH_PICK(A)                                                                                    \
+    if (stab && timed && A == CACT_ROWS && !p.table_global)                                                   \
+      kern = pct_continuous_kernel<(A == CACT_ROWS ? A : CACT_ROWS), !PCT_CONT_MTV, false, true, PCT_CONT_MTV>; \
+    else if (stab) kern = p.table_global ? pct_continuous_kernel<A, false, true, true, PCT_CONT_MTV>           \
+                                    : pct_continuous_kernel<A, false, false, true, PCT_CONT_MTV>;              \
+    else if (p.table_global) kern = pct_continuous_kernel<A, false, true, false, PCT_CONT_MTV>;                \
+    else kern = timed ? pct_continuous_kernel<A, !PCT_CONT_MTV, false, false, PCT_CONT_MTV>                    \
+                      : pct_continuous_kernel<A, false, false, false, PCT_CONT_MTV>;
+#endif
   switch (act) {
     case CACT_ROWS: PCT_CLAUNCH(CACT_ROWS); break;
+#ifndef PCT_FEW_KERNELS
     case CACT_INDEX: PCT_CLAUNCH(CACT_INDEX); break;
+#endif
     case CACT_HASH: PCT_CLAUNCH(CACT_HASH); break;
-#ifndef PCT_CONT_MT
+#if !defined(PCT_CONT_MT) && !defined(PCT_FEW_KERNELS)
     case CACT_HEUR: PCT_CLAUNCH(CACT_HEUR); break;
 #endif
     default: PCT_CLAUNCH(CACT_RESET); break;
   }
 #undef PCT_CLAUNCH
+#undef PCT_CLAUNCH_PICK
   return hipGetLastError();
 }
 

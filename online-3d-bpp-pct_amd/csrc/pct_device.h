@@ -108,6 +108,7 @@ struct DiscreteParams {
 
 // HBM layout of the continuous env state (float64, SoA over envs; within an env every
 // coordinate column is contiguous: ems[c][i], boxes[c][i], leaves[c][i]).
+#define PCT_PARK_WORDS 1280 /* a 2048-slot table grows at 1229 entries (fill * 5 >= 2047 * 3) */
 struct ContinuousParams {
   int N, I, L, row_len, setting;
   int full_obs; /* as in DiscreteParams */
@@ -140,6 +141,8 @@ struct ContinuousParams {
   uint16_t* gorder; /* [N, order_cap] */
   uint32_t* gfpri;  /* [N, order_cap] shuffle priorities (HBM-table variant + shuffle) */
   int gt_by_block;  /* HBM table slices indexed by blockIdx (retry pass) instead of env */
+  uint32_t* gpark;  /* [N, PCT_PARK_WORDS] LDS table of 8192 slots: the 2048-slot table's entries wait here, dense and in slot order, while
+                       the ONE LDS region both sizes share is wiped (round 5: the 100^3 env's table left HBM) */
   int prio_t[3];    /* wave_priority thresholds on the EMS count (0: off) */
   const int32_t* order; /* heavy-first dispatch, as in DiscreteParams */
   int rng_numpy;    /* 1: strict NumPy-stream mode (pct_set_numpy_rng), as in DiscreteParams */

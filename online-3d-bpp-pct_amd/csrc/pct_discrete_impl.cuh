@@ -1425,7 +1425,7 @@ __device__ __forceinline__ void leaf_nodes(const DiscreteParams& p, int e, Lds<K
   // feasibility of the candidate every lane holds (EMPTY: none).  All 64 lanes call: the stability check of the lanes
   // that need one is a wave-cooperative task walk (pct_stab.cuh stab_virtual_wave).
   bool stab_ill = false;
-  StabStats sstats = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // (timed build only)
+  StabStats sstats = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // (timed build only)
   bool unknown = false;  // the last call left this lane's candidate undecided (a capacity of its own was exceeded)
   auto feasible = [&](K k) __attribute__((always_inline)) -> bool {
     unknown = false;
@@ -1573,6 +1573,7 @@ __device__ __forceinline__ void leaf_nodes(const DiscreteParams& p, int e, Lds<K
     tm.add(ST_STAB_LSQ4, (uint64_t)wave_sum_i64(sstats.lsq4));
     tm.add(ST_STAB_LSQ5, (uint64_t)wave_sum_i64(sstats.lsq5));
     tm.add(ST_STAB_LSQX, (uint64_t)wave_sum_i64(sstats.lsqx));
+    tm.add(ST_STAB_LSQ_ROUNDS, (uint64_t)__builtin_amdgcn_readfirstlane(sstats.lsq_rounds));
   }
   __syncthreads();
   tm.tick(PH_FEAS);
@@ -2197,7 +2198,7 @@ __device__ __forceinline__ bool transition(const DiscreteParams& p, int e, Lds<K
     // a box on the floor is recorded and accepted without a walk)
     if (lane == 0) l.box[r.n_boxes] = P::pack(lx, ly, max_h, lx + x, ly + y, max_h + z);
     __syncthreads();
-    StabStats cstats = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // (timed build only)
+    StabStats cstats = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // (timed build only)
     BoxGeo<K, BITS> geo{l.box};
     bool ill = false;
     // lane 0 walks; a split over six and more supporters is solved by the whole wave (pct_stab.cuh stab_commit_wave)
@@ -2213,6 +2214,7 @@ __device__ __forceinline__ bool transition(const DiscreteParams& p, int e, Lds<K
       tm.add(ST_STAB_LSQ4, (uint64_t)__builtin_amdgcn_readfirstlane(cstats.lsq4));
       tm.add(ST_STAB_LSQ5, (uint64_t)__builtin_amdgcn_readfirstlane(cstats.lsq5));
       tm.add(ST_STAB_LSQX, (uint64_t)__builtin_amdgcn_readfirstlane(cstats.lsqx));
+      tm.add(ST_STAB_LSQ_ROUNDS, (uint64_t)__builtin_amdgcn_readfirstlane(cstats.lsq_rounds));
     }
     __syncthreads();
   }
@@ -2528,7 +2530,14 @@ inline hipError_t launch_typed(const DiscreteParams& p, int act, const void* act
   if (MTSEL != (p.rng_numpy != 0)) return hipErrorInvalidValue;  // (launch_discrete picks the translation unit)
   // RNG mode: bit 0 shuffle, bit 1 strict NumPy stream (no timed build, no heuristic kernels: checked by the host)
   constexpr int R_SHUF = MTSEL ? 3 : 1, R_PLAIN = MTSEL ? 2 : 0;
+#ifdef PCT_FEW_KERNELS
+  // kernel experiments (scripts/build_variant.py): only the untimed LNES = EMS kernels without shuffle -- a stability translation unit
+  // then compiles in a minute instead of five; everything else is refused
+  if (p.shuffle || scheme == 1 || timed || act == ACT_HEUR || act == ACT_INDEX) return hipErrorNotSupported;
+#define PCT_KERN(A, T, S, C) pct_discrete_kernel<K, BITS, A, false, S, 0, R_PLAIN>
+#else
 #define PCT_KERN(A, T, S, C) (p.shuffle ? pct_discrete_kernel<K, BITS, A, false, S, C, R_SHUF> : pct_discrete_kernel<K, BITS, A, (MTSEL ? false : T), S, C, R_PLAIN>)
+#endif
 #define PCT_LAUNCH(A)                                                                                        \
   do {                                                                                                       \
     void (*kern)(DiscreteParams, const void*, int, int, const int32_t*, int);                                \
@@ -2543,7 +2552,11 @@ inline hipError_t launch_typed(const DiscreteParams& p, int act, const void* act
                           (hipEvent_t)p.launch_ev_stop, 0, p, actions, row_len, n_steps, env_ids, n_ids); \
   } while (0)
   if (act == ACT_HEUR) {  // heuristic policies read the EMS list: LNES == EMS only (checked by the caller)
+#ifdef PCT_FEW_KERNELS
+    if constexpr (true) {
+#else
     if constexpr (MTSEL) {
+#endif
       return hipErrorInvalidValue;
     } else {
     void (*kern)(DiscreteParams, const void*, int, int, const int32_t*, int);
@@ -2560,7 +2573,9 @@ inline hipError_t launch_typed(const DiscreteParams& p, int act, const void* act
   }
   switch (act) {
     case ACT_ROWS: PCT_LAUNCH(ACT_ROWS); break;
+#ifndef PCT_FEW_KERNELS
     case ACT_INDEX: PCT_LAUNCH(ACT_INDEX); break;
+#endif
     case ACT_HASH: PCT_LAUNCH(ACT_HASH); break;
     default: PCT_LAUNCH(ACT_RESET); break;
   }

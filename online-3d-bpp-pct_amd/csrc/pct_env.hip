@@ -357,8 +357,8 @@ void stab_default_caps(int I, pct::StabCaps& normal, pct::StabCaps& retry) {
   normal.queue = 96;
   /* least-squares splits over up to 8 supporters in the normal pass (3.3 KB of LDS: one system of 7 / 8 supporters or two of 6 at
    * a time), up to 16 in the retry pass (four / two systems of the small classes side by side) */
-  normal.gelsd = 0; /* pct_set_lstsq_mode */
-  retry.gelsd = 0;
+  normal.gelsd = PCT_LSTSQ_GELSD; /* the default since round 5 (pct_set_lstsq_mode): the reference's own np.linalg.lstsq */
+  retry.gelsd = PCT_LSTSQ_GELSD;
   normal.lsq_n = 8;
   normal.lsq_bytes = (int)pct::stab_lsq_bytes(normal.lsq_n, false);
   retry.lsq_n = pct::STAB_LSQ;
@@ -463,7 +463,10 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
                                                           /* larger discrete bins under the stability settings: two orientations x
                                                            * 256 EMS = at most 512 candidates, a 2048-slot table; 8192 slots of
                                                            * 64-bit keys would not leave room for the stability state */
-                                                          : (cont ? 32768 : (cfg->setting != 2 ? 2048 : 8192)));
+                                                          /* larger continuous bins (round 5): 8192 slots in LDS (4915 distinct candidates;
+                                                           * C5 holds ~1800, beyond goes to the retry pass's 32768-slot HBM table).
+                                                           * Rounds 1-4: 32768 slots in HBM, every probe an agent-scope atomic */
+                                                          : (cont ? (cfg->setting != 2 ? 32768 : 8192) : (cfg->setting != 2 ? 2048 : 8192)));
   if (knob("PCT_CAND_CAP") && cfg->candidate_capacity <= 0) cand_cap = atoi(knob("PCT_CAND_CAP")); /* kernel experiments only; never over an explicit capacity */
   if (!is_cand_cap_ok(cand_cap)) return fail(PCT_ERR_INVALID_ARG, "candidate_capacity must be 8*4^k (8,32,...,2048,8192)");
 
@@ -512,7 +515,9 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
      * table sits behind the 2048-slot one it grows from) and the GENEMS children scratch (6 int32 words per
      * child): 2 * ems_cap children when the table lives in LDS (225 pre-elimination entries were seen at C3),
      * ems_cap otherwise */
-    size_t tab_words = c.table_global ? 0 : (size_t)(cand_cap > 2048 ? cand_cap + cand_cap / 4 : cand_cap);
+    /* (round 5: the 8192-slot table shares ONE region with the 2048-slot one it grows from -- the old entries wait in an HBM row,
+     * gpark, while the region is wiped) */
+    size_t tab_words = c.table_global ? 0 : (size_t)cand_cap;
     size_t child_words = (size_t)6 * ems_cap * (c.table_global ? 1 : 2);
     c.union_words = (int)(tab_words > child_words ? tab_words : child_words);
     if (c.union_words < 192) c.union_words = 192; /* the fast start parks 64 generator ids behind a 128-slot table */
@@ -573,6 +578,7 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
       CALLOC_(c.sb.up, Nn * c.I * sizeof(uint32_t));
       CALLOC_(c.sb.ent, Nn * c.sb.sp_stride * sizeof(uint32_t));
     }
+    if (!c.table_global && cand_cap > 2048) CALLOC_(c.gpark, Nn * (size_t)PCT_PARK_WORDS * sizeof(uint32_t));
     if (c.table_global) {
       CALLOC_(c.gtab, Nn * (size_t)(cand_cap + cand_cap / 4) * sizeof(uint32_t));
       CALLOC_(c.gorder, Nn * (size_t)c.order_cap * sizeof(uint16_t));

@@ -284,6 +284,64 @@ PCT_GD double dnrm2(int n, const double* x, int incx) {
   for (int k = 0; k < 3; k++) t = ext_add(t, k == 0 ? a : (k == 1 ? b : d));
   return ext_sqrt_to_double(t);
 }
+// dnrm2 by the group, for vectors long enough to pay two hand-overs through LDS: the squares an element per lane, then the four
+// accumulator chains (A: elements 0, 4, 8 ... of the leading blocks of eight and then the tail, in order; B, C, D: elements 1, 2, 3
+// mod 4 of the blocks) a chain per lane -- every chain the serial x87 sum it is on the FPU -- and ((C + A) + B) + D, the root and the
+// rounding in every lane.  The value is dnrm2's bit for bit: the same additions in the same order within each accumulator.
+// scratch: 2 n + 8 doubles nobody else uses meanwhile (split_t: the V^T region, idle until dbdsqr).
+#ifndef PCT_GELSD_COOP_NRM2_MIN
+#define PCT_GELSD_COOP_NRM2_MIN 5
+#endif
+PCT_GD double dnrm2_g(Grp g, int n, const double* x, int incx, double* scratch) {
+#if !defined(PCT_GELSD_COOP_NRM2_ALWAYS)
+  if (g.G < 4 || n < PCT_GELSD_COOP_NRM2_MIN) return dnrm2(n, x, incx);
+#else
+  if (n <= 1) return dnrm2(n, x, incx);
+#endif
+  uint64_t* sm = reinterpret_cast<uint64_t*>(scratch);  // [2 i] mantissa, [2 i + 1] exponent of element i's square; then the four partial sums
+  const int n8 = n & ~7;
+  PCT_GSYNC();
+  for (int i = g.gl; i < n; i += g.G) {
+    const Ext sq = ext_square(x[i * incx]);
+    sm[2 * i] = sq.m;
+    sm[2 * i + 1] = (uint64_t)(int64_t)sq.e;
+  }
+  PCT_GSYNC();
+  for (int w = g.gl; w < 4; w += g.G) {
+    Ext acc;
+    acc.m = 0; acc.e = 0;
+    PCT_GNOUNROLL
+    for (int i = w; i < n8; i += 4) {
+      Ext sq;
+      sq.m = sm[2 * i];
+      sq.e = (int)(int64_t)sm[2 * i + 1];
+      acc = ext_add(acc, sq);
+    }
+    if (w == 0) {
+      PCT_GNOUNROLL
+      for (int i = n8; i < n; i++) {
+        Ext sq;
+        sq.m = sm[2 * i];
+        sq.e = (int)(int64_t)sm[2 * i + 1];
+        acc = ext_add(acc, sq);
+      }
+    }
+    sm[2 * n + 2 * w] = acc.m;
+    sm[2 * n + 2 * w + 1] = (uint64_t)(int64_t)acc.e;
+  }
+  PCT_GSYNC();
+  Ext p[4];
+  for (int w = 0; w < 4; w++) {
+    p[w].m = sm[2 * n + 2 * w];
+    p[w].e = (int)(int64_t)sm[2 * n + 2 * w + 1];
+  }
+  PCT_GSYNC();
+  Ext t = p[2];
+  t = ext_add(t, p[0]);
+  t = ext_add(t, p[1]);
+  t = ext_add(t, p[3]);
+  return ext_sqrt_to_double(t);
+}
 // x := alpha x, an element per lane
 PCT_GD void dscal(Grp g, int n, double alpha, double* x, int incx) {
   for (int i = g.gl; i < n; i += g.G) x[i * incx] = alpha * x[i * incx];
@@ -383,7 +441,7 @@ PCT_GD double dlapy2(double x, double y) {
 }
 // dlarfg(n, alpha, x, incx): returns tau; x is scaled in place (an element per lane); `beta` is what dlarfg leaves in alpha
 // (alpha itself when tau = 0) -- the caller stores it when it has applied the reflector, whose leading 1 it writes there first
-PCT_GD double dlarfg(Grp g, int n, const double* alpha, double* x, int incx, double& beta) {
+PCT_GD double dlarfg(Grp g, int n, const double* alpha, double* x, int incx, double& beta, double* nrm2_scratch) {
   double a0 = *alpha;
   beta = a0;
   if (n <= 1) return 0.0;
@@ -392,7 +450,7 @@ PCT_GD double dlarfg(Grp g, int n, const double* alpha, double* x, int incx, dou
   PCT_GNOUNROLL
   for (int pass = 0; pass < 2; pass++) {  // (the second pass: after a rescaling of a tiny vector, which these systems never need)
     PCT_GPROF_T0(tn)
-    const double xnorm = dnrm2(n - 1, x, incx);
+    const double xnorm = dnrm2_g(g, n - 1, x, incx, nrm2_scratch);
     PCT_GPROF_ADD(5, tn)
     if (pass == 0 && xnorm == 0.0) return 0.0;
     beta = -sgn(dlapy2(a0, xnorm), a0);
@@ -881,7 +939,7 @@ PCT_GD bool split_t(Grp g, double* ws, int k, const double* in, double s0, doubl
         double* alpha = part == 0 ? &a[i + i * lda] : &a[i + (i + 1) * lda];
         double* xv = part == 0 ? &a[(i + 1 < rows ? i + 1 : rows - 1) + i * lda] : &a[i + (i + 2 < n ? i + 2 : n - 1) * lda];
         double saved;
-        const double tauv = dlarfg(g, len, alpha, xv, inc, saved);
+        const double tauv = dlarfg(g, len, alpha, xv, inc, saved, vt);  // (dnrm2's hand-over words: V^T and tau, n (n + 1) doubles, idle until dlalsd)
         if (stage == 1) {
           if (part == 0) d[i] = saved;
           else { e[i] = saved; taup[i] = tauv; }

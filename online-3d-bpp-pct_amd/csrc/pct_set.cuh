@@ -819,7 +819,7 @@ enum { PH_LOAD = 0, PH_DROP = 1, PH_GENEMS = 2, PH_SET = 3, PH_FEAS = 4, PH_OBS 
        // stability build also fills -- ADVICE r4): commit walk visits, virtual-check passes / tasks / single-task passes / level-0
        // candidates, least-squares splits by supporter count
        ST_STAB_COMMIT_VISITS = 30, ST_STAB_VPASSES = 31, ST_STAB_VTASKS = 32, ST_STAB_VNARROW = 33, ST_STAB_LSQ3 = 34,
-       ST_STAB_LSQ4 = 35, ST_STAB_LSQ5 = 36, ST_STAB_LSQX = 37, ST_STAB_LEVEL0 = 38 };
+       ST_STAB_LSQ4 = 35, ST_STAB_LSQ5 = 36, ST_STAB_LSQX = 37, ST_STAB_LEVEL0 = 38, ST_STAB_LSQ_ROUNDS = 39 };
 
 
 }  // namespace pct

@@ -80,7 +80,7 @@ struct StabCaps {
                  // system on a slot of the same workspace, instead of the Jacobi solves
 };
 #if !defined(__HIPCC__)
-static int g_stab_host_gelsd = 0;  // host test build (tests/host): the mode the handle carries in StabCaps on the device
+static int g_stab_host_gelsd = 1;  // host test build (tests/host): the mode the handle carries in StabCaps on the device
 #endif
 
 // per-env stability state: pointers into LDS (device) or host memory
@@ -450,6 +450,7 @@ struct StabStats {
   int v_passes, v_tasks, v_narrow;    // virtual checks: queue passes, tasks popped, passes that popped a single task
   int v_level0;                       // candidates that went through a level-0 task
   int lsq3, lsq4, lsq5, lsqx;         // least-squares splits by supporter count (x: the generic 6..STAB_LSQ solve)
+  int lsq_rounds;                     // calls of the wave's solve (stab_lsq_wave / stab_gelsd_slots): each is one solve's latency for the wave
 };
 
 // How a box with stack `stk` splits over its k supporters (D/space.py:88-160 / :182-256).
@@ -798,7 +799,9 @@ PCT_HD int stab_lsq_group(int k, bool gelsd = false) {
   return k <= 6 ? 16 : (k <= 8 ? 32 : 64);
 }
 PCT_HD int stab_lsq_class_n(int k, int lsq_n, bool gelsd = false) {
-  if (gelsd) return k <= 4 ? 4 : (k <= 8 ? 8 : lsq_n);
+  // (gelsd: a class of its own for five and six supporters -- a slot of 218 doubles instead of 417, so eight such systems instead of
+  // five share a round's workspace: the c3s1 env whose candidates' walks pass through a box on six supporters 33 times in one step)
+  if (gelsd) return k <= 4 ? 4 : (k <= 6 ? 6 : (k <= 8 ? 8 : lsq_n));
   return k <= 6 ? 6 : (k <= 8 ? 8 : lsq_n);
 }
 // workspace bytes: one system of up to n supporters (narrow: the normal pass, where LDS is what bounds the resident envs --
@@ -1131,7 +1134,7 @@ __device__ __forceinline__ bool stab_virtual_wave(const Geo& geo, const StabStat
           const int kf = __builtin_amdgcn_readlane(kk, first);
           const int G = stab_lsq_group(kf, w.gelsd), cn = stab_lsq_class_n(kf, w.lsq_n, w.gelsd);
           const size_t sd = stab_lsq_slot_doubles(cn, w.gelsd);
-          const bool mine = ((cm >> lane) & 1ull) && stab_lsq_group(kk, w.gelsd) == G;
+          const bool mine = ((cm >> lane) & 1ull) && stab_lsq_class_n(kk, w.lsq_n, w.gelsd) == cn;
           const uint64_t mm = __ballot(mine);
           const int rk = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
           // systems of this class the workspace holds (with the hull workspace behind it when that is idle), at most one per lane group
@@ -1142,6 +1145,7 @@ __device__ __forceinline__ bool stab_virtual_wave(const Geo& geo, const StabStat
           __syncthreads();
           if (sel) stab_lsq_inputs<CONT>(geo, bg, kk, sup, stk, w.lsq + (size_t)rk * sd);
           __syncthreads();
+          if (ss && lane == 0) ss->lsq_rounds++;
           const bool gill = w.gelsd ? stab_gelsd_slots(w.lsq, G, cn, nslot, lane, w.gelsd_avx2) : stab_lsq_wave(w.lsq, G, cn, nslot, lane);
           // a system's notice comes back in its group's lanes: fetch the one of this lane's slot
           const uint64_t illm = __ballot(gill);
@@ -1477,6 +1481,7 @@ __device__ __forceinline__ int stab_commit_wave(const Geo& geo, StabState& st, i
     const int ks = __builtin_amdgcn_readfirstlane(pend_k);
     const int G = stab_lsq_group(ks, w.gelsd), cn = stab_lsq_class_n(ks, w.lsq_n, w.gelsd);
     __syncthreads();
+    if (ss && lane == 0) ss->lsq_rounds++;
     const bool sill = w.gelsd ? stab_gelsd_slots(w.lsq, G, cn, 1, lane, w.gelsd_avx2) : stab_lsq_wave(w.lsq, G, cn, 1, lane);  // one system, in slot 0
     if (lane == 0) {
       if (ks <= 5) {  // (gelsd mode only)

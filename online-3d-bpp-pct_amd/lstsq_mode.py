@@ -37,11 +37,34 @@ def numpy_blas():
     return None, None
 
 
+# releases whose routines were checked against the restatement (tests/golden/check_gelsd_port.py, check_other_numpy.py: NumPy 1.26.4 ... 2.2.6)
+CHECKED_OPENBLAS = ("0.3.23", "0.3.29")
+
+
 def numpy_lstsq_mode(strict=False):
-    """'gelsd' / 'gelsd_avx2' for the kernel set this process's NumPy runs, else None (strict: raise).  A version of OpenBLAS other
-    than the pinned one is reported through the second value of numpy_blas(); the mode is still returned."""
-    arch, _ = numpy_blas()
+    """'gelsd' / 'gelsd_avx2' for the kernel set this process's NumPy runs, else None (strict: raise).  An OpenBLAS release outside the
+    checked span (or one whose version cannot be read) is a warning -- the mode is still returned -- and an error under strict:
+    another release may order its kernel sums differently, and the claim "bit-identical to this NumPy" would be unfounded."""
+    arch, version = numpy_blas()
     mode = RESTATED.get(arch)
-    if mode is None and strict:
-        raise RuntimeError("NumPy's BLAS on this host runs the %r kernel set; restated are %s" % (arch, sorted(RESTATED)))
+    if mode is None:
+        if strict:
+            raise RuntimeError("NumPy's BLAS on this host runs the %r kernel set; restated are %s" % (arch, sorted(RESTATED)))
+        return None
+    v = (version or "").split(".dev")[0]
+    lo, hi = (tuple(int(x) for x in c.split(".")) for c in CHECKED_OPENBLAS)
+    try:
+        known = lo <= tuple(int(x) for x in v.split(".")[:3]) <= hi
+    except ValueError:
+        known = False
+    if not known:
+        msg = ("NumPy's OpenBLAS is %s; the dgelsd restatement was checked against %s ... %s (pinned: %s)"
+               % (version or "of unknown version", CHECKED_OPENBLAS[0], CHECKED_OPENBLAS[1], PINNED_OPENBLAS))
+        if strict:
+            raise RuntimeError(msg)
+        import warnings
+        warnings.warn(msg)
     return mode
+
+
+__all__ = ["numpy_blas", "numpy_lstsq_mode", "RESTATED", "PINNED_OPENBLAS", "CHECKED_OPENBLAS"]

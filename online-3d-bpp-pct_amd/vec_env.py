@@ -130,7 +130,7 @@ class PctVecEnv(VecEnv):
                  load_test_data=False, internal_node_holder=80, leaf_node_holder=50, LNES="EMS", shuffle=False,
                  sample_from_distribution=False, sample_left_bound=None, sample_right_bound=None,
                  device="cuda:0", seed=0, env_id_base=0, item_stream=None, continuous=False, monitor=True,
-                 strict=True, ems_capacity=0, candidate_capacity=0, overflow_retry=True, rng="counter", lstsq="jacobi"):
+                 strict=True, ems_capacity=0, candidate_capacity=0, overflow_retry=True, rng="counter", lstsq="gelsd"):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise PctEnvError("PctVecEnv runs on an AMD GPU only (device=%r); there is no CPU path" % (device,))
@@ -222,20 +222,22 @@ class PctVecEnv(VecEnv):
 
         if shuffle:
             _lib.check(self._L.pct_set_shuffle_seed(self._h, int(seed)))
-        # the solver behind np.linalg.lstsq in the stability check (settings 1 / 3): "jacobi" (default; the reference's solution up
-        # to the last bits) or "gelsd" (LAPACK dgelsd as the reference's NumPy executes it: bit-identical, slower) -- pct_env.h
+        # the solver behind np.linalg.lstsq in the stability check (settings 1 / 3): "gelsd" (default since round 5: LAPACK dgelsd as the
+        # reference's NumPy executes it on AVX-512 hosts -- bit-identical to the reference) or "jacobi" (the stand-in of rounds 1-4: the
+        # reference's solution up to the last bits, ~1.35 x the throughput) -- pct_env.h
         # ("gelsd_avx2": as NumPy executes it on AVX2 hosts, AMD Zen included -- OpenBLAS' other kernel set)
         # ("numpy": whichever of the two this process's NumPy runs on this host -- lstsq_mode.py; for comparing against a reference
         # that runs in the same Python)
         modes = {"jacobi": _lib.LSTSQ_JACOBI, "gelsd": _lib.LSTSQ_GELSD, "gelsd_avx2": _lib.LSTSQ_GELSD_AVX2}
         if lstsq == "numpy":
             from .lstsq_mode import numpy_lstsq_mode
-            lstsq = numpy_lstsq_mode(strict=True)
+            lstsq = numpy_lstsq_mode(strict=bool(strict))  # (a BLAS outside the checked releases: an error under strict, else a warning)
+            if lstsq is None:
+                raise RuntimeError("lstsq='numpy': this process's NumPy runs a BLAS kernel set that is not restated (lstsq_mode.py)")
         if lstsq not in modes:
             raise ValueError("lstsq must be 'jacobi', 'gelsd', 'gelsd_avx2' or 'numpy'")
         self.lstsq = lstsq
-        if lstsq != "jacobi":
-            _lib.check(self._L.pct_set_lstsq_mode(self._h, modes[lstsq]))
+        _lib.check(self._L.pct_set_lstsq_mode(self._h, modes[lstsq]))
         # outputs live in torch tensors bound into the handle (zero copy)
         dev = self.device
         self._obs = torch.zeros(self.N, self.row_len, dtype=torch.float32, device=dev)
@@ -249,6 +251,8 @@ class PctVecEnv(VecEnv):
             o += N * w
         self._pack = torch.zeros(o, dtype=torch.uint8, device=dev)
         self._h_pack = torch.zeros(o, dtype=torch.uint8).pin_memory()
+        self._pack_offs = offs
+        self._h_ring = None  # two more pinned mirrors + events, made on the first step_outputs_async()
         view = lambda buf, nm: buf[offs[nm][0]:offs[nm][1]].view(offs[nm][2])
         self._ratio, self._reward, self._counter = view(self._pack, "ratio"), view(self._pack, "reward"), view(self._pack, "counter")
         self._flags, self._done = view(self._pack, "flags"), view(self._pack, "done")
@@ -502,6 +506,48 @@ class PctVecEnv(VecEnv):
         _lib.check(self._L.pct_debug_phase_timing(self._h, int(bool(on)), out.ctypes.data))
         return out
 
+    def step_outputs_async(self):
+        """The small per-step outputs WITHOUT a stream synchronisation: enqueues the packed D2H copy of the step just launched into
+        one of two pinned mirrors and returns a ticket; `ticket.wait()` -> (reward [N,1] CPU, done bool [N], infos) blocks only
+        until THAT copy has landed.  A caller whose next action needs only the device-resident observation (the reference's trainer:
+        train_tools.py:63-79 reads reward / done / infos for its episode statistics, the policy reads obs) launches step t + 1 first
+        and consumes step t's ticket while the GPU works: the host's share of a step is hidden behind the kernel.  At most two tickets
+        may be outstanding."""
+        if self._h_ring is None:
+            self._h_ring = [torch.zeros_like(self._h_pack).pin_memory() for _ in range(2)]
+            self._ring_ev = [torch.cuda.Event() for _ in range(2)]
+            self._ring_i = 0
+        buf, ev = self._h_ring[self._ring_i], self._ring_ev[self._ring_i]
+        self._ring_i ^= 1
+        buf.copy_(self._pack, non_blocking=True)
+        if self._reward.data_ptr() != self._own[1].data_ptr():  # a rollout slot holds the reward (step_into)
+            o = self._pack_offs["reward"]
+            buf[o[0]:o[1]].view(o[2]).copy_(self._reward.reshape(-1), non_blocking=True)
+        ev.record(torch.cuda.current_stream(self.device))
+        self.waiting_step = False
+        return _StepTicket(self, buf, ev)
+
+    def _outputs_from(self, buf):
+        offs = self._pack_offs
+        view = lambda nm: buf[offs[nm][0]:offs[nm][1]].view(offs[nm][2])
+        reward = view("reward").clone().unsqueeze(1)
+        done = view("done").numpy().astype(bool)
+        counter = view("counter").numpy().copy()
+        ratio = view("ratio").numpy().copy()
+        if self.strict:
+            f = view("flags").numpy().view(np.uint32) & np.uint32(_lib.FLAG_ERROR_MASK)
+            if f.any():
+                bad = int(np.nonzero(f)[0][0])
+                raise PctEnvError("env %d raised error flags 0x%x (include/pct_env.h PCT_FLAG_*)" % (bad, int(f[bad])))
+        ep_r = ep_l = None
+        if self._monitor:
+            self._ep_r += reward[:, 0].numpy()
+            self._ep_l += 1
+            ep_r, ep_l = self._ep_r.copy(), self._ep_l.copy()
+            self._ep_r[done] = 0
+            self._ep_l[done] = 0
+        return reward, done, LazyInfos(counter, ratio, done, ep_r, ep_l, time.time() - self._tstart)
+
     def step_wait(self):
         # ONE async D2H of the packed output block, then a single stream sync (envs.py:178-182)
         self._h_pack.copy_(self._pack, non_blocking=True)
@@ -573,6 +619,17 @@ class PctVecEnv(VecEnv):
             pass
 
 
+class _StepTicket(object):
+    """What PctVecEnv.step_outputs_async returns: the packed outputs of one step on their way to a pinned host buffer."""
+
+    def __init__(self, env, buf, ev):
+        self._env, self._buf, self._ev = env, buf, ev
+
+    def wait(self):
+        self._ev.synchronize()
+        return self._env._outputs_from(self._buf)
+
+
 def make_vec_envs(args, log_dir=None, allow_early_resets=True):
     """Drop-in for envs.make_vec_envs (envs.py:75-116): same `args` namespace
     (tools.py:130-198), returns the object the trainer steps (train_tools.py:39,67)."""
@@ -596,6 +653,9 @@ def make_vec_envs(args, log_dir=None, allow_early_resets=True):
         continuous=kind.startswith("PctContinuous"),
         item_stream=getattr(args, "item_stream", None),
         rng=getattr(args, "rng", "counter"),  # "numpy": the reference's own per-env MT19937 stream (discrete env)
+        # the stability settings' np.linalg.lstsq: "gelsd" = the reference's own (default), "gelsd_avx2" / "numpy" = as the NumPy of an
+        # AVX2 host / of this process executes it, "jacobi" = the faster stand-in of rounds 1-4
+        lstsq=getattr(args, "lstsq", "gelsd"),
     )
 
 

@@ -78,8 +78,8 @@ def lib():
         L.pcto_get_lstsq_mode.restype = ctypes.c_int
         L.gelsd_lstsq.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]
         L.gelsd_lstsq.restype = ctypes.c_int
-        if os.environ.get("PCT_ORACLE_LSTSQ", "") in ("gelsd", "gelsd_avx2"):
-            L.pcto_set_lstsq_mode(1 if os.environ["PCT_ORACLE_LSTSQ"] == "gelsd" else 2)
+        if os.environ.get("PCT_ORACLE_LSTSQ", "") in ("jacobi", "gelsd", "gelsd_avx2"):
+            L.pcto_set_lstsq_mode({"jacobi": 0, "gelsd": 1, "gelsd_avx2": 2}[os.environ["PCT_ORACLE_LSTSQ"]])
         _LIB = L
     return _LIB
 
@@ -88,8 +88,8 @@ LSTSQ_JACOBI, LSTSQ_GELSD, LSTSQ_GELSD_AVX2 = 0, 1, 2
 
 
 def set_lstsq_mode(mode):
-    """Process-wide solver behind np.linalg.lstsq in the oracle's stability check: LSTSQ_JACOBI (default, what the kernels run by
-    default) LSTSQ_GELSD (LAPACK dgelsd as the reference's NumPy executes it on AVX-512 hosts, oracle/pct_oracle_gelsd.c) or LSTSQ_GELSD_AVX2
+    """Process-wide solver behind np.linalg.lstsq in the oracle's stability check: LSTSQ_GELSD (default, as the kernels: LAPACK dgelsd as
+    the reference's NumPy executes it on AVX-512 hosts, oracle/pct_oracle_gelsd.c), LSTSQ_JACOBI (the stand-in of rounds 1-4) or LSTSQ_GELSD_AVX2
     (the same with the kernel set OpenBLAS runs on AVX2 hosts, AMD Zen included).  Returns the old mode."""
     old = lib().pcto_get_lstsq_mode()
     lib().pcto_set_lstsq_mode(int(mode))

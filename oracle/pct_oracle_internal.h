@@ -132,7 +132,7 @@ void stab_free(struct stab* s);
 int stab_ill_conditioned(const struct stab* s); /* sticky notice, see pct_oracle_stab.c */
 int stab_ill_commit(const struct stab* s);      /* ... raised by a solve of a commit walk */
 void stab_set_ill_near(int on);
-void stab_set_lstsq_mode(int mode); /* 0: Jacobi stand-in (default), 1: dgelsd as NumPy's OpenBLAS executes it */
+void stab_set_lstsq_mode(int mode); /* 0: Jacobi stand-in, 1 (default): dgelsd as NumPy's OpenBLAS executes it, 2: ... on AVX2 hosts */
 int stab_get_lstsq_mode(void);
 /* pct_oracle_gelsd.c */
 void gelsd_set_kernel_set(int s); /* 0: OpenBLAS "SkylakeX" kernels (AVX-512 hosts), 1: "Haswell" (AVX2 hosts, AMD Zen) */

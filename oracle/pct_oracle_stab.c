@@ -214,8 +214,8 @@ static int point_in_polygon(const double pt[2], double (*co)[2], int n) {
  * NumPy's default rcond = eps * max(M, N).  Working on A (not on A^T A) keeps the small singular values accurate
  * to eps * sigma_max, as dgelsd does -- the normal-equations form loses everything below sqrt(eps) * sigma_max
  * and then disagrees with LAPACK by up to 5e-3 on the nearly rank-deficient systems this check produces. */
-static int g_lstsq_mode = 0; /* 0: the Jacobi stand-in below (what the kernels run by default), 1: LAPACK dgelsd as the
-                                reference's NumPy executes it (pct_oracle_gelsd.c) */
+static int g_lstsq_mode = 1; /* 1 (default since round 5, as the kernels): LAPACK dgelsd as the reference's NumPy executes it
+                                (pct_oracle_gelsd.c); 0: the Jacobi stand-in below (PCT_LSTSQ_JACOBI) */
 void stab_set_lstsq_mode(int mode) { /* 0: Jacobi; 1: dgelsd, AVX-512 kernel set; 2: dgelsd, AVX2 (Haswell / Zen) kernel set */
   g_lstsq_mode = mode != 0;
   gelsd_set_kernel_set(mode == 2);

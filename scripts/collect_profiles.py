@@ -14,7 +14,8 @@ envs = int(sys.argv[3])
 alg = int(sys.argv[4])
 tsteps = int(sys.argv[5]) if len(sys.argv) > 5 else 2000  # timed steps of the traced run
 psteps = int(sys.argv[6]) if len(sys.argv) > 6 else 100   # timed (= warm-up) steps of each PMC run
-src = os.path.join(ROOT, "gpurun_out", "prof_%s_%s" % (tag, wl))
+suf = os.environ.get("PROFILE_SUFFIX", "")
+src = os.path.join(ROOT, "gpurun_out", "prof_%s_%s%s" % (tag, wl, suf))
 dst = os.environ.get("PCT_PROFILE_DST") or os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 KERNEL = "pct_continuous_kernel" if wl in ("c3", "c5", "c3s1") else "pct_discrete_kernel"
@@ -49,7 +50,7 @@ if os.path.exists(db):
         for ln in open(bj):
             if ln.startswith("{"):
                 lines += ["", "bench line of the traced run:", ln.strip()]
-    open(os.path.join(dst, "%s_trace_%s.txt" % (tag, wl)), "w").write("\n".join(lines) + "\n")
+    open(os.path.join(dst, "%s_trace_%s%s.txt" % (tag, wl, suf)), "w").write("\n".join(lines) + "\n")
 
 pmc = {}
 for sub in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
@@ -82,6 +83,6 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     fetch, write = pmc["FETCH_SIZE"] * 1024, pmc["WRITE_SIZE"] * 1024
     out.update({"fetch_bytes_raw": fetch, "fetch_bytes_corrected_x2": 2 * fetch, "write_bytes": write,
                 "hbm_bytes_per_launch": 2 * fetch + write, "algorithmic_bytes_per_launch": alg * envs})
-json.dump(out, open(os.path.join(dst, "%s_pmc_%s.json" % (tag, wl)), "w"), indent=1)
+json.dump(out, open(os.path.join(dst, "%s_pmc_%s%s.json" % (tag, wl, suf)), "w"), indent=1)
 print("\n".join(lines[:5]))
 print(json.dumps({k: v for k, v in out.items() if k != "pmc_per_launch"}, indent=1))

@@ -70,7 +70,7 @@ print("  slowest env of a launch: mean %.0f cycles (= %.1f us at 2.4 GHz); mean 
     keymax.mean(), keymax.mean() / 2400, keymean.mean(), int((retry > 0).sum())))
 names = ["load", "drop+commit", "genems", "set", "feas", "obs", "store"]
 stat_names = {12: "EMS", 13: "distinct", 30: "commit visits", 31: "virtual passes", 32: "virtual tasks", 33: "narrow passes",
-              34: "lsq k=3", 35: "lsq k=4", 36: "lsq k=5", 37: "lsq k>5", 38: "level-0 candidates"}
+              34: "lsq k=3", 35: "lsq k=4", 36: "lsq k=5", 37: "lsq k>5", 38: "level-0 candidates", 39: "solve rounds"}
 order = np.argsort(-dur)
 print("  launches beyond 2x the median (%d of %d), longest first:" % (int((dur > 2 * med).sum()), K))
 for s in order[:max(12, int((dur > 2 * med).sum()))][:40]:

@@ -62,17 +62,25 @@ def main():
     lib = ctypes.CDLL(os.path.join(ROOT, "scripts", "mb", "libmb_gelsd.so"))
     rng = np.random.default_rng(2025)
     quick = "--quick" in sys.argv
+    only = os.environ.get("MB_ONLY")  # "k,variant,G,per_wave": one configuration (for a profiler run)
+    only = tuple(int(v) for v in only.split(",")) if only else None
     bad = 0
     for k, n, groups in ((3, 4, (1, 4)), (4, 4, (1, 4)), (5, 8, (1, 8)), (8, 8, (1, 8, 16)), (11, 16, (1, 16)), (16, 16, (1, 16, 64))):
         count = 256 if k <= 8 else 64
         if quick:
             count //= 4
+        if only and only[0] != k:
+            continue
         ins, xs, near = make_systems(k, count, rng)
-        for variant in (0, 1):
+        for variant in (0, 1, 2):
             for G in groups:
-                if variant == 0 and G != 1:
+                if variant != 1 and G != 1:
+                    continue
+                if variant == 2 and k > 4:
                     continue
                 for per_wave in sorted({1, max(1, min(64 // G, 8)), 64 // G}):
+                    if only and only != (k, variant, G, per_wave):
+                        continue
                     if per_wave * (4 + 3 * n + (n * (n - 1) // 2 + 1) * (n + 1) + n * n + 8 * n) * 8 > 150000:
                         continue
                     x, ill, cyc = run(lib, ins, per_wave, G, n, variant)
@@ -80,7 +88,7 @@ def main():
                     okn = int(np.sum(ill == near))
                     bad += (count - ok) + (count - okn)
                     print("k=%2d class=%2d %s G=%2d systems/wave=%2d: bit-exact %d/%d, notice %d/%d, cycles/solve-call median %8d  max %8d"
-                          % (k, n, "r04-serial" if variant == 0 else "r05-group ", G, per_wave, ok, count, okn, count, int(np.median(cyc)), int(cyc.max())),
+                          % (k, n, ("r04-serial", "r05-group ", "r05-fixed ")[variant], G, per_wave, ok, count, okn, count, int(np.median(cyc)), int(cyc.max())),
                           flush=True)
     print("MISMATCHES", bad)
 

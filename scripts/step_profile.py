@@ -16,9 +16,9 @@ if MODE == "c5":
                         sample_left_bound=5.0, sample_right_bound=25.0, seed=4, device="cuda:0", monitor=False,
                         ems_capacity=384, candidate_capacity=8192)
 elif MODE == "c1":
-    env = pkg.PctVecEnv(N, setting=1, item_set=items, seed=4, device="cuda:0", monitor=False)
+    env = pkg.PctVecEnv(N, setting=1, item_set=items, seed=4, device="cuda:0", monitor=False, lstsq=os.environ.get("PCT_LSTSQ", "gelsd"))
 elif MODE == "c3s1":
-    env = pkg.PctVecEnv(N, continuous=True, setting=1, container_size=(1, 1, 1), sample_left_bound=0.1, sample_right_bound=0.5,
+    env = pkg.PctVecEnv(N, continuous=True, setting=1, container_size=(1, 1, 1), sample_left_bound=0.1, sample_right_bound=0.5, lstsq=os.environ.get("PCT_LSTSQ", "gelsd"),
                         seed=4, device="cuda:0", monitor=False)
 elif MODE == "c3":
     env = pkg.PctVecEnv(N, continuous=True, sample_left_bound=1.0, sample_right_bound=5.0, seed=4, device="cuda:0", monitor=False)
@@ -58,7 +58,7 @@ for i, n in extra.items():
     print("    %-34s %9.1f   (all-env mean %9.1f)" % (n, worst[:, i].mean(), rec[:, :, i].mean()))
 if MODE in ("c1", "c3s1"):  # the stability counters have slots of their own (30..38)
     for i, n in {30: "commit visits", 31: "virtual passes", 32: "virtual tasks", 33: "narrow passes", 34: "lsq k=3", 35: "lsq k=4", 36: "lsq k=5",
-                 37: "lsq k>5", 38: "level-0 candidates"}.items():
+                 37: "lsq k>5", 38: "level-0 candidates", 39: "solve rounds (one solve's latency each)"}.items():
         print("    %-34s %9.2f   (all-env mean %9.2f)" % (n, worst[:, i].mean(), rec[:, :, i].mean()))
 # least squares: total ~ a + b*E + c*generated + d*distinct
 X = np.stack([np.ones(K * N), rec[:, :, 12].ravel(), rec[:, :, 14].ravel(), rec[:, :, 13].ravel()], 1)

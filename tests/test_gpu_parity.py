@@ -711,14 +711,15 @@ def test_hip_continuous_heuristics_match_oracle_batched(heur, setting):
 
 @pytest.mark.gpu
 def test_hip_notice_precedes_the_lapack_divergence():
-    """on the adversarial stream whose env 0 meets a rank decision at the least-squares cut (the
-    unmodified reference's trajectory is LAPACK dgelsd's from step 79 on; tests/golden/check_ill_notice.py), the kernels
-    equal the reference before that step and on the other envs throughout, part ways exactly there, and have raised the
-    non-fatal PCT_FLAG_ILL_CONDITIONED on that env -- and only on it -- no later than that step; no error flag."""
+    """VERDICT r2 item 2, the JACOBI mode (the default of rounds 1-4, now opt-in): on the adversarial stream whose env 0 meets a
+    rank decision at the least-squares cut (the unmodified reference's trajectory is LAPACK dgelsd's from step 79 on;
+    tests/golden/check_ill_notice.py), the kernels equal the reference before that step and on the other envs throughout, part ways
+    exactly there, and have raised the non-fatal PCT_FLAG_ILL_CONDITIONED on that env -- and only on it -- no later than that step;
+    no error flag.  (In the default mode the kernels follow the recording to its end: tests/test_zz_gpu_gelsd.py.)"""
     c, z = load_case("discrete_s1_flat_diverging")
     env = _pkg().PctVecEnv(c["N"], setting=c["setting"], container_size=c["container"], item_set=case_items(c),
                            internal_node_holder=c["I"], leaf_node_holder=c["L"], env_id_base=c["base"], item_stream=z["stream"],
-                           device="cuda:0")
+                           device="cuda:0", lstsq="jacobi")
     obs = env.reset()
     div = z["first_divergence"]
     alive = np.ones(c["N"], bool)

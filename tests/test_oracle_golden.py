@@ -281,7 +281,17 @@ def test_oracle_notice_precedes_the_lapack_divergence():
     env 0 meets a least-squares system with a rank decision at the cut (sigma_max 1.1e15, smallest kept singular value
     1.97 x the rcond cut): from step 79 on the reference's trajectory is LAPACK dgelsd's.  The oracle must equal the
     reference before that step and on every other env throughout, and its notice (the product's
-    PCT_FLAG_ILL_CONDITIONED) must be up on env 0 no later than that step and on no other env."""
+    PCT_FLAG_ILL_CONDITIONED) must be up on env 0 no later than that step and on no other env.  This is the JACOBI stand-in
+    (rounds 1-4's default, now opt-in); in the default mode the oracle follows the recording to its end (tests/test_gelsd_port.py)."""
+    from oracle import oracle_lib
+    old = oracle_lib.set_lstsq_mode(oracle_lib.LSTSQ_JACOBI)
+    try:
+        _notice_precedes_the_divergence()
+    finally:
+        oracle_lib.set_lstsq_mode(old)
+
+
+def _notice_precedes_the_divergence():
     c, z = load_case("discrete_s1_flat_diverging")
     env = OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"], item_set=case_items(c),
                        internal_node_holder=c["I"], leaf_node_holder=c["L"], env_id_base=c["base"])

@@ -61,7 +61,18 @@ def test_product_stability_known_answer():
     assert h.hexdigest()[:16] == "443198ae2c0162db"
 
 
-def test_product_stability_equals_oracle_on_random_streams():
+@pytest.mark.parametrize("mode", ["default", "jacobi"])
+def test_product_stability_equals_oracle_on_random_streams(mode):
+    """the product's stability source against the oracle's, both in the default solver mode (dgelsd) and both in the Jacobi stand-in
+    (rounds 1-4's default, now opt-in: pct_stab.cuh's stab_split_fixed / stab_lstsq against the oracle's lstsq_min_norm)"""
+    if mode == "jacobi":
+        with _Gelsd(ol.LSTSQ_JACOBI):
+            _product_equals_oracle(ol.LSTSQ_JACOBI)
+    else:
+        _product_equals_oracle(None)
+
+
+def _product_equals_oracle(force_mode):
     items = item_set_range(1, 5)
     stream = make_stream(99, 48, 1024, items)
     a = ol.OracleVecEnv(48, setting=1, container_size=(10, 10, 10), item_set=items)
@@ -74,14 +85,19 @@ def test_product_stability_equals_oracle_on_random_streams():
         ref_done.append(a.done.copy())
     a.close()
     with _Variant():
-        b = ol.OracleVecEnv(48, setting=1, container_size=(10, 10, 10), item_set=items)
-        b.set_item_stream(stream)
-        b.reset()
-        for t in range(600):
-            assert np.array_equal(b.obs, ref_obs[t]), t
-            b.step_hash_policy(1)
-            assert np.array_equal(b.done, ref_done[t]), t
-        b.close()
+        old = ol.set_lstsq_mode(force_mode) if force_mode is not None else None
+        try:
+            b = ol.OracleVecEnv(48, setting=1, container_size=(10, 10, 10), item_set=items)
+            b.set_item_stream(stream)
+            b.reset()
+            for t in range(600):
+                assert np.array_equal(b.obs, ref_obs[t]), t
+                b.step_hash_policy(1)
+                assert np.array_equal(b.done, ref_done[t]), t
+            b.close()
+        finally:
+            if old is not None:
+                ol.set_lstsq_mode(old)
 
 
 @pytest.mark.parametrize("name", CONT_STAB_CASES)
@@ -324,5 +340,5 @@ def test_product_gelsd_avx2_split_equals_oracle_avx2():
         total += 1
         differ += not np.array_equal(xs[0], xs[1])
     plain.gelsd_set_kernel_set(0)
-    var.stab_set_lstsq_mode(0)
+    var.stab_set_lstsq_mode(1)  # (the default)
     assert differ > 0.5 * total
