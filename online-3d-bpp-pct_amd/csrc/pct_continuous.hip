@@ -1542,10 +1542,13 @@ enum { CACT_ROWS = 0, CACT_INDEX = 1, CACT_HASH = 2, CACT_RESET = 3, CACT_HEUR =
 
 template <int ACT, bool TIMED, bool GT, bool STAB, bool MT>
 #ifndef PCT_CONT_WAVES
-#define PCT_CONT_WAVES 3 /* waves per SIMD the plain kernel is compiled for.  C3's 14.2 KB of LDS admit 11 envs per CU, two waves
-                            per SIMD only 8.  Round 2: 3 (168 VGPRs, 68 of them spilled) was as fast as 2 at 4096 envs and its spills
-                            made 162 MB of HBM traffic per launch.  Round 4 (the kernel needs 217 VGPRs since the kernarg entry): 3
-                            spills 32 -- C3 26.8 -> 27.3 M env-steps/s, 34.2 -> 37.4 M at 8192 envs, C5 unchanged */
+#define PCT_CONT_WAVES 2 /* waves per SIMD the plain kernel is compiled for.  The kernel needs 217 VGPRs: at two waves per SIMD (256) nothing
+                            spills; at three (168; C3's 14.2 KB of LDS would admit 11 envs per CU instead of 8) 32 VGPRs spill.  Round 4
+                            shipped three: C3 +3 % (28.8 against 27.9 M env-steps/s, +9 % at 8192 envs) for 2.8 x the HBM traffic
+                            (71.7 against 25.7 MB per launch = 3.7 x against 1.3 x the algorithmic bytes) -- the trade round 4 itself
+                            refused on C2 (write-through stores).  Round 5 re-measured one / two / three (scripts/r05_variants.sh:
+                            C3 27.94 / 27.91 / 28.76 M, C5 2.186 / 2.160 / 2.159 M) and went back to two: a launch of C3 is its
+                            slowest env's chain (profiles/r05_step_profile_c3.txt), which occupancy does not shorten */
 #endif
 #ifndef PCT_STAB_WAVES
 #define PCT_STAB_WAVES 1 /* waves per SIMD the stability-check kernels are compiled for (2: 256 VGPRs, ~470 of them spilled -- slower, profiles/r03_stability_tuning.txt) */
@@ -1754,8 +1757,8 @@ hipError_t PCT_CONT_LAUNCH(const ContinuousParams& p, int act, const void* actio
   if (grid <= 0) return hipSuccess;
 #ifdef PCT_FEW_KERNELS
   // kernel experiments (scripts/build_variant.py): only the untimed LDS-table kernels of the action kinds the benchmark uses
-  if (timed || p.table_global || act == CACT_HEUR || act == CACT_INDEX) return hipErrorNotSupported;
-#define PCT_CKERN(A) (stab ? pct_continuous_kernel<A, false, false, true, PCT_CONT_MTV> : pct_continuous_kernel<A, false, false, false, PCT_CONT_MTV>)
+  if (timed || (stab && p.table_global) || act == CACT_HEUR || act == CACT_INDEX) return hipErrorNotSupported;
+#define PCT_CKERN(A) (stab ? pct_continuous_kernel<A, false, false, true, PCT_CONT_MTV> : (p.table_global ? pct_continuous_kernel<A, false, true, false, PCT_CONT_MTV> : pct_continuous_kernel<A, false, false, false, PCT_CONT_MTV>))
 #endif
 #define PCT_CLAUNCH(A)                                                                                         \
   do {                                                                                                         \

@@ -29,5 +29,5 @@ PCT_PROFILE_DST=$REPO/gpurun_out/profiles_$TAG PROFILE_SUFFIX=$SUF python script
 cp $OUT/trace/*kernel_stats.csv $REPO/gpurun_out/profiles_$TAG/${TAG}_trace_${WL}${SUF}_kernel_stats.csv 2>/dev/null
 cd $OUT
 # keep the merge-back bounded: the per-dispatch PMC tables and the trace CSV of a 2000-step run are a few MB each
-find . -size +12M -delete
+find . -size +1M -delete  # (the rocpd databases and the per-dispatch trace / counter tables: 20-30 MB per workload; the stats CSVs stay)
 du -sh .
