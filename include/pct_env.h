@@ -348,10 +348,10 @@ int pct_debug_retry_count(pct_env* env, int32_t* last, int64_t* envs_total, int6
 
 /* Per-phase cycle accounting of the transition kernel (profiling aid).  on != 0: (re)start
  * accumulation; host_out, if non-NULL, first receives the accumulators gathered so far:
- * uint64 [N,40] = s_memtime cycles in {load, drop_box, GENEMS, candidate set, feasibility,
+ * uint64 [N,44] = s_memtime cycles in {load, drop_box, GENEMS, candidate set, feasibility,
  * observation write, state store}, the number of steps, then the candidate-set detail
  * {generation + membership probes, batch de-duplication, matching, rebuilds}, the set's statistics
- * (slots 12..29) and the stability settings' counters (slots 30..38, csrc/pct_set.cuh).
+ * (slots 12..29) and the stability settings' counters (slots 30..43, csrc/pct_set.cuh).
  * Synchronises the device. */
 int pct_debug_phase_timing(pct_env* env, int32_t on, uint64_t* host_out);
 

@@ -837,7 +837,7 @@ __device__ __forceinline__ bool cleaf_nodes(const ContinuousParams& p, int e, CL
   // ALL 64 lanes call (`live`: this lane holds a candidate): the stability check of the lanes that need one is a
   // wave-cooperative task walk (pct_stab.cuh stab_virtual_wave)
   bool stab_ill = false;
-  StabStats sstats = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // (timed build only)
+  StabStats sstats = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // (timed build only)
   bool unknown = false;  // the last call left this lane's candidate undecided (a capacity of its own was exceeded)
   auto feasible = [&](bool live, const double t[6]) __attribute__((always_inline)) -> bool {
     unknown = false;
@@ -951,6 +951,9 @@ __device__ __forceinline__ bool cleaf_nodes(const ContinuousParams& p, int e, CL
     tm.add(ST_STAB_LSQ5, (uint64_t)wave_sum_i64(sstats.lsq5));
     tm.add(ST_STAB_LSQX, (uint64_t)wave_sum_i64(sstats.lsqx));
     tm.add(ST_STAB_LSQ_ROUNDS, (uint64_t)__builtin_amdgcn_readfirstlane(sstats.lsq_rounds));
+    tm.add(ST_STAB_LSQ_ROUNDS_L0, (uint64_t)__builtin_amdgcn_readfirstlane(sstats.lsq_rounds_l0));
+    tm.add(ST_STAB_VROUNDS, (uint64_t)__builtin_amdgcn_readfirstlane(sstats.v_rounds));
+    tm.add(ST_STAB_VCALLS, (uint64_t)__builtin_amdgcn_readfirstlane(sstats.v_calls));
   }
   __syncthreads();
   tm.tick(PH_FEAS);
@@ -1192,7 +1195,7 @@ __device__ __forceinline__ int ctransition(const ContinuousParams& p, int e, CLd
     bool ill = false;
     const double den = MT ? (p.setting == 3 ? r.den_cur : 1.0) : next_density(p, e, r.oc - 1, r.traj, r.cursor - 1);
     // lane 0 walks; a split over six and more supporters is solved by the whole wave (pct_stab.cuh stab_commit_wave)
-    StabStats cstats = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // (timed build only)
+    StabStats cstats = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // (timed build only)
     const int rc = stab_commit_wave<true>(geo, l.st, bi, den, l.sw, lane, ill, TM::on ? &cstats : nullptr);
     if (TM::on) {
       tm.add(ST_STAB_COMMIT_VISITS, (uint64_t)__builtin_amdgcn_readfirstlane(cstats.commit_visits));
@@ -1201,6 +1204,7 @@ __device__ __forceinline__ int ctransition(const ContinuousParams& p, int e, CLd
       tm.add(ST_STAB_LSQ5, (uint64_t)__builtin_amdgcn_readfirstlane(cstats.lsq5));
       tm.add(ST_STAB_LSQX, (uint64_t)__builtin_amdgcn_readfirstlane(cstats.lsqx));
       tm.add(ST_STAB_LSQ_ROUNDS, (uint64_t)__builtin_amdgcn_readfirstlane(cstats.lsq_rounds));
+      tm.add(ST_STAB_COMMIT_ROUNDS, (uint64_t)__builtin_amdgcn_readfirstlane(cstats.lsq_rounds));
     }
     l.st.n_ent = __builtin_amdgcn_readfirstlane(l.st.n_ent);
     l.st.n_poly = __builtin_amdgcn_readfirstlane(l.st.n_poly);

@@ -1425,7 +1425,7 @@ __device__ __forceinline__ void leaf_nodes(const DiscreteParams& p, int e, Lds<K
   // feasibility of the candidate every lane holds (EMPTY: none).  All 64 lanes call: the stability check of the lanes
   // that need one is a wave-cooperative task walk (pct_stab.cuh stab_virtual_wave).
   bool stab_ill = false;
-  StabStats sstats = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // (timed build only)
+  StabStats sstats = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // (timed build only)
   bool unknown = false;  // the last call left this lane's candidate undecided (a capacity of its own was exceeded)
   auto feasible = [&](K k) __attribute__((always_inline)) -> bool {
     unknown = false;
@@ -1574,6 +1574,9 @@ __device__ __forceinline__ void leaf_nodes(const DiscreteParams& p, int e, Lds<K
     tm.add(ST_STAB_LSQ5, (uint64_t)wave_sum_i64(sstats.lsq5));
     tm.add(ST_STAB_LSQX, (uint64_t)wave_sum_i64(sstats.lsqx));
     tm.add(ST_STAB_LSQ_ROUNDS, (uint64_t)__builtin_amdgcn_readfirstlane(sstats.lsq_rounds));
+    tm.add(ST_STAB_LSQ_ROUNDS_L0, (uint64_t)__builtin_amdgcn_readfirstlane(sstats.lsq_rounds_l0));
+    tm.add(ST_STAB_VROUNDS, (uint64_t)__builtin_amdgcn_readfirstlane(sstats.v_rounds));
+    tm.add(ST_STAB_VCALLS, (uint64_t)__builtin_amdgcn_readfirstlane(sstats.v_calls));
   }
   __syncthreads();
   tm.tick(PH_FEAS);
@@ -2198,7 +2201,7 @@ __device__ __forceinline__ bool transition(const DiscreteParams& p, int e, Lds<K
     // a box on the floor is recorded and accepted without a walk)
     if (lane == 0) l.box[r.n_boxes] = P::pack(lx, ly, max_h, lx + x, ly + y, max_h + z);
     __syncthreads();
-    StabStats cstats = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // (timed build only)
+    StabStats cstats = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // (timed build only)
     BoxGeo<K, BITS> geo{l.box};
     bool ill = false;
     // lane 0 walks; a split over six and more supporters is solved by the whole wave (pct_stab.cuh stab_commit_wave)
@@ -2215,6 +2218,7 @@ __device__ __forceinline__ bool transition(const DiscreteParams& p, int e, Lds<K
       tm.add(ST_STAB_LSQ5, (uint64_t)__builtin_amdgcn_readfirstlane(cstats.lsq5));
       tm.add(ST_STAB_LSQX, (uint64_t)__builtin_amdgcn_readfirstlane(cstats.lsqx));
       tm.add(ST_STAB_LSQ_ROUNDS, (uint64_t)__builtin_amdgcn_readfirstlane(cstats.lsq_rounds));
+      tm.add(ST_STAB_COMMIT_ROUNDS, (uint64_t)__builtin_amdgcn_readfirstlane(cstats.lsq_rounds));
     }
     __syncthreads();
   }
@@ -2533,8 +2537,13 @@ inline hipError_t launch_typed(const DiscreteParams& p, int act, const void* act
 #ifdef PCT_FEW_KERNELS
   // kernel experiments (scripts/build_variant.py): only the untimed LNES = EMS kernels without shuffle -- a stability translation unit
   // then compiles in a minute instead of five; everything else is refused
+#ifdef PCT_FEW_TIMED
+  if (p.shuffle || scheme == 1 || act == ACT_HEUR || act == ACT_INDEX) return hipErrorNotSupported;
+#define PCT_KERN(A, T, S, C) pct_discrete_kernel<K, BITS, A, T, S, 0, R_PLAIN>
+#else
   if (p.shuffle || scheme == 1 || timed || act == ACT_HEUR || act == ACT_INDEX) return hipErrorNotSupported;
 #define PCT_KERN(A, T, S, C) pct_discrete_kernel<K, BITS, A, false, S, 0, R_PLAIN>
+#endif
 #else
 #define PCT_KERN(A, T, S, C) (p.shuffle ? pct_discrete_kernel<K, BITS, A, false, S, C, R_SHUF> : pct_discrete_kernel<K, BITS, A, (MTSEL ? false : T), S, C, R_PLAIN>)
 #endif

@@ -764,7 +764,7 @@ __device__ __forceinline__ uint32_t table_region(uint32_t cap, uint32_t size) {
   return (lv & 1) ? cap : 0u;
 }
 
-#define PCT_TIMING_SLOTS 40
+#define PCT_TIMING_SLOTS 44
 // optional per-phase cycle accounting (pct_debug_phase_timing): s_memtime deltas per env.
 // The untimed specialisation is empty, so production kernels carry no extra registers.
 template <bool ON>
@@ -819,7 +819,8 @@ enum { PH_LOAD = 0, PH_DROP = 1, PH_GENEMS = 2, PH_SET = 3, PH_FEAS = 4, PH_OBS 
        // stability build also fills -- ADVICE r4): commit walk visits, virtual-check passes / tasks / single-task passes / level-0
        // candidates, least-squares splits by supporter count
        ST_STAB_COMMIT_VISITS = 30, ST_STAB_VPASSES = 31, ST_STAB_VTASKS = 32, ST_STAB_VNARROW = 33, ST_STAB_LSQ3 = 34,
-       ST_STAB_LSQ4 = 35, ST_STAB_LSQ5 = 36, ST_STAB_LSQX = 37, ST_STAB_LEVEL0 = 38, ST_STAB_LSQ_ROUNDS = 39 };
+       ST_STAB_LSQ4 = 35, ST_STAB_LSQ5 = 36, ST_STAB_LSQX = 37, ST_STAB_LEVEL0 = 38, ST_STAB_LSQ_ROUNDS = 39,
+       ST_STAB_LSQ_ROUNDS_L0 = 40, ST_STAB_COMMIT_ROUNDS = 41, ST_STAB_VROUNDS = 42, ST_STAB_VCALLS = 43 };
 
 
 }  // namespace pct

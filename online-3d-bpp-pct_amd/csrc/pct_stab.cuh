@@ -451,6 +451,8 @@ struct StabStats {
   int v_level0;                       // candidates that went through a level-0 task
   int lsq3, lsq4, lsq5, lsqx;         // least-squares splits by supporter count (x: the generic 6..STAB_LSQ solve)
   int lsq_rounds;                     // calls of the wave's solve (stab_lsq_wave / stab_gelsd_slots): each is one solve's latency for the wave
+  int lsq_rounds_l0;                  // ... of them in the first pass of a round (the candidates' own splits)
+  int v_rounds, v_calls;              // level-0 rounds (class x workspace capacity), calls of stab_virtual_wave (batches of 64 candidates)
 };
 
 // How a box with stack `stk` splits over its k supporters (D/space.py:88-160 / :182-256).
@@ -1061,6 +1063,7 @@ __device__ __forceinline__ bool stab_virtual_wave(const Geo& geo, const StabStat
     }
   }
   if (!__ballot(need && k > 0)) return true;
+  if (ss && lane == 0) ss->v_calls++;
   double cstk[4];
   stab_cand_stack(cand, density, cstk);
   lane_err = false;
@@ -1116,6 +1119,7 @@ __device__ __forceinline__ bool stab_virtual_wave(const Geo& geo, const StabStat
       for (int c = 0; c < 9; c++) bg[c] = cand[c];
       stk[0] = cstk[0]; stk[1] = cstk[1]; stk[2] = cstk[2]; stk[3] = cstk[3];
     }
+    if (ss && lane == 0) ss->v_rounds++;
     bool hull_idle = false;  // (the first pass of a round examines the candidates themselves: their supporter ids are in the hull workspace)
     while (true) {
       {
@@ -1145,7 +1149,7 @@ __device__ __forceinline__ bool stab_virtual_wave(const Geo& geo, const StabStat
           __syncthreads();
           if (sel) stab_lsq_inputs<CONT>(geo, bg, kk, sup, stk, w.lsq + (size_t)rk * sd);
           __syncthreads();
-          if (ss && lane == 0) ss->lsq_rounds++;
+          if (ss && lane == 0) { ss->lsq_rounds++; ss->lsq_rounds_l0 += hull_idle ? 0 : 1; }
           const bool gill = w.gelsd ? stab_gelsd_slots(w.lsq, G, cn, nslot, lane, w.gelsd_avx2) : stab_lsq_wave(w.lsq, G, cn, nslot, lane);
           // a system's notice comes back in its group's lanes: fetch the one of this lane's slot
           const uint64_t illm = __ballot(gill);

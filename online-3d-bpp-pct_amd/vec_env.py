@@ -499,10 +499,10 @@ class PctVecEnv(VecEnv):
         return n.value, ms.value
 
     def phase_timing(self, on=True):
-        """Start/stop per-phase cycle accounting; returns the uint64 [N,40] gathered so far
+        """Start/stop per-phase cycle accounting; returns the uint64 [N,44] gathered so far
         (columns: load, drop, genems, set, feas, obs, store, steps, set-gen, set-dedup, set-match, set-rebuild, set statistics
-        12..29, stability counters 30..38: csrc/pct_set.cuh)."""
-        out = np.zeros((self.N, 40), np.uint64)  # PCT_TIMING_SLOTS
+        12..29, stability counters 30..43: csrc/pct_set.cuh)."""
+        out = np.zeros((self.N, 44), np.uint64)  # PCT_TIMING_SLOTS
         _lib.check(self._L.pct_debug_phase_timing(self._h, int(bool(on)), out.ctypes.data))
         return out
 

@@ -47,7 +47,7 @@ keymean = np.zeros(K)
 emsat = np.zeros(K, np.int64)
 boxes = np.zeros(K, np.int64)
 retry = np.zeros(K, np.int64)
-phase = np.zeros((K, 40))
+phase = np.zeros((K, 44))
 for s in range(K):
     env.step_rows_device(rows)
     n, ms = env.profile_read()

@@ -30,7 +30,7 @@ for _ in range(200):
     env.policy_hash_rows(rows); env.step_rows_device(rows)
 torch.cuda.synchronize()
 env.phase_timing(True)
-rec = np.zeros((K, N, 40))
+rec = np.zeros((K, N, 44))
 for s in range(K):
     env.policy_hash_rows(rows); env.step_rows_device(rows)
     rec[s] = env.phase_timing(True)
@@ -58,7 +58,7 @@ for i, n in extra.items():
     print("    %-34s %9.1f   (all-env mean %9.1f)" % (n, worst[:, i].mean(), rec[:, :, i].mean()))
 if MODE in ("c1", "c3s1"):  # the stability counters have slots of their own (30..38)
     for i, n in {30: "commit visits", 31: "virtual passes", 32: "virtual tasks", 33: "narrow passes", 34: "lsq k=3", 35: "lsq k=4", 36: "lsq k=5",
-                 37: "lsq k>5", 38: "level-0 candidates", 39: "solve rounds (one solve's latency each)"}.items():
+                 37: "lsq k>5", 38: "level-0 candidates", 39: "solve rounds (one solve's latency each)", 40: "  ... at level 0 (a round's candidates)", 41: "  ... in the commit walk", 42: "level-0 rounds", 43: "virtual-check calls (batches of 64)"}.items():
         print("    %-34s %9.2f   (all-env mean %9.2f)" % (n, worst[:, i].mean(), rec[:, :, i].mean()))
 # least squares: total ~ a + b*E + c*generated + d*distinct
 X = np.stack([np.ones(K * N), rec[:, :, 12].ravel(), rec[:, :, 14].ravel(), rec[:, :, 13].ravel()], 1)
