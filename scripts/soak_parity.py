@@ -1,12 +1,16 @@
 """GPU soak: HIP path vs the CPU oracle on millions of env-steps (fused stand-in policy, counter
 sampler), comparing observations every `check_every` steps and done/reward every step.
-python scripts/soak_parity.py [discrete_s2|discrete_s1|continuous_s2|continuous_s1|cp|fc] [envs] [steps]"""
+python scripts/soak_parity.py [discrete_s2|discrete_s1|continuous_s2|continuous_s1|cp|fc] [envs] [steps]
+PCT_LSTSQ=gelsd|gelsd_avx2|jacobi selects the stability settings' solver on BOTH sides (default: gelsd, the library's default)."""
 import importlib, os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pkg = importlib.import_module("online-3d-bpp-pct_amd")
 from oracle.oracle_lib import OracleVecEnv
+from oracle import oracle_lib
+LSTSQ = os.environ.get("PCT_LSTSQ", "gelsd")
+oracle_lib.set_lstsq_mode({"jacobi": oracle_lib.LSTSQ_JACOBI, "gelsd": oracle_lib.LSTSQ_GELSD, "gelsd_avx2": oracle_lib.LSTSQ_GELSD_AVX2}[LSTSQ])
 from tests.common import item_set_range
 
 which = sys.argv[1] if len(sys.argv) > 1 else "discrete_s2"
@@ -19,13 +23,13 @@ if which.startswith("continuous"):
     # setting 1 draws z from {0.1..0.5} (C/bin3D.py:110-112), which is meant for the unit bin (givenData.py:5)
     bin_, lo, hi = ((1, 1, 1), 0.1, 0.5) if setting == 1 else ((10, 10, 10), 1.0, 5.0)
     env = pkg.PctVecEnv(N, setting=setting, container_size=bin_, continuous=True, sample_left_bound=lo,
-                        sample_right_bound=hi, seed=17, device="cuda:0", strict=False)
+                        sample_right_bound=hi, seed=17, device="cuda:0", strict=False, lstsq=LSTSQ)
     ora = OracleVecEnv(N, setting=setting, container_size=bin_, env_kind=1, sample_bounds=(lo, hi), threads=threads)
 else:
     setting = 1 if which == "discrete_s1" else 2
     lnes = {"cp": ("CP", 3), "fc": ("FC", 4)}.get(which, ("EMS", 0))
     env = pkg.PctVecEnv(N, setting=setting, container_size=(10, 10, 10), item_set=items, seed=17, device="cuda:0",
-                        LNES=lnes[0], strict=False)
+                        LNES=lnes[0], strict=False, lstsq=LSTSQ)
     ora = OracleVecEnv(N, setting=setting, container_size=(10, 10, 10), item_set=items, lnes=lnes[1], threads=threads)
 ora.set_sampler(17)
 obs = env.reset(); ora.reset()
@@ -43,5 +47,5 @@ for t in range(steps):
         e = np.nonzero(done.astype(np.uint8) != ora.done)[0]
         print("DONE/REWARD MISMATCH step", t, "envs", e[:8], "flags", env.error_flags[e[:8]] if len(e) else None); bad = 1; break
 fl = env.error_flags
-print("%s: %d envs x %d steps = %d env-steps, %d episodes, mismatches=%d, gpu flags set on %d envs (%s), oracle flags %d, %.1fs" % (
+print("lstsq=" + LSTSQ + " %s: %d envs x %d steps = %d env-steps, %d episodes, mismatches=%d, gpu flags set on %d envs (%s), oracle flags %d, %.1fs" % (
     which, N, t + 1, N * (t + 1), eps, bad, int((fl != 0).sum()), np.unique(fl[fl != 0]).tolist(), int((ora.flags != 0).sum()), time.time() - t0))
