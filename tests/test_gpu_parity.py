@@ -193,11 +193,14 @@ def test_hip_policy_kernel_rows_path_equals_fused():
     b.close()
 
 
+@pytest.mark.parametrize("in_place", [False, True])
 @pytest.mark.parametrize("kind", ["discrete_s2", "discrete_s1", "continuous_s2", "continuous_big"])
-def test_hip_policy_epilogue_writes_the_policy_kernels_rows(kind):
+def test_hip_policy_epilogue_writes_the_policy_kernels_rows(kind, in_place):
     """pct_bind_policy_rows (round 4): the transition kernel's stand-in policy epilogue writes, after reset and after every
     step (auto-resets, heavy-first dispatch and the large-capacity retry pass included), byte for byte the rows the separate
-    policy kernel gathers from the observation -- and stepping on them is stepping with the fused stand-in policy."""
+    policy kernel gathers from the observation -- and stepping on them is stepping with the fused stand-in policy.  in_place: the
+    launch reads its actions from the very buffer its epilogue rewrites (what bench.py's default mode does; ADVICE r4: the `actions`
+    pointer is no longer `__restrict__`, every env reads its row before its own epilogue writes it)."""
     items = item_set_range(1, 5)
     N = 2048
     if kind == "discrete_s2":
@@ -220,7 +223,7 @@ def test_hip_policy_epilogue_writes_the_policy_kernels_rows(kind):
     for t in range(60):
         a.policy_hash_rows(check)
         assert torch.equal(rows, check), (kind, t, (rows != check).any(1).nonzero()[:4].ravel().tolist())
-        a.step_rows_device(rows.clone())  # (a copy: the launch rewrites `rows` while it reads its actions)
+        a.step_rows_device(rows if in_place else rows.clone())  # (the copy: actions and epilogue rows in different buffers)
         b.step_hash_policy(1)
     oa, ra, da, _ = a.step_wait()
     ob, rb, db, _ = b.step_wait()
