@@ -1761,8 +1761,9 @@ hipError_t PCT_CONT_LAUNCH(const ContinuousParams& p, int act, const void* actio
   if (grid <= 0) return hipSuccess;
 #ifdef PCT_FEW_KERNELS
   // kernel experiments (scripts/build_variant.py): only the untimed LDS-table kernels of the action kinds the benchmark uses
-  if (timed || (stab && p.table_global) || act == CACT_HEUR || act == CACT_INDEX) return hipErrorNotSupported;
-#define PCT_CKERN(A) (stab ? pct_continuous_kernel<A, false, false, true, PCT_CONT_MTV> : (p.table_global ? pct_continuous_kernel<A, false, true, false, PCT_CONT_MTV> : pct_continuous_kernel<A, false, false, false, PCT_CONT_MTV>))
+  if (timed || act == CACT_HEUR || act == CACT_INDEX) return hipErrorNotSupported;
+#define PCT_CKERN(A) (stab ? (p.table_global ? pct_continuous_kernel<A, false, true, true, PCT_CONT_MTV> : pct_continuous_kernel<A, false, false, true, PCT_CONT_MTV>) \
+                           : (p.table_global ? pct_continuous_kernel<A, false, true, false, PCT_CONT_MTV> : pct_continuous_kernel<A, false, false, false, PCT_CONT_MTV>))
 #endif
 #define PCT_CLAUNCH(A)                                                                                         \
   do {                                                                                                         \

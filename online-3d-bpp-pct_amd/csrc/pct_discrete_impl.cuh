@@ -1499,6 +1499,20 @@ __device__ __forceinline__ void leaf_nodes(const DiscreteParams& p, int e, Lds<K
   } else if (SHUFFLE) {
     // bin3D.py:114-115 np.random.shuffle(allPostion) -> pct_shuffle_priority: every candidate is
     // tested, the feasible ones are ranked by (priority, list index), the first L ranks are kept
+    if (STAB && size > 64) {  // (keys instead of slots, as in the plain sweep below: one call of the stability check per 64 candidates)
+      uint32_t cnt = 0;
+      for (uint32_t sb = 0; sb < size; sb += 64) {
+        K k = tabs[toff + sb + lane];
+        bool occ = k != SlotWord<K>::EMPTY;
+        uint64_t m = __ballot(occ);
+        if (occ) tabs[toff + cnt + rank_below(m)] = k;
+        cnt += (uint32_t)__popcll(m);
+      }
+      const uint32_t padded = (cnt + 63u) & ~63u;
+      if (cnt + lane < padded) tabs[toff + cnt + lane] = SlotWord<K>::EMPTY;
+      size = padded;
+      __syncthreads();
+    }
     int nlist = 0, nf = 0;
     for (uint32_t sb = 0; sb < size; sb += 64) {
       uint32_t s2 = sb + lane;
@@ -1531,10 +1545,13 @@ __device__ __forceinline__ void leaf_nodes(const DiscreteParams& p, int e, Lds<K
     }
     nleaf = nf;
   } else {
-    if (size >= 512) {
+    if (size >= 512 || (STAB && size > 64)) {
       // a big table is at most 60 % full (usually far less): squeeze the keys to the front, in slot
       // order, so that the feasibility sweep below walks keys instead of slots (the table is not
-      // needed as a table any more; a chunk is read whole before it is written, leftwards)
+      // needed as a table any more; a chunk is read whole before it is written, leftwards).
+      // Stability settings (round 5): from 128 slots on -- the ~40 candidates of a 128-slot table then make ONE call of the
+      // wave-cooperative check instead of two half-empty ones, and every call is a chain of level-0 rounds, walk passes and
+      // solve rounds (the slowest env of a c1 launch: 1.98 calls, 3.6 level-0 rounds, 4.7 solve rounds per step before)
       uint32_t cnt = 0;
       for (uint32_t sb = 0; sb < size; sb += 64) {
         K k = tabs[toff + sb + lane];

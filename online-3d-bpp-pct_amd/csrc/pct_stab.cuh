@@ -969,12 +969,12 @@ __device__ __forceinline__ void stab_lsq_inputs(const Geo& geo, const double bg[
 // gelsd mode: the systems of slots 0 .. nslot - 1 (laid out for class n: stab_lsq_slot_doubles(n, true) doubles each, the header
 // as stab_lsq_wave reads it), each solved by a GROUP of G lanes -- lanes s * G .. s * G + G - 1 take slot s -- with pct_gelsd.cuh on
 // the slot's own workspace (round 4: one lane per system).  All 64 lanes call; returns the system's notice in its group's lanes.
-__device__ __forceinline__ bool stab_gelsd_slots(double* ws, int G, int n, int nslot, int lane, bool avx2) {
-  const size_t sd = stab_lsq_slot_doubles(n, true);
-  const int slot = lane / G;
+// (gslot: the slot of this lane's group -- contiguous slots of the workspace, or the hull-workspace slices of the level-0 candidates
+// themselves, PCT_STAB_OWN_SLICE; gact: the group has a system)
+__device__ __forceinline__ bool stab_gelsd_slots(double* gslot, bool gact, int G, int n, int lane, bool avx2) {
   bool ill = false;
-  if (slot < nslot) {
-    double* w = ws + (size_t)slot * sd;
+  if (gact) {
+    double* w = gslot;
     const int k = (int)w[0];
     const gelsd::Grp g = {lane & (G - 1), G};
     if (k >= 3) gelsd::split_t(g, w + 4 + 3 * n, k, w + 4, w[1], w[2], StabDot2{avx2}, w + 4 + 2 * n, ill, avx2);
@@ -1071,39 +1071,61 @@ __device__ __forceinline__ bool stab_virtual_wave(const Geo& geo, const StabStat
   __syncthreads();
   bool pending = need && k > 0;
   const int mycls = stab_class(k);
+#ifndef PCT_STAB_INTERLEAVE
+#define PCT_STAB_INTERLEAVE 1 /* round 5, discrete env: the level-0 rounds of a call run back to back as far as the queue has room, and
+                                 their subtrees are drained TOGETHER -- walk tasks of different rounds share passes (each pass is a latency
+                                 chain, each solve round a solve's latency): c1 +2.8 %.  0 (and always in the continuous env, whose
+                                 candidates rest on more supporters: the fuller queue sends the wave into its one-task-per-pass descent,
+                                 c3s1 -15 %): every round drains its own subtree before the next one starts */
+#endif
+  constexpr bool kInterleave = PCT_STAB_INTERLEAVE && !CONT;
   while (true) {
     const uint64_t pm = __ballot(pending);
-    if (!pm) break;
-    const int first = __ffsll((unsigned long long)pm) - 1;
-    const int kc = __builtin_amdgcn_readlane(mycls, first);
-    const int per = kc <= STAB_NSUP_MAX ? stab_ws_need(kc) : 0x7FFFFFFF;
-    const int fit = w.hull_bytes / per;
-    const bool member = pending && mycls == kc;
-    const uint64_t mm = __ballot(member);
-    const int rk = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
-    bool act = member && rk < fit;
-    if (fit == 0) {  // this class does not fit the workspace at all (wave-uniform)
-      if (member) atomicOr(&w.ctl[4 + (lane >> 5)], 1u << (lane & 31));
-      pending = pending && !member;
-      continue;
-    }
-    {
-      // ... and only as many candidates as the (empty) queue takes children of: the first ones whose supporter counts
-      // add up to its capacity
-      const int cum = stab_wave_incl_sum(act ? k : 0, lane);
-      act = act && (cum <= w.qcap - stab_queue_reserve(w.qcap) || (lane == first && k <= w.qcap));
-      if (!__ballot(act)) {  // a single candidate's children do not fit
-        if (lane == first) atomicOr(&w.ctl[3], STAB_WHY_QUEUE);
+    // tasks earlier rounds have left in the queue (wave-uniform; 0 when every round drains its own)
+    const int qn0 = kInterleave ? (int)(w.ctl[0] < (uint32_t)w.qcap ? w.ctl[0] : (uint32_t)w.qcap) : 0;
+    if (!pm && qn0 == 0) break;
+    int kc = 2, per = 1, rk = 0;
+    bool act = false;
+    if (pm) {
+      const int first = __ffsll((unsigned long long)pm) - 1;
+      kc = __builtin_amdgcn_readlane(mycls, first);
+      per = kc <= STAB_NSUP_MAX ? stab_ws_need(kc) : 0x7FFFFFFF;
+      const int fit = w.hull_bytes / per;
+      const bool member = pending && mycls == kc;
+      const uint64_t mm = __ballot(member);
+      rk = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+      act = member && rk < fit;
+      if (fit == 0) {  // this class does not fit the workspace at all (wave-uniform)
+        if (member) atomicOr(&w.ctl[4 + (lane >> 5)], 1u << (lane & 31));
         pending = pending && !member;
         continue;
       }
+      // ... and only as many candidates as the queue takes children of: the first ones whose supporter counts add up to the room it
+      // has left (all of it up to the reserve when it is empty)
+      const int cum = stab_wave_incl_sum(act ? k : 0, lane);
+      act = act && (qn0 + cum <= w.qcap - stab_queue_reserve(w.qcap) || (qn0 == 0 && lane == first && k <= w.qcap));
+      if (!__ballot(act)) {
+        if (qn0 == 0) {  // a single candidate's children do not fit an empty queue
+          if (lane == first) atomicOr(&w.ctl[3], STAB_WHY_QUEUE);
+          pending = pending && !member;
+          continue;
+        }
+        // (no room beside what the earlier rounds have queued: this pass only pops; the round starts once the queue has drained)
+      }
+      pending = pending && !act;
     }
-    pending = pending && !act;
     // what the lane examines in this pass: a candidate (level 0) or, further down, a popped task
     bool have = false;
     double bg[9], stk[4] = {0, 0, 0, 0};
     int kk = 0, skip = (int)STAB_NOBOX, cl = lane;
     const uint32_t* supw = w.qmeta;
+#ifndef PCT_STAB_OWN_SLICE
+#define PCT_STAB_OWN_SLICE 1
+#endif
+    // the candidate's own slice of the hull workspace: once its hull has been tested only the supporter ids at the slice's end are
+    // still read, and the front takes the candidate's least-squares system (gelsd mode, up to four supporters: below)
+    double* const lvl0_slice = reinterpret_cast<double*>(w.hull + (size_t)(act ? rk : 0) * (act ? per : 0));
+    const bool slice_takes_system = PCT_STAB_OWN_SLICE && (size_t)kc * 128 + 16 >= sizeof(double) * stab_lsq_slot_doubles(4, true);  // (ids begin at 128 kc + 16)
     if (act) {
       StabWsView v = stab_ws_view(w.hull + (size_t)rk * per, kc);
       if (kc == 2) { v.ids[0] = id0; v.ids[1] = id1; }
@@ -1120,7 +1142,9 @@ __device__ __forceinline__ bool stab_virtual_wave(const Geo& geo, const StabStat
       stk[0] = cstk[0]; stk[1] = cstk[1]; stk[2] = cstk[2]; stk[3] = cstk[3];
     }
     if (ss && lane == 0) ss->v_rounds++;
-    bool hull_idle = false;  // (the first pass of a round examines the candidates themselves: their supporter ids are in the hull workspace)
+    // (the first pass of a round examines the candidates themselves: their supporter ids are in the hull workspace; a pass that only
+    // pops -- the last candidates have had their round, or the queue has no room for the next one yet -- leaves it idle)
+    bool hull_idle = !__ballot(act);
     while (true) {
       {
         // how the box under examination splits its stack over its supporters; a split over six and more goes to the wave
@@ -1141,20 +1165,34 @@ __device__ __forceinline__ bool stab_virtual_wave(const Geo& geo, const StabStat
           const bool mine = ((cm >> lane) & 1ull) && stab_lsq_class_n(kk, w.lsq_n, w.gelsd) == cn;
           const uint64_t mm = __ballot(mine);
           const int rk = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+          // gelsd mode, the first pass of a round (the candidates themselves; the hull workspace is not idle, so the shared workspace
+          // holds 4 systems of the <= 4-supporter class): every such candidate solves in its own hull slice -- 16 systems per solve
+          // round instead of 4.  The slot addresses travel through the first words of the shared workspace.
+          const bool own = w.gelsd && !hull_idle && cn == 4 && slice_takes_system;  // (wave-uniform)
           // systems of this class the workspace holds (with the hull workspace behind it when that is idle), at most one per lane group
           int nslot = (w.lsq_doubles + (hull_idle ? w.hull_bytes / (int)sizeof(double) : 0)) / (int)sd;
+          if (own) nslot = 64;
           nslot = nslot < 64 / G ? nslot : 64 / G;
           const bool sel = mine && rk < nslot;
-          if (lane < nslot) w.lsq[(size_t)lane * sd] = 0.0;  // idle slots
+          double* const myslot = own ? lvl0_slice : w.lsq + (size_t)rk * sd;
+          if (!own && lane < nslot) w.lsq[(size_t)lane * sd] = 0.0;  // idle slots
           __syncthreads();
-          if (sel) stab_lsq_inputs<CONT>(geo, bg, kk, sup, stk, w.lsq + (size_t)rk * sd);
+          if (sel) stab_lsq_inputs<CONT>(geo, bg, kk, sup, stk, myslot);
+          if (own && sel) reinterpret_cast<uint32_t*>(w.lsq)[rk] = (uint32_t)(reinterpret_cast<unsigned char*>(myslot) - reinterpret_cast<unsigned char*>(w.lsq));
           __syncthreads();
           if (ss && lane == 0) { ss->lsq_rounds++; ss->lsq_rounds_l0 += hull_idle ? 0 : 1; }
-          const bool gill = w.gelsd ? stab_gelsd_slots(w.lsq, G, cn, nslot, lane, w.gelsd_avx2) : stab_lsq_wave(w.lsq, G, cn, nslot, lane);
+          const int grp = lane / G;
+          bool gact = grp < nslot;
+          double* gslot = w.lsq + (size_t)(gact ? grp : 0) * sd;
+          if (own) {
+            gact = grp < __popcll(__ballot(sel));
+            gslot = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(w.lsq) + (gact ? reinterpret_cast<const uint32_t*>(w.lsq)[grp] : 0u));
+          }
+          const bool gill = w.gelsd ? stab_gelsd_slots(gslot, gact, G, cn, lane, w.gelsd_avx2) : stab_lsq_wave(w.lsq, G, cn, nslot, lane);
           // a system's notice comes back in its group's lanes: fetch the one of this lane's slot
           const uint64_t illm = __ballot(gill);
           if (sel) {
-            const double* slot = w.lsq + (size_t)rk * sd;
+            const double* slot = myslot;
             if (kk <= 5) {  // (gelsd mode only: up to five fractions live in registers, as after the per-lane solves)
               sp.f[0] = slot[4 + 2 * cn]; sp.f[1] = slot[5 + 2 * cn]; sp.f[2] = slot[6 + 2 * cn];
               sp.f[3] = kk > 3 ? slot[7 + 2 * cn] : 0.0;
@@ -1189,6 +1227,15 @@ __device__ __forceinline__ bool stab_virtual_wave(const Geo& geo, const StabStat
       const uint32_t qraw = w.ctl[0];
       const int qn = (int)(qraw < (uint32_t)w.qcap ? qraw : (uint32_t)w.qcap);
       if (qn == 0 || w.ctl[3]) break;
+      if (kInterleave) {
+        // candidates that have not had their level-0 pass yet come first, as long as the first of them finds room for its children
+        // (the same test the admission above applies): their tasks then share the passes that follow with the ones queued already
+        const uint64_t pm2 = __ballot(pending);
+        if (pm2) {
+          const int k1 = __builtin_amdgcn_readlane(k, __ffsll((unsigned long long)pm2) - 1);
+          if (qn + k1 <= w.qcap - stab_queue_reserve(w.qcap)) break;
+        }
+      }
       const uint64_t failed = (((uint64_t)w.ctl[2] << 32) | w.ctl[1]) | (((uint64_t)w.ctl[5] << 32) | w.ctl[4]);
       // pop from the end: lane j looks at task qn - 1 - j.  As many tasks are taken as the queue can then hold the
       // children of (every task of box S pushes nsup(S)): the longest prefix of lanes with
@@ -1486,7 +1533,7 @@ __device__ __forceinline__ int stab_commit_wave(const Geo& geo, StabState& st, i
     const int G = stab_lsq_group(ks, w.gelsd), cn = stab_lsq_class_n(ks, w.lsq_n, w.gelsd);
     __syncthreads();
     if (ss && lane == 0) ss->lsq_rounds++;
-    const bool sill = w.gelsd ? stab_gelsd_slots(w.lsq, G, cn, 1, lane, w.gelsd_avx2) : stab_lsq_wave(w.lsq, G, cn, 1, lane);  // one system, in slot 0
+    const bool sill = w.gelsd ? stab_gelsd_slots(w.lsq, lane < G, G, cn, lane, w.gelsd_avx2) : stab_lsq_wave(w.lsq, G, cn, 1, lane);  // one system, in slot 0
     if (lane == 0) {
       if (ks <= 5) {  // (gelsd mode only)
         sp.f[0] = w.lsq[4 + 2 * cn]; sp.f[1] = w.lsq[5 + 2 * cn]; sp.f[2] = w.lsq[6 + 2 * cn];
