@@ -101,3 +101,57 @@ def test_fused_collect_matches_reference_fixture(name):
     assert o3.data_ptr() == env.current_obs().data_ptr() and o3.data_ptr() != keep.data_ptr()
     assert o3.shape == (N, (I + L + 1) * 9)
     env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("slot", [False, True])
+def test_step_outputs_async_equals_step_wait(slot):
+    """PctVecEnv.step_outputs_async (the host outputs of a step without a stream synchronisation, consumed one step late; bench.py
+    --mode host_overlap) returns, ticket by ticket, what step_wait returns for the same steps of a twin env -- with the handle's own
+    buffers and with a rollout slot bound (the reward then lives in the slot)."""
+    pkg = importlib.import_module("online-3d-bpp-pct_amd")
+    N, T = 512, 40
+    items = item_set_range(1, 5)
+    a = pkg.PctVecEnv(N, item_set=items, seed=23, device="cuda:0")
+    b = pkg.PctVecEnv(N, item_set=items, seed=23, device="cuda:0")
+    a.reset()
+    b.reset()
+    rows = torch.empty(N, 9, dtype=torch.float32, device="cuda:0")
+    slots = rollout.RolloutSlots(5, N, (a.row_len,), 1.0, "cuda:0") if slot else None
+    if slot:
+        slots.begin(a)
+    pending, got, want = None, [], []
+    for t in range(T):
+        b.policy_hash_rows(rows)
+        b.step_rows_device(rows)
+        _, rb, db, ib = b.step_wait()
+        want.append((rb.clone(), db.copy(), [ib[i]["counter"] for i in (0, N - 1)]))
+        if slot:
+            ob = slots.obs[slots.step].view(N, -1, 9)
+            a.policy_hash_rows(rows)  # (the stand-in policy reads the env's current observation: the slot just written)
+            idx = None
+        else:
+            a.policy_hash_rows(rows)
+        if slot:
+            # the same leaf rows, as an index step into the bound slot: recover the index the rows stand for
+            leaf = ob[:, a.I:a.I + a.Lh, :]
+            idx = (leaf == rows[:, None, :]).all(2).float().argmax(1).to(torch.int64)
+            slots.step_env(a, idx)
+            if slots.step == 0:
+                slots.after_update()  # storage.py:41-43: slot 0 <- the last observation, once per T steps
+        else:
+            a.step_rows_device(rows)
+        nxt = a.step_outputs_async()
+        if pending is not None:
+            got.append(pending.wait())
+        pending = nxt
+    got.append(pending.wait())
+    assert len(got) == T
+    for t, ((ra, da, ia), (rb, db, cb)) in enumerate(zip(got, want)):
+        assert torch.equal(ra, rb) and np.array_equal(da, db), t
+        assert [ia[i]["counter"] for i in (0, N - 1)] == cb, t
+    assert not a.error_flags.any()
+    if slot:
+        a.unbind_rollout_slot()
+    a.close()
+    b.close()
