@@ -417,7 +417,10 @@ def main():
     act = 2 if args.mode == "fused" else 0
     stab = "true" if w["setting"] != 2 else "false"
     if w["cont"]:
-        gt = "true" if max(w["container"]) > 12 else "false"  # candidate table in HBM (pct_create: bins beyond 12 units)
+        # candidate table in HBM: beyond 8192 slots (pct_create: an explicit capacity, or the default of bins beyond 12 units under the
+        # stability settings; setting 2 defaults to an 8192-slot LDS table there since round 5)
+        cc = args.candidate_capacity or ((8192 if w["setting"] == 2 else 32768) if max(w["container"]) > 12 else 2048)
+        gt = "true" if cc > 8192 else "false"
         kernel_name = ("void pct::pct_continuous_kernel<%d, false, %s, %s, false>(pct::ContinuousParams, void const*, int, int, "
                        "int const*, int)" % (act, gt, stab))
     else:
