@@ -1074,9 +1074,9 @@ __device__ __forceinline__ bool stab_virtual_wave(const Geo& geo, const StabStat
 #ifndef PCT_STAB_INTERLEAVE
 #define PCT_STAB_INTERLEAVE 1 /* round 5, discrete env: the level-0 rounds of a call run back to back as far as the queue has room, and
                                  their subtrees are drained TOGETHER -- walk tasks of different rounds share passes (each pass is a latency
-                                 chain, each solve round a solve's latency): c1 +2.8 %.  0 (and always in the continuous env, whose
-                                 candidates rest on more supporters: the fuller queue sends the wave into its one-task-per-pass descent,
-                                 c3s1 -15 %): every round drains its own subtree before the next one starts */
+                                 chain, each solve round a solve's latency): c1 +2.8 %.  0 (and always in the continuous env: c3s1 -15 %
+                                 with it, also when capped to a half / a third of the queue's room -- profiles/r05_experiments.txt
+                                 item 9): every round drains its own subtree before the next one starts */
 #endif
   constexpr bool kInterleave = PCT_STAB_INTERLEAVE && !CONT;
   while (true) {
