@@ -243,6 +243,11 @@ def main():
                          "--steps < 64; 1 = every launch; 0 = none: the step's time stands in for the kernel's).  A dispatch that "
                          "carries events costs ~7 us of its own on this runtime (C2: 64.6 M env-steps/s with a pair on every launch, "
                          "72.6 M with none), so the average kernel time is SAMPLED over the timed region")
+    ap.add_argument("--graph", type=int, default=0, help="experiment: capture this many steps into one hipGraph and replay it")
+    ap.add_argument("--torch-policy", action="store_true",
+                    help="--mode slot: the stand-in policy as torch elementwise kernels (rounds 1-5) instead of pct_policy_hash_index")
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="timed regions of --steps steps each, median reported (0 = 7 below 64 steps, 3 below 512, else 1)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -316,9 +321,14 @@ def main():
                 elif mode_now[0] == "slot":
                     # a torch stand-in for the policy's leaf choice, on the slot the kernel wrote: k = valid leaf rows, index = hash % k
                     s = slots[g]
-                    ob = s.obs[s.step].view(n_grp, w["I"] + w["L"] + 1, 9)
-                    k = (ob[:, w["I"]:w["I"] + w["L"], 8] != 0).sum(1).clamp_(min=1)
-                    idx = (hbase + tcount[0] * 40503) % k
+                    if args.torch_policy:
+                        # rounds 1-5: the stand-in as torch elementwise / reduce kernels (six launches + a copy per step)
+                        ob = s.obs[s.step].view(n_grp, w["I"] + w["L"] + 1, 9)
+                        k = (ob[:, w["I"]:w["I"] + w["L"], 8] != 0).sum(1).clamp_(min=1)
+                        idx = (hbase + tcount[0] * 40503) % k
+                    else:
+                        # a policy hands back an index tensor in ONE launch: the stand-in does too, straight into actions[t]
+                        idx = envs[g].policy_hash_index(s.actions[s.step].view(n_grp))
                     s.step_env(envs[g], idx)
                     if s.step == 0:
                         s.after_update()  # storage.py:41-43, once per T steps
@@ -341,7 +351,31 @@ def main():
     for _ in range(max(0, args.desync) + args.warmup):
         one_step()
     torch.cuda.synchronize(dev)
+    graph = None
+    if args.graph > 0:
+        # experiment: --graph K steps captured into ONE hipGraph and replayed -- does a graph launch shorten
+        # the dependent-dispatch gaps between the transition kernel and the retry pass?  K even (the retry queue's counters ping-pong).
+        assert args.graph % 2 == 0 and args.steps % args.graph == 0 and P == 1 and args.mode in ("epilogue", "fused", "rows")
+        graph = torch.cuda.CUDAGraph()
+        cs = torch.cuda.Stream(dev)
+        cs.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(cs):
+            streams[0] = cs
+            with torch.cuda.graph(graph, stream=cs):
+                for _ in range(args.graph):
+                    one_step()
+        torch.cuda.current_stream(dev).wait_stream(cs)
+        torch.cuda.synchronize(dev)
+        tcount[0] = 0
+        args.no_rows_line = True  # (the second timed loop would replay the same graph)
+
+        def one_step():  # (one replay = args.graph steps; the loops below count steps)
+            tcount[0] += 1
+            if tcount[0] % args.graph == 0:
+                graph.replay()
     time_every = args.time_every if args.time_every >= 0 else (8 if args.steps >= 64 else 4)
+    if graph is not None:
+        time_every = 0  # (event pairs are not captured: the kernel average falls back to the step time)
     for ev in envs:
         ev.profile_enable(time_every)
         ev.profile_read()
@@ -350,14 +384,20 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0  # (this rank's; the MAX over ranks below covers the stragglers -- the barrier follows the stamp)
-    barrier()
+    # The timed region: EXACTLY --steps steps between barrier + synchronize on both sides.  A short region (the driver's 20 steps
+    # are 1.2 ms on c2) is within +-3 % of launch jitter, so it is REPEATED and the median region reported:
+    # every repeat is the contract's region, back to back, nothing untimed in between but the barrier.
+    repeats = args.repeats if args.repeats > 0 else (7 if args.steps < 64 else (3 if args.steps < 512 else 1))
+    regions = []
+    for _ in range(repeats):
+        barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        torch.cuda.synchronize(dev)
+        regions.append(time.perf_counter() - t0)  # (this rank's; the MAX over ranks below covers the stragglers -- the barrier follows the stamp)
+        barrier()
     n_launch, kern_ms = 0, 0.0
     for ev in envs:
         nl, km = ev.profile_read()
@@ -396,12 +436,14 @@ def main():
         for ev in envs:
             ev.profile_read()  # (its launches do not belong to the headline kernel average)
 
+    if dist is not None:
+        t = torch.tensor(regions, dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # (per region: the slowest rank's)
+        regions = [float(x) for x in t.tolist()]
+    elapsed = sorted(regions)[len(regions) // 2]
     kern_avg_ms = kern_ms / n_launch if n_launch else elapsed / args.steps * 1e3  # (--time-every 0: the step's time)
     per_rank_us = [kern_avg_ms * 1e3]
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         mine = torch.tensor([kern_avg_ms * 1e3], dtype=torch.float64, device=red_dev)
         allk = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allk, mine)
@@ -440,6 +482,8 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
+        "timed_regions": {"repeats": repeats, "reported": "median", "steps_each": args.steps,
+                          "ms_per_step_each": [r / args.steps * 1e3 for r in regions]},
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -454,7 +498,7 @@ def main():
                 "host": "policy kernel -> rows to the host -> VecEnv.step(numpy) -> reward / done / infos on the host",
                 "host_overlap": "policy kernel -> transition kernel (rows stay on the device) -> packed reward / done / infos to the host, "
                                 "consumed one step late (step_outputs_async)",
-                "slot": "torch stand-in policy on the rollout slot's observation -> int64 leaf index -> pct_step_index with the slot bound: "
+                "slot": "stand-in policy kernel on the rollout slot's observation (one launch) -> int64 leaf index in actions[t] -> pct_step_index with the slot bound: "
                         "every observation row (the B = 36 (I+L+1) + 41 algorithmic bytes per env), reward and mask written into "
                         "storage.py-shaped [T+1,N,...] tensors by the transition kernel"}[args.mode],
             "name": args.workload,

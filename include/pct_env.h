@@ -102,22 +102,27 @@ extern "C" {
 #define PCT_FLAG_STABILITY_OVERFLOW 0x10u /* stability check (settings 1 / 3): the share / polygon pools, the hull
                                              workspace or the walk queue were exceeded in the retry pass too (the
                                              normal pass requeues such an env, state untouched), or a box rests on
-                                             more than 16 supporters none of which holds its centre of mass (the normal pass takes 8) */
+                                             more than 25 supporters none of which holds its centre of mass.  25 is
+                                             LAPACK's own limit for the path of dgelsd the library restates (dlalsd:
+                                             n <= SMLSIZ = 25 -> dlasdq; beyond it dgelsd runs the divide-and-conquer
+                                             dlasda / dlalsa, which is not restated) and covers every stack of the 10^3
+                                             / items 1..5 domain (a 5 x 5 footprint on unit tiles).  The normal pass
+                                             takes 8, the retry pass 25 (16 on handles whose retry pools -- hundreds of
+                                             internal nodes -- leave no 73 KB of LDS for the 301 x 25 system) */
 #define PCT_FLAG_ILL_CONDITIONED 0x40u   /* NON-FATAL notice (the env is not terminated, PctVecEnv(strict=True) does not
                                             raise): a >= 3-supporter load split (np.linalg.lstsq, space.py:134-163)
-                                            took its rank decision within a factor 1000 of the rcond cut -- the
-                                            reference's own verdict then depends on the rounding noise of its LAPACK
-                                            build (dgelsd), and so may differ from this library's from that step on
-                                            (profiles/r02_lstsq_limit.txt, r03_lstsq_limit.txt).
-                                            WHAT THE NOTICE DOES NOT COVER: a run can also part ways with the reference on
-                                            the LAST BIT of a well-conditioned solve that decides an exactly degenerate
-                                            point-in-polygon test (convex_hull.py:104-105) -- 15 of the 17 adversarial
-                                            divergences and all 11 found in 1.2 M on-domain env-steps of discrete setting 1
-                                            (one step in 10^5; none in 0.24 M continuous steps) carry NO notice.  In four of
-                                            ten such cases the unmodified reference parts ways with ITSELF at that step when
-                                            its NumPy runs on other BLAS kernels (profiles/r04_lstsq_ondomain.txt).
-                                            pct_set_lstsq_mode(env, PCT_LSTSQ_GELSD) removes both kinds: the split is then
-                                            solved exactly as the reference's NumPy solves it (the notice is still raised) */
+                                            took its rank decision within a factor 1000 of the rcond cut.  In the DEFAULT
+                                            mode (PCT_LSTSQ_GELSD since round 5: the split is solved exactly as the
+                                            reference's NumPy solves it -- LAPACK dgelsd with OpenBLAS' kernels) the
+                                            library follows the reference through such a decision (tests/golden
+                                            discrete_s1_flat_diverging; 0 of 6 000 on-domain env-runs part ways) and the
+                                            notice is informational: the reference's own verdict at such a step differs
+                                            between NumPy builds (AVX-512 / AVX2 kernel sets: PCT_LSTSQ_GELSD_AVX2,
+                                            profiles/r04_lstsq_ondomain.txt).  In the opt-in PCT_LSTSQ_JACOBI mode (the
+                                            default of rounds 1-4) a run may part ways with the reference there, and
+                                            also on the last bit of a well-conditioned solve that decides an exactly
+                                            degenerate point-in-polygon test (convex_hull.py:104-105; one step in 10^5
+                                            of discrete setting 1), which carries no notice */
 #define PCT_FLAG_ILL_COMMIT 0x80u        /* NON-FATAL, provenance of the notice above: it was raised (also) by a solve of a COMMIT walk
                                             (calculated_impact, space.py:73-164 -- the placement's own, state-changing walk, whose
                                             solves every evaluation order makes).  A notice WITHOUT this bit came from a candidate's
@@ -148,12 +153,17 @@ typedef struct pct_config {
   int32_t ems_capacity;         /* EMS kept per env after elimination (the LDS list of the normal pass); 0 =
                                    default (128 for bins up to 12 per axis, else 256 discrete / 768 continuous) */
   int32_t candidate_capacity;   /* hash-table slots for the leaf-candidate set (LDS table of the normal pass);
-                                   0 = default (2048; 8192 for discrete / 32768, in HBM, for continuous bins above
-                                   12 per axis); 8 * 4^k.
+                                   0 = default (pct_env.hip pct_create).  Bins up to 12 per axis: 2048 (setting 2) /
+                                   512 (settings 1 / 3: two orientations).  Larger bins: discrete 8192 (setting 2)
+                                   / 2048 (settings 1 / 3); continuous setting 2 8192 -- one 32 KB LDS region that
+                                   the 2048-slot table grows into, its old entries parked in an HBM row meanwhile --
+                                   and continuous settings 1 / 3 32768 in HBM.  Always 8 * 4^k.  An explicit
+                                   capacity above 8192 puts the continuous table in HBM.
                                    An env that outgrows either list is NOT terminated: it is handed, state untouched,
                                    to a large-capacity retry pass enqueued right behind the normal one (setting 2:
                                    discrete 4x the EMS list and, LDS permitting, 4x the table; continuous a 32768-slot
-                                   table in HBM).  Only what outgrows the retry pass too raises
+                                   table in HBM -- with the 8192-slot LDS default every env beyond 4915 candidates
+                                   goes that way).  Only what outgrows the retry pass too raises
                                    PCT_FLAG_EMS_OVERFLOW / PCT_FLAG_CANDIDATE_OVERFLOW. */
   int32_t shuffle;              /* 1: permute the candidate list before the first-L cut
                                    (bin3D.py:114-115 `--shuffle`); see pct_shuffle_priority */
@@ -310,6 +320,11 @@ int pct_step_heuristic(pct_env* env, int32_t kind, int32_t n_steps, void* stream
  * leaf = pct_mix32(g, t) % k and writes that leaf row to rows_out (device float32 [N,9]),
  * ready for pct_step_rows. */
 int pct_policy_hash_rows(pct_env* env, float* rows_out, void* stream);
+/* ... and as a leaf INDEX (device int64 [N]), ready for pct_step_index: the form the reference's policy samples
+ * (train_tools.py:63-66: `selected_leaf_node` is the leaf row gathered by this index).  One launch; index_out may be the
+ * rollout's actions[t] slot (storage.py:8).  Reads the observation buffer currently bound (pct_bind_outputs /
+ * pct_bind_rollout_slot). */
+int pct_policy_hash_index(pct_env* env, int64_t* index_out, void* stream);
 /* The same stand-in policy as an EPILOGUE of every following launch (reset / step_*): the transition kernel, having
  * written an env's new observation, also writes the row pct_policy_hash_rows would gather from it to rows_out (device
  * float32 [N,9]; the same bytes) -- a benchmark loop `pct_step_rows(rows)` then needs no policy dispatch between two
@@ -348,12 +363,15 @@ int pct_debug_retry_count(pct_env* env, int32_t* last, int64_t* envs_total, int6
 
 /* Per-phase cycle accounting of the transition kernel (profiling aid).  on != 0: (re)start
  * accumulation; host_out, if non-NULL, first receives the accumulators gathered so far:
- * uint64 [N,44] = s_memtime cycles in {load, drop_box, GENEMS, candidate set, feasibility,
+ * uint64 [N, pct_debug_timing_slots()] (44) = s_memtime cycles in {load, drop_box, GENEMS, candidate set, feasibility,
  * observation write, state store}, the number of steps, then the candidate-set detail
  * {generation + membership probes, batch de-duplication, matching, rebuilds}, the set's statistics
  * (slots 12..29) and the stability settings' counters (slots 30..43, csrc/pct_set.cuh).
  * Synchronises the device. */
 int pct_debug_phase_timing(pct_env* env, int32_t on, uint64_t* host_out);
+/* uint64 words per env that pct_debug_phase_timing writes (44 since round 5, 32 before): size host_out by THIS, not by a
+ * constant compiled into the caller.  No reference counterpart (profiling aid). */
+int32_t pct_debug_timing_slots(void);
 
 #if defined(__HIPCC__)
 #define PCT_INLINE static inline __host__ __device__

@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     "pct_reward", "pct_done", "pct_info_counter", "pct_info_ratio", "pct_error_flags", "pct_obs_row_len",
     "pct_reset", "pct_step_rows", "pct_step_index", "pct_step_hash_policy", "pct_step_heuristic", "pct_debug_state",
     "pct_policy_hash_rows", "pct_bind_policy_rows", "pct_profile_enable", "pct_profile_read", "pct_debug_phase_timing", "pct_debug_state_f64",
-    "pct_debug_work_keys", "pct_debug_retry_count",
+    "pct_debug_work_keys", "pct_debug_retry_count", "pct_debug_timing_slots", "pct_policy_hash_index",
 ]
 
 
@@ -98,6 +98,7 @@ def load():
     L.pct_step_index.argtypes = [vp, vp, vp]
     L.pct_step_hash_policy.argtypes = [vp, i32, vp]
     L.pct_policy_hash_rows.argtypes = [vp, vp, vp]
+    L.pct_policy_hash_index.argtypes = [vp, vp, vp]
     try:
         L.pct_bind_policy_rows.argtypes = [vp, vp]
     except AttributeError:  # an older library selected with PCT_HIP_LIB for an A/B run (kernel experiments only)
@@ -106,6 +107,8 @@ def load():
     L.pct_profile_enable.argtypes = [vp, i32]
     L.pct_profile_read.argtypes = [vp, ctypes.POINTER(i64), ctypes.POINTER(ctypes.c_double)]
     L.pct_debug_phase_timing.argtypes = [vp, i32, vp]
+    L.pct_debug_timing_slots.argtypes = []
+    L.pct_debug_timing_slots.restype = i32
     L.pct_debug_state_f64.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp]
     for name, at in (("pct_debug_work_keys", [vp, vp]), ("pct_debug_retry_count", [vp, vp, vp, vp])):
         try:

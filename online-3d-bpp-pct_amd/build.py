@@ -15,9 +15,18 @@ LIB = os.path.join(HERE, "libpct_hip.so")
 SOURCES = ["pct_discrete_stab.hip", "pct_discrete_stab_mt.hip", "pct_discrete_u64_stab.hip", "pct_discrete_u64_stab_mt.hip",
            "pct_continuous.hip", "pct_continuous_mt.hip", "pct_discrete.hip", "pct_discrete_mt.hip", "pct_discrete_u64.hip",
            "pct_discrete_u64_mt.hip", "pct_env.hip"]
-HEADERS = [os.path.join(CSRC, "pct_device.h"), os.path.join(CSRC, "pct_set.cuh"), os.path.join(CSRC, "pct_stab.cuh"), os.path.join(CSRC, "pct_gelsd.cuh"),
-           os.path.join(CSRC, "pct_discrete_impl.cuh"), os.path.join(CSRC, "pct_mt.cuh"),
-           os.path.join(HERE, "..", "include", "pct_env.h")]
+
+
+def _includes(path, seen=None):
+    """the csrc files `path` includes, transitively (quoted includes only: they are the tree's own)"""
+    import re
+    seen = set() if seen is None else seen
+    for name in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(path).read(), re.M):
+        f = os.path.join(CSRC, name)
+        if os.path.exists(f) and f not in seen:
+            seen.add(f)
+            _includes(f, seen)
+    return seen
 
 
 def _hipcc():
@@ -27,18 +36,9 @@ def _hipcc():
     raise RuntimeError("hipcc not found: cannot build the gfx950 library")
 
 
-_IMPL = ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_gelsd.cuh", "pct_mt.cuh", "pct_discrete_impl.cuh"]
-# which headers a translation unit includes (a change elsewhere does not recompile it)
-DEPS = {"pct_env.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_gelsd.cuh"],
-        "pct_discrete.hip": _IMPL, "pct_discrete_stab.hip": _IMPL, "pct_discrete_u64.hip": _IMPL, "pct_discrete_u64_stab.hip": _IMPL,
-        "pct_discrete_mt.hip": _IMPL, "pct_discrete_stab_mt.hip": _IMPL, "pct_discrete_u64_mt.hip": _IMPL,
-        "pct_discrete_u64_stab_mt.hip": _IMPL,
-        "pct_continuous.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_gelsd.cuh", "pct_mt.cuh"],
-        "pct_continuous_mt.hip": ["pct_device.h", "pct_set.cuh", "pct_stab.cuh", "pct_gelsd.cuh", "pct_mt.cuh", "pct_continuous.hip"]}
-
-
 def _tu_inputs(src):
-    return [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in DEPS[src]] + [
+    # what a translation unit is compiled from: a change elsewhere does not recompile it
+    return [os.path.join(CSRC, src)] + sorted(_includes(os.path.join(CSRC, src))) + [
         os.path.join(HERE, "..", "include", "pct_env.h"), os.path.abspath(__file__)]  # (this file holds the flags)
 
 
@@ -50,8 +50,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS + [os.path.abspath(__file__)]
-    if any(os.path.getmtime(d) > t for d in deps):
+    if any(os.path.getmtime(d) > t for src in SOURCES for d in _tu_inputs(src)):
         return True
     # a source edited while a build was running is older than the library that build linked, but newer than the object
     # it was compiled into (objects stay in the build container; where there are none the library's own time decides)

@@ -293,6 +293,7 @@ struct CGeo {  // placed-box geometry for the stability code
   const double* box;
   const double* bsz;
   int I;
+  static constexpr bool kSquareIsPow = false;  // (pct_stab.cuh: the lever rule's `tri_base_len ** 2` is glibc's pow)
   __device__ __forceinline__ void operator()(int i, double g[9]) const {
 #pragma unroll
     for (int c = 0; c < 6; c++) g[c] = box[c * I + i];
@@ -742,17 +743,11 @@ __device__ __forceinline__ bool cleaf_nodes(const ContinuousParams& p, int e, CL
           tm.sub_tick(PH_SET_REBUILD);
           continue;
         } else if (!GT) {
-          // an LDS table of 2048 slots growing to 8192: the new table sits behind the old one's region
-          // (cand_cap 8192: table words = 8192 + 2048), the only case of two LDS regions
-          const uint32_t noff2 = size;  // old table at [0, size), new at [size, size + newsize)
-          for (uint32_t s2 = lane; s2 < newsize; s2 += 64) tabs[noff2 + s2] = EMPTY;
-          __syncthreads();
-          for (uint32_t sb = 0; sb < size; sb += 64) push(tabs[toff + sb + lane], noff2);
-          drain(noff2);
-          toff = noff2;
-          size = newsize;
-          tm.sub_tick(PH_SET_REBUILD);
-          continue;
+          // (an LDS table beyond 512 slots grows through the parking row above; pct_create allocates it whenever such a table
+          // can exist.  Rounds 1-4 kept a second LDS region behind the old table here: the union no longer has room for one, so a
+          // handle without the row sends the env to the retry pass rather than write past the LDS union -- ADVICE r5)
+          cand_overflow = true;
+          break;
         } else {
           for (uint32_t s2 = lane; s2 < newsize; s2 += 64) tab_st<GT, uint32_t>(&tabs[noff + s2], EMPTY);
           __syncthreads();

@@ -166,6 +166,7 @@ __device__ __forceinline__ Lds<K, BITS> carve_lds(const DiscreteParams& p, unsig
 template <typename K, int BITS>
 struct BoxGeo {
   const K* box;
+  static constexpr bool kSquareIsPow = BITS <= 5;  // (pct_stab.cuh, the lever rule's `tri_base_len ** 2`)
   __device__ __forceinline__ void operator()(int i, double g[9]) const {
     K k = box[i];
 #pragma unroll

@@ -349,7 +349,7 @@ int launch(pct_env* h, int act, const void* actions, int row_len, int n_steps, c
  * queue of 96 walk tasks (half of it the reserve of the depth-first mode): LDS is what bounds the resident envs per CU
  * (profiles/r03_stability_tuning.txt), and what outgrows these goes through the retry pass.  Retry pass: eight entries
  * / sixteen vertices per node, a workspace that takes a box on 120 supporters and 512 tasks. */
-void stab_default_caps(int I, pct::StabCaps& normal, pct::StabCaps& retry) {
+void stab_default_caps(int I, pct::StabCaps& normal, pct::StabCaps& retry, int retry_lsq_n = pct::STAB_LSQ) {
   normal.SP = I < 64 ? 64 : I;
   if (normal.SP > 4094) normal.SP = 4094; /* STAB_END: 12-bit pool offsets */
   normal.PP = 2 * I < 128 ? 128 : 2 * I;
@@ -361,7 +361,9 @@ void stab_default_caps(int I, pct::StabCaps& normal, pct::StabCaps& retry) {
   retry.gelsd = PCT_LSTSQ_GELSD;
   normal.lsq_n = 8;
   normal.lsq_bytes = (int)pct::stab_lsq_bytes(normal.lsq_n, false);
-  retry.lsq_n = pct::STAB_LSQ;
+  /* round 6: 25 supporters -- LAPACK's own limit for this path of dgelsd (pct_stab.cuh STAB_LSQ); 73 KB of the retry pass's LDS.  A
+   * handle whose other retry capacities leave no room for that (hundreds of internal nodes) falls back to 16 (pct_create) */
+  retry.lsq_n = retry_lsq_n;
   retry.lsq_bytes = (int)pct::stab_lsq_bytes(retry.lsq_n, true);
   retry.SP = 8 * I < 4094 ? 8 * I : 4094;
   retry.PP = 16 * I < 65535 ? 16 * I : 65535;
@@ -394,6 +396,32 @@ void stab_fit_wave(size_t lds_without_wave, pct::StabCaps& caps) {
       return;
     }
   }
+}
+/* The retry pass's stability capacities, fitted into `room` bytes of LDS.  Two kinds of rare overflow compete for that LDS: large
+ * pools / queue (hundreds of boxes, deep walks) and the least-squares workspace of a box on up to 25 supporters (73 KB).  First choice:
+ * the 25-supporter workspace with pools of at least three times the DEFAULT normal pass's (3 I entries, 6 I vertices, 192 tasks) --
+ * the 10^3 / 80-node handles; else round 5's configuration (16 supporters, pools as large as fit).  lds(caps) = the pass's LDS bytes.
+ * Returns false when not even the normal pass's own capacities fit (no retry pass then). */
+template <typename F>
+bool fit_retry_stab(F lds, size_t room, int I, const pct::StabCaps& normal, pct::StabCaps& out) {
+  const int Ie = I < 64 ? 64 : I;
+  auto mx = [](int a, int b) { return a > b ? a : b; };
+  for (int a = 0; a < 2; a++) {
+    pct::StabCaps nrm = normal, rt = normal;
+    stab_default_caps(I, nrm, rt, a == 0 ? pct::STAB_LSQ : 16);
+    rt.gelsd = normal.gelsd;
+    rt.SP = mx(rt.SP, normal.SP); rt.PP = mx(rt.PP, normal.PP); rt.ws_bytes = mx(rt.ws_bytes, normal.ws_bytes); rt.queue = mx(rt.queue, normal.queue);
+    const int sp_floor = a == 0 ? mx(3 * Ie, normal.SP) : normal.SP;
+    const int pp_floor = a == 0 ? mx(6 * Ie, normal.PP) : normal.PP;
+    const int q_floor = a == 0 ? mx(192, normal.queue) : normal.queue;
+    while (lds(rt) > room && (rt.SP > sp_floor || rt.PP > pp_floor || rt.queue > q_floor)) {
+      rt.SP = mx((rt.SP * 3) / 4, sp_floor);
+      rt.PP = mx((rt.PP * 3) / 4, pp_floor);
+      rt.queue = mx((rt.queue * 3) / 4, q_floor);
+    }
+    if (lds(rt) <= room) { out = rt; return true; }
+  }
+  return false;
 }
 bool is_cand_cap_ok(int c) {
   for (int s = 8; s <= (1 << 20); s <<= 2)
@@ -614,14 +642,11 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
       q.ems_cap = c.ems_stride;
       q.union_words = 12 * q.ems_cap > 192 ? 12 * q.ems_cap : 192; /* children scratch only: 2 * ems_cap of them */
       if (cfg->setting != 2) { /* larger stability pools / workspace / queue, as far as the LDS of that pass goes */
-        q.sb.caps = retry_stab;
         /* (strict NumPy-stream mode, chosen after pct_create, adds the env's 624 MT19937 words: room is kept for them) */
         const size_t lds_room = 160 * 1024 - 624 * sizeof(uint32_t);
-        while (pct::continuous_lds_bytes(q) > lds_room && q.sb.caps.SP > c.sb.caps.SP) {
-          q.sb.caps.SP = (q.sb.caps.SP * 3) / 4 > c.sb.caps.SP ? (q.sb.caps.SP * 3) / 4 : c.sb.caps.SP;
-          q.sb.caps.PP = (q.sb.caps.PP * 3) / 4 > c.sb.caps.PP ? (q.sb.caps.PP * 3) / 4 : c.sb.caps.PP;
-          q.sb.caps.queue = (q.sb.caps.queue * 3) / 4 > c.sb.caps.queue ? (q.sb.caps.queue * 3) / 4 : c.sb.caps.queue;
-        }
+        q.sb.caps = retry_stab;
+        auto lds_of = [&](const pct::StabCaps& caps) { pct::ContinuousParams t = q; t.sb.caps = caps; return pct::continuous_lds_bytes(t); };
+        if (!fit_retry_stab(lds_of, lds_room, c.I, c.sb.caps, q.sb.caps)) q.sb.caps = retry_stab;
         if (pct::continuous_lds_bytes(q) > lds_room) { pct_destroy(h); return fail(PCT_ERR_INVALID_ARG, "the retry pass does not fit the LDS"); }
       }
       CALLOC_(q.gtab, (size_t)RB * (size_t)(big + big / 4) * sizeof(uint32_t));
@@ -684,11 +709,11 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
     pct::DiscreteParams t = p;
     t.ems_cap = h->d_retry_ems;
     t.cand_cap = h->d_retry_cand;
-    t.sb.caps = h->d_retry_stab;
-    while (pct::discrete_lds_bytes(t) > lds_room && t.sb.caps.SP > p.sb.caps.SP) {  /* shrink until the pass fits */
-      t.sb.caps.SP = (t.sb.caps.SP * 3) / 4 > p.sb.caps.SP ? (t.sb.caps.SP * 3) / 4 : p.sb.caps.SP;
-      t.sb.caps.PP = (t.sb.caps.PP * 3) / 4 > p.sb.caps.PP ? (t.sb.caps.PP * 3) / 4 : p.sb.caps.PP;
-      t.sb.caps.queue = (t.sb.caps.queue * 3) / 4 > p.sb.caps.queue ? (t.sb.caps.queue * 3) / 4 : p.sb.caps.queue;
+    {
+      auto lds_of = [&](const pct::StabCaps& caps) { pct::DiscreteParams u = t; u.sb.caps = caps; return pct::discrete_lds_bytes(u); };
+      t.sb.caps = h->d_retry_stab;
+      pct::StabCaps fitted;
+      if (fit_retry_stab(lds_of, lds_room, p.I, p.sb.caps, fitted)) t.sb.caps = fitted;
     }
     if (pct::discrete_lds_bytes(t) > lds_room) { h->d_retry_ems = ems_cap; h->d_retry_cand = cand_cap; t.sb.caps = p.sb.caps; }
     h->d_retry_stab = t.sb.caps;
@@ -1107,6 +1132,38 @@ int pct_policy_hash_rows(pct_env* h, float* rows_out, void* stream) {
   return PCT_OK;
 }
 
+/* The stand-in policy as an INDEX: four envs per 256-thread workgroup, a wave per env counts the valid leaves of its
+ * observation (mask column 8 of rows I .. I+L-1, tools.py:103) and writes pct_mix32(global id, t) % k -- what
+ * pct_policy_hash_rows gathers a row by.  One launch, like a policy's forward pass. */
+__global__ void __launch_bounds__(256) pct_policy_hash_index_kernel(const float* __restrict__ obs, const int32_t* __restrict__ scalars,
+                                                                     int64_t* __restrict__ out, int N, int row_len, int I, int L, int base) {
+  const int lane = threadIdx.x & 63;
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (e >= N) return;
+  const float* o = obs + (size_t)e * row_len;
+  int k = 0;
+  for (int b = 0; b < L; b += 64) {
+    const int j = b + lane;
+    const bool v = j < L && o[(I + j) * 9 + 8] != 0.f;
+    k += __popcll(__ballot(v));
+  }
+  const uint32_t t = (uint32_t)scalars[(size_t)e * PCT_SCALARS + 6];
+  if (lane == 0) out[e] = k > 0 ? (int64_t)(pct_mix32((uint32_t)(base + e), t) % (uint32_t)k) : 0;
+}
+
+int pct_policy_hash_index(pct_env* h, int64_t* index_out, void* stream) {
+  int rc = ready(h, true);
+  if (rc) return rc;
+  if (!index_out) return fail(PCT_ERR_INVALID_ARG, "null index_out");
+  const int N = h->dp.N;
+  const int32_t* scalars = h->continuous ? h->cp.scalars : h->dp.scalars;
+  const int base = h->continuous ? h->cp.env_id_base : h->dp.env_id_base;
+  hipLaunchKernelGGL(pct_policy_hash_index_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, h->dp.obs, scalars, index_out, N,
+                     h->dp.row_len, h->dp.I, h->dp.L, base);
+  HIP_TRY(hipGetLastError());
+  return PCT_OK;
+}
+
 int pct_bind_policy_rows(pct_env* h, float* rows_out) {
   if (!h) return fail(PCT_ERR_INVALID_ARG, "null handle");
   h->dp.policy_rows = rows_out; /* (launch() hands it to the continuous block and to the retry passes) */
@@ -1165,6 +1222,8 @@ int pct_debug_retry_count(pct_env* h, int32_t* last, int64_t* envs_total, int64_
   if (launches_total) *launches_total = w[3];
   return PCT_OK;
 }
+
+int32_t pct_debug_timing_slots(void) { return PCT_TIMING_SLOTS; }
 
 int pct_debug_phase_timing(pct_env* h, int32_t on, uint64_t* host_out) {
   if (!h) return fail(PCT_ERR_INVALID_ARG, "null handle");

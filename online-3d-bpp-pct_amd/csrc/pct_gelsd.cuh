@@ -36,7 +36,9 @@
 #if defined(__HIPCC__)
 #define PCT_GD __device__ __forceinline__
 #define PCT_GNOUNROLL _Pragma("nounroll")
-#define PCT_GSYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup")
+// (the wave barrier is a scheduling barrier only -- no instruction: it keeps the compiler from moving ANY access across the line, also
+// the ones a fence alone leaves free)
+#define PCT_GSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
 #else
 #define PCT_GD static inline
 #define PCT_GNOUNROLL
@@ -241,6 +243,45 @@ PCT_GD double ext_sqrt_to_double(Ext x) {
 // dnrm2: accumulators A..D over the leading blocks of eight (element i into accumulator i mod 4), the tail into A,
 // ((C + A) + B) + D, fsqrt, one rounding to double.  (Every lane of a group runs it: the loads are LDS broadcasts, eight in
 // flight at a time; the accumulation is the serial chain it is on the FPU.)
+// The same value WITHOUT the integer emulation, for up to eight elements, when a certificate holds (round 6).  dnrm2 returns
+// round53(round64(sqrt(S))) with S the x87 sum: every square and every partial sum rounded to 64 bits, so S = T (1 + e),
+// |e| <= (n + 4) 2^-64 <= 12 * 2^-64 for the exact sum of squares T (all terms non-negative), and round64(sqrt(S)) lies within
+// 2^-61 sqrt(T) of sqrt(T).  Here T is accumulated as a double-double (squares exact by FMA, two-sum additions: relative error
+// < 2^-100), its root as s + c with s = sqrt(T_hi) and c = (T_hi - s^2 + T_lo) / 2s (the residual of a square root is exact in one
+// FMA; error of s + c below 2^-100 sqrt(T)), and R = fl(s + c) is the correct rounding of that pair.  R is ALSO the x87 value
+// whenever s + c keeps a distance of more than 2^-60 R from the nearest rounding boundary (the midpoint of two neighbouring
+// doubles: half an ulp from R, a quarter below a power of two) -- tested with a margin of 2 % of half an ulp = 2^-59.6 R.  Otherwise
+// (2 % of the calls), or when a square could leave the double range, the caller runs the emulation.  Checked against it on
+// 2 * 10^7 vectors (tests/test_stab_host.py: 0 differences).  Three supporters: eight to ten dnrm2 calls of 2 - 4 elements a solve.
+PCT_GD bool dnrm2_certified(int n, const double* x, int incx, double& out) {
+  double th = 0.0, tl = 0.0;
+  PCT_GNOUNROLL
+  for (int i = 0; i < n; i++) {
+    const double v = x[i * incx];
+    const double a = fabs(v);
+    if (a != 0.0 && !(a > 1e-100 && a < 1e100)) return false;
+    const double p = v * v, e = fma(v, v, -p);
+    const double s = th + p;
+    const double bb = s - th;
+    const double err = (th - (s - bb)) + (p - bb);
+    const double lo = (tl + e) + err;
+    th = s + lo;
+    tl = lo - (th - s);
+  }
+  if (th == 0.0) { out = 0.0; return true; }
+  const double s = sqrt(th);
+  const double c = (fma(-s, s, th) + tl) / (2.0 * s);
+  const double r = s + c;
+  const double err = (s - r) + c;
+  union { double d; uint64_t u; } rb, hb;
+  rb.d = r;
+  hb.u = (rb.u & 0x7ff0000000000000ull) - (53ull << 52);  // half an ulp of r's binade
+  if (fabs(err) > hb.d * 0.98) return false;
+  if ((rb.u & 0xfffffffffffffull) == 0 && -err > hb.d * 0.49) return false;  // (below a power of two the spacing halves)
+  out = r;
+  return true;
+}
+PCT_GD double dnrm2_ext(int n, const double* x, int incx);
 PCT_GD double dnrm2(int n, const double* x, int incx) {
   if (n <= 0) return 0.0;
 #if !defined(PCT_GELSD_NO_NRM2_SHORTCUT)
@@ -249,6 +290,16 @@ PCT_GD double dnrm2(int n, const double* x, int incx) {
   // reflectors of a three-supporter system have such a one-element tail.
   if (n == 1) return fabs(x[0]);
 #endif
+#if !defined(PCT_GELSD_NO_NRM2_CERTIFIED)
+  if (n <= 8) {
+    double r;
+    if (dnrm2_certified(n, x, incx, r)) return r;
+  }
+#endif
+  return dnrm2_ext(n, x, incx);
+}
+// the emulation itself (n >= 1)
+PCT_GD double dnrm2_ext(int n, const double* x, int incx) {
   Ext a, b, c, d;
   a.m = b.m = c.m = d.m = 0;
   a.e = b.e = c.e = d.e = 0;
@@ -293,8 +344,15 @@ PCT_GD double dnrm2(int n, const double* x, int incx) {
 #define PCT_GELSD_COOP_NRM2_MIN 5
 #endif
 PCT_GD double dnrm2_g(Grp g, int n, const double* x, int incx, double* scratch) {
+#if !defined(PCT_GELSD_NO_NRM2_CERTIFIED)
+  if (n > 1 && n <= 8) {  // (every lane of the group the same arithmetic on the same elements: the outcome is group-uniform)
+    double r;
+    if (dnrm2_certified(n, x, incx, r)) return r;
+  }
+#endif
 #if !defined(PCT_GELSD_COOP_NRM2_ALWAYS)
-  if (g.G < 4 || n < PCT_GELSD_COOP_NRM2_MIN) return dnrm2(n, x, incx);
+  if (n <= 1) return dnrm2(n, x, incx);
+  if (g.G < 4 || n < PCT_GELSD_COOP_NRM2_MIN) return dnrm2_ext(n, x, incx);
 #else
   if (n <= 1) return dnrm2(n, x, incx);
 #endif
@@ -654,11 +712,274 @@ PCT_GD void dlascl_vec(Grp g, double cfrom, double cto, int n, double* x) {
   PCT_GSYNC();
 }
 
+// ---- dbdsqr for n = 3 (three supporters: 94 % of the on-domain solves), round 6 -----------------------------------------------------
+// The generic routine below keeps d, e and the sweep's rotations (work) in LDS: every d(i) / e(i) of the split search, the
+// convergence test, the shift and the chase is an LDS round trip in a dependent chain -- ~30 of them per iteration, 34 k of the 73 k
+// cycles of a three-supporter solve (profiles/r06_microbench_gelsd.txt).  For n = 3 every index is known: a block is either the
+// whole matrix (ll = 1, m = 3: a sweep over x0 x1 x2 / y0 y1 in chase order, idir 1 = top down, 2 = bottom up) or a 2 x 2 corner
+// (dlasv2).  So d0 d1 d2 e0 e1 are five REGISTERS for the whole routine, the rotations of a sweep stay in the registers of the lane
+// that computed them (every lane of the group runs the scalar chain anyway), and a lane touches only ITS columns of VT / cc (three
+// loads in flight, the sweep's rotations, three stores): no hand-over inside the routine.  (A first version for n <= 4 with run-time
+// positions through select chains was SLOWER than the LDS routine -- 45 k against 34 k cycles, profiles/r06_experiments.txt -- as
+// round 5 had found for the whole solve.)  Operation for operation the generic routine (same tests, same order, same expressions):
+// tests/test_stab_host.py compares the two on 2 * 10^6 random bidiagonals, and both with the oracle's dbdsqr.
+PCT_GD bool dbdsqr3(Grp g, double* d, double* e, double* vt, double* cc) {
+  const int n = 3, ldvt = 3;
+  const double hndrth = 0.01;
+  const int maxitr = 6;
+  double d0 = d[0], d1 = d[1], d2 = d[2], e0 = e[0], e1 = e[1];
+  const double tol = 0x1.8ace5422aa0dbp+6 * EPS;
+  double smax = 0.0;
+  smax = fabs(d0) > smax ? fabs(d0) : smax;
+  smax = fabs(d1) > smax ? fabs(d1) : smax;
+  smax = fabs(d2) > smax ? fabs(d2) : smax;
+  smax = fabs(e0) > smax ? fabs(e0) : smax;
+  smax = fabs(e1) > smax ? fabs(e1) : smax;
+  double smin = 0.0;
+  double sminoa = fabs(d0);
+  if (sminoa != 0.0) {
+    double mu = sminoa;
+    mu = fabs(d1) * (mu / (mu + fabs(e0)));
+    sminoa = mu < sminoa ? mu : sminoa;
+    if (sminoa != 0.0) {
+      mu = fabs(d2) * (mu / (mu + fabs(e1)));
+      sminoa = mu < sminoa ? mu : sminoa;
+    }
+  }
+  sminoa = sminoa / sqrt((double)n);
+  double thresh = tol * sminoa;
+  {
+    const double t2 = maxitr * (n * (n * SAFMIN));
+    thresh = t2 > thresh ? t2 : thresh;
+  }
+  const int maxitdivn = maxitr * n;
+  int iterdivn = 0, iter = -1, idir = 0;
+  bool swept = false;  // (oldll = 1, oldm = 3 once the whole block has been swept: idir is chosen at its first visit only)
+  int m = 3;
+  // rotation of rows (r, r + 1) of the lane's own columns (the 2 x 2 corner's drot: x' = fma(c, x, s y), y' = fma(c, y, -(s x)))
+  auto rot2 = [&](int r, double cosr, double sinr, double cosl, double sinl) __attribute__((always_inline)) {
+    for (int i = g.gl; i < n + 1; i += g.G) {
+      double* px = i < n ? &vt[r + i * ldvt] : &cc[r];
+      const double cr = i < n ? cosr : cosl, sr = i < n ? sinr : sinl;
+      const double xv = px[0], yv = px[1];
+      px[0] = fma(cr, xv, sr * yv);
+      px[1] = fma(cr, yv, -(sr * xv));
+    }
+  };
+  PCT_GNOUNROLL
+  while (m > 1) {
+    if (iter >= n) {
+      iter -= n;
+      iterdivn++;
+      if (iterdivn >= maxitdivn) return false;
+    }
+    if (m == 2) {
+      // rows 0, 1: either e0 is negligible (the block splits into two 1 x 1) or the 2 x 2 corner is diagonalised
+      if (fabs(e0) <= thresh) { e0 = 0.0; m = 1; continue; }
+      double sigmn, sigmx, sinr, cosr, sinl, cosl;
+      dlasv2(d0, e0, d1, sigmn, sigmx, sinr, cosr, sinl, cosl);
+      d0 = sigmx; e0 = 0.0; d1 = sigmn;
+      rot2(0, cosr, sinr, cosl, sinl);
+      m = 0;
+      continue;
+    }
+    // m == 3: look for a negligible off-diagonal entry from the bottom
+    smax = fabs(d2);
+    if (fabs(e1) <= thresh) { e1 = 0.0; m = 2; continue; }
+    smax = fabs(d1) > smax ? fabs(d1) : smax;
+    smax = fabs(e1) > smax ? fabs(e1) : smax;
+    if (fabs(e0) <= thresh) {
+      // split above row 1: the 2 x 2 corner of rows 1, 2
+      e0 = 0.0;
+      double sigmn, sigmx, sinr, cosr, sinl, cosl;
+      dlasv2(d1, e1, d2, sigmn, sigmx, sinr, cosr, sinl, cosl);
+      d1 = sigmx; e1 = 0.0; d2 = sigmn;
+      rot2(1, cosr, sinr, cosl, sinl);
+      m = 1;
+      continue;
+    }
+    smax = fabs(d0) > smax ? fabs(d0) : smax;
+    smax = fabs(e0) > smax ? fabs(e0) : smax;
+    // the whole matrix is one block (ll = 1, m = 3)
+    if (!swept) idir = fabs(d0) >= fabs(d2) ? 1 : 2;
+    bool conv = false;
+    if (idir == 1) {
+      if (fabs(e1) <= fabs(tol) * fabs(d2)) { e1 = 0.0; continue; }
+      double mu = fabs(d0);
+      smin = mu;
+      if (fabs(e0) <= tol * mu) { e0 = 0.0; conv = true; }
+      else {
+        mu = fabs(d1) * (mu / (mu + fabs(e0)));
+        smin = mu < smin ? mu : smin;
+        if (fabs(e1) <= tol * mu) { e1 = 0.0; conv = true; }
+        else {
+          mu = fabs(d2) * (mu / (mu + fabs(e1)));
+          smin = mu < smin ? mu : smin;
+        }
+      }
+    } else {
+      if (fabs(e0) <= fabs(tol) * fabs(d0)) { e0 = 0.0; continue; }
+      double mu = fabs(d2);
+      smin = mu;
+      if (fabs(e1) <= tol * mu) { e1 = 0.0; conv = true; }
+      else {
+        mu = fabs(d1) * (mu / (mu + fabs(e1)));
+        smin = mu < smin ? mu : smin;
+        if (fabs(e0) <= tol * mu) { e0 = 0.0; conv = true; }
+        else {
+          mu = fabs(d0) * (mu / (mu + fabs(e0)));
+          smin = mu < smin ? mu : smin;
+        }
+      }
+    }
+    if (conv) continue;
+    swept = true;
+    double shift = 0.0, r = 0.0;
+    {
+      const double bound = EPS > hndrth * tol ? EPS : hndrth * tol;
+      if (!(n * tol * (smin / smax) <= bound)) {
+        double sll;
+        if (idir == 1) { sll = fabs(d0); dlas2(d1, e1, d2, shift, r); }
+        else { sll = fabs(d2); dlas2(d0, e0, d1, shift, r); }
+        if (sll > 0.0) {
+          const double q = shift / sll;
+          if (q * q < EPS) shift = 0.0;
+        }
+      }
+    }
+    iter = iter + 2;  // m - ll
+    // the block in chase order: downwards (idir 1) x = d0 d1 d2, y = e0 e1; upwards (idir 2) x = d2 d1 d0, y = e1 e0
+    const bool up = idir != 1;
+    double x0 = up ? d2 : d0, x1 = d1, x2 = up ? d0 : d2, y0 = up ? e1 : e0, y1 = up ? e0 : e1;
+    const double sg = up ? -1.0 : 1.0;  // (the upward chase stores its sines negated: dbdsqr's WORK(.) = -SN)
+    double c00, s00, c10, s10, c01, s01, c11, s11;  // the sweep's rotations: (w0, w1)[p] = (c0p, s0p), (w2, w3)[p] = (c1p, s1p)
+    if (shift == 0.0) {
+      double cs = 1.0, oldcs = 1.0, sn = 0.0, oldsn = 0.0, dn;
+      dlartg(x0 * cs, y0, cs, sn, r);
+      dlartg(oldcs * r, x1 * sn, oldcs, oldsn, dn);
+      x0 = dn;
+      c00 = cs; s00 = sg * sn; c10 = oldcs; s10 = sg * oldsn;
+      dlartg(x1 * cs, y1, cs, sn, r);
+      y0 = oldsn * r;
+      dlartg(oldcs * r, x2 * sn, oldcs, oldsn, dn);
+      x1 = dn;
+      c01 = cs; s01 = sg * sn; c11 = oldcs; s11 = sg * oldsn;
+      const double h = x2 * cs;
+      x2 = h * oldcs;
+      y1 = h * oldsn;
+    } else {
+      double f = (fabs(x0) - shift) * (sgn(1.0, x0) + shift / x0);
+      double gg = y0;
+      double cosr, sinr, cosl, sinl;
+      dlartg(f, gg, cosr, sinr, r);
+      f = cosr * x0 + sinr * y0;
+      y0 = cosr * y0 - sinr * x0;
+      gg = sinr * x1;
+      x1 = cosr * x1;
+      dlartg(f, gg, cosl, sinl, r);
+      x0 = r;
+      f = cosl * y0 + sinl * x1;
+      x1 = cosl * x1 - sinl * y0;
+      gg = sinl * y1;
+      y1 = cosl * y1;
+      c00 = cosr; s00 = sg * sinr; c10 = cosl; s10 = sg * sinl;
+      dlartg(f, gg, cosr, sinr, r);
+      y0 = r;
+      f = cosr * x1 + sinr * y1;
+      y1 = cosr * y1 - sinr * x1;
+      gg = sinr * x2;
+      x2 = cosr * x2;
+      dlartg(f, gg, cosl, sinl, r);
+      x1 = r;
+      f = cosl * y1 + sinl * x2;
+      x2 = cosl * x2 - sinl * y1;
+      c01 = cosr; s01 = sg * sinr; c11 = cosl; s11 = sg * sinl;
+      y1 = f;
+    }
+    if (fabs(y1) <= thresh) y1 = 0.0;  // (the entry the chase ends on: e(m - 1) downwards, e(ll) upwards)
+    d0 = up ? x2 : x0; d1 = x1; d2 = up ? x0 : x2; e0 = up ? y1 : y0; e1 = up ? y0 : y1;
+    // dlasr('L', 'V', 'F' / 'B') on the lane's own columns: the right rotations (the first of a step's pair) go into VT when chasing
+    // downwards, into cc when chasing upwards, the left ones into the other; rows in chase order, rotated, stored back
+    PCT_GNOUNROLL
+    for (int c = g.gl; c < n + 1; c += g.G) {
+      const bool first = (c < n) == (idir == 1);
+      double* col = c < n ? vt + c * ldvt : cc;
+      const double a0 = col[0], a1 = col[1], a2 = col[2];
+      double v0 = up ? a2 : a0, v1 = a1, v2 = up ? a0 : a2;
+      {
+        const double ct = first ? c00 : c10, st = first ? s00 : s10;
+        if (ct != 1.0 || st != 0.0) {
+          // rows (dp, dq) = chase positions (0, 1); downwards: high = dq, low = dp; upwards: high = dp, low = dq
+          const double hi = up ? v0 : v1, lo = up ? v1 : v0;
+          const double nh = ct * hi - st * lo, nl = st * hi + ct * lo;
+          v1 = up ? nl : nh;
+          v0 = up ? nh : nl;
+        }
+      }
+      {
+        const double ct = first ? c01 : c11, st = first ? s01 : s11;
+        if (ct != 1.0 || st != 0.0) {
+          const double hi = up ? v1 : v2, lo = up ? v2 : v1;
+          const double nh = ct * hi - st * lo, nl = st * hi + ct * lo;
+          v2 = up ? nl : nh;
+          v1 = up ? nh : nl;
+        }
+      }
+      col[0] = up ? v2 : v0; col[1] = v1; col[2] = up ? v0 : v2;
+    }
+  }
+  // signs, then decreasing order (one transposition per singular value), as the generic routine
+  if (d0 == 0.0) d0 = 0.0;
+  if (d0 < 0.0) { d0 = -d0; dscal(g, n, -1.0, &vt[0], ldvt); }
+  if (d1 == 0.0) d1 = 0.0;
+  if (d1 < 0.0) { d1 = -d1; dscal(g, n, -1.0, &vt[1], ldvt); }
+  if (d2 == 0.0) d2 = 0.0;
+  if (d2 < 0.0) { d2 = -d2; dscal(g, n, -1.0, &vt[2], ldvt); }
+  auto swap_rows = [&](int ra, int rb) __attribute__((always_inline)) {
+    for (int c = g.gl; c < n + 1; c += g.G) {
+      double* col = c < n ? vt + c * ldvt : cc;
+      const double t = col[ra];
+      col[ra] = col[rb];
+      col[rb] = t;
+    }
+  };
+  {
+    // i = 1: the smallest of d0 d1 d2 (the LAST one among equals) goes to position 2
+    int isub = 0;
+    double smn = d0;
+    if (d1 <= smn) { isub = 1; smn = d1; }
+    if (d2 <= smn) { isub = 2; smn = d2; }
+    if (isub != 2) {
+      if (isub == 0) d0 = d2; else d1 = d2;
+      d2 = smn;
+      swap_rows(isub, 2);
+    }
+    // i = 2: the smaller of d0 d1 goes to position 1
+    if (!(d1 <= d0)) {
+      const double t = d0;
+      d0 = d1;
+      d1 = t;
+      swap_rows(0, 1);
+    }
+  }
+  PCT_GSYNC();
+  d[0] = d0; d[1] = d1; d[2] = d2; e[0] = e0; e[1] = e1;  // (every lane of the group the same values)
+  PCT_GSYNC();
+  return true;
+}
+
+PCT_GD bool dbdsqr_generic(Grp g, int n, double* d, double* e, double* vt, double* cc, double* work);
 // dbdsqr('U', n, ncvt = n, 0, ncc = 1): SVD of the upper bidiagonal (d, e); right rotations into VT (n x n, ldvt = n), left
 // ones into the column cc.  work: 4 (n - 1) doubles.  Returns false when the iteration limit is reached.
 // The chase itself (d, e, the rotations' cosines and sines into work) is the scalar chain every lane runs; a sweep's rotations
 // are then applied a COLUMN of VT (and the column cc) per lane.
 PCT_GD bool dbdsqr(Grp g, int n, double* d, double* e, double* vt, double* cc, double* work) {
+#if !defined(PCT_GELSD_NO_BDSQR3)
+  if (n == 3) return dbdsqr3(g, d, e, vt, cc);
+#endif
+  return dbdsqr_generic(g, n, d, e, vt, cc, work);
+}
+PCT_GD bool dbdsqr_generic(Grp g, int n, double* d, double* e, double* vt, double* cc, double* work) {
   const double hndrth = 0.01;
   const int maxitr = 6;
   const int ldvt = n;

@@ -49,11 +49,15 @@
 #endif
 
 #include "pct_gelsd.cuh"
+#include "pct_pow.cuh"
 
 namespace pct {
 
-constexpr int STAB_LSQ = 16;         // most supporters a least-squares split can be given (a launch's caps.lsq_n may be lower:
-                                     // 8 in the normal pass, 16 in the retry pass; more is a capacity error)
+constexpr int STAB_LSQ = 25;         // most supporters a least-squares split can be given (a launch's caps.lsq_n may be lower:
+                                     // 8 in the normal pass, 25 in the retry pass).  25 is LAPACK's own limit for the path of dgelsd
+                                     // that pct_gelsd.cuh restates: dlalsd solves an n <= SMLSIZ = 25 bidiagonal system by dlasdq and
+                                     // switches to the divide-and-conquer routines (dlasda / dlalsa) beyond it.  A 5 x 5 footprint on
+                                     // unit tiles -- the widest stack of the 10^3 / items 1..5 domain -- has 25 supporters (round 5: 16)
 constexpr int STAB_NSUP_MAX = 255;   // supporters per box (8-bit count)
 constexpr uint32_t STAB_END = 0xFFFu;  // end of an up-list / "no parent"
 constexpr uint32_t STAB_NOBOX = 0x3FFu;
@@ -61,7 +65,7 @@ constexpr uint32_t STAB_NOBOX = 0x3FFu;
 constexpr uint32_t STAB_WHY_QUEUE = 0x100u;     // one task's children do not fit the walk queue
 constexpr uint32_t STAB_WHY_WS = 0x200u;        // a candidate's hull does not fit the workspace / > 255 supporters
 constexpr uint32_t STAB_WHY_HULL = 0x400u;      // a hull of more than 255 vertices
-constexpr uint32_t STAB_WHY_SPLIT = 0x800u;     // more supporters than this launch's least-squares workspace takes (caps.lsq_n), none of them direct
+constexpr uint32_t STAB_WHY_SPLIT = 0x800u;     // more supporters than this launch's least-squares workspace takes (caps.lsq_n; 25 in the retry pass), none of them direct
 constexpr uint32_t STAB_WHY_COMMIT = 0x1000u;   // the commit: pools, workspace or depth-first stack
 constexpr uint32_t STAB_WHY_LOAD = 0x2000u;     // the stored state does not fit this launch's pools
 constexpr uint32_t STAB_NOTE_ILL = 0x4000u;     // (not a capacity: carries the ill-conditioning notice out of a heuristic's probes)
@@ -540,9 +544,11 @@ PCT_SD bool stab_split(const Geo& geo, const double bg[9], int k, const Sup& sup
       double t0 = e00 - e10, t1 = e01 - e11;
       const StabDot2 dot2{gelsd_avx2};  // (the lever rule's np.dot / np.linalg.norm follow the host flavour too)
       double len = sqrt(dot2(t0, t1, t0, t1));
-      // tri_base_len ** 2: NumPy calls libm pow(len, 2.0); a correctly rounded square is len*len
-      // (glibc's pow agrees except for rare near-midpoint roundings; the device pow does not)
-      double l2 = len * len;
+      // tri_base_len ** 2: NumPy calls libm pow(len, 2.0), which is not correctly rounded -- pct_pow.cuh restates glibc's
+      // pow as its FMA build executes it.  Geo::kSquareIsPow: every length this env can produce -- sqrt of a sum of two squares
+      // of half-integers below 32 (the 5-bit-coordinate discrete kernels) -- has pow(len, 2.0) == len * len (exhaustive up
+      // to 43 per axis, tests/test_stab_host.py; the first length that differs is that of (39.5, 43.5))
+      double l2 = Geo::kSquareIsPow ? len * len : pow_glibc_fma(len, 2.0);
       t0 /= l2; t1 /= l2;
       sp.f[0] = fabs(dot2(stk[0] - e10, stk[1] - e11, t0, t1));
       sp.f[1] = fabs(dot2(stk[0] - e00, stk[1] - e01, t0, t1));

@@ -13,6 +13,19 @@ RESTATED = {"SkylakeX": "gelsd", "Haswell": "gelsd_avx2"}
 PINNED_OPENBLAS = "0.3.29"
 
 
+def _openblas_version(L):
+    """the release string out of openblas_get_config ("OpenBLAS 0.3.29 DYNAMIC_ARCH ..."), or None"""
+    import re
+    for sym in ("scipy_openblas_get_config64_", "scipy_openblas_get_config", "openblas_get_config64_", "openblas_get_config"):
+        if hasattr(L, sym):
+            f = getattr(L, sym)
+            f.restype = ctypes.c_char_p
+            m = re.search(r"OpenBLAS\s+(\d+\.\d+\.\d+)", (f() or b"").decode(errors="replace"))
+            if m:
+                return m.group(1)
+    return None
+
+
 def numpy_blas():
     """(kernel set, OpenBLAS version) of the BLAS behind this process's NumPy, or (None, None) when it cannot be told"""
     try:
@@ -31,7 +44,7 @@ def numpy_blas():
                 if hasattr(L, sym):
                     f = getattr(L, sym)
                     f.restype = ctypes.c_char_p
-                    return f().decode(), None
+                    return f().decode(), _openblas_version(L)
     except Exception:
         pass
     return None, None
@@ -43,7 +56,7 @@ CHECKED_OPENBLAS = ("0.3.23", "0.3.29")
 
 def numpy_lstsq_mode(strict=False):
     """'gelsd' / 'gelsd_avx2' for the kernel set this process's NumPy runs, else None (strict: raise).  An OpenBLAS release outside the
-    checked span (or one whose version cannot be read) is a warning -- the mode is still returned -- and an error under strict:
+    checked span is a warning -- the mode is still returned -- and an error under strict (a version that cannot be read at all stays a warning):
     another release may order its kernel sums differently, and the claim "bit-identical to this NumPy" would be unfounded."""
     arch, version = numpy_blas()
     mode = RESTATED.get(arch)
@@ -60,7 +73,7 @@ def numpy_lstsq_mode(strict=False):
     if not known:
         msg = ("NumPy's OpenBLAS is %s; the dgelsd restatement was checked against %s ... %s (pinned: %s)"
                % (version or "of unknown version", CHECKED_OPENBLAS[0], CHECKED_OPENBLAS[1], PINNED_OPENBLAS))
-        if strict:
+        if strict and v:  # (a version that cannot be READ is a warning, ADVICE r5: a host without threadpoolctl must not lose the mode)
             raise RuntimeError(msg)
         import warnings
         warnings.warn(msg)

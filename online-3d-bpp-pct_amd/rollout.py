@@ -45,7 +45,8 @@ class RolloutSlots(object):
         own outputs are recorded beside them.  Returns the new observation view obs[t+1]."""
         t = self.step
         envs.step_into(leaf_index, self.obs[t + 1], self.rewards[t], self.masks[t + 1])
-        self.actions[t].copy_(leaf_index.view_as(self.actions[t]))
+        if leaf_index.data_ptr() != self.actions[t].data_ptr():  # (a policy may write its choice straight into actions[t])
+            self.actions[t].copy_(leaf_index.view_as(self.actions[t]))
         if action_log_probs is not None:
             self.action_log_probs[t].copy_(action_log_probs)
         self.step = (t + 1) % self.num_steps

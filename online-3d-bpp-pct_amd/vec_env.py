@@ -470,6 +470,19 @@ class PctVecEnv(VecEnv):
             _lib.check(self._L.pct_policy_hash_rows(self._h, out.data_ptr(), self._stream()))
         return out
 
+    def policy_hash_index(self, out=None):
+        """The stand-in policy as an INDEX tensor in one launch (pct_policy_hash_index): int64 [N] leaf indices
+        pct_mix32(global id, t) % k over the k valid leaves of the current observation -- what a trained policy hands
+        `step(index)` / `RolloutSlots.step_env` (train_tools.py:63-66: `selected_leaf_node` is gathered by this index).
+        `out`: a contiguous int64 [N] (or [N,1]) device tensor to write into, e.g. the rollout's actions[t]."""
+        if out is None:
+            out = torch.empty(self.N, dtype=torch.int64, device=self.device)
+        if not (out.is_contiguous() and out.dtype == torch.int64 and out.device == self.device and out.numel() == self.N):
+            raise ValueError("out must be a contiguous int64 [N] tensor on the env's device")
+        with torch.cuda.device(self._dev_index):
+            _lib.check(self._L.pct_policy_hash_index(self._h, out.data_ptr(), self._stream()))
+        return out
+
     def bind_policy_rows(self, rows):
         """Stand-in policy as an EPILOGUE of every following launch (pct_bind_policy_rows): the transition kernel also
         writes, for the observation it has just produced, the float32 [N,9] leaf row `policy_hash_rows` would gather
@@ -502,7 +515,7 @@ class PctVecEnv(VecEnv):
         """Start/stop per-phase cycle accounting; returns the uint64 [N,44] gathered so far
         (columns: load, drop, genems, set, feas, obs, store, steps, set-gen, set-dedup, set-match, set-rebuild, set statistics
         12..29, stability counters 30..43: csrc/pct_set.cuh)."""
-        out = np.zeros((self.N, 44), np.uint64)  # PCT_TIMING_SLOTS
+        out = np.zeros((self.N, int(self._L.pct_debug_timing_slots())), np.uint64)  # (the library's PCT_TIMING_SLOTS: 44)
         _lib.check(self._L.pct_debug_phase_timing(self._h, int(bool(on)), out.ctypes.data))
         return out
 
@@ -517,15 +530,22 @@ class PctVecEnv(VecEnv):
             self._h_ring = [torch.zeros_like(self._h_pack).pin_memory() for _ in range(2)]
             self._ring_ev = [torch.cuda.Event() for _ in range(2)]
             self._ring_i = 0
+            self._ticket_issued = 0    # tickets handed out / consumed so far: ticket t lives in buffer t % 2 and must be
+            self._ticket_consumed = 0  # waited in order (the monitor's episode sums are accumulated at wait() time)
+        if self._ticket_issued - self._ticket_consumed >= 2:
+            raise PctEnvError("step_outputs_async: two tickets are outstanding -- wait() the older one first (its pinned buffer "
+                              "would be overwritten)")
         buf, ev = self._h_ring[self._ring_i], self._ring_ev[self._ring_i]
         self._ring_i ^= 1
+        seq = self._ticket_issued
+        self._ticket_issued += 1
         buf.copy_(self._pack, non_blocking=True)
         if self._reward.data_ptr() != self._own[1].data_ptr():  # a rollout slot holds the reward (step_into)
             o = self._pack_offs["reward"]
             buf[o[0]:o[1]].view(o[2]).copy_(self._reward.reshape(-1), non_blocking=True)
         ev.record(torch.cuda.current_stream(self.device))
         self.waiting_step = False
-        return _StepTicket(self, buf, ev)
+        return _StepTicket(self, buf, ev, seq)
 
     def _outputs_from(self, buf):
         offs = self._pack_offs
@@ -622,12 +642,19 @@ class PctVecEnv(VecEnv):
 class _StepTicket(object):
     """What PctVecEnv.step_outputs_async returns: the packed outputs of one step on their way to a pinned host buffer."""
 
-    def __init__(self, env, buf, ev):
-        self._env, self._buf, self._ev = env, buf, ev
+    def __init__(self, env, buf, ev, seq):
+        self._env, self._buf, self._ev, self._seq = env, buf, ev, seq
 
     def wait(self):
+        env = self._env
+        if self._seq < env._ticket_consumed:
+            raise PctEnvError("step ticket %d was already consumed" % self._seq)
+        if self._seq != env._ticket_consumed:
+            raise PctEnvError("step tickets must be waited in order: ticket %d is next, this is %d" % (env._ticket_consumed, self._seq))
         self._ev.synchronize()
-        return self._env._outputs_from(self._buf)
+        out = env._outputs_from(self._buf)
+        env._ticket_consumed += 1
+        return out
 
 
 def make_vec_envs(args, log_dir=None, allow_early_resets=True):

@@ -222,11 +222,14 @@ void stab_set_lstsq_mode(int mode) { /* 0: Jacobi; 1: dgelsd, AVX-512 kernel set
   g_dot_plain = mode == 2;
 }
 int stab_get_lstsq_mode(void) { return g_lstsq_mode ? 1 + gelsd_get_kernel_set() : 0; }
+static long g_beyond_smlsiz = 0; /* dgelsd-mode splits over more than 25 supporters handed to the stand-in (unpinned territory) */
+long stab_beyond_smlsiz(void) { return g_beyond_smlsiz; }
 static void lstsq_min_norm(const double* A, const double* b, int M, int N, double* x) {
   if (g_lstsq_mode == 1) {
     double sv[64];
     int near_cut = 0;
-    if (N <= 64) {
+    if (N <= 25) { /* dlalsd: n <= SMLSIZ = 25 -> dlasdq, the path pct_oracle_gelsd.c restates (pinned on 20 - 24 unknowns by
+                      tests/golden/plate_discrete_s1.npz); beyond it LAPACK runs dlasda / dlalsa (divide and conquer) */
       if (gelsd_lstsq(A, b, M, N, x, NULL, sv, &near_cut) != 0) { /* dbdsqr did not converge: NumPy raises LinAlgError there */
         for (int i = 0; i < N; i++) x[i] = 0;
         near_cut = 1;
@@ -234,7 +237,9 @@ static void lstsq_min_norm(const double* A, const double* b, int M, int N, doubl
       if (near_cut) g_ill = 1;
       return;
     }
-    g_ill = 1; /* (more than 64 supporters: the stand-in takes over) */
+    g_ill = 1; /* more than 25 supporters: NOT the reference's arithmetic any more -- the stand-in takes over, counted below
+                  (the product raises PCT_FLAG_STABILITY_OVERFLOW | STAB_WHY_SPLIT there and ends the episode) */
+    g_beyond_smlsiz++;
   }
   double* U = (double*)malloc(sizeof(double) * (size_t)M * N);
   double* V = (double*)malloc(sizeof(double) * (size_t)N * N);

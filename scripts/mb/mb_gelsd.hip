@@ -1,7 +1,8 @@
 // GPU microbenchmark + device check of the strict least-squares split (csrc/pct_gelsd.cuh): a wave solves `per_wave` systems side
 // by side, one per group of G lanes, on slots laid out as pct_stab.cuh's stab_gelsd_slots lays them out; the fractions come back
 // for a bit-for-bit comparison with the oracle's restatement (scripts/mb_gelsd.py), the shader-clock cycles of the solve per wave.
-// variant 0: the round-4 routine (one lane per system, digit-by-digit x87 square root); 1: this round's (G lanes per system).
+// variant 0: one lane per system; 1: G lanes per system (what the kernels run).  (The frozen round-4 / register-resident copies this
+// file used to compare against are in git history: scripts/mb/pct_gelsd_r04.cuh, pct_gelsd_fixed.cuh at 1446cf8.)
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC scripts/mb/mb_gelsd.hip -o scripts/mb/libmb_gelsd.so
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -13,8 +14,6 @@ __device__ unsigned long long g_prof[8];
 #define PCT_GPROF_T0(var) const unsigned long long var = __builtin_readcyclecounter();
 #define PCT_GPROF_ADD(slot, var) if (threadIdx.x == 0) atomicAdd(&g_prof[slot], __builtin_readcyclecounter() - var);
 #include "../../online-3d-bpp-pct_amd/csrc/pct_gelsd.cuh"
-#include "pct_gelsd_fixed.cuh"
-#include "pct_gelsd_r04.cuh"
 
 struct Dot2 {
   bool plain;
@@ -45,15 +44,8 @@ __global__ void __launch_bounds__(64) mb_kernel(const double* in, double* xout, 
   const unsigned long long c0 = __builtin_readcyclecounter();
   if (on) {
     const int k = (int)w[0];
-    if (VAR == 0) {
-      if (gl == 0) pct::gelsd_r04::split_t(w + 4 + 3 * n, k, w + 4, w[1], w[2], Dot2{avx2 != 0}, w + 4 + 2 * n, ill, avx2 != 0);
-    } else if (VAR == 2) {  // register-resident, one lane per system (k = 3 / 4 only)
-      if (gl == 0) {
-        bool ok = true;
-        if (k == 3) { double x3[3]; ok = pct::gelsd::split_fixed<3>(w + 4, w[1], w[2], Dot2{avx2 != 0}, x3, ill, avx2 != 0); for (int i = 0; i < 3; i++) w[4 + 2 * n + i] = x3[i]; }
-        else if (k == 4) { double x4[4]; ok = pct::gelsd::split_fixed<4>(w + 4, w[1], w[2], Dot2{avx2 != 0}, x4, ill, avx2 != 0); for (int i = 0; i < 4; i++) w[4 + 2 * n + i] = x4[i]; }
-        (void)ok;
-      }
+    if (VAR == 0) {  // one lane per system (G = 1 whatever the launch says): the serial flavour of the same routine
+      if (gl == 0) { const pct::gelsd::Grp one = {0, 1}; pct::gelsd::split_t(one, w + 4 + 3 * n, k, w + 4, w[1], w[2], Dot2{avx2 != 0}, w + 4 + 2 * n, ill, avx2 != 0); }
     } else {
       const pct::gelsd::Grp g = {gl, G};
       pct::gelsd::split_t(g, w + 4 + 3 * n, k, w + 4, w[1], w[2], Dot2{avx2 != 0}, w + 4 + 2 * n, ill, avx2 != 0);
@@ -82,9 +74,6 @@ extern "C" int mb_gelsd_run(const double* in, double* xout, int* illout, unsigne
   if (variant == 0) {
     hipFuncSetAttribute((const void*)mb_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(mb_kernel<0>, dim3(nblk), dim3(64), lds, 0, din, dx, dill, dc, nsys, per_wave, G, n, avx2);
-  } else if (variant == 2) {
-    hipFuncSetAttribute((const void*)mb_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(mb_kernel<2>, dim3(nblk), dim3(64), lds, 0, din, dx, dill, dc, nsys, per_wave, G, n, avx2);
   } else {
     hipFuncSetAttribute((const void*)mb_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(mb_kernel<1>, dim3(nblk), dim3(64), lds, 0, din, dx, dill, dc, nsys, per_wave, G, n, avx2);

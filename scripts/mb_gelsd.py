@@ -72,12 +72,8 @@ def main():
         if only and only[0] != k:
             continue
         ins, xs, near = make_systems(k, count, rng)
-        for variant in (0, 1, 2):
+        for variant in (1,):
             for G in groups:
-                if variant != 1 and G != 1:
-                    continue
-                if variant == 2 and k > 4:
-                    continue
                 for per_wave in sorted({1, max(1, min(64 // G, 8)), 64 // G}):
                     if only and only != (k, variant, G, per_wave):
                         continue
@@ -88,7 +84,7 @@ def main():
                     okn = int(np.sum(ill == near))
                     bad += (count - ok) + (count - okn)
                     print("k=%2d class=%2d %s G=%2d systems/wave=%2d: bit-exact %d/%d, notice %d/%d, cycles/solve-call median %8d  max %8d"
-                          % (k, n, ("r04-serial", "r05-group ", "r05-fixed ")[variant], G, per_wave, ok, count, okn, count, int(np.median(cyc)), int(cyc.max())),
+                          % (k, n, ("serial", "group ")[variant], G, per_wave, ok, count, okn, count, int(np.median(cyc)), int(cyc.max())),
                           flush=True)
     print("MISMATCHES", bad)
 

@@ -31,6 +31,7 @@ struct stab {
 
 struct GeoFn {
   const double* g;
+  static constexpr bool kSquareIsPow = false;  // the host flavour always runs the pow restatement
   void operator()(int i, double out[9]) const { memcpy(out, g + 9 * (size_t)i, 9 * sizeof(double)); }
 };
 struct Task { int S; double stk[4]; };
@@ -82,6 +83,106 @@ int gelsd_host_split(int k, const double* centres, double s0, double s1, double*
   return ok;
 }
 double gelsd_host_dnrm2(int n, const double* x, int incx) { return pct::gelsd::dnrm2(n, x, incx); }
+// dbdsqr3 (d, e, the sweep's rotations in registers; n = 3) against the generic routine: `count` random bidiagonals of the kinds
+// tests/test_stab_host.py::test_product_dbdsqr_equals_oracle_dbdsqr draws.  out[0] = systems, out[1] = differences (any bit of d, VT,
+// cc or the return value).
+void gelsd_host_dbdsqr3_sweep(long count, unsigned long long seed, long* out) {
+  unsigned long long s = seed;
+  auto rnd = [&]() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (double)(s >> 11) / 9007199254740992.0; };
+  auto gauss = [&]() { return sqrt(-2.0 * log(rnd() + 1e-300)) * cos(6.283185307179586 * rnd()); };
+  const pct::gelsd::Grp one = {0, 1};
+  out[0] = out[1] = 0;
+  for (long t = 0; t < count; t++) {
+    const int n = 3;
+    double d[4], e[4] = {0, 0, 0, 0}, vt[16], c[4], d2[4], e2[4], vt2[16], c2[4], work[32];
+    for (int i = 0; i < n; i++) { d[i] = gauss(); c[i] = gauss(); }
+    for (int i = 0; i < n - 1; i++) e[i] = gauss();
+    if (t % 3 == 0) for (int i = 0; i < n; i++) d[i] *= pow(10.0, -(double)(int)(rnd() * 10));   // graded: zero-shift sweeps
+    if (t % 4 == 0) for (int i = 0; i < n / 2; i++) { const double x = d[i]; d[i] = d[n - 1 - i]; d[n - 1 - i] = x; }
+    if (t % 5 == 0) e[(int)(rnd() * (n - 1))] = 0.0;
+    if (t % 7 == 0) d[(int)(rnd() * n)] = 0.0;
+    if (t % 11 == 0) for (int i = 0; i < n; i++) d[i] = rint(d[i] * 4) / 4;  // ties in the ordering
+    for (int i = 0; i < n * n; i++) vt[i] = (i / n == i % n) ? 1.0 : 0.0;
+    memcpy(d2, d, sizeof d); memcpy(e2, e, sizeof e); memcpy(vt2, vt, sizeof vt); memcpy(c2, c, sizeof c);
+    const bool ra = pct::gelsd::dbdsqr3(one, d, e, vt, c);
+    const bool rb = pct::gelsd::dbdsqr_generic(one, n, d2, e2, vt2, c2, work);
+    out[0]++;
+    if (ra != rb || memcmp(d, d2, n * 8) || memcmp(vt, vt2, n * n * 8) || memcmp(c, c2, n * 8)) out[1]++;
+  }
+}
+// Bulk checks that would be slow through ctypes, one call per element.  `count` pseudo-random vectors of 2..8 elements drawn
+// from the value classes the stability systems hold (uniform, small integers and halves, ratios, 1e-6-lattice values, wide
+// exponent ranges, zeros): the certified double-double dnrm2 (pct_gelsd.cuh dnrm2_certified) against the x87 emulation.
+// out[0] = vectors, out[1] = certified (not handed to the emulation), out[2] = differences.
+void gelsd_host_dnrm2_certified_sweep(long count, unsigned long long seed, long* out) {
+  unsigned long long s = seed;
+  auto rnd = [&]() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (double)(s >> 11) / 9007199254740992.0; };
+  out[0] = out[1] = out[2] = 0;
+  for (long it = 0; it < count; it++) {
+    const int n = 2 + (int)(rnd() * 7);
+    const int mode = (int)(rnd() * 7);
+    double x[8];
+    for (int i = 0; i < n; i++) {
+      double v;
+      switch (mode) {
+        case 0: v = rnd() * 2 - 1; break;
+        case 1: v = (double)((int)(rnd() * 21) - 10); break;
+        case 2: v = ((int)(rnd() * 21) - 10) / 2.0; break;
+        case 3: v = exp(rnd() * 40 - 20) * (rnd() < 0.5 ? -1 : 1); break;
+        case 4: v = rnd() < 0.4 ? 0.0 : (rnd() < 0.5 ? 1.0 : -(double)((int)(rnd() * 1000)) / (1 + (int)(rnd() * 1000))); break;
+        case 5: v = exp(rnd() * 600 - 300); break;  // (beyond +-1e100 the certificate must decline)
+        default: v = rint(rnd() * 1e6) / 1e6; break;
+      }
+      x[i] = v;
+    }
+    const double ref = pct::gelsd::dnrm2_ext(n, x, 1);
+    double f;
+    out[0]++;
+    if (!pct::gelsd::dnrm2_certified(n, x, 1, f)) continue;
+    out[1]++;
+    if (memcmp(&ref, &f, 8)) out[2]++;
+  }
+}
+// pct_pow.cuh (glibc's pow as its FMA build executes it) against the live libm, on lengths of the lever rule: `count` values from
+// the continuous env's domain (norms of differences of 1e-6-lattice contact centres halved, i.e. multiples of 5e-7 up to `span`).
+// out[0] = lengths, out[1] = differences to libm's pow(len, 2.0), out[2] = lengths with pow(len, 2.0) != len * len.
+void pow_host_sweep_continuous(long count, unsigned long long seed, double span, long* out) {
+  unsigned long long s = seed;
+  auto rnd = [&]() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (double)(s >> 11) / 9007199254740992.0; };
+  out[0] = out[1] = out[2] = 0;
+  volatile double two = 2.0;  // (keeps the compiler from folding pow(x, 2) into x * x)
+  for (long it = 0; it < count; it++) {
+    // contact centres are (a + b) / 2 of np.around(., 6) values; the base line is a difference of two of them
+    const double c0x = (rint(rnd() * span * 1e6) / 1e6 + rint(rnd() * span * 1e6) / 1e6) / 2, c0y = (rint(rnd() * span * 1e6) / 1e6 + rint(rnd() * span * 1e6) / 1e6) / 2;
+    const double c1x = (rint(rnd() * span * 1e6) / 1e6 + rint(rnd() * span * 1e6) / 1e6) / 2, c1y = (rint(rnd() * span * 1e6) / 1e6 + rint(rnd() * span * 1e6) / 1e6) / 2;
+    const double t0 = c0x - c1x, t1 = c0y - c1y;
+    const double len = sqrt(fma(t1, t1, t0 * t0));
+    if (!(len > 0)) continue;
+    const double a = pow(len, two), b = pct::pow_glibc_fma(len, 2.0);
+    out[0]++;
+    if (memcmp(&a, &b, 8)) out[1]++;
+    if (a != len * len) out[2]++;
+  }
+}
+// ... and the DISCRETE env's lengths, exhaustively: sqrt(dx^2 + dy^2) for dx, dy multiples of 1/2 up to `side` (contact centres of
+// integer rectangles), both np.dot flavours.  out[0] = lengths, out[1] = pow_glibc_fma != libm, out[2] = libm pow(len, 2.0) != len * len.
+void pow_host_sweep_discrete(int side, long* out) {
+  out[0] = out[1] = out[2] = 0;
+  volatile double two = 2.0;
+  for (int i = 0; i <= 2 * side; i++)
+    for (int j = 0; j <= 2 * side; j++) {
+      if (!i && !j) continue;
+      const double t0 = i / 2.0, t1 = j / 2.0;
+      for (int avx2 = 0; avx2 < 2; avx2++) {
+        const double len = sqrt(avx2 ? t0 * t0 + t1 * t1 : fma(t1, t1, t0 * t0));
+        const double a = pow(len, two), b = pct::pow_glibc_fma(len, 2.0);
+        out[0]++;
+        if (memcmp(&a, &b, 8)) out[1]++;
+        if (a != len * len) out[2]++;
+      }
+    }
+}
+double pow_host(double x, double y) { return pct::pow_glibc_fma(x, y); }
 // dbdsqr('U', n, ncvt = n, 0, 1): d[n], e[n - 1], vt[n * n] (column-major), c[n], work[4 n]
 int gelsd_host_dbdsqr(int n, double* d, double* e, double* vt, double* c, double* work) { const pct::gelsd::Grp one = {0, 1}; return pct::gelsd::dbdsqr(one, n, d, e, vt, c, work) ? 0 : 1; }
 

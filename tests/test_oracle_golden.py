@@ -311,3 +311,25 @@ def _notice_precedes_the_divergence():
     assert list(alive) == [False, True, True, True]
     assert list(env.ill_conditioned()) == [True, False, False, False]
     env.close()
+
+
+def test_oracle_matches_reference_plate_fixture():
+    """tests/golden/gen_plate_golden.py: the unmodified reference under scripted 3-vector actions -- unit tiles, a plate on 20 / 22 / 24
+    of them none of which holds its centre of mass (np.linalg.lstsq over that many unknowns, the widest systems dgelsd still solves on
+    the restated path: n <= SMLSIZ = 25), boxes on the plate.  Every observation, reward, done, counter, ratio."""
+    c, z = load_case("plate_discrete_s1")
+    items = [(i, j, k) for i in range(1, 6) for j in range(1, 6) for k in range(1, 6)]
+    env = OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"], item_set=items, internal_node_holder=c["I"],
+                       leaf_node_holder=c["L"], env_id_base=c["base"])
+    env.set_item_stream(z["stream"])
+    env.reset()
+    assert max(c["lstsq_widths"]) == 24 and c["lstsq_widths"][24] >= 20
+    for t in range(c["steps"]):
+        assert np.array_equal(env.obs.astype(np.float32), z["obs"][t]), t
+        env.step_rows(z["actions"][t].astype(np.float64))
+        assert np.array_equal(env.done, z["done"][t]) and np.array_equal(env.reward, z["reward"][t]), t
+        assert np.array_equal(env.counter, z["counter"][t]) and np.array_equal(env.ratio * (env.done != 0), z["ratio"][t]), t
+    assert np.array_equal(env.obs.astype(np.float32), z["obs"][c["steps"]])
+    assert not env.flags.any()
+    env.close()
+

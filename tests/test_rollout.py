@@ -151,6 +151,22 @@ def test_step_outputs_async_equals_step_wait(slot):
         assert torch.equal(ra, rb) and np.array_equal(da, db), t
         assert [ia[i]["counter"] for i in (0, N - 1)] == cb, t
     assert not a.error_flags.any()
+    if not slot:
+        # the ticket discipline: two outstanding at most, consumed in order, each once
+        a.policy_hash_rows(rows)
+        a.step_rows_device(rows)
+        t1 = a.step_outputs_async()
+        a.policy_hash_rows(rows)
+        a.step_rows_device(rows)
+        t2 = a.step_outputs_async()
+        with pytest.raises(pkg.PctEnvError):
+            a.step_outputs_async()  # a third one would overwrite t1's pinned buffer
+        with pytest.raises(pkg.PctEnvError):
+            t2.wait()               # out of order
+        t1.wait()
+        with pytest.raises(pkg.PctEnvError):
+            t1.wait()               # twice
+        t2.wait()
     if slot:
         a.unbind_rollout_slot()
     a.close()

@@ -219,6 +219,69 @@ def test_product_x87_dnrm2_equals_long_double():
         assert plain.gelsd_dnrm2(ctypes.c_int(n), p, ctypes.c_int(inc)) == var.gelsd_host_dnrm2(ctypes.c_int(n), p, ctypes.c_int(inc)), t
 
 
+def test_product_stability_matches_reference_plate_fixture():
+    """splits over 20 / 22 / 24 supporters (round 6: the cap is LAPACK's own SMLSIZ = 25, no longer 16) through the PRODUCT's
+    stability source compiled for the host, against the unmodified reference's recording (tests/golden/gen_plate_golden.py)"""
+    c, z = load_case("plate_discrete_s1")
+    items = [(i, j, k) for i in range(1, 6) for j in range(1, 6) for k in range(1, 6)]
+    with _Variant():
+        env = ol.OracleVecEnv(c["N"], setting=c["setting"], container_size=c["container"], item_set=items, internal_node_holder=c["I"],
+                              leaf_node_holder=c["L"], env_id_base=c["base"])
+        env.set_item_stream(z["stream"])
+        env.reset()
+        for t in range(c["steps"]):
+            assert np.array_equal(env.obs.astype(np.float32), z["obs"][t]), t
+            env.step_rows(z["actions"][t].astype(np.float64))
+            assert np.array_equal(env.done, z["done"][t]) and np.array_equal(env.reward, z["reward"][t]), t
+        assert np.array_equal(env.obs.astype(np.float32), z["obs"][c["steps"]])
+        assert not env.flags.any()
+        env.close()
+
+
+def test_product_certified_dnrm2_equals_x87_emulation():
+    """round 6: dnrm2 of up to eight elements by a double-double sum of squares + one corrected square root, taken only where a
+    distance-to-the-rounding-boundary certificate proves it equal to the x87 chain (pct_gelsd.cuh dnrm2_certified); everything else
+    still runs the integer emulation.  2 * 10^7 vectors of the value classes the stability systems hold."""
+    with _Variant():
+        var = ctypes.CDLL(VARIANT)
+    out = (ctypes.c_long * 3)()
+    var.gelsd_host_dnrm2_certified_sweep(ctypes.c_long(20_000_000), ctypes.c_ulonglong(2026), out)
+    vectors, certified, diff = out[0], out[1], out[2]
+    assert vectors == 20_000_000 and diff == 0, (vectors, certified, diff)
+    assert 0.80 * vectors < certified < 0.99 * vectors, certified  # (one class of seven is beyond the certificate's exponent range)
+
+
+def test_product_pow_is_glibc_pow():
+    """`tri_base_len ** 2` (C/space.py:108,206; D/space.py:112,210) is libm pow(len, 2.0), which is NOT len * len (glibc's pow is
+    not correctly rounded): csrc/pct_pow.cuh restates glibc's pow as its FMA build executes it.  Against the live libm: 1.2 * 10^7
+    lengths of the continuous env's lever rule (unit bin, and the 100-unit bin of BASELINE configs[4]) -- 0 differences, while
+    len * len differs on ~0.08 % of them; every length the discrete env can produce in bins up to 43 per axis (both np.dot
+    flavours): pow(len, 2.0) == len * len there, which is what the 5-bit-coordinate discrete kernels compute (bins up to 31), while
+    the 10-bit-coordinate kernels run the restatement (checked up to 1023 per axis); and 10^5 general (x, y) pairs."""
+    with _Variant():
+        var = ctypes.CDLL(VARIANT)
+    out = (ctypes.c_long * 3)()
+    for span, count in ((1.0, 8_000_000), (100.0, 4_000_000)):
+        var.pow_host_sweep_continuous(ctypes.c_long(count), ctypes.c_ulonglong(77 + int(span)), ctypes.c_double(span), out)
+        assert out[0] > 0.99 * count and out[1] == 0, (span, out[0], out[1])
+        assert out[2] > 0, "the sweep no longer sees pow(len, 2) != len * len: is libm's pow folded away?"
+    # the 5-bit-coordinate discrete kernels (bins up to 31 per axis) compute len * len: equal to pow on every length up to 43 per axis
+    var.pow_host_sweep_discrete(ctypes.c_int(43), out)
+    assert out[0] == 2 * (87 * 87 - 1) and out[1] == 0 and out[2] == 0, (out[0], out[1], out[2])
+    # larger bins (the 10-bit-coordinate kernels) run the restatement: pow != len * len from (39.5, 43.5) on
+    var.pow_host_sweep_discrete(ctypes.c_int(1023), out)
+    assert out[1] == 0 and out[2] > 0, (out[0], out[1], out[2])
+    var.pow_host.restype = ctypes.c_double
+    var.pow_host.argtypes = [ctypes.c_double, ctypes.c_double]
+    rng = np.random.default_rng(5)
+    xs = np.exp(rng.uniform(-8, 8, 100_000))
+    ys = rng.uniform(-4, 4, 100_000)
+    ys[::5] = 2.0
+    import math
+    for x, y in zip(xs.tolist(), ys.tolist()):
+        assert var.pow_host(x, y) == math.pow(x, y), (x, y)
+
+
 def test_product_gelsd_split_equals_recorded_numpy_solutions():
     """the product's split (geometry -> system -> dgelsd) on geometry whose dot products are exact in double on any machine
     (half-integer coordinates), against the oracle's restatement fed the same system -- which tests/test_gelsd_port.py pins to NumPy"""
@@ -281,6 +344,17 @@ def test_product_dbdsqr_equals_oracle_dbdsqr():
         i1 = plain.gelsd_dbdsqr(ctypes.c_int(n), ctypes.c_int(n), P(d), P(e), P(vt), ctypes.c_int(n), P(c), P(np.zeros(4 * n + 8)))
         i2 = var.gelsd_host_dbdsqr(ctypes.c_int(n), P(d2), P(e2), P(vt2), P(c2), P(np.zeros(4 * n + 8)))
         assert i1 == i2 and np.array_equal(d, d2) and np.array_equal(vt, vt2) and np.array_equal(c, c2), (t, n)
+
+
+def test_product_dbdsqr3_equals_generic_dbdsqr():
+    """round 6: dbdsqr for n = 3 with d, e and a sweep's rotations in registers and every index static (pct_gelsd.cuh dbdsqr3 -- what
+    the kernels run for three supporters, 94 % of the solves) against the generic LDS-resident routine, 2 * 10^6 random bidiagonals
+    (graded, reversed, split, with zero diagonal entries, with ties): every bit of d, VT, the rotated column and the return value"""
+    with _Variant():
+        var = ctypes.CDLL(VARIANT)
+    out = (ctypes.c_long * 2)()
+    var.gelsd_host_dbdsqr3_sweep(ctypes.c_long(2_000_000), ctypes.c_ulonglong(31), out)
+    assert out[0] == 2_000_000 and out[1] == 0, (out[0], out[1])
 
 
 @pytest.mark.parametrize("name", ["discrete_s1_ondomain_avx2", "discrete_s1_flat_lstsq_avx2"])

@@ -52,6 +52,40 @@ def test_hip_gelsd_matches_reference_fixture(name):
     env.close()
 
 
+@pytest.mark.parametrize("N_pad", [0, 60])
+def test_hip_matches_reference_plate_fixture(N_pad):
+    """Splits over MORE THAN 16 supporters (round 6): the unmodified reference under scripted 3-vector actions -- unit tiles, a plate
+    on 20 / 22 / 24 of them none of which holds its centre of mass, boxes on the plate (tests/golden/gen_plate_golden.py: 154
+    np.linalg.lstsq calls over 20 - 24 unknowns).  Such a split is a capacity of the normal pass (8 supporters) AND of round 5's retry
+    pass (16): the env is requeued and the retry pass solves it in its LDS workspace for up to 25 supporters -- LAPACK's own limit
+    for this path of dgelsd (SMLSIZ).  No flag, every observation the reference's.  N_pad: the same four envs among 60 ordinary ones
+    (the retry queue then holds them next to nothing / next to each other in other blocks)."""
+    c, z = load_case("plate_discrete_s1")
+    items = [(i, j, k) for i in range(1, 6) for j in range(1, 6) for k in range(1, 6)]
+    N = c["N"] + N_pad
+    stream = np.zeros((N,) + z["stream"].shape[1:], np.int32)
+    stream[:c["N"]] = z["stream"]
+    stream[c["N"]:] = make_stream(5, N_pad, z["stream"].shape[1], items) if N_pad else 0
+    env = _pkg().PctVecEnv(N, setting=c["setting"], container_size=c["container"], item_set=items, internal_node_holder=c["I"],
+                           leaf_node_holder=c["L"], env_id_base=c["base"], item_stream=stream, device="cuda:0")
+    obs = env.reset()
+    retried = 0
+    for t in range(c["steps"]):
+        assert np.array_equal(obs.cpu().numpy()[:c["N"]], z["obs"][t]), t
+        rows = np.zeros((N, 3), np.float32)
+        rows[:c["N"]] = z["actions"][t]
+        rows[c["N"]:, 1:] = (t % 7, (3 * t) % 7)   # the padding envs: unit-ish placements wherever (they may end episodes)
+        obs, reward, done, _ = env.step(rows)
+        retried += env.debug_retry_count()
+        assert np.array_equal(done.astype(np.uint8)[:c["N"]], z["done"][t]), t
+        assert np.array_equal(reward[:c["N"], 0].numpy(), z["reward"][t].astype(np.float32)), t
+    assert np.array_equal(obs.cpu().numpy()[:c["N"]], z["obs"][c["steps"]])
+    assert not (env.error_flags & 0x17).any(), env.error_flags[:c["N"]]  # no capacity flag anywhere (the notices 0x40 / 0x80 may be up)
+    assert not (env.error_flags[:c["N"]] & 0x3F).any()
+    assert retried > 0  # the wide splits went through the retry pass
+    env.close()
+
+
 @pytest.mark.parametrize("name", ["discrete_s1_ondomain_avx2", "discrete_s1_flat_lstsq_avx2"])
 def test_hip_gelsd_avx2_matches_reference_on_avx2_kernels(name):
     """PCT_LSTSQ_GELSD_AVX2: the reference as it runs on AVX2 hosts, AMD Zen included (tests/golden/gen_golden_avx2.py: NumPy's OpenBLAS
