@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpct_hip.so")
 # (slowest translation units first: they are handed to the worker pool in this order)
 SOURCES = ["pct_discrete_stab.hip", "pct_discrete_stab_mt.hip", "pct_discrete_u64_stab.hip", "pct_discrete_u64_stab_mt.hip",
-           "pct_continuous.hip", "pct_continuous_mt.hip", "pct_discrete.hip", "pct_discrete_mt.hip", "pct_discrete_u64.hip",
+           "pct_continuous.hip", "pct_continuous_mt.hip", "pct_continuous_pipe.hip", "pct_discrete.hip", "pct_discrete_mt.hip", "pct_discrete_u64.hip",
            "pct_discrete_u64_mt.hip", "pct_env.hip"]
 
 

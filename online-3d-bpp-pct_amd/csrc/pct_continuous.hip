@@ -105,7 +105,42 @@ struct CLds {
   uint32_t* mt;     // [624] MT19937 state of this env (strict NumPy-stream mode only)
   StabState st;     // settings 1 / 3: the env's stability state, resident for the whole transition (pct_stab.cuh) ...
   StabWave sw;      // ... and the wave's hull workspace + task queue
+  // two-wave candidate pipeline (p.pipe): control words, a ring of batch records, the producer's own de-duplication buckets
+  struct PipeCtl* pc;
+  uint64_t* ring_hash;  // [PIPE_K][64]
+  uint16_t* ring_g;     // [PIPE_K][64]
+  uint64_t* ring_mask;  // [PIPE_K]
+  uint32_t* pdd;        // [128]
 };
+// ---- the two-wave candidate pipeline (round 6; pct_continuous_pipe.hip) -----------------------------------------------------
+// C5 (100^3, 200 / 200): 51 KB of LDS per env = THREE one-wave workgroups per CU -- one of the four SIMDs idles, the other three
+// run one latency-bound wave each -- and 550 k of the 768 k cycles of an env-step are the candidate set: per batch of 64 tuples,
+// generation + CPython float hashes (82 k in all), exact in-batch de-duplication (167 k), then the insertion walks and the
+// table rebuilds (185 k + 115 k), strictly in batch order.  Only the insertion depends on the table; the front half does not.
+// So the env's workgroup gets a SECOND wave (on another SIMD of the same CU): it runs the pair loop, builds, hashes and
+// de-duplicates batch after batch and hands {generator ids, hashes, survivor mask} over through a two-slot ring in LDS; the
+// first wave takes the records in order and does what flush() does after its de-duplication.  Same batches, same order, same
+// table: the result is bit for bit the one-wave kernel's.  Everything else of the step runs on the first wave as before (the
+// second waits on an LDS ticket).  Hand-over = LDS words + workgroup-scope fences; inside either wave `__syncthreads()` is a
+// WAVE-level LDS fence (pct_continuous_pipe.hip redefines it: the two waves are never at the same barrier).
+struct PipeCtl {
+  int go;      // ticket of the set phase the first wave has opened (0: none yet, -1: the workgroup is done)
+  int prod;    // batch records produced in this phase
+  int cons;    // ... consumed (the producer keeps at most PIPE_K ahead)
+  int done;    // the producer has finished the phase (prod is final)
+  int abort;   // the consumer gave up (table overflow): stop producing
+  int E;       // EMS count
+  int kind;    // what the ticket asks the second wave for: PIPE_JOB_*
+  int a0, a1, a2;  // job arguments (GENEMS: a0 = the number of children)
+  double b0, b1, b2;  // the item
+  uint64_t mask;      // FEAS: the chunk's feasibility bits, back from the second wave
+};
+enum { PIPE_JOB_SET = 0 /* produce the candidate batches */, PIPE_JOB_ELIM = 1 /* GENEMS: the odd chunks of the children's elimination */,
+       PIPE_JOB_FEAS = 2 /* the feasibility bits of one 64-candidate chunk of list(set) (first index a0, list length a1, a2 boxes) */ };
+constexpr int PIPE_K = 2;
+constexpr size_t PIPE_CTL_BYTES = 128;
+static_assert(sizeof(PipeCtl) <= PIPE_CTL_BYTES, "PipeCtl outgrew its LDS slot");
+constexpr size_t PIPE_BYTES = PIPE_CTL_BYTES + (size_t)PIPE_K * (64 * 8 + 64 * 2 + 8) + 128 * 4;
 
 // words of the region shared by the hash table and the GENEMS children scratch
 __host__ __device__ __forceinline__ int cunion_words(const ContinuousParams& p) { return p.union_words; }
@@ -117,7 +152,7 @@ __host__ __device__ __forceinline__ size_t continuous_lds_base_bytes(const Conti
   size_t i32 = 6 * (size_t)p.ems_cap + (size_t)p.union_words + 4 * (size_t)p.I + 128 + (p.rng_numpy ? 624 : 0);
   size_t u16 = 128 + 64 + (((size_t)p.L + 1) & ~(size_t)1);
   if (p.shuffle && !p.table_global) u16 += 2 * (size_t)p.order_cap;
-  return (dbl * 8 + i32 * 4 + u16 * 2 + 16 + 15) & ~(size_t)15;
+  return ((dbl * 8 + i32 * 4 + u16 * 2 + 16 + 15) & ~(size_t)15) + (p.pipe ? PIPE_BYTES : 0);
 }
 
 __device__ __forceinline__ CLds carve(const ContinuousParams& p, unsigned char* base) {
@@ -140,6 +175,15 @@ __device__ __forceinline__ CLds carve(const ContinuousParams& p, unsigned char* 
   l.vp = h; h += 64;
   l.leafg = h; h += (p.L + 1) & ~1;
   l.fpri = reinterpret_cast<uint32_t*>(h);
+  l.pc = nullptr; l.ring_hash = nullptr; l.ring_g = nullptr; l.ring_mask = nullptr; l.pdd = nullptr;
+  if (p.pipe) {  // (the last PIPE_BYTES of the base region)
+    unsigned char* pb = base + continuous_lds_base_bytes(p) - PIPE_BYTES;
+    l.pc = reinterpret_cast<PipeCtl*>(pb); pb += PIPE_CTL_BYTES;
+    l.ring_hash = reinterpret_cast<uint64_t*>(pb); pb += (size_t)PIPE_K * 64 * 8;
+    l.ring_mask = reinterpret_cast<uint64_t*>(pb); pb += (size_t)PIPE_K * 8;
+    l.ring_g = reinterpret_cast<uint16_t*>(pb); pb += (size_t)PIPE_K * 64 * 2;
+    l.pdd = reinterpret_cast<uint32_t*>(pb);
+  }
   if (stab) {
     unsigned char* sbase = base + continuous_lds_base_bytes(p);
     l.st = stab_carve(sbase, p.I, p.sb.caps);
@@ -148,7 +192,7 @@ __device__ __forceinline__ CLds carve(const ContinuousParams& p, unsigned char* 
   return l;
 }
 
-#ifndef PCT_CONT_MT
+#if !defined(PCT_CONT_MT) && !defined(PCT_CONT_PIPE)  // (the translation unit that owns the non-template symbols)
 size_t continuous_lds_bytes(const ContinuousParams& p) {
   size_t b = PCT_LDS_STASH + continuous_lds_base_bytes(p);
   if (p.setting != 2) b += ((stab_state_bytes(p.I, p.sb.caps) + 15) & ~(size_t)15) + stab_wave_bytes(p.sb.caps);
@@ -300,69 +344,28 @@ struct CGeo {  // placed-box geometry for the stability code
     g[6] = bsz[0 * I + i]; g[7] = bsz[1 * I + i]; g[8] = bsz[2 * I + i];
   }
 };
-// C/space.py:441-487 GENEMS + :510-528 EliminateInscribedEMS.  l.emsk -> l.emsk.
-__device__ __forceinline__ void cgenems(const ContinuousParams& p, CLds& l, CRegs& r, int lane, const double loc[6]) {
-  // Survivors (EMS the box does not intersect) stay where they are in l.emsk until the end; only the
-  // children go to the scratch list (l.emsb, [6][scap], aliasing the idle hash table).  The pre-GENEMS
-  // list is containment-free and a child lies inside its parent, so a survivor can neither be deleted
-  // nor sit inside a child: each child is tested against the survivors and the other children (non-strict,
-  // on the pre-deletion list: identical children delete each other).  The reference compares the float64
-  // coordinates; they are all of the form lat2d(k), strictly increasing in k, so the lattice integers compare
-  // the same way.  The intersection and usability tests keep the reference's float64 arithmetic.
-  const int E = r.n_ems, cap = p.ems_cap, scap = p.union_words / 6;
-  const double lb = p.low_bound;
-  const double n0 = -loc[0], n1 = -loc[1], n2 = -loc[2];
-  uint32_t* const smask = l.dd;       // [2 per 64-EMS chunk] survivor bits (the de-duplication buckets are idle)
-  uint32_t* const kmask = l.dd + 64;  // [2 per 64-child chunk] children that survive the elimination
-  int C = 0;
-  for (int base = 0; base < E; base += 64) {
-    int i = base + lane;
-    bool live = i < E;
-    int k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0, k5 = 0;
-    if (live) {
-      k0 = l.emsk[0 * cap + i]; k1 = l.emsk[1 * cap + i]; k2 = l.emsk[2 * cap + i];
-      k3 = l.emsk[3 * cap + i]; k4 = l.emsk[4 * cap + i]; k5 = l.emsk[5 * cap + i];
-    }
-    const double x1 = lat2d(k0), y1 = lat2d(k1), z1 = lat2d(k2), x2 = lat2d(k3), y2 = lat2d(k4), z2 = lat2d(k5);
-    // np.around(np.minimum(item, EMS), 6): the rounded values decide (and give the child coordinates)
-    double q0 = around6(fmin(n0, -x1)), q1 = around6(fmin(n1, -y1)), q2 = around6(fmin(n2, -z1));
-    double q3 = around6(fmin(loc[3], x2)), q4 = around6(fmin(loc[4], y2)), q5 = around6(fmin(loc[5], z2));
-    bool inter = live && (q0 + q3 > 0) && (q1 + q4 > 0) && (q2 + q5 > 0);
-    uint64_t ms = __ballot(live && !inter);
-    if (lane == 0) { smask[(base >> 6) * 2] = (uint32_t)ms; smask[(base >> 6) * 2 + 1] = (uint32_t)(ms >> 32); }
-    double x3 = -q0, y3 = -q1, x4 = q3, y4 = q4, z4 = q5;  // intersect[:, 0:3] *= -1
-    bool uy = (y2 - y1 + 1e-6 >= lb), uz = (z2 - z1 + 1e-6 >= lb), ux = (x2 - x1 + 1e-6 >= lb);
-    bool c0 = inter && (x3 - x1 + 1e-6 >= lb) && uy && uz;  // [x1,y1,z1,x3,y2,z2]
-    bool c1 = inter && (x2 - x4 + 1e-6 >= lb) && uy && uz;  // [x4,y1,z1,x2,y2,z2]
-    bool c2 = inter && ux && (y3 - y1 + 1e-6 >= lb) && uz;  // [x1,y1,z1,x2,y3,z2]
-    bool c3 = inter && ux && (y2 - y4 + 1e-6 >= lb) && uz;  // [x1,y4,z1,x2,y2,z2]
-    bool c4 = inter && ux && uy && (z2 - z4 + 1e-6 >= lb);  // [x1,y1,z4,x2,y2,z2]
-    uint64_t m0 = __ballot(c0), m1 = __ballot(c1), m2 = __ballot(c2), m3 = __ballot(c3), m4 = __ballot(c4);
-    int pos = C + rank_below(m0) + rank_below(m1) + rank_below(m2) + rank_below(m3) + rank_below(m4);
-    const int kx3 = klat(x3), ky3 = klat(y3), kx4 = klat(x4), ky4 = klat(y4), kz4 = klat(z4);  // the rounded values' own k
-#define PCT_PUT(A, B, Cc, D, Ee, F)                                                                \
-  do {                                                                                            \
-    if (pos < scap) {                                                                             \
-      l.emsb[0 * scap + pos] = (A); l.emsb[1 * scap + pos] = (B); l.emsb[2 * scap + pos] = (Cc);  \
-      l.emsb[3 * scap + pos] = (D); l.emsb[4 * scap + pos] = (Ee); l.emsb[5 * scap + pos] = (F);  \
-    }                                                                                             \
-    pos++;                                                                                        \
-  } while (0)
-    if (c0) PCT_PUT(k0, k1, k2, kx3, k4, k5);
-    if (c1) PCT_PUT(kx4, k1, k2, k3, k4, k5);
-    if (c2) PCT_PUT(k0, k1, k2, k3, ky3, k5);
-    if (c3) PCT_PUT(k0, ky4, k2, k3, k4, k5);
-    if (c4) PCT_PUT(k0, k1, kz4, k3, k4, k5);
-#undef PCT_PUT
-    C += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3) + __popcll(m4);
-  }
-  if (C > scap) {
-    C = scap;
-    r.flags |= PCT_FLAG_EMS_OVERFLOW;
-  }
-  __syncthreads();
-  // which children survive
-  for (int base = 0; base < C; base += 64) {
+// pipe-side helpers: relaxed LDS words both waves poll (volatile: one ds_read per look), handed over under workgroup-scope fences
+__device__ __forceinline__ int pipe_ld(const int* w) { return __builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int*>(w)); }
+__device__ __forceinline__ void pipe_st(int* w, int v) { *reinterpret_cast<volatile int*>(w) = v; }
+// first wave: open a job for the second wave (its arguments are already in the control block) / wait until it has finished it
+__device__ __forceinline__ void pipe_post(PipeCtl* pc, int kind, int lane) {
+  if (lane == 0) { pipe_st(&pc->kind, kind); pipe_st(&pc->done, 0); }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) pipe_st(&pc->go, pipe_ld(&pc->go) + 1);
+}
+__device__ __forceinline__ void pipe_join(PipeCtl* pc) {
+  while (!pipe_ld(&pc->done)) __builtin_amdgcn_s_sleep(2);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// GENEMS, "which children survive": the chunks first, first + stride, ... of the C children in l.emsb against the survivors (smask) of the
+// E EMS in l.emsk and against each other; a chunk's verdicts go to its two kmask words.  Chunks are independent of each other
+// (everything they read is final), so the two waves of a pipeline workgroup take every other one.
+__device__ __forceinline__ void cgenems_elim(const ContinuousParams& p, CLds& l, int lane, int E, int C, int first, int stride) {
+  const int cap = p.ems_cap, scap = p.union_words / 6;
+  uint32_t* const smask = l.dd;
+  uint32_t* const kmask = l.dd + 64;
+  for (int base = 64 * first; base < C; base += 64 * stride) {
     int i = base + lane;
     bool live = i < C;
     int a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
@@ -439,6 +442,78 @@ __device__ __forceinline__ void cgenems(const ContinuousParams& p, CLds& l, CReg
     }
     if (lane == 0) { kmask[(base >> 6) * 2] = (uint32_t)mk; kmask[(base >> 6) * 2 + 1] = (uint32_t)(mk >> 32); }
   }
+}
+
+// C/space.py:441-487 GENEMS + :510-528 EliminateInscribedEMS.  l.emsk -> l.emsk.
+__device__ __forceinline__ void cgenems(const ContinuousParams& p, CLds& l, CRegs& r, int lane, const double loc[6], bool helper = false) {
+  // Survivors (EMS the box does not intersect) stay where they are in l.emsk until the end; only the
+  // children go to the scratch list (l.emsb, [6][scap], aliasing the idle hash table).  The pre-GENEMS
+  // list is containment-free and a child lies inside its parent, so a survivor can neither be deleted
+  // nor sit inside a child: each child is tested against the survivors and the other children (non-strict,
+  // on the pre-deletion list: identical children delete each other).  The reference compares the float64
+  // coordinates; they are all of the form lat2d(k), strictly increasing in k, so the lattice integers compare
+  // the same way.  The intersection and usability tests keep the reference's float64 arithmetic.
+  const int E = r.n_ems, cap = p.ems_cap, scap = p.union_words / 6;
+  const double lb = p.low_bound;
+  const double n0 = -loc[0], n1 = -loc[1], n2 = -loc[2];
+  uint32_t* const smask = l.dd;       // [2 per 64-EMS chunk] survivor bits (the de-duplication buckets are idle)
+  uint32_t* const kmask = l.dd + 64;  // [2 per 64-child chunk] children that survive the elimination
+  int C = 0;
+  for (int base = 0; base < E; base += 64) {
+    int i = base + lane;
+    bool live = i < E;
+    int k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0, k5 = 0;
+    if (live) {
+      k0 = l.emsk[0 * cap + i]; k1 = l.emsk[1 * cap + i]; k2 = l.emsk[2 * cap + i];
+      k3 = l.emsk[3 * cap + i]; k4 = l.emsk[4 * cap + i]; k5 = l.emsk[5 * cap + i];
+    }
+    const double x1 = lat2d(k0), y1 = lat2d(k1), z1 = lat2d(k2), x2 = lat2d(k3), y2 = lat2d(k4), z2 = lat2d(k5);
+    // np.around(np.minimum(item, EMS), 6): the rounded values decide (and give the child coordinates)
+    double q0 = around6(fmin(n0, -x1)), q1 = around6(fmin(n1, -y1)), q2 = around6(fmin(n2, -z1));
+    double q3 = around6(fmin(loc[3], x2)), q4 = around6(fmin(loc[4], y2)), q5 = around6(fmin(loc[5], z2));
+    bool inter = live && (q0 + q3 > 0) && (q1 + q4 > 0) && (q2 + q5 > 0);
+    uint64_t ms = __ballot(live && !inter);
+    if (lane == 0) { smask[(base >> 6) * 2] = (uint32_t)ms; smask[(base >> 6) * 2 + 1] = (uint32_t)(ms >> 32); }
+    double x3 = -q0, y3 = -q1, x4 = q3, y4 = q4, z4 = q5;  // intersect[:, 0:3] *= -1
+    bool uy = (y2 - y1 + 1e-6 >= lb), uz = (z2 - z1 + 1e-6 >= lb), ux = (x2 - x1 + 1e-6 >= lb);
+    bool c0 = inter && (x3 - x1 + 1e-6 >= lb) && uy && uz;  // [x1,y1,z1,x3,y2,z2]
+    bool c1 = inter && (x2 - x4 + 1e-6 >= lb) && uy && uz;  // [x4,y1,z1,x2,y2,z2]
+    bool c2 = inter && ux && (y3 - y1 + 1e-6 >= lb) && uz;  // [x1,y1,z1,x2,y3,z2]
+    bool c3 = inter && ux && (y2 - y4 + 1e-6 >= lb) && uz;  // [x1,y4,z1,x2,y2,z2]
+    bool c4 = inter && ux && uy && (z2 - z4 + 1e-6 >= lb);  // [x1,y1,z4,x2,y2,z2]
+    uint64_t m0 = __ballot(c0), m1 = __ballot(c1), m2 = __ballot(c2), m3 = __ballot(c3), m4 = __ballot(c4);
+    int pos = C + rank_below(m0) + rank_below(m1) + rank_below(m2) + rank_below(m3) + rank_below(m4);
+    const int kx3 = klat(x3), ky3 = klat(y3), kx4 = klat(x4), ky4 = klat(y4), kz4 = klat(z4);  // the rounded values' own k
+#define PCT_PUT(A, B, Cc, D, Ee, F)                                                                \
+  do {                                                                                            \
+    if (pos < scap) {                                                                             \
+      l.emsb[0 * scap + pos] = (A); l.emsb[1 * scap + pos] = (B); l.emsb[2 * scap + pos] = (Cc);  \
+      l.emsb[3 * scap + pos] = (D); l.emsb[4 * scap + pos] = (Ee); l.emsb[5 * scap + pos] = (F);  \
+    }                                                                                             \
+    pos++;                                                                                        \
+  } while (0)
+    if (c0) PCT_PUT(k0, k1, k2, kx3, k4, k5);
+    if (c1) PCT_PUT(kx4, k1, k2, k3, k4, k5);
+    if (c2) PCT_PUT(k0, k1, k2, k3, ky3, k5);
+    if (c3) PCT_PUT(k0, ky4, k2, k3, k4, k5);
+    if (c4) PCT_PUT(k0, k1, kz4, k3, k4, k5);
+#undef PCT_PUT
+    C += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3) + __popcll(m4);
+  }
+  if (C > scap) {
+    C = scap;
+    r.flags |= PCT_FLAG_EMS_OVERFLOW;
+  }
+  __syncthreads();
+  // which children survive (cgenems_elim); with a second wave at hand it takes the odd chunks
+  if (helper && C > 64) {
+    if (lane == 0) { l.pc->a0 = C; l.pc->E = E; }
+    pipe_post(l.pc, PIPE_JOB_ELIM, lane);
+    cgenems_elim(p, l, lane, E, C, 0, 2);
+    pipe_join(l.pc);
+  } else {
+    cgenems_elim(p, l, lane, E, C, 0, 1);
+  }
   __syncthreads();
   // survivors close ranks in place (a chunk is read whole before it is written, leftwards) ...
   int out = 0;
@@ -491,7 +566,108 @@ __device__ __forceinline__ void cgenems(const ContinuousParams& p, CLds& l, CReg
 // MT: strict NumPy-stream mode (np.random.shuffle drawn from the env's MT19937).  COUNT_ONLY (MT): the observation
 // a failed step builds and discards (C/bin3D.py:183) -- only its draws matter: the set is built for its size, the
 // shuffle's draws are consumed, nothing is written.
-template <bool GT, bool STAB, bool MT, bool COUNT_ONLY, typename TM>
+
+// drop_box_virtual of one 64-candidate chunk of list(set) (C/space.py:380-425), setting 2: lane = candidate order[base + lane]; returns the
+// chunk's feasibility bits.  (cleaf_nodes' `feasible` without the stability part -- the pipeline kernels are setting 2 -- as a function
+// of its own, so that both waves of a pipeline workgroup can run it on alternate chunks.)
+__device__ __forceinline__ uint64_t cfeas_chunk(const ContinuousParams& p, const CLds& l, const CRegs& r, int lane, const uint16_t* order,
+                                                  int base, int norder, int nb, int orient) {
+  const int i = base + lane;
+  const bool live = i < norder;
+  const uint32_t gid = live ? (uint32_t)order[i] : 0u;
+  double t[6];
+  cand_tuple(p, l, r, orient, gid, t);
+  const double lx = t[0], ly = t[1];
+  const double x = t[3] - t[0], y = t[4] - t[1], z = t[5] - t[2];
+  bool ok = live;
+  if (lx + x - 1e-6 > p.W || ly + y - 1e-6 > p.Ly) ok = false;
+  if (lx + 1e-6 < 0 || ly + 1e-6 < 0) ok = false;
+  const int c0 = klat(-lx), c1 = klat(-ly), c2 = klat(lx + x), c3 = klat(ly + y);
+  double max_h = 0.0;
+  if (live)
+    for (int b2 = 0; b2 < nb; b2++) {
+      const int u0 = l.bk[0 * p.I + b2], u1 = l.bk[1 * p.I + b2], u2 = l.bk[2 * p.I + b2], u3 = l.bk[3 * p.I + b2];
+      const bool ov = (min(c0, u0) + min(c2, u2) > 0) && (min(c1, u1) + min(c3, u3) > 0);
+      const double top = l.top[b2];
+      max_h = (ov && top > max_h) ? top : max_h;
+    }
+  if (max_h + z - 1e-6 > p.H) ok = false;
+  return __ballot(ok);
+}
+
+// The producer wave of the candidate pipeline: the pair loop, the pending queue and the front half of flush() -- tuples, CPython
+// hashes, exact in-batch de-duplication -- of cleaf_nodes below, batch by batch into the ring.
+__device__ __forceinline__ void cpipe_produce(const ContinuousParams& p, CLds& l, int lane) {
+  PipeCtl* const pc = l.pc;
+  CRegs r;
+  r.b0 = pc->b0; r.b1 = pc->b1; r.b2 = pc->b2;
+  const int E = pipe_ld(&pc->E), cap = p.ems_cap;
+  const int orient = (p.setting == 2) ? 6 : 2;
+  const int NP = E * orient;
+  int npend = 0, nprod = 0;
+  bool stop = false;
+  l.pdd[lane] = 0xFFFFFFFFu;
+  l.pdd[lane + 64] = 0xFFFFFFFFu;
+  __syncthreads();
+  auto emit = [&](int cnt) __attribute__((always_inline)) {
+    bool pending = lane < cnt;
+    const uint32_t g = pending ? (uint32_t)l.pend[lane] : 0u;
+    const uint16_t mv = (lane + 64 < npend) ? l.pend[lane + 64] : (uint16_t)0;
+    __syncthreads();
+    if (lane + 64 < npend) l.pend[lane] = mv;
+    npend -= cnt;
+    double t[6];
+    cand_tuple(p, l, r, orient, g, t);
+    const uint64_t hash = tuplehash6d(t);
+    __syncthreads();
+    pending = pending && !batch_find_duplicates_t6<128>(l.pdd, pending, hash, t, lane);
+    // a free slot of the ring (the consumer frees one as soon as it has the record in registers)
+    while (nprod - pipe_ld(&pc->cons) >= PIPE_K) {
+      if (pipe_ld(&pc->abort)) { stop = true; return; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    const int slot = nprod % PIPE_K;
+    l.ring_hash[slot * 64 + lane] = hash;
+    l.ring_g[slot * 64 + lane] = (uint16_t)g;
+    const uint64_t pm = __ballot(pending);
+    if (lane == 0) l.ring_mask[slot] = pm;
+    nprod++;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) pipe_st(&pc->prod, nprod);
+  };
+  for (int pbase = 0; pbase < NP && !stop; pbase += 64) {
+    const int q = pbase + lane;
+    bool pv = q < NP;
+    const int ei = q / orient, rot = q - ei * orient;
+    double sx, sy, sz;
+    const bool skip = crot_size(r, rot, sx, sy, sz);
+    if (pv) {
+      const double x0 = lat2d(l.emsk[0 * cap + ei]), y0 = lat2d(l.emsk[1 * cap + ei]), z0 = lat2d(l.emsk[2 * cap + ei]);
+      const double x1 = lat2d(l.emsk[3 * cap + ei]), y1 = lat2d(l.emsk[4 * cap + ei]), z1 = lat2d(l.emsk[5 * cap + ei]);
+      pv = !skip && (x1 - x0 + 1e-6 >= sx) && (y1 - y0 + 1e-6 >= sy) && (z1 - z0 + 1e-6 >= sz);
+    }
+    const uint64_t pm = __ballot(pv);
+    const int nt = 4 * __popcll(pm);
+    if (pv) l.vp[rank_below(pm)] = (uint16_t)q;
+    __syncthreads();
+    for (int tb = 0; tb < nt && !stop; tb += 64) {
+      const int tt = tb + lane;
+      const bool valid = tt < nt;
+      const uint32_t g = valid ? ((uint32_t)l.vp[tt >> 2] << 2 | (uint32_t)(tt & 3)) : 0u;
+      const uint64_t nm = __ballot(valid);
+      if (valid) l.pend[npend + rank_below(nm)] = (uint16_t)g;
+      npend += __popcll(nm);
+      __syncthreads();
+      if (npend >= 64) emit(64);
+    }
+    __syncthreads();
+  }
+  while (npend > 0 && !stop) emit(npend < 64 ? npend : 64);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) pipe_st(&pc->done, 1);
+}
+
+template <bool GT, bool STAB, bool MT, bool COUNT_ONLY, typename TM, bool PIPE = false>
 __device__ __forceinline__ bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CRegs& r, int lane, TM& tm) {
   const int E = r.n_ems, cap = p.ems_cap;
   const int orient = (p.setting == 2) ? 6 : 2;
@@ -516,21 +692,8 @@ __device__ __forceinline__ bool cleaf_nodes(const ContinuousParams& p, int e, CL
   int npend = 0;
   tm.sub_start();
 
-  auto flush = [&](int cnt) __attribute__((always_inline)) {
-    bool pending = lane < cnt;
-    uint32_t g = pending ? (uint32_t)l.pend[lane] : 0u;
-    uint16_t mv = (lane + 64 < npend) ? l.pend[lane + 64] : (uint16_t)0;
-    __syncthreads();
-    if (lane + 64 < npend) l.pend[lane] = mv;
-    npend -= cnt;
-    tm.sub_tick(PH_SET_GEN);
-    double t[6];
-    cand_tuple(p, l, r, orient, g, t);
-    uint64_t hash = tuplehash6d(t);
-    __syncthreads();
-    // exact in-batch de-duplication (first occurrence stays): the first holder's tuple comes over cross-lane reads
-    pending = pending && !batch_find_duplicates_t6<128>(l.dd, pending, hash, t, lane);
-    tm.sub_tick(PH_SET_DEDUP);
+  // the back half of a batch: the de-duplicated tuples (generator id g, hash, coordinates t) enter the set, in lane order
+  auto consume = [&](bool pending, uint32_t g, uint64_t hash, const double (&t)[6]) __attribute__((always_inline)) {
     if (fill == 0 && size == 8 && p.cand_cap >= 512) {
       const uint64_t pm0 = __ballot(pending);
       if (__popcll(pm0) >= 19) {
@@ -764,6 +927,61 @@ __device__ __forceinline__ bool cleaf_nodes(const ContinuousParams& p, int e, CL
     }
   };
 
+  auto flush = [&](int cnt) __attribute__((always_inline)) {
+    bool pending = lane < cnt;
+    uint32_t g = pending ? (uint32_t)l.pend[lane] : 0u;
+    uint16_t mv = (lane + 64 < npend) ? l.pend[lane + 64] : (uint16_t)0;
+    __syncthreads();
+    if (lane + 64 < npend) l.pend[lane] = mv;
+    npend -= cnt;
+    tm.sub_tick(PH_SET_GEN);
+    double t[6];
+    cand_tuple(p, l, r, orient, g, t);
+    uint64_t hash = tuplehash6d(t);
+    __syncthreads();
+    // exact in-batch de-duplication (first occurrence stays): the first holder's tuple comes over cross-lane reads
+    pending = pending && !batch_find_duplicates_t6<128>(l.dd, pending, hash, t, lane);
+    tm.sub_tick(PH_SET_DEDUP);
+    consume(pending, g, hash, t);
+  };
+
+  if (PIPE) {
+    // consumer side of the two-wave pipeline: open the phase for the producer wave, then take its batch records in order
+    PipeCtl* const pc = l.pc;
+    if (lane == 0) {
+      pc->E = E; pc->b0 = r.b0; pc->b1 = r.b1; pc->b2 = r.b2;
+      pipe_st(&pc->prod, 0); pipe_st(&pc->cons, 0); pipe_st(&pc->abort, 0);
+    }
+    pipe_post(pc, PIPE_JOB_SET, lane);
+    int ncons = 0;
+    while (true) {
+      int pr;
+      while (true) {
+        pr = pipe_ld(&pc->prod);
+        if (pr > ncons) break;
+        if (pipe_ld(&pc->done)) { pr = pipe_ld(&pc->prod); break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (pr <= ncons) break;  // the producer is through and every record has been taken
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const int slot = ncons % PIPE_K;
+      const uint64_t hash = l.ring_hash[slot * 64 + lane];
+      const uint32_t g = (uint32_t)l.ring_g[slot * 64 + lane];
+      const uint64_t pm = l.ring_mask[slot];
+      ncons++;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // (the record is in registers: the slot is free)
+      if (lane == 0) pipe_st(&pc->cons, ncons);
+      tm.add(ST_GENERATED, (uint64_t)__popcll(pm));
+      double t[6];
+      cand_tuple(p, l, r, orient, g, t);  // (the coordinates again, for the equality tests of the insertion)
+      consume((pm >> lane) & 1ull, g, hash, t);
+      if (cand_overflow) break;
+    }
+    if (cand_overflow) {  // stop the producer and wait until it has left the phase (it reads the EMS list)
+      if (lane == 0) pipe_st(&pc->abort, 1);
+      while (!pipe_ld(&pc->done)) __builtin_amdgcn_s_sleep(2);
+    }
+  } else {
   for (int pbase = 0; pbase < NP && !cand_overflow; pbase += 64) {
     int q = pbase + lane;
     bool pv = q < NP;
@@ -796,6 +1014,7 @@ __device__ __forceinline__ bool cleaf_nodes(const ContinuousParams& p, int e, CL
     __syncthreads();
   }
   while (npend > 0 && !cand_overflow) flush(npend < 64 ? npend : 64);
+  }
   if (cand_overflow) {
     // the table outgrew this launch's capacity: hand the env to the large-capacity pass
     // (state untouched) if there is one, else record the overflow
@@ -917,6 +1136,33 @@ __device__ __forceinline__ bool cleaf_nodes(const ContinuousParams& p, int e, CL
       if (live && rank < p.L) l.leafg[rank] = tab_ld<GT, uint16_t>(&order[a2]);
     }
     nleaf = nf;
+  } else if (PIPE && !GT && !STAB) {
+    // two chunks of list(set) at a time: the second wave tests the odd one while this wave tests the even one; merged in list order
+    PipeCtl* const pc = l.pc;
+    for (int base = 0; base < norder && nleaf < p.L; base += 128) {
+      const bool two = base + 64 < norder;
+      if (two) {
+        if (lane == 0) { pc->a0 = base + 64; pc->a1 = norder; pc->a2 = nb; pc->b0 = r.b0; pc->b1 = r.b1; pc->b2 = r.b2; }
+        pipe_post(pc, PIPE_JOB_FEAS, lane);
+      }
+      const uint64_t m0 = cfeas_chunk(p, l, r, lane, order, base, norder, nb, orient);
+      {
+        const int i = base + lane;
+        const int idx = nleaf + rank_below(m0);
+        if (((m0 >> lane) & 1ull) && idx < p.L) l.leafg[idx] = order[i];
+        nleaf += __popcll(m0);
+      }
+      if (two) {
+        pipe_join(pc);
+        const uint64_t m1 = pc->mask;
+        if (nleaf < p.L) {
+          const int i = base + 64 + lane;
+          const int idx = nleaf + rank_below(m1);
+          if (((m1 >> lane) & 1ull) && idx < p.L) l.leafg[idx] = order[i];
+          nleaf += __popcll(m1);
+        }
+      }
+    }
   } else {
     for (int base = 0; base < norder && nleaf < p.L; base += 64) {
       int i = base + lane;
@@ -1156,7 +1402,8 @@ __device__ __forceinline__ void cstore(const ContinuousParams& p, int e, const C
 // observation's candidate set outgrew this launch's table -- requeue
 template <bool GT, bool STAB, bool MT, typename TM>
 __device__ __forceinline__ int ctransition(const ContinuousParams& p, int e, CLds& l, CRegs& r, int lane, int flag, double a1,
-                                   double a2, double bx, double by, double bz, TM& tm, double newbox[6], bool giveup = false) {
+                                   double a2, double bx, double by, double bz, TM& tm, double newbox[6], bool giveup = false,
+                                   bool helper = false) {
   r.t++;
   const double lx = around6(a1), ly = around6(a2);  // idx = [round(action[1], 6), round(action[2], 6)]
   const double x = flag ? by : bx, y = flag ? bx : by, z = bz;  // C/space.py:330-333
@@ -1241,7 +1488,7 @@ __device__ __forceinline__ int ctransition(const ContinuousParams& p, int e, CLd
     tm.tick(PH_DROP);
     // GENEMS([lx, ly, lz, round(lx+x,6), round(ly+y,6), round(lz+z,6)]) (C/bin3D.py:190-194)
     const double loc[6] = {lx, ly, max_h, around6(lx + x), around6(ly + y), around6(max_h + z)};
-    cgenems(p, l, r, lane, loc);
+    cgenems(p, l, r, lane, loc, helper);
     tm.tick(PH_GENEMS);
     reward = (float)(((r.b0 * r.b1 * r.b2) / mx) * 10);
     done = 0;
@@ -1539,7 +1786,7 @@ __device__ __forceinline__ void cdecode_leaf(const CRegs& r, bool zero_row, doub
 
 enum { CACT_ROWS = 0, CACT_INDEX = 1, CACT_HASH = 2, CACT_RESET = 3, CACT_HEUR = 4 /* row_len = PCT_HEUR_* */ };
 
-template <int ACT, bool TIMED, bool GT, bool STAB, bool MT>
+template <int ACT, bool TIMED, bool GT, bool STAB, bool MT, bool PIPE = false>
 #ifndef PCT_CONT_WAVES
 #define PCT_CONT_WAVES 2 /* waves per SIMD the plain kernel is compiled for.  The kernel needs 217 VGPRs: at two waves per SIMD (256) nothing
                             spills; at three (168; C3's 14.2 KB of LDS would admit 11 envs per CU instead of 8) 32 VGPRs spill.  Round 4
@@ -1552,12 +1799,14 @@ template <int ACT, bool TIMED, bool GT, bool STAB, bool MT>
 #ifndef PCT_STAB_WAVES
 #define PCT_STAB_WAVES 1 /* waves per SIMD the stability-check kernels are compiled for (2: 256 VGPRs, ~470 of them spilled -- slower, profiles/r03_stability_tuning.txt) */
 #endif
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TIMED ? 1 : (STAB ? PCT_STAB_WAVES : PCT_CONT_WAVES))))
+__global__ void __launch_bounds__(PIPE ? 128 : 64) __attribute__((amdgpu_waves_per_eu(TIMED ? 1 : (STAB ? PCT_STAB_WAVES : PCT_CONT_WAVES))))
 pct_continuous_kernel(ContinuousParams p_arg, const void* actions,
                                                             int row_len, int n_steps,
                                                             const int32_t* __restrict__ env_ids, int n_ids) {
   extern __shared__ __align__(16) unsigned char smem[];
-  const int lane = threadIdx.x;
+  // (pipe: two waves per env -- wave 0 steps the env, wave 1 serves the candidate pipeline of its set phases)
+  const int lane = PIPE ? (int)(threadIdx.x & 63u) : (int)threadIdx.x;
+  const int wave = PIPE ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
 #if PCT_KERNARG_PTR
   // the parameter block is read where it is used, from the kernarg segment (pct_device.h pct_param_fence)
   const ContinuousParams& p = *(const ContinuousParams*)pct_param_fence((PctConstParams<ContinuousParams>)__builtin_amdgcn_kernarg_segment_ptr());
@@ -1585,6 +1834,41 @@ pct_continuous_kernel(ContinuousParams p_arg, const void* actions,
   if (e < 0 || e >= p.N) continue;
   work_key_begin(smem);
   CLds l = carve(p, smem + PCT_LDS_STASH);
+  if (PIPE) {
+    // the ticket word starts at 0 for both waves (the only real workgroup barrier of the kernel: s_barrier, not the
+    // wave-level fence __syncthreads() stands for in this translation unit); the pipe launcher runs ONE env per workgroup
+    if (threadIdx.x == 0) pipe_st(&l.pc->go, 0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (wave == 1) {
+      int last = 0;
+      while (true) {
+        int t;
+        while ((t = pipe_ld(&l.pc->go)) == last) __builtin_amdgcn_s_sleep(4);
+        if (t < 0) break;
+        last = t;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int kind = pipe_ld(&l.pc->kind);
+        if (kind == PIPE_JOB_ELIM) {
+          cgenems_elim(p, l, lane, pipe_ld(&l.pc->E), pipe_ld(&l.pc->a0), 1, 2);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if (lane == 0) pipe_st(&l.pc->done, 1);
+        } else if (kind == PIPE_JOB_FEAS) {
+          CRegs rr;
+          rr.b0 = l.pc->b0; rr.b1 = l.pc->b1; rr.b2 = l.pc->b2;
+          const uint64_t m = cfeas_chunk(p, l, rr, lane, reinterpret_cast<const uint16_t*>(l.tab), pipe_ld(&l.pc->a0), pipe_ld(&l.pc->a1),
+                                         pipe_ld(&l.pc->a2), (p.setting == 2) ? 6 : 2);
+          if (lane == 0) l.pc->mask = m;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if (lane == 0) pipe_st(&l.pc->done, 1);
+        } else {
+          cpipe_produce(p, l, lane);
+        }
+      }
+      return;
+    }
+  }
   CRegs r;
   PhaseTimer<TIMED> tm;
   tm.start();
@@ -1600,6 +1884,10 @@ pct_continuous_kernel(ContinuousParams p_arg, const void* actions,
   if (requeue) {
     retry_enqueue(p.retry_count, p.retry_ids, e);
     __syncthreads();
+    if (PIPE) {  // release the producer wave
+      if (lane == 0) pipe_st(&l.pc->go, -1);
+      break;
+    }
     continue;
   }
 
@@ -1612,7 +1900,7 @@ pct_continuous_kernel(ContinuousParams p_arg, const void* actions,
     } else {
       cdraw_item(p, e, r);
     }
-    requeue = cleaf_nodes<GT, STAB, MT, false>(p, e, l, r, lane, tm);
+    requeue = cleaf_nodes<GT, STAB, MT, false, PhaseTimer<TIMED>, PIPE>(p, e, l, r, lane, tm);
     if (STAB && r.stab_over) {
       if (can_retry) requeue = true;
       else r.flags |= PCT_FLAG_STABILITY_OVERFLOW | r.stab_over;
@@ -1682,11 +1970,11 @@ pct_continuous_kernel(ContinuousParams p_arg, const void* actions,
       cdecode_leaf(r, zero_row, a0, a1, a3, a4, p1, p2, bx, by, bz);
     }
     double newbox[6] = {0, 0, 0, 0, 0, 0};
-    const int tr = ctransition<GT, STAB, MT>(p, e, l, r, lane, flag, p1, p2, bx, by, bz, tm, newbox, giveup);
+    const int tr = ctransition<GT, STAB, MT>(p, e, l, r, lane, flag, p1, p2, bx, by, bz, tm, newbox, giveup, PIPE);
     if (tr == 2) { requeue = true; break; }
     const bool ended = tr != 0;
     if (can_retry && ((r.flags & ~flags_in) & PCT_FLAG_EMS_OVERFLOW)) { requeue = true; break; }
-    requeue = cleaf_nodes<GT, STAB, MT, false>(p, e, l, r, lane, tm);
+    requeue = cleaf_nodes<GT, STAB, MT, false, PhaseTimer<TIMED>, PIPE>(p, e, l, r, lane, tm);
     // a stability capacity exceeded (pools, workspace, queue -- in the commit or in a virtual check): the step goes, state
     // untouched (the stability state is LDS-resident, nothing of it has been stored), to the large-capacity pass
     if (STAB && r.stab_over) {
@@ -1708,10 +1996,15 @@ pct_continuous_kernel(ContinuousParams p_arg, const void* actions,
   if (requeue) retry_enqueue(p.retry_count, p.retry_ids, e);
   work_key_end(smem, p.scalars, p.N, e, ACT == CACT_RESET, r.n_ems);
   __syncthreads();
+  if (PIPE) {  // release the producer wave
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) pipe_st(&l.pc->go, -1);
+    break;
+  }
   }  // work items
 }
 
-#ifndef PCT_CONT_MT
+#if !defined(PCT_CONT_MT) && !defined(PCT_CONT_PIPE)
 // stand-in policy kernel on the float32 observation (same as the discrete one)
 __global__ void __launch_bounds__(64) pct_cpolicy_hash_rows_kernel(ContinuousParams p, float* __restrict__ rows_out) {
   const int lane = threadIdx.x;
@@ -1744,10 +2037,37 @@ hipError_t launch_cpolicy_hash_rows(const ContinuousParams& p, float* rows_out, 
 #define PCT_CONT_LAUNCH launch_continuous
 #define PCT_CONT_MTV false
 #endif
+#ifdef PCT_CONT_PIPE
+// the two-wave pipeline kernels: the normal pass of setting 2 with the table in LDS, one env per 128-thread workgroup
+hipError_t launch_continuous_pipe(const ContinuousParams& p, int act, const void* actions, int row_len, int n_steps, const int32_t* env_ids,
+                                  int n_ids, hipStream_t stream) {
+  const size_t lds = continuous_lds_bytes(p);
+  const int grid = p.N;
+  if (grid <= 0) return hipSuccess;
+  void (*kern)(ContinuousParams, const void*, int, int, const int32_t*, int) = nullptr;
+  switch (act) {
+    case CACT_ROWS: kern = pct_continuous_kernel<CACT_ROWS, false, false, false, false, true>; break;
+    case CACT_INDEX: kern = pct_continuous_kernel<CACT_INDEX, false, false, false, false, true>; break;
+    case CACT_HASH: kern = pct_continuous_kernel<CACT_HASH, false, false, false, false, true>; break;
+    case CACT_RESET: kern = pct_continuous_kernel<CACT_RESET, false, false, false, false, true>; break;
+    default: return hipErrorNotSupported;
+  }
+  if (lds > 48 * 1024) {
+    hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (er != hipSuccess) return er;
+  }
+  hipExtLaunchKernelGGL(kern, dim3(grid), dim3(128), lds, stream, (hipEvent_t)p.launch_ev_start, (hipEvent_t)p.launch_ev_stop, 0, p, actions,
+                        row_len, n_steps, env_ids, n_ids);
+  return hipGetLastError();
+}
+#else
 hipError_t PCT_CONT_LAUNCH(const ContinuousParams& p, int act, const void* actions, int row_len, int n_steps,
                            const int32_t* env_ids, int n_ids, hipStream_t stream) {
 #ifndef PCT_CONT_MT
   if (p.rng_numpy) return launch_continuous_mt(p, act, actions, row_len, n_steps, env_ids, n_ids, stream);
+  // the two-wave candidate pipeline (pct_continuous_pipe.hip): the whole-batch normal pass of setting 2 with the table in LDS
+  if (p.pipe && !p.retry_mode && p.setting == 2 && !p.table_global && p.timing == nullptr && act != CACT_HEUR && !(act == CACT_RESET && env_ids))
+    return launch_continuous_pipe(p, act, actions, row_len, n_steps, env_ids, n_ids, stream);
 #endif
   size_t lds = continuous_lds_bytes(p);
   const bool timed = !PCT_CONT_MTV && p.timing != nullptr && act != CACT_RESET;
@@ -1799,5 +2119,6 @@ hipError_t PCT_CONT_LAUNCH(const ContinuousParams& p, int act, const void* actio
 #undef PCT_CLAUNCH_PICK
   return hipGetLastError();
 }
+#endif  // PCT_CONT_PIPE
 
 }  // namespace pct

@@ -141,6 +141,8 @@ struct ContinuousParams {
   uint16_t* gorder; /* [N, order_cap] */
   uint32_t* gfpri;  /* [N, order_cap] shuffle priorities (HBM-table variant + shuffle) */
   int gt_by_block;  /* HBM table slices indexed by blockIdx (retry pass) instead of env */
+  int pipe;         /* 1: the normal pass runs the two-wave candidate pipeline (pct_continuous_pipe.hip; setting 2, LDS table): a second
+                       wave of the env's workgroup generates, hashes and de-duplicates the candidate batches while the first inserts them */
   uint32_t* gpark;  /* [N, PCT_PARK_WORDS] LDS table of 8192 slots: the 2048-slot table's entries wait here, dense and in slot order, while
                        the ONE LDS region both sizes share is wiped (round 5: the 100^3 env's table left HBM) */
   int prio_t[3];    /* wave_priority thresholds on the EMS count (0: off) */
@@ -238,6 +240,8 @@ __device__ __forceinline__ double next_density(const Params& p, int e, uint32_t 
 
 size_t continuous_lds_bytes(const ContinuousParams& p);
 hipError_t launch_cpolicy_hash_rows(const ContinuousParams& p, float* rows_out, hipStream_t stream);
+hipError_t launch_continuous_pipe(const ContinuousParams& p, int act, const void* actions, int row_len, int n_steps, const int32_t* env_ids,
+                                  int n_ids, hipStream_t stream);
 hipError_t launch_continuous_mt(const ContinuousParams& p, int act, const void* actions, int row_len, int n_steps,
                                 const int32_t* env_ids, int n_ids, hipStream_t stream);
 hipError_t launch_continuous(const ContinuousParams& p, int act, const void* actions, int row_len, int n_steps,

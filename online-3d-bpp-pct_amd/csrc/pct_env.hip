@@ -539,6 +539,10 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
     c.cand_cap = cand_cap;
     c.order_cap = (cand_cap * 3) / 5 + 8;
     c.table_global = cand_cap > 8192 ? 1 : 0; /* beyond 8192 slots the table cannot share LDS with the EMS */
+    /* the two-wave candidate pipeline (pct_continuous_pipe.hip): on where the LDS -- not the registers -- bounds the resident envs
+     * (the 8192-slot LDS table of the large bins: three envs per CU, one wave each, a SIMD idle), off for the small bins, whose
+     * one-wave workgroups already fill the SIMDs' wave slots.  PCT_PIPE = 0 / 1 (kernel experiments) overrides for any LDS table. */
+    c.pipe = (cfg->setting == 2 && !c.table_global) ? knob_int("PCT_PIPE", cand_cap > 2048 ? 1 : 0, 0, 1) : 0;
     /* the LDS region shared by the hash table (one region for every table size up to 2048 slots; a 8192-slot
      * table sits behind the 2048-slot one it grows from) and the GENEMS children scratch (6 int32 words per
      * child): 2 * ems_cap children when the table lives in LDS (225 pre-elimination entries were seen at C3),
@@ -584,6 +588,7 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
       pct::ContinuousParams t = c;
       t.ems_cap = big;
       t.table_global = 1;
+      t.pipe = 0;
       t.union_words = 12 * big;
       while (big > ems_cap && pct::continuous_lds_bytes(t) > 150 * 1024) {
         big -= ems_cap;
@@ -635,6 +640,7 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
       h->cp_retry = c;
       pct::ContinuousParams& q = h->cp_retry;
       q.retry_mode = 1;
+      q.pipe = 0;
       q.table_global = 1;
       q.gt_by_block = 1;
       q.cand_cap = big;

@@ -719,9 +719,11 @@ PCT_GD void dlascl_vec(Grp g, double cfrom, double cto, int n, double* x) {
 // whole matrix (ll = 1, m = 3: a sweep over x0 x1 x2 / y0 y1 in chase order, idir 1 = top down, 2 = bottom up) or a 2 x 2 corner
 // (dlasv2).  So d0 d1 d2 e0 e1 are five REGISTERS for the whole routine, the rotations of a sweep stay in the registers of the lane
 // that computed them (every lane of the group runs the scalar chain anyway), and a lane touches only ITS columns of VT / cc (three
-// loads in flight, the sweep's rotations, three stores): no hand-over inside the routine.  (A first version for n <= 4 with run-time
-// positions through select chains was SLOWER than the LDS routine -- 45 k against 34 k cycles, profiles/r06_experiments.txt -- as
-// round 5 had found for the whole solve.)  Operation for operation the generic routine (same tests, same order, same expressions):
+// loads in flight, the sweep's rotations, three stores): no hand-over inside the routine: 27 k cycles.  (A first version for n <= 4
+// with run-time positions through select chains was SLOWER than the LDS routine -- 45 k against 34 k cycles -- as round 5 had found
+// for the whole solve; a version for n = 4 .. 6 that keeps d, e in LDS but reads them in two batches of independent loads per
+// iteration gained 5 - 10 % (71 -> 67 k, 102 -> 92 k): what is left is the division / square-root chain of the rotations themselves,
+// ~22 of them per iteration at ~150 cycles.  Neither is in the library; profiles/r06_experiments.txt.)  Operation for operation the generic routine (same tests, same order, same expressions):
 // tests/test_stab_host.py compares the two on 2 * 10^6 random bidiagonals, and both with the oracle's dbdsqr.
 PCT_GD bool dbdsqr3(Grp g, double* d, double* e, double* vt, double* cc) {
   const int n = 3, ldvt = 3;

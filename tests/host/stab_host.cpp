@@ -83,9 +83,9 @@ int gelsd_host_split(int k, const double* centres, double s0, double s1, double*
   return ok;
 }
 double gelsd_host_dnrm2(int n, const double* x, int incx) { return pct::gelsd::dnrm2(n, x, incx); }
-// dbdsqr3 (d, e, the sweep's rotations in registers; n = 3) against the generic routine: `count` random bidiagonals of the kinds
-// tests/test_stab_host.py::test_product_dbdsqr_equals_oracle_dbdsqr draws.  out[0] = systems, out[1] = differences (any bit of d, VT,
-// cc or the return value).
+// dbdsqr3 (n = 3: d, e, the sweep's rotations in registers, every index static) against the generic routine: `count` random
+// bidiagonals of the kinds tests/test_stab_host.py::test_product_dbdsqr_equals_oracle_dbdsqr draws.
+// out[0] = systems, out[1] = differences (any bit of d, VT, cc or the return value).
 void gelsd_host_dbdsqr3_sweep(long count, unsigned long long seed, long* out) {
   unsigned long long s = seed;
   auto rnd = [&]() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (double)(s >> 11) / 9007199254740992.0; };
@@ -102,6 +102,7 @@ void gelsd_host_dbdsqr3_sweep(long count, unsigned long long seed, long* out) {
     if (t % 5 == 0) e[(int)(rnd() * (n - 1))] = 0.0;
     if (t % 7 == 0) d[(int)(rnd() * n)] = 0.0;
     if (t % 11 == 0) for (int i = 0; i < n; i++) d[i] = rint(d[i] * 4) / 4;  // ties in the ordering
+    if (t % 13 == 0) for (int i = 0; i < n - 1; i++) e[i] *= 1e-9;             // nearly diagonal: the convergence tests fire
     for (int i = 0; i < n * n; i++) vt[i] = (i / n == i % n) ? 1.0 : 0.0;
     memcpy(d2, d, sizeof d); memcpy(e2, e, sizeof e); memcpy(vt2, vt, sizeof vt); memcpy(c2, c, sizeof c);
     const bool ra = pct::gelsd::dbdsqr3(one, d, e, vt, c);

@@ -358,6 +358,27 @@ def test_hip_continuous_matches_reference_fixture(name, mode):
     env.close()
 
 
+@pytest.mark.parametrize("name,pipe", [("continuous_s2_10_80_50", "1"), ("continuous_s2_rect_60_20", "1"), ("continuous_s2_100_200_200", "0")])
+def test_hip_continuous_candidate_pipeline_on_and_off(name, pipe, monkeypatch):
+    """Round 6: the two-wave candidate pipeline (csrc/pct_continuous_pipe.hip: a second wave of the env's workgroup generates, hashes
+    and de-duplicates the candidate batches while the first inserts them) is the default where the 8192-slot LDS table bounds the
+    resident envs -- every large-bin fixture above runs it.  Here the other way round: forced ON for the small-bin fixtures (2048-slot
+    table, rebuilds through registers), forced OFF for the 100^3 one (the one-wave kernel of rounds 1-5).  Same observations."""
+    monkeypatch.setenv("PCT_EXPERIMENT", "1")
+    monkeypatch.setenv("PCT_PIPE", pipe)
+    c, z = load_case(name)
+    big = max(c["container"]) > 16
+    env = _make_cont(c, z["stream"], ems_capacity=640 if big else 0, candidate_capacity=8192 if big else 0)
+    obs = env.reset()
+    for t in range(c["steps"]):
+        assert np.array_equal(obs.cpu().numpy(), z["obs"][t].astype(np.float32)), (name, t)
+        env.step_hash_policy(1)
+        obs, reward, done, infos = env.step_wait()
+        assert np.array_equal(done.astype(np.uint8), z["done"][t]), (name, t)
+    assert not env.error_flags.any()
+    env.close()
+
+
 def test_hip_continuous_hbm_table_variant_matches_fixture():
     """candidate_capacity > 8192 moves the hash table and the list(set) order to HBM (the
     C5-scale path): same results as the LDS-resident table."""

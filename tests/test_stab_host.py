@@ -349,7 +349,8 @@ def test_product_dbdsqr_equals_oracle_dbdsqr():
 def test_product_dbdsqr3_equals_generic_dbdsqr():
     """round 6: dbdsqr for n = 3 with d, e and a sweep's rotations in registers and every index static (pct_gelsd.cuh dbdsqr3 -- what
     the kernels run for three supporters, 94 % of the solves) against the generic LDS-resident routine, 2 * 10^6 random bidiagonals
-    (graded, reversed, split, with zero diagonal entries, with ties): every bit of d, VT, the rotated column and the return value"""
+    (graded, reversed, split, nearly diagonal, with zero diagonal entries, with ties): every bit of d, VT, the rotated column and the
+    return value"""
     with _Variant():
         var = ctypes.CDLL(VARIANT)
     out = (ctypes.c_long * 2)()
