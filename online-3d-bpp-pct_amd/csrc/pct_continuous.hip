@@ -137,7 +137,10 @@ struct PipeCtl {
 };
 enum { PIPE_JOB_SET = 0 /* produce the candidate batches */, PIPE_JOB_ELIM = 1 /* GENEMS: the odd chunks of the children's elimination */,
        PIPE_JOB_FEAS = 2 /* the feasibility bits of one 64-candidate chunk of list(set) (first index a0, list length a1, a2 boxes) */ };
-constexpr int PIPE_K = 2;
+#ifndef PCT_PIPE_K
+#define PCT_PIPE_K 2 /* ring depth: batches the producer may run ahead (3: 2.98 -> see profiles/r06_experiments.txt) */
+#endif
+constexpr int PIPE_K = PCT_PIPE_K;
 constexpr size_t PIPE_CTL_BYTES = 128;
 static_assert(sizeof(PipeCtl) <= PIPE_CTL_BYTES, "PipeCtl outgrew its LDS slot");
 constexpr size_t PIPE_BYTES = PIPE_CTL_BYTES + (size_t)PIPE_K * (64 * 8 + 64 * 2 + 8) + 128 * 4;

@@ -56,6 +56,16 @@ struct DiscreteParams {
                             other counter of the ping-pong pair, which it zeroes for the next step) */
   int* retry_count;      /* this step's counter of envs queued by the normal pass, or null: no retry pass */
   int* retry_ids;        /* [N] */
+  /* Round 6: the retry pass INSIDE the launch (pct_discrete_tail_kernel, the plain setting-2 kernels): tail_blocks extra workgroups
+   * behind the N of the normal pass wait until those have all left (tail_done: 64 sub-counters, workgroup b adds to b mod 64), then
+   * re-run the queued envs with the retry pass's capacities, their lists in a per-workgroup row of HBM (tail_scratch) instead of LDS.
+   * One dispatch per step instead of two: the dependent-dispatch gap of the (normally idle) retry kernel was 5 us of C2's 61. */
+  int tail_blocks;             /* 0: no in-launch tail (a separate retry dispatch follows) */
+  int tail_rm;                 /* +64 / -64: offset of the OTHER step's sub-counters in the ping-pong pair (the tail zeroes them) */
+  int* tail_done;              /* [64] this step's sub-counters of finished normal-pass workgroups */
+  unsigned char* tail_scratch; /* [tail_blocks][tail_scratch_bytes] */
+  int tail_scratch_bytes;
+  const DiscreteParams* tail_q; /* HOST pointer (never read on the device): the retry pass's parameter block, handed to the tail kernel by value */
   int key_bytes; /* 4: six 5-bit coords (bins <= 31); 8: six 10-bit coords (<= 1023) */
   // item source
   int source, n_items, env_id_base;
@@ -224,6 +234,9 @@ __device__ __forceinline__ void obs_st(float* q, float v) {
 // the flag does not lift the barrier on gfx950 and the counter cost the normal pass 1 us, profiles/r04_experiments.txt.)
 __device__ __forceinline__ void retry_enqueue(int* count, int* ids, int e) {
   if (threadIdx.x == 0) ids[atomicAdd(count, 1)] = e;
+  // (round 6: the retry pass may run as the TAIL of this very launch, on another XCD: the entry is released at agent scope before
+  // the workgroup reports itself finished -- pct_discrete_tail_kernel; a rare path, the fence costs an ordinary step nothing)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 }
 
 template <typename Params>
@@ -249,6 +262,12 @@ hipError_t launch_continuous(const ContinuousParams& p, int act, const void* act
 
 size_t discrete_lds_bytes(const DiscreteParams& p);
 hipError_t launch_policy_hash_rows(const DiscreteParams& p, float* rows_out, hipStream_t stream);
+// which launches run the retry pass as their own tail (pct_discrete_tail_kernel) -- the host (pct_env.hip: no separate retry dispatch
+// then) and the launcher must agree: the plain setting-2 transition of a whole batch, LNES = EMS, counter-keyed draws, untimed
+inline bool discrete_tail_eligible(const DiscreteParams& p, int act, const int32_t* env_ids) {
+  return p.tail_blocks > 0 && p.setting == 2 && p.lnes == PCT_LNES_EMS && !p.shuffle && !p.rng_numpy && p.timing == nullptr && !p.retry_mode &&
+         env_ids == nullptr && (act == 0 /* ACT_ROWS */ || act == 1 /* ACT_INDEX */ || act == 2 /* ACT_HASH */);
+}
 hipError_t launch_discrete(const DiscreteParams& p, int act, const void* actions, int row_len, int n_steps,
                            const int32_t* env_ids, int n_ids, hipStream_t stream);
 

@@ -2497,6 +2497,8 @@ pct_discrete_kernel(DiscreteParams p_arg, const void* actions,
       p.retry_count[rm] = 0;
       if (limit > 0 && p.retry_total) { p.retry_total[0] += limit; p.retry_total[1] += 1; }
     }
+    // (a handle whose plain steps run the retry pass as the tail of their own launch: its sub-counters of the other step, too)
+    if (blockIdx.x == 0 && p.tail_done) p.tail_done[p.tail_rm + (int)threadIdx.x] = 0;
   }
   int w = blockIdx.x;
   while (true) {
@@ -2522,6 +2524,66 @@ pct_discrete_kernel(DiscreteParams p_arg, const void* actions,
     __syncthreads();
     w += gridDim.x;
   }
+}
+
+
+// ---- one dispatch per step: the retry pass as the TAIL of the normal pass's launch (round 6) -----------------------------------
+// The plain setting-2 transition (LNES = EMS, counter-keyed draws, no shuffle): workgroups 0 .. N - 1 are the normal pass (as
+// pct_discrete_kernel), workgroups N .. N + R - 1 the retry pass -- dispatched last, they wait until the N others have left (64
+// sub-counters, one lane polls each), then stride over the queue with the retry pass's capacities (`q`: the parameter block the
+// separate retry dispatch would get), their "LDS" lists in a per-workgroup row of HBM.  The transition is inlined a second
+// time for that (generic address space): cold code that an ordinary step never enters.  What it buys: the 16-block retry kernel
+// that follows every transition otherwise -- idle, but a dependent dispatch -- was 5.5 us of C2's 61.8 us step.
+template <typename K, int BITS, int ACT>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
+pct_discrete_tail_kernel(DiscreteParams p_arg, const void* actions, int row_len, int n_steps, DiscreteParams q_arg) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const char __attribute__((address_space(4)))* const ka = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+  const DiscreteParams& p = *(const DiscreteParams*)pct_param_fence((PctConstParams<DiscreteParams>)ka);
+  constexpr size_t q_off = (sizeof(DiscreteParams) + sizeof(void*) + 2 * sizeof(int) + 7) & ~(size_t)7;
+  (void)p_arg; (void)q_arg;
+  if ((int)blockIdx.x >= p.N) {
+    // ---- the retry pass -------------------------------------------------------------------------------------------------
+    const DiscreteParams& q = *(const DiscreteParams*)pct_param_fence((PctConstParams<DiscreteParams>)(ka + q_off));
+    const int tb = (int)blockIdx.x - p.N, R = (int)gridDim.x - p.N;
+    const int lane = threadIdx.x;
+    while (true) {  // every normal-pass workgroup has added one to its sub-counter when it left
+      int c = __hip_atomic_load(&p.tail_done[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
+      if (c >= p.N) break;
+      __builtin_amdgcn_s_sleep(16);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const int limit = __hip_atomic_load(p.retry_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tb == 0) {  // the OTHER step's counters (the next launch's, which cannot start before this kernel ends)
+      p.tail_done[p.tail_rm + lane] = 0;
+      if (lane == 0) {
+        p.retry_count[p.tail_rm > 0 ? 1 : -1] = 0;
+        if (limit > 0 && p.retry_total) { p.retry_total[0] += limit; p.retry_total[1] += 1; }
+      }
+    }
+    unsigned char* const base = p.tail_scratch + (size_t)tb * (size_t)p.tail_scratch_bytes;
+    for (int w = tb; w < limit; w += R) {
+      const int e = __builtin_amdgcn_readfirstlane(p.retry_ids[w]);
+      work_key_begin(smem);
+      int n_ems = 0;
+      discrete_env_steps<K, BITS, ACT, false, false, 0, 0>(q, actions, row_len, n_steps, e, base, n_ems);
+      work_key_end(smem, p.scalars, p.N, e, false, n_ems);
+      __syncthreads();
+    }
+    return;
+  }
+  // ---- the normal pass --------------------------------------------------------------------------------------------------
+  int e = blockIdx.x;
+  if (p.order) e = __builtin_amdgcn_readfirstlane(p.order[e]);
+  work_key_begin(smem);
+  int n_ems = 0;
+  discrete_env_steps<K, BITS, ACT, false, false, 0, 0>(p, actions, row_len, n_steps, e, smem, n_ems);
+  work_key_end(smem, p.scalars, p.N, e, false, n_ems);
+  // (an env this workgroup queued: retry_enqueue has released its queue entry at agent scope; a workgroup that queued nothing has
+  // nothing to publish -- what a queued env had already written, reward / done / counter, the tail writes again, identically)
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(&p.tail_done[blockIdx.x & 63], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace pct
@@ -2596,6 +2658,20 @@ inline hipError_t launch_typed(const DiscreteParams& p, int act, const void* act
     hipExtLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, stream, (hipEvent_t)p.launch_ev_start, (hipEvent_t)p.launch_ev_stop,
                           0, p, actions, row_len, n_steps, env_ids, n_ids);
     return hipGetLastError();
+    }
+  }
+  if constexpr (!STAB && !MTSEL) {
+    if (discrete_tail_eligible(p, act, env_ids) && p.tail_q) {
+      // one dispatch: the normal pass + the retry pass as its tail (pct_discrete_tail_kernel); q = the retry pass's parameter block
+      void (*kern)(DiscreteParams, const void*, int, int, DiscreteParams) = nullptr;
+      switch (act) {
+        case ACT_ROWS: kern = pct_discrete_tail_kernel<K, BITS, ACT_ROWS>; break;
+        case ACT_INDEX: kern = pct_discrete_tail_kernel<K, BITS, ACT_INDEX>; break;
+        default: kern = pct_discrete_tail_kernel<K, BITS, ACT_HASH>; break;
+      }
+      hipExtLaunchKernelGGL(kern, dim3(p.N + p.tail_blocks), dim3(64), lds, stream, (hipEvent_t)p.launch_ev_start,
+                            (hipEvent_t)p.launch_ev_stop, 0, p, actions, row_len, n_steps, *p.tail_q);
+      return hipGetLastError();
     }
   }
   switch (act) {

@@ -65,6 +65,9 @@ struct pct_env {
   int* c_retry_base;    /* continuous env: the same */
   int c_retry_parity;
   int d_retry_blocks;   /* grid of the discrete retry pass */
+  int* d_tail_base;     /* [2][64] ping-pong sub-counters of finished normal-pass workgroups (the retry pass as the launch's own tail) */
+  size_t d_tail_lds;    /* bytes of one tail workgroup's HBM row = the retry pass's LDS layout */
+  int d_tail_blocks;    /* tail workgroups of a launch that carries its retry pass (0: never) */
   bool continuous;
   // owned device memory
   std::vector<void*> owned;
@@ -319,24 +322,39 @@ int launch(pct_env* h, int act, const void* actions, int row_len, int n_steps, c
     }
     if (act != ACT_RESET || !ids) h->dp.full_obs = 0;
   } else {
+    pct::DiscreteParams q;
+    h->dp.tail_q = nullptr;
     if (h->has_dretry) { /* ping-pong pair of queue counters: this step's is h->d_retry_base[parity] */
       h->dp.retry_count = h->d_retry_base + h->d_retry_parity;
-    }
-    {
-      const hipError_t le = pct::launch_discrete(h->dp, act, actions, row_len, n_steps, ids, n_ids, s);
-      if (le != hipSuccess) return launch_failed(h, timed && normal_grid > 0, le, "launch_discrete");
-    }
-    if (h->has_dretry) {
-      /* the same step again, with larger LDS lists, for the envs the normal pass queued (usually none: the
-       * small grid then exits at once) */
-      pct::DiscreteParams q = h->dp;
+      if (h->d_tail_base) {
+        h->dp.tail_done = h->d_tail_base + 64 * h->d_retry_parity;
+        h->dp.tail_rm = h->d_retry_parity ? -64 : 64;
+        /* one dispatch per step where every env is resident at once (C2: +1.3 %, 72.3 against 71.4 M env-steps/s); a launch that
+         * holds more envs than the chip (heavy-first dispatch on: C4) keeps the separate retry dispatch -- there the tail's second
+         * inlined transition costs the common path more than the dispatch gap it saves (101.5 against 102.9 M): profiles/r06_experiments.txt */
+        h->dp.tail_blocks = (h->order_state == 1 && !knob("PCT_TAIL")) ? 0 : h->d_tail_blocks;
+      }
+      /* the same step again, with larger lists, for the envs the normal pass queued (usually none) */
+      q = h->dp;
       q.ems_cap = h->d_retry_ems;
       q.cand_cap = h->d_retry_cand;
       q.sb.caps = h->d_retry_stab;
       q.retry_mode = h->d_retry_parity ? -1 : 1;
       q.timing = nullptr;
       q.launch_ev_start = q.launch_ev_stop = nullptr;
-      HIP_TRY(pct::launch_discrete(q, act, actions, row_len, n_steps, nullptr, h->d_retry_blocks, s));
+      q.tail_blocks = 0;
+      h->dp.tail_q = &q; /* (read by the launcher only if this launch carries the retry pass as its own tail) */
+    }
+    const bool tail = h->has_dretry && pct::discrete_tail_eligible(h->dp, act, ids);
+    {
+      const hipError_t le = pct::launch_discrete(h->dp, act, actions, row_len, n_steps, ids, n_ids, s);
+      h->dp.tail_q = nullptr;
+      if (le != hipSuccess) return launch_failed(h, timed && normal_grid > 0, le, "launch_discrete");
+    }
+    if (h->has_dretry) {
+      /* ... as a small grid-strided dispatch of its own (the grid exits at once when nothing was queued) -- unless the
+       * launch above carried it as its tail (pct_discrete_tail_kernel: one dispatch per step) */
+      if (!tail) HIP_TRY(pct::launch_discrete(q, act, actions, row_len, n_steps, nullptr, h->d_retry_blocks, s));
       h->d_retry_parity ^= 1;
     }
     if (act != ACT_RESET || !ids) h->dp.full_obs = 0; /* every env has rewritten its rows */
@@ -747,7 +765,7 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
   ALLOC(p.boxes, N * p.I * p.key_bytes);
   ALLOC(p.leaves, N * p.L * p.key_bytes);
   ALLOC(p.scalars, N * (PCT_SCALARS + 1) * sizeof(int32_t)); /* (+ the [N] work keys of the heavy-first dispatch) */
-  ALLOC(p.set_scratch, N * 768 * sizeof(uint32_t)); /* pct_discrete_impl.cuh WS_KMAX: one row per workgroup of any pass */
+  ALLOC(p.set_scratch, (N + 1024) * 768 * sizeof(uint32_t)); /* pct_discrete_impl.cuh WS_KMAX: one row per workgroup of any pass (the tail's included) */
   if (cfg->setting != 2) {
     ALLOC(p.sb.stk, N * p.I * 4 * sizeof(double));
     ALLOC(p.sb.den, N * p.I * sizeof(double));
@@ -762,6 +780,21 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
     p.retry_total = h->d_retry_base + 2;
     p.retry_count = h->d_retry_base;
     h->d_retry_parity = 0;
+    /* Round 6: the plain setting-2 steps run the retry pass as the TAIL of their own launch (pct_discrete_tail_kernel): its
+     * workgroups keep the retry pass's LDS layout in a row of HBM each.  PCT_TAIL=0 (kernel experiments): two dispatches */
+    if (cfg->setting == 2 && knob_int("PCT_TAIL", 1, 0, 1)) {
+      pct::DiscreteParams t = p;
+      t.ems_cap = h->d_retry_ems;
+      t.cand_cap = h->d_retry_cand;
+      h->d_tail_lds = (pct::discrete_lds_bytes(t) + 255) & ~(size_t)255;
+      h->d_tail_blocks = h->d_retry_blocks;
+      p.tail_blocks = h->d_tail_blocks;
+      p.tail_scratch_bytes = (int)h->d_tail_lds;
+      ALLOC(h->d_tail_base, 2 * 64 * sizeof(int));
+      ALLOC(p.tail_scratch, (size_t)p.tail_blocks * h->d_tail_lds);
+      p.tail_done = h->d_tail_base;
+      p.tail_rm = 64;
+    }
     ALLOC(p.retry_ids, N * sizeof(int));
   }
   ALLOC(h->own_flags, N * sizeof(uint32_t));
