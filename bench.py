@@ -162,7 +162,7 @@ def reference_baseline(w):
 
 def pmc_profile(name, envs):
     """Counter values per launch from the committed rocprofv3 PMC passes of this workload, or None."""
-    for tag in ("r05", "r04", "r03", "r02"):  # the newest committed profile of this workload
+    for tag in ("r06", "r05", "r04", "r03", "r02"):  # the newest committed profile of this workload
         rel = "profiles/%s_pmc_%s.json" % (tag, name)
         path = os.path.join(ROOT, rel)
         if not os.path.exists(path):
@@ -465,9 +465,18 @@ def main():
         gt = "true" if cc > 8192 else "false"
         kernel_name = ("void pct::pct_continuous_kernel<%d, false, %s, %s, false>(pct::ContinuousParams, void const*, int, int, "
                        "int const*, int)" % (act, gt, stab))
+        if w["setting"] == 2 and cc == 8192:
+            # round 6: the two-wave candidate pipeline (csrc/pct_continuous_pipe.hip) is the normal pass wherever the 8192-slot LDS table is
+            kernel_name = ("void pct::pct_continuous_kernel<%d, false, false, false, false, true>(pct::ContinuousParams, void const*, int, "
+                           "int, int const*, int)" % act)
     else:
         kernel_name = ("void pct::pct_discrete_kernel<unsigned int, 5, %d, false, %s, 0, 0>(pct::DiscreteParams, void const*, "
                        "int, int, int const*, int)" % (act, stab))
+        if w["setting"] == 2 and not args.no_overflow_retry and n_grp <= 4096:
+            # round 6: where every env is resident at once the launch carries the retry pass as its own tail workgroups
+            # (pct_discrete_tail_kernel: one dispatch per step); its duration is the normal pass + the tail's hand-over
+            kernel_name = ("void pct::pct_discrete_tail_kernel<unsigned int, 5, %d>(pct::DiscreteParams, void const*, int, int, "
+                           "pct::DiscreteParams)" % (1 if args.mode == "slot" else act))
 
     kernel_src = "assembled from the template arguments (no committed kernel-stats CSV of this workload names it)"
     traced, traced_path = traced_kernel_name(args.workload, kernel_name.split("(")[0].replace("void ", ""))

@@ -18,7 +18,9 @@ suf = os.environ.get("PROFILE_SUFFIX", "")
 src = os.path.join(ROOT, "gpurun_out", "prof_%s_%s%s" % (tag, wl, suf))
 dst = os.environ.get("PCT_PROFILE_DST") or os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
-KERNEL = "pct_continuous_kernel" if wl in ("c3", "c5", "c3s1") else "pct_discrete_kernel"
+# the step kernel's name: pct_discrete_kernel / pct_continuous_kernel, or -- round 6 -- pct_discrete_tail_kernel where the launch
+# carries the retry pass as its own tail workgroups (the plain setting-2 steps of a batch that is resident at once: c2)
+KERNEL = "pct_continuous_kernel" if wl in ("c3", "c5", "c3s1") else "pct_discrete_%kernel"
 
 out = {"tag": tag, "workload": wl, "envs_per_launch": envs,
        "command": "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --workload %s --steps %d --warmup 200; "
@@ -69,7 +71,7 @@ for sub in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
         by_d.setdefault(n, {})[did] = v
     for n, dv in by_d.items():
         ids = sorted(dv)
-        per_step = len(ids) / (2.0 * psteps)  # warm-up + timed steps (+ reset)
+        per_step = len(ids) / (2.0 * psteps)  # warm-up + timed steps (+ reset); 1 where the step is one dispatch, 2 with a retry dispatch
         k = max(1, int(round(per_step)))
         m = max(1, psteps // 2)
         last = ids[-m * k:]

@@ -10,7 +10,7 @@ REPO=$PWD
 OUT=$PWD/gpurun_out/prof_${TAG}_${WL}${PROFILE_SUFFIX:-}
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python $PWD/bench.py --no-cpu-baseline --no-rows-line --workload $WL $BENCH_EXTRA"  # (BENCH_EXTRA: e.g. --lstsq jacobi, --mode slot)
+BENCH="python $PWD/bench.py --no-cpu-baseline --no-rows-line --repeats 1 --workload $WL $BENCH_EXTRA"  # (one timed region: collect_profiles.py counts dispatches per step)  # (BENCH_EXTRA: e.g. --lstsq jacobi, --mode slot)
 SUF=${PROFILE_SUFFIX:-}  # names the variant in the file names (e.g. _jacobi)
 cd /tmp
 # 1. kernel trace + stats over the same command as the bench line

@@ -1,6 +1,6 @@
 """GPU soak: HIP path vs the CPU oracle on millions of env-steps (fused stand-in policy, counter
 sampler), comparing observations every `check_every` steps and done/reward every step.
-python scripts/soak_parity.py [discrete_s2|discrete_s1|continuous_s2|continuous_s1|cp|fc] [envs] [steps]
+python scripts/soak_parity.py [discrete_s2|discrete_s1|continuous_s2|continuous_s1|continuous_c5|cp|fc] [envs] [steps]
 PCT_LSTSQ=gelsd|gelsd_avx2|jacobi selects the stability settings' solver on BOTH sides (default: gelsd, the library's default)."""
 import importlib, os, sys, time
 import numpy as np, torch
@@ -18,7 +18,13 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 400
 items = item_set_range(1, 5)
 threads = min(os.cpu_count() or 1, 64)
-if which.startswith("continuous"):
+if which == "continuous_c5":
+    # BASELINE configs[4] per env: 100^3 bin, 200 / 200 nodes, items U(5, 25) -- the two-wave candidate pipeline's workload
+    env = pkg.PctVecEnv(N, setting=2, container_size=(100, 100, 100), continuous=True, sample_left_bound=5.0, sample_right_bound=25.0,
+                        internal_node_holder=200, leaf_node_holder=200, seed=17, device="cuda:0", strict=False)
+    ora = OracleVecEnv(N, setting=2, container_size=(100, 100, 100), env_kind=1, sample_bounds=(5.0, 25.0), internal_node_holder=200,
+                       leaf_node_holder=200, threads=threads)
+elif which.startswith("continuous"):
     setting = 1 if which.endswith("s1") else 2
     # setting 1 draws z from {0.1..0.5} (C/bin3D.py:110-112), which is meant for the unit bin (givenData.py:5)
     bin_, lo, hi = ((1, 1, 1), 0.1, 0.5) if setting == 1 else ((10, 10, 10), 1.0, 5.0)
