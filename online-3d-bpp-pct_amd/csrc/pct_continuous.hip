@@ -671,7 +671,7 @@ __device__ __forceinline__ void cpipe_produce(const ContinuousParams& p, CLds& l
 }
 
 template <bool GT, bool STAB, bool MT, bool COUNT_ONLY, typename TM, bool PIPE = false>
-__device__ __forceinline__ bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CRegs& r, int lane, TM& tm) {
+__device__ __forceinline__ bool cleaf_nodes(const ContinuousParams& p, int e, CLds& l, CRegs& r, int lane, TM& tm, bool helper = PIPE) {
   const int E = r.n_ems, cap = p.ems_cap;
   const int orient = (p.setting == 2) ? 6 : 2;
   const int NP = E * orient;
@@ -948,7 +948,7 @@ __device__ __forceinline__ bool cleaf_nodes(const ContinuousParams& p, int e, CL
     consume(pending, g, hash, t);
   };
 
-  if (PIPE) {
+  if (PIPE && helper) {
     // consumer side of the two-wave pipeline: open the phase for the producer wave, then take its batch records in order
     PipeCtl* const pc = l.pc;
     if (lane == 0) {
@@ -1139,7 +1139,7 @@ __device__ __forceinline__ bool cleaf_nodes(const ContinuousParams& p, int e, CL
       if (live && rank < p.L) l.leafg[rank] = tab_ld<GT, uint16_t>(&order[a2]);
     }
     nleaf = nf;
-  } else if (PIPE && !GT && !STAB) {
+  } else if (PIPE && !GT && !STAB && helper) {
     // two chunks of list(set) at a time: the second wave tests the odd one while this wave tests the even one; merged in list order
     PipeCtl* const pc = l.pc;
     for (int base = 0; base < norder && nleaf < p.L; base += 128) {
@@ -1845,6 +1845,7 @@ pct_continuous_kernel(ContinuousParams p_arg, const void* actions,
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if (wave == 1) {
+      if (p.pipe == 2 && p.scalars[(size_t)e * PCT_SCALARS] < p.pipe_min_ems) return;  // (a light env: one wave steps it)
       int last = 0;
       while (true) {
         int t;
@@ -1878,6 +1879,8 @@ pct_continuous_kernel(ContinuousParams p_arg, const void* actions,
   cload(p, e, l, r, lane);
   tm.tick(PH_LOAD);
   wave_priority(r.n_ems, p.prio_t);
+  // (pipe = 2: the second wave has stayed only if the env entered the step with pipe_min_ems EMS -- the count both waves read)
+  const bool helper = PIPE && !(p.pipe == 2 && r.n_ems < p.pipe_min_ems);
   float* obs = p.obs + (size_t)e * p.row_len;
   // an env whose EMS list outgrows this launch's LDS list -- already at load, or in this step's GENEMS -- goes,
   // state untouched, to the large-capacity pass, like one whose candidate set outgrows the table
@@ -1903,7 +1906,7 @@ pct_continuous_kernel(ContinuousParams p_arg, const void* actions,
     } else {
       cdraw_item(p, e, r);
     }
-    requeue = cleaf_nodes<GT, STAB, MT, false, PhaseTimer<TIMED>, PIPE>(p, e, l, r, lane, tm);
+    requeue = cleaf_nodes<GT, STAB, MT, false, PhaseTimer<TIMED>, PIPE>(p, e, l, r, lane, tm, helper);
     if (STAB && r.stab_over) {
       if (can_retry) requeue = true;
       else r.flags |= PCT_FLAG_STABILITY_OVERFLOW | r.stab_over;
@@ -1973,11 +1976,11 @@ pct_continuous_kernel(ContinuousParams p_arg, const void* actions,
       cdecode_leaf(r, zero_row, a0, a1, a3, a4, p1, p2, bx, by, bz);
     }
     double newbox[6] = {0, 0, 0, 0, 0, 0};
-    const int tr = ctransition<GT, STAB, MT>(p, e, l, r, lane, flag, p1, p2, bx, by, bz, tm, newbox, giveup, PIPE);
+    const int tr = ctransition<GT, STAB, MT>(p, e, l, r, lane, flag, p1, p2, bx, by, bz, tm, newbox, giveup, helper);
     if (tr == 2) { requeue = true; break; }
     const bool ended = tr != 0;
     if (can_retry && ((r.flags & ~flags_in) & PCT_FLAG_EMS_OVERFLOW)) { requeue = true; break; }
-    requeue = cleaf_nodes<GT, STAB, MT, false, PhaseTimer<TIMED>, PIPE>(p, e, l, r, lane, tm);
+    requeue = cleaf_nodes<GT, STAB, MT, false, PhaseTimer<TIMED>, PIPE>(p, e, l, r, lane, tm, helper);
     // a stability capacity exceeded (pools, workspace, queue -- in the commit or in a virtual check): the step goes, state
     // untouched (the stability state is LDS-resident, nothing of it has been stored), to the large-capacity pass
     if (STAB && r.stab_over) {

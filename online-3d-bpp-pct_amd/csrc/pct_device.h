@@ -152,7 +152,11 @@ struct ContinuousParams {
   uint32_t* gfpri;  /* [N, order_cap] shuffle priorities (HBM-table variant + shuffle) */
   int gt_by_block;  /* HBM table slices indexed by blockIdx (retry pass) instead of env */
   int pipe;         /* 1: the normal pass runs the two-wave candidate pipeline (pct_continuous_pipe.hip; setting 2, LDS table): a second
-                       wave of the env's workgroup generates, hashes and de-duplicates the candidate batches while the first inserts them */
+                       wave of the env's workgroup generates, hashes and de-duplicates the candidate batches while the first inserts them;
+                       2: ... for the envs that enter the step with at least pipe_min_ems EMS only -- the second wave of every other
+                       workgroup leaves at once (the small-bin configs: the registers bound the resident envs there, and the launch is
+                       as long as its EMS-richest env) */
+  int pipe_min_ems;
   uint32_t* gpark;  /* [N, PCT_PARK_WORDS] LDS table of 8192 slots: the 2048-slot table's entries wait here, dense and in slot order, while
                        the ONE LDS region both sizes share is wiped (round 5: the 100^3 env's table left HBM) */
   int prio_t[3];    /* wave_priority thresholds on the EMS count (0: off) */

@@ -560,7 +560,8 @@ int pct_create(const pct_config* cfg, int device, pct_env** out) {
     /* the two-wave candidate pipeline (pct_continuous_pipe.hip): on where the LDS -- not the registers -- bounds the resident envs
      * (the 8192-slot LDS table of the large bins: three envs per CU, one wave each, a SIMD idle), off for the small bins, whose
      * one-wave workgroups already fill the SIMDs' wave slots.  PCT_PIPE = 0 / 1 (kernel experiments) overrides for any LDS table. */
-    c.pipe = (cfg->setting == 2 && !c.table_global) ? knob_int("PCT_PIPE", cand_cap > 2048 ? 1 : 0, 0, 1) : 0;
+    c.pipe = (cfg->setting == 2 && !c.table_global) ? knob_int("PCT_PIPE", cand_cap > 2048 ? 1 : 0, 0, 2) : 0;
+    c.pipe_min_ems = knob_int("PCT_PIPE_MIN_EMS", 32, 0, 4096); /* pipe = 2 (experiment): a second wave for the EMS-rich envs only */
     /* the LDS region shared by the hash table (one region for every table size up to 2048 slots; a 8192-slot
      * table sits behind the 2048-slot one it grows from) and the GENEMS children scratch (6 int32 words per
      * child): 2 * ems_cap children when the table lives in LDS (225 pre-elimination entries were seen at C3),

@@ -53,6 +53,20 @@ def _mix32_torch(g, t):
     return h ^ (h >> 16)
 
 
+def hash_policy_index_steps(k, base):
+    """[T,N] leaf indices of the stand-in policy: mix32(base + e, t) % k[t, e] (0 where no leaf is valid) -- include/pct_env.h pct_mix32"""
+    T, N = k.shape
+    M = np.uint64(0xFFFFFFFF)
+    g = (np.arange(N, dtype=np.uint64) + np.uint64(base))[None, :]
+    t = np.arange(T, dtype=np.uint64)[:, None]
+    h = (g * np.uint64(0x9E3779B1) + t * np.uint64(0x85EBCA77) + np.uint64(0xC2B2AE3D)) & M
+    h ^= h >> np.uint64(16); h = (h * np.uint64(0x7FEB352D)) & M
+    h ^= h >> np.uint64(15); h = (h * np.uint64(0x846CA68B)) & M
+    h ^= h >> np.uint64(16)
+    kk = k.astype(np.uint64)
+    return np.where(kk > 0, h % np.maximum(kk, np.uint64(1)), np.uint64(0)).astype(np.int64)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["discrete_s2_10_80_50", "discrete_s1_10_80_50", "continuous_s2_10_80_50"])
 def test_fused_collect_matches_reference_fixture(name):
@@ -100,6 +114,40 @@ def test_fused_collect_matches_reference_fixture(name):
     o3, r3, d3, _ = env.step(torch.zeros(N, dtype=torch.int64))
     assert o3.data_ptr() == env.current_obs().data_ptr() and o3.data_ptr() != keep.data_ptr()
     assert o3.shape == (N, (I + L + 1) * 9)
+    env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["discrete_s2_10_80_50", "continuous_s2_10_80_50"])
+def test_policy_hash_index_drives_the_rollout_like_the_fixture(name):
+    """Round 6: pct_policy_hash_index -- the stand-in policy as the int64 leaf INDEX a trained policy hands step(), ONE launch, written
+    straight into the rollout's actions[t] (bench.py --mode slot) -- reads the observation slot currently bound.  Driving
+    RolloutSlots.step_env with it must walk the unmodified reference's trajectory (whose recordings used the same stand-in)."""
+    pkg = importlib.import_module("online-3d-bpp-pct_amd")
+    c, z = load_case(name)
+    N, I, L, T = c["N"], c["I"], c["L"], c["steps"]
+    kw = dict(setting=c["setting"], container_size=c["container"], internal_node_holder=I, leaf_node_holder=L,
+              env_id_base=c["base"], item_stream=z["stream"], device="cuda:0")
+    if name.startswith("continuous"):
+        env = pkg.PctVecEnv(N, continuous=True, sample_left_bound=c["lo"], sample_right_bound=c["hi"], **kw)
+    else:
+        env = pkg.PctVecEnv(N, item_set=case_items(c), **kw)
+    env.reset()
+    ro = pkg.RolloutSlots(T, N, ((I + L + 1) * 9,), 1.0, "cuda:0")
+    ro.begin(env)
+    for t in range(T):
+        idx = env.policy_hash_index(ro.actions[t].view(N))   # into the slot itself: step_env then copies nothing
+        assert idx.data_ptr() == ro.actions[t].data_ptr()
+        ro.step_env(env, idx)
+    obs = ro.obs.reshape(T + 1, N, -1).cpu().numpy()
+    assert np.array_equal(obs, z["obs"][:T + 1].astype(np.float32))
+    assert np.array_equal(ro.rewards[:, :, 0].cpu().numpy(), z["reward"][:T].astype(np.float32))
+    # the indices are the fixtures' own: mix32(global id, t) % (number of valid leaves)
+    leaf = z["obs"][:T].reshape(T, N, -1, 9)[:, :, I:I + L, 8]
+    k = (leaf != 0).sum(-1)
+    want = hash_policy_index_steps(k, c["base"])
+    assert np.array_equal(ro.actions[:, :, 0].cpu().numpy(), want)
+    env.unbind_rollout_slot()
     env.close()
 
 
