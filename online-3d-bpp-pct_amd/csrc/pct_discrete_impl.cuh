@@ -2542,7 +2542,7 @@ pct_discrete_tail_kernel(DiscreteParams p_arg, const void* actions, int row_len,
   const DiscreteParams& p = *(const DiscreteParams*)pct_param_fence((PctConstParams<DiscreteParams>)ka);
   constexpr size_t q_off = (sizeof(DiscreteParams) + sizeof(void*) + 2 * sizeof(int) + 7) & ~(size_t)7;
   (void)p_arg; (void)q_arg;
-  if ((int)blockIdx.x >= p.N) {
+  if (__builtin_expect((int)blockIdx.x >= p.N, 0)) {
     // ---- the retry pass -------------------------------------------------------------------------------------------------
     const DiscreteParams& q = *(const DiscreteParams*)pct_param_fence((PctConstParams<DiscreteParams>)(ka + q_off));
     const int tb = (int)blockIdx.x - p.N, R = (int)gridDim.x - p.N;
@@ -2552,7 +2552,7 @@ pct_discrete_tail_kernel(DiscreteParams p_arg, const void* actions, int row_len,
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
       if (c >= p.N) break;
-      __builtin_amdgcn_s_sleep(16);
+      __builtin_amdgcn_s_sleep(2);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     const int limit = __hip_atomic_load(p.retry_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
