@@ -482,6 +482,28 @@ def test_hip_continuous_candidate_overflow_is_rerun_with_hbm_tables():
     env.close()
 
 
+@pytest.mark.parametrize("ems,cand", [(0, 512), (24, 0), (24, 512)])
+def test_hip_candidate_pipeline_overflow_paths(ems, cand, monkeypatch):
+    """The two-wave pipeline's give-up paths (forced on for the small-bin fixture, capacities far too small): the candidate table
+    outgrows the launch's capacity in the middle of a set phase -- the consumer wave stops the producer, waits until it has left the
+    phase, and the env goes, state untouched, to the retry pass -- and the EMS list outgrows it (the env is requeued before / after
+    GENEMS and the producer wave is released without ever having worked).  Same observations, no flag, nothing hangs."""
+    monkeypatch.setenv("PCT_EXPERIMENT", "1")
+    monkeypatch.setenv("PCT_PIPE", "1")
+    c, z = load_case("continuous_s2_10_80_50")
+    env = _make_cont(c, z["stream"], ems_capacity=ems, candidate_capacity=cand)
+    obs = env.reset()
+    retried = 0
+    for t in range(120):
+        assert np.array_equal(obs.cpu().numpy(), z["obs"][t].astype(np.float32)), t
+        env.step_hash_policy(1)
+        obs, reward, done, infos = env.step_wait()
+        retried += env.debug_retry_count()
+        assert np.array_equal(done.astype(np.uint8), z["done"][t])
+    assert retried > 0 and not env.error_flags.any()
+    env.close()
+
+
 @pytest.mark.parametrize("kind", ["discrete", "continuous"])
 def test_hip_shuffle_matches_oracle(kind):
     """shuffle=True: the counter-keyed permutation of include/pct_env.h (pct_shuffle_priority)
